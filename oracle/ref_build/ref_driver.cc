@@ -1,0 +1,290 @@
+/* xapian_ref — test-infrastructure driver around the REAL vendored Xapian of the reference
+ * (/root/reference/src/xapian, compiled from where it lies by oracle/ref_build/Makefile into
+ * oracle/_ref/).  It is the ground-truth oracle for the match/rank path
+ * (Xapian::Enquire::get_mset, reference src/xapian/api/enquire.cc:396-470) and is used only by
+ * tests/, by tests/golden/make_golden.py and by bench.py's cpu_baseline leg.  Nothing in the
+ * product path links or executes it.
+ *
+ * Sub-commands
+ *   build  <dbdir> <seed> <n_docs> <vocab> <len_lo> <len_hi> [n_shards shard]
+ *          Index the deterministic synthetic corpus (tools/xgm_corpus.h) into a glass DB with
+ *          Document::add_posting(term, pos).  With n_shards > 1 only global docs
+ *          g with (g-1) % n_shards == shard are indexed, in order, so local id = (g-1)/n_shards+1
+ *          (reference src/xapian/backends/multi.h:38-73).
+ *   query  <queries.txt> <out.txt> <dbdir> [<dbdir> ...]
+ *          Run every query through Enquire.  One dbdir: plain get_mset().  Several dbdirs: the
+ *          two-phase per-shard protocol Xapiand itself runs (prepare_mset → add_prepared_mset →
+ *          set_prepared_mset → get_mset → unshard_docids → merge_mset;
+ *          reference src/database/handler.cc:1250-1343, 1532-1549).
+ *   time   <queries.txt> <n_threads> <repeat> <dbdir> [<dbdir> ...]
+ *          Time get_mset per query (steady_clock; Enquire construction and set_query excluded,
+ *          prepare_mset included — BASELINE.md §3).  Prints one JSON line.
+ *   export <dbdir> <out.raw>
+ *          Walk the public iterators (allterms_begin / postlist_begin / positionlist_begin /
+ *          get_doclength) and write the raw-postings file that the segment
+ *          builder consumes (format: include/xgm.h "raw postings").
+ *
+ * Query file: one query per line  "<AND|OR|PHRASE> <first> <maxitems> <window> term term ..."
+ * (window is only used by PHRASE; 0 means "number of terms" = exact phrase).
+ * Output: "Q <idx> <n_hits> <matches_lower> <matches_est> <matches_upper> <max_possible %a> <max_attained %a>"
+ * followed by n_hits lines "H <rank> <docid> <weight %a> <percent>".
+ */
+#include <xapian.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "xgm_corpus.h"
+
+namespace {
+
+struct QuerySpec {
+    std::string op;
+    unsigned first = 0, maxitems = 10, window = 0;
+    std::vector<std::string> terms;
+};
+
+std::vector<QuerySpec> read_queries(const char* path) {
+    std::vector<QuerySpec> out;
+    std::ifstream in(path);
+    if (!in) { fprintf(stderr, "cannot open %s\n", path); exit(2); }
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ss(line);
+        QuerySpec q;
+        ss >> q.op >> q.first >> q.maxitems >> q.window;
+        std::string t;
+        while (ss >> t) q.terms.push_back(t);
+        out.push_back(q);
+    }
+    return out;
+}
+
+Xapian::Query make_query(const QuerySpec& q) {
+    std::vector<Xapian::Query> subs;
+    for (auto& t : q.terms) subs.emplace_back(t);
+    if (q.op == "AND") return Xapian::Query(Xapian::Query::OP_AND, subs.begin(), subs.end());
+    if (q.op == "OR") return Xapian::Query(Xapian::Query::OP_OR, subs.begin(), subs.end());
+    if (q.op == "PHRASE") {
+        /* Explicit positions 1..n as Xapiand's DSL and the QueryParser produce them. */
+        std::vector<Xapian::Query> psubs;
+        unsigned pos = 1;
+        for (auto& t : q.terms) psubs.emplace_back(t, 1, pos++);
+        unsigned window = q.window ? q.window : (unsigned)q.terms.size();
+        return Xapian::Query(Xapian::Query::OP_PHRASE, psubs.begin(), psubs.end(), window);
+    }
+    fprintf(stderr, "unknown op %s\n", q.op.c_str());
+    exit(2);
+}
+
+/* One query, Xapiand style.  n_shards == 1 → plain get_mset. */
+Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& query, unsigned first,
+                       unsigned maxitems) {
+    size_t n_shards = dbs.size();
+    if (n_shards == 1) {
+        Xapian::Enquire enq(dbs[0]);
+        enq.set_query(query);
+        return enq.get_mset(first, maxitems);
+    }
+    bool full_db_has_positions = false;
+    for (auto& db : dbs) full_db_has_positions = full_db_has_positions || db.has_positions();
+    Xapian::Enquire merger{Xapian::Database{}};
+    std::vector<Xapian::Enquire> enqs;
+    std::vector<Xapian::MSet> msets(n_shards);
+    Xapian::doccount doccount = 0;
+    enqs.reserve(n_shards);
+    for (size_t s = 0; s < n_shards; ++s) {
+        enqs.emplace_back(dbs[s]);
+        enqs[s].set_query(query);
+        Xapian::MSet prepared = enqs[s].prepare_mset("q", full_db_has_positions, nullptr, nullptr);
+        doccount += dbs[s].get_doccount();
+        merger.add_prepared_mset(prepared);
+    }
+    for (size_t s = 0; s < n_shards; ++s) {
+        enqs[s].set_prepared_mset(merger.get_prepared_mset());
+        msets[s] = enqs[s].get_mset(0, first + maxitems);
+        msets[s].unshard_docids(s, n_shards);
+    }
+    return merger.merge_mset(msets, doccount, first, maxitems);
+}
+
+int cmd_build(int argc, char** argv) {
+    if (argc < 8) return 2;
+    const char* dir = argv[2];
+    xgm_corpus_params cp;
+    cp.seed = strtoull(argv[3], nullptr, 0);
+    uint64_t n_docs = strtoull(argv[4], nullptr, 0);
+    cp.vocab = (uint32_t)strtoul(argv[5], nullptr, 0);
+    cp.len_lo = (uint32_t)strtoul(argv[6], nullptr, 0);
+    cp.len_hi = (uint32_t)strtoul(argv[7], nullptr, 0);
+    unsigned n_shards = argc > 9 ? (unsigned)strtoul(argv[8], nullptr, 0) : 1;
+    unsigned shard = argc > 9 ? (unsigned)strtoul(argv[9], nullptr, 0) : 0;
+    std::vector<uint64_t> thr(cp.vocab);
+    xgm_zipf_thresholds(cp.vocab, thr.data());
+    Xapian::WritableDatabase db(dir, Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS |
+                                         Xapian::DB_NO_SYNC);
+    char name[16];
+    uint64_t added = 0;
+    for (uint64_t g = 1; g <= n_docs; ++g) {
+        if ((g - 1) % n_shards != shard) continue;
+        Xapian::Document doc;
+        uint32_t len = xgm_doc_len(&cp, g);
+        for (uint32_t pos = 1; pos <= len; ++pos) {
+            snprintf(name, sizeof name, "t%u", xgm_token(&cp, thr.data(), g, pos));
+            doc.add_posting(name, pos);
+        }
+        db.add_document(doc);
+        if (++added % 100000 == 0) db.commit();
+    }
+    db.commit();
+    printf("{\"doccount\": %u, \"lastdocid\": %u, \"total_length\": %" PRIu64 "}\n", db.get_doccount(),
+           db.get_lastdocid(), (uint64_t)db.get_total_length());
+    return 0;
+}
+
+std::vector<Xapian::Database> open_dbs(int argc, char** argv, int from) {
+    std::vector<Xapian::Database> dbs;
+    for (int i = from; i < argc; ++i) dbs.emplace_back(argv[i]);
+    return dbs;
+}
+
+int cmd_query(int argc, char** argv) {
+    if (argc < 5) return 2;
+    auto queries = read_queries(argv[2]);
+    FILE* out = fopen(argv[3], "w");
+    if (!out) return 2;
+    auto dbs = open_dbs(argc, argv, 4);
+    for (size_t qi = 0; qi < queries.size(); ++qi) {
+        const QuerySpec& q = queries[qi];
+        Xapian::MSet m = run_query(dbs, make_query(q), q.first, q.maxitems);
+        fprintf(out, "Q %zu %u %u %u %u %a %a\n", qi, m.size(), m.get_matches_lower_bound(),
+                m.get_matches_estimated(), m.get_matches_upper_bound(), m.get_max_possible(),
+                m.get_max_attained());
+        unsigned rank = q.first;
+        for (auto it = m.begin(); it != m.end(); ++it, ++rank) {
+            int pct = dbs.size() == 1 ? it.get_percent() : -1;
+            fprintf(out, "H %u %u %a %d\n", rank, *it, it.get_weight(), pct);
+        }
+    }
+    fclose(out);
+    return 0;
+}
+
+int cmd_time(int argc, char** argv) {
+    if (argc < 6) return 2;
+    auto queries = read_queries(argv[2]);
+    unsigned n_threads = (unsigned)strtoul(argv[3], nullptr, 0);
+    unsigned repeat = (unsigned)strtoul(argv[4], nullptr, 0);
+    std::vector<double> lat(queries.size() * repeat, 0.0);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> threads;
+    for (unsigned t = 0; t < n_threads; ++t) {
+        threads.emplace_back([&, t]() {
+            auto dbs = open_dbs(argc, argv, 5);   /* one handle per thread: handles are not thread-safe */
+            for (unsigned r = 0; r < repeat; ++r) {
+                for (size_t qi = t; qi < queries.size(); qi += n_threads) {
+                    const QuerySpec& q = queries[qi];
+                    Xapian::Query query = make_query(q);
+                    auto a = std::chrono::steady_clock::now();
+                    Xapian::MSet m = run_query(dbs, query, q.first, q.maxitems);
+                    auto b = std::chrono::steady_clock::now();
+                    lat[r * queries.size() + qi] = std::chrono::duration<double>(b - a).count();
+                    if (m.size() > q.maxitems) abort();
+                }
+            }
+        });
+    }
+    for (auto& th : threads) th.join();
+    double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::sort(lat.begin(), lat.end());
+    double sum = 0;
+    for (double x : lat) sum += x;
+    printf("{\"queries\": %zu, \"threads\": %u, \"wall_s\": %.6f, \"qps\": %.3f, \"sum_latency_s\": %.6f, "
+           "\"p50_us\": %.2f, \"p99_us\": %.2f}\n",
+           lat.size(), n_threads, wall, lat.size() / wall, sum, lat[lat.size() / 2] * 1e6,
+           lat[(size_t)(lat.size() * 0.99)] * 1e6);
+    return 0;
+}
+
+template <class T>
+void put(FILE* f, const T& v) { fwrite(&v, sizeof v, 1, f); }
+
+int cmd_export(int argc, char** argv) {
+    if (argc < 4) return 2;
+    Xapian::Database db(argv[2]);
+    FILE* f = fopen(argv[3], "wb");
+    if (!f) return 2;
+    std::vector<std::string> terms;
+    std::vector<uint32_t> df;
+    std::vector<uint32_t> dids, wdfs, pos;
+    std::vector<uint64_t> pos_off;
+    bool has_pos = db.has_positions();
+    pos_off.push_back(0);
+    for (auto t = db.allterms_begin(); t != db.allterms_end(); ++t) {
+        terms.push_back(*t);
+        uint32_t n = 0;
+        for (auto p = db.postlist_begin(*t); p != db.postlist_end(*t); ++p, ++n) {
+            dids.push_back(*p);
+            wdfs.push_back(p.get_wdf());
+            if (has_pos) {
+                for (auto pi = p.positionlist_begin(); pi != p.positionlist_end(); ++pi) pos.push_back(*pi);
+                pos_off.push_back(pos.size());
+            }
+        }
+        df.push_back(n);
+    }
+    uint32_t lastdocid = db.get_lastdocid();
+    std::vector<uint32_t> doclen(lastdocid + 1, 0);
+    for (auto p = db.postlist_begin(""); p != db.postlist_end(""); ++p) doclen[*p] = db.get_doclength(*p);
+    fwrite("XGMRAW1", 1, 8, f);
+    put<uint32_t>(f, (uint32_t)terms.size());
+    put<uint32_t>(f, lastdocid);
+    put<uint32_t>(f, db.get_doccount());
+    put<uint32_t>(f, has_pos ? 1u : 0u);
+    put<uint64_t>(f, (uint64_t)db.get_total_length());
+    put<uint64_t>(f, (uint64_t)dids.size());
+    put<uint64_t>(f, (uint64_t)pos.size());
+    put<uint64_t>(f, (uint64_t)db.get_revision());
+    fwrite(doclen.data(), 4, doclen.size(), f);
+    for (auto& t : terms) { put<uint32_t>(f, (uint32_t)t.size()); fwrite(t.data(), 1, t.size(), f); }
+    fwrite(df.data(), 4, df.size(), f);
+    fwrite(dids.data(), 4, dids.size(), f);
+    fwrite(wdfs.data(), 4, wdfs.size(), f);
+    if (has_pos) {
+        fwrite(pos_off.data(), 8, pos_off.size(), f);
+        fwrite(pos.data(), 4, pos.size(), f);
+    }
+    fclose(f);
+    printf("{\"terms\": %zu, \"postings\": %zu, \"positions\": %zu}\n", terms.size(), dids.size(), pos.size());
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) { fprintf(stderr, "usage: xapian_ref build|query|time|export ...\n"); return 2; }
+    try {
+        std::string cmd = argv[1];
+        int rc = 2;
+        if (cmd == "build") rc = cmd_build(argc, argv);
+        else if (cmd == "query") rc = cmd_query(argc, argv);
+        else if (cmd == "time") rc = cmd_time(argc, argv);
+        else if (cmd == "export") rc = cmd_export(argc, argv);
+        if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());
+        return rc;
+    } catch (const Xapian::Error& e) {
+        fprintf(stderr, "Xapian error: %s\n", e.get_description().c_str());
+        return 1;
+    }
+}
