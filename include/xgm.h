@@ -1,0 +1,267 @@
+/* xgm.h — C ABI of the MI355X match/rank engine ("xgm" = Xapian GPU Matcher).
+ *
+ * This is the drop-in boundary for ONE hot path of Kronuz/Xapiand: the body of
+ * Xapian::Enquire::get_mset as Xapiand calls it once per shard
+ *   reference: src/database/handler.cc:1338      DocMatcher::get_mset → enquire.get_mset(...)
+ *              src/xapian/api/enquire.cc:396-470  Enquire::Internal::get_mset
+ *              src/xapian/matcher/matcher.cc:346-542  Matcher::get_local_mset (the hot loop :482-536)
+ * The Xapian::Enquire / Query / MSet surface and Xapiand's query_dsl lowering stay as they are; a
+ * hook in Matcher::get_local_mset lowers an eligible Xapian::Query to an
+ * `xgm_query_desc`, calls the functions below, and builds the Xapian::MSet from `xgm_hit`s.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types; no exceptions cross the boundary.
+ *   - return 0 = ok; > 0 = "query shape not supported, use the CPU path" (never a user error);
+ *     < 0 = hard failure (the hook throws Xapian::DatabaseError so Xapiand's retry logic,
+ *     src/database/handler.cc:1348-1368, applies).  xgm_last_error() gives the message
+ *     (thread-local).
+ *   - The caller owns every buffer it passes; the library owns xgm_index and all device memory.
+ *   - There is NO CPU fallback inside the library: search entry points fail with XGM_E_NO_DEVICE
+ *     when no HIP device is usable.
+ *   - Thread safety: any number of threads may call xgm_search* / xgm_plan_query / xgm_lookup_term
+ *     concurrently on one xgm_index (per-call scratch is pooled per thread).  open/close are
+ *     serialised by the caller (Xapiand's lock_shard / DatabasePool).
+ */
+#ifndef XGM_H
+#define XGM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XGM_MAX_TERMS 16      /* leaves per query handled on the device path            */
+#define XGM_MAX_K 1024        /* first + maxitems handled on the device path            */
+
+/* return codes */
+#define XGM_OK 0
+#define XGM_UNSUPPORTED 1           /* fall back to the CPU matcher                       */
+#define XGM_E_INVALID (-1)          /* bad argument / corrupt segment                     */
+#define XGM_E_IO (-2)
+#define XGM_E_NO_DEVICE (-3)        /* HIP runtime/device unavailable                     */
+#define XGM_E_DEVICE (-4)           /* a HIP call failed                                  */
+#define XGM_E_REVISION (-5)         /* segment revision != requested (DatabaseModifiedError) */
+#define XGM_E_NOMEM (-6)
+
+/* query operators: the subset of Xapian::Query::op in BASELINE.json's configs
+ * (reference: src/xapian/query.h:48-  OP_AND = 0, OP_OR = 1, OP_PHRASE = 7). */
+#define XGM_OP_AND 1
+#define XGM_OP_OR 2
+#define XGM_OP_PHRASE 3
+
+typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
+
+/* ---- raw postings: what the exporter hands to the segment builder -----------------------------
+ * Produced by walking Xapian's public iterators over a glass shard (Database::allterms_begin /
+ * postlist_begin / PostingIterator::get_wdf / positionlist_begin / get_doclength — SURVEY.md
+ * Appendix A; reference src/xapian/api/database.cc:198,347).  Terms sorted bytewise, postings of a
+ * term sorted by docid, positions of a posting ascending.  File form ("XGMRAW1"), little endian,
+ * every array padded to a multiple of 8 bytes:
+ *   char magic[8]; u32 n_terms, lastdocid, doccount, has_positions; u64 total_length, n_postings,
+ *   n_positions, revision, term_bytes_total;           (64-byte header)
+ *   u32 doclen[lastdocid+1]; u32 df[n_terms]; u32 did[n_postings]; u32 wdf[n_postings];
+ *   if has_positions: u64 pos_off[n_postings+1]; u32 pos[n_positions];
+ *   u32 term_len[n_terms]; char term_bytes[term_bytes_total] (concatenated). */
+typedef struct {
+    uint32_t n_terms;
+    uint32_t lastdocid;          /* highest docid in the shard (docids are 1-based)               */
+    uint32_t doccount;           /* number of documents (== lastdocid when there are no gaps)      */
+    uint32_t has_positions;
+    uint64_t total_length;       /* sum of document lengths (Weight::Internal::total_length)       */
+    uint64_t n_postings;
+    uint64_t n_positions;
+    uint64_t revision;           /* Database::get_revision() of the shard this was exported from   */
+    const uint32_t* doclen;      /* [lastdocid+1], entry 0 unused, 0 for absent docids             */
+    const char* const* terms;    /* [n_terms] term bytes (may contain \0)                          */
+    const uint32_t* term_len;    /* [n_terms]                                                      */
+    const uint32_t* df;          /* [n_terms] termfreq; postings of term t are the next df[t]      */
+    const uint32_t* did;         /* [n_postings]                                                   */
+    const uint32_t* wdf;         /* [n_postings]                                                   */
+    const uint64_t* pos_off;     /* [n_postings+1] or NULL                                         */
+    const uint32_t* pos;         /* [n_positions] or NULL                                          */
+} xgm_raw_postings;
+
+/* Build the block-compressed device segment from raw postings on the host and write
+ * it to `out_path`.  stripe_bits: log2 of the docid stripe width (0 = default 13).  Index-build
+ * side: replaces nothing in the reference's query path; it is the exporter SURVEY.md §7 step 2. */
+int xgm_segment_build(const xgm_raw_postings* raw, uint32_t stripe_bits, const char* out_path);
+
+/* Same, reading the "XGMRAW1" file form. */
+int xgm_segment_build_from_file(const char* raw_path, uint32_t stripe_bits, const char* out_path);
+
+/* Host-side decode of one term's postings out of a segment FILE (index utility used to verify an
+ * export; not a search path).  Returns the number of postings written (<= cap) or < 0. */
+int64_t xgm_segment_decode_term(const char* segment_path, const char* term, size_t len,
+                                uint32_t* did, uint32_t* wdf, uint64_t cap);
+
+/* ---- index lifetime ---------------------------------------------------------------------------*/
+
+/* Load a segment file into HBM on `device`.  `revision` must equal the segment's revision unless it
+ * is UINT64_MAX (don't care).  Replaces: opening GlassPostList cursors per query
+ * (reference src/xapian/backends/glass/glass_database.cc:861-877, glass_postlist.cc:696-747). */
+int xgm_index_open(const char* segment_path, int device, uint64_t revision, xgm_index** out);
+
+/* Synthetic-corpus segment built directly in HBM by the GPU segment builder (bench/test tooling;
+ * the corpus is tools/xgm_corpus.h).  Global docs g in 1..n_docs_global with
+ * (g-1) % n_shards == shard land in this shard with local id (g-1)/n_shards + 1
+ * (reference src/xapian/backends/multi.h:38-73). */
+typedef struct {
+    uint64_t seed;
+    uint32_t vocab, len_lo, len_hi;
+    uint64_t n_docs_global;
+    uint32_t n_shards, shard;
+    uint32_t stripe_bits;        /* 0 = default */
+    uint32_t with_positions;
+} xgm_synth_params;
+int xgm_index_build_synthetic(const xgm_synth_params* p, int device, xgm_index** out);
+
+void xgm_index_close(xgm_index*);
+
+/* Write the device-resident segment back to a file (round-trips with xgm_index_open). */
+int xgm_index_save(const xgm_index*, const char* segment_path);
+
+typedef struct {
+    uint32_t n_terms, lastdocid, doccount, has_positions;
+    uint64_t total_length, revision, n_postings, n_positions, n_blocks;
+    uint64_t device_bytes;       /* HBM held by the segment                                        */
+    uint64_t payload_bytes;      /* bit-packed posting payload only                                 */
+    uint32_t stripe_bits, block_size;
+    uint32_t doclen_lower_bound, wdf_upper_bound;
+} xgm_index_info;
+int xgm_index_get_info(const xgm_index*, xgm_index_info* out);
+
+/* Run all work of this index on the caller's HIP stream (hipStream_t cast to void*; NULL = the
+ * index's own stream).  Lets a host that owns a stream (torch, the server) order our kernels with
+ * its copies/collectives without extra synchronisation. */
+int xgm_index_set_stream(xgm_index*, void* hip_stream);
+
+/* Dictionary lookup.  Replaces GlassPostListTable::get_freqs
+ * (reference src/xapian/backends/glass/glass_postlist.cc:151-192) and get_wdf_upper_bound
+ * (glass_database.cc:823-830).  Returns XGM_OK and termfreq 0 when the term is absent. */
+int xgm_lookup_term(const xgm_index*, const char* term, size_t len, uint32_t* term_id,
+                    uint32_t* termfreq, uint32_t* collfreq, uint32_t* wdf_ub);
+
+/* Bulk per-term statistics for the cross-shard stats merge (Weight::Internal::operator+=,
+ * reference src/xapian/weight/weightinternal.cc:55-71): copies termfreq[n_terms] (host). */
+int xgm_index_termfreqs(const xgm_index*, uint32_t* termfreq, uint32_t cap);
+
+/* ---- query planning (host) --------------------------------------------------------------------*/
+
+/* What the hook extracts from an eligible Xapian::Query (reference src/xapian/query.h:575-622:
+ * get_type / get_num_subqueries / get_subquery / get_leaf_wqf). */
+typedef struct {
+    uint32_t op;                          /* XGM_OP_*                                              */
+    uint32_t n_terms;
+    const char* terms[XGM_MAX_TERMS];     /* in QUERY order (phrase order for PHRASE)              */
+    uint32_t term_len[XGM_MAX_TERMS];
+    uint32_t window;                      /* PHRASE: 0 = n_terms (exact phrase)                    */
+    uint32_t first, maxitems, check_at_least;
+    /* BM25 parameters (reference src/xapian/weight.h:635-667 defaults 1, 0, 1, 0.5, 0.5) */
+    double k1, k2, k3, b, min_normlen;
+} xgm_query_desc;
+
+/* Collection statistics merged over all shards of the index, i.e. what Enquire::add_prepared_mset
+ * accumulates (reference src/xapian/api/enquire.cc:385-394).  NULL → the shard's own. */
+typedef struct {
+    uint64_t total_length;
+    uint32_t collection_size;
+    uint32_t full_db_has_positions;       /* any shard has positions (handler.cc:1374)             */
+    uint32_t termfreq[XGM_MAX_TERMS];     /* merged termfreq of desc->terms[i] (query order)       */
+} xgm_global_stats;
+
+typedef struct {
+    uint32_t term_id;        /* id in THIS shard's dictionary (UINT32_MAX = absent in the shard)   */
+    uint32_t phrase_index;   /* PHRASE: position of this leaf in the phrase (query order)          */
+    double termweight;       /* BM25Weight::init result (host libm log), bm25weight.cc:46-115      */
+} xgm_term;
+
+/* The executable plan.  terms[] are in MultiAndPostList order for AND/PHRASE (ascending SHARD-LOCAL
+ * termfreq, reference src/xapian/matcher/multiandpostlist.h:117-130) and in query order for OR.
+ * sum_prog is the weight summation in post-order: entry >= 0 pushes terms[entry]'s weight,
+ * XGM_SUM_ADD pops r, pops l, pushes l + r.  For AND this is the left-deep chain of
+ * MultiAndPostList::get_weight (multiandpostlist.cc:150-160); for OR the Huffman-shaped OrPostList
+ * tree of OrContext::postlist (reference src/xapian/api/queryinternal.cc:440-489). */
+#define XGM_SUM_ADD (-1)
+typedef struct {
+    uint32_t op, n_terms;
+    xgm_term terms[XGM_MAX_TERMS];
+    int8_t sum_prog[2 * XGM_MAX_TERMS];
+    uint32_t sum_len;
+    uint32_t window;             /* PHRASE only; == n_terms means exact phrase                     */
+    uint32_t phrase_active;      /* 0: PHRASE degraded to AND (no positions anywhere)              */
+    double len_factor, k1, b, min_normlen;
+    uint32_t first, maxitems, check_at_least;
+    double max_possible;         /* Σ get_maxpart (bm25weight.cc:183-207); MSet field only         */
+} xgm_query;
+
+/* Lower a query description to a plan against this shard.  Replaces, for the supported shapes,
+ * LocalSubMatch::get_postlist / open_post_list (reference src/xapian/matcher/localsubmatch.cc:164-
+ * 196, 231-309), Query::Internal::postlist (src/xapian/api/queryinternal.cc:1049, 2083, 2193,
+ * 2300-2354) and BM25Weight::init.  Returns XGM_UNSUPPORTED for shapes the device path declines
+ * (duplicate terms, > XGM_MAX_TERMS leaves, first+maxitems > XGM_MAX_K, k2 != 0, wdf too large...). */
+int xgm_plan_query(const xgm_index*, const xgm_query_desc*, const xgm_global_stats*, xgm_query* out);
+
+/* ---- search -----------------------------------------------------------------------------------*/
+
+typedef struct {
+    uint32_t docid;              /* shard-local (xgm_search*) or global (xgm_merge_shards*)        */
+    uint32_t subqs_matched;      /* leaves matching this doc (PostList::count_matching_subqs)      */
+    double weight;
+} xgm_hit;                       /* 16 bytes                                                        */
+
+typedef struct {
+    uint32_t n_hits;             /* hits written: min(matches, first + maxitems)                   */
+    uint32_t max_weight_subqs_matched; /* of the top-weighted doc (protomset.h:174-183)            */
+    uint64_t matches_exact;      /* exact match count (the reference only estimates it)            */
+    double max_attained;         /* weight of the best doc, 0 if none                              */
+    double max_possible;
+} xgm_result_hdr;                /* 32 bytes                                                        */
+
+/* One query on one shard: hits[0 .. first+maxitems) sorted by (weight desc, docid asc) — the order
+ * of msetcmp_by_relevance<true> (reference src/xapian/matcher/msetcmp.cc:55-62); the caller drops
+ * the first `first`.  Replaces the hot loop of Matcher::get_local_mset + ProtoMSet. */
+int xgm_search(xgm_index*, const xgm_query*, xgm_hit* hits, xgm_result_hdr* hdr);
+
+/* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
+int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
+                     xgm_hit* hits, xgm_result_hdr* hdrs);
+
+/* Same, but results stay in HBM: d_hits ([nq][k_stride] xgm_hit) and d_hdrs ([nq] xgm_result_hdr)
+ * are DEVICE pointers owned by the caller (e.g. torch tensors feeding an RCCL all-gather).
+ * Asynchronous on the index's stream. */
+int xgm_search_batch_device(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
+                            void* d_hits, void* d_hdrs);
+
+/* Merge per-shard results after the all-gather.  d_all_hits is [n_shards][nq][k_stride], d_all_hdrs
+ * [n_shards][nq] (device); output [nq][k_stride] / [nq] (device) with GLOBAL docids
+ * did = (local-1)*n_shards + shard + 1.  Replaces MSet::unshard_docids + Matcher::merge_mset +
+ * MSet::Internal::merge_stats (reference src/xapian/api/mset.cc:367-395,
+ * src/xapian/matcher/matcher.cc:653-781).  k[q] = first+maxitems of query q. */
+int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_all_hdrs,
+                            uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* k,
+                            void* d_out_hits, void* d_out_hdrs);
+
+/* Milliseconds spent in the dominant kernel (xgm_match_kernel) by the last xgm_search* call on this
+ * index from this thread, measured with hipEvents on the launch stream; < 0 if profiling is off.
+ * Enable with xgm_index_set_profiling(idx, 1) (adds two events per call). */
+int xgm_index_set_profiling(xgm_index*, int on);
+double xgm_last_kernel_ms(const xgm_index*);
+
+/* Algorithmic bytes of a planned query on this shard, SURVEY.md §8(d):
+ * Σ_t df_t·8 + S·4 (+ P·4) + k·16, with S and P taken from the last executed result header
+ * when given (hdr may be NULL → only the postings term). */
+uint64_t xgm_query_postings_bytes(const xgm_index*, const xgm_query*);
+
+/* Diagnostics: decode one term's whole posting list on the DEVICE (kernel K1 alone) into host
+ * arrays; returns df or < 0.  Used to verify a segment against its source postings. */
+int64_t xgm_debug_decode_term_device(xgm_index*, uint32_t term_id, uint32_t* did, uint32_t* wdf, uint64_t cap);
+
+const char* xgm_last_error(void);
+const char* xgm_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XGM_H */

@@ -247,6 +247,14 @@ int cmd_export(int argc, char** argv) {
     uint32_t lastdocid = db.get_lastdocid();
     std::vector<uint32_t> doclen(lastdocid + 1, 0);
     for (auto p = db.postlist_begin(""); p != db.postlist_end(""); ++p) doclen[*p] = db.get_doclength(*p);
+    auto put_arr = [&](const void* p, size_t bytes) {
+        fwrite(p, 1, bytes, f);
+        static const char zeros[8] = {0};
+        if (bytes % 8) fwrite(zeros, 1, 8 - bytes % 8, f);
+    };
+    uint64_t str_total = 0;
+    std::vector<uint32_t> lens;
+    for (auto& t : terms) { lens.push_back((uint32_t)t.size()); str_total += t.size(); }
     fwrite("XGMRAW1", 1, 8, f);
     put<uint32_t>(f, (uint32_t)terms.size());
     put<uint32_t>(f, lastdocid);
@@ -256,15 +264,17 @@ int cmd_export(int argc, char** argv) {
     put<uint64_t>(f, (uint64_t)dids.size());
     put<uint64_t>(f, (uint64_t)pos.size());
     put<uint64_t>(f, (uint64_t)db.get_revision());
-    fwrite(doclen.data(), 4, doclen.size(), f);
-    for (auto& t : terms) { put<uint32_t>(f, (uint32_t)t.size()); fwrite(t.data(), 1, t.size(), f); }
-    fwrite(df.data(), 4, df.size(), f);
-    fwrite(dids.data(), 4, dids.size(), f);
-    fwrite(wdfs.data(), 4, wdfs.size(), f);
+    put<uint64_t>(f, str_total);
+    put_arr(doclen.data(), doclen.size() * 4);
+    put_arr(df.data(), df.size() * 4);
+    put_arr(dids.data(), dids.size() * 4);
+    put_arr(wdfs.data(), wdfs.size() * 4);
     if (has_pos) {
-        fwrite(pos_off.data(), 8, pos_off.size(), f);
-        fwrite(pos.data(), 4, pos.size(), f);
+        put_arr(pos_off.data(), pos_off.size() * 8);
+        put_arr(pos.data(), pos.size() * 4);
     }
+    put_arr(lens.data(), lens.size() * 4);
+    for (auto& t : terms) fwrite(t.data(), 1, t.size(), f);
     fclose(f);
     printf("{\"terms\": %zu, \"postings\": %zu, \"positions\": %zu}\n", terms.size(), dids.size(), pos.size());
     return 0;

@@ -1,0 +1,693 @@
+/* xgm_oracle — CPU restatement of the reference's match/rank path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the
+ * product (xapiand_amd/, include/) never does.  It is pinned against the REAL reference
+ * (oracle/_ref/xapian_ref, built from /root/reference) by tests/test_oracle_vs_reference.py and by
+ * the committed fixtures under tests/golden/ which that binary generated.
+ *
+ * What is restated, with the reference lines each part follows (paths under src/xapian/):
+ *   - glass posting-list chunk format + iteration:   backends/glass/glass_postlist.cc:677-695 (format),
+ *       :110-124 (read_did_increase/read_wdf), :768-829 (next_in_chunk/next_chunk), :933-991 (skip_to),
+ *       CHUNKSIZE 2000 (:224); varints common/pack.h:296-310, 325-389
+ *   - doclen lookups through the doclen list:          glass_postlist.cc:194-205, 994-1021
+ *   - BM25 term weight and per-document weight:        weight/bm25weight.cc:46-130, 170-181
+ *   - AND: MultiAndPostList ordering + leapfrog + sum: matcher/multiandpostlist.h:117-130,
+ *                                                      multiandpostlist.cc:150-160, 180-207
+ *   - OR: Huffman tree of OrPostLists, l + r weights:  api/queryinternal.cc:440-489 with common/heap.h,
+ *                                                      matcher/orpostlist.cc:94-103
+ *         (exhaustive merge: the reference's MaxScore-style decay, orpostlist.cc:35-78, never changes
+ *          the top-k set or the weights, only how many documents get scored)
+ *   - PHRASE: ExactPhrasePostList / PhrasePostList:    matcher/exactphrasepostlist.cc:75-133,
+ *                                                      matcher/phrasepostlist.cc:60-90
+ *   - top-k: ProtoMSet::add min-heap + final sort:      matcher/protomset.h:340-400, 657;
+ *                                                      order matcher/msetcmp.cc:55-62
+ *   - multi-shard protocol: merged stats, unshard, merge: api/enquire.cc:385-394, backends/multi.h:69-73,
+ *                                                      matcher/matcher.cc:653-743
+ * Plus the deterministic synthetic corpus of tools/xgm_corpus.h and its inversion to raw postings.
+ *
+ * Build: g++ -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).  C ABI for ctypes.
+ */
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../tools/xgm_corpus.h"
+
+namespace {
+
+/* ----------------------------------------------------------------------------- corpus ---------- */
+
+struct Corpus {
+    uint32_t lastdocid = 0, doccount = 0;
+    uint64_t total_length = 0;
+    bool has_positions = false;
+    std::vector<uint32_t> doclen;               /* [lastdocid+1] */
+    std::vector<std::string> terms;             /* sorted bytewise */
+    std::vector<uint32_t> term_len;
+    std::vector<const char*> term_ptr;
+    std::vector<uint32_t> df;
+    std::vector<uint64_t> term_start;           /* [n_terms+1] into did/wdf */
+    std::vector<uint32_t> did, wdf;
+    std::vector<uint64_t> pos_off;
+    std::vector<uint32_t> pos;
+};
+
+Corpus* corpus_build(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint32_t len_lo, uint32_t len_hi,
+                     uint32_t n_shards, uint32_t shard, bool with_positions) {
+    xgm_corpus_params cp{seed, vocab, len_lo, len_hi};
+    std::vector<uint64_t> thr(vocab);
+    xgm_zipf_thresholds(vocab, thr.data());
+    /* tokens as (rank, local doc, pos) triples, sorted → postings */
+    struct Tok { uint32_t rank, doc; uint32_t pos; };
+    std::vector<Tok> toks;
+    Corpus* c = new Corpus();
+    c->has_positions = with_positions;
+    uint32_t local = 0;
+    c->doclen.push_back(0);
+    for (uint64_t g = 1; g <= n_docs_global; ++g) {
+        if ((g - 1) % n_shards != shard) continue;
+        ++local;
+        uint32_t len = xgm_doc_len(&cp, g);
+        c->doclen.push_back(len);
+        c->total_length += len;
+        for (uint32_t p = 1; p <= len; ++p) toks.push_back(Tok{xgm_token(&cp, thr.data(), g, p), local, p});
+    }
+    c->lastdocid = c->doccount = local;
+    /* term order = bytewise order of "t<rank>" */
+    std::vector<uint32_t> ranks;
+    {
+        std::vector<uint8_t> seen(vocab + 1, 0);
+        for (auto& t : toks) seen[t.rank] = 1;
+        for (uint32_t r = 1; r <= vocab; ++r) if (seen[r]) ranks.push_back(r);
+    }
+    std::vector<std::string> names(ranks.size());
+    for (size_t i = 0; i < ranks.size(); ++i) names[i] = "t" + std::to_string(ranks[i]);
+    std::vector<uint32_t> perm(ranks.size());
+    for (size_t i = 0; i < perm.size(); ++i) perm[i] = (uint32_t)i;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+    std::vector<uint32_t> rank2id(vocab + 1, UINT32_MAX);
+    for (size_t i = 0; i < perm.size(); ++i) {
+        c->terms.push_back(names[perm[i]]);
+        rank2id[ranks[perm[i]]] = (uint32_t)i;
+    }
+    std::sort(toks.begin(), toks.end(), [&](const Tok& a, const Tok& b) {
+        uint32_t ia = rank2id[a.rank], ib = rank2id[b.rank];
+        if (ia != ib) return ia < ib;
+        if (a.doc != b.doc) return a.doc < b.doc;
+        return a.pos < b.pos;
+    });
+    c->df.assign(c->terms.size(), 0);
+    c->term_start.assign(c->terms.size() + 1, 0);
+    if (with_positions) c->pos_off.push_back(0);
+    for (size_t i = 0; i < toks.size();) {
+        size_t j = i;
+        while (j < toks.size() && toks[j].rank == toks[i].rank && toks[j].doc == toks[i].doc) ++j;
+        uint32_t id = rank2id[toks[i].rank];
+        c->did.push_back(toks[i].doc);
+        c->wdf.push_back((uint32_t)(j - i));
+        c->df[id]++;
+        if (with_positions) {
+            for (size_t q = i; q < j; ++q) c->pos.push_back(toks[q].pos);
+            c->pos_off.push_back(c->pos.size());
+        }
+        i = j;
+    }
+    for (size_t t = 0; t < c->terms.size(); ++t) c->term_start[t + 1] = c->term_start[t] + c->df[t];
+    for (auto& s : c->terms) { c->term_len.push_back((uint32_t)s.size()); }
+    for (auto& s : c->terms) c->term_ptr.push_back(s.data());
+    return c;
+}
+
+/* ----------------------------------------------------------------------------- glass lists ----- */
+
+void put_varint(std::vector<uint8_t>& out, uint64_t v) {         /* pack_uint, common/pack.h:296-310 */
+    while (v >= 128) { out.push_back((uint8_t)(v | 0x80)); v >>= 7; }
+    out.push_back((uint8_t)v);
+}
+inline uint32_t get_varint(const uint8_t*& p) {                  /* unpack_uint, common/pack.h:325-389 */
+    uint32_t v = 0; int sh = 0;
+    while (true) { uint8_t b = *p++; v |= (uint32_t)(b & 0x7F) << sh; if (!(b & 0x80)) break; sh += 7; }
+    return v;
+}
+
+/* One posting list in glass's chunk layout: each chunk is `varint(wdf0) {varint(gap-1) varint(wdf)}*`
+ * with first/last docid kept beside it (the reference keeps them in the B-tree key and chunk header). */
+struct GlassList {
+    struct Chunk { uint32_t first, last; uint32_t off, end; };
+    std::vector<Chunk> chunks;
+    std::vector<uint8_t> bytes;
+    uint32_t termfreq = 0;
+    static constexpr size_t CHUNKSIZE = 2000;                    /* glass_postlist.cc:224 */
+    void build(const uint32_t* did, const uint32_t* wdf, uint32_t n) {
+        termfreq = n;
+        uint32_t i = 0;
+        while (i < n) {
+            Chunk c;
+            c.first = did[i];
+            c.off = (uint32_t)bytes.size();
+            put_varint(bytes, wdf[i]);
+            uint32_t prev = did[i];
+            ++i;
+            while (i < n && bytes.size() - c.off < CHUNKSIZE) {
+                put_varint(bytes, did[i] - prev - 1);
+                put_varint(bytes, wdf[i]);
+                prev = did[i];
+                ++i;
+            }
+            c.last = prev;
+            c.end = (uint32_t)bytes.size();
+            chunks.push_back(c);
+        }
+    }
+};
+
+struct GlassIter {
+    const GlassList* l = nullptr;
+    size_t ci = 0;
+    const uint8_t *p = nullptr, *e = nullptr;
+    uint32_t did = 0, wdf = 0;
+    bool ended = true, started = false;
+    void init(const GlassList* list) { l = list; ended = list->chunks.empty(); started = false; ci = 0; did = 0; }
+    void open_chunk(size_t i) {
+        ci = i;
+        const auto& c = l->chunks[i];
+        p = l->bytes.data() + c.off; e = l->bytes.data() + c.end;
+        did = c.first;
+        wdf = get_varint(p);
+    }
+    bool at_end() const { return ended; }
+    void next() {                                                /* GlassPostList::next, :853-872 */
+        if (ended) return;
+        if (!started) { started = true; open_chunk(0); return; }
+        if (p < e) { did += get_varint(p) + 1; wdf = get_varint(p); return; }
+        if (ci + 1 < l->chunks.size()) { open_chunk(ci + 1); return; }
+        ended = true;
+    }
+    void skip_to(uint32_t target) {                              /* GlassPostList::skip_to, :959-991 */
+        if (ended) return;
+        if (!started) { started = true; open_chunk(0); }
+        if (target <= did) return;
+        if (target > l->chunks[ci].last) {
+            /* B-tree find_entry(term || target): last chunk whose first docid <= target */
+            size_t lo = ci, hi = l->chunks.size();
+            while (hi - lo > 1) { size_t mid = (lo + hi) / 2; if (l->chunks[mid].first <= target) lo = mid; else hi = mid; }
+            if (target > l->chunks[lo].last) {
+                if (lo + 1 >= l->chunks.size()) { ended = true; return; }
+                ++lo;
+            }
+            open_chunk(lo);
+        }
+        while (did < target) { did += get_varint(p) + 1; wdf = get_varint(p); }   /* move_forward_in_chunk_to_at_least */
+    }
+};
+
+/* ----------------------------------------------------------------------------- index ----------- */
+
+struct Index {
+    uint32_t lastdocid = 0, doccount = 0, doclen_lb = 0, wdf_ub_db = 0;
+    uint64_t total_length = 0;
+    bool has_positions = false;
+    std::map<std::string, uint32_t> dict;
+    std::vector<uint32_t> df, cf, wdf_ub;
+    std::vector<uint64_t> term_start;
+    const uint32_t *did = nullptr, *wdf = nullptr, *pos = nullptr;
+    const uint64_t* pos_off = nullptr;
+    std::vector<GlassList> lists;            /* lazily built */
+    std::vector<uint8_t> built;
+    GlassList doclen_list;                   /* the special doclen posting list */
+    std::vector<uint32_t> doclen_dense;
+    GlassList& list(uint32_t id) {
+        if (!built[id]) { lists[id].build(did + term_start[id], wdf + term_start[id], df[id]); built[id] = 1; }
+        return lists[id];
+    }
+};
+
+Index* index_from_raw(uint32_t n_terms, uint32_t lastdocid, uint32_t doccount, uint64_t total_length, const uint32_t* doclen,
+                      const char* const* terms, const uint32_t* term_len, const uint32_t* df, const uint32_t* did,
+                      const uint32_t* wdf, const uint64_t* pos_off, const uint32_t* pos) {
+    Index* ix = new Index();
+    ix->lastdocid = lastdocid; ix->doccount = doccount; ix->total_length = total_length;
+    ix->has_positions = pos_off != nullptr;
+    ix->df.assign(df, df + n_terms);
+    ix->did = did; ix->wdf = wdf; ix->pos = pos; ix->pos_off = pos_off;
+    ix->term_start.assign(n_terms + 1, 0);
+    uint64_t np = 0;
+    for (uint32_t t = 0; t < n_terms; ++t) { ix->term_start[t] = np; np += df[t]; ix->dict[std::string(terms[t], term_len[t])] = t; }
+    ix->term_start[n_terms] = np;
+    for (uint64_t i = 0; i < np; ++i) ix->wdf_ub_db = std::max(ix->wdf_ub_db, wdf[i]);
+    ix->cf.resize(n_terms); ix->wdf_ub.resize(n_terms);
+    for (uint32_t t = 0; t < n_terms; ++t) {
+        uint64_t c = 0;
+        for (uint64_t i = ix->term_start[t]; i < ix->term_start[t + 1]; ++i) c += wdf[i];
+        ix->cf[t] = (uint32_t)c;
+        /* GlassPostListTable::get_freqs :175-189, GlassDatabase::get_wdf_upper_bound :823-830 */
+        uint32_t first_wdf = wdf[ix->term_start[t]];
+        uint32_t ub = (c == 0 || df[t] == 1) ? (uint32_t)c : std::max((uint32_t)c - first_wdf, first_wdf);
+        ix->wdf_ub[t] = std::min(ub, ix->wdf_ub_db);
+    }
+    ix->lists.resize(n_terms); ix->built.assign(n_terms, 0);
+    std::vector<uint32_t> dd, dl;
+    for (uint32_t d = 1; d <= lastdocid; ++d) {
+        if (doclen[d] == 0) continue;              /* synthetic corpora have no empty documents */
+        dd.push_back(d); dl.push_back(doclen[d]);
+        if (ix->doclen_lb == 0 || doclen[d] < ix->doclen_lb) ix->doclen_lb = doclen[d];
+    }
+    ix->doclen_list.build(dd.data(), dl.data(), (uint32_t)dd.size());
+    ix->doclen_dense.assign(doclen, doclen + lastdocid + 1);
+    return ix;
+}
+
+/* ----------------------------------------------------------------------------- weights --------- */
+
+struct BM25 {
+    double k1 = 1, k2 = 0, k3 = 1, b = 0.5, min_normlen = 0.5;
+    double termweight = 0, len_factor = 0;
+    void init(uint32_t collection_size, uint32_t tf, double avg_len) {       /* bm25weight.cc:46-130 */
+        double tw = (collection_size - tf + 0.5) / (tf + 0.5);
+        if (tw < 2) tw = tw * 0.5 + 1;
+        termweight = std::log(tw) * 1.0;
+        if (k3 != 0) { double wqf_double = 1; termweight *= (k3 + 1) * wqf_double / (k3 + wqf_double); }
+        termweight *= (k1 + 1);
+        if (k2 == 0 && (b == 0 || k1 == 0)) len_factor = 0;
+        else { len_factor = avg_len; if (len_factor != 0) len_factor = 1 / len_factor; }
+    }
+    double sumpart(uint32_t wdf, uint32_t len) const {                       /* bm25weight.cc:170-181 */
+        double normlen = std::max(len * len_factor, min_normlen);
+        double wdf_double = wdf;
+        double denom = k1 * (normlen * b + (1 - b)) + wdf_double;
+        return termweight * (wdf_double / denom);
+    }
+    double maxpart(uint32_t wdf_ub, uint32_t doclen_lb) const {              /* bm25weight.cc:183-207 */
+        double denom = k1;
+        if (k1 != 0.0 && b != 0.0) {
+            double normlen_lb = std::max(std::max(wdf_ub, doclen_lb) * len_factor, min_normlen);
+            denom *= (normlen_lb * b + (1 - b));
+        }
+        double wdf_max = wdf_ub;
+        denom += wdf_max;
+        return termweight * (wdf_max / denom);
+    }
+};
+
+struct Hit { uint32_t did; uint32_t subqs; double weight; };
+
+inline bool mcmp(const Hit& a, const Hit& b) {                 /* msetcmp_by_relevance<true>, msetcmp.cc:55-62 */
+    if (a.weight > b.weight) return true;
+    if (a.weight < b.weight) return false;
+    return a.did < b.did;
+}
+
+/* ProtoMSet::add without collapsing, check_at_least <= max_size (protomset.h:340-400) */
+struct ProtoMSet {
+    size_t max_size;
+    std::vector<Hit> results;
+    std::vector<uint32_t> heap;
+    double min_weight = 0.0, max_weight = 0.0;
+    uint32_t max_weight_subqs = 0;
+    uint64_t known_matching_docs = 0;
+    explicit ProtoMSet(size_t k) : max_size(k) {}
+    struct Cmp { ProtoMSet* p; bool operator()(uint32_t a, uint32_t b) const { return mcmp(p->results[a], p->results[b]); } };
+    void add(const Hit& item) {
+        ++known_matching_docs;
+        if (item.weight > max_weight) {                      /* update_max_weight, protomset.h:174-183 */
+            max_weight = item.weight;
+            max_weight_subqs = item.subqs;
+        }
+        if (item.weight < min_weight) return;
+        if (results.size() < max_size) { results.push_back(item); return; }
+        if (max_size == 0) return;
+        if (heap.empty()) {
+            for (uint32_t i = 0; i < results.size(); ++i) heap.push_back(i);
+            std::make_heap(heap.begin(), heap.end(), Cmp{this});          /* worst item on top */
+            min_weight = results[heap.front()].weight;
+        }
+        uint32_t worst = heap.front();
+        if (!mcmp(item, results[worst])) return;
+        results[worst] = item;
+        std::pop_heap(heap.begin(), heap.end(), Cmp{this});
+        heap.back() = worst;
+        std::push_heap(heap.begin(), heap.end(), Cmp{this});
+        min_weight = results[heap.front()].weight;
+    }
+    void finalise() { std::sort(results.begin(), results.end(), mcmp); }  /* protomset.h:657 */
+};
+
+/* ----------------------------------------------------------------------------- query ----------- */
+
+struct QueryIn {
+    uint32_t op;                 /* 1 AND, 2 OR, 3 PHRASE */
+    uint32_t n_terms;
+    const char* const* terms; const uint32_t* term_len;
+    uint32_t window, first, maxitems;
+    /* merged statistics (NULL-equivalent: use_global = 0) */
+    uint32_t use_global; uint64_t g_total_length; uint32_t g_collection_size; uint32_t g_has_positions;
+    const uint32_t* g_termfreq;
+    /* 1: reproduce the reference's SelectPostList stale cached_weight (matcher/selectpostlist.cc:28-55:
+     * vet() refreshes cached_weight through pltree->get_weight(), which re-enters
+     * SelectPostList::get_weight and returns the PREVIOUS cached value once it is >= 0), so that the
+     * oracle can be pinned to the real reference for PHRASE with k < matches.  0: the intended
+     * semantics (true weights), which is what the device path implements.  DESIGN.md §7. */
+    uint32_t select_cache_bug;
+};
+
+struct Leaf { uint32_t tf, idx; };
+struct TfAsc { bool operator()(const Leaf& a, const Leaf& b) const { return a.tf < b.tf; } };
+
+/* common/heap.h sift-down (libc++), comparator "a.tf > b.tf" (queryinternal.cc:140-147) */
+struct HItem { uint64_t tf; int node; };
+inline bool hcomp(const HItem& a, const HItem& b) { return a.tf > b.tf; }
+void sift_down(std::vector<HItem>& h, size_t len, size_t start) {
+    if (len < 2 || (len - 2) / 2 < start) return;
+    size_t child = 2 * start + 1;
+    if (child + 1 < len && hcomp(h[child], h[child + 1])) ++child;
+    if (hcomp(h[child], h[start])) return;
+    HItem top = h[start];
+    do {
+        h[start] = h[child]; start = child;
+        if ((len - 2) / 2 < child) break;
+        child = 2 * child + 1;
+        if (child + 1 < len && hcomp(h[child], h[child + 1])) ++child;
+    } while (!hcomp(h[child], top));
+    h[start] = top;
+}
+
+struct PosCursor { const uint32_t* p; uint32_t n, c; bool started;
+    bool skip_to(uint32_t t) { if (!started) { started = true; c = 0; } while (c < n && p[c] < t) ++c; return c < n; }
+    bool next() { if (!started) { started = true; c = 0; } else ++c; return c < n; }
+    uint32_t get() const { return p[c]; } };
+
+bool exact_phrase(std::vector<PosCursor>& pl, const std::vector<uint32_t>& wdfs) {
+    /* exactphrasepostlist.cc:75-133 */
+    size_t n = pl.size();
+    std::vector<unsigned> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (unsigned)i;
+    std::sort(order.begin(), order.end(), [&](unsigned a, unsigned b) { return wdfs[a] < wdfs[b]; });
+    std::vector<PosCursor*> pls(n);
+    for (size_t i = 0; i < n; ++i) pls[i] = &pl[order[i]];
+    if (!pls[0]->skip_to(order[0])) return false;
+    if (pls[0]->n > pls[1]->n) {
+        if (!pls[1]->skip_to(order[1])) return false;
+        std::swap(pls[0], pls[1]); std::swap(order[0], order[1]);
+    }
+    uint32_t idx0 = order[0];
+    uint32_t base = pls[0]->get() - idx0;
+    unsigned i = 1;
+    while (true) {
+        uint32_t idx = order[i];
+        uint32_t required = base + idx;
+        if (!pls[i]->skip_to(required)) return false;
+        uint32_t got = pls[i]->get();
+        if (got == required) { if (++i == n) return true; continue; }
+        if (!pls[0]->skip_to(got - idx + idx0)) return false;
+        base = pls[0]->get() - idx0;
+        i = 1;
+    }
+}
+
+bool window_phrase(std::vector<PosCursor>& pl, uint32_t window) {
+    /* phrasepostlist.cc:60-90 */
+    size_t n = pl.size();
+    if (!pl[0].next()) return false;
+    uint32_t b;
+    do {
+        uint32_t base = pl[0].get();
+        uint32_t pos = base;
+        unsigned i = 0;
+        do {
+            if (++i == n) return true;
+            if (!pl[i].skip_to(pos + 1)) return false;
+            pos = pl[i].get();
+            b = pos + (uint32_t)(n - i);
+        } while (b - base <= window);
+    } while (pl[0].skip_to(b - window));
+    return false;
+}
+
+struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0; };
+
+int run_query(Index* ix, const QueryIn& q, Result* out) {
+    const uint32_t n = q.n_terms;
+    BM25 proto;
+    const uint32_t N = q.use_global ? q.g_collection_size : ix->doccount;
+    const uint64_t TL = q.use_global ? q.g_total_length : ix->total_length;
+    const bool full_pos = q.use_global ? q.g_has_positions != 0 : ix->has_positions;
+    const double avg = N == 0 ? 0.0 : (double)TL / N;
+    /* enquire.cc:419-426 */
+    uint32_t docs = ix->doccount;
+    uint32_t first = std::min(q.first, docs);
+    uint32_t maxitems = std::min(q.maxitems, docs - first);
+    const size_t k = (size_t)first + maxitems;
+
+    std::vector<uint32_t> id(n), tf_local(n);
+    std::vector<BM25> wt(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        auto it = ix->dict.find(std::string(q.terms[i], q.term_len[i]));
+        id[i] = it == ix->dict.end() ? UINT32_MAX : it->second;
+        tf_local[i] = id[i] == UINT32_MAX ? 0 : ix->df[id[i]];
+        wt[i] = proto;
+        wt[i].init(N, q.use_global ? q.g_termfreq[i] : tf_local[i], avg);
+    }
+    bool phrase = q.op == 3 && n > 1 && full_pos;
+    if (phrase && !ix->has_positions) { out->hits.clear(); return 0; }
+    uint32_t window = q.window ? q.window : n;
+
+    /* plan order + tree */
+    std::vector<uint32_t> order(n);
+    std::vector<std::pair<int, int>> nodes;
+    int root = 0;
+    if (q.op == 2) {
+        for (uint32_t i = 0; i < n; ++i) order[i] = i;
+        if (n > 1) {
+            std::vector<HItem> h;
+            for (uint32_t i = 0; i < n; ++i) h.push_back(HItem{tf_local[i], (int)i});
+            for (long s = (long)((n - 2) / 2); s >= 0; --s) sift_down(h, n, (size_t)s);
+            while (true) {
+                HItem r = h.front();
+                size_t len = h.size();
+                if (len > 1) { std::swap(h[0], h[len - 1]); sift_down(h, len - 1, 0); }
+                h.pop_back();
+                HItem l = h.front();
+                nodes.push_back({l.node, r.node});
+                int nid = (int)n + (int)nodes.size() - 1;
+                if (h.size() == 1) { root = nid; break; }
+                h[0].node = nid; h[0].tf = l.tf + r.tf;
+                sift_down(h, h.size(), 0);
+            }
+        }
+    } else {
+        std::vector<Leaf> in(n), sorted(n);
+        for (uint32_t i = 0; i < n; ++i) in[i] = Leaf{tf_local[i], i};
+        std::partial_sort_copy(in.begin(), in.end(), sorted.begin(), sorted.end(), TfAsc());
+        for (uint32_t i = 0; i < n; ++i) order[i] = sorted[i].idx;
+        for (uint32_t p = 1; p < n; ++p) { nodes.push_back({root, (int)p}); root = (int)n + (int)nodes.size() - 1; }
+    }
+    {
+        std::vector<double> val(2 * n);
+        for (uint32_t p = 0; p < n; ++p) {
+            uint32_t i = order[p];
+            val[p] = wt[i].maxpart(id[i] == UINT32_MAX ? 0 : ix->wdf_ub[id[i]], ix->doclen_lb);
+        }
+        for (size_t j = 0; j < nodes.size(); ++j) val[n + j] = val[nodes[j].first] + val[nodes[j].second];
+        out->max_possible = val[root];
+    }
+
+    std::vector<GlassIter> it(n);
+    for (uint32_t p = 0; p < n; ++p) {
+        uint32_t i = order[p];
+        static GlassList empty;
+        it[p].init(id[i] == UINT32_MAX ? &empty : &ix->list(id[i]));
+    }
+    GlassIter dl;
+    dl.init(&ix->doclen_list);
+    ProtoMSet pm(k);
+    double select_cached = -HUGE_VAL;
+    std::vector<double> val(2 * n);
+    std::vector<char> present(n);
+
+    uint32_t last_subqs = 0;
+    auto weigh = [&](uint32_t did) -> double {
+        dl.skip_to(did);                                      /* get_doclength → jump_to, :994-1021 */
+        uint32_t len = dl.wdf;
+        uint32_t subqs = 0;
+        for (uint32_t p = 0; p < n; ++p) {
+            if (present[p]) { val[p] = wt[order[p]].sumpart(it[p].wdf, len); ++subqs; }
+        }
+        /* tree sum; an absent side contributes no addition (orpostlist.cc:94-103).  For AND the chain
+         * starts at 0.0 in the reference (multiandpostlist.cc:150-160): 0.0 + w0 == w0 exactly. */
+        std::vector<char> pr(2 * n, 0);
+        for (uint32_t p = 0; p < n; ++p) pr[p] = present[p];
+        for (size_t j = 0; j < nodes.size(); ++j) {
+            int a = nodes[j].first, b = nodes[j].second;
+            size_t o = n + j;
+            if (pr[a] && pr[b]) { val[o] = val[a] + val[b]; pr[o] = 1; }
+            else if (pr[a]) { val[o] = val[a]; pr[o] = 1; }
+            else if (pr[b]) { val[o] = val[b]; pr[o] = 1; }
+        }
+        last_subqs = subqs;
+        return val[root];
+    };
+    auto score = [&](uint32_t did) {
+        double w = weigh(did);
+        if (w < pm.min_weight) { return; }                    /* matcher.cc:496-498 */
+        pm.add(Hit{did, last_subqs, w});
+    };
+
+    if (q.op == 2) {
+        for (uint32_t p = 0; p < n; ++p) it[p].next();
+        while (true) {
+            uint32_t did = UINT32_MAX;
+            for (uint32_t p = 0; p < n; ++p) if (!it[p].at_end()) did = std::min(did, it[p].did);
+            if (did == UINT32_MAX) break;
+            for (uint32_t p = 0; p < n; ++p) present[p] = (!it[p].at_end() && it[p].did == did);
+            score(did);
+            for (uint32_t p = 0; p < n; ++p) if (present[p]) it[p].next();
+        }
+    } else {
+        /* MultiAndPostList::find_next_match, multiandpostlist.cc:180-207 */
+        std::fill(present.begin(), present.end(), 1);
+        it[0].next();
+        while (!it[0].at_end()) {
+            uint32_t did = it[0].did;
+            bool matched = true;
+            for (uint32_t p = 1; p < n; ++p) {
+                it[p].skip_to(did);
+                if (it[p].at_end()) { matched = false; did = UINT32_MAX; break; }
+                if (it[p].did != did) { it[0].skip_to(it[p].did); matched = false; break; }
+            }
+            if (did == UINT32_MAX) break;
+            if (!matched) continue;
+            bool ok = true;
+            double cached_weight = -HUGE_VAL;
+            if (phrase) {
+                if (q.select_cache_bug) {
+                    /* SelectPostList::vet, selectpostlist.cc:28-46, with its stale cache */
+                    double w_min = pm.min_weight;
+                    if (w_min <= 0.0) {
+                        select_cached = -HUGE_VAL;
+                    } else {
+                        if (!(select_cached >= 0)) select_cached = weigh(did);
+                        if (select_cached < w_min) { it[0].next(); continue; }
+                    }
+                    cached_weight = select_cached;
+                }
+                /* position lists in PHRASE order (terms[] of the PosFilter = query order) */
+                std::vector<PosCursor> pl(n);
+                std::vector<uint32_t> wdfs(n);
+                for (uint32_t p = 0; p < n; ++p) {
+                    uint32_t i = order[p];
+                    /* ordinal of the posting: recover from the raw arrays by binary search */
+                    const uint32_t* b = ix->did + ix->term_start[id[i]];
+                    const uint32_t* e = ix->did + ix->term_start[id[i] + 1];
+                    uint64_t ord = (uint64_t)(std::lower_bound(b, e, did) - ix->did);
+                    pl[i] = PosCursor{ix->pos + ix->pos_off[ord], (uint32_t)(ix->pos_off[ord + 1] - ix->pos_off[ord]), 0, false};
+                    wdfs[i] = it[p].wdf;
+                }
+                ok = (window == n) ? exact_phrase(pl, wdfs) : window_phrase(pl, window);
+            }
+            if (ok) {
+                if (cached_weight >= 0) {
+                    /* SelectPostList::get_weight returns the cached value (selectpostlist.cc:48-55) */
+                    weigh(did);
+                    if (!(cached_weight < pm.min_weight)) pm.add(Hit{did, last_subqs, cached_weight});
+                } else {
+                    score(did);
+                }
+            }
+            it[0].next();
+        }
+    }
+    pm.finalise();
+    out->hits = pm.results;
+    out->matches = pm.known_matching_docs;
+    out->max_attained = pm.results.empty() ? 0.0 : pm.results[0].weight;
+    out->max_subqs = pm.results.empty() ? 0 : pm.results[0].subqs;
+    return 0;
+}
+
+}  // namespace
+
+/* ----------------------------------------------------------------------------- C ABI ----------- */
+
+extern "C" {
+
+void* xgo_corpus_build(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint32_t len_lo, uint32_t len_hi,
+                       uint32_t n_shards, uint32_t shard, int with_positions) {
+    return corpus_build(seed, n_docs_global, vocab, len_lo, len_hi, n_shards, shard, with_positions != 0);
+}
+void xgo_corpus_free(void* c) { delete (Corpus*)c; }
+
+struct xgo_corpus_view {
+    uint32_t n_terms, lastdocid, doccount, has_positions;
+    uint64_t total_length, n_postings, n_positions;
+    const uint32_t* doclen; const char* const* terms; const uint32_t* term_len; const uint32_t* df;
+    const uint32_t* did; const uint32_t* wdf; const uint64_t* pos_off; const uint32_t* pos;
+};
+void xgo_corpus_get(void* cv, xgo_corpus_view* v) {
+    Corpus* c = (Corpus*)cv;
+    v->n_terms = (uint32_t)c->terms.size(); v->lastdocid = c->lastdocid; v->doccount = c->doccount;
+    v->has_positions = c->has_positions; v->total_length = c->total_length;
+    v->n_postings = c->did.size(); v->n_positions = c->pos.size();
+    v->doclen = c->doclen.data(); v->terms = c->term_ptr.data(); v->term_len = c->term_len.data(); v->df = c->df.data();
+    v->did = c->did.data(); v->wdf = c->wdf.data();
+    v->pos_off = c->has_positions ? c->pos_off.data() : nullptr; v->pos = c->has_positions ? c->pos.data() : nullptr;
+}
+
+/* The index borrows the raw arrays: keep them alive. */
+void* xgo_index_from_raw(uint32_t n_terms, uint32_t lastdocid, uint32_t doccount, uint64_t total_length, const uint32_t* doclen,
+                         const char* const* terms, const uint32_t* term_len, const uint32_t* df, const uint32_t* did,
+                         const uint32_t* wdf, const uint64_t* pos_off, const uint32_t* pos) {
+    return index_from_raw(n_terms, lastdocid, doccount, total_length, doclen, terms, term_len, df, did, wdf, pos_off, pos);
+}
+void xgo_index_free(void* ix) { delete (Index*)ix; }
+
+int xgo_index_termfreq(void* ixv, const char* term, uint32_t len) {
+    Index* ix = (Index*)ixv;
+    auto it = ix->dict.find(std::string(term, len));
+    return it == ix->dict.end() ? 0 : (int)ix->df[it->second];
+}
+
+/* Pre-encode a term's glass list (so timing runs do not include the encoding). */
+void xgo_index_warm(void* ixv, const char* term, uint32_t len) {
+    Index* ix = (Index*)ixv;
+    auto it = ix->dict.find(std::string(term, len));
+    if (it != ix->dict.end()) ix->list(it->second);
+}
+
+struct xgo_hit { uint32_t docid, subqs; double weight; };
+struct xgo_result_hdr { uint32_t n_hits, max_subqs; uint64_t matches; double max_attained, max_possible; };
+
+int xgo_search(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
+               uint32_t first, uint32_t maxitems, uint32_t use_global, uint64_t g_total_length, uint32_t g_collection_size,
+               uint32_t g_has_positions, const uint32_t* g_termfreq, uint32_t select_cache_bug, xgo_hit* hits,
+               xgo_result_hdr* hdr) {
+    QueryIn q{op, n_terms, terms, term_len, window, first, maxitems, use_global, g_total_length, g_collection_size,
+              g_has_positions, g_termfreq, select_cache_bug};
+    Result r;
+    int rc = run_query((Index*)ixv, q, &r);
+    if (rc) return rc;
+    hdr->n_hits = (uint32_t)r.hits.size(); hdr->max_subqs = r.max_subqs; hdr->matches = r.matches;
+    hdr->max_attained = r.max_attained; hdr->max_possible = r.max_possible;
+    for (size_t i = 0; i < r.hits.size(); ++i) { hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight; }
+    return 0;
+}
+
+/* Matcher::merge_mset + unshard_docids for per-shard result lists (already sorted). */
+int xgo_merge(uint32_t n_shards, const xgo_hit* const* shard_hits, const uint32_t* n_hits, uint32_t first, uint32_t maxitems,
+              xgo_hit* out) {
+    std::vector<Hit> all;
+    for (uint32_t s = 0; s < n_shards; ++s)
+        for (uint32_t i = 0; i < n_hits[s]; ++i)
+            all.push_back(Hit{(shard_hits[s][i].docid - 1) * n_shards + s + 1, shard_hits[s][i].subqs, shard_hits[s][i].weight});
+    std::sort(all.begin(), all.end(), mcmp);
+    uint32_t n = 0;
+    for (size_t i = first; i < all.size() && n < maxitems; ++i, ++n) { out[n].docid = all[i].did; out[n].subqs = all[i].subqs; out[n].weight = all[i].weight; }
+    return (int)n;
+}
+
+}  // extern "C"

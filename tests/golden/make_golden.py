@@ -1,0 +1,64 @@
+"""Regenerate tests/golden/*.json from the REAL reference (oracle/_ref/xapian_ref = the vendored
+Xapian of /root/reference compiled by oracle/ref_build/Makefile).  Run in the authoring container:
+
+    python tests/golden/make_golden.py
+
+Each fixture records the corpus parameters (tools/xgm_corpus.h), the queries, and for every query
+the reference MSet: (docid, weight as a C99 hex float) per rank plus max_possible / max_attained.
+Config C1 of BASELINE.json: 10k-doc synthetic index, 3-term AND BM25 top-10 through Enquire; the
+other fixtures cover OR-5 top-100, full-result PHRASE, paging (first > 0) and a 4-shard index run
+through Xapiand's prepare/merge protocol.
+"""
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import helpers as H  # noqa: E402
+
+N_DOCS, VOCAB = 10000, 1000000
+
+
+def run(tmp, dbs, queries, tag):
+    qf, of = os.path.join(tmp, tag + ".q"), os.path.join(tmp, tag + ".out")
+    H.write_queries(qf, queries)
+    H.xapian_ref("query", qf, of, *dbs)
+    ref = H.parse_ref_output(of)
+    out = []
+    for q, r in zip(queries, ref):
+        out.append(dict(query=q, max_possible=r["max_possible"].hex(), max_attained=r["max_attained"].hex(),
+                        hits=[[d, w.hex(), pct] for d, w, pct in r["hits"]]))
+    return out
+
+
+def main():
+    with tempfile.TemporaryDirectory() as tmp:
+        db = os.path.join(tmp, "db")
+        H.xapian_ref("build", db, H.CORPUS_SEED, N_DOCS, VOCAB, 50, 150)
+        corpus = dict(seed=H.CORPUS_SEED, n_docs=N_DOCS, vocab=VOCAB, len_lo=50, len_hi=150)
+        fixtures = {
+            "c1_and3_top10": H.gen_term_queries("AND", 60, 3, 1, 64, maxitems=10),
+            "or5_top100": H.gen_term_queries("OR", 30, 5, 8, 4096, maxitems=100, seed=21),
+            "and_paging": H.gen_term_queries("AND", 10, 2, 1, 64, first=7, maxitems=10, seed=22),
+            "phrase_full": H.gen_phrase_queries(30, N_DOCS, VOCAB, maxitems=N_DOCS, seed=23),
+        }
+        for name, qs in fixtures.items():
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(dict(corpus=corpus, n_shards=1, results=run(tmp, [db], qs, name)), f, indent=0)
+        n_shards = 4
+        dbs = []
+        for s in range(n_shards):
+            d = os.path.join(tmp, "s%d" % s)
+            H.xapian_ref("build", d, H.CORPUS_SEED, N_DOCS, VOCAB, 50, 150, n_shards, s)
+            dbs.append(d)
+        qs = H.gen_term_queries("AND", 30, 3, 1, 64, maxitems=10, seed=24) + H.gen_term_queries("OR", 10, 5, 8, 4096, maxitems=20, seed=25)
+        with open(os.path.join(HERE, "sharded4_and3_top10.json"), "w") as f:
+            json.dump(dict(corpus=corpus, n_shards=n_shards, results=run(tmp, dbs, qs, "sh")), f, indent=0)
+    print("golden fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,280 @@
+"""Test-side helpers: ctypes binding of the CPU oracle (oracle/libxgm_oracle.so), the runner of the
+real-reference binary (oracle/_ref/xapian_ref), seeded query generators and the glue that feeds the
+oracle's raw postings to the product's segment builder.  Only tests/, smoke() and bench.py's
+cpu_baseline leg import this module."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_LIB = os.path.join(ROOT, "oracle", "libxgm_oracle.so")
+XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
+
+CORPUS_SEED = 0x5EED0001
+QUERY_SEED = 0x5EED0002
+OPS = {"AND": 1, "OR": 2, "PHRASE": 3}
+
+
+class CorpusView(C.Structure):
+    _fields_ = [("n_terms", C.c_uint32), ("lastdocid", C.c_uint32), ("doccount", C.c_uint32),
+                ("has_positions", C.c_uint32), ("total_length", C.c_uint64), ("n_postings", C.c_uint64),
+                ("n_positions", C.c_uint64),
+                ("doclen", C.POINTER(C.c_uint32)), ("terms", C.POINTER(C.c_char_p)),
+                ("term_len", C.POINTER(C.c_uint32)), ("df", C.POINTER(C.c_uint32)),
+                ("did", C.POINTER(C.c_uint32)), ("wdf", C.POINTER(C.c_uint32)),
+                ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint32))]
+
+
+class OHit(C.Structure):
+    _fields_ = [("docid", C.c_uint32), ("subqs", C.c_uint32), ("weight", C.c_double)]
+
+
+class OHdr(C.Structure):
+    _fields_ = [("n_hits", C.c_uint32), ("max_subqs", C.c_uint32), ("matches", C.c_uint64),
+                ("max_attained", C.c_double), ("max_possible", C.c_double)]
+
+
+_olib = None
+
+
+def olib():
+    global _olib
+    if _olib is None:
+        l = C.CDLL(ORACLE_LIB)
+        l.xgo_corpus_build.restype = C.c_void_p
+        l.xgo_corpus_build.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        l.xgo_corpus_free.argtypes = [C.c_void_p]
+        l.xgo_corpus_get.argtypes = [C.c_void_p, C.POINTER(CorpusView)]
+        l.xgo_index_from_raw.restype = C.c_void_p
+        l.xgo_index_from_raw.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                         C.POINTER(C.c_uint32)]
+        l.xgo_index_free.argtypes = [C.c_void_p]
+        l.xgo_index_termfreq.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        l.xgo_index_warm.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        l.xgo_search.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32,
+                                 C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr)]
+        _olib = l
+    return _olib
+
+
+class Corpus:
+    """Deterministic synthetic corpus shard (tools/xgm_corpus.h) inverted to raw postings by the oracle."""
+
+    def __init__(self, n_docs_global, vocab, seed=CORPUS_SEED, len_lo=50, len_hi=150, n_shards=1, shard=0, positions=True):
+        self.params = dict(seed=seed, n_docs_global=n_docs_global, vocab=vocab, len_lo=len_lo, len_hi=len_hi,
+                           n_shards=n_shards, shard=shard)
+        self._h = olib().xgo_corpus_build(seed, n_docs_global, vocab, len_lo, len_hi, n_shards, shard, 1 if positions else 0)
+        self.v = CorpusView()
+        olib().xgo_corpus_get(self._h, C.byref(self.v))
+        self._oidx = None
+
+    def close(self):
+        if self._oidx:
+            olib().xgo_index_free(self._oidx)
+            self._oidx = None
+        if self._h:
+            olib().xgo_corpus_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def terms(self):
+        return [C.string_at(self.v.terms[i], self.v.term_len[i]) for i in range(self.v.n_terms)]
+
+    def df_array(self):
+        return np.ctypeslib.as_array(self.v.df, shape=(self.v.n_terms,))
+
+    def term_postings(self, idx):
+        df = self.df_array()
+        start = int(df[:idx].sum())
+        n = int(df[idx])
+        did = np.ctypeslib.as_array(self.v.did, shape=(self.v.n_postings,))[start:start + n]
+        wdf = np.ctypeslib.as_array(self.v.wdf, shape=(self.v.n_postings,))[start:start + n]
+        return did, wdf
+
+    def raw_postings(self, revision=1):
+        """Fill the product's xgm_raw_postings from the oracle's arrays (borrowed pointers)."""
+        from xapiand_amd import _lib
+        r = _lib.RawPostings()
+        v = self.v
+        r.n_terms, r.lastdocid, r.doccount, r.has_positions = v.n_terms, v.lastdocid, v.doccount, v.has_positions
+        r.total_length, r.n_postings, r.n_positions, r.revision = v.total_length, v.n_postings, v.n_positions, revision
+        r.doclen, r.terms, r.term_len, r.df, r.did, r.wdf = v.doclen, v.terms, v.term_len, v.df, v.did, v.wdf
+        r.pos_off, r.pos = v.pos_off, v.pos
+        return r
+
+    def build_segment(self, path, stripe_bits=0, revision=1):
+        from xapiand_amd import _lib
+        r = self.raw_postings(revision)
+        _lib.check(_lib.lib().xgm_segment_build(C.byref(r), stripe_bits, path.encode()))
+        return path
+
+    def oracle_index(self):
+        if self._oidx is None:
+            v = self.v
+            self._oidx = olib().xgo_index_from_raw(v.n_terms, v.lastdocid, v.doccount, v.total_length, v.doclen, v.terms,
+                                                   v.term_len, v.df, v.did, v.wdf, v.pos_off, v.pos)
+        return self._oidx
+
+    def termfreq(self, term):
+        t = term if isinstance(term, bytes) else term.encode()
+        return olib().xgo_index_termfreq(self.oracle_index(), t, len(t))
+
+
+def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=None, reference_select_bug=False):
+    """Run the CPU oracle.  Returns (list of (docid, weight, subqs), hdr)."""
+    n = len(terms)
+    tb = [t if isinstance(t, bytes) else t.encode() for t in terms]
+    arr = (C.c_char_p * n)(*tb)
+    lens = (C.c_uint32 * n)(*[len(t) for t in tb])
+    cap = max(1, first + maxitems)
+    hits = (OHit * cap)()
+    hdr = OHdr()
+    bug = 1 if reference_select_bug else 0
+    if global_stats is None:
+        rc = olib().xgo_search(corpus.oracle_index(), OPS[op], n, arr, lens, window, first, maxitems, 0, 0, 0, 0, None, bug, hits, C.byref(hdr))
+    else:
+        tf = (C.c_uint32 * n)(*global_stats["termfreq"])
+        rc = olib().xgo_search(corpus.oracle_index(), OPS[op], n, arr, lens, window, first, maxitems, 1,
+                               global_stats["total_length"], global_stats["collection_size"],
+                               1 if global_stats["has_positions"] else 0, tf, bug, hits, C.byref(hdr))
+    assert rc == 0
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs) for i in range(hdr.n_hits)], hdr
+
+
+def oracle_search_sharded(corpora, op, terms, first, maxitems, window=0):
+    """Xapiand's per-shard protocol on the oracle: merged stats, per-shard top first+maxitems, unshard, merge."""
+    gs = dict(total_length=sum(c.v.total_length for c in corpora), collection_size=sum(c.v.doccount for c in corpora),
+              has_positions=any(c.v.has_positions for c in corpora),
+              termfreq=[sum(c.termfreq(t) for c in corpora) for t in terms])
+    n = len(corpora)
+    allhits = []
+    for s, c in enumerate(corpora):
+        hits, _ = oracle_search(c, op, terms, 0, first + maxitems, window, gs)
+        allhits += [((d - 1) * n + s + 1, w, m) for d, w, m in hits]
+    allhits.sort(key=lambda x: (-x[1], x[0]))
+    return allhits[first:first + maxitems]
+
+
+# ---- the real reference -------------------------------------------------------------------------
+
+def have_xapian_ref():
+    return os.path.exists(XAPIAN_REF)
+
+
+def xapian_ref(*args):
+    return subprocess.run([XAPIAN_REF] + [str(a) for a in args], check=True, capture_output=True, text=True).stdout
+
+
+def write_queries(path, queries):
+    with open(path, "w") as f:
+        for q in queries:
+            f.write("%s %d %d %d %s\n" % (q["op"], q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
+
+
+def parse_ref_output(path):
+    """Parse xapian_ref query output → list of dicts with exact (hex) weights."""
+    out = []
+    with open(path) as f:
+        for line in f:
+            p = line.split()
+            if p[0] == "Q":
+                out.append(dict(n=int(p[2]), lb=int(p[3]), est=int(p[4]), ub=int(p[5]), max_possible=float.fromhex(p[6]),
+                                max_attained=float.fromhex(p[7]), hits=[]))
+            elif p[0] == "H":
+                out[-1]["hits"].append((int(p[2]), float.fromhex(p[3]), int(p[4])))
+    return out
+
+
+# ---- seeded query generators ---------------------------------------------------
+
+def log_uniform_rank(rng, lo, hi):
+    import math
+    return int(round(math.exp(rng.uniform(math.log(lo), math.log(hi)))))
+
+
+def gen_term_queries(op, n_queries, n_terms, rank_lo, rank_hi, first=0, maxitems=10, seed=QUERY_SEED):
+    rng = random.Random(seed)
+    qs = []
+    for _ in range(n_queries):
+        ranks = set()
+        while len(ranks) < n_terms:
+            ranks.add(max(1, log_uniform_rank(rng, rank_lo, rank_hi)))
+        ranks = list(ranks)
+        rng.shuffle(ranks)
+        qs.append(dict(op=op, terms=["t%d" % r for r in ranks], first=first, maxitems=maxitems, window=0))
+    return qs
+
+
+def hash64(seed, a, b):
+    """tools/xgm_corpus.h xgm_hash3 in Python ints."""
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+    return mix(mix(seed ^ ((a * 0xD6E8FEB86659FD93) & M)) ^ ((b * 0xA0761D6478BD642F) & M))
+
+
+_thr_cache = {}
+
+
+def zipf_thresholds(vocab):
+    if vocab not in _thr_cache:
+        inv = 1.0 / np.arange(1, vocab + 1, dtype=np.float64)
+        # sequential summation exactly like the C code (np.cumsum is sequential for float64)
+        h = np.cumsum(inv)
+        hv = 0.0
+        for x in inv:       # same order of additions as xgm_zipf_thresholds' first loop
+            hv += x
+        f = h / hv
+        hi = f * 4294967296.0
+        hi_i = np.floor(hi)
+        lo = (hi - hi_i) * 4294967296.0
+        thr = (hi_i.astype(np.uint64) << np.uint64(32)) | np.floor(lo).astype(np.uint64)
+        thr[-1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        thr[f >= 1.0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        _thr_cache[vocab] = thr
+    return _thr_cache[vocab]
+
+
+def doc_tokens(seed, vocab, len_lo, len_hi, g):
+    """Tokens (ranks) of global doc g — Python restatement of the corpus for phrase-query sampling."""
+    thr = zipf_thresholds(vocab)
+    n = len_lo + hash64(seed, g, 0xFFFFFFFF) % (len_hi - len_lo + 1)
+    toks = []
+    for pos in range(1, n + 1):
+        u = np.uint64(hash64(seed, g, pos))
+        toks.append(int(np.searchsorted(thr, u, side="right")) + 1 if u >= thr[0] else 1)
+    return toks
+
+
+def gen_phrase_queries(n_queries, n_docs_global, vocab, len_lo=50, len_hi=150, corpus_seed=CORPUS_SEED, seed=QUERY_SEED,
+                       maxitems=10, window_extra=0):
+    """2-3-grams that actually occur in a random document (so results are non-empty); n-grams with a
+    repeated term are skipped (the device path declines them, like any other unsupported shape)."""
+    rng = random.Random(seed)
+    qs = []
+    while len(qs) < n_queries:
+        g = rng.randint(1, n_docs_global)
+        toks = doc_tokens(corpus_seed, vocab, len_lo, len_hi, g)
+        n = rng.choice([2, 3])
+        i = rng.randint(0, len(toks) - n)
+        gram = toks[i:i + n]
+        if len(set(gram)) != n:
+            continue
+        qs.append(dict(op="PHRASE", terms=["t%d" % r for r in gram], first=0, maxitems=maxitems,
+                       window=(n + window_extra) if window_extra else 0))
+    return qs

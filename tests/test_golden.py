@@ -1,0 +1,42 @@
+"""CPU-only: the CPU oracle reproduces the committed golden vectors that the real reference
+generated (tests/golden/make_golden.py) — docid at every rank identical, weights bit-identical."""
+import glob
+import json
+import os
+
+import pytest
+
+import helpers as H
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "*.json")))
+
+_cache = {}
+
+
+def shards_for(fx):
+    c = fx["corpus"]
+    key = (c["seed"], c["n_docs"], c["vocab"], fx["n_shards"])
+    if key not in _cache:
+        _cache[key] = [H.Corpus(c["n_docs"], c["vocab"], seed=c["seed"], len_lo=c["len_lo"], len_hi=c["len_hi"],
+                                n_shards=fx["n_shards"], shard=s) for s in range(fx["n_shards"])]
+    return _cache[key]
+
+
+def expected(r):
+    return [(d, float.fromhex(w)) for d, w, _ in r["hits"]]
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_matches_golden(path):
+    fx = json.load(open(path))
+    shards = shards_for(fx)
+    assert fx["results"]
+    for r in fx["results"]:
+        q = r["query"]
+        if fx["n_shards"] == 1:
+            hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0))
+            got = [(d, w) for d, w, _ in hits[q["first"]:]]
+            assert hdr.max_possible == float.fromhex(r["max_possible"])
+        else:
+            got = [(d, w) for d, w, _ in H.oracle_search_sharded(shards, q["op"], q["terms"], q["first"], q["maxitems"])]
+        assert got == expected(r), q

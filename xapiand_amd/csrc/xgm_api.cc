@@ -1,0 +1,578 @@
+/* C-ABI entry points: index lifetime, dictionary lookup, search drivers.  Host code only; the
+ * kernels live in xgm_kernels.hip and are reached through xgm_launch.h.  There is deliberately no
+ * CPU implementation of the search path here: without a HIP device the search calls fail. */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstring>
+
+#include "xgm_internal.h"
+#include "xgm_launch.h"
+
+int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob);
+
+/* ------------------------------------------------------------------ errors ------------------- */
+
+static thread_local char g_err[512] = "";
+
+int xgm_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int xgm_launch_error(const char* what, int code, const char* msg) {
+    return xgm_set_error(XGM_E_DEVICE, "%s failed (%d): %s", what, code, msg ? msg : "?");
+}
+
+extern "C" const char* xgm_last_error(void) { return g_err; }
+extern "C" const char* xgm_version(void) { return "xgm 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return xgm_launch_error(#expr, (int)e_, hipGetErrorString(e_)); \
+    } while (0)
+
+static int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return xgm_set_error(XGM_E_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return xgm_set_error(XGM_E_NO_DEVICE, "HIP device %d out of range (have %d)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    return XGM_OK;
+}
+
+/* ------------------------------------------------------------------ scratch ------------------ */
+
+struct XgmScratch {
+    hipStream_t stream = nullptr;
+    /* device */
+    xgm_dev_query* d_queries = nullptr; size_t cap_queries = 0;
+    xgm_cand* d_cand = nullptr; size_t cap_cand = 0;
+    xgm_group_hdr* d_ghdr = nullptr; size_t cap_ghdr = 0;
+    uint32_t* d_kq = nullptr; double* d_maxposs = nullptr; size_t cap_kq = 0;
+    xgm_hit* d_hits = nullptr; size_t cap_hits = 0;
+    xgm_result_hdr* d_hdrs = nullptr; size_t cap_hdrs = 0;
+    /* pinned host */
+    void* h_up = nullptr; size_t cap_up = 0;
+    void* h_down = nullptr; size_t cap_down = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr;   /* recorded after an asynchronous call that still uses this scratch */
+    bool pending = false;
+};
+
+template <class T>
+static int grow(T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return XGM_OK;
+    if (*p) HIP_TRY(hipFree(*p));
+    *p = nullptr;
+    size_t n = std::max(need, *cap * 2);
+    HIP_TRY(hipMalloc((void**)p, n * sizeof(T)));
+    *cap = n;
+    return XGM_OK;
+}
+
+static int grow_pinned(void** p, size_t* cap, size_t need) {
+    if (need <= *cap) return XGM_OK;
+    if (*p) HIP_TRY(hipHostFree(*p));
+    *p = nullptr;
+    size_t n = std::max(need, *cap * 2);
+    HIP_TRY(hipHostMalloc(p, n, hipHostMallocDefault));
+    *cap = n;
+    return XGM_OK;
+}
+
+static int scratch_acquire(xgm_index* idx, XgmScratch** out) {
+    *out = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(idx->scratch_mu);
+        if (!idx->scratch_pool.empty()) {
+            *out = idx->scratch_pool.back();
+            idx->scratch_pool.pop_back();
+        }
+    }
+    if (*out) {
+        if ((*out)->pending) { hipEventSynchronize((*out)->ev_done); (*out)->pending = false; }
+        return XGM_OK;
+    }
+    XgmScratch* s = new XgmScratch();
+    hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete s; return xgm_launch_error("hipStreamCreate", (int)e, hipGetErrorString(e)); }
+    hipEventCreate(&s->ev0);
+    hipEventCreate(&s->ev1);
+    hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
+    *out = s;
+    return XGM_OK;
+}
+
+static void scratch_release(xgm_index* idx, XgmScratch* s) {
+    std::lock_guard<std::mutex> lk(idx->scratch_mu);
+    idx->scratch_pool.push_back(s);
+}
+
+static void scratch_destroy(XgmScratch* s) {
+    if (!s) return;
+    hipFree(s->d_queries); hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_kq); hipFree(s->d_maxposs);
+    hipFree(s->d_hits); hipFree(s->d_hdrs);
+    if (s->h_up) hipHostFree(s->h_up);
+    if (s->h_down) hipHostFree(s->h_down);
+    if (s->ev0) hipEventDestroy(s->ev0);
+    if (s->ev1) hipEventDestroy(s->ev1);
+    if (s->ev_done) hipEventDestroy(s->ev_done);
+    if (s->stream) hipStreamDestroy(s->stream);
+    delete s;
+}
+
+/* ------------------------------------------------------------------ index lifetime ----------- */
+
+static void fill_view(xgm_index* idx) {
+    xgm_seg_dev& v = idx->view;
+    v.doclen = (const uint32_t*)idx->d_sections[XGM_S_DOCLEN];
+    v.term_blk = (const uint64_t*)idx->d_sections[XGM_S_TERM_BLK];
+    v.term_word = (const uint64_t*)idx->d_sections[XGM_S_TERM_WORD];
+    v.term_pos = (const uint64_t*)idx->d_sections[XGM_S_TERM_POS];
+    v.blk_first = (const uint32_t*)idx->d_sections[XGM_S_BLK_FIRST];
+    v.blk_meta = (const uint32_t*)idx->d_sections[XGM_S_BLK_META];
+    v.blk_word = (const uint32_t*)idx->d_sections[XGM_S_BLK_WORD];
+    v.blk_pos = (const uint32_t*)idx->d_sections[XGM_S_BLK_POS];
+    v.words = (const uint32_t*)idx->d_sections[XGM_S_WORDS];
+    v.positions = (const uint32_t*)idx->d_sections[XGM_S_POSITIONS];
+    v.stripe_bits = idx->hdr.stripe_bits;
+    v.lastdocid = idx->hdr.lastdocid;
+}
+
+/* Host copies of the dictionary arrays from a host blob. */
+static void adopt_host_dictionary(xgm_index* idx, const XgmSegmentBlob& blob) {
+    const xgm_seg_header* h = blob.header();
+    const uint32_t T = h->n_terms;
+    idx->term_df.assign(blob.section<uint32_t>(XGM_S_TERM_DF), blob.section<uint32_t>(XGM_S_TERM_DF) + T);
+    idx->term_cf.assign(blob.section<uint32_t>(XGM_S_TERM_CF), blob.section<uint32_t>(XGM_S_TERM_CF) + T);
+    idx->term_wdfub.assign(blob.section<uint32_t>(XGM_S_TERM_WDFUB), blob.section<uint32_t>(XGM_S_TERM_WDFUB) + T);
+    idx->term_flags.assign(blob.section<uint32_t>(XGM_S_TERM_FLAGS), blob.section<uint32_t>(XGM_S_TERM_FLAGS) + T);
+    idx->term_blk.assign(blob.section<uint64_t>(XGM_S_TERM_BLK), blob.section<uint64_t>(XGM_S_TERM_BLK) + T + 1);
+    idx->term_word.assign(blob.section<uint64_t>(XGM_S_TERM_WORD), blob.section<uint64_t>(XGM_S_TERM_WORD) + T + 1);
+    idx->str_off.assign(blob.section<uint64_t>(XGM_S_STR_OFF), blob.section<uint64_t>(XGM_S_STR_OFF) + T + 1);
+    const char* sb = blob.section<char>(XGM_S_STR_BYTES);
+    idx->str_bytes.assign(sb, sb + h->sec_bytes[XGM_S_STR_BYTES]);
+}
+
+extern "C" int xgm_index_open(const char* segment_path, int device, uint64_t revision, xgm_index** out) {
+    if (!segment_path || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    *out = nullptr;
+    XgmSegmentBlob blob;
+    int rc = xgm_read_segment_file(segment_path, &blob);
+    if (rc) return rc;
+    const xgm_seg_header* h = blob.header();
+    if (revision != UINT64_MAX && revision != h->revision)
+        return xgm_set_error(XGM_E_REVISION, "segment revision %llu != requested %llu", (unsigned long long)h->revision,
+                             (unsigned long long)revision);
+    if (h->n_blocks >= 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "segment has too many blocks");
+    rc = use_device(device);
+    if (rc) return rc;
+    xgm_index* idx = new xgm_index();
+    idx->device = device;
+    idx->hdr = *h;
+    adopt_host_dictionary(idx, blob);
+    hipError_t e = hipMalloc(&idx->d_blob, h->file_bytes);
+    if (e != hipSuccess) { delete idx; return xgm_launch_error("hipMalloc(segment)", (int)e, hipGetErrorString(e)); }
+    e = hipMemcpy(idx->d_blob, blob.bytes.data(), h->file_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(idx->d_blob); delete idx; return xgm_launch_error("hipMemcpy(segment)", (int)e, hipGetErrorString(e)); }
+    idx->device_bytes = h->file_bytes;
+    for (int s = 0; s < XGM_S_COUNT; ++s) idx->d_sections[s] = (char*)idx->d_blob + h->sec_off[s];
+    fill_view(idx);
+    *out = idx;
+    return XGM_OK;
+}
+
+extern "C" void xgm_index_close(xgm_index* idx) {
+    if (!idx) return;
+    hipSetDevice(idx->device);
+    hipDeviceSynchronize();
+    for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
+    if (idx->sections_owned) {
+        for (int s = 0; s < XGM_S_COUNT; ++s) if (idx->d_sections[s]) hipFree(idx->d_sections[s]);
+    }
+    if (idx->d_blob) hipFree(idx->d_blob);
+    delete idx;
+}
+
+extern "C" int xgm_index_save(const xgm_index* idx, const char* path) {
+    if (!idx || !path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    /* recompute the section table for a contiguous file */
+    xgm_seg_header h = idx->hdr;
+    uint64_t off = (sizeof h + 255) / 256 * 256;
+    for (int s = 0; s < XGM_S_COUNT; ++s) { h.sec_off[s] = off; off = (off + h.sec_bytes[s] + 255) / 256 * 256; }
+    h.file_bytes = off;
+    std::vector<uint8_t> bytes(off, 0);
+    memcpy(bytes.data(), &h, sizeof h);
+    for (int s = 0; s < XGM_S_COUNT; ++s) {
+        if (!h.sec_bytes[s]) continue;
+        if (s == XGM_S_STR_OFF) memcpy(bytes.data() + h.sec_off[s], idx->str_off.data(), h.sec_bytes[s]);
+        else if (s == XGM_S_STR_BYTES) memcpy(bytes.data() + h.sec_off[s], idx->str_bytes.data(), h.sec_bytes[s]);
+        else HIP_TRY(hipMemcpy(bytes.data() + h.sec_off[s], idx->d_sections[s], h.sec_bytes[s], hipMemcpyDeviceToHost));
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s", path);
+    size_t w = fwrite(bytes.data(), 1, bytes.size(), f);
+    if (fclose(f) != 0 || w != bytes.size()) return xgm_set_error(XGM_E_IO, "short write on %s", path);
+    return XGM_OK;
+}
+
+extern "C" int xgm_index_get_info(const xgm_index* idx, xgm_index_info* out) {
+    if (!idx || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    const xgm_seg_header& h = idx->hdr;
+    out->n_terms = h.n_terms; out->lastdocid = h.lastdocid; out->doccount = h.doccount; out->has_positions = h.has_positions;
+    out->total_length = h.total_length; out->revision = h.revision; out->n_postings = h.n_postings;
+    out->n_positions = h.n_positions; out->n_blocks = h.n_blocks;
+    out->device_bytes = idx->device_bytes;
+    out->payload_bytes = h.n_words * 4;
+    out->stripe_bits = h.stripe_bits; out->block_size = h.block_size;
+    out->doclen_lower_bound = h.doclen_lower_bound; out->wdf_upper_bound = h.wdf_upper_bound;
+    return XGM_OK;
+}
+
+extern "C" int xgm_index_set_stream(xgm_index* idx, void* hip_stream) {
+    if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
+    idx->stream = hip_stream;
+    idx->own_stream = false;
+    return XGM_OK;
+}
+
+extern "C" int xgm_index_set_profiling(xgm_index* idx, int on) {
+    if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
+    idx->profiling = on != 0;
+    return XGM_OK;
+}
+
+static thread_local double g_last_kernel_ms = -1.0;
+extern "C" double xgm_last_kernel_ms(const xgm_index*) { return g_last_kernel_ms; }
+
+/* ------------------------------------------------------------------ dictionary --------------- */
+
+int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id) {
+    uint32_t lo = 0, hi = idx->hdr.n_terms;
+    const uint64_t* so = idx->str_off.data();
+    const char* sb = idx->str_bytes.data();
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        size_t ml = (size_t)(so[mid + 1] - so[mid]);
+        int c = memcmp(sb + so[mid], term, std::min(ml, len));
+        if (c < 0 || (c == 0 && ml < len)) lo = mid + 1; else hi = mid;
+    }
+    if (lo < idx->hdr.n_terms && (size_t)(so[lo + 1] - so[lo]) == len && memcmp(sb + so[lo], term, len) == 0) {
+        *id = lo;
+        return 1;
+    }
+    *id = UINT32_MAX;
+    return 0;
+}
+
+extern "C" int xgm_lookup_term(const xgm_index* idx, const char* term, size_t len, uint32_t* term_id, uint32_t* termfreq,
+                               uint32_t* collfreq, uint32_t* wdf_ub) {
+    if (!idx || !term) return xgm_set_error(XGM_E_INVALID, "null argument");
+    uint32_t id;
+    bool found = xgm_lookup_term_id(idx, term, len, &id) != 0;
+    if (term_id) *term_id = id;
+    if (termfreq) *termfreq = found ? idx->term_df[id] : 0;
+    if (collfreq) *collfreq = found ? idx->term_cf[id] : 0;
+    if (wdf_ub) *wdf_ub = found ? idx->term_wdfub[id] : 0;
+    return XGM_OK;
+}
+
+extern "C" int xgm_index_termfreqs(const xgm_index* idx, uint32_t* termfreq, uint32_t cap) {
+    if (!idx || !termfreq) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (cap < idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "buffer too small");
+    memcpy(termfreq, idx->term_df.data(), (size_t)idx->hdr.n_terms * 4);
+    return XGM_OK;
+}
+
+extern "C" uint64_t xgm_query_postings_bytes(const xgm_index* idx, const xgm_query* q) {
+    uint64_t n = 0;
+    for (uint32_t t = 0; t < q->n_terms; ++t)
+        if (q->terms[t].term_id != UINT32_MAX) n += idx->term_df[q->terms[t].term_id];
+    return n * 8;
+}
+
+/* ------------------------------------------------------------------ search ------------------- */
+
+static uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+/* xgm_query → device form; returns the wdf table width the query needs (1 or 2 bytes), 0 if too big */
+static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query* d) {
+    memset(d, 0, sizeof *d);
+    d->op = q->op;
+    d->n_terms = q->n_terms;
+    d->k = q->first + q->maxitems;
+    d->window = q->window;
+    d->len_factor = q->len_factor; d->k1 = q->k1; d->b = q->b; d->min_normlen = q->min_normlen;
+    int width = 1;
+    bool any_absent = false, all_absent = true;
+    for (uint32_t t = 0; t < q->n_terms; ++t) {
+        d->term_id[t] = q->terms[t].term_id;
+        d->termweight[t] = q->terms[t].termweight;
+        d->phrase_index[t] = (uint8_t)q->terms[t].phrase_index;
+        if (q->terms[t].term_id == UINT32_MAX) { any_absent = true; continue; }
+        all_absent = false;
+        if (q->terms[t].term_id >= idx->hdr.n_terms) return -1;
+        uint32_t ub = idx->term_wdfub[q->terms[t].term_id];
+        if (ub > 65534u) return 0;
+        if (ub > 254u) width = 2;
+    }
+    if (q->op == XGM_OP_PHRASE && q->phrase_active) {
+        d->flags |= XGM_QF_PHRASE;
+        if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
+    }
+    if (q->op == XGM_OP_OR ? all_absent : any_absent) d->flags |= XGM_QF_EMPTY;
+    /* post-order program → node list */
+    int stack[2 * XGM_MAX_TERMS];
+    int sp = 0, n_nodes = 0;
+    if (q->sum_len != 2 * q->n_terms - 1) return -1;
+    for (uint32_t i = 0; i < q->sum_len; ++i) {
+        int8_t op = q->sum_prog[i];
+        if (op >= 0) {
+            if ((uint32_t)op >= q->n_terms) return -1;
+            stack[sp++] = op;
+        } else {
+            if (sp < 2) return -1;
+            int r = stack[--sp], l = stack[--sp];
+            d->node_a[n_nodes] = (uint8_t)l;
+            d->node_b[n_nodes] = (uint8_t)r;
+            stack[sp++] = (int)q->n_terms + n_nodes;
+            ++n_nodes;
+        }
+    }
+    if (sp != 1 || n_nodes != (int)q->n_terms - 1) return -1;
+    return width;
+}
+
+struct BatchPlan {
+    uint32_t nq, k_max, tab_terms, n_groups, stripes_per_group, cap, k_stride_c, merge_cap;
+    bool phrase, wide;
+};
+
+static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
+                      BatchPlan* bp) {
+    bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false;
+    for (uint32_t i = 0; i < nq; ++i) {
+        if (qs[i].n_terms == 0 || qs[i].n_terms > XGM_MAX_TERMS) return xgm_set_error(XGM_E_INVALID, "query %u: bad n_terms", i);
+        int width = to_dev_query(idx, &qs[i], &dq[i]);
+        if (width < 0) return xgm_set_error(XGM_E_INVALID, "query %u: malformed plan", i);
+        if (width == 0) return XGM_UNSUPPORTED;
+        if (dq[i].k > XGM_MAX_K) return XGM_UNSUPPORTED;
+        if (width == 2) bp->wide = true;
+        if (dq[i].flags & XGM_QF_PHRASE) {
+            if (dq[i].n_terms > XGM_PHRASE_MAX_TERMS) return XGM_UNSUPPORTED;
+            bp->phrase = true;
+        }
+        bp->k_max = std::max(bp->k_max, dq[i].k);
+        bp->tab_terms = std::max(bp->tab_terms, dq[i].n_terms);
+        kq[i] = dq[i].k;
+        maxposs[i] = qs[i].max_possible;
+    }
+    if (bp->phrase && bp->tab_terms > XGM_PHRASE_MAX_TERMS) {
+        /* a batch mixing long AND/OR queries with phrases would blow the LDS budget: caller splits */
+        return XGM_UNSUPPORTED;
+    }
+    bp->cap = std::max(512u, next_pow2(bp->k_max + XGM_WG));
+    const size_t smem = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide);
+    if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
+    const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
+    /* groups per query: fill the chip (~8 workgroups per CU across the batch), bounded by the merge
+     * kernel's LDS sort capacity */
+    uint32_t want = std::max(1u, 2048u / nq);
+    uint32_t g_cap = std::max(1u, XGM_MERGE_CAP / next_pow2(bp->k_max));
+    want = std::min(std::min(want, g_cap), n_stripes);
+    bp->stripes_per_group = (n_stripes + want - 1) / want;
+    bp->n_groups = (n_stripes + bp->stripes_per_group - 1) / bp->stripes_per_group;
+    bp->k_stride_c = bp->k_max;
+    bp->merge_cap = std::max(512u, next_pow2(bp->n_groups * bp->k_max));
+    return XGM_OK;
+}
+
+/* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`. */
+static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
+                     xgm_hit* d_hits, xgm_result_hdr* d_hdrs) {
+    int rc;
+    size_t up_bytes = (size_t)nq * (sizeof(xgm_dev_query) + sizeof(uint32_t) + sizeof(double));
+    if ((rc = grow_pinned(&s->h_up, &s->cap_up, up_bytes))) return rc;
+    xgm_dev_query* h_dq = (xgm_dev_query*)s->h_up;
+    double* h_mp = (double*)(h_dq + nq);
+    uint32_t* h_kq = (uint32_t*)(h_mp + nq);
+    BatchPlan bp;
+    if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp))) return rc;
+    if (k_stride < bp.k_max) return xgm_set_error(XGM_E_INVALID, "k_stride %u < first+maxitems %u", k_stride, bp.k_max);
+    if ((rc = grow(&s->d_queries, &s->cap_queries, (size_t)nq))) return rc;
+    if (nq > s->cap_kq) {
+        if (s->d_kq) hipFree(s->d_kq);
+        if (s->d_maxposs) hipFree(s->d_maxposs);
+        s->d_kq = nullptr; s->d_maxposs = nullptr;
+        HIP_TRY(hipMalloc((void**)&s->d_kq, (size_t)nq * 4));
+        HIP_TRY(hipMalloc((void**)&s->d_maxposs, (size_t)nq * 8));
+        s->cap_kq = nq;
+    }
+    if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)nq * bp.n_groups * bp.k_stride_c))) return rc;
+    if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)nq * bp.n_groups))) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_queries, h_dq, (size_t)nq * sizeof(xgm_dev_query), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->d_maxposs, h_mp, (size_t)nq * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(s->d_kq, h_kq, (size_t)nq * 4, hipMemcpyHostToDevice, stream));
+
+    xgm_match_launch L;
+    L.seg = idx->view;
+    L.queries = s->d_queries;
+    L.nq = nq; L.n_groups = bp.n_groups; L.stripes_per_group = bp.stripes_per_group;
+    L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
+    L.phrase = bp.phrase; L.wide = bp.wide;
+    L.cand = s->d_cand; L.ghdr = s->d_ghdr;
+    if (idx->profiling) HIP_TRY(hipEventRecord(s->ev0, stream));
+    if ((rc = xgm_launch_match(L, stream))) return rc;
+    if (idx->profiling) HIP_TRY(hipEventRecord(s->ev1, stream));
+    if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, bp.n_groups, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
+                               d_hdrs, s->d_maxposs, stream)))
+        return rc;
+    return XGM_OK;
+}
+
+static hipStream_t pick_stream(xgm_index* idx, XgmScratch* s) { return idx->stream ? (hipStream_t)idx->stream : s->stream; }
+
+extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits,
+                                xgm_result_hdr* hdrs) {
+    if (!idx || !qs || !hits || !hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (nq == 0) return XGM_OK;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    XgmScratch* s;
+    if ((rc = scratch_acquire(idx, &s))) return rc;
+    hipStream_t stream = pick_stream(idx, s);
+    do {
+        if ((rc = grow(&s->d_hits, &s->cap_hits, (size_t)nq * k_stride))) break;
+        if ((rc = grow(&s->d_hdrs, &s->cap_hdrs, (size_t)nq))) break;
+        size_t down = (size_t)nq * k_stride * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
+        if ((rc = grow_pinned(&s->h_down, &s->cap_down, down))) break;
+        if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, s->d_hdrs))) break;
+        xgm_hit* h_hits = (xgm_hit*)s->h_down;
+        xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + (size_t)nq * k_stride);
+        hipError_t e = hipMemcpyAsync(h_hits, s->d_hits, (size_t)nq * k_stride * sizeof(xgm_hit), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_hdrs, s->d_hdrs, (size_t)nq * sizeof(xgm_result_hdr), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { rc = xgm_launch_error("result copy", (int)e, hipGetErrorString(e)); break; }
+        memcpy(hdrs, h_hdrs, (size_t)nq * sizeof(xgm_result_hdr));
+        /* only the valid prefix of each row is defined on the device */
+        for (uint32_t i = 0; i < nq; ++i)
+            memcpy(hits + (size_t)i * k_stride, h_hits + (size_t)i * k_stride, (size_t)h_hdrs[i].n_hits * sizeof(xgm_hit));
+        if (idx->profiling) {
+            float ms = -1.f;
+            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) g_last_kernel_ms = ms;
+        }
+    } while (0);
+    scratch_release(idx, s);
+    return rc;
+}
+
+extern "C" int xgm_search(xgm_index* idx, const xgm_query* q, xgm_hit* hits, xgm_result_hdr* hdr) {
+    if (!q) return xgm_set_error(XGM_E_INVALID, "null argument");
+    uint32_t k = q->first + q->maxitems;
+    return xgm_search_batch(idx, q, 1, k ? k : 1, hits, hdr);
+}
+
+extern "C" int xgm_search_batch_device(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, void* d_hits,
+                                       void* d_hdrs) {
+    if (!idx || !qs || !d_hits || !d_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (nq == 0) return XGM_OK;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    XgmScratch* s;
+    if ((rc = scratch_acquire(idx, &s))) return rc;
+    hipStream_t stream = pick_stream(idx, s);
+    rc = run_batch(idx, s, stream, qs, nq, k_stride, (xgm_hit*)d_hits, (xgm_result_hdr*)d_hdrs);
+    if (rc == XGM_OK && idx->profiling) {
+        float ms = -1.f;
+        if (hipEventSynchronize(s->ev1) == hipSuccess && hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) g_last_kernel_ms = ms;
+    }
+    /* the scratch (queries, candidates) is still in use by the enqueued kernels: mark it pending so
+     * the next acquire waits for them. */
+    if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
+    if (!idx->stream) hipStreamSynchronize(stream);
+    scratch_release(idx, s);
+    return rc;
+}
+
+extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
+                                       uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
+    if (!idx || !d_all_hits || !d_all_hdrs || !k || !d_out_hits || !d_out_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (nq == 0) return XGM_OK;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    XgmScratch* s;
+    if ((rc = scratch_acquire(idx, &s))) return rc;
+    hipStream_t stream = pick_stream(idx, s);
+    do {
+        uint32_t k_max = 1;
+        for (uint32_t i = 0; i < nq; ++i) k_max = std::max(k_max, k[i]);
+        if (k_max > k_stride) { rc = xgm_set_error(XGM_E_INVALID, "k > k_stride"); break; }
+        uint32_t cap = std::max(512u, next_pow2(n_shards * k_max));
+        if (cap > XGM_MERGE_CAP) { rc = XGM_UNSUPPORTED; break; }
+        if (nq > s->cap_kq) {
+            if (s->d_kq) hipFree(s->d_kq);
+            if (s->d_maxposs) hipFree(s->d_maxposs);
+            s->d_kq = nullptr; s->d_maxposs = nullptr; s->cap_kq = 0;
+            hipError_t e = hipMalloc((void**)&s->d_kq, (size_t)nq * 4);
+            if (e == hipSuccess) e = hipMalloc((void**)&s->d_maxposs, (size_t)nq * 8);
+            if (e != hipSuccess) { rc = xgm_launch_error("hipMalloc", (int)e, hipGetErrorString(e)); break; }
+            s->cap_kq = nq;
+        }
+        if ((rc = grow_pinned(&s->h_up, &s->cap_up, (size_t)nq * 4))) break;
+        memcpy(s->h_up, k, (size_t)nq * 4);
+        hipError_t e = hipMemcpyAsync(s->d_kq, s->h_up, (size_t)nq * 4, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { rc = xgm_launch_error("hipMemcpyAsync", (int)e, hipGetErrorString(e)); break; }
+        rc = xgm_launch_merge_shards((const xgm_hit*)d_all_hits, (const xgm_result_hdr*)d_all_hdrs, n_shards, nq, k_stride, s->d_kq,
+                                     cap, (xgm_hit*)d_out_hits, (xgm_result_hdr*)d_out_hdrs, stream);
+    } while (0);
+    if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
+    if (!idx->stream) hipStreamSynchronize(stream);
+    scratch_release(idx, s);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ diagnostics -------------- */
+
+/* Decode one term's whole posting list on the DEVICE (K1 alone) into host arrays. */
+extern "C" int64_t xgm_debug_decode_term_device(xgm_index* idx, uint32_t term_id, uint32_t* did, uint32_t* wdf, uint64_t cap) {
+    if (!idx || !did || !wdf) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (term_id >= idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "term id out of range");
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    const uint32_t df = idx->term_df[term_id];
+    if (cap < df) return xgm_set_error(XGM_E_INVALID, "buffer too small");
+    const uint32_t b0 = (uint32_t)idx->term_blk[term_id], b1 = (uint32_t)idx->term_blk[term_id + 1];
+    const uint32_t nblk = b1 - b0;
+    std::vector<uint32_t> meta(nblk);
+    HIP_TRY(hipMemcpy(meta.data(), (const uint32_t*)idx->d_sections[XGM_S_BLK_META] + b0, (size_t)nblk * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> ord(nblk);
+    uint64_t o = 0;
+    for (uint32_t i = 0; i < nblk; ++i) { ord[i] = o; o += XGM_META_COUNT(meta[i]); }
+    if (o != df) return xgm_set_error(XGM_E_INVALID, "block counts (%llu) != df (%u)", (unsigned long long)o, df);
+    uint64_t* d_ord = nullptr; uint32_t *d_did = nullptr, *d_wdf = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_ord, (size_t)nblk * 8));
+    HIP_TRY(hipMalloc((void**)&d_did, (size_t)df * 4));
+    HIP_TRY(hipMalloc((void**)&d_wdf, (size_t)df * 4));
+    HIP_TRY(hipMemcpy(d_ord, ord.data(), (size_t)nblk * 8, hipMemcpyHostToDevice));
+    rc = xgm_launch_decode(idx->view, term_id, b0, nblk, d_ord, d_did, d_wdf, nullptr);
+    if (rc == XGM_OK) {
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(did, d_did, (size_t)df * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(wdf, d_wdf, (size_t)df * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = xgm_launch_error("decode", (int)e, hipGetErrorString(e));
+    }
+    hipFree(d_ord); hipFree(d_did); hipFree(d_wdf);
+    return rc ? rc : (int64_t)df;
+}

@@ -1,0 +1,47 @@
+/* Host↔device structures of the match engine (not part of the public ABI). */
+#ifndef XGM_DEVICE_H
+#define XGM_DEVICE_H
+
+#include <stdint.h>
+
+#include "../../include/xgm.h"
+#include "xgm_segment.h"
+
+#define XGM_WG 256u                 /* threads per workgroup of the match kernel (4 waves)        */
+#define XGM_WAVES (XGM_WG / 64u)
+#define XGM_MERGE_CAP 8192u         /* candidates one merge workgroup can sort in LDS             */
+#define XGM_PHRASE_MAX_TERMS 3u     /* position tables are 4 B/slot/term: LDS bound */
+
+#define XGM_QF_PHRASE 1u            /* apply the positional filter                                 */
+#define XGM_QF_EXACT 2u             /* window == n_terms: ExactPhrasePostList semantics            */
+#define XGM_QF_EMPTY 4u             /* provably no match on this shard (absent AND term, ...)      */
+
+/* Executable form of xgm_query, one per query of a batch, read with scalar loads. */
+typedef struct {
+    uint32_t op, n_terms, k, window;
+    uint32_t flags, pad0;
+    double len_factor, k1, b, min_normlen;
+    double termweight[XGM_MAX_TERMS];
+    uint32_t term_id[XGM_MAX_TERMS];      /* UINT32_MAX: absent in this shard                      */
+    uint8_t phrase_index[XGM_MAX_TERMS];
+    /* weight summation as a node list: node j (0 <= j < n_terms-1) = val[node_a[j]] + val[node_b[j]]
+     * where val[0..n_terms) are the leaves and val[n_terms + j] the inner nodes; root = last node */
+    uint8_t node_a[XGM_MAX_TERMS];
+    uint8_t node_b[XGM_MAX_TERMS];
+} xgm_dev_query;
+
+/* One top-k candidate: 16 bytes. */
+typedef struct {
+    uint64_t wbits;        /* IEEE bits of the (non-negative) weight: orders like the double       */
+    uint32_t did;
+    uint32_t subqs;
+} xgm_cand;
+
+/* Per (query, group) summary written by the match kernel. */
+typedef struct {
+    uint64_t matches;
+    uint32_t n_cand;
+    uint32_t pad;
+} xgm_group_hdr;
+
+#endif

@@ -1,0 +1,56 @@
+/* Internal declarations shared by the translation units of libxgm.so (host side). */
+#ifndef XGM_INTERNAL_H
+#define XGM_INTERNAL_H
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/xgm.h"
+#include "xgm_segment.h"
+
+int xgm_set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+/* A complete segment as one host blob (header + sections). */
+struct XgmSegmentBlob {
+    std::vector<uint8_t> bytes;
+    const xgm_seg_header* header() const { return reinterpret_cast<const xgm_seg_header*>(bytes.data()); }
+    template <class T>
+    const T* section(int s) const { return reinterpret_cast<const T*>(bytes.data() + header()->sec_off[s]); }
+};
+
+int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out);
+int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vector<const char*>* term_ptrs,
+                      std::vector<uint32_t>* term_lens, xgm_raw_postings* raw);
+int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes);
+
+/* Per-thread scratch for searches (device + pinned host buffers), see xgm_api.cc. */
+struct XgmScratch;
+
+struct xgm_index {
+    int device = -1;
+    xgm_seg_header hdr{};
+    /* host copies used for planning / lookup */
+    std::vector<uint32_t> term_df, term_cf, term_wdfub, term_flags;
+    std::vector<uint64_t> term_blk, term_word;
+    std::vector<uint64_t> str_off;
+    std::vector<char> str_bytes;
+    /* device */
+    void* d_blob = nullptr;            /* whole segment (file-loaded) or nullptr when sections are separate */
+    void* d_sections[XGM_S_COUNT] = {};/* device pointer of each device-resident section             */
+    bool sections_owned = false;       /* synthetic builder allocates sections one by one            */
+    xgm_seg_dev view{};
+    uint64_t device_bytes = 0;
+    void* stream = nullptr;            /* hipStream_t                                                */
+    bool own_stream = false;
+    bool profiling = false;
+    std::mutex scratch_mu;
+    std::vector<XgmScratch*> scratch_pool;
+};
+
+int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id);
+
+#endif

@@ -1,0 +1,755 @@
+/* HIP kernels of the match/rank path for gfx950 (wave64).  No MFMA: this is integer/pointer work
+ * bounded by HBM and LDS, plus fp64 BM25 on the survivors.
+ *
+ *   xgm_match_kernel  — one workgroup per (query, docid range).  Per stripe of W docids:
+ *        K1 decode   : each wave stages one 128-posting block's bit-packed payload into its LDS
+ *                      window (coalesced 16-B loads), unpacks two postings per lane, rebuilds
+ *                      docids with a DPP wave prefix sum, and scatters wdf+1 into a per-term
+ *                      direct-address LDS table (reference: GlassPostList::next/skip_to varint
+ *                      decode, glass_postlist.cc:768-991);
+ *        K2/K3 match : a byte-parallel AND (or OR) of the tables finds matching slots, compacted
+ *                      with ballot/mbcnt into an LDS queue (reference: MultiAndPostList::
+ *                      find_next_match multiandpostlist.cc:180-207, OrPostList::next
+ *                      orpostlist.cc:114-204);
+ *        K6 phrase   : optional positional filter per survivor (ExactPhrasePostList::test_doc
+ *                      exactphrasepostlist.cc:75-133, PhrasePostList::test_doc
+ *                      phrasepostlist.cc:60-90);
+ *        K4 bm25     : fp64 BM25Weight::get_sumpart (bm25weight.cc:170-181) per (doc, term), summed
+ *                      in the reference's association (multiandpostlist.cc:150-160,
+ *                      orpostlist.cc:94-103);
+ *        K5 top-k    : threshold-filtered LDS candidate buffer + bitonic selection under the total
+ *                      order of msetcmp_by_relevance<true> (msetcmp.cc:55-62; ProtoMSet::add
+ *                      protomset.h:340-400).
+ *   xgm_merge_kernel  — per query, merges the groups' (or shards') candidates into the final hits
+ *                      (reference: ProtoMSet::finalise sort protomset.h:657; Matcher::merge_mset
+ *                      matcher.cc:653-781; MSet::unshard_docids mset.cc:367-373).
+ *   xgm_decode_kernel — K1 alone, whole term → (did, wdf) arrays; used to verify segments and as a
+ *                      decode micro-benchmark.
+ *
+ * Compile with -ffp-contract=off: BM25 must round exactly like the reference's x86-64 doubles.
+ */
+#include <hip/hip_runtime.h>
+
+#include "xgm_device.h"
+#include "xgm_launch.h"
+
+namespace {
+
+constexpr uint32_t kInfStripe = 0xFFFFFFFFu;
+constexpr uint32_t kStageWords = 272;   /* 256 payload words + overrun, per wave */
+
+/* ---------------------------------------------------------------- wave primitives ------------ */
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+/* Inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each 16-lane row, then
+ * row_bcast:15 / row_bcast:31 to carry across rows (CDNA DPP). */
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += dpp0<0x111, 0xf>(v);
+    v += dpp0<0x112, 0xf>(v);
+    v += dpp0<0x114, 0xf>(v);
+    v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);
+    v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t lane_id() {
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+/* First index in [lo, hi) with arr[i] >= key (hi if none); 64-ary search, result wave-uniform. */
+__device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ arr, uint32_t lo, uint32_t hi, uint32_t key,
+                                     uint32_t lane) {
+    while (hi - lo > 64u) {
+        uint32_t step = (hi - lo + 63u) / 64u;
+        uint32_t p = lo + lane * step;
+        bool less = (p < hi) && (arr[p] < key);
+        uint32_t c = (uint32_t)__popcll(__ballot(less));
+        if (c == 0) return lo;
+        uint32_t nlo = lo + (c - 1u) * step + 1u;
+        uint32_t nhi = lo + c * step;
+        hi = nhi < hi ? nhi : hi;
+        lo = nlo;
+    }
+    uint32_t p = lo + lane;
+    bool less = (p < hi) && (arr[p] < key);
+    return lo + (uint32_t)__popcll(__ballot(less));
+}
+
+__device__ __forceinline__ uint32_t extract_bits(const uint32_t* s, uint32_t idx, uint32_t bw) {
+    uint32_t bit = idx * bw;
+    uint32_t w = bit >> 5;
+    uint32_t v = __builtin_amdgcn_alignbit(s[w + 1], s[w], bit & 31u);
+    return bw >= 32u ? v : (v & ((1u << bw) - 1u));
+}
+
+/* ---------------------------------------------------------------- K1: block decode ----------- */
+
+struct DecodedPair {
+    uint32_t d0, d1, w0, w1;      /* docids and wdfs of postings 2*lane and 2*lane+1 */
+    uint32_t p0, p1;              /* position offsets (relative to the block) — PHRASE only */
+    bool v0, v1;
+};
+
+/* Stage the block's payload into the wave's LDS window and unpack two postings per lane. */
+template <bool WITH_POS>
+__device__ __forceinline__ DecodedPair decode_block(const uint32_t* __restrict__ payload, uint32_t first_did,
+                                                    uint32_t meta, uint32_t* stage, uint32_t lane) {
+    const uint32_t n = XGM_META_COUNT(meta), bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta);
+    const uint32_t ngw = (n * bwg + 31u) >> 5, nww = (n * bww + 31u) >> 5;
+    const uint32_t need = ngw + nww + 2u;                 /* +2: 2-word windows may overrun */
+    for (uint32_t w = lane * 4u; w < need; w += 256u) {
+        /* payload is 4-byte aligned; the segment is padded so this never leaves the allocation */
+        uint32_t a = payload[w], b = payload[w + 1], c = payload[w + 2], d = payload[w + 3];
+        stage[w] = a; stage[w + 1] = b; stage[w + 2] = c; stage[w + 3] = d;
+    }
+    wave_lds_fence();
+    DecodedPair r;
+    const uint32_t i0 = lane * 2u, i1 = i0 + 1u;
+    r.v0 = i0 < n;
+    r.v1 = i1 < n;
+    uint32_t g0 = (r.v0 && i0 > 0u) ? extract_bits(stage, i0, bwg) + 1u : 0u;
+    uint32_t g1 = r.v1 ? extract_bits(stage, i1, bwg) + 1u : 0u;
+    r.w0 = r.v0 ? extract_bits(stage + ngw, i0, bww) : 0u;
+    r.w1 = r.v1 ? extract_bits(stage + ngw, i1, bww) : 0u;
+    uint32_t local = g0 + g1;
+    uint32_t excl = wave_incl_scan(local) - local;
+    r.d0 = first_did + excl + g0;
+    r.d1 = r.d0 + g1;
+    if (WITH_POS) {
+        uint32_t lw = r.w0 + r.w1;
+        uint32_t pex = wave_incl_scan(lw) - lw;
+        r.p0 = pex;
+        r.p1 = pex + r.w0;
+    } else {
+        r.p0 = r.p1 = 0;
+    }
+    wave_lds_fence();    /* the next block may overwrite the window */
+    return r;
+}
+
+/* ---------------------------------------------------------------- K5: top-k in LDS ----------- */
+
+/* Candidate order: weight descending, then docid ascending (msetcmp_by_relevance<true>).  Weights
+ * are non-negative doubles so their bit patterns order like the values.  "a before b". */
+__device__ __forceinline__ bool cand_before(uint64_t aw, uint32_t ad, uint64_t bw, uint32_t bd) {
+    return aw > bw || (aw == bw && ad < bd);
+}
+
+struct TopK {
+    uint64_t* w;       /* [cap] */
+    uint32_t* d;       /* [cap] */
+    uint32_t* m;       /* [cap] subqs matched */
+    uint32_t cap;      /* power of two */
+};
+
+/* Bitonic sort of all `cap` entries into "before" order (best first); unused entries must hold the
+ * sentinel (w = 0, d = UINT32_MAX, m = UINT32_MAX) which sorts last.  All threads of the WG. */
+__device__ void topk_sort(const TopK& tk, uint32_t tid) {
+    for (uint32_t size = 2; size <= tk.cap; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < (tk.cap >> 1); i += XGM_WG) {
+                uint32_t lo = 2u * i - (i & (stride - 1u));
+                uint32_t hi = lo + stride;
+                bool asc = ((lo & size) == 0);       /* this run sorts best-first */
+                uint64_t aw = tk.w[lo], bw = tk.w[hi];
+                uint32_t ad = tk.d[lo], bd = tk.d[hi];
+                bool swap = asc ? cand_before(bw, bd, aw, ad) : cand_before(aw, ad, bw, bd);
+                if (swap) {
+                    tk.w[lo] = bw; tk.w[hi] = aw;
+                    tk.d[lo] = bd; tk.d[hi] = ad;
+                    uint32_t am = tk.m[lo], bm = tk.m[hi];
+                    tk.m[lo] = bm; tk.m[hi] = am;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+/* ---------------------------------------------------------------- control block -------------- */
+
+struct Ctrl {
+    uint32_t cur[XGM_MAX_TERMS];      /* next unread block of each term (global block index)      */
+    uint32_t end[XGM_MAX_TERMS];      /* end of the term's blocks inside this group's docid range  */
+    uint32_t st[XGM_MAX_TERMS];       /* stripe of block cur[t], kInfStripe when exhausted         */
+    uint32_t run[XGM_MAX_TERMS];      /* number of blocks of stripe st[t] starting at cur[t]       */
+    uint32_t qn;                      /* queue fill                                                */
+    uint32_t tkn;                     /* top-k buffer fill                                         */
+    uint32_t theta_valid;
+    uint32_t theta_d;
+    uint64_t theta_w;
+    unsigned long long matches;
+};
+
+struct KernelSmem {
+    unsigned char* tab;   /* [T][W] of TabT */
+    uint32_t* ptab;       /* [T][W] (phrase) */
+    uint16_t* queue;      /* [W] */
+    TopK tk;
+    uint32_t* stage;      /* [WAVES][kStageWords] */
+    Ctrl* ctrl;
+};
+
+template <typename TabT>
+__device__ __forceinline__ KernelSmem carve(unsigned char* smem, uint32_t W, uint32_t T, bool phrase, uint32_t cap) {
+    KernelSmem s;
+    size_t off = 0;
+    s.tk.w = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)cap * 8;
+    s.ctrl = reinterpret_cast<Ctrl*>(smem + off); off += (sizeof(Ctrl) + 15) & ~(size_t)15;
+    s.tab = smem + off; off += (size_t)T * W * sizeof(TabT);
+    s.ptab = reinterpret_cast<uint32_t*>(smem + off); off += phrase ? (size_t)T * W * 4 : 0;
+    s.tk.d = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)cap * 4;
+    s.tk.m = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)cap * 4;
+    s.stage = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)XGM_WAVES * kStageWords * 4;
+    s.queue = reinterpret_cast<uint16_t*>(smem + off); off += (size_t)W * 2;
+    s.tk.cap = cap;
+    return s;
+}
+
+/* nonzero-byte mask of a packed word: bit 7 of every byte that is != 0 */
+__device__ __forceinline__ uint32_t nz_bytes(uint32_t x) {
+    return (x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t nz_halves(uint32_t x) {
+    return (x | ((x & 0x7FFF7FFFu) + 0x7FFF7FFFu)) & 0x80008000u;
+}
+
+/* ---------------------------------------------------------------- K6: positional filter ------ */
+
+struct PosList { const uint32_t* p; uint32_t n; };
+
+/* ExactPhrasePostList::test_doc: is there a base with term i at base + phrase_index[i] for all i? */
+__device__ bool phrase_exact(const PosList* pl, const uint8_t* pidx, uint32_t n_terms) {
+    /* drive from the shortest list */
+    uint32_t drv = 0;
+    for (uint32_t t = 1; t < n_terms; ++t) if (pl[t].n < pl[drv].n) drv = t;
+    uint32_t cursor[XGM_PHRASE_MAX_TERMS] = {0, 0, 0};
+    for (uint32_t i = 0; i < pl[drv].n; ++i) {
+        uint32_t x = pl[drv].p[i];
+        if (x < pidx[drv]) continue;
+        uint32_t base = x - pidx[drv];
+        bool ok = true;
+        for (uint32_t t = 0; t < n_terms && ok; ++t) {
+            if (t == drv) continue;
+            uint32_t want = base + pidx[t];
+            uint32_t c = cursor[t];
+            while (c < pl[t].n && pl[t].p[c] < want) ++c;
+            cursor[t] = c;
+            ok = (c < pl[t].n) && (pl[t].p[c] == want);
+        }
+        if (ok) return true;
+    }
+    return false;
+}
+
+/* PhrasePostList::test_doc (windowed, ordered), restated with the same forward-only cursors. */
+__device__ bool phrase_window(const PosList* pl_plan, const uint8_t* pidx, uint32_t n_terms, uint32_t window) {
+    /* reorder to phrase order: terms[i] of the reference is the i-th word of the phrase */
+    PosList pl[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < n_terms; ++t) pl[pidx[t]] = pl_plan[t];
+    uint32_t cur[XGM_PHRASE_MAX_TERMS] = {0, 0, 0};
+    bool started[XGM_PHRASE_MAX_TERMS] = {false, false, false};
+    if (pl[0].n == 0) return false;               /* poslists[0]->next() */
+    uint32_t b;
+    while (true) {
+        uint32_t base = pl[0].p[cur[0]];
+        uint32_t pos = base;
+        uint32_t i = 0;
+        while (true) {
+            if (++i == n_terms) return true;
+            /* skip_to(pos + 1) on a forward-only list: never moves backwards */
+            uint32_t c = cur[i];
+            if (!started[i]) { started[i] = true; c = 0; }
+            while (c < pl[i].n && pl[i].p[c] < pos + 1u) ++c;
+            cur[i] = c;
+            if (c >= pl[i].n) return false;
+            pos = pl[i].p[c];
+            b = pos + (n_terms - i);
+            if (!(b - base <= window)) break;
+        }
+        uint32_t want = b - window;
+        uint32_t c0 = cur[0];
+        while (c0 < pl[0].n && pl[0].p[c0] < want) ++c0;
+        cur[0] = c0;
+        if (c0 >= pl[0].n) return false;
+    }
+}
+
+/* ---------------------------------------------------------------- the match kernel ----------- */
+
+template <typename TabT, bool PHRASE>
+__global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                            uint32_t n_groups, uint32_t stripes_per_group,
+                                                            uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                            xgm_cand* __restrict__ cand_out,
+                                                            xgm_group_hdr* __restrict__ ghdr_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t g = blockIdx.x, qi = blockIdx.y;
+    const xgm_dev_query& q = queries[qi];
+    const uint32_t SB = seg.stripe_bits;
+    const uint32_t W = 1u << SB;
+    const uint32_t T = q.n_terms;
+    const bool is_or = (q.op == XGM_OP_OR);
+    const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
+    const uint32_t k = q.k;
+
+    KernelSmem sm = carve<TabT>(smem, W, tab_terms, PHRASE, cap);
+    Ctrl& ctl = *sm.ctrl;
+    TabT* tab = reinterpret_cast<TabT*>(sm.tab);
+    uint32_t* my_stage = sm.stage + wave * kStageWords;
+
+    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
+    const uint32_t s_begin = g * stripes_per_group;
+    uint32_t s_end = s_begin + stripes_per_group;
+    if (s_end > n_stripes) s_end = n_stripes;
+
+    /* ---- init: top-k buffer, cursors ---- */
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+    if (tid == 0) { ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; }
+    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
+    if (!empty) {
+        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
+            uint32_t id = q.term_id[t];
+            uint32_t c = 0, e = 0;
+            if (id != 0xFFFFFFFFu) {
+                uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+                c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+                e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+            }
+            if (lane == 0) { ctl.cur[t] = c; ctl.end[t] = e; }
+        }
+    }
+    __syncthreads();
+
+    unsigned long long my_matches = 0;
+    uint32_t target = s_begin;
+    while (!empty) {
+        /* ---- stripe selection: leapfrog (AND) / min (OR) over the terms' next stripes ---- */
+        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
+            uint32_t c = ctl.cur[t], e = ctl.end[t];
+            uint32_t id = q.term_id[t];
+            uint32_t st = kInfStripe, run = 0;
+            if (c < e) {
+                uint32_t f = seg.blk_first[c];
+                if ((f >> SB) < target) {
+                    c = wave_lower_bound(seg.blk_first, c, e, target << SB, lane);
+                }
+                if (c < e) {
+                    st = seg.blk_first[c] >> SB;
+                    /* blocks of one stripe: at most W/128 <= 64 → one ballot */
+                    uint32_t p = c + lane;
+                    bool in = (p < e) && ((seg.blk_first[p] >> SB) == st);
+                    run = (uint32_t)__popcll(__ballot(in));
+                }
+            }
+            (void)id;
+            if (lane == 0) { ctl.cur[t] = c; ctl.st[t] = st; ctl.run[t] = run; }
+        }
+        __syncthreads();
+        uint32_t s = is_or ? kInfStripe : 0u;
+        bool all_same = true;
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t st = ctl.st[t];
+            if (is_or) s = st < s ? st : s; else s = st > s ? st : s;
+        }
+        for (uint32_t t = 0; t < T; ++t) all_same = all_same && (ctl.st[t] == s);
+        if (s == kInfStripe || s >= s_end) break;          /* uniform */
+        if (!is_or && !all_same) { target = s; __syncthreads(); continue; }
+
+        /* ---- zero the tables ---- */
+        {
+            uint4* z = reinterpret_cast<uint4*>(sm.tab);
+            const uint32_t n16 = (uint32_t)((size_t)T * W * sizeof(TabT) / 16);
+            for (uint32_t i = tid; i < n16; i += XGM_WG) z[i] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+
+        /* ---- K1: decode every block of stripe s into the tables ---- */
+        {
+            uint32_t total = 0;
+            for (uint32_t t = 0; t < T; ++t) total += (ctl.st[t] == s) ? ctl.run[t] : 0u;
+            for (uint32_t item = wave; item < total; item += XGM_WAVES) {
+                uint32_t t = 0, j = item;
+                while (true) {
+                    uint32_t r = (ctl.st[t] == s) ? ctl.run[t] : 0u;
+                    if (j < r) break;
+                    j -= r; ++t;
+                }
+                const uint32_t id = q.term_id[t];
+                const uint32_t b = ctl.cur[t] + j;
+                const uint32_t meta = seg.blk_meta[b];
+                const uint32_t* payload = seg.words + seg.term_word[id] + seg.blk_word[b];
+                DecodedPair r = decode_block<PHRASE>(payload, seg.blk_first[b], meta, my_stage, lane);
+                TabT* row = tab + (size_t)t * W;
+                if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
+                if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
+                if (PHRASE) {
+                    uint32_t* prow = sm.ptab + (size_t)t * W;
+                    uint32_t pb = seg.blk_pos[b];
+                    if (r.v0) prow[r.d0 & (W - 1u)] = pb + r.p0;
+                    if (r.v1) prow[r.d1 & (W - 1u)] = pb + r.p1;
+                }
+            }
+        }
+        __syncthreads();
+
+        /* ---- K2/K3: find matching slots, compact into the queue ---- */
+        {
+            constexpr uint32_t PER = 16u / sizeof(TabT);        /* slots per 16-byte read */
+            for (uint32_t base0 = 0; base0 < W; base0 += XGM_WG * PER) {     /* uniform trip count */
+                const uint32_t base = base0 + tid * PER;
+                uint32_t bits = 0;
+                if (base < W) {
+                    uint32_t m[4];
+                    m[0] = m[1] = m[2] = m[3] = is_or ? 0u : 0xFFFFFFFFu;
+                    for (uint32_t t = 0; t < T; ++t) {
+                        uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)t * W + base);
+                        uint32_t x[4] = {v.x, v.y, v.z, v.w};
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t nz = sizeof(TabT) == 1 ? nz_bytes(x[c]) : nz_halves(x[c]);
+                            m[c] = is_or ? (m[c] | nz) : (m[c] & nz);
+                        }
+                    }
+                    /* one flag bit per slot */
+                    if (sizeof(TabT) == 1) {
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t f = m[c] >> 7;                      /* bits 0,8,16,24 */
+                            f = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+                            bits |= f << (4 * c);
+                        }
+                    } else {
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t f = m[c] >> 15;                     /* bits 0,16 */
+                            f = (f | (f >> 15)) & 0x3u;
+                            bits |= f << (2 * c);
+                        }
+                    }
+                }
+                uint32_t cnt = (uint32_t)__popc(bits);
+                uint32_t incl = wave_incl_scan(cnt);
+                uint32_t wtotal = __builtin_amdgcn_readlane(incl, 63);
+                if (wtotal) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&ctl.qn, wtotal);
+                    wbase = __builtin_amdgcn_readfirstlane(wbase);
+                    uint32_t o = wbase + incl - cnt;
+                    while (bits) {
+                        uint32_t bit = (uint32_t)__ffs(bits) - 1u;
+                        bits &= bits - 1u;
+                        sm.queue[o++] = (uint16_t)(base + bit);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        /* ---- K6 + K4 + K5: filter, score and collect the survivors ---- */
+        const uint32_t qn = ctl.qn;
+        const uint32_t stripe_base = s << SB;
+        for (uint32_t i0 = 0; i0 < qn; i0 += XGM_WG) {
+            /* make room: at most XGM_WG candidates are appended per round.  Everyone must see the
+             * same fill, so read it, then barrier before anyone appends. */
+            const uint32_t fill_now = ctl.tkn;
+            __syncthreads();
+            if (fill_now + XGM_WG > cap) {
+                topk_sort(sm.tk, tid);
+                if (tid == 0) {
+                    uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
+                    ctl.tkn = keep;
+                    if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
+                }
+                __syncthreads();
+                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+                __syncthreads();
+            }
+            const uint32_t i = i0 + tid;
+            if (i < qn) {
+                const uint32_t slot = sm.queue[i];
+                const uint32_t did = stripe_base + slot;
+                bool pass = true;
+                if (phrase) {
+                    PosList pl[XGM_PHRASE_MAX_TERMS];
+                    for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
+                        pl[t].p = seg.positions + seg.term_pos[q.term_id[t]] + sm.ptab[(size_t)t * W + slot];
+                        pl[t].n = (uint32_t)tab[(size_t)t * W + slot] - 1u;
+                    }
+                    pass = (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T)
+                                                    : phrase_window(pl, q.phrase_index, T, q.window);
+                }
+                if (pass) {
+                    ++my_matches;
+                    /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
+                    const double len = (double)seg.doclen[did];
+                    double normlen = len * q.len_factor;
+                    normlen = normlen > q.min_normlen ? normlen : q.min_normlen;   /* std::max(a, b) */
+                    const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                    double val[2 * XGM_MAX_TERMS];
+                    uint32_t subqs = 0;
+                    for (uint32_t t = 0; t < T; ++t) {
+                        uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
+                        double wt = -0.0;                       /* absent leaf: x + (-0.0) == x */
+                        if (e) {
+                            double wdf = (double)(e - 1u);
+                            double denom = denom_len + wdf;
+                            wt = q.termweight[t] * (wdf / denom);
+                            ++subqs;
+                        }
+                        val[t] = wt;
+                    }
+                    for (uint32_t j = 0; j + 1u < T; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
+                    double weight = val[T == 1 ? 0 : 2u * T - 2u];
+                    uint64_t wb = (uint64_t)__double_as_longlong(weight);
+                    bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
+                    if (take) {
+                        uint32_t o = atomicAdd(&ctl.tkn, 1u);
+                        sm.tk.w[o] = wb; sm.tk.d[o] = did; sm.tk.m[o] = subqs;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) ctl.qn = 0;
+        /* consume the stripe */
+        if (tid < T && ctl.st[tid] == s) ctl.cur[tid] += ctl.run[tid];
+        target = s + 1u;
+        __syncthreads();
+    }
+
+    /* ---- group epilogue: sort, publish the best k candidates and the match count ---- */
+    __syncthreads();
+    topk_sort(sm.tk, tid);
+    if (my_matches) atomicAdd(&ctl.matches, my_matches);
+    __syncthreads();
+    const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
+    xgm_cand* out = cand_out + ((size_t)qi * n_groups + g) * k_stride;
+    for (uint32_t i = tid; i < n_out; i += XGM_WG) {
+        xgm_cand c;
+        c.wbits = sm.tk.w[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
+        out[i] = c;
+    }
+    if (tid == 0) {
+        xgm_group_hdr h;
+        h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
+        ghdr_out[(size_t)qi * n_groups + g] = h;
+    }
+}
+
+/* ---------------------------------------------------------------- merge kernel --------------- */
+
+/* One workgroup per query.  Sources: n_src candidate lists of up to k_stride entries
+ * (groups of one shard, or shards after the all-gather).  did_mul/did_add remap shard-local
+ * docids: global = (local - 1) * n_shards + shard + 1 (multi.h:69-73) when unshard != 0. */
+__global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __restrict__ cand, const xgm_group_hdr* __restrict__ ghdr,
+                                                            uint32_t n_src, uint32_t k_stride_in, const uint32_t* __restrict__ kq,
+                                                            uint32_t cap, uint32_t k_stride_out, xgm_hit* __restrict__ hits,
+                                                            xgm_result_hdr* __restrict__ hdrs, const double* __restrict__ max_possible) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+    TopK tk;
+    tk.w = reinterpret_cast<uint64_t*>(smem);
+    tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
+    tk.m = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 12);
+    tk.cap = cap;
+    unsigned long long& matches = *reinterpret_cast<unsigned long long*>(smem + (size_t)cap * 16);
+    uint32_t& fill = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 8);
+    uint32_t& base = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 12);
+    if (tid == 0) { fill = 0; matches = 0; }
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { tk.w[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
+        const xgm_group_hdr h = ghdr[(size_t)qi * n_src + sidx];
+        const xgm_cand* src = cand + ((size_t)qi * n_src + sidx) * k_stride_in;
+        if (tid == 0) { base = fill; fill += h.n_cand; matches += h.matches; }
+        __syncthreads();
+        for (uint32_t i = tid; i < h.n_cand; i += XGM_WG) {
+            xgm_cand c = src[i];
+            tk.w[base + i] = c.wbits; tk.d[base + i] = c.did; tk.m[base + i] = c.subqs;
+        }
+        __syncthreads();
+    }
+    topk_sort(tk, tid);
+    const uint32_t k = kq[qi];
+    const uint32_t n = fill < k ? fill : k;
+    for (uint32_t i = tid; i < n; i += XGM_WG) {
+        xgm_hit hit;
+        hit.docid = tk.d[i]; hit.subqs_matched = tk.m[i]; hit.weight = __longlong_as_double((long long)tk.w[i]);
+        hits[(size_t)qi * k_stride_out + i] = hit;
+    }
+    if (tid == 0) {
+        xgm_result_hdr r;
+        r.n_hits = n;
+        r.max_weight_subqs_matched = fill ? tk.m[0] : 0u;
+        r.matches_exact = matches;
+        r.max_attained = fill ? __longlong_as_double((long long)tk.w[0]) : 0.0;
+        r.max_possible = max_possible ? max_possible[qi] : 0.0;
+        hdrs[qi] = r;
+    }
+}
+
+/* Shard merge after the all-gather: sources are whole result lists (xgm_hit) of each shard. */
+__global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit* __restrict__ all_hits, const xgm_result_hdr* __restrict__ all_hdrs,
+                                                                   uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* __restrict__ kq,
+                                                                   uint32_t cap, xgm_hit* __restrict__ hits, xgm_result_hdr* __restrict__ hdrs) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+    TopK tk;
+    tk.w = reinterpret_cast<uint64_t*>(smem);
+    tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
+    tk.m = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 12);
+    tk.cap = cap;
+    unsigned long long& matches = *reinterpret_cast<unsigned long long*>(smem + (size_t)cap * 16);
+    double& max_possible = *reinterpret_cast<double*>(smem + (size_t)cap * 16 + 8);
+    double& max_attained = *reinterpret_cast<double*>(smem + (size_t)cap * 16 + 16);
+    uint32_t& fill = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 24);
+    uint32_t& base = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 28);
+    uint32_t& max_subqs = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 32);
+    if (tid == 0) { fill = 0; matches = 0; max_possible = 0.0; max_attained = 0.0; max_subqs = 0; }
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { tk.w[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; }
+    __syncthreads();
+    for (uint32_t sh = 0; sh < n_shards; ++sh) {
+        const xgm_result_hdr h = all_hdrs[(size_t)sh * nq + qi];
+        const xgm_hit* src = all_hits + ((size_t)sh * nq + qi) * k_stride;
+        if (tid == 0) {
+            base = fill; fill += h.n_hits; matches += h.matches_exact;
+            /* MSet::Internal::merge_stats, mset.cc:376-395: max of max_possible / max_attained */
+            if (h.max_possible > max_possible) max_possible = h.max_possible;
+            if (h.max_attained > max_attained) { max_attained = h.max_attained; max_subqs = h.max_weight_subqs_matched; }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < h.n_hits; i += XGM_WG) {
+            xgm_hit c = src[i];
+            tk.w[base + i] = (uint64_t)__double_as_longlong(c.weight);
+            tk.d[base + i] = (c.docid - 1u) * n_shards + sh + 1u;
+            tk.m[base + i] = c.subqs_matched;
+        }
+        __syncthreads();
+    }
+    topk_sort(tk, tid);
+    const uint32_t k = kq[qi];
+    const uint32_t n = fill < k ? fill : k;
+    for (uint32_t i = tid; i < n; i += XGM_WG) {
+        xgm_hit hit;
+        hit.docid = tk.d[i]; hit.subqs_matched = tk.m[i]; hit.weight = __longlong_as_double((long long)tk.w[i]);
+        hits[(size_t)qi * k_stride + i] = hit;
+    }
+    if (tid == 0) {
+        xgm_result_hdr r;
+        r.n_hits = n; r.max_weight_subqs_matched = max_subqs; r.matches_exact = matches;
+        r.max_attained = max_attained; r.max_possible = max_possible;
+        hdrs[qi] = r;
+    }
+}
+
+/* ---------------------------------------------------------------- decode-only kernel ---------- */
+
+/* One wave per block of the term; writes postings at their ordinal.  ord_base[b - b0] = ordinal of
+ * the block's first posting (exclusive scan of the block counts, computed by the caller). */
+__global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uint32_t term_id, uint32_t b0, uint32_t nblk,
+                                                             const uint64_t* __restrict__ ord_base, uint32_t* __restrict__ out_did,
+                                                             uint32_t* __restrict__ out_wdf) {
+    __shared__ uint32_t stage_all[XGM_WAVES * kStageWords];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* stage = stage_all + wave * kStageWords;
+    for (uint32_t i = blockIdx.x * XGM_WAVES + wave; i < nblk; i += gridDim.x * XGM_WAVES) {
+        const uint32_t b = b0 + i;
+        const uint32_t* payload = seg.words + seg.term_word[term_id] + seg.blk_word[b];
+        DecodedPair r = decode_block<false>(payload, seg.blk_first[b], seg.blk_meta[b], stage, lane);
+        uint64_t o = ord_base[i] + 2u * lane;
+        if (r.v0) { out_did[o] = r.d0; out_wdf[o] = r.w0; }
+        if (r.v1) { out_did[o + 1] = r.d1; out_wdf[o + 1] = r.w1; }
+    }
+}
+
+size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_t tab_elem) {
+    size_t off = 0;
+    off += (size_t)cap * 8;
+    off += (sizeof(Ctrl) + 15) & ~(size_t)15;
+    off += (size_t)T * W * tab_elem;
+    off += phrase ? (size_t)T * W * 4 : 0;
+    off += (size_t)cap * 4 * 2;
+    off += (size_t)XGM_WAVES * kStageWords * 4;
+    off += (size_t)W * 2;
+    return (off + 15) & ~(size_t)15;
+}
+
+}  // namespace
+
+/* ---------------------------------------------------------------- launchers ------------------- */
+
+#define XGM_HIP_CHECK(expr)                                                                     \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) return xgm_launch_error(#expr, (int)e_, hipGetErrorString(e_));  \
+    } while (0)
+
+size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide) {
+    return match_smem_bytes(1u << stripe_bits, tab_terms, phrase, cap, wide ? 2 : 1);
+}
+
+int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
+    dim3 grid(L.n_groups, L.nq), block(XGM_WG);
+    const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide);
+    if (smem > 160u * 1024u) return xgm_launch_error("match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+#define XGM_LAUNCH(TT, PH)                                                                                   \
+    do {                                                                                                     \
+        auto kern = xgm_match_kernel<TT, PH>;                                                                \
+        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.n_groups, L.stripes_per_group, \
+                           L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);                                  \
+    } while (0)
+    if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
+    else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }
+#undef XGM_LAUNCH
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t n_src, uint32_t k_stride_in,
+                     const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
+                     xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream) {
+    const size_t smem = (size_t)cap * 16 + 64;
+    XGM_HIP_CHECK(hipFuncSetAttribute((const void*)xgm_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, n_src, k_stride_in, kq, cap,
+                       k_stride_out, hits, hdrs, max_possible);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
+                            uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
+                            hipStream_t stream) {
+    const size_t smem = (size_t)cap * 16 + 64;
+    XGM_HIP_CHECK(hipFuncSetAttribute((const void*)xgm_merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_shards, nq,
+                       k_stride, kq, cap, hits, hdrs);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int xgm_launch_decode(const xgm_seg_dev& seg, uint32_t term_id, uint32_t b0, uint32_t nblk, const uint64_t* ord_base,
+                      uint32_t* out_did, uint32_t* out_wdf, hipStream_t stream) {
+    if (nblk == 0) return 0;
+    uint32_t grid = (nblk + XGM_WAVES - 1) / XGM_WAVES;
+    if (grid > 4096u) grid = 4096u;
+    hipLaunchKernelGGL(xgm_decode_kernel, dim3(grid), dim3(XGM_WG), 0, stream, seg, term_id, b0, nblk, ord_base, out_did, out_wdf);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}

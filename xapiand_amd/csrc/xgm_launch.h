@@ -1,0 +1,35 @@
+/* Launch interface between the host API (xgm_api.cc) and the HIP translation units. */
+#ifndef XGM_LAUNCH_H
+#define XGM_LAUNCH_H
+
+#include <hip/hip_runtime.h>
+
+#include "xgm_device.h"
+
+struct xgm_match_launch {
+    xgm_seg_dev seg;
+    const xgm_dev_query* queries;     /* device, [nq] */
+    uint32_t nq, n_groups, stripes_per_group;
+    uint32_t tab_terms;               /* max n_terms in the batch (LDS table rows)               */
+    uint32_t cap;                     /* top-k buffer capacity, power of two >= k_max + XGM_WG    */
+    uint32_t k_stride;                /* candidates reserved per (query, group)                   */
+    bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
+    xgm_cand* cand;                   /* device, [nq][n_groups][k_stride]                         */
+    xgm_group_hdr* ghdr;              /* device, [nq][n_groups]                                   */
+};
+
+size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide);
+int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
+int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t n_src, uint32_t k_stride_in,
+                     const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
+                     xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream);
+int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
+                            uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
+                            hipStream_t stream);
+int xgm_launch_decode(const xgm_seg_dev& seg, uint32_t term_id, uint32_t b0, uint32_t nblk, const uint64_t* ord_base,
+                      uint32_t* out_did, uint32_t* out_wdf, hipStream_t stream);
+
+/* records "<what> failed: <msg>" as the thread's last error and returns XGM_E_DEVICE */
+int xgm_launch_error(const char* what, int code, const char* msg);
+
+#endif

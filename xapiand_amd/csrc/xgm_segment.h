@@ -1,0 +1,91 @@
+/* Device segment format ("XGMSEG1"), shared by the host builder, the GPU synthetic builder, the
+ * loader and the kernels.  One segment = one shard revision.  DESIGN.md §3 describes the layout and
+ * why it looks like this; the short version:
+ *
+ *   - docid space is cut into STRIPES of W = 2^stripe_bits docids;
+ *   - a posting list is a sequence of BLOCKS of <= 128 postings that never straddle a stripe;
+ *   - a block stores its first docid in a header array and the rest as frame-of-reference bit-packed
+ *     (gap-1) values plus bit-packed wdf values in a contiguous little-endian u32 payload;
+ *   - positions (when present) are a flat u32 array; a posting's positions start at
+ *     term_pos[t] + blk_pos[b] + Σ wdf of the earlier postings in its block.
+ *
+ * This replaces, for the query path, glass's chunked-varint posting lists and doclen list
+ * (reference src/xapian/backends/glass/glass_postlist.cc:677-695 format comment) and its
+ * interpolative-coded position table (glass_positionlist.cc:36-52).
+ */
+#ifndef XGM_SEGMENT_H
+#define XGM_SEGMENT_H
+
+#include <stdint.h>
+
+#define XGM_SEG_MAGIC "XGMSEG1"
+#define XGM_SEG_VERSION 1u
+#define XGM_BLOCK 128u                 /* postings per block (two per lane of a wave64)          */
+#define XGM_DEFAULT_STRIPE_BITS 13u    /* 8192 docids per stripe                                  */
+#define XGM_MIN_STRIPE_BITS 8u
+#define XGM_MAX_STRIPE_BITS 13u        /* bounded by the LDS tables of the match kernel           */
+#define XGM_WORD_PAD 8u                /* zero words after the payload so 2-word windows may overrun */
+
+/* blk_meta: bits 0-7 count-1, 8-15 gap bit width (0..32), 16-23 wdf bit width (0..32) */
+#define XGM_META(count, bwg, bww) (((count)-1u) | ((uint32_t)(bwg) << 8) | ((uint32_t)(bww) << 16))
+#define XGM_META_COUNT(m) (((m)&0xFFu) + 1u)
+#define XGM_META_BWG(m) (((m) >> 8) & 0xFFu)
+#define XGM_META_BWW(m) (((m) >> 16) & 0xFFu)
+
+/* term_flags */
+#define XGM_TF_POS_OK 1u               /* every posting has exactly wdf positions → phrase capable */
+
+enum xgm_section {
+    XGM_S_DOCLEN = 0,   /* u32[lastdocid+1]                                    */
+    XGM_S_TERM_DF,      /* u32[n_terms]   termfreq                              */
+    XGM_S_TERM_CF,      /* u32[n_terms]   collection frequency (Σ wdf)          */
+    XGM_S_TERM_WDFUB,   /* u32[n_terms]   glass-style wdf upper bound           */
+    XGM_S_TERM_FLAGS,   /* u32[n_terms]                                         */
+    XGM_S_TERM_BLK,     /* u64[n_terms+1] first block of each term              */
+    XGM_S_TERM_WORD,    /* u64[n_terms+1] first payload word of each term       */
+    XGM_S_TERM_POS,     /* u64[n_terms+1] first position of each term           */
+    XGM_S_BLK_FIRST,    /* u32[n_blocks]  first docid of the block              */
+    XGM_S_BLK_META,     /* u32[n_blocks]                                        */
+    XGM_S_BLK_WORD,     /* u32[n_blocks]  payload word offset, relative to term */
+    XGM_S_BLK_POS,      /* u32[n_blocks]  position offset, relative to term     */
+    XGM_S_WORDS,        /* u32[n_words + XGM_WORD_PAD]                          */
+    XGM_S_POSITIONS,    /* u32[n_positions]                                     */
+    XGM_S_STR_OFF,      /* u64[n_terms+1] (host only)                           */
+    XGM_S_STR_BYTES,    /* term bytes, sorted (host only)                       */
+    XGM_S_COUNT
+};
+
+typedef struct {
+    char magic[8];
+    uint32_t version, stripe_bits, block_size, n_terms;
+    uint32_t lastdocid, doccount, has_positions, doclen_lower_bound;
+    uint32_t wdf_upper_bound, reserved0;
+    uint64_t total_length, revision, n_postings, n_positions, n_blocks, n_words;
+    uint64_t file_bytes;
+    uint64_t sec_off[XGM_S_COUNT];     /* byte offset from the start of the blob, 256-B aligned   */
+    uint64_t sec_bytes[XGM_S_COUNT];
+} xgm_seg_header;
+
+/* Device-side view: raw pointers into the HBM blob. */
+typedef struct {
+    const uint32_t* doclen;
+    const uint64_t* term_blk;
+    const uint64_t* term_word;
+    const uint64_t* term_pos;
+    const uint32_t* blk_first;
+    const uint32_t* blk_meta;
+    const uint32_t* blk_word;
+    const uint32_t* blk_pos;
+    const uint32_t* words;
+    const uint32_t* positions;
+    uint32_t stripe_bits;
+    uint32_t lastdocid;
+} xgm_seg_dev;
+
+static inline uint32_t xgm_bits_needed(uint32_t v) {
+    uint32_t b = 0;
+    while (v) { ++b; v >>= 1; }
+    return b;
+}
+
+#endif /* XGM_SEGMENT_H */

@@ -1,0 +1,343 @@
+/* Host-side segment builder / exporter back end: raw postings → "XGMSEG1" blob.
+ *
+ * Index-build side.  The query path never runs this code.  The GPU synthetic
+ * builder (xgm_synth.hip) must produce bit-identical sections for the same postings; the tests
+ * check that.
+ */
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+
+#include "xgm_internal.h"
+
+namespace {
+
+constexpr uint64_t kAlign = 256;
+
+uint64_t align_up(uint64_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+struct BitWriter {
+    std::vector<uint32_t>& words;
+    uint64_t base;       /* word index where the current section starts */
+    explicit BitWriter(std::vector<uint32_t>& w) : words(w), base(w.size()) {}
+    void begin(uint32_t n_values, uint32_t bw) {
+        base = words.size();
+        words.resize(base + ((uint64_t)n_values * bw + 31) / 32, 0u);
+    }
+    void put(uint32_t i, uint32_t bw, uint32_t v) {
+        if (!bw) return;
+        uint64_t bit = (uint64_t)i * bw;
+        uint64_t w = base + (bit >> 5);
+        uint32_t sh = (uint32_t)(bit & 31);
+        words[w] |= v << sh;
+        if (sh + bw > 32) words[w + 1] |= v >> (32 - sh);
+    }
+};
+
+}  // namespace
+
+int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes) {
+    if (memcmp(h->magic, XGM_SEG_MAGIC, 8) != 0) return xgm_set_error(XGM_E_INVALID, "not an XGMSEG1 segment");
+    if (h->version != XGM_SEG_VERSION) return xgm_set_error(XGM_E_INVALID, "segment version %u unsupported", h->version);
+    if (h->block_size != XGM_BLOCK) return xgm_set_error(XGM_E_INVALID, "segment block size %u unsupported", h->block_size);
+    if (h->stripe_bits < XGM_MIN_STRIPE_BITS || h->stripe_bits > XGM_MAX_STRIPE_BITS)
+        return xgm_set_error(XGM_E_INVALID, "segment stripe_bits %u out of range", h->stripe_bits);
+    if (h->file_bytes > avail_bytes) return xgm_set_error(XGM_E_INVALID, "segment truncated");
+    for (int s = 0; s < XGM_S_COUNT; ++s)
+        if (h->sec_off[s] + h->sec_bytes[s] > h->file_bytes) return xgm_set_error(XGM_E_INVALID, "segment section %d out of bounds", s);
+    return XGM_OK;
+}
+
+int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out) {
+    if (!raw || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (stripe_bits == 0) stripe_bits = XGM_DEFAULT_STRIPE_BITS;
+    if (stripe_bits < XGM_MIN_STRIPE_BITS || stripe_bits > XGM_MAX_STRIPE_BITS)
+        return xgm_set_error(XGM_E_INVALID, "stripe_bits %u out of range [%u, %u]", stripe_bits, XGM_MIN_STRIPE_BITS,
+                             XGM_MAX_STRIPE_BITS);
+    const uint32_t T = raw->n_terms;
+    const bool has_pos = raw->has_positions && raw->pos_off && (raw->pos || raw->n_positions == 0);
+
+    std::vector<uint32_t> term_cf(T), term_wdfub(T), term_flags(T);
+    std::vector<uint64_t> term_blk(T + 1), term_word(T + 1), term_pos(T + 1);
+    std::vector<uint32_t> blk_first, blk_meta, blk_word, blk_pos, words, positions;
+    std::vector<uint64_t> str_off(T + 1);
+    std::vector<char> str_bytes;
+
+    /* DB-wide bounds the way glass tracks them (reference glass_version.h:252-270):
+     * doclen lower bound = smallest non-zero length, wdf upper bound = largest wdf. */
+    uint32_t doclen_lb = 0, wdf_ub_db = 0;
+    for (uint64_t d = 1; d <= raw->lastdocid; ++d) {
+        uint32_t l = raw->doclen[d];
+        if (l && (doclen_lb == 0 || l < doclen_lb)) doclen_lb = l;
+    }
+    for (uint64_t i = 0; i < raw->n_postings; ++i) wdf_ub_db = std::max(wdf_ub_db, raw->wdf[i]);
+
+    uint64_t p0 = 0;
+    BitWriter bw(words);
+    for (uint32_t t = 0; t < T; ++t) {
+        if (t > 0) {
+            /* terms must be strictly ascending bytewise */
+            const uint32_t la = raw->term_len[t - 1], lb = raw->term_len[t];
+            int c = memcmp(raw->terms[t - 1], raw->terms[t], std::min(la, lb));
+            if (c > 0 || (c == 0 && la >= lb)) return xgm_set_error(XGM_E_INVALID, "terms not sorted at index %u", t);
+        }
+        str_off[t] = str_bytes.size();
+        str_bytes.insert(str_bytes.end(), raw->terms[t], raw->terms[t] + raw->term_len[t]);
+
+        const uint32_t df = raw->df[t];
+        if (df == 0) return xgm_set_error(XGM_E_INVALID, "term %u has df 0", t);
+        if (p0 + df > raw->n_postings) return xgm_set_error(XGM_E_INVALID, "df overruns postings");
+        term_blk[t] = blk_first.size();
+        term_word[t] = words.size();
+        term_pos[t] = positions.size();
+        uint64_t cf = 0;
+        bool pos_ok = has_pos;
+        for (uint32_t i = 0; i < df; ++i) {
+            cf += raw->wdf[p0 + i];
+            if (i && raw->did[p0 + i] <= raw->did[p0 + i - 1]) return xgm_set_error(XGM_E_INVALID, "docids of term %u not ascending", t);
+            if (raw->did[p0 + i] == 0 || raw->did[p0 + i] > raw->lastdocid) return xgm_set_error(XGM_E_INVALID, "docid out of range in term %u", t);
+            if (has_pos && raw->pos_off[p0 + i + 1] - raw->pos_off[p0 + i] != raw->wdf[p0 + i]) pos_ok = false;
+        }
+        if (cf > 0xFFFFFFFFull) cf = 0xFFFFFFFFull;
+        term_cf[t] = (uint32_t)cf;
+        /* GlassPostListTable::get_freqs (glass_postlist.cc:175-189) capped as in
+         * GlassDatabase::get_wdf_upper_bound (glass_database.cc:823-830). */
+        uint32_t first_wdf = raw->wdf[p0];
+        uint32_t ub = (cf == 0 || df == 1) ? (uint32_t)cf : std::max((uint32_t)cf - first_wdf, first_wdf);
+        term_wdfub[t] = std::min(ub, wdf_ub_db);
+        term_flags[t] = pos_ok ? XGM_TF_POS_OK : 0u;
+
+        /* cut into blocks: same stripe, <= XGM_BLOCK postings */
+        uint32_t i = 0;
+        while (i < df) {
+            uint32_t stripe = raw->did[p0 + i] >> stripe_bits;
+            uint32_t n = 1;
+            while (n < XGM_BLOCK && i + n < df && (raw->did[p0 + i + n] >> stripe_bits) == stripe) ++n;
+            uint32_t maxgap = 0, maxwdf = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                if (j) maxgap = std::max(maxgap, raw->did[p0 + i + j] - raw->did[p0 + i + j - 1] - 1);
+                maxwdf = std::max(maxwdf, raw->wdf[p0 + i + j]);
+            }
+            uint32_t bwg = xgm_bits_needed(maxgap), bww = xgm_bits_needed(maxwdf);
+            uint64_t woff = words.size() - term_word[t];
+            uint64_t poff = positions.size() - term_pos[t];
+            if (woff > 0xFFFFFFFFull || poff > 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "term %u too large for 32-bit block offsets", t);
+            blk_first.push_back(raw->did[p0 + i]);
+            blk_meta.push_back(XGM_META(n, bwg, bww));
+            blk_word.push_back((uint32_t)woff);
+            blk_pos.push_back((uint32_t)poff);
+            bw.begin(n, bwg);
+            for (uint32_t j = 1; j < n; ++j) bw.put(j, bwg, raw->did[p0 + i + j] - raw->did[p0 + i + j - 1] - 1);
+            bw.begin(n, bww);
+            for (uint32_t j = 0; j < n; ++j) bw.put(j, bww, raw->wdf[p0 + i + j]);
+            if (pos_ok) {
+                for (uint32_t j = 0; j < n; ++j)
+                    for (uint64_t q = raw->pos_off[p0 + i + j]; q < raw->pos_off[p0 + i + j + 1]; ++q) positions.push_back(raw->pos[q]);
+            }
+            i += n;
+        }
+        p0 += df;
+    }
+    if (p0 != raw->n_postings) return xgm_set_error(XGM_E_INVALID, "sum of df (%llu) != n_postings (%llu)", (unsigned long long)p0, (unsigned long long)raw->n_postings);
+    term_blk[T] = blk_first.size();
+    term_word[T] = words.size();
+    term_pos[T] = positions.size();
+    str_off[T] = str_bytes.size();
+    const uint64_t n_words = words.size();
+    words.resize(n_words + XGM_WORD_PAD, 0u);
+
+    xgm_seg_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, XGM_SEG_MAGIC, 8);
+    h.version = XGM_SEG_VERSION;
+    h.stripe_bits = stripe_bits;
+    h.block_size = XGM_BLOCK;
+    h.n_terms = T;
+    h.lastdocid = raw->lastdocid;
+    h.doccount = raw->doccount;
+    h.has_positions = has_pos ? 1u : 0u;
+    h.doclen_lower_bound = doclen_lb;
+    h.wdf_upper_bound = wdf_ub_db;
+    h.total_length = raw->total_length;
+    h.revision = raw->revision;
+    h.n_postings = raw->n_postings;
+    h.n_positions = positions.size();
+    h.n_blocks = blk_first.size();
+    h.n_words = n_words;
+
+    struct Sec { int id; const void* p; uint64_t bytes; };
+    const Sec secs[] = {
+        {XGM_S_DOCLEN, raw->doclen, ((uint64_t)raw->lastdocid + 1) * 4},
+        {XGM_S_TERM_DF, raw->df, (uint64_t)T * 4},
+        {XGM_S_TERM_CF, term_cf.data(), (uint64_t)T * 4},
+        {XGM_S_TERM_WDFUB, term_wdfub.data(), (uint64_t)T * 4},
+        {XGM_S_TERM_FLAGS, term_flags.data(), (uint64_t)T * 4},
+        {XGM_S_TERM_BLK, term_blk.data(), (uint64_t)(T + 1) * 8},
+        {XGM_S_TERM_WORD, term_word.data(), (uint64_t)(T + 1) * 8},
+        {XGM_S_TERM_POS, term_pos.data(), (uint64_t)(T + 1) * 8},
+        {XGM_S_BLK_FIRST, blk_first.data(), blk_first.size() * 4},
+        {XGM_S_BLK_META, blk_meta.data(), blk_meta.size() * 4},
+        {XGM_S_BLK_WORD, blk_word.data(), blk_word.size() * 4},
+        {XGM_S_BLK_POS, blk_pos.data(), blk_pos.size() * 4},
+        {XGM_S_WORDS, words.data(), words.size() * 4},
+        {XGM_S_POSITIONS, positions.data(), positions.size() * 4},
+        {XGM_S_STR_OFF, str_off.data(), (uint64_t)(T + 1) * 8},
+        {XGM_S_STR_BYTES, str_bytes.data(), str_bytes.size()},
+    };
+    uint64_t off = align_up(sizeof h);
+    for (const Sec& s : secs) {
+        h.sec_off[s.id] = off;
+        h.sec_bytes[s.id] = s.bytes;
+        off = align_up(off + s.bytes);
+    }
+    h.file_bytes = off;
+    out->bytes.assign(off, 0);
+    memcpy(out->bytes.data(), &h, sizeof h);
+    for (const Sec& s : secs)
+        if (s.bytes) memcpy(out->bytes.data() + h.sec_off[s.id], s.p, s.bytes);
+    return XGM_OK;
+}
+
+int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vector<const char*>* term_ptrs,
+                      std::vector<uint32_t>* term_lens, xgm_raw_postings* raw) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", path, strerror(errno));
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    storage->resize((size_t)sz);
+    size_t got = fread(storage->data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) return xgm_set_error(XGM_E_IO, "short read on %s", path);
+    const uint8_t* p = storage->data();
+    const uint8_t* e = p + sz;
+    auto pad8 = [](uint64_t n) { return (n + 7) / 8 * 8; };
+    if (sz < 64 || memcmp(p, "XGMRAW1", 8) != 0) return xgm_set_error(XGM_E_INVALID, "%s is not an XGMRAW1 file", path);
+    memset(raw, 0, sizeof *raw);
+    uint64_t str_total;
+    memcpy(&raw->n_terms, p + 8, 4);
+    memcpy(&raw->lastdocid, p + 12, 4);
+    memcpy(&raw->doccount, p + 16, 4);
+    memcpy(&raw->has_positions, p + 20, 4);
+    memcpy(&raw->total_length, p + 24, 8);
+    memcpy(&raw->n_postings, p + 32, 8);
+    memcpy(&raw->n_positions, p + 40, 8);
+    memcpy(&raw->revision, p + 48, 8);
+    memcpy(&str_total, p + 56, 8);
+    p += 64;
+    uint64_t need = pad8(((uint64_t)raw->lastdocid + 1) * 4) + pad8((uint64_t)raw->n_terms * 4) * 2 +
+                    pad8(raw->n_postings * 4) * 2 + str_total +
+                    (raw->has_positions ? (raw->n_postings + 1) * 8 + pad8(raw->n_positions * 4) : 0);
+    if ((uint64_t)(e - p) < need) return xgm_set_error(XGM_E_INVALID, "raw file %s truncated", path);
+    raw->doclen = reinterpret_cast<const uint32_t*>(p); p += pad8(((uint64_t)raw->lastdocid + 1) * 4);
+    raw->df = reinterpret_cast<const uint32_t*>(p); p += pad8((uint64_t)raw->n_terms * 4);
+    raw->did = reinterpret_cast<const uint32_t*>(p); p += pad8(raw->n_postings * 4);
+    raw->wdf = reinterpret_cast<const uint32_t*>(p); p += pad8(raw->n_postings * 4);
+    if (raw->has_positions) {
+        raw->pos_off = reinterpret_cast<const uint64_t*>(p); p += (raw->n_postings + 1) * 8;
+        raw->pos = reinterpret_cast<const uint32_t*>(p); p += pad8(raw->n_positions * 4);
+    }
+    const uint32_t* lens = reinterpret_cast<const uint32_t*>(p); p += pad8((uint64_t)raw->n_terms * 4);
+    term_ptrs->resize(raw->n_terms);
+    term_lens->assign(lens, lens + raw->n_terms);
+    uint64_t o = 0;
+    for (uint32_t t = 0; t < raw->n_terms; ++t) {
+        (*term_ptrs)[t] = reinterpret_cast<const char*>(p + o);
+        o += lens[t];
+    }
+    if (o != str_total) return xgm_set_error(XGM_E_INVALID, "raw file %s: term bytes mismatch", path);
+    raw->terms = term_ptrs->data();
+    raw->term_len = term_lens->data();
+    return XGM_OK;
+}
+
+static int write_blob(const XgmSegmentBlob& blob, const char* path) {
+    FILE* f = fopen(path, "wb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s: %s", path, strerror(errno));
+    size_t w = fwrite(blob.bytes.data(), 1, blob.bytes.size(), f);
+    int rc = fclose(f);
+    if (w != blob.bytes.size() || rc != 0) return xgm_set_error(XGM_E_IO, "short write on %s", path);
+    return XGM_OK;
+}
+
+extern "C" int xgm_segment_build(const xgm_raw_postings* raw, uint32_t stripe_bits, const char* out_path) {
+    XgmSegmentBlob blob;
+    int rc = xgm_build_segment_blob(raw, stripe_bits, &blob);
+    if (rc) return rc;
+    return write_blob(blob, out_path);
+}
+
+extern "C" int xgm_segment_build_from_file(const char* raw_path, uint32_t stripe_bits, const char* out_path) {
+    std::vector<uint8_t> storage;
+    std::vector<const char*> tp;
+    std::vector<uint32_t> tl;
+    xgm_raw_postings raw;
+    int rc = xgm_read_raw_file(raw_path, &storage, &tp, &tl, &raw);
+    if (rc) return rc;
+    return xgm_segment_build(&raw, stripe_bits, out_path);
+}
+
+static int read_whole(const char* path, std::vector<uint8_t>* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", path, strerror(errno));
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    out->resize((size_t)sz);
+    size_t got = fread(out->data(), 1, (size_t)sz, f);
+    fclose(f);
+    if (got != (size_t)sz) return xgm_set_error(XGM_E_IO, "short read on %s", path);
+    return XGM_OK;
+}
+
+int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob) {
+    int rc = read_whole(path, &blob->bytes);
+    if (rc) return rc;
+    if (blob->bytes.size() < sizeof(xgm_seg_header)) return xgm_set_error(XGM_E_INVALID, "%s too small", path);
+    return xgm_validate_header(blob->header(), blob->bytes.size());
+}
+
+static uint32_t get_bits(const uint32_t* w, uint32_t i, uint32_t bw) {
+    if (!bw) return 0;
+    uint64_t bit = (uint64_t)i * bw;
+    const uint32_t* p = w + (bit >> 5);
+    uint64_t v = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
+    return (uint32_t)((v >> (bit & 31)) & ((bw == 32) ? 0xFFFFFFFFull : ((1ull << bw) - 1)));
+}
+
+extern "C" int64_t xgm_segment_decode_term(const char* segment_path, const char* term, size_t len, uint32_t* did,
+                                           uint32_t* wdf, uint64_t cap) {
+    XgmSegmentBlob blob;
+    int rc = xgm_read_segment_file(segment_path, &blob);
+    if (rc) return rc;
+    const xgm_seg_header* h = blob.header();
+    const uint64_t* so = blob.section<uint64_t>(XGM_S_STR_OFF);
+    const char* sb = blob.section<char>(XGM_S_STR_BYTES);
+    uint32_t lo = 0, hi = h->n_terms;
+    while (lo < hi) {
+        uint32_t mid = lo + (hi - lo) / 2;
+        size_t ml = (size_t)(so[mid + 1] - so[mid]);
+        int c = memcmp(sb + so[mid], term, std::min(ml, len));
+        if (c < 0 || (c == 0 && ml < len)) lo = mid + 1; else hi = mid;
+    }
+    if (lo == h->n_terms || (size_t)(so[lo + 1] - so[lo]) != len || memcmp(sb + so[lo], term, len) != 0) return 0;
+    const uint64_t* tb = blob.section<uint64_t>(XGM_S_TERM_BLK);
+    const uint64_t* tw = blob.section<uint64_t>(XGM_S_TERM_WORD);
+    const uint32_t* bf = blob.section<uint32_t>(XGM_S_BLK_FIRST);
+    const uint32_t* bm = blob.section<uint32_t>(XGM_S_BLK_META);
+    const uint32_t* bwd = blob.section<uint32_t>(XGM_S_BLK_WORD);
+    const uint32_t* words = blob.section<uint32_t>(XGM_S_WORDS);
+    uint64_t n = 0;
+    for (uint64_t b = tb[lo]; b < tb[lo + 1]; ++b) {
+        uint32_t cnt = XGM_META_COUNT(bm[b]), bwg = XGM_META_BWG(bm[b]), bww = XGM_META_BWW(bm[b]);
+        const uint32_t* gw = words + tw[lo] + bwd[b];
+        const uint32_t* ww = gw + ((uint64_t)cnt * bwg + 31) / 32;
+        uint32_t d = bf[b];
+        for (uint32_t j = 0; j < cnt; ++j) {
+            if (j) d += get_bits(gw, j, bwg) + 1;
+            if (n < cap) { did[n] = d; wdf[n] = get_bits(ww, j, bww); }
+            ++n;
+        }
+    }
+    return (int64_t)n;
+}

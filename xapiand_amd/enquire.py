@@ -1,0 +1,353 @@
+"""Host-side mirror of the reference surface for the match/rank path.
+
+Names, argument meaning and error behaviour follow Xapian's (reference src/xapian/query.h,
+enquire.h, mset.h) so the parity tests read like Xapian code:
+
+    db = Database("shard0.seg")                       # ~ Xapian::Database(path)
+    enq = Enquire(db)                                 # ~ Xapian::Enquire enq(db)
+    enq.set_query(Query(Query.OP_AND, ["t1", "t5"]))  # ~ enq.set_query(Xapian::Query(OP_AND, ...))
+    mset = enq.get_mset(0, 10)                        # ~ enq.get_mset(first, maxitems)
+    for item in mset: item.docid, item.weight, item.rank, item.percent
+
+Everything below the method signatures goes through the C ABI (include/xgm.h) to the HIP kernels.
+Query shapes the device path declines raise `Unsupported` — in Xapiand the hook would simply let the
+CPU matcher run; this package has no CPU matcher.
+"""
+import ctypes as C
+import sys
+
+from . import _lib
+from ._lib import XgmError, XgmUnsupported as Unsupported  # noqa: F401  (re-exported)
+
+DBL_EPSILON = sys.float_info.epsilon
+
+
+class Query:
+    """Subset of Xapian::Query (reference src/xapian/query.h:48-): a term, or AND/OR/PHRASE of terms."""
+    OP_AND, OP_OR, OP_PHRASE = "AND", "OR", "PHRASE"
+    LEAF_TERM = "TERM"
+    _OPS = {OP_AND: _lib.XGM_OP_AND, OP_OR: _lib.XGM_OP_OR, OP_PHRASE: _lib.XGM_OP_PHRASE}
+
+    def __init__(self, op_or_term, subqueries=None, window=0):
+        if subqueries is None:
+            self.op = Query.LEAF_TERM
+            self.terms = [_as_bytes(op_or_term)]
+            self.window = 0
+            return
+        if op_or_term not in Query._OPS:
+            raise ValueError("unsupported query operator %r" % (op_or_term,))
+        terms = []
+        for s in subqueries:
+            if isinstance(s, Query):
+                if s.op != Query.LEAF_TERM:
+                    raise Unsupported("nested operators are not handled by the device path")
+                terms.append(s.terms[0])
+            else:
+                terms.append(_as_bytes(s))
+        if not terms:
+            raise ValueError("empty query")
+        self.op = op_or_term
+        self.terms = terms
+        self.window = window
+
+    def get_type(self):
+        return self.op
+
+    def get_num_subqueries(self):
+        return 0 if self.op == Query.LEAF_TERM else len(self.terms)
+
+    def empty(self):
+        return not self.terms
+
+    def get_description(self):
+        if self.op == Query.LEAF_TERM:
+            return "Query(%s)" % self.terms[0].decode("utf-8", "replace")
+        sep = {"AND": " AND ", "OR": " OR ", "PHRASE": " PHRASE %d " % (self.window or len(self.terms))}[self.op]
+        return "Query((" + sep.join(t.decode("utf-8", "replace") for t in self.terms) + "))"
+
+
+def _as_bytes(t):
+    return t if isinstance(t, bytes) else str(t).encode("utf-8")
+
+
+class BM25Weight:
+    """Parameters of Xapian::BM25Weight (reference src/xapian/weight.h:635-667 defaults)."""
+
+    def __init__(self, k1=1.0, k2=0.0, k3=1.0, b=0.5, min_normlen=0.5):
+        self.k1, self.k2, self.k3, self.b, self.min_normlen = k1, k2, k3, b, min_normlen
+
+    def name(self):
+        return "Xapian::BM25Weight"
+
+
+class Database:
+    """A device-resident shard: one XGMSEG1 segment loaded into HBM (or built there)."""
+
+    def __init__(self, path=None, device=0, revision=None, _handle=None):
+        self._h = C.c_void_p()
+        if _handle is not None:
+            self._h = _handle
+        else:
+            rev = _lib.UINT64_MAX if revision is None else revision
+            _lib.check(_lib.lib().xgm_index_open(_as_bytes(path), device, rev, C.byref(self._h)))
+        self._info = _lib.IndexInfo()
+        _lib.check(_lib.lib().xgm_index_get_info(self._h, C.byref(self._info)))
+
+    @classmethod
+    def synthetic(cls, seed, n_docs_global, vocab, len_lo=50, len_hi=150, n_shards=1, shard=0, device=0,
+                  stripe_bits=0, with_positions=True):
+        """Build the synthetic corpus shard (tools/xgm_corpus.h) directly in HBM with the GPU builder."""
+        p = _lib.SynthParams(seed, vocab, len_lo, len_hi, n_docs_global, n_shards, shard, stripe_bits,
+                             1 if with_positions else 0)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().xgm_index_build_synthetic(C.byref(p), device, C.byref(h)))
+        return cls(_handle=h)
+
+    def close(self):
+        if self._h:
+            _lib.lib().xgm_index_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- Xapian::Database accessors -------------------------------------------------------------
+    def get_doccount(self):
+        return self._info.doccount
+
+    def get_lastdocid(self):
+        return self._info.lastdocid
+
+    def get_total_length(self):
+        return self._info.total_length
+
+    def get_average_length(self):
+        return self._info.total_length / self._info.doccount if self._info.doccount else 0.0
+
+    def has_positions(self):
+        return bool(self._info.has_positions)
+
+    def get_revision(self):
+        return self._info.revision
+
+    def info(self):
+        return self._info
+
+    def get_termfreq(self, term):
+        tf = C.c_uint32()
+        t = _as_bytes(term)
+        _lib.check(_lib.lib().xgm_lookup_term(self._h, t, len(t), None, C.byref(tf), None, None))
+        return tf.value
+
+    def get_collection_freq(self, term):
+        cf = C.c_uint32()
+        t = _as_bytes(term)
+        _lib.check(_lib.lib().xgm_lookup_term(self._h, t, len(t), None, None, C.byref(cf), None))
+        return cf.value
+
+    def get_wdf_upper_bound(self, term):
+        ub = C.c_uint32()
+        t = _as_bytes(term)
+        _lib.check(_lib.lib().xgm_lookup_term(self._h, t, len(t), None, None, None, C.byref(ub)))
+        return ub.value
+
+    def save(self, path):
+        _lib.check(_lib.lib().xgm_index_save(self._h, _as_bytes(path)))
+
+    def set_stream(self, hip_stream):
+        _lib.check(_lib.lib().xgm_index_set_stream(self._h, C.c_void_p(hip_stream)))
+
+    def set_profiling(self, on):
+        _lib.check(_lib.lib().xgm_index_set_profiling(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        return _lib.lib().xgm_last_kernel_ms(self._h)
+
+
+class MSetItem:
+    __slots__ = ("docid", "weight", "rank", "percent", "subqs_matched")
+
+    def __init__(self, docid, weight, rank, percent, subqs_matched):
+        self.docid, self.weight, self.rank, self.percent, self.subqs_matched = docid, weight, rank, percent, subqs_matched
+
+    def __repr__(self):
+        return "MSetItem(rank=%d, docid=%d, weight=%r, percent=%d)" % (self.rank, self.docid, self.weight, self.percent)
+
+
+class MSet:
+    """Mirror of Xapian::MSet for the fields the path produces.  matches_* are EXACT here (the
+    reference estimates them, protomset.h:497-619) — documented parity exception."""
+
+    def __init__(self, first, hits, hdr, total_subqs):
+        self._first = first
+        # MSet::Internal percent_scale_factor, protomset.h:466-471 and :682
+        if hdr.n_hits and hdr.max_attained != 0.0 and total_subqs:
+            scale = hdr.max_weight_subqs_matched / float(total_subqs)
+            scale /= hdr.max_attained
+            self._percent_scale_factor = scale * 100.0
+        else:
+            self._percent_scale_factor = 0.0
+        self._items = []
+        for rank, h in enumerate(hits):
+            if rank < first:
+                continue
+            self._items.append(MSetItem(h.docid, h.weight, rank, self.convert_to_percent(h.weight), h.subqs_matched))
+        self._matches = hdr.matches_exact
+        self._max_possible = hdr.max_possible
+        self._max_attained = hdr.max_attained
+
+    def convert_to_percent(self, weight):
+        """MSet::Internal::convert_to_percent, reference src/xapian/api/mset.cc:334-362."""
+        if self._percent_scale_factor == 0.0:
+            return 100
+        if weight <= 0.0:
+            return 0
+        percent = int(weight * self._percent_scale_factor + 100.0 * DBL_EPSILON)
+        if percent <= 0:
+            return 1
+        return min(percent, 100)
+
+    def size(self):
+        return len(self._items)
+
+    def __len__(self):
+        return len(self._items)
+
+    def __iter__(self):
+        return iter(self._items)
+
+    def __getitem__(self, i):
+        return self._items[i]
+
+    def get_firstitem(self):
+        return self._first
+
+    def get_matches_estimated(self):
+        return self._matches
+
+    get_matches_lower_bound = get_matches_estimated
+    get_matches_upper_bound = get_matches_estimated
+
+    def get_max_possible(self):
+        return self._max_possible
+
+    def get_max_attained(self):
+        return self._max_attained
+
+
+def _desc(query, first, maxitems, check_at_least, weight):
+    n = len(query.terms)
+    d = _lib.QueryDesc()
+    if query.op == Query.LEAF_TERM:
+        d.op = _lib.XGM_OP_AND
+    else:
+        d.op = Query._OPS[query.op]
+    if n > _lib.XGM_MAX_TERMS:
+        raise Unsupported("too many terms")
+    d.n_terms = n
+    for i, t in enumerate(query.terms):
+        d.terms[i] = t
+        d.term_len[i] = len(t)
+    d.window = query.window
+    d.first, d.maxitems, d.check_at_least = first, maxitems, check_at_least
+    d.k1, d.k2, d.k3, d.b, d.min_normlen = weight.k1, weight.k2, weight.k3, weight.b, weight.min_normlen
+    return d
+
+
+def plan(db, query, first, maxitems, check_at_least=0, weight=None, global_stats=None):
+    """xgm_plan_query: lower a Query against one shard (optionally with merged statistics)."""
+    weight = weight or BM25Weight()
+    d = _desc(query, first, maxitems, check_at_least, weight)
+    q = _lib.Query()
+    gs = C.byref(global_stats) if global_stats is not None else None
+    _lib.check(_lib.lib().xgm_plan_query(db._h, C.byref(d), gs, C.byref(q)))
+    q._keepalive = d
+    return q
+
+
+def search_batch(db, plans):
+    """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
+    nq = len(plans)
+    if nq == 0:
+        return []
+    k_stride = max(1, max(p.first + p.maxitems for p in plans))
+    qs = (_lib.Query * nq)(*plans)
+    hits = (_lib.Hit * (nq * k_stride))()
+    hdrs = (_lib.ResultHdr * nq)()
+    _lib.check(_lib.lib().xgm_search_batch(db._h, qs, nq, k_stride, hits, hdrs))
+    out = []
+    for i in range(nq):
+        n = hdrs[i].n_hits
+        out.append(([hits[i * k_stride + j] for j in range(n)], hdrs[i]))
+    return out
+
+
+class Enquire:
+    """Mirror of Xapian::Enquire for relevance-ordered BM25 searches on one shard."""
+
+    def __init__(self, db):
+        self._db = db
+        self._query = None
+        self._weight = BM25Weight()
+
+    def set_query(self, query):
+        self._query = query
+
+    def get_query(self):
+        return self._query
+
+    def set_weighting_scheme(self, weight):
+        if not isinstance(weight, BM25Weight):
+            raise Unsupported("only BM25Weight runs on the device path")
+        self._weight = weight
+
+    def get_mset(self, first, maxitems, check_at_least=0):
+        """Enquire::get_mset (reference src/xapian/api/enquire.cc:237, 396-470)."""
+        if self._query is None or self._query.empty():
+            return MSet(first, [], _lib.ResultHdr(), 0)
+        p = plan(self._db, self._query, first, maxitems, check_at_least, self._weight)
+        (hits, hdr), = search_batch(self._db, [p])
+        return MSet(p.first, hits, hdr, len(self._query.terms))
+
+
+def merged_stats(dbs, query):
+    """What Enquire::add_prepared_mset accumulates over the shards (enquire.cc:385-394,
+    weightinternal.cc:55-71): Σ total_length, Σ doccount, Σ termfreq per query term."""
+    gs = _lib.GlobalStats()
+    gs.total_length = sum(db.get_total_length() for db in dbs)
+    gs.collection_size = sum(db.get_doccount() for db in dbs)
+    gs.full_db_has_positions = 1 if any(db.has_positions() for db in dbs) else 0
+    for i, t in enumerate(query.terms):
+        gs.termfreq[i] = sum(db.get_termfreq(t) for db in dbs)
+    return gs
+
+
+def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None):
+    """Xapiand's per-shard protocol (reference src/database/handler.cc:1485-1549) with every shard
+    on the local device(s): merged stats → per-shard search for first+maxitems → unshard + merge
+    (host side here; the multi-GPU path does the same merge on device after the RCCL all-gather)."""
+    gs = merged_stats(dbs, query)
+    per = []
+    for db in dbs:
+        p = plan(db, query, 0, first + maxitems, check_at_least, weight, gs)
+        (hits, hdr), = search_batch(db, [p])
+        per.append((hits, hdr))
+    n_shards = len(dbs)
+    allhits = []
+    hdr = _lib.ResultHdr()
+    for s, (hits, h) in enumerate(per):
+        for x in hits:
+            g = _lib.Hit((x.docid - 1) * n_shards + s + 1, x.subqs_matched, x.weight)
+            allhits.append(g)
+        hdr.matches_exact += h.matches_exact
+        hdr.max_possible = max(hdr.max_possible, h.max_possible)
+        if h.max_attained > hdr.max_attained:
+            hdr.max_attained = h.max_attained
+            hdr.max_weight_subqs_matched = h.max_weight_subqs_matched
+    allhits.sort(key=lambda x: (-x.weight, x.docid))
+    allhits = allhits[: first + maxitems]
+    hdr.n_hits = len(allhits)
+    return MSet(first, allhits, hdr, len(query.terms))
