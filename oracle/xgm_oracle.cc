@@ -532,7 +532,9 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
         last_subqs = subqs;
         return val[root];
     };
+    uint64_t true_matches = 0;      /* every matching document, pruned or not (the reference only estimates this) */
     auto score = [&](uint32_t did) {
+        ++true_matches;
         double w = weigh(did);
         if (w < pm.min_weight) { return; }                    /* matcher.cc:496-498 */
         pm.add(Hit{did, last_subqs, w});
@@ -593,6 +595,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
             if (ok) {
                 if (cached_weight >= 0) {
                     /* SelectPostList::get_weight returns the cached value (selectpostlist.cc:48-55) */
+                    ++true_matches;
                     weigh(did);
                     if (!(cached_weight < pm.min_weight)) pm.add(Hit{did, last_subqs, cached_weight});
                 } else {
@@ -604,7 +607,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     }
     pm.finalise();
     out->hits = pm.results;
-    out->matches = pm.known_matching_docs;
+    out->matches = true_matches;
     out->max_attained = pm.results.empty() ? 0.0 : pm.results[0].weight;
     out->max_subqs = pm.results.empty() ? 0 : pm.results[0].subqs;
     return 0;

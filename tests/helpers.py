@@ -278,3 +278,56 @@ def gen_phrase_queries(n_queries, n_docs_global, vocab, len_lo=50, len_hi=150, c
         qs.append(dict(op="PHRASE", terms=["t%d" % r for r in gram], first=0, maxitems=maxitems,
                        window=(n + window_extra) if window_extra else 0))
     return qs
+
+
+class ManualCorpus(Corpus):
+    """Hand-made postings: {term: [(docid, wdf, [positions...]), ...]} plus doc lengths.  Same
+    interface as Corpus so it can feed both the oracle and the segment builder."""
+
+    def __init__(self, postings, doclen, positions=True):
+        terms = sorted((t if isinstance(t, bytes) else t.encode()) for t in postings)
+        by = {(t if isinstance(t, bytes) else t.encode()): v for t, v in postings.items()}
+        lastdocid = max(doclen) if doclen else 0
+        self._doclen = np.zeros(lastdocid + 1, dtype=np.uint32)
+        for d, l in doclen.items():
+            self._doclen[d] = l
+        df, did, wdf, pos_off, pos = [], [], [], [0], []
+        for t in terms:
+            plist = sorted(by[t])
+            df.append(len(plist))
+            for p in plist:
+                did.append(p[0]); wdf.append(p[1])
+                pp = list(p[2]) if len(p) > 2 and p[2] is not None else []
+                pos += pp
+                pos_off.append(len(pos))
+        self._df = np.array(df, dtype=np.uint32)
+        self._did = np.array(did, dtype=np.uint32)
+        self._wdf = np.array(wdf, dtype=np.uint32)
+        self._pos_off = np.array(pos_off, dtype=np.uint64)
+        self._pos = np.array(pos if pos else [0], dtype=np.uint32)
+        self._term_len = np.array([len(t) for t in terms], dtype=np.uint32)
+        self._terms = (C.c_char_p * len(terms))(*terms)
+        self._term_bytes = terms
+        v = CorpusView()
+        v.n_terms, v.lastdocid = len(terms), lastdocid
+        v.doccount = int((self._doclen > 0).sum())
+        v.has_positions = 1 if positions else 0
+        v.total_length = int(self._doclen.sum())
+        v.n_postings, v.n_positions = len(did), len(pos)
+        u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+        v.doclen = self._doclen.ctypes.data_as(u32p)
+        v.terms = C.cast(self._terms, C.POINTER(C.c_char_p))
+        v.term_len = self._term_len.ctypes.data_as(u32p)
+        v.df = self._df.ctypes.data_as(u32p)
+        v.did = self._did.ctypes.data_as(u32p)
+        v.wdf = self._wdf.ctypes.data_as(u32p)
+        if positions:
+            v.pos_off = self._pos_off.ctypes.data_as(u64p)
+            v.pos = self._pos.ctypes.data_as(u32p)
+        self.v = v
+        self._h = None
+        self._oidx = None
+        self.params = None
+
+    def terms(self):
+        return list(self._term_bytes)

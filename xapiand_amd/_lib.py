@@ -126,6 +126,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libxgm.so is not built: run `python -m xapiand_amd.build` (or __graft_entry__.build())")
+        # A process must hold ONE HIP runtime.  PyTorch bundles its own libamdhip64.so (soname
+        # libamdhip64.so.7, the same as /opt/rocm's): when torch is going to be used in this process
+        # (device tensors, RCCL), it has to be loaded first so libxgm.so binds to that copy instead of
+        # pulling in a second runtime that cannot see the GPU.  A C++ host without torch just gets
+        # /opt/rocm's runtime through libxgm.so's RUNPATH.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, res, args in _API:
             fn = getattr(l, name)       # AttributeError if the ABI symbol is missing
