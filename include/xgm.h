@@ -243,9 +243,10 @@ int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_al
                             uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* k,
                             void* d_out_hits, void* d_out_hdrs);
 
-/* Milliseconds spent in the dominant kernel (xgm_match_kernel) by the last xgm_search* call on this
- * index from this thread, measured with hipEvents on the launch stream; < 0 if profiling is off.
- * Enable with xgm_index_set_profiling(idx, 1) (adds two events per call). */
+/* Kernel timing with HIP events on the launch stream.  xgm_index_set_profiling(idx, 1) makes every
+ * later xgm_search* call record an event pair around the dominant kernel (xgm_match_kernel) without
+ * synchronising; xgm_last_kernel_ms waits for the recorded launches, returns their MEAN duration in
+ * milliseconds (< 0 if none) and starts a new window. */
 int xgm_index_set_profiling(xgm_index*, int on);
 double xgm_last_kernel_ms(const xgm_index*);
 
@@ -257,6 +258,9 @@ uint64_t xgm_query_postings_bytes(const xgm_index*, const xgm_query*);
 /* Diagnostics: decode one term's whole posting list on the DEVICE (kernel K1 alone) into host
  * arrays; returns df or < 0.  Used to verify a segment against its source postings. */
 int64_t xgm_debug_decode_term_device(xgm_index*, uint32_t term_id, uint32_t* did, uint32_t* wdf, uint64_t cap);
+
+/* Diagnostics: copy the dense doclen array (u32[lastdocid+1]) to the host; returns its length. */
+int64_t xgm_debug_read_doclen(xgm_index*, uint32_t* out, uint64_t cap);
 
 const char* xgm_last_error(void);
 const char* xgm_version(void);

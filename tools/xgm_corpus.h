@@ -61,7 +61,6 @@ XGM_HD static inline uint32_t xgm_token(const xgm_corpus_params* p, const uint64
     return xgm_zipf_rank(thresholds, p->vocab, xgm_hash3(p->seed, g, pos));
 }
 
-#ifndef __HIP_DEVICE_COMPILE__
 /* Host-only: fill thresholds[0..V-1].  Sequential double summation of 1/r: only IEEE add and
  * divide, so every host computes the same table. */
 static inline void xgm_zipf_thresholds(uint32_t vocab, uint64_t* thresholds) {
@@ -79,6 +78,5 @@ static inline void xgm_zipf_thresholds(uint32_t vocab, uint64_t* thresholds) {
         thresholds[r - 1] = (hi_i << 32) | (uint64_t)lo;
     }
 }
-#endif
 
 #endif /* XGM_CORPUS_H */

@@ -193,6 +193,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     hipSetDevice(idx->device);
     hipDeviceSynchronize();
     for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
+    for (auto& pr : idx->prof_events) { hipEventDestroy((hipEvent_t)pr.first); hipEventDestroy((hipEvent_t)pr.second); }
     if (idx->sections_owned) {
         for (int s = 0; s < XGM_S_COUNT; ++s) if (idx->d_sections[s]) hipFree(idx->d_sections[s]);
     }
@@ -246,12 +247,29 @@ extern "C" int xgm_index_set_stream(xgm_index* idx, void* hip_stream) {
 
 extern "C" int xgm_index_set_profiling(xgm_index* idx, int on) {
     if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(idx->scratch_mu);
     idx->profiling = on != 0;
+    idx->prof_used = 0;
     return XGM_OK;
 }
 
-static thread_local double g_last_kernel_ms = -1.0;
-extern "C" double xgm_last_kernel_ms(const xgm_index*) { return g_last_kernel_ms; }
+/* Mean duration of the match kernel over the launches recorded since profiling was switched on (or
+ * since the previous collection); waits for the last of them, then starts a new window. */
+extern "C" double xgm_last_kernel_ms(const xgm_index* cidx) {
+    xgm_index* idx = const_cast<xgm_index*>(cidx);
+    if (!idx) return -1.0;
+    std::lock_guard<std::mutex> lk(idx->scratch_mu);
+    if (idx->prof_used == 0) return -1.0;
+    double sum = 0.0;
+    size_t n = 0;
+    for (size_t i = 0; i < idx->prof_used; ++i) {
+        hipEvent_t a = (hipEvent_t)idx->prof_events[i].first, b = (hipEvent_t)idx->prof_events[i].second;
+        float ms = 0.f;
+        if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) { sum += ms; ++n; }
+    }
+    idx->prof_used = 0;
+    return n ? sum / (double)n : -1.0;
+}
 
 /* ------------------------------------------------------------------ dictionary --------------- */
 
@@ -433,9 +451,22 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
     L.phrase = bp.phrase; L.wide = bp.wide;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
-    if (idx->profiling) HIP_TRY(hipEventRecord(s->ev0, stream));
+    hipEvent_t pe0 = nullptr, pe1 = nullptr;
+    if (idx->profiling) {
+        std::lock_guard<std::mutex> lk(idx->scratch_mu);
+        if (idx->prof_used == idx->prof_events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            idx->prof_events.push_back({a, b});
+        }
+        pe0 = (hipEvent_t)idx->prof_events[idx->prof_used].first;
+        pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
+        ++idx->prof_used;
+    }
+    if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
     if ((rc = xgm_launch_match(L, stream))) return rc;
-    if (idx->profiling) HIP_TRY(hipEventRecord(s->ev1, stream));
+    if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, bp.n_groups, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
                                d_hdrs, s->d_maxposs, stream)))
         return rc;
@@ -469,10 +500,6 @@ extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq
         /* only the valid prefix of each row is defined on the device */
         for (uint32_t i = 0; i < nq; ++i)
             memcpy(hits + (size_t)i * k_stride, h_hits + (size_t)i * k_stride, (size_t)h_hdrs[i].n_hits * sizeof(xgm_hit));
-        if (idx->profiling) {
-            float ms = -1.f;
-            if (hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) g_last_kernel_ms = ms;
-        }
     } while (0);
     scratch_release(idx, s);
     return rc;
@@ -494,10 +521,6 @@ extern "C" int xgm_search_batch_device(xgm_index* idx, const xgm_query* qs, uint
     if ((rc = scratch_acquire(idx, &s))) return rc;
     hipStream_t stream = pick_stream(idx, s);
     rc = run_batch(idx, s, stream, qs, nq, k_stride, (xgm_hit*)d_hits, (xgm_result_hdr*)d_hdrs);
-    if (rc == XGM_OK && idx->profiling) {
-        float ms = -1.f;
-        if (hipEventSynchronize(s->ev1) == hipSuccess && hipEventElapsedTime(&ms, s->ev0, s->ev1) == hipSuccess) g_last_kernel_ms = ms;
-    }
     /* the scratch (queries, candidates) is still in use by the enqueued kernels: mark it pending so
      * the next acquire waits for them. */
     if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
@@ -575,4 +598,15 @@ extern "C" int64_t xgm_debug_decode_term_device(xgm_index* idx, uint32_t term_id
     }
     hipFree(d_ord); hipFree(d_did); hipFree(d_wdf);
     return rc ? rc : (int64_t)df;
+}
+
+/* Copy the dense doclen array (entry d = length of docid d, entry 0 unused) to the host. */
+extern "C" int64_t xgm_debug_read_doclen(xgm_index* idx, uint32_t* out, uint64_t cap) {
+    if (!idx || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    uint64_t n = (uint64_t)idx->hdr.lastdocid + 1;
+    if (cap < n) return xgm_set_error(XGM_E_INVALID, "buffer too small");
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, idx->d_sections[XGM_S_DOCLEN], n * 4, hipMemcpyDeviceToHost));
+    return (int64_t)n;
 }

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/xgm.h"
@@ -47,6 +48,8 @@ struct xgm_index {
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
+    std::vector<std::pair<void*, void*>> prof_events;   /* hipEvent_t pairs around the match kernel */
+    size_t prof_used = 0;
     std::mutex scratch_mu;
     std::vector<XgmScratch*> scratch_pool;
 };
