@@ -31,7 +31,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from xapiand_amd import Database, Query, _lib, plan  # noqa: E402
+from xapiand_amd import Database, Query, _lib  # noqa: E402
+from xapiand_amd.distributed import ShardedSearcher  # noqa: E402
 
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 CORPUS_SEED = 0x5EED0001
@@ -89,46 +90,21 @@ def main():
     info = db.info()
     db.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards) -------------------
+    # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards): one all-reduce ----
     pool = gen_queries(1100, args.terms, 8, 4096, QUERY_SEED)
-    vocab_terms = sorted({t for q in pool for t in q})
-    tf_local = torch.tensor([db.get_termfreq(t) for t in vocab_terms], dtype=torch.int64, device=dev)
-    coll = torch.tensor([info.total_length, info.doccount, info.has_positions], dtype=torch.int64, device=dev)
-    if world > 1:
-        dist.all_reduce(tf_local)
-        dist.all_reduce(coll)
-    tf_global = dict(zip(vocab_terms, tf_local.tolist()))
-    total_length, collection_size, any_pos = coll.tolist()
     k = args.topk
-    plans = []
-    for terms in pool:
-        gs = _lib.GlobalStats()
-        gs.total_length, gs.collection_size, gs.full_db_has_positions = total_length, collection_size, 1 if any_pos else 0
-        for i, t in enumerate(terms):
-            gs.termfreq[i] = tf_global[t]
-        plans.append(plan(db, Query(args.op, terms), 0, k, global_stats=gs))
+    searcher = ShardedSearcher(db, rank, world, dev)
+    plans = searcher.prepare([Query(args.op, terms) for terms in pool], 0, k)
     warm_plans, timed_plans = plans[:100], plans[100:]
     n_batches = len(timed_plans) // BATCH
     batches = [(_lib.Query * BATCH)(*timed_plans[i * BATCH:(i + 1) * BATCH]) for i in range(n_batches)]
     warm_batch = (_lib.Query * BATCH)(*(warm_plans * 3)[:BATCH])
-
-    hits = torch.zeros((BATCH, k, 2), dtype=torch.float64, device=dev)
-    hdrs = torch.zeros((BATCH, 4), dtype=torch.float64, device=dev)
-    if world > 1:
-        all_hits = torch.zeros((world, BATCH, k, 2), dtype=torch.float64, device=dev)
-        all_hdrs = torch.zeros((world, BATCH, 4), dtype=torch.float64, device=dev)
-        out_hits = torch.zeros_like(hits)
-        out_hdrs = torch.zeros_like(hdrs)
-        ks = (C.c_uint32 * BATCH)(*([k] * BATCH))
     L = _lib.lib()
+    state = {}
 
     def step(batch):
-        _lib.check(L.xgm_search_batch_device(db._h, batch, BATCH, k, hits.data_ptr(), hdrs.data_ptr()))
-        if world > 1:
-            dist.all_gather_into_tensor(all_hits, hits)
-            dist.all_gather_into_tensor(all_hdrs, hdrs)
-            _lib.check(L.xgm_merge_shards_device(db._h, all_hits.data_ptr(), all_hdrs.data_ptr(), world, BATCH, k, ks,
-                                                 out_hits.data_ptr(), out_hdrs.data_ptr()))
+        # xgm_search_batch_device (+ RCCL all-gather of top-k + xgm_merge_shards_device when sharded)
+        state["hits"], state["hdrs"] = searcher.run_batch(batch, BATCH, k)
 
     for _ in range(args.warmup):
         step(warm_batch)
@@ -158,7 +134,7 @@ def main():
     for b in range(n_batches):
         step(batches[b])
         torch.cuda.synchronize()
-        h = hdrs.cpu().numpy().view(np.uint8).reshape(BATCH, 32)
+        h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
         matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in timed_plans[b * BATCH:(b + 1) * BATCH])
         alg_bytes.append(post + int(matches.sum()) * 4 + BATCH * k * 16)
