@@ -402,16 +402,18 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         return XGM_UNSUPPORTED;
     }
     bp->cap = std::max(512u, next_pow2(bp->k_max + XGM_WG));
-    const size_t smem = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide);
-    if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
     const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
     /* groups per query: fill the chip (~8 workgroups per CU across the batch), bounded by the merge
-     * kernel's LDS sort capacity */
+     * kernel's LDS sort capacity; a group's run table (8 B per term and stripe) must fit in LDS */
     uint32_t want = std::max(1u, 2048u / nq);
     uint32_t g_cap = std::max(1u, XGM_MERGE_CAP / next_pow2(bp->k_max));
     want = std::min(std::min(want, g_cap), n_stripes);
-    bp->stripes_per_group = (n_stripes + want - 1) / want;
+    const uint32_t spg_max = std::max(1u, (24u * 1024u) / (8u * bp->tab_terms));
+    bp->stripes_per_group = std::min((n_stripes + want - 1) / want, spg_max);
     bp->n_groups = (n_stripes + bp->stripes_per_group - 1) / bp->stripes_per_group;
+    if ((uint64_t)bp->n_groups * next_pow2(bp->k_max) > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
+    const size_t smem = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
+    if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
     bp->k_stride_c = bp->k_max;
     bp->merge_cap = std::max(512u, next_pow2(bp->n_groups * bp->k_max));
     return XGM_OK;

@@ -197,6 +197,7 @@ struct Ctrl {
 };
 
 struct KernelSmem {
+    uint32_t* runs;       /* [2][T][SPG]: block range of every (term, stripe) of the group */
     unsigned char* tab;   /* [T][W] of TabT */
     uint32_t* ptab;       /* [T][W] (phrase) */
     uint16_t* queue;      /* [W] */
@@ -206,7 +207,7 @@ struct KernelSmem {
 };
 
 template <typename TabT>
-__device__ __forceinline__ KernelSmem carve(unsigned char* smem, uint32_t W, uint32_t T, bool phrase, uint32_t cap) {
+__device__ __forceinline__ KernelSmem carve(unsigned char* smem, uint32_t W, uint32_t T, bool phrase, uint32_t cap, uint32_t spg) {
     KernelSmem s;
     size_t off = 0;
     s.tk.w = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)cap * 8;
@@ -217,6 +218,7 @@ __device__ __forceinline__ KernelSmem carve(unsigned char* smem, uint32_t W, uin
     s.tk.m = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)cap * 4;
     s.stage = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)XGM_WAVES * kStageWords * 4;
     s.queue = reinterpret_cast<uint16_t*>(smem + off); off += (size_t)W * 2;
+    s.runs = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 * T * spg * 4;
     s.tk.cap = cap;
     return s;
 }
@@ -292,6 +294,41 @@ __device__ bool phrase_window(const PosList* pl_plan, const uint8_t* pidx, uint3
 
 /* ---------------------------------------------------------------- the match kernel ----------- */
 
+struct __attribute__((packed, aligned(4))) Words4 { uint32_t a, b, c, d; };
+
+/* Unpack a staged block (payload already in the wave's LDS window). */
+template <bool WITH_POS>
+__device__ __forceinline__ DecodedPair unpack_staged(const uint32_t* stage, uint32_t first_did, uint32_t meta, uint32_t lane) {
+    const uint32_t n = XGM_META_COUNT(meta), bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta);
+    const uint32_t ngw = (n * bwg + 31u) >> 5;
+    DecodedPair r;
+    const uint32_t i0 = lane * 2u, i1 = i0 + 1u;
+    r.v0 = i0 < n;
+    r.v1 = i1 < n;
+    uint32_t g0 = (r.v0 && i0 > 0u) ? extract_bits(stage, i0, bwg) + 1u : 0u;
+    uint32_t g1 = r.v1 ? extract_bits(stage, i1, bwg) + 1u : 0u;
+    r.w0 = r.v0 ? extract_bits(stage + ngw, i0, bww) : 0u;
+    r.w1 = r.v1 ? extract_bits(stage + ngw, i1, bww) : 0u;
+    uint32_t local = g0 + g1;
+    uint32_t excl = wave_incl_scan(local) - local;
+    r.d0 = first_did + excl + g0;
+    r.d1 = r.d0 + g1;
+    if (WITH_POS) {
+        uint32_t lw = r.w0 + r.w1;
+        uint32_t pex = wave_incl_scan(lw) - lw;
+        r.p0 = pex;
+        r.p1 = pex + r.w0;
+    } else {
+        r.p0 = r.p1 = 0;
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t payload_words(uint32_t meta) {
+    const uint32_t n = XGM_META_COUNT(meta);
+    return ((n * XGM_META_BWG(meta) + 31u) >> 5) + ((n * XGM_META_BWW(meta) + 31u) >> 5) + 2u;   /* +2: window overrun */
+}
+
 template <typename TabT, bool PHRASE>
 __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                             uint32_t n_groups, uint32_t stripes_per_group,
@@ -310,19 +347,21 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     const bool is_or = (q.op == XGM_OP_OR);
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
     const uint32_t k = q.k;
+    const uint32_t SPG = stripes_per_group;
 
-    KernelSmem sm = carve<TabT>(smem, W, tab_terms, PHRASE, cap);
+    KernelSmem sm = carve<TabT>(smem, W, tab_terms, PHRASE, cap, SPG);
     Ctrl& ctl = *sm.ctrl;
     TabT* tab = reinterpret_cast<TabT*>(sm.tab);
     uint32_t* my_stage = sm.stage + wave * kStageWords;
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
-    const uint32_t s_begin = g * stripes_per_group;
-    uint32_t s_end = s_begin + stripes_per_group;
+    const uint32_t s_begin = g * SPG;
+    uint32_t s_end = s_begin + SPG;
     if (s_end > n_stripes) s_end = n_stripes;
 
-    /* ---- init: top-k buffer, cursors ---- */
+    /* ---- init: top-k buffer, the group's block ranges ---- */
     for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
     if (tid == 0) { ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; }
     const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
     if (!empty) {
@@ -339,40 +378,38 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     }
     __syncthreads();
 
-    unsigned long long my_matches = 0;
-    uint32_t target = s_begin;
-    while (!empty) {
-        /* ---- stripe selection: leapfrog (AND) / min (OR) over the terms' next stripes ---- */
-        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
-            uint32_t c = ctl.cur[t], e = ctl.end[t];
-            uint32_t id = q.term_id[t];
-            uint32_t st = kInfStripe, run = 0;
-            if (c < e) {
-                uint32_t f = seg.blk_first[c];
-                if ((f >> SB) < target) {
-                    c = wave_lower_bound(seg.blk_first, c, e, target << SB, lane);
-                }
-                if (c < e) {
-                    st = seg.blk_first[c] >> SB;
-                    /* blocks of one stripe: at most W/128 <= 64 → one ballot */
-                    uint32_t p = c + lane;
-                    bool in = (p < e) && ((seg.blk_first[p] >> SB) == st);
-                    run = (uint32_t)__popcll(__ballot(in));
-                }
-            }
-            (void)id;
-            if (lane == 0) { ctl.cur[t] = c; ctl.st[t] = st; ctl.run[t] = run; }
-        }
-        __syncthreads();
-        uint32_t s = is_or ? kInfStripe : 0u;
-        bool all_same = true;
+    /* ---- run table: for every (term, stripe of this group) the block range [start, end) ----
+     * One coalesced pass over the group's slice of blk_first per term; afterwards stripe selection
+     * (AND: every term present, OR: any) reads LDS only. */
+    uint32_t* rstart = sm.runs;
+    uint32_t* rend = sm.runs + (size_t)tab_terms * SPG;
+    if (!empty) {
         for (uint32_t t = 0; t < T; ++t) {
-            uint32_t st = ctl.st[t];
-            if (is_or) s = st < s ? st : s; else s = st > s ? st : s;
+            const uint32_t c = ctl.cur[t], e = ctl.end[t];
+            for (uint32_t i = c + tid; i < e; i += XGM_WG) {
+                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
+                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                if (s != sp) rstart[t * SPG + s] = i;
+                if (s != sn) rend[t * SPG + s] = i + 1u;
+            }
         }
-        for (uint32_t t = 0; t < T; ++t) all_same = all_same && (ctl.st[t] == s);
-        if (s == kInfStripe || s >= s_end) break;          /* uniform */
-        if (!is_or && !all_same) { target = s; __syncthreads(); continue; }
+    }
+    __syncthreads();
+
+    unsigned long long my_matches = 0;
+    const uint32_t n_local = empty ? 0u : s_end - s_begin;
+    for (uint32_t sl = 0; sl < n_local; ++sl) {
+        /* ---- stripe selection from the run table (uniform, no barrier) ---- */
+        uint32_t total = 0;
+        bool all = true;
+        for (uint32_t t = 0; t < T; ++t) {
+            uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
+            total += cnt;
+            all = all && cnt != 0;
+        }
+        if (is_or ? total == 0 : !all) continue;
+        const uint32_t s = s_begin + sl;
 
         /* ---- zero the tables ---- */
         {
@@ -382,30 +419,64 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
         }
         __syncthreads();
 
-        /* ---- K1: decode every block of stripe s into the tables ---- */
+        /* ---- K1: decode every block of stripe s into the tables ----
+         * Items (blocks) are dealt round-robin to the 4 waves.  A wave first loads the headers of up
+         * to 64 of its blocks with ONE load per field (lane j = j-th block), then walks them with the
+         * payload of the next block already in flight (register double buffer → LDS window). */
         {
-            uint32_t total = 0;
-            for (uint32_t t = 0; t < T; ++t) total += (ctl.st[t] == s) ? ctl.run[t] : 0u;
-            for (uint32_t item = wave; item < total; item += XGM_WAVES) {
-                uint32_t t = 0, j = item;
-                while (true) {
-                    uint32_t r = (ctl.st[t] == s) ? ctl.run[t] : 0u;
-                    if (j < r) break;
-                    j -= r; ++t;
+            const uint32_t wave_items = total > wave ? (total - wave + XGM_WAVES - 1u) / XGM_WAVES : 0u;
+            for (uint32_t base = 0; base < wave_items; base += 64u) {
+                const uint32_t nthis = wave_items - base < 64u ? wave_items - base : 64u;
+                uint32_t h_meta = 0, h_first = 0, h_t = 0, h_pos = 0;
+                uint64_t h_addr = 0;
+                if (lane < nthis) {
+                    uint32_t item = wave + XGM_WAVES * (base + lane);
+                    uint32_t t = 0;
+                    while (true) {
+                        uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
+                        if (item < cnt) break;
+                        item -= cnt; ++t;
+                    }
+                    const uint32_t b = rstart[t * SPG + sl] + item;
+                    h_t = t;
+                    h_meta = seg.blk_meta[b];
+                    h_first = seg.blk_first[b];
+                    h_addr = seg.term_word[q.term_id[t]] + seg.blk_word[b];
+                    if (PHRASE) h_pos = seg.blk_pos[b];
                 }
-                const uint32_t id = q.term_id[t];
-                const uint32_t b = ctl.cur[t] + j;
-                const uint32_t meta = seg.blk_meta[b];
-                const uint32_t* payload = seg.words + seg.term_word[id] + seg.blk_word[b];
-                DecodedPair r = decode_block<PHRASE>(payload, seg.blk_first[b], meta, my_stage, lane);
-                TabT* row = tab + (size_t)t * W;
-                if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
-                if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
-                if (PHRASE) {
-                    uint32_t* prow = sm.ptab + (size_t)t * W;
-                    uint32_t pb = seg.blk_pos[b];
-                    if (r.v0) prow[r.d0 & (W - 1u)] = pb + r.p0;
-                    if (r.v1) prow[r.d1 & (W - 1u)] = pb + r.p1;
+                /* prefetch block 0 */
+                Words4 pre = {0, 0, 0, 0};
+                {
+                    const uint32_t m0 = __builtin_amdgcn_readlane(h_meta, 0);
+                    const uint64_t a0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(h_addr >> 32), 0) << 32) | __builtin_amdgcn_readlane((uint32_t)h_addr, 0);
+                    if (lane * 4u < payload_words(m0)) pre = *reinterpret_cast<const Words4*>(seg.words + a0 + lane * 4u);
+                }
+                for (uint32_t x = 0; x < nthis; ++x) {
+                    const uint32_t xs = __builtin_amdgcn_readfirstlane(x);
+                    const uint32_t meta = __builtin_amdgcn_readlane(h_meta, xs);
+                    const uint32_t first = __builtin_amdgcn_readlane(h_first, xs);
+                    const uint32_t t = __builtin_amdgcn_readlane(h_t, xs);
+                    const Words4 cur = pre;
+                    if (x + 1u < nthis) {
+                        const uint32_t m1 = __builtin_amdgcn_readlane(h_meta, xs + 1u);
+                        const uint64_t a1 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(h_addr >> 32), xs + 1u) << 32) | __builtin_amdgcn_readlane((uint32_t)h_addr, xs + 1u);
+                        if (lane * 4u < payload_words(m1)) pre = *reinterpret_cast<const Words4*>(seg.words + a1 + lane * 4u);
+                    }
+                    if (lane * 4u < payload_words(meta)) {
+                        my_stage[lane * 4u] = cur.a; my_stage[lane * 4u + 1] = cur.b; my_stage[lane * 4u + 2] = cur.c; my_stage[lane * 4u + 3] = cur.d;
+                    }
+                    wave_lds_fence();
+                    DecodedPair r = unpack_staged<PHRASE>(my_stage, first, meta, lane);
+                    wave_lds_fence();
+                    TabT* row = tab + (size_t)t * W;
+                    if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
+                    if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
+                    if (PHRASE) {
+                        uint32_t* prow = sm.ptab + (size_t)t * W;
+                        const uint32_t pb = __builtin_amdgcn_readlane(h_pos, xs);
+                        if (r.v0) prow[r.d0 & (W - 1u)] = pb + r.p0;
+                        if (r.v1) prow[r.d1 & (W - 1u)] = pb + r.p1;
+                    }
                 }
             }
         }
@@ -460,6 +531,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
             }
         }
         __syncthreads();
+
 
         /* ---- K6 + K4 + K5: filter, score and collect the survivors ---- */
         const uint32_t qn = ctl.qn;
@@ -526,10 +598,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
             }
             __syncthreads();
         }
+
         if (tid == 0) ctl.qn = 0;
-        /* consume the stripe */
-        if (tid < T && ctl.st[tid] == s) ctl.cur[tid] += ctl.run[tid];
-        target = s + 1u;
         __syncthreads();
     }
 
@@ -551,6 +621,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
         ghdr_out[(size_t)qi * n_groups + g] = h;
     }
 }
+
 
 /* ---------------------------------------------------------------- merge kernel --------------- */
 
@@ -678,7 +749,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uin
     }
 }
 
-size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_t tab_elem) {
+size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
     off += (size_t)cap * 8;
     off += (sizeof(Ctrl) + 15) & ~(size_t)15;
@@ -687,6 +758,7 @@ size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_
     off += (size_t)cap * 4 * 2;
     off += (size_t)XGM_WAVES * kStageWords * 4;
     off += (size_t)W * 2;
+    off += (size_t)2 * T * spg * 4;
     return (off + 15) & ~(size_t)15;
 }
 
@@ -700,13 +772,13 @@ size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_
         if (e_ != hipSuccess) return xgm_launch_error(#expr, (int)e_, hipGetErrorString(e_));  \
     } while (0)
 
-size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide) {
-    return match_smem_bytes(1u << stripe_bits, tab_terms, phrase, cap, wide ? 2 : 1);
+size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group) {
+    return match_smem_bytes(1u << stripe_bits, tab_terms, phrase, cap, wide ? 2 : 1, stripes_per_group);
 }
 
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
     dim3 grid(L.n_groups, L.nq), block(XGM_WG);
-    const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide);
+    const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
 #define XGM_LAUNCH(TT, PH)                                                                                   \
     do {                                                                                                     \

@@ -18,7 +18,7 @@ struct xgm_match_launch {
     xgm_group_hdr* ghdr;              /* device, [nq][n_groups]                                   */
 };
 
-size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide);
+size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t n_src, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
