@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--op", default="AND")
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     args = ap.parse_args()
@@ -84,7 +85,8 @@ def main():
     # ---- index: this rank's shard, generated + inverted + block-encoded on the GPU ----------------
     n_docs_global = args.docs_per_gpu * world
     t0 = time.time()
-    db = Database.synthetic(CORPUS_SEED, n_docs_global, args.vocab, n_shards=world, shard=rank, device=local_rank)
+    db = Database.synthetic(CORPUS_SEED, n_docs_global, args.vocab, n_shards=world, shard=rank, device=local_rank,
+                            stripe_bits=args.stripe_bits)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     info = db.info()

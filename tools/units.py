@@ -1,0 +1,44 @@
+"""Diagnostics: per work-unit timeline of the last batch launch of bench.py (occupancy over time,
+cycles per stripe, slowest units).  Run on the GPU box: python tools/units.py [bench args]."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+
+import bench  # noqa: E402
+from xapiand_amd import _lib, enquire  # noqa: E402
+
+sys.argv = ["bench.py", "--steps", "4", "--warmup", "1", "--no-cpu-baseline"] + sys.argv[1:]
+L = _lib.lib()
+L.xgm_debug_last_units.restype = C.c_int64
+L.xgm_debug_last_units.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint64]
+oc = enquire.Database.close
+
+
+def close(self):
+    cap = 20000
+    buf = (C.c_ulonglong * (6 * cap))()
+    n = L.xgm_debug_last_units(self._h, buf, cap)
+    if n > 0:
+        a = np.array(buf[:6 * n], dtype=np.uint64).reshape(n, 6)
+        t0 = a[:, 4].min()
+        dur = (a[:, 5] - a[:, 4]).astype(np.float64)
+        st = (a[:, 4] - t0).astype(np.float64)
+        en = (a[:, 5] - t0).astype(np.float64)
+        span = en.max()
+        print("UNITS n", n, "span_cycles", span, "dur mean/p50/p95/max", dur.mean(), np.median(dur), np.percentile(dur, 95), dur.max(),
+              "avg concurrency", dur.sum() / span)
+        edges = np.linspace(0, span, 11)
+        print("UNITS concurrency per decile", [int(((st < edges[i + 1]) & (en > edges[i])).sum()) for i in range(10)])
+        stripes = (a[:, 2] - a[:, 1]).astype(np.float64)
+        print("UNITS cycles/stripe mean", (dur / np.maximum(1, stripes)).mean(), "stripes/unit mean,max", stripes.mean(), stripes.max())
+        order = np.argsort(-dur)[:5]
+        print("UNITS slowest (qi, s_begin, s_end, cycles, start)", [(int(a[i, 0]), int(a[i, 1]), int(a[i, 2]), int(dur[i]), int(st[i])) for i in order])
+    oc(self)
+
+
+enquire.Database.close = close
+bench.main()

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstdlib>
+#include <cmath>
 #include <cstring>
 
 #include "xgm_internal.h"
@@ -55,11 +57,14 @@ struct XgmScratch {
     xgm_cand* d_cand = nullptr; size_t cap_cand = 0;
     xgm_group_hdr* d_ghdr = nullptr; size_t cap_ghdr = 0;
     uint32_t* d_kq = nullptr; double* d_maxposs = nullptr; size_t cap_kq = 0;
+    xgm_work* d_work = nullptr; size_t cap_work = 0;
+    uint32_t* d_goff = nullptr; size_t cap_goff = 0;
     xgm_hit* d_hits = nullptr; size_t cap_hits = 0;
     xgm_result_hdr* d_hdrs = nullptr; size_t cap_hdrs = 0;
     /* pinned host */
     void* h_up = nullptr; size_t cap_up = 0;
     void* h_down = nullptr; size_t cap_down = 0;
+    void* h_work = nullptr; size_t cap_hwork = 0;     /* pinned copy of the work list + group offsets */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_done = nullptr;   /* recorded after an asynchronous call that still uses this scratch */
     bool pending = false;
@@ -117,9 +122,10 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_queries); hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_kq); hipFree(s->d_maxposs);
-    hipFree(s->d_hits); hipFree(s->d_hdrs);
+    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_work); hipFree(s->d_goff);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
+    if (s->h_work) hipHostFree(s->h_work);
     if (s->ev0) hipEventDestroy(s->ev0);
     if (s->ev1) hipEventDestroy(s->ev1);
     if (s->ev_done) hipEventDestroy(s->ev_done);
@@ -373,14 +379,22 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
     return width;
 }
 
+static std::vector<xgm_work> g_last_work;          /* diagnostics only */
+static xgm_group_hdr* g_last_ghdr = nullptr;
+
 struct BatchPlan {
-    uint32_t nq, k_max, tab_terms, n_groups, stripes_per_group, cap, k_stride_c, merge_cap;
+    uint32_t nq, k_max, tab_terms, n_work, stripes_per_group, cap, k_stride_c, merge_cap;
+    std::vector<xgm_work> work;        /* heaviest first */
+    std::vector<uint32_t> goff;        /* [nq+1] first output slot of each query */
     bool phrase, wide;
+    bool and_only;      /* every query is a plain conjunction of >= 2 terms → xgm_and_kernel */
 };
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
                       BatchPlan* bp) {
-    bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false;
+    bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
+    static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
+    if (no_and_kernel) bp->and_only = false;
     for (uint32_t i = 0; i < nq; ++i) {
         if (qs[i].n_terms == 0 || qs[i].n_terms > XGM_MAX_TERMS) return xgm_set_error(XGM_E_INVALID, "query %u: bad n_terms", i);
         int width = to_dev_query(idx, &qs[i], &dq[i]);
@@ -388,6 +402,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         if (width == 0) return XGM_UNSUPPORTED;
         if (dq[i].k > XGM_MAX_K) return XGM_UNSUPPORTED;
         if (width == 2) bp->wide = true;
+        if (dq[i].op != XGM_OP_AND || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE)) bp->and_only = false;
         if (dq[i].flags & XGM_QF_PHRASE) {
             if (dq[i].n_terms > XGM_PHRASE_MAX_TERMS) return XGM_UNSUPPORTED;
             bp->phrase = true;
@@ -403,19 +418,62 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     }
     bp->cap = std::max(512u, next_pow2(bp->k_max + XGM_WG));
     const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
-    /* groups per query: fill the chip (~8 workgroups per CU across the batch), bounded by the merge
-     * kernel's LDS sort capacity; a group's run table (8 B per term and stripe) must fit in LDS */
-    uint32_t want = std::max(1u, 2048u / nq);
-    uint32_t g_cap = std::max(1u, XGM_MERGE_CAP / next_pow2(bp->k_max));
-    want = std::min(std::min(want, g_cap), n_stripes);
-    const uint32_t spg_max = std::max(1u, (24u * 1024u) / (8u * bp->tab_terms));
-    bp->stripes_per_group = std::min((n_stripes + want - 1) / want, spg_max);
-    bp->n_groups = (n_stripes + bp->stripes_per_group - 1) / bp->stripes_per_group;
-    if ((uint64_t)bp->n_groups * next_pow2(bp->k_max) > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
+    /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
+     * plus about one partial block per stripe a term touches).  Every query is cut into units of
+     * about total/(8 units per CU) cost — heavy queries into many — bounded by the LDS run table
+     * (8 B per term and stripe → at most spg_max stripes per unit) and by the merge kernel's sort
+     * capacity (units × k candidates). */
+    const uint32_t spg_max = std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
+    const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
+    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, XGM_MERGE_CAP / next_pow2(bp->k_max))));
+    if ((uint64_t)g_min * next_pow2(bp->k_max) > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
+    /* measured on MI355X (profiles/r01_v3_phase_cycles.txt): a stripe costs ~8k cycles of fixed
+     * latency chain (candidate block fetch, doclen gather, barriers) plus ~0.9k cycles per posting
+     * block of the other terms; a unit's time is stripes x that, so BOTH terms matter */
+    std::vector<double> cost(nq);
+    double total_cost = 0;
+    for (uint32_t i = 0; i < nq; ++i) {
+        double blocks = 0, min_df = 1e30;
+        for (uint32_t t = 0; t < qs[i].n_terms; ++t) {
+            uint32_t id = qs[i].terms[t].term_id;
+            if (id == UINT32_MAX) { min_df = 0; continue; }
+            const double df = idx->term_df[id];
+            blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes);
+            min_df = std::min(min_df, df);
+        }
+        /* AND visits only stripes where the rarest term has postings */
+        const double stripes = qs[i].op == XGM_OP_OR ? n_stripes : std::min<double>(n_stripes, min_df);
+        cost[i] = 8.0 * stripes + 0.9 * blocks + 1.0;
+        total_cost += cost[i];
+    }
+    const double unit_cost = std::max(1.0, total_cost / 3072.0);
+    bp->goff.assign(nq + 1, 0);
+    bp->work.clear();
+    uint32_t spg_used = 1;
+    struct Tmp { double c; xgm_work w; };
+    std::vector<Tmp> tmp;
+    for (uint32_t i = 0; i < nq; ++i) {
+        uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
+        uint32_t spg = (n_stripes + gq - 1) / gq;
+        gq = (n_stripes + spg - 1) / spg;
+        spg_used = std::max(spg_used, spg);
+        bp->goff[i + 1] = bp->goff[i] + gq;
+        for (uint32_t g = 0; g < gq; ++g) {
+            xgm_work w;
+            w.qi = i; w.s_begin = g * spg; w.s_end = std::min(n_stripes, (g + 1) * spg); w.slot = bp->goff[i] + g;
+            tmp.push_back(Tmp{cost[i] / gq, w});
+        }
+    }
+    std::stable_sort(tmp.begin(), tmp.end(), [](const Tmp& a, const Tmp& b) { return a.c > b.c; });
+    for (const Tmp& t : tmp) bp->work.push_back(t.w);
+    bp->n_work = (uint32_t)bp->work.size();
+    bp->stripes_per_group = spg_used;
+    uint32_t g_most = 0;
+    for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
     const size_t smem = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
+    bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));
     bp->k_stride_c = bp->k_max;
-    bp->merge_cap = std::max(512u, next_pow2(bp->n_groups * bp->k_max));
     return XGM_OK;
 }
 
@@ -440,8 +498,18 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         HIP_TRY(hipMalloc((void**)&s->d_maxposs, (size_t)nq * 8));
         s->cap_kq = nq;
     }
-    if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)nq * bp.n_groups * bp.k_stride_c))) return rc;
-    if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)nq * bp.n_groups))) return rc;
+    if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)bp.n_work * bp.k_stride_c))) return rc;
+    if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)bp.n_work))) return rc;
+    if ((rc = grow(&s->d_work, &s->cap_work, (size_t)bp.n_work))) return rc;
+    if ((rc = grow(&s->d_goff, &s->cap_goff, (size_t)nq + 1))) return rc;
+    {
+        const size_t wb = (size_t)bp.n_work * sizeof(xgm_work), gb = ((size_t)nq + 1) * 4;
+        if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, wb + gb))) return rc;
+        memcpy(s->h_work, bp.work.data(), wb);
+        memcpy((char*)s->h_work + wb, bp.goff.data(), gb);
+        HIP_TRY(hipMemcpyAsync(s->d_work, s->h_work, wb, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(s->d_goff, (char*)s->h_work + wb, gb, hipMemcpyHostToDevice, stream));
+    }
     HIP_TRY(hipMemcpyAsync(s->d_queries, h_dq, (size_t)nq * sizeof(xgm_dev_query), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(s->d_maxposs, h_mp, (size_t)nq * 8, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipMemcpyAsync(s->d_kq, h_kq, (size_t)nq * 4, hipMemcpyHostToDevice, stream));
@@ -449,7 +517,8 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = s->d_queries;
-    L.nq = nq; L.n_groups = bp.n_groups; L.stripes_per_group = bp.stripes_per_group;
+    L.nq = nq; L.n_work = bp.n_work; L.work = s->d_work; L.stripes_per_group = bp.stripes_per_group;
+    if (nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
     L.phrase = bp.phrase; L.wide = bp.wide;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
@@ -467,9 +536,9 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         ++idx->prof_used;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = xgm_launch_match(L, stream))) return rc;
+    if ((rc = bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream))) return rc;
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
-    if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, bp.n_groups, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
+    if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
                                d_hdrs, s->d_maxposs, stream)))
         return rc;
     return XGM_OK;
@@ -610,5 +679,26 @@ extern "C" int64_t xgm_debug_read_doclen(xgm_index* idx, uint32_t* out, uint64_t
     int rc = use_device(idx->device);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, idx->d_sections[XGM_S_DOCLEN], n * 4, hipMemcpyDeviceToHost));
+    return (int64_t)n;
+}
+
+int xgm_phase_cycles_fetch(unsigned long long* out8);
+/* Diagnostics: per-phase s_memtime cycle sums of xgm_and_kernel (thread 0 of every workgroup) since
+ * the last call; needs XGM_PHASE_TIMING=1 in the environment.  out[0..6] phases, out[7] stripes. */
+extern "C" int xgm_debug_phase_cycles(unsigned long long* out8) { return xgm_phase_cycles_fetch(out8); }
+
+/* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end) of the LAST batch launched on
+ * this index from any thread; out is u64[6 * cap]; returns the number of units. */
+extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out, uint64_t cap) {
+    if (!idx || !out || !g_last_ghdr) return -1;
+    hipDeviceSynchronize();
+    std::vector<xgm_group_hdr> h(g_last_work.size());
+    if (hipMemcpy(h.data(), g_last_ghdr, h.size() * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    uint64_t n = std::min<uint64_t>(cap, g_last_work.size());
+    for (uint64_t i = 0; i < n; ++i) {
+        const xgm_work& w = g_last_work[i];
+        out[6 * i] = w.qi; out[6 * i + 1] = w.s_begin; out[6 * i + 2] = w.s_end; out[6 * i + 3] = w.slot;
+        out[6 * i + 4] = h[w.slot].t_start; out[6 * i + 5] = h[w.slot].t_end;
+    }
     return (int64_t)n;
 }

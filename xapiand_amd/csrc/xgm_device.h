@@ -37,11 +37,22 @@ typedef struct {
     uint32_t subqs;
 } xgm_cand;
 
-/* Per (query, group) summary written by the match kernel. */
+/* One unit of work of the match kernels: a query and a contiguous range of docid stripes.  The host
+ * cuts every query into units of roughly equal posting-block counts (heavy queries get more units)
+ * and sorts the list heaviest-first, so the chip stays full until the end of the launch. */
+typedef struct {
+    uint32_t qi;           /* query of the batch                                                   */
+    uint32_t s_begin;      /* first stripe                                                         */
+    uint32_t s_end;        /* one past the last stripe                                             */
+    uint32_t slot;         /* where the unit's candidates / header go: goff[qi] + index in query   */
+} xgm_work;
+
+/* Per work-unit summary written by the match kernel. */
 typedef struct {
     uint64_t matches;
     uint32_t n_cand;
     uint32_t pad;
+    uint64_t t_start, t_end;   /* s_memtime at unit start / end (diagnostics: occupancy timeline) */
 } xgm_group_hdr;
 
 #endif

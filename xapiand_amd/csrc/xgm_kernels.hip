@@ -30,6 +30,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "xgm_device.h"
 #include "xgm_launch.h"
 
@@ -331,7 +334,7 @@ __device__ __forceinline__ uint32_t payload_words(uint32_t meta) {
 
 template <typename TabT, bool PHRASE>
 __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
-                                                            uint32_t n_groups, uint32_t stripes_per_group,
+                                                            const xgm_work* __restrict__ work, uint32_t stripes_per_group,
                                                             uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                             xgm_cand* __restrict__ cand_out,
                                                             xgm_group_hdr* __restrict__ ghdr_out) {
@@ -339,7 +342,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-    const uint32_t g = blockIdx.x, qi = blockIdx.y;
+    const xgm_work wk = work[blockIdx.x];
+    const uint32_t qi = wk.qi;
     const xgm_dev_query& q = queries[qi];
     const uint32_t SB = seg.stripe_bits;
     const uint32_t W = 1u << SB;
@@ -355,9 +359,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     uint32_t* my_stage = sm.stage + wave * kStageWords;
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
-    const uint32_t s_begin = g * SPG;
-    uint32_t s_end = s_begin + SPG;
-    if (s_end > n_stripes) s_end = n_stripes;
+    const uint32_t s_begin = wk.s_begin;
+    const uint32_t s_end = wk.s_end;
 
     /* ---- init: top-k buffer, the group's block ranges ---- */
     for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
@@ -609,7 +612,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     if (my_matches) atomicAdd(&ctl.matches, my_matches);
     __syncthreads();
     const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
-    xgm_cand* out = cand_out + ((size_t)qi * n_groups + g) * k_stride;
+    xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = tid; i < n_out; i += XGM_WG) {
         xgm_cand c;
         c.wbits = sm.tk.w[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
@@ -618,10 +621,434 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     if (tid == 0) {
         xgm_group_hdr h;
         h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
-        ghdr_out[(size_t)qi * n_groups + g] = h;
+        h.t_start = 0; h.t_end = 0;
+        ghdr_out[wk.slot] = h;
     }
 }
 
+
+/* ---------------------------------------------------------------- the AND kernel ------------- */
+
+/* Conjunctions get their own kernel (K2 specialised): the rarest term's postings of a stripe ARE the
+ * candidate set (the reference drives MultiAndPostList from its shortest list the same way,
+ * multiandpostlist.cc:180-207), so instead of per-term direct-address tables over the whole stripe
+ * the workgroup keeps
+ *     c_slot[ord], c_w[t][ord]   candidates in docid order and their wdf+1 per term (0 = absent)
+ *     bitmap[W/32], rankw[W/32]  candidate membership + ordinal of the first candidate of each word
+ * and only decodes those blocks of the other terms whose docid range contains a candidate.  LDS drops
+ * from ~54 KB to ~20 KB per workgroup, which is what lets 7 workgroups (28 waves) share a CU and hide
+ * the LDS round trips of the decode. */
+constexpr uint32_t kAndCand = 1024;                 /* candidates per chunk = 8 blocks of term 0 */
+constexpr uint32_t kAndChunkBlocks = kAndCand / XGM_BLOCK;
+constexpr uint32_t kAndWindows = 1;                 /* blocks a wave unpacks at once (measured: 4-way interleave is slower - more LDS, fewer resident workgroups) */
+
+struct AndCtrl {
+    uint32_t cur[XGM_MAX_TERMS];
+    uint32_t end[XGM_MAX_TERMS];
+    uint64_t tbase[XGM_MAX_TERMS];
+    uint32_t tkn, theta_valid, theta_d, pad;
+    uint64_t theta_w;
+    unsigned long long matches;
+};
+
+struct AndSmem {
+    TopK tk;
+    AndCtrl* ctrl;
+    uint32_t* runs;       /* [2][T][SPG] */
+    uint32_t* stage;      /* [WAVES][kStageWords] */
+    uint32_t* bitmap;     /* [W/32] */
+    uint32_t* rankw;      /* [W/32] ordinal of the first candidate in the word (UINT32_MAX if none) */
+    uint16_t* c_slot;     /* [kAndCand] */
+    unsigned char* c_w;   /* [T][kAndCand] of TabT */
+};
+
+__host__ __device__ inline size_t and_smem_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
+    size_t off = 0;
+    off += (size_t)cap * 8;                                    /* tk.w */
+    off += (sizeof(AndCtrl) + 15) & ~(size_t)15;
+    off += (size_t)cap * 4 * 2;                                /* tk.d, tk.m */
+    off += (size_t)2 * T * spg * 4;                            /* runs */
+    off += (size_t)XGM_WAVES * kAndWindows * kStageWords * 4;
+    off += (size_t)(W / 32u) * 4 * 2;                          /* bitmap, rankw */
+    off += (size_t)kAndCand * 2;                               /* c_slot */
+    off += (size_t)T * kAndCand * tab_elem;                    /* c_w */
+    return (off + 15) & ~(size_t)15;
+}
+
+template <typename TabT>
+__device__ __forceinline__ AndSmem and_carve(unsigned char* smem, uint32_t W, uint32_t T, uint32_t cap, uint32_t spg) {
+    AndSmem s;
+    size_t off = 0;
+    s.tk.w = reinterpret_cast<uint64_t*>(smem + off); off += (size_t)cap * 8;
+    s.ctrl = reinterpret_cast<AndCtrl*>(smem + off); off += (sizeof(AndCtrl) + 15) & ~(size_t)15;
+    s.tk.d = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)cap * 4;
+    s.tk.m = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)cap * 4;
+    s.runs = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)2 * T * spg * 4;
+    s.stage = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)XGM_WAVES * kAndWindows * kStageWords * 4;
+    s.bitmap = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)(W / 32u) * 4;
+    s.rankw = reinterpret_cast<uint32_t*>(smem + off); off += (size_t)(W / 32u) * 4;
+    s.c_slot = reinterpret_cast<uint16_t*>(smem + off); off += (size_t)kAndCand * 2;
+    s.c_w = smem + off; off += (size_t)T * kAndCand * sizeof(TabT);
+    s.tk.cap = cap;
+    return s;
+}
+
+/* number of candidates with slot < x (c_slot is ascending) */
+__device__ __forceinline__ uint32_t cand_lower_bound(const uint16_t* c_slot, uint32_t n, uint32_t x) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (c_slot[mid] < x) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
+/* load the block's payload (16 B per lane) and unpack it through the wave's LDS window */
+__device__ __forceinline__ DecodedPair fetch_unpack(const uint32_t* __restrict__ payload, uint32_t first, uint32_t meta, uint32_t* stage, uint32_t lane) {
+    if (lane * 4u < payload_words(meta)) {
+        const Words4 v = *reinterpret_cast<const Words4*>(payload + lane * 4u);
+        stage[lane * 4u] = v.a; stage[lane * 4u + 1] = v.b; stage[lane * 4u + 2] = v.c; stage[lane * 4u + 3] = v.d;
+    }
+    wave_lds_fence();
+    DecodedPair r = unpack_staged<false>(stage, first, meta, lane);
+    wave_lds_fence();
+    return r;
+}
+
+template <typename TabT>
+__global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                          const xgm_work* __restrict__ work, uint32_t stripes_per_group, uint32_t tab_terms,
+                                                          uint32_t cap, uint32_t k_stride, xgm_cand* __restrict__ cand_out,
+                                                          xgm_group_hdr* __restrict__ ghdr_out, unsigned long long* __restrict__ phase_cycles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    /* optional phase timing (diagnostics): thread 0 accumulates s_memtime deltas per phase */
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long t_unit_start = __builtin_readcyclecounter();
+    unsigned long long tmark = phase_cycles ? __builtin_readcyclecounter() : 0ull;
+#define XGM_PHASE(i) do { if (phase_cycles) { unsigned long long n_ = __builtin_readcyclecounter(); pc[i] += n_ - tmark; tmark = n_; } } while (0)
+    const xgm_work wk = work[blockIdx.x];
+    const uint32_t qi = wk.qi;
+    const xgm_dev_query& q = queries[qi];
+    const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
+    const uint32_t T = q.n_terms, k = q.k, SPG = stripes_per_group;
+
+    AndSmem sm = and_carve<TabT>(smem, W, tab_terms, cap, SPG);
+    AndCtrl& ctl = *sm.ctrl;
+    TabT* c_w = reinterpret_cast<TabT*>(sm.c_w);
+    uint32_t* my_stage = sm.stage + wave * kAndWindows * kStageWords;
+    uint32_t* rs = sm.runs;
+    uint32_t* re = sm.runs + (size_t)tab_terms * SPG;
+
+    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
+    const uint32_t s_begin = wk.s_begin;
+    const uint32_t s_end = wk.s_end;
+
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
+    for (uint32_t i = tid; i < NW; i += XGM_WG) { sm.bitmap[i] = 0; sm.rankw[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < T * kAndCand; i += XGM_WG) c_w[i] = 0;
+    if (tid == 0) { ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; }
+    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
+    if (!empty) {
+        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
+            const uint32_t id = q.term_id[t];
+            uint32_t c = 0, e = 0;
+            uint64_t tb = 0;
+            if (id != 0xFFFFFFFFu) {
+                const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+                c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+                e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+                tb = seg.term_word[id];
+            }
+            if (lane == 0) { ctl.cur[t] = c; ctl.end[t] = e; ctl.tbase[t] = tb; }
+        }
+    }
+    __syncthreads();
+    if (!empty) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t c = ctl.cur[t], e = ctl.end[t];
+            for (uint32_t i = c + tid; i < e; i += XGM_WG) {
+                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
+                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                if (s != sp) rs[t * SPG + s] = i;
+                if (s != sn) re[t * SPG + s] = i + 1u;
+            }
+        }
+    }
+    __syncthreads();
+
+    XGM_PHASE(0);                                                  /* init + run table */
+    unsigned long long my_matches = 0;
+    const uint32_t n_local = empty ? 0u : s_end - s_begin;
+
+    /* Every wave serves every other term and takes each 4th needed block of it, so the four waves
+     * finish P3 together whatever the terms' densities are. */
+    auto next_active = [&](uint32_t from) {
+        uint32_t x = from;
+        for (; x < n_local; ++x) {
+            bool all = true;
+            for (uint32_t t = 0; t < T; ++t) all = all && (re[t * SPG + x] != rs[t * SPG + x]);
+            if (all) break;
+        }
+        return x;
+    };
+
+    /* software-pipelined header registers: lane j holds block j of the run */
+    uint32_t h0_meta = 0, h0_first = 0, h0_word = 0;                 /* term 0, first chunk (lanes 0..7) */
+    uint32_t ha_meta = 0, ha_first = 0, ha_word = 0, ha_next = 0;    /* term 1 (lanes 0..63)             */
+    uint32_t hb_meta = 0, hb_first = 0, hb_word = 0, hb_next = 0;    /* term 2, when T >= 3              */
+    auto issue_headers = [&](uint32_t x) {
+        const uint32_t r0 = rs[x], n0b = re[x] - r0;
+        if (lane < n0b && lane < kAndChunkBlocks) {
+            h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
+        }
+        {
+            const uint32_t rb = rs[1u * SPG + x], nb = re[1u * SPG + x] - rb;
+            if (lane < nb) {
+                ha_meta = seg.blk_meta[rb + lane]; ha_first = seg.blk_first[rb + lane]; ha_word = seg.blk_word[rb + lane];
+                ha_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+            }
+        }
+        if (T >= 3u) {
+            const uint32_t rb = rs[2u * SPG + x], nb = re[2u * SPG + x] - rb;
+            if (lane < nb) {
+                hb_meta = seg.blk_meta[rb + lane]; hb_first = seg.blk_first[rb + lane]; hb_word = seg.blk_word[rb + lane];
+                hb_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+            }
+        }
+    };
+
+    uint32_t sl = next_active(0);
+    if (sl < n_local) issue_headers(sl);
+    while (sl < n_local) {
+        if (phase_cycles) pc[7] += 1;
+        const uint32_t s = s_begin + sl;
+        const uint32_t stripe_base = s << SB;
+        const uint32_t r0 = rs[sl], r0e = re[sl];                  /* term 0 (rarest) blocks */
+        const uint32_t sl_next = next_active(sl + 1u);
+
+        for (uint32_t cb = r0; cb < r0e; cb += kAndChunkBlocks) {
+            const uint32_t nblk0 = r0e - cb < kAndChunkBlocks ? r0e - cb : kAndChunkBlocks;
+            /* ---- P1: term-0 blocks of the chunk → candidates (ordinals follow docid order) ---- */
+            uint32_t n_c;
+            {
+                uint32_t m0 = h0_meta, f0 = h0_first, w0 = h0_word;
+                if (cb != r0) {                                     /* later chunks: not prefetched */
+                    m0 = lane < nblk0 ? seg.blk_meta[cb + lane] : 0u;
+                    f0 = lane < nblk0 ? seg.blk_first[cb + lane] : 0u;
+                    w0 = lane < nblk0 ? seg.blk_word[cb + lane] : 0u;
+                }
+                uint32_t cnt0 = lane < nblk0 ? XGM_META_COUNT(m0) : 0u;
+                uint32_t incl = wave_incl_scan(cnt0);
+                n_c = __builtin_amdgcn_readlane(incl, 63);
+                /* this wave's blocks: j = wave, wave + 4 (at most two): fetch both payloads first */
+                const uint32_t ja = wave, jb = wave + XGM_WAVES;
+                Words4 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+                uint32_t ma = 0, mb = 0;
+                if (ja < nblk0) {
+                    ma = __builtin_amdgcn_readlane(m0, ja);
+                    if (lane * 4u < payload_words(ma)) pa = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + __builtin_amdgcn_readlane(w0, ja) + lane * 4u);
+                }
+                if (jb < nblk0) {
+                    mb = __builtin_amdgcn_readlane(m0, jb);
+                    if (lane * 4u < payload_words(mb)) pb = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + __builtin_amdgcn_readlane(w0, jb) + lane * 4u);
+                }
+                for (uint32_t pass = 0; pass < 2u; ++pass) {
+                    const uint32_t j = pass ? jb : ja;
+                    if (j >= nblk0) break;
+                    const uint32_t meta = pass ? mb : ma;
+                    const Words4 pv = pass ? pb : pa;
+                    const uint32_t obase = __builtin_amdgcn_readlane(incl, j) - XGM_META_COUNT(meta);
+                    const uint32_t first = __builtin_amdgcn_readlane(f0, j);
+                    if (lane * 4u < payload_words(meta)) {
+                        my_stage[lane * 4u] = pv.a; my_stage[lane * 4u + 1] = pv.b; my_stage[lane * 4u + 2] = pv.c; my_stage[lane * 4u + 3] = pv.d;
+                    }
+                    wave_lds_fence();
+                    DecodedPair r = unpack_staged<false>(my_stage, first, meta, lane);
+                    wave_lds_fence();
+                    const uint32_t s0 = r.d0 - stripe_base, s1 = r.d1 - stripe_base;
+                    uint32_t prev1 = (uint32_t)__shfl_up((int)s1, 1);
+                    const uint32_t pw0 = lane == 0 ? 0xFFFFFFFFu : (prev1 >> 5);
+                    if (r.v0) {
+                        const uint32_t o = obase + 2u * lane;
+                        sm.c_slot[o] = (uint16_t)s0;
+                        c_w[o] = (TabT)(r.w0 + 1u);
+                        atomicOr(&sm.bitmap[s0 >> 5], 1u << (s0 & 31u));
+                        if ((s0 >> 5) != pw0) atomicMin(&sm.rankw[s0 >> 5], o);
+                    }
+                    if (r.v1) {
+                        const uint32_t o = obase + 2u * lane + 1u;
+                        sm.c_slot[o] = (uint16_t)s1;
+                        c_w[o] = (TabT)(r.w1 + 1u);
+                        atomicOr(&sm.bitmap[s1 >> 5], 1u << (s1 & 31u));
+                        if ((s1 >> 5) != (s0 >> 5)) atomicMin(&sm.rankw[s1 >> 5], o);
+                    }
+                }
+            }
+            XGM_PHASE(1);
+            __syncthreads();
+            XGM_PHASE(2);
+
+            /* ---- P3: the other terms: decode only blocks whose docid range contains a candidate ---- */
+            for (uint32_t t = 1; t < T; ++t) {
+                const uint32_t rb = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb;      /* nb <= 64 */
+                uint32_t meta, first, woff, nfirst;
+                if (t == 1u) { meta = ha_meta; first = ha_first; woff = ha_word; nfirst = ha_next; }
+                else if (t == 2u) { meta = hb_meta; first = hb_first; woff = hb_word; nfirst = hb_next; }
+                else {                                              /* 4th term onwards: not prefetched */
+                    meta = first = woff = 0; nfirst = 0xFFFFFFFFu;
+                    if (lane < nb) {
+                        meta = seg.blk_meta[rb + lane]; first = seg.blk_first[rb + lane]; woff = seg.blk_word[rb + lane];
+                        nfirst = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+                    }
+                }
+                bool need = false;
+                if (lane < nb) {
+                    const uint32_t nf = nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base;
+                    /* with many candidates per block nearly every block is hit: skip the two searches */
+                    need = n_c >= 4u * nb || cand_lower_bound(sm.c_slot, n_c, nf) > cand_lower_bound(sm.c_slot, n_c, first - stripe_base);
+                }
+                uint64_t mask = __ballot(need);
+                for (uint32_t x = 0; x < wave && mask; ++x) mask &= mask - 1u;          /* this wave's share */
+                TabT* row = c_w + (size_t)t * kAndCand;
+                while (mask) {
+                    /* up to 8 of my blocks: all payload loads first, then the decodes */
+                    uint32_t jj[8], n_here = 0;
+                    Words4 pv[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) {
+                        jj[u] = 64u;
+                        pv[u] = Words4{0, 0, 0, 0};
+                        if (mask) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask);
+                            for (uint32_t x = 0; x < XGM_WAVES && mask; ++x) mask &= mask - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(meta, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[t] + __builtin_amdgcn_readlane(woff, jj[u]) + lane * 4u);
+                            n_here = u + 1u;
+                        }
+                    }
+                    /* unpack four blocks at a time: their LDS round trips overlap */
+#pragma unroll
+                    for (uint32_t u0 = 0; u0 < 8u; u0 += kAndWindows) {
+                        if (u0 < n_here) {
+                            uint32_t bmeta[kAndWindows], bfirst[kAndWindows];
+#pragma unroll
+                            for (uint32_t v = 0; v < kAndWindows; ++v) {
+                                const uint32_t u = u0 + v;
+                                const uint32_t jv = jj[u] < 64u ? jj[u] : 0u;
+                                bmeta[v] = __builtin_amdgcn_readlane(meta, jv);
+                                bfirst[v] = __builtin_amdgcn_readlane(first, jv);
+                                uint32_t* st = my_stage + v * kStageWords;
+                                if (u < n_here && lane * 4u < payload_words(bmeta[v])) {
+                                    st[lane * 4u] = pv[u].a; st[lane * 4u + 1] = pv[u].b; st[lane * 4u + 2] = pv[u].c; st[lane * 4u + 3] = pv[u].d;
+                                }
+                            }
+                            wave_lds_fence();
+                            DecodedPair r[kAndWindows];
+#pragma unroll
+                            for (uint32_t v = 0; v < kAndWindows; ++v) r[v] = unpack_staged<false>(my_stage + v * kStageWords, bfirst[v], bmeta[v], lane);
+                            wave_lds_fence();
+#pragma unroll
+                            for (uint32_t v = 0; v < kAndWindows; ++v) {
+                                if (u0 + v < n_here) {
+                                    if (r[v].v0) {
+                                        const uint32_t sl0 = r[v].d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
+                                        const uint32_t bm = sm.bitmap[wd];
+                                        if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r[v].w0 + 1u);
+                                    }
+                                    if (r[v].v1) {
+                                        const uint32_t sl1 = r[v].d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
+                                        const uint32_t bm = sm.bitmap[wd];
+                                        if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r[v].w1 + 1u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            XGM_PHASE(3);
+            __syncthreads();
+            XGM_PHASE(4);
+
+            /* headers of the next active stripe: in flight while this one is scored */
+            if (cb + kAndChunkBlocks >= r0e && sl_next < n_local) issue_headers(sl_next);
+
+            /* ---- P4: candidates present in every term are matches: BM25 + top-k ---- */
+            for (uint32_t i0 = 0; i0 < n_c; i0 += XGM_WG) {
+                const uint32_t fill_now = ctl.tkn;
+                __syncthreads();
+                if (fill_now + XGM_WG > cap) {
+                    topk_sort(sm.tk, tid);
+                    if (tid == 0) {
+                        uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
+                        ctl.tkn = keep;
+                        if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
+                    }
+                    __syncthreads();
+                    for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+                    __syncthreads();
+                }
+                const uint32_t o = i0 + tid;
+                if (o < n_c) {
+                    bool pass = true;
+                    for (uint32_t t = 1; t < T; ++t) pass = pass && c_w[(size_t)t * kAndCand + o] != 0;
+                    if (pass) {
+                        ++my_matches;
+                        const uint32_t did = stripe_base + sm.c_slot[o];
+                        /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
+                        const double len = (double)seg.doclen[did];
+                        double normlen = len * q.len_factor;
+                        normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+                        const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                        /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... in plan order */
+                        double weight = 0.0;
+                        for (uint32_t t = 0; t < T; ++t) {
+                            const double wdf = (double)((uint32_t)c_w[(size_t)t * kAndCand + o] - 1u);
+                            const double denom = denom_len + wdf;
+                            weight = weight + q.termweight[t] * (wdf / denom);
+                        }
+                        const uint64_t wb = (uint64_t)__double_as_longlong(weight);
+                        const bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
+                        if (take) {
+                            const uint32_t p = atomicAdd(&ctl.tkn, 1u);
+                            sm.tk.w[p] = wb; sm.tk.d[p] = did; sm.tk.m[p] = T;
+                        }
+                    }
+                    for (uint32_t t = 1; t < T; ++t) c_w[(size_t)t * kAndCand + o] = 0;
+                }
+                __syncthreads();
+            }
+            for (uint32_t i = tid; i < NW; i += XGM_WG) { sm.bitmap[i] = 0; sm.rankw[i] = 0xFFFFFFFFu; }
+            __syncthreads();
+            XGM_PHASE(5);
+        }
+        sl = sl_next;
+    }
+    if (phase_cycles && tid == 0) { XGM_PHASE(6); for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
+#undef XGM_PHASE
+
+    /* ---- group epilogue ---- */
+    __syncthreads();
+    topk_sort(sm.tk, tid);
+    if (my_matches) atomicAdd(&ctl.matches, my_matches);
+    __syncthreads();
+    const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
+    xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
+    for (uint32_t i = tid; i < n_out; i += XGM_WG) {
+        xgm_cand c;
+        c.wbits = sm.tk.w[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
+        out[i] = c;
+    }
+    if (tid == 0) {
+        xgm_group_hdr h;
+        h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
+        h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
+        ghdr_out[wk.slot] = h;
+    }
+}
 
 /* ---------------------------------------------------------------- merge kernel --------------- */
 
@@ -629,7 +1056,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
  * (groups of one shard, or shards after the all-gather).  did_mul/did_add remap shard-local
  * docids: global = (local - 1) * n_shards + shard + 1 (multi.h:69-73) when unshard != 0. */
 __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __restrict__ cand, const xgm_group_hdr* __restrict__ ghdr,
-                                                            uint32_t n_src, uint32_t k_stride_in, const uint32_t* __restrict__ kq,
+                                                            const uint32_t* __restrict__ goff, uint32_t k_stride_in, const uint32_t* __restrict__ kq,
                                                             uint32_t cap, uint32_t k_stride_out, xgm_hit* __restrict__ hits,
                                                             xgm_result_hdr* __restrict__ hdrs, const double* __restrict__ max_possible) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -645,9 +1072,10 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     if (tid == 0) { fill = 0; matches = 0; }
     for (uint32_t i = tid; i < cap; i += XGM_WG) { tk.w[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; }
     __syncthreads();
-    for (uint32_t sidx = 0; sidx < n_src; ++sidx) {
-        const xgm_group_hdr h = ghdr[(size_t)qi * n_src + sidx];
-        const xgm_cand* src = cand + ((size_t)qi * n_src + sidx) * k_stride_in;
+    const uint32_t g0 = goff[qi], g1 = goff[qi + 1];
+    for (uint32_t sidx = g0; sidx < g1; ++sidx) {
+        const xgm_group_hdr h = ghdr[sidx];
+        const xgm_cand* src = cand + (size_t)sidx * k_stride_in;
         if (tid == 0) { base = fill; fill += h.n_cand; matches += h.matches; }
         __syncthreads();
         for (uint32_t i = tid; i < h.n_cand; i += XGM_WG) {
@@ -777,14 +1205,14 @@ size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phras
 }
 
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
-    dim3 grid(L.n_groups, L.nq), block(XGM_WG);
+    dim3 grid(L.n_work), block(XGM_WG);
     const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
 #define XGM_LAUNCH(TT, PH)                                                                                   \
     do {                                                                                                     \
         auto kern = xgm_match_kernel<TT, PH>;                                                                \
         XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.n_groups, L.stripes_per_group, \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
                            L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);                                  \
     } while (0)
     if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
@@ -794,12 +1222,55 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
     return 0;
 }
 
-int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t n_src, uint32_t k_stride_in,
+size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group) {
+    return and_smem_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, stripes_per_group);
+}
+
+static unsigned long long* g_phase_cycles = nullptr;        /* device buffer, diagnostics only */
+
+int xgm_phase_cycles_fetch(unsigned long long* out8) {
+    if (!g_phase_cycles) return -1;
+    hipDeviceSynchronize();
+    hipMemcpy(out8, g_phase_cycles, 64, hipMemcpyDeviceToHost);
+    hipMemset(g_phase_cycles, 0, 64);
+    return 0;
+}
+
+int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream) {
+    static const bool timing = getenv("XGM_PHASE_TIMING") != nullptr;
+    if (timing && !g_phase_cycles) { hipMalloc((void**)&g_phase_cycles, 64); hipMemset(g_phase_cycles, 0, 64); }
+    dim3 grid(L.n_work), block(XGM_WG);
+    const size_t smem = xgm_and_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
+    if (smem > 160u * 1024u) return xgm_launch_error("and kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+    static bool occ_printed = false;
+    if (getenv("XGM_DEBUG_OCC") && !occ_printed) {
+        occ_printed = true;
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)xgm_and_kernel<uint8_t>, XGM_WG, smem);
+        hipFuncAttributes fa;
+        hipFuncGetAttributes(&fa, (const void*)xgm_and_kernel<uint8_t>);
+        fprintf(stderr, "XGM_OCC and_kernel: smem=%zu blocks/CU=%d regs=%d sharedStatic=%zu localSize=%zu maxDyn=%d n_work=%u\n", smem, nb, fa.numRegs,
+                fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes, L.n_work);
+    }
+    if (L.wide) {
+        auto kern = xgm_and_kernel<uint16_t>;
+        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, g_phase_cycles);
+    } else {
+        auto kern = xgm_and_kernel<uint8_t>;
+        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, g_phase_cycles);
+    }
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream) {
     const size_t smem = (size_t)cap * 16 + 64;
     XGM_HIP_CHECK(hipFuncSetAttribute((const void*)xgm_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, n_src, k_stride_in, kq, cap,
+    hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, goff, k_stride_in, kq, cap,
                        k_stride_out, hits, hdrs, max_possible);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -9,18 +9,23 @@
 struct xgm_match_launch {
     xgm_seg_dev seg;
     const xgm_dev_query* queries;     /* device, [nq] */
-    uint32_t nq, n_groups, stripes_per_group;
+    uint32_t nq, n_work;              /* queries in the batch, work units (= workgroups)          */
+    const xgm_work* work;             /* device, [n_work], heaviest first                         */
+    uint32_t stripes_per_group;       /* max stripes of a unit (sizes the LDS run table)          */
     uint32_t tab_terms;               /* max n_terms in the batch (LDS table rows)               */
     uint32_t cap;                     /* top-k buffer capacity, power of two >= k_max + XGM_WG    */
     uint32_t k_stride;                /* candidates reserved per (query, group)                   */
     bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
-    xgm_cand* cand;                   /* device, [nq][n_groups][k_stride]                         */
-    xgm_group_hdr* ghdr;              /* device, [nq][n_groups]                                   */
+    xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
+    xgm_group_hdr* ghdr;              /* device, [n_work]                                         */
 };
 
 size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
-int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t n_src, uint32_t k_stride_in,
+/* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
+size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
+int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
+int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream);
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
