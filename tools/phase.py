@@ -18,8 +18,8 @@ def close(self):
     out = (C.c_ulonglong * 8)()
     if L.xgm_debug_phase_cycles(out) == 0:
         v = list(out)
-        tot = sum(v[:7]) or 1
-        names = ["init", "P1work", "P1wait", "P3work", "P3wait", "P4+clear", "tail"]
+        tot = sum(v[:6]) or 1
+        names = ["init", "P1work", "P1wait", "P3work", "P3wait", "P4+clear", "-"]
         print("PHASES(all launches since start):", {n: round(100.0 * x / tot, 1) for n, x in zip(names, v)}, "stripes", v[7],
               "cycles/stripe", round(sum(v[1:6]) / max(1, v[7])))
     oc(self)

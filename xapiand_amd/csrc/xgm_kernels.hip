@@ -649,6 +649,7 @@ struct AndCtrl {
     uint32_t tkn, theta_valid, theta_d, pad;
     uint64_t theta_w;
     unsigned long long matches;
+    unsigned long long coarse;        /* bit i: some candidate has slot in [128 i, 128 i + 127] */
 };
 
 struct AndSmem {
@@ -748,7 +749,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
     for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
     for (uint32_t i = tid; i < NW; i += XGM_WG) { sm.bitmap[i] = 0; sm.rankw[i] = 0xFFFFFFFFu; }
     for (uint32_t i = tid; i < T * kAndCand; i += XGM_WG) c_w[i] = 0;
-    if (tid == 0) { ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; }
+    if (tid == 0) { ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; ctl.coarse = 0; }
     const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
     if (!empty) {
         for (uint32_t t = wave; t < T; t += XGM_WAVES) {
@@ -871,12 +872,14 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                     const uint32_t s0 = r.d0 - stripe_base, s1 = r.d1 - stripe_base;
                     uint32_t prev1 = (uint32_t)__shfl_up((int)s1, 1);
                     const uint32_t pw0 = lane == 0 ? 0xFFFFFFFFu : (prev1 >> 5);
+                    unsigned long long cbits = 0;
                     if (r.v0) {
                         const uint32_t o = obase + 2u * lane;
                         sm.c_slot[o] = (uint16_t)s0;
                         c_w[o] = (TabT)(r.w0 + 1u);
                         atomicOr(&sm.bitmap[s0 >> 5], 1u << (s0 & 31u));
                         if ((s0 >> 5) != pw0) atomicMin(&sm.rankw[s0 >> 5], o);
+                        cbits |= 1ull << (s0 >> 7);
                     }
                     if (r.v1) {
                         const uint32_t o = obase + 2u * lane + 1u;
@@ -884,86 +887,113 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                         c_w[o] = (TabT)(r.w1 + 1u);
                         atomicOr(&sm.bitmap[s1 >> 5], 1u << (s1 & 31u));
                         if ((s1 >> 5) != (s0 >> 5)) atomicMin(&sm.rankw[s1 >> 5], o);
+                        cbits |= 1ull << (s1 >> 7);
                     }
+                    /* wave-wide OR of the buckets touched by this block, one LDS atomic */
+                    uint32_t clo = (uint32_t)cbits, chi = (uint32_t)(cbits >> 32);
+                    for (int sh = 32; sh > 0; sh >>= 1) { clo |= (uint32_t)__shfl_xor((int)clo, sh); chi |= (uint32_t)__shfl_xor((int)chi, sh); }
+                    if (lane == 0) atomicOr(&ctl.coarse, ((unsigned long long)chi << 32) | clo);
                 }
             }
-            XGM_PHASE(1);
+            XGM_PHASE(1);                                          /* P1 work */
             __syncthreads();
             XGM_PHASE(2);
 
-            /* ---- P3: the other terms: decode only blocks whose docid range contains a candidate ---- */
-            for (uint32_t t = 1; t < T; ++t) {
-                const uint32_t rb = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb;      /* nb <= 64 */
-                uint32_t meta, first, woff, nfirst;
-                if (t == 1u) { meta = ha_meta; first = ha_first; woff = ha_word; nfirst = ha_next; }
-                else if (t == 2u) { meta = hb_meta; first = hb_first; woff = hb_word; nfirst = hb_next; }
-                else {                                              /* 4th term onwards: not prefetched */
-                    meta = first = woff = 0; nfirst = 0xFFFFFFFFu;
-                    if (lane < nb) {
-                        meta = seg.blk_meta[rb + lane]; first = seg.blk_first[rb + lane]; woff = seg.blk_word[rb + lane];
-                        nfirst = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
-                    }
-                }
-                bool need = false;
-                if (lane < nb) {
-                    const uint32_t nf = nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base;
-                    /* with many candidates per block nearly every block is hit: skip the two searches */
-                    need = n_c >= 4u * nb || cand_lower_bound(sm.c_slot, n_c, nf) > cand_lower_bound(sm.c_slot, n_c, first - stripe_base);
-                }
-                uint64_t mask = __ballot(need);
-                for (uint32_t x = 0; x < wave && mask; ++x) mask &= mask - 1u;          /* this wave's share */
-                TabT* row = c_w + (size_t)t * kAndCand;
-                while (mask) {
-                    /* up to 8 of my blocks: all payload loads first, then the decodes */
-                    uint32_t jj[8], n_here = 0;
-                    Words4 pv[8];
+            /* doclen of every candidate: requested now, consumed in P4 after the decodes */
+            uint32_t dl[kAndCand / XGM_WG];
 #pragma unroll
-                    for (uint32_t u = 0; u < 8u; ++u) {
-                        jj[u] = 64u;
-                        pv[u] = Words4{0, 0, 0, 0};
-                        if (mask) {
-                            jj[u] = (uint32_t)__builtin_ctzll(mask);
-                            for (uint32_t x = 0; x < XGM_WAVES && mask; ++x) mask &= mask - 1u;
-                            const uint32_t bm = __builtin_amdgcn_readlane(meta, jj[u]);
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[t] + __builtin_amdgcn_readlane(woff, jj[u]) + lane * 4u);
-                            n_here = u + 1u;
+            for (uint32_t c = 0; c < kAndCand / XGM_WG; ++c) {
+                const uint32_t o = tid + c * XGM_WG;
+                dl[c] = o < n_c ? seg.doclen[stripe_base + sm.c_slot[o]] : 0u;
+            }
+            const unsigned long long coarse = ctl.coarse;
+
+            /* ---- P3: the other terms: decode only blocks whose docid range may contain a candidate.
+             * Terms are taken two at a time so that the payload loads of both are in flight together;
+             * every wave takes each 4th needed block of each term. ---- */
+            auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
+                const uint32_t lo = (first - stripe_base) >> 7;
+                const uint32_t hi = ((nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base) - 1u) >> 7;
+                const unsigned long long m = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+                return (coarse & m) != 0ull;
+            };
+            for (uint32_t ta = 1; ta < T; ta += 2u) {
+                const uint32_t tb = ta + 1u;
+                const bool have_b = tb < T;
+                uint32_t a_meta, a_first, a_word, a_next, b_meta = 0, b_first = 0, b_word = 0, b_next = 0xFFFFFFFFu;
+                const uint32_t nba = re[ta * SPG + sl] - rs[ta * SPG + sl];
+                const uint32_t nbb = have_b ? re[tb * SPG + sl] - rs[tb * SPG + sl] : 0u;
+                if (ta == 1u) {
+                    a_meta = ha_meta; a_first = ha_first; a_word = ha_word; a_next = ha_next;
+                    b_meta = hb_meta; b_first = hb_first; b_word = hb_word; b_next = hb_next;
+                } else {                                            /* 4th term onwards: not prefetched */
+                    a_meta = a_first = a_word = 0; a_next = 0xFFFFFFFFu;
+                    const uint32_t rba = rs[ta * SPG + sl];
+                    if (lane < nba) {
+                        a_meta = seg.blk_meta[rba + lane]; a_first = seg.blk_first[rba + lane]; a_word = seg.blk_word[rba + lane];
+                        a_next = lane + 1u < nba ? seg.blk_first[rba + lane + 1u] : 0xFFFFFFFFu;
+                    }
+                    if (have_b) {
+                        const uint32_t rbb = rs[tb * SPG + sl];
+                        if (lane < nbb) {
+                            b_meta = seg.blk_meta[rbb + lane]; b_first = seg.blk_first[rbb + lane]; b_word = seg.blk_word[rbb + lane];
+                            b_next = lane + 1u < nbb ? seg.blk_first[rbb + lane + 1u] : 0xFFFFFFFFu;
                         }
                     }
-                    /* unpack four blocks at a time: their LDS round trips overlap */
+                }
+                uint64_t mask_a = __ballot(lane < nba && bucket_need(a_first, a_next));
+                uint64_t mask_b = __ballot(have_b && lane < nbb && bucket_need(b_first, b_next));
+                for (uint32_t x = 0; x < wave; ++x) { mask_a &= mask_a - 1u; mask_b &= mask_b - 1u; }      /* this wave's share */
+                TabT* row_a = c_w + (size_t)ta * kAndCand;
+                TabT* row_b = c_w + (size_t)tb * kAndCand;
+                while (mask_a | mask_b) {
+                    /* up to 4 + 4 of my blocks: all payload loads first, then the decodes */
+                    uint32_t jj[8], n_a = 0, n_b = 0;
+                    Words4 pv[8];
 #pragma unroll
-                    for (uint32_t u0 = 0; u0 < 8u; u0 += kAndWindows) {
-                        if (u0 < n_here) {
-                            uint32_t bmeta[kAndWindows], bfirst[kAndWindows];
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                        if (mask_a) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask_a);
+                            for (uint32_t x = 0; x < XGM_WAVES && mask_a; ++x) mask_a &= mask_a - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(a_meta, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[ta] + __builtin_amdgcn_readlane(a_word, jj[u]) + lane * 4u);
+                            n_a = u + 1u;
+                        }
+                    }
 #pragma unroll
-                            for (uint32_t v = 0; v < kAndWindows; ++v) {
-                                const uint32_t u = u0 + v;
-                                const uint32_t jv = jj[u] < 64u ? jj[u] : 0u;
-                                bmeta[v] = __builtin_amdgcn_readlane(meta, jv);
-                                bfirst[v] = __builtin_amdgcn_readlane(first, jv);
-                                uint32_t* st = my_stage + v * kStageWords;
-                                if (u < n_here && lane * 4u < payload_words(bmeta[v])) {
-                                    st[lane * 4u] = pv[u].a; st[lane * 4u + 1] = pv[u].b; st[lane * 4u + 2] = pv[u].c; st[lane * 4u + 3] = pv[u].d;
-                                }
+                    for (uint32_t u = 4; u < 8u; ++u) {
+                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                        if (mask_b) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask_b);
+                            for (uint32_t x = 0; x < XGM_WAVES && mask_b; ++x) mask_b &= mask_b - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(b_meta, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[tb] + __builtin_amdgcn_readlane(b_word, jj[u]) + lane * 4u);
+                            n_b = u - 3u;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) {
+                        const bool is_b = u >= 4u;
+                        if (is_b ? (u - 4u < n_b) : (u < n_a)) {
+                            const uint32_t bmeta = __builtin_amdgcn_readlane(is_b ? b_meta : a_meta, jj[u]);
+                            const uint32_t bfirst = __builtin_amdgcn_readlane(is_b ? b_first : a_first, jj[u]);
+                            TabT* row = is_b ? row_b : row_a;
+                            if (lane * 4u < payload_words(bmeta)) {
+                                my_stage[lane * 4u] = pv[u].a; my_stage[lane * 4u + 1] = pv[u].b; my_stage[lane * 4u + 2] = pv[u].c; my_stage[lane * 4u + 3] = pv[u].d;
                             }
                             wave_lds_fence();
-                            DecodedPair r[kAndWindows];
-#pragma unroll
-                            for (uint32_t v = 0; v < kAndWindows; ++v) r[v] = unpack_staged<false>(my_stage + v * kStageWords, bfirst[v], bmeta[v], lane);
+                            DecodedPair r = unpack_staged<false>(my_stage, bfirst, bmeta, lane);
                             wave_lds_fence();
-#pragma unroll
-                            for (uint32_t v = 0; v < kAndWindows; ++v) {
-                                if (u0 + v < n_here) {
-                                    if (r[v].v0) {
-                                        const uint32_t sl0 = r[v].d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
-                                        const uint32_t bm = sm.bitmap[wd];
-                                        if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r[v].w0 + 1u);
-                                    }
-                                    if (r[v].v1) {
-                                        const uint32_t sl1 = r[v].d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
-                                        const uint32_t bm = sm.bitmap[wd];
-                                        if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r[v].w1 + 1u);
-                                    }
-                                }
+                            if (r.v0) {
+                                const uint32_t sl0 = r.d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
+                                const uint32_t bm = sm.bitmap[wd];
+                                if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w0 + 1u);
+                            }
+                            if (r.v1) {
+                                const uint32_t sl1 = r.d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
+                                const uint32_t bm = sm.bitmap[wd];
+                                if ((bm >> bit) & 1u) row[sm.rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w1 + 1u);
                             }
                         }
                     }
@@ -999,7 +1029,10 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                         ++my_matches;
                         const uint32_t did = stripe_base + sm.c_slot[o];
                         /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
-                        const double len = (double)seg.doclen[did];
+                        uint32_t dlen = dl[0];
+#pragma unroll
+                        for (uint32_t c = 1; c < kAndCand / XGM_WG; ++c) dlen = (i0 == c * XGM_WG) ? dl[c] : dlen;
+                        const double len = (double)dlen;
                         double normlen = len * q.len_factor;
                         normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
                         const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
@@ -1022,12 +1055,13 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                 __syncthreads();
             }
             for (uint32_t i = tid; i < NW; i += XGM_WG) { sm.bitmap[i] = 0; sm.rankw[i] = 0xFFFFFFFFu; }
+            if (tid == 0) ctl.coarse = 0;
             __syncthreads();
             XGM_PHASE(5);
         }
         sl = sl_next;
     }
-    if (phase_cycles && tid == 0) { XGM_PHASE(6); for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
+    if (phase_cycles && tid == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
 #undef XGM_PHASE
 
     /* ---- group epilogue ---- */
