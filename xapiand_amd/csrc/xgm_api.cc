@@ -388,6 +388,7 @@ struct BatchPlan {
     std::vector<uint32_t> goff;        /* [nq+1] first output slot of each query */
     bool phrase, wide;
     bool and_only;      /* every query is a plain conjunction of >= 2 terms → xgm_and_kernel */
+    bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
 };
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
@@ -416,20 +417,20 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         /* a batch mixing long AND/OR queries with phrases would blow the LDS budget: caller splits */
         return XGM_UNSUPPORTED;
     }
-    bp->cap = std::max(512u, next_pow2(bp->k_max + XGM_WG));
+    static const bool no_andw = getenv("XGM_NO_ANDW") != nullptr;                    /* A/B switch for measurements */
     const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
+    const uint32_t k_pad = next_pow2(bp->k_max);
+    bp->andw = bp->and_only && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP;
+    bp->cap = bp->andw ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
      * plus about one partial block per stripe a term touches).  Every query is cut into units of
-     * about total/(8 units per CU) cost — heavy queries into many — bounded by the LDS run table
+     * about total/(units the chip holds) cost — heavy queries into many — bounded by the LDS run table
      * (8 B per term and stripe → at most spg_max stripes per unit) and by the merge kernel's sort
      * capacity (units × k candidates). */
-    const uint32_t spg_max = std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
+    const uint32_t spg_max = bp->andw ? 32u : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
     const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
-    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, XGM_MERGE_CAP / next_pow2(bp->k_max))));
-    if ((uint64_t)g_min * next_pow2(bp->k_max) > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
-    /* measured on MI355X (profiles/r01_v3_phase_cycles.txt): a stripe costs ~8k cycles of fixed
-     * latency chain (candidate block fetch, doclen gather, barriers) plus ~0.9k cycles per posting
-     * block of the other terms; a unit's time is stripes x that, so BOTH terms matter */
+    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, XGM_MERGE_CAP / k_pad)));
+    if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     std::vector<double> cost(nq);
     double total_cost = 0;
     for (uint32_t i = 0; i < nq; ++i) {
@@ -446,7 +447,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         cost[i] = 8.0 * stripes + 0.9 * blocks + 1.0;
         total_cost += cost[i];
     }
-    const double unit_cost = std::max(1.0, total_cost / 3072.0);
+    const double unit_cost = std::max(1.0, total_cost / (bp->andw ? 12288.0 : 3072.0));
     bp->goff.assign(nq + 1, 0);
     bp->work.clear();
     uint32_t spg_used = 1;
@@ -470,7 +471,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
     for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
-    const size_t smem = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
+    const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
+                                 : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
     bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));
     bp->k_stride_c = bp->k_max;
@@ -536,7 +538,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         ++idx->prof_used;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream))) return rc;
+    if ((rc = bp.andw ? xgm_launch_andw(L, stream) : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream))) return rc;
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
                                d_hdrs, s->d_maxposs, stream)))

@@ -1084,6 +1084,392 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
     }
 }
 
+/* ---------------------------------------------------------------- wave-autonomous AND kernel ---- */
+
+/* Same algorithm as xgm_and_kernel, different decomposition: ONE WAVE owns a work unit (a query and a
+ * short stripe range) and runs it start to finish out of a private LDS slice — no workgroup barrier
+ * anywhere, so a CU keeps ~20 independent instruction streams in flight instead of 4-6 barrier-coupled
+ * groups, and the per-stripe latency chain of one unit is covered by the others.  Wave-uniform state
+ * (top-k fill, threshold, coarse mask) lives in registers.  Used when first+maxitems <= kAndwMaxK. */
+constexpr uint32_t kAndwCand = 512;                  /* candidates per chunk = 4 blocks of term 0 */
+constexpr uint32_t kAndwChunkBlocks = kAndwCand / XGM_BLOCK;
+constexpr uint32_t kAndwMaxK = 192;                  /* top-k buffer cap 256 */
+
+__host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
+    size_t off = 0;
+    off += (size_t)cap * 8;                                    /* tk_w */
+    off += (size_t)cap * 4;                                    /* tk_d */
+    off += (size_t)kStageWords * 4;                            /* stage */
+    off += (size_t)(W / 32u) * 4;                              /* bitmap */
+    off += (size_t)2 * T * spg * 4;                            /* runs */
+    off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
+    off += (size_t)kAndwCand * 2;                              /* c_slot */
+    off += (size_t)T * kAndwCand * tab_elem;                   /* c_w */
+    return (off + 15) & ~(size_t)15;
+}
+
+/* bitonic sort of cap (power of two, >= 128) candidates by one wave; best first */
+__device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t lane) {
+    for (uint32_t size = 2; size <= cap; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            wave_lds_fence();
+            for (uint32_t i = lane; i < (cap >> 1); i += 64u) {
+                const uint32_t lo = 2u * i - (i & (stride - 1u)), hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const uint64_t aw = w[lo], bw = w[hi];
+                const uint32_t ad = d[lo], bd = d[hi];
+                const bool swap = asc ? cand_before(bw, bd, aw, ad) : cand_before(aw, ad, bw, bd);
+                if (swap) { w[lo] = bw; w[hi] = aw; d[lo] = bd; d[hi] = ad; }
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+template <typename TabT>
+__global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
+                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                           xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
+    if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
+    const xgm_work wk = work[unit];
+    const xgm_dev_query& q = queries[wk.qi];
+    const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
+    const uint32_t T = q.n_terms, k = q.k, SPG = spg_max;
+    const unsigned long long t_unit_start = __builtin_readcyclecounter();
+
+    /* private LDS slice */
+    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG);
+    size_t off = 0;
+    uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
+    uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
+    uint32_t* stage = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kStageWords * 4;
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+    uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
+    uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
+    uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
+    uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)kAndwCand * 2;
+    TabT* c_w = reinterpret_cast<TabT*>(base + off);
+
+    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
+    const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
+    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
+
+    for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = lane; i < 2u * tab_terms * SPG; i += 64u) rs[i] = 0;        /* rs and re are adjacent */
+    for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
+    for (uint32_t i = lane; i < T * kAndwCand; i += 64u) c_w[i] = 0;
+    wave_lds_fence();
+
+    /* block ranges of every term inside the unit's docid range → run table */
+    uint64_t tbase_reg = 0;                                        /* lane t holds term_word[term t] */
+    if (!empty) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t id = q.term_id[t];
+            const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+            const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+            const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+            if (lane == t) tbase_reg = seg.term_word[id];
+            for (uint32_t i = c + lane; i < e; i += 64u) {
+                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
+                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                if (s != sp) rs[t * SPG + s] = i;
+                if (s != sn) re[t * SPG + s] = i + 1u;
+            }
+        }
+    }
+    wave_lds_fence();
+    auto tbase = [&](uint32_t t) {
+        return ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tbase_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tbase_reg, t);
+    };
+
+    uint32_t tkn = 0;                                              /* wave-uniform top-k state */
+    bool theta_valid = false;
+    uint64_t theta_w = 0;
+    uint32_t theta_d = 0;
+    unsigned long long matches = 0;                                /* per lane, reduced at the end */
+    const uint32_t n_local = empty ? 0u : s_end - s_begin;
+
+    auto next_active = [&](uint32_t from) {
+        uint32_t x = from;
+        for (; x < n_local; ++x) {
+            bool all = true;
+            for (uint32_t t = 0; t < T; ++t) all = all && (re[t * SPG + x] != rs[t * SPG + x]);
+            if (all) break;
+        }
+        return x;
+    };
+
+    /* software-pipelined header registers: lane j holds block j of the run */
+    uint32_t h0_meta = 0, h0_first = 0, h0_word = 0;
+    uint32_t ha_meta = 0, ha_first = 0, ha_word = 0, ha_next = 0;
+    uint32_t hb_meta = 0, hb_first = 0, hb_word = 0, hb_next = 0;
+    auto issue_headers = [&](uint32_t x) {
+        const uint32_t r0 = rs[x], n0b = re[x] - r0;
+        if (lane < n0b && lane < kAndwChunkBlocks) {
+            h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
+        }
+        {
+            const uint32_t rb = rs[1u * SPG + x], nb = re[1u * SPG + x] - rb;
+            if (lane < nb) {
+                ha_meta = seg.blk_meta[rb + lane]; ha_first = seg.blk_first[rb + lane]; ha_word = seg.blk_word[rb + lane];
+                ha_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+            }
+        }
+        if (T >= 3u) {
+            const uint32_t rb = rs[2u * SPG + x], nb = re[2u * SPG + x] - rb;
+            if (lane < nb) {
+                hb_meta = seg.blk_meta[rb + lane]; hb_first = seg.blk_first[rb + lane]; hb_word = seg.blk_word[rb + lane];
+                hb_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+            }
+        }
+    };
+
+    uint32_t sl = next_active(0);
+    if (sl < n_local) issue_headers(sl);
+    while (sl < n_local) {
+        const uint32_t stripe_base = (s_begin + sl) << SB;
+        const uint32_t r0 = rs[sl], r0e = re[sl];
+        const uint32_t sl_next = next_active(sl + 1u);
+
+        for (uint32_t cb = r0; cb < r0e; cb += kAndwChunkBlocks) {
+            const uint32_t nblk0 = r0e - cb < kAndwChunkBlocks ? r0e - cb : kAndwChunkBlocks;
+            /* ---- P1: term-0 blocks of the chunk → candidates (ordinals follow docid order) ---- */
+            uint32_t m0 = h0_meta, f0 = h0_first, w0 = h0_word;
+            if (cb != r0) {
+                m0 = lane < nblk0 ? seg.blk_meta[cb + lane] : 0u;
+                f0 = lane < nblk0 ? seg.blk_first[cb + lane] : 0u;
+                w0 = lane < nblk0 ? seg.blk_word[cb + lane] : 0u;
+            }
+            const uint32_t cnt0 = lane < nblk0 ? XGM_META_COUNT(m0) : 0u;
+            const uint32_t incl = wave_incl_scan(cnt0);
+            const uint32_t n_c = __builtin_amdgcn_readlane(incl, 63);
+            Words4 p0[kAndwChunkBlocks];
+#pragma unroll
+            for (uint32_t j = 0; j < kAndwChunkBlocks; ++j) {
+                p0[j] = Words4{0, 0, 0, 0};
+                if (j < nblk0) {
+                    const uint32_t mj = __builtin_amdgcn_readlane(m0, j);
+                    if (lane * 4u < payload_words(mj)) p0[j] = *reinterpret_cast<const Words4*>(seg.words + tbase(0) + __builtin_amdgcn_readlane(w0, j) + lane * 4u);
+                }
+            }
+            unsigned long long coarse = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < kAndwChunkBlocks; ++j) {
+                if (j < nblk0) {
+                    const uint32_t meta = __builtin_amdgcn_readlane(m0, j);
+                    const uint32_t obase = __builtin_amdgcn_readlane(incl, j) - XGM_META_COUNT(meta);
+                    const uint32_t first = __builtin_amdgcn_readlane(f0, j);
+                    if (lane * 4u < payload_words(meta)) {
+                        stage[lane * 4u] = p0[j].a; stage[lane * 4u + 1] = p0[j].b; stage[lane * 4u + 2] = p0[j].c; stage[lane * 4u + 3] = p0[j].d;
+                    }
+                    wave_lds_fence();
+                    DecodedPair r = unpack_staged<false>(stage, first, meta, lane);
+                    wave_lds_fence();
+                    const uint32_t s0 = r.d0 - stripe_base, s1 = r.d1 - stripe_base;
+                    const uint32_t prev1 = (uint32_t)__shfl_up((int)s1, 1);
+                    const uint32_t pw0 = lane == 0 ? 0xFFFFFFFFu : (prev1 >> 5);
+                    unsigned long long cbits = 0;
+                    if (r.v0) {
+                        const uint32_t o = obase + 2u * lane;
+                        c_slot[o] = (uint16_t)s0;
+                        c_w[o] = (TabT)(r.w0 + 1u);
+                        atomicOr(&bitmap[s0 >> 5], 1u << (s0 & 31u));
+                        /* first candidate of its word inside this block; a later block can only add larger ordinals */
+                        if ((s0 >> 5) != pw0 && rankw[s0 >> 5] == 0xFFFFu) rankw[s0 >> 5] = (uint16_t)o;
+                        cbits |= 1ull << (s0 >> 7);
+                    }
+                    if (r.v1) {
+                        const uint32_t o = obase + 2u * lane + 1u;
+                        c_slot[o] = (uint16_t)s1;
+                        c_w[o] = (TabT)(r.w1 + 1u);
+                        atomicOr(&bitmap[s1 >> 5], 1u << (s1 & 31u));
+                        if ((s1 >> 5) != (s0 >> 5) && rankw[s1 >> 5] == 0xFFFFu) rankw[s1 >> 5] = (uint16_t)o;
+                        cbits |= 1ull << (s1 >> 7);
+                    }
+                    uint32_t clo = (uint32_t)cbits, chi = (uint32_t)(cbits >> 32);
+                    for (int sh = 32; sh > 0; sh >>= 1) { clo |= (uint32_t)__shfl_xor((int)clo, sh); chi |= (uint32_t)__shfl_xor((int)chi, sh); }
+                    coarse |= ((unsigned long long)chi << 32) | clo;
+                    wave_lds_fence();                                   /* rankw of this block visible to the next */
+                }
+            }
+
+            /* doclen of the first 256 candidates: requested now, consumed in P4 */
+            uint32_t dl[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; ++c) {
+                const uint32_t o = lane + c * 64u;
+                dl[c] = o < n_c ? seg.doclen[stripe_base + c_slot[o]] : 0u;
+            }
+
+            /* ---- P3: other terms, two at a time; only blocks whose 128-slot buckets hold a candidate ---- */
+            auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
+                const uint32_t lo = (first - stripe_base) >> 7;
+                const uint32_t hi = ((nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base) - 1u) >> 7;
+                const unsigned long long m = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+                return (coarse & m) != 0ull;
+            };
+            for (uint32_t ta = 1; ta < T; ta += 2u) {
+                const uint32_t tb = ta + 1u;
+                const bool have_b = tb < T;
+                uint32_t a_meta, a_first, a_word, a_next, b_meta = 0, b_first = 0, b_word = 0, b_next = 0xFFFFFFFFu;
+                const uint32_t nba = re[ta * SPG + sl] - rs[ta * SPG + sl];
+                const uint32_t nbb = have_b ? re[tb * SPG + sl] - rs[tb * SPG + sl] : 0u;
+                if (ta == 1u) {
+                    a_meta = ha_meta; a_first = ha_first; a_word = ha_word; a_next = ha_next;
+                    b_meta = hb_meta; b_first = hb_first; b_word = hb_word; b_next = hb_next;
+                } else {
+                    a_meta = a_first = a_word = 0; a_next = 0xFFFFFFFFu;
+                    const uint32_t rba = rs[ta * SPG + sl];
+                    if (lane < nba) {
+                        a_meta = seg.blk_meta[rba + lane]; a_first = seg.blk_first[rba + lane]; a_word = seg.blk_word[rba + lane];
+                        a_next = lane + 1u < nba ? seg.blk_first[rba + lane + 1u] : 0xFFFFFFFFu;
+                    }
+                    if (have_b) {
+                        const uint32_t rbb = rs[tb * SPG + sl];
+                        if (lane < nbb) {
+                            b_meta = seg.blk_meta[rbb + lane]; b_first = seg.blk_first[rbb + lane]; b_word = seg.blk_word[rbb + lane];
+                            b_next = lane + 1u < nbb ? seg.blk_first[rbb + lane + 1u] : 0xFFFFFFFFu;
+                        }
+                    }
+                }
+                uint64_t mask_a = __ballot(lane < nba && bucket_need(a_first, a_next));
+                uint64_t mask_b = __ballot(have_b && lane < nbb && bucket_need(b_first, b_next));
+                const uint64_t tba = tbase(ta), tbb = have_b ? tbase(tb) : 0ull;
+                TabT* row_a = c_w + (size_t)ta * kAndwCand;
+                TabT* row_b = c_w + (size_t)tb * kAndwCand;
+                while (mask_a | mask_b) {
+                    uint32_t jj[8], n_a = 0, n_b = 0;
+                    Words4 pv[8];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                        if (mask_a) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask_a);
+                            mask_a &= mask_a - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(a_meta, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tba + __builtin_amdgcn_readlane(a_word, jj[u]) + lane * 4u);
+                            n_a = u + 1u;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 4; u < 8u; ++u) {
+                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                        if (mask_b) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask_b);
+                            mask_b &= mask_b - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(b_meta, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbb + __builtin_amdgcn_readlane(b_word, jj[u]) + lane * 4u);
+                            n_b = u - 3u;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; ++u) {
+                        const bool is_b = u >= 4u;
+                        if (is_b ? (u - 4u < n_b) : (u < n_a)) {
+                            const uint32_t bmeta = __builtin_amdgcn_readlane(is_b ? b_meta : a_meta, jj[u]);
+                            const uint32_t bfirst = __builtin_amdgcn_readlane(is_b ? b_first : a_first, jj[u]);
+                            TabT* row = is_b ? row_b : row_a;
+                            if (lane * 4u < payload_words(bmeta)) {
+                                stage[lane * 4u] = pv[u].a; stage[lane * 4u + 1] = pv[u].b; stage[lane * 4u + 2] = pv[u].c; stage[lane * 4u + 3] = pv[u].d;
+                            }
+                            wave_lds_fence();
+                            DecodedPair r = unpack_staged<false>(stage, bfirst, bmeta, lane);
+                            wave_lds_fence();
+                            if (r.v0) {
+                                const uint32_t sl0 = r.d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
+                                const uint32_t bm = bitmap[wd];
+                                if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w0 + 1u);
+                            }
+                            if (r.v1) {
+                                const uint32_t sl1 = r.d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
+                                const uint32_t bm = bitmap[wd];
+                                if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w1 + 1u);
+                            }
+                        }
+                    }
+                }
+            }
+            wave_lds_fence();
+
+            /* headers of the next active stripe: in flight while this one is scored */
+            if (cb + kAndwChunkBlocks >= r0e && sl_next < n_local) issue_headers(sl_next);
+
+            /* ---- P4: candidates present in every term are matches: BM25 + top-k (64 per round) ---- */
+            for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
+                if (tkn + 64u > cap) {
+                    wave_topk_sort(tk_w, tk_d, cap, lane);
+                    tkn = tkn < k ? tkn : k;
+                    if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
+                    for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
+                    wave_lds_fence();
+                }
+                const uint32_t o = i0 + lane;
+                bool take = false;
+                uint64_t wb = 0;
+                uint32_t did = 0;
+                if (o < n_c) {
+                    bool pass = true;
+                    for (uint32_t t = 1; t < T; ++t) pass = pass && c_w[(size_t)t * kAndwCand + o] != 0;
+                    if (pass) {
+                        ++matches;
+                        did = stripe_base + c_slot[o];
+                        uint32_t dlen;
+                        if (i0 < 256u) {
+                            dlen = dl[0];
+#pragma unroll
+                            for (uint32_t c = 1; c < 4u; ++c) dlen = (i0 == c * 64u) ? dl[c] : dlen;
+                        } else {
+                            dlen = seg.doclen[did];
+                        }
+                        /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
+                        const double len = (double)dlen;
+                        double normlen = len * q.len_factor;
+                        normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+                        const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                        double weight = 0.0;                   /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
+                        for (uint32_t t = 0; t < T; ++t) {
+                            const double wdf = (double)((uint32_t)c_w[(size_t)t * kAndwCand + o] - 1u);
+                            const double denom = denom_len + wdf;
+                            weight = weight + q.termweight[t] * (wdf / denom);
+                        }
+                        wb = (uint64_t)__double_as_longlong(weight);
+                        take = !theta_valid || cand_before(wb, did, theta_w, theta_d);
+                    }
+                    for (uint32_t t = 1; t < T; ++t) c_w[(size_t)t * kAndwCand + o] = 0;
+                }
+                const uint64_t tm = __ballot(take);
+                if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; }
+                tkn += (uint32_t)__popcll(tm);
+            }
+            for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
+            wave_lds_fence();
+        }
+        sl = sl_next;
+    }
+
+    /* ---- unit epilogue ---- */
+    wave_topk_sort(tk_w, tk_d, cap, lane);
+    for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
+    const uint32_t n_out = tkn < k ? tkn : k;
+    xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
+    for (uint32_t i = lane; i < n_out; i += 64u) {
+        xgm_cand c;
+        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = T;
+        out[i] = c;
+    }
+    if (lane == 0) {
+        xgm_group_hdr h;
+        h.matches = matches; h.n_cand = n_out; h.pad = 0;
+        h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
+        ghdr_out[wk.slot] = h;
+    }
+}
+
 /* ---------------------------------------------------------------- merge kernel --------------- */
 
 /* One workgroup per query.  Sources: n_src candidate lists of up to k_stride entries
@@ -1294,6 +1680,27 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream) {
         auto kern = xgm_and_kernel<uint8_t>;
         XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, g_phase_cycles);
+    }
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg) {
+    return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg);
+}
+
+int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
+    dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
+    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
+    if (smem > 160u * 1024u) return xgm_launch_error("andw kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+    if (L.wide) {
+        auto kern = xgm_andw_kernel<uint16_t>;
+        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
+    } else {
+        auto kern = xgm_andw_kernel<uint8_t>;
+        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
     }
     XGM_HIP_CHECK(hipGetLastError());
     return 0;

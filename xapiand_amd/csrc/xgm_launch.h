@@ -25,6 +25,9 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
 size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
+/* wave-autonomous variant: one wave per work unit, no workgroup barriers (first+maxitems <= 192) */
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
+int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream);
