@@ -173,7 +173,7 @@ def main():
             "p99_latency_us": lat[int(len(lat) * 0.99)] * 1e6 if lat else None,
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,
                       "device_bytes": info.device_bytes, "build_seconds": build_s},
-            "roofline": {"bound": "hbm", "kernel": "xgm_match_kernel", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": ("xgm_andw_kernel" if args.op == "AND" and k <= 192 else "xgm_match_kernel"), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms": kernel_ms},
         }

@@ -429,7 +429,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
      * capacity (units × k candidates). */
     const uint32_t spg_max = bp->andw ? 32u : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
     const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
-    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, XGM_MERGE_CAP / k_pad)));
+    /* few queries in flight (latency mode): a smaller merge (sort of <= 4096) beats more units */
+    const uint32_t merge_budget = nq <= 4u ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;
+    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     std::vector<double> cost(nq);
     double total_cost = 0;
@@ -474,7 +476,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
-    bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));
+    bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));     /* fixed window of k_max per unit */
     bp->k_stride_c = bp->k_max;
     return XGM_OK;
 }

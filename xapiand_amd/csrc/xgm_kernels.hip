@@ -1488,22 +1488,25 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     tk.cap = cap;
     unsigned long long& matches = *reinterpret_cast<unsigned long long*>(smem + (size_t)cap * 16);
     uint32_t& fill = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 8);
-    uint32_t& base = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 12);
     if (tid == 0) { fill = 0; matches = 0; }
-    for (uint32_t i = tid; i < cap; i += XGM_WG) { tk.w[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; }
     __syncthreads();
-    const uint32_t g0 = goff[qi], g1 = goff[qi + 1];
-    for (uint32_t sidx = g0; sidx < g1; ++sidx) {
-        const xgm_group_hdr h = ghdr[sidx];
-        const xgm_cand* src = cand + (size_t)sidx * k_stride_in;
-        if (tid == 0) { base = fill; fill += h.n_cand; matches += h.matches; }
-        __syncthreads();
-        for (uint32_t i = tid; i < h.n_cand; i += XGM_WG) {
-            xgm_cand c = src[i];
-            tk.w[base + i] = c.wbits; tk.d[base + i] = c.did; tk.m[base + i] = c.subqs;
+    /* gather: unit u of the query owns the fixed window [u * k_in, (u+1) * k_in) of the sort buffer
+     * (k_in = its candidate stride); empty places get the sentinel.  Fully parallel: no prefix sums. */
+    const uint32_t g0 = goff[qi], n_src = goff[qi + 1] - g0;
+    for (uint32_t x = tid; x < cap; x += XGM_WG) {
+        const uint32_t u = x / k_stride_in, j = x - u * k_stride_in;
+        uint64_t w = 0; uint32_t d = 0xFFFFFFFFu, m = 0xFFFFFFFFu;
+        if (u < n_src) {
+            const xgm_group_hdr h = ghdr[g0 + u];
+            if (j < h.n_cand) {
+                const xgm_cand c = cand[(size_t)(g0 + u) * k_stride_in + j];
+                w = c.wbits; d = c.did; m = c.subqs;
+            }
+            if (j == 0) { atomicAdd(&matches, (unsigned long long)h.matches); atomicAdd(&fill, h.n_cand); }
         }
-        __syncthreads();
+        tk.w[x] = w; tk.d[x] = d; tk.m[x] = m;
     }
+    __syncthreads();
     topk_sort(tk, tid);
     const uint32_t k = kq[qi];
     const uint32_t n = fill < k ? fill : k;
@@ -1614,6 +1617,18 @@ size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_
 
 /* ---------------------------------------------------------------- launchers ------------------- */
 
+/* hipFuncSetAttribute(MaxDynamicSharedMemorySize) only when a launch needs more than any before it
+ * (the call costs microseconds that the single-query latency path would pay three times). */
+#include <atomic>
+template <class K>
+static int ensure_dyn_smem(K kern, size_t smem, std::atomic<size_t>& seen) {
+    if (smem <= seen.load(std::memory_order_relaxed)) return 0;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return xgm_launch_error("hipFuncSetAttribute", (int)e, hipGetErrorString(e));
+    seen.store(smem, std::memory_order_relaxed);
+    return 0;
+}
+
 #define XGM_HIP_CHECK(expr)                                                                     \
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
@@ -1631,7 +1646,8 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
 #define XGM_LAUNCH(TT, PH)                                                                                   \
     do {                                                                                                     \
         auto kern = xgm_match_kernel<TT, PH>;                                                                \
-        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        static std::atomic<size_t> seen{0};                                                                  \
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
                            L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);                                  \
     } while (0)
@@ -1674,11 +1690,13 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream) {
     }
     if (L.wide) {
         auto kern = xgm_and_kernel<uint16_t>;
-        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, g_phase_cycles);
     } else {
         auto kern = xgm_and_kernel<uint8_t>;
-        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, g_phase_cycles);
     }
     XGM_HIP_CHECK(hipGetLastError());
@@ -1695,11 +1713,13 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
     if (smem > 160u * 1024u) return xgm_launch_error("andw kernel LDS budget", 0, "LDS request exceeds 160 KiB");
     if (L.wide) {
         auto kern = xgm_andw_kernel<uint16_t>;
-        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
     } else {
         auto kern = xgm_andw_kernel<uint8_t>;
-        XGM_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
     }
     XGM_HIP_CHECK(hipGetLastError());
@@ -1710,7 +1730,7 @@ int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream) {
     const size_t smem = (size_t)cap * 16 + 64;
-    XGM_HIP_CHECK(hipFuncSetAttribute((const void*)xgm_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, goff, k_stride_in, kq, cap,
                        k_stride_out, hits, hdrs, max_possible);
     XGM_HIP_CHECK(hipGetLastError());
@@ -1721,7 +1741,7 @@ int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_h
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
                             hipStream_t stream) {
     const size_t smem = (size_t)cap * 16 + 64;
-    XGM_HIP_CHECK(hipFuncSetAttribute((const void*)xgm_merge_shards_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_shards_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_shards, nq,
                        k_stride, kq, cap, hits, hdrs);
     XGM_HIP_CHECK(hipGetLastError());
