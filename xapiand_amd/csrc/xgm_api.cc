@@ -149,6 +149,8 @@ static void fill_view(xgm_index* idx) {
     v.positions = (const uint32_t*)idx->d_sections[XGM_S_POSITIONS];
     v.stripe_bits = idx->hdr.stripe_bits;
     v.lastdocid = idx->hdr.lastdocid;
+    v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0;
+    v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
 /* Host copies of the dictionary arrays from a host blob. */
@@ -190,6 +192,7 @@ extern "C" int xgm_index_open(const char* segment_path, int device, uint64_t rev
     idx->device_bytes = h->file_bytes;
     for (int s = 0; s < XGM_S_COUNT; ++s) idx->d_sections[s] = (char*)idx->d_blob + h->sec_off[s];
     fill_view(idx);
+    if ((rc = xgm_build_dense(idx))) { xgm_index_close(idx); return rc; }
     *out = idx;
     return XGM_OK;
 }
@@ -204,6 +207,9 @@ extern "C" void xgm_index_close(xgm_index* idx) {
         for (int s = 0; s < XGM_S_COUNT; ++s) if (idx->d_sections[s]) hipFree(idx->d_sections[s]);
     }
     if (idx->d_blob) hipFree(idx->d_blob);
+    if (idx->d_dense_id) hipFree(idx->d_dense_id);
+    if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
+    if (idx->d_dense_data) hipFree(idx->d_dense_data);
     delete idx;
 }
 

@@ -1,0 +1,182 @@
+/* Probe containers for dense terms (see xgm_segment.h).  Built on the device from the block-encoded
+ * posting lists when an index is opened — an acceleration structure of the query path, like a
+ * bitmap index beside the compressed lists; the reference's closest analogue is the B-tree skip
+ * (find_entry) that GlassPostList::skip_to uses to avoid scanning (glass_postlist.cc:959-991). */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <vector>
+
+#include "xgm_device.h"
+#include "xgm_internal.h"
+#include "xgm_launch.h"
+
+namespace {
+
+#define DN_TRY(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) { rc = xgm_launch_error(#expr, (int)e_, hipGetErrorString(e_)); goto fail; } \
+    } while (0)
+
+constexpr uint32_t kStage = 272;
+
+__device__ __forceinline__ uint32_t dn_extract(const uint32_t* s, uint32_t idx, uint32_t bw) {
+    uint32_t bit = idx * bw, w = bit >> 5;
+    uint32_t v = __builtin_amdgcn_alignbit(s[w + 1], s[w], bit & 31u);
+    return bw >= 32u ? v : (v & ((1u << bw) - 1u));
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dn_dpp(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ uint32_t dn_scan(uint32_t v) {
+    v += dn_dpp<0x111, 0xf>(v); v += dn_dpp<0x112, 0xf>(v); v += dn_dpp<0x114, 0xf>(v); v += dn_dpp<0x118, 0xf>(v);
+    v += dn_dpp<0x142, 0xa>(v); v += dn_dpp<0x143, 0xc>(v);
+    return v;
+}
+
+/* postings per (dense term, stripe) */
+__global__ void k_dense_count(xgm_seg_dev seg, const uint32_t* __restrict__ dense_terms, uint32_t n_stripes, uint32_t* __restrict__ cnt) {
+    const uint32_t d = blockIdx.y, t = dense_terms[d];
+    const uint64_t b0 = seg.term_blk[t], b1 = seg.term_blk[t + 1];
+    for (uint64_t b = b0 + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b < b1; b += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&cnt[(size_t)d * n_stripes + (seg.blk_first[b] >> seg.stripe_bits)], XGM_META_COUNT(seg.blk_meta[b]));
+}
+
+/* one workgroup per (stripe, dense term): decode the run, write bitmap + rank + wdf bytes */
+__global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint32_t* __restrict__ dense_terms, uint32_t n_stripes,
+                                                    const uint32_t* __restrict__ dir, unsigned char* __restrict__ data) {
+    __shared__ uint32_t bitmap[256];
+    __shared__ uint32_t obase[64];
+    __shared__ uint32_t stage_all[4 * kStage];
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t run[2];
+    const uint32_t s = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t off = dir[(size_t)d * n_stripes + s];
+    if (off == 0) return;
+    const uint32_t t = dense_terms[d];
+    const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
+    const uint32_t b0 = (uint32_t)seg.term_blk[t], b1 = (uint32_t)seg.term_blk[t + 1];
+    if (tid < NW) bitmap[tid] = 0;
+    if (tid == 0) {                       /* the run's blocks: binary searches on the term's block firsts */
+        uint32_t lo = b0, hi = b1;
+        const uint32_t key0 = s << SB;
+        while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (seg.blk_first[mid] < key0) lo = mid + 1; else hi = mid; }
+        run[0] = lo;
+        uint32_t e = lo;
+        while (e < b1 && (seg.blk_first[e] >> SB) == s) ++e;
+        run[1] = e;
+    }
+    __syncthreads();
+    const uint32_t rb = run[0], nb = run[1] - rb;
+    if (wave == 0) {
+        uint32_t c = lane < nb ? XGM_META_COUNT(seg.blk_meta[rb + lane]) : 0u;
+        uint32_t incl = dn_scan(c);
+        obase[lane] = incl - c;
+    }
+    __syncthreads();
+    unsigned char* cont = data + (size_t)off * 16;
+    unsigned char* wdf_out = cont + (size_t)NW * 8;
+    uint32_t* stage = stage_all + wave * kStage;
+    for (uint32_t j = wave; j < nb; j += 4u) {
+        const uint32_t b = rb + j, meta = seg.blk_meta[b], first = seg.blk_first[b];
+        const uint32_t n = XGM_META_COUNT(meta), bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta);
+        const uint32_t ngw = (n * bwg + 31u) >> 5, nww = (n * bww + 31u) >> 5;
+        const uint32_t* payload = seg.words + seg.term_word[t] + seg.blk_word[b];
+        for (uint32_t w = lane; w < ngw + nww + 2u; w += 64u) stage[w] = payload[w];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t i0 = lane * 2u, i1 = i0 + 1u;
+        const bool v0 = i0 < n, v1 = i1 < n;
+        const uint32_t g0 = (v0 && i0 > 0u) ? dn_extract(stage, i0, bwg) + 1u : 0u;
+        const uint32_t g1 = v1 ? dn_extract(stage, i1, bwg) + 1u : 0u;
+        const uint32_t w0 = v0 ? dn_extract(stage + ngw, i0, bww) : 0u;
+        const uint32_t w1 = v1 ? dn_extract(stage + ngw, i1, bww) : 0u;
+        const uint32_t local = g0 + g1;
+        const uint32_t excl = dn_scan(local) - local;
+        const uint32_t d0 = first + excl + g0, d1 = d0 + g1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[obase[j] + i0] = (unsigned char)w0; }
+        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[obase[j] + i1] = (unsigned char)w1; }
+    }
+    __syncthreads();
+    /* rank = exclusive prefix popcount over the words */
+    const uint32_t bits = tid < NW ? bitmap[tid] : 0u;
+    const uint32_t pc = (uint32_t)__popc(bits);
+    const uint32_t incl = dn_scan(pc);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0;
+    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
+    if (tid < NW) reinterpret_cast<uint2*>(cont)[tid] = make_uint2(bits, before + incl - pc);
+}
+
+}  // namespace
+
+int xgm_build_dense(xgm_index* idx) {
+    idx->view.dense_id = nullptr; idx->view.dense_dir = nullptr; idx->view.dense_data = nullptr;
+    idx->view.n_dense = 0;
+    const uint32_t SB = idx->hdr.stripe_bits;
+    const uint32_t n_stripes = (idx->hdr.lastdocid >> SB) + 1u;
+    idx->view.n_stripes = n_stripes;
+    if (getenv("XGM_NO_DENSE")) return XGM_OK;                          /* A/B switch for measurements */
+    const uint32_t NW = (1u << SB) / 32u;
+    std::vector<uint32_t> dense_terms;
+    std::vector<uint32_t> dense_id(idx->hdr.n_terms, 0xFFFFFFFFu);
+    uint32_t max_blocks = 1;
+    for (uint32_t t = 0; t < idx->hdr.n_terms; ++t) {
+        if ((uint64_t)idx->term_df[t] >= (uint64_t)XGM_DENSE_MIN_AVG * n_stripes && idx->term_wdfub[t] <= 254u) {
+            dense_id[t] = (uint32_t)dense_terms.size();
+            dense_terms.push_back(t);
+            max_blocks = std::max<uint32_t>(max_blocks, (uint32_t)(idx->term_blk[t + 1] - idx->term_blk[t]));
+        }
+    }
+    const uint32_t n_dense = (uint32_t)dense_terms.size();
+    if (n_dense == 0) return XGM_OK;
+    int rc = XGM_OK;
+    uint32_t *d_terms = nullptr, *d_cnt = nullptr;
+    std::vector<uint32_t> cnt((size_t)n_dense * n_stripes), dir((size_t)n_dense * n_stripes, 0u);
+    uint64_t units = 1;                                                  /* 16-byte units; offset 0 means "no container" */
+    DN_TRY(hipMalloc((void**)&d_terms, (size_t)n_dense * 4));
+    DN_TRY(hipMalloc((void**)&d_cnt, cnt.size() * 4));
+    DN_TRY(hipMemcpy(d_terms, dense_terms.data(), (size_t)n_dense * 4, hipMemcpyHostToDevice));
+    DN_TRY(hipMemset(d_cnt, 0, cnt.size() * 4));
+    {
+        dim3 grid(std::min<uint32_t>((max_blocks + 255u) / 256u, 4096u), n_dense);
+        hipLaunchKernelGGL(k_dense_count, grid, dim3(256), 0, 0, idx->view, d_terms, n_stripes, d_cnt);
+        DN_TRY(hipGetLastError());
+    }
+    DN_TRY(hipMemcpy(cnt.data(), d_cnt, cnt.size() * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cnt.size(); ++i) {
+        if (!cnt[i]) continue;
+        if (units > 0xFFFFFFFFull) { rc = xgm_set_error(XGM_E_INVALID, "dense containers exceed the 32-bit directory"); goto fail; }
+        dir[i] = (uint32_t)units;
+        units += ((uint64_t)NW * 8 + cnt[i] + 15) / 16;
+    }
+    DN_TRY(hipMalloc(&idx->d_dense_id, dense_id.size() * 4));
+    DN_TRY(hipMalloc(&idx->d_dense_dir, dir.size() * 4));
+    DN_TRY(hipMalloc(&idx->d_dense_data, units * 16 + 64));
+    DN_TRY(hipMemcpy(idx->d_dense_id, dense_id.data(), dense_id.size() * 4, hipMemcpyHostToDevice));
+    DN_TRY(hipMemcpy(idx->d_dense_dir, dir.data(), dir.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_dense_fill, dim3(n_stripes, n_dense), dim3(256), 0, 0, idx->view, d_terms, n_stripes, (const uint32_t*)idx->d_dense_dir,
+                       (unsigned char*)idx->d_dense_data);
+    DN_TRY(hipGetLastError());
+    DN_TRY(hipDeviceSynchronize());
+    idx->dense_bytes = dense_id.size() * 4 + dir.size() * 4 + units * 16;
+    idx->device_bytes += idx->dense_bytes;
+    idx->view.dense_id = (const uint32_t*)idx->d_dense_id;
+    idx->view.dense_dir = (const uint32_t*)idx->d_dense_dir;
+    idx->view.dense_data = (const unsigned char*)idx->d_dense_data;
+    idx->view.n_dense = n_dense;
+    hipFree(d_terms); hipFree(d_cnt);
+    return XGM_OK;
+fail:
+    if (d_terms) hipFree(d_terms);
+    if (d_cnt) hipFree(d_cnt);
+    if (idx->d_dense_id) { hipFree(idx->d_dense_id); idx->d_dense_id = nullptr; }
+    if (idx->d_dense_dir) { hipFree(idx->d_dense_dir); idx->d_dense_dir = nullptr; }
+    if (idx->d_dense_data) { hipFree(idx->d_dense_data); idx->d_dense_data = nullptr; }
+    return rc;
+}

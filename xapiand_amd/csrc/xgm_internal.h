@@ -45,6 +45,10 @@ struct xgm_index {
     bool sections_owned = false;       /* synthetic builder allocates sections one by one            */
     xgm_seg_dev view{};
     uint64_t device_bytes = 0;
+    void* d_dense_id = nullptr;        /* probe containers (xgm_dense.hip) */
+    void* d_dense_dir = nullptr;
+    void* d_dense_data = nullptr;
+    uint64_t dense_bytes = 0;
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
@@ -55,5 +59,9 @@ struct xgm_index {
 };
 
 int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id);
+
+/* Build the probe containers of the dense terms from the block-encoded postings already in HBM and
+ * attach them to idx->view.  No-op (n_dense = 0) when no term qualifies. */
+int xgm_build_dense(xgm_index* idx);
 
 #endif

@@ -1128,9 +1128,9 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
 
 template <typename TabT>
 __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
-                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
-                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                           xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+                                                              const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
+                                                              uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
@@ -1164,15 +1164,20 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
     for (uint32_t i = lane; i < T * kAndwCand; i += 64u) c_w[i] = 0;
     wave_lds_fence();
 
-    /* block ranges of every term inside the unit's docid range → run table */
-    uint64_t tbase_reg = 0;                                        /* lane t holds term_word[term t] */
+    /* block ranges of every term inside the unit's docid range → run table; lane t keeps term t's
+     * payload base and dense-container index */
+    uint64_t tbase_reg = 0;
+    uint32_t dense_reg = 0xFFFFFFFFu;
     if (!empty) {
         for (uint32_t t = 0; t < T; ++t) {
             const uint32_t id = q.term_id[t];
             const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
             const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
             const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
-            if (lane == t) tbase_reg = seg.term_word[id];
+            if (lane == t) {
+                tbase_reg = seg.term_word[id];
+                if (sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
+            }
             for (uint32_t i = c + lane; i < e; i += 64u) {
                 const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
                 const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
@@ -1186,6 +1191,11 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
     auto tbase = [&](uint32_t t) {
         return ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tbase_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tbase_reg, t);
     };
+    /* Plan order is ascending termfreq and "dense" is a termfreq threshold, so the dense terms are a
+     * suffix [td, T).  td == 0: every term is dense → candidates come from the AND of the bitmaps.
+     * (With more than 4 terms term 0 is always decoded, to bound the registers of that path.) */
+    uint32_t td = (uint32_t)__popcll(__ballot(lane < T && dense_reg == 0xFFFFFFFFu));
+    if (td == 0 && T > 4u) td = 1;
 
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
     bool theta_valid = false;
@@ -1204,38 +1214,171 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
         return x;
     };
 
-    /* software-pipelined header registers: lane j holds block j of the run */
+    /* software-pipelined per-stripe registers: block headers of the sparse terms (lane j = block j of
+     * the run) and, in lane t, the container offset of dense term t */
     uint32_t h0_meta = 0, h0_first = 0, h0_word = 0;
     uint32_t ha_meta = 0, ha_first = 0, ha_word = 0, ha_next = 0;
     uint32_t hb_meta = 0, hb_first = 0, hb_word = 0, hb_next = 0;
+    uint32_t hc_off = 0;
     auto issue_headers = [&](uint32_t x) {
-        const uint32_t r0 = rs[x], n0b = re[x] - r0;
-        if (lane < n0b && lane < kAndwChunkBlocks) {
-            h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
+        if (td > 0u) {
+            const uint32_t r0 = rs[x], n0b = re[x] - r0;
+            if (lane < n0b && lane < kAndwChunkBlocks) {
+                h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
+            }
         }
-        {
+        if (td > 1u) {
             const uint32_t rb = rs[1u * SPG + x], nb = re[1u * SPG + x] - rb;
             if (lane < nb) {
                 ha_meta = seg.blk_meta[rb + lane]; ha_first = seg.blk_first[rb + lane]; ha_word = seg.blk_word[rb + lane];
                 ha_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
             }
         }
-        if (T >= 3u) {
+        if (td > 2u) {
             const uint32_t rb = rs[2u * SPG + x], nb = re[2u * SPG + x] - rb;
             if (lane < nb) {
                 hb_meta = seg.blk_meta[rb + lane]; hb_first = seg.blk_first[rb + lane]; hb_word = seg.blk_word[rb + lane];
                 hb_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
             }
         }
+        if (lane >= td && lane < T) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
+    };
+
+    uint32_t dl[4] = {0, 0, 0, 0};
+    uint32_t stripe_base = 0;
+    uint32_t hc_cur = 0;                                           /* container offsets of the stripe being processed */
+
+    /* wdf of the dense terms [t_lo, T) for the n_c candidates in c_slot: two loads per candidate and
+     * term (bits+rank word, then the wdf byte), issued four terms at a time */
+    auto probe_dense = [&](uint32_t t_lo, uint32_t n_c) {
+        for (uint32_t c0 = 0; c0 < n_c; c0 += 64u) {
+            const uint32_t o = c0 + lane;
+            const bool valid = o < n_c;
+            const uint32_t slot = valid ? c_slot[o] : 0u;
+            for (uint32_t t0 = t_lo; t0 < T; t0 += 4u) {
+                uint2 wr[4];
+                const unsigned char* cb[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    wr[u] = make_uint2(0, 0);
+                    cb[u] = seg.dense_data;
+                    if (t0 + u < T) {
+                        cb[u] = seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t0 + u) * 16;
+                        if (valid) wr[u] = reinterpret_cast<const uint2*>(cb[u])[slot >> 5];
+                    }
+                }
+                uint32_t wv[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    wv[u] = 0;
+                    if (t0 + u < T && ((wr[u].x >> (slot & 31u)) & 1u))
+                        wv[u] = 1u + (uint32_t)cb[u][(size_t)NW * 8 + wr[u].y + (uint32_t)__popc(wr[u].x & ((1u << (slot & 31u)) - 1u))];
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u)
+                    if (valid && t0 + u < T) c_w[(size_t)(t0 + u) * kAndwCand + o] = (TabT)wv[u];
+            }
+        }
+        wave_lds_fence();
+    };
+
+    /* candidates present in every term are matches: BM25 + top-k, 64 per round; also clears c_w */
+    auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
+        for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
+            if (tkn + 64u > cap) {
+                wave_topk_sort(tk_w, tk_d, cap, lane);
+                tkn = tkn < k ? tkn : k;
+                if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
+                for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
+                wave_lds_fence();
+            }
+            const uint32_t o = i0 + lane;
+            bool take = false;
+            uint64_t wb = 0;
+            uint32_t did = 0;
+            if (o < n_c) {
+                bool pass = true;
+                for (uint32_t t = 0; t < T; ++t) pass = pass && c_w[(size_t)t * kAndwCand + o] != 0;
+                if (pass) {
+                    ++matches;
+                    did = stripe_base + c_slot[o];
+                    uint32_t dlen;
+                    if (dl_ready && i0 < 256u) {
+                        dlen = dl[0];
+#pragma unroll
+                        for (uint32_t c = 1; c < 4u; ++c) dlen = (i0 == c * 64u) ? dl[c] : dlen;
+                    } else {
+                        dlen = seg.doclen[did];
+                    }
+                    /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
+                    const double len = (double)dlen;
+                    double normlen = len * q.len_factor;
+                    normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+                    const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                    double weight = 0.0;                       /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
+                    for (uint32_t t = 0; t < T; ++t) {
+                        const double wdf = (double)((uint32_t)c_w[(size_t)t * kAndwCand + o] - 1u);
+                        const double denom = denom_len + wdf;
+                        weight = weight + q.termweight[t] * (wdf / denom);
+                    }
+                    wb = (uint64_t)__double_as_longlong(weight);
+                    take = !theta_valid || cand_before(wb, did, theta_w, theta_d);
+                }
+                for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * kAndwCand + o] = 0;
+            }
+            const uint64_t tm = __ballot(take);
+            if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; }
+            tkn += (uint32_t)__popcll(tm);
+        }
     };
 
     uint32_t sl = next_active(0);
     if (sl < n_local) issue_headers(sl);
     while (sl < n_local) {
-        const uint32_t stripe_base = (s_begin + sl) << SB;
-        const uint32_t r0 = rs[sl], r0e = re[sl];
+        stripe_base = (s_begin + sl) << SB;
         const uint32_t sl_next = next_active(sl + 1u);
+        hc_cur = hc_off;
 
+        if (td == 0u) {
+            /* ---- every term dense: candidates = AND of the containers' bitmaps (4 words per lane) ---- */
+            uint32_t m[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                if (t < T) {
+                    const uint2* wrp = reinterpret_cast<const uint2*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t) * 16);
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t w = lane * 4u + i;
+                        m[i] &= w < NW ? wrp[w].x : 0u;
+                    }
+                }
+            }
+            const uint32_t cnt = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
+            uint32_t o = incl - cnt;                                   /* this lane's next ordinal */
+            if (sl_next < n_local) issue_headers(sl_next);             /* next stripe's offsets in flight (this stripe uses hc_cur) */
+            for (uint32_t lo = 0; lo < n_total; lo += kAndwCand) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    while (m[i] && o < lo + kAndwCand) {
+                        const uint32_t bit = (uint32_t)__ffs(m[i]) - 1u;
+                        c_slot[o - lo] = (uint16_t)((lane * 4u + i) * 32u + bit);
+                        m[i] &= m[i] - 1u;
+                        ++o;
+                    }
+                }
+                wave_lds_fence();
+                const uint32_t n_c = n_total - lo < kAndwCand ? n_total - lo : kAndwCand;
+                probe_dense(0u, n_c);
+                score_candidates(n_c, false);
+                wave_lds_fence();
+            }
+            sl = sl_next;
+            continue;
+        }
+
+        const uint32_t r0 = rs[sl], r0e = re[sl];
         for (uint32_t cb = r0; cb < r0e; cb += kAndwChunkBlocks) {
             const uint32_t nblk0 = r0e - cb < kAndwChunkBlocks ? r0e - cb : kAndwChunkBlocks;
             /* ---- P1: term-0 blocks of the chunk → candidates (ordinals follow docid order) ---- */
@@ -1298,24 +1441,23 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
                 }
             }
 
-            /* doclen of the first 256 candidates: requested now, consumed in P4 */
-            uint32_t dl[4];
+            /* doclen of the first 256 candidates: requested now, consumed when scoring */
 #pragma unroll
             for (uint32_t c = 0; c < 4u; ++c) {
                 const uint32_t o = lane + c * 64u;
                 dl[c] = o < n_c ? seg.doclen[stripe_base + c_slot[o]] : 0u;
             }
 
-            /* ---- P3: other terms, two at a time; only blocks whose 128-slot buckets hold a candidate ---- */
+            /* ---- P3a: sparse other terms [1, td), two at a time; only blocks whose 128-slot buckets hold a candidate ---- */
             auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
                 const uint32_t lo = (first - stripe_base) >> 7;
                 const uint32_t hi = ((nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base) - 1u) >> 7;
-                const unsigned long long m = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
-                return (coarse & m) != 0ull;
+                const unsigned long long mm = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+                return (coarse & mm) != 0ull;
             };
-            for (uint32_t ta = 1; ta < T; ta += 2u) {
+            for (uint32_t ta = 1; ta < td; ta += 2u) {
                 const uint32_t tb = ta + 1u;
-                const bool have_b = tb < T;
+                const bool have_b = tb < td;
                 uint32_t a_meta, a_first, a_word, a_next, b_meta = 0, b_first = 0, b_word = 0, b_next = 0xFFFFFFFFu;
                 const uint32_t nba = re[ta * SPG + sl] - rs[ta * SPG + sl];
                 const uint32_t nbb = have_b ? re[tb * SPG + sl] - rs[tb * SPG + sl] : 0u;
@@ -1396,56 +1538,14 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
             }
             wave_lds_fence();
 
+            /* ---- P3b: dense other terms [td, T): O(1) probes of their containers ---- */
+            if (td < T) probe_dense(td, n_c);
+
             /* headers of the next active stripe: in flight while this one is scored */
             if (cb + kAndwChunkBlocks >= r0e && sl_next < n_local) issue_headers(sl_next);
 
-            /* ---- P4: candidates present in every term are matches: BM25 + top-k (64 per round) ---- */
-            for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
-                if (tkn + 64u > cap) {
-                    wave_topk_sort(tk_w, tk_d, cap, lane);
-                    tkn = tkn < k ? tkn : k;
-                    if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
-                    for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
-                    wave_lds_fence();
-                }
-                const uint32_t o = i0 + lane;
-                bool take = false;
-                uint64_t wb = 0;
-                uint32_t did = 0;
-                if (o < n_c) {
-                    bool pass = true;
-                    for (uint32_t t = 1; t < T; ++t) pass = pass && c_w[(size_t)t * kAndwCand + o] != 0;
-                    if (pass) {
-                        ++matches;
-                        did = stripe_base + c_slot[o];
-                        uint32_t dlen;
-                        if (i0 < 256u) {
-                            dlen = dl[0];
-#pragma unroll
-                            for (uint32_t c = 1; c < 4u; ++c) dlen = (i0 == c * 64u) ? dl[c] : dlen;
-                        } else {
-                            dlen = seg.doclen[did];
-                        }
-                        /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
-                        const double len = (double)dlen;
-                        double normlen = len * q.len_factor;
-                        normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
-                        const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
-                        double weight = 0.0;                   /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
-                        for (uint32_t t = 0; t < T; ++t) {
-                            const double wdf = (double)((uint32_t)c_w[(size_t)t * kAndwCand + o] - 1u);
-                            const double denom = denom_len + wdf;
-                            weight = weight + q.termweight[t] * (wdf / denom);
-                        }
-                        wb = (uint64_t)__double_as_longlong(weight);
-                        take = !theta_valid || cand_before(wb, did, theta_w, theta_d);
-                    }
-                    for (uint32_t t = 1; t < T; ++t) c_w[(size_t)t * kAndwCand + o] = 0;
-                }
-                const uint64_t tm = __ballot(take);
-                if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; }
-                tkn += (uint32_t)__popcll(tm);
-            }
+            /* ---- P4 ---- */
+            score_candidates(n_c, true);
             for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
             wave_lds_fence();
         }

@@ -80,7 +80,19 @@ typedef struct {
     const uint32_t* positions;
     uint32_t stripe_bits;
     uint32_t lastdocid;
+    /* Probe containers (built in HBM when the index is opened, never stored in the segment file): for
+     * every term dense enough to average >= XGM_DENSE_MIN_AVG postings per stripe, each non-empty
+     * (term, stripe) run also exists as  { u32 bits; u32 rank; }[W/32]  (rank = postings of the run in
+     * earlier words) followed by one wdf byte per posting.  Conjunctions probe these in O(1) per
+     * candidate instead of decoding the run's blocks. */
+    const uint32_t* dense_id;       /* [n_terms] dense index of the term, 0xFFFFFFFF if it has none   */
+    const uint32_t* dense_dir;      /* [n_dense][n_stripes] container offset in 16-byte units, 0 = none */
+    const unsigned char* dense_data;
+    uint32_t n_dense;
+    uint32_t n_stripes;
 } xgm_seg_dev;
+
+#define XGM_DENSE_MIN_AVG 96u          /* postings per stripe (on average) that make a term dense     */
 
 static inline uint32_t xgm_bits_needed(uint32_t v) {
     uint32_t b = 0;

@@ -517,6 +517,7 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
         v.stripe_bits = sb;
         v.lastdocid = n_local;
     }
+    if ((rc = xgm_build_dense(idx))) goto fail;
     *out = idx;
     return XGM_OK;
 
