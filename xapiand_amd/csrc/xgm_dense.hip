@@ -44,13 +44,11 @@ __global__ void k_dense_count(xgm_seg_dev seg, const uint32_t* __restrict__ dens
         atomicAdd(&cnt[(size_t)d * n_stripes + (seg.blk_first[b] >> seg.stripe_bits)], XGM_META_COUNT(seg.blk_meta[b]));
 }
 
-/* one workgroup per (stripe, dense term): decode the run, write bitmap + rank + wdf bytes */
+/* one workgroup per (stripe, dense term): decode the run, write the bitmap and the per-slot wdf+1 bytes */
 __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint32_t* __restrict__ dense_terms, uint32_t n_stripes,
                                                     const uint32_t* __restrict__ dir, unsigned char* __restrict__ data) {
     __shared__ uint32_t bitmap[256];
-    __shared__ uint32_t obase[64];
     __shared__ uint32_t stage_all[4 * kStage];
-    __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t run[2];
     const uint32_t s = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t off = dir[(size_t)d * n_stripes + s];
@@ -58,8 +56,11 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     const uint32_t t = dense_terms[d];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t b0 = (uint32_t)seg.term_blk[t], b1 = (uint32_t)seg.term_blk[t + 1];
+    unsigned char* cont = data + (size_t)off * 16;
+    unsigned char* wdf_out = cont + (size_t)NW * 4;
     if (tid < NW) bitmap[tid] = 0;
-    if (tid == 0) {                       /* the run's blocks: binary searches on the term's block firsts */
+    for (uint32_t i = tid; i < W / 16u; i += 256u) reinterpret_cast<uint4*>(wdf_out)[i] = make_uint4(0, 0, 0, 0);
+    if (tid == 0) {                       /* the run's blocks: binary search on the term's block firsts */
         uint32_t lo = b0, hi = b1;
         const uint32_t key0 = s << SB;
         while (lo < hi) { uint32_t mid = lo + (hi - lo) / 2; if (seg.blk_first[mid] < key0) lo = mid + 1; else hi = mid; }
@@ -70,14 +71,6 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     }
     __syncthreads();
     const uint32_t rb = run[0], nb = run[1] - rb;
-    if (wave == 0) {
-        uint32_t c = lane < nb ? XGM_META_COUNT(seg.blk_meta[rb + lane]) : 0u;
-        uint32_t incl = dn_scan(c);
-        obase[lane] = incl - c;
-    }
-    __syncthreads();
-    unsigned char* cont = data + (size_t)off * 16;
-    unsigned char* wdf_out = cont + (size_t)NW * 8;
     uint32_t* stage = stage_all + wave * kStage;
     for (uint32_t j = wave; j < nb; j += 4u) {
         const uint32_t b = rb + j, meta = seg.blk_meta[b], first = seg.blk_first[b];
@@ -98,19 +91,11 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
         const uint32_t d0 = first + excl + g0, d1 = d0 + g1;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[obase[j] + i0] = (unsigned char)w0; }
-        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[obase[j] + i1] = (unsigned char)w1; }
+        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w0 + 1u); }
+        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w1 + 1u); }
     }
     __syncthreads();
-    /* rank = exclusive prefix popcount over the words */
-    const uint32_t bits = tid < NW ? bitmap[tid] : 0u;
-    const uint32_t pc = (uint32_t)__popc(bits);
-    const uint32_t incl = dn_scan(pc);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < wave; ++w) before += wave_tot[w];
-    if (tid < NW) reinterpret_cast<uint2*>(cont)[tid] = make_uint2(bits, before + incl - pc);
+    if (tid < NW) reinterpret_cast<uint32_t*>(cont)[tid] = bitmap[tid];
 }
 
 }  // namespace
@@ -123,11 +108,12 @@ int xgm_build_dense(xgm_index* idx) {
     idx->view.n_stripes = n_stripes;
     if (getenv("XGM_NO_DENSE")) return XGM_OK;                          /* A/B switch for measurements */
     const uint32_t NW = (1u << SB) / 32u;
+    const uint32_t min_avg = getenv("XGM_DENSE_MIN_AVG") ? (uint32_t)atoi(getenv("XGM_DENSE_MIN_AVG")) : XGM_DENSE_MIN_AVG;   /* tuning knob */
     std::vector<uint32_t> dense_terms;
     std::vector<uint32_t> dense_id(idx->hdr.n_terms, 0xFFFFFFFFu);
     uint32_t max_blocks = 1;
     for (uint32_t t = 0; t < idx->hdr.n_terms; ++t) {
-        if ((uint64_t)idx->term_df[t] >= (uint64_t)XGM_DENSE_MIN_AVG * n_stripes && idx->term_wdfub[t] <= 254u) {
+        if ((uint64_t)idx->term_df[t] >= (uint64_t)min_avg * n_stripes && idx->term_wdfub[t] <= 254u) {
             dense_id[t] = (uint32_t)dense_terms.size();
             dense_terms.push_back(t);
             max_blocks = std::max<uint32_t>(max_blocks, (uint32_t)(idx->term_blk[t + 1] - idx->term_blk[t]));
@@ -153,7 +139,7 @@ int xgm_build_dense(xgm_index* idx) {
         if (!cnt[i]) continue;
         if (units > 0xFFFFFFFFull) { rc = xgm_set_error(XGM_E_INVALID, "dense containers exceed the 32-bit directory"); goto fail; }
         dir[i] = (uint32_t)units;
-        units += ((uint64_t)NW * 8 + cnt[i] + 15) / 16;
+        units += ((uint64_t)NW * 4 + ((uint64_t)NW * 32)) / 16;            /* bitmap + one byte per slot */
     }
     DN_TRY(hipMalloc(&idx->d_dense_id, dense_id.size() * 4));
     DN_TRY(hipMalloc(&idx->d_dense_dir, dir.size() * 4));

@@ -1248,31 +1248,20 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
     uint32_t stripe_base = 0;
     uint32_t hc_cur = 0;                                           /* container offsets of the stripe being processed */
 
-    /* wdf of the dense terms [t_lo, T) for the n_c candidates in c_slot: two loads per candidate and
-     * term (bits+rank word, then the wdf byte), issued four terms at a time */
+    /* wdf of the dense terms [t_lo, T) for the n_c candidates in c_slot: ONE byte load per candidate
+     * and term from the container's direct wdf+1 array (0 = the term does not index that docid) */
     auto probe_dense = [&](uint32_t t_lo, uint32_t n_c) {
         for (uint32_t c0 = 0; c0 < n_c; c0 += 64u) {
             const uint32_t o = c0 + lane;
             const bool valid = o < n_c;
             const uint32_t slot = valid ? c_slot[o] : 0u;
             for (uint32_t t0 = t_lo; t0 < T; t0 += 4u) {
-                uint2 wr[4];
-                const unsigned char* cb[4];
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    wr[u] = make_uint2(0, 0);
-                    cb[u] = seg.dense_data;
-                    if (t0 + u < T) {
-                        cb[u] = seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t0 + u) * 16;
-                        if (valid) wr[u] = reinterpret_cast<const uint2*>(cb[u])[slot >> 5];
-                    }
-                }
                 uint32_t wv[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     wv[u] = 0;
-                    if (t0 + u < T && ((wr[u].x >> (slot & 31u)) & 1u))
-                        wv[u] = 1u + (uint32_t)cb[u][(size_t)NW * 8 + wr[u].y + (uint32_t)__popc(wr[u].x & ((1u << (slot & 31u)) - 1u))];
+                    if (t0 + u < T && valid)
+                        wv[u] = seg.dense_data[(size_t)__builtin_amdgcn_readlane(hc_cur, t0 + u) * 16 + (size_t)NW * 4 + slot];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u)
@@ -1345,11 +1334,11 @@ __global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, co
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
                 if (t < T) {
-                    const uint2* wrp = reinterpret_cast<const uint2*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t) * 16);
+                    const uint32_t* bmp = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t) * 16);
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
                         const uint32_t w = lane * 4u + i;
-                        m[i] &= w < NW ? wrp[w].x : 0u;
+                        m[i] &= w < NW ? bmp[w] : 0u;
                     }
                 }
             }
