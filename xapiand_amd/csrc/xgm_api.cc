@@ -439,20 +439,29 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     const uint32_t merge_budget = nq <= 4u ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;
     const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
+    /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
+     * active stripe pays a fixed latency chain; each posting block that still has to be decoded (terms
+     * without probe containers) adds ~1; each candidate costs a probe + a share of the scoring. */
     std::vector<double> cost(nq);
     double total_cost = 0;
+    const double n_docs = std::max<double>(1.0, idx->hdr.doccount);
+    const double Wd = (double)(1u << idx->hdr.stripe_bits);
     for (uint32_t i = 0; i < nq; ++i) {
-        double blocks = 0, min_df = 1e30;
+        double sparse_blocks = 0, min_df = 1e30, dens = 1.0;
+        bool all_dense = bp->andw;
         for (uint32_t t = 0; t < qs[i].n_terms; ++t) {
             uint32_t id = qs[i].terms[t].term_id;
-            if (id == UINT32_MAX) { min_df = 0; continue; }
+            if (id == UINT32_MAX) { min_df = 0; all_dense = false; continue; }
             const double df = idx->term_df[id];
-            blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes);
+            const bool dense = bp->andw && !bp->wide && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
+            if (!dense) { sparse_blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes); all_dense = false; }
             min_df = std::min(min_df, df);
+            dens *= df / n_docs;
         }
         /* AND visits only stripes where the rarest term has postings */
         const double stripes = qs[i].op == XGM_OP_OR ? n_stripes : std::min<double>(n_stripes, min_df);
-        cost[i] = 8.0 * stripes + 0.9 * blocks + 1.0;
+        const double cand_per_stripe = all_dense ? Wd * dens : (stripes > 0 ? min_df / stripes : 0.0);
+        cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + 0.03 * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
         total_cost += cost[i];
     }
     const double unit_cost = std::max(1.0, total_cost / (bp->andw ? 12288.0 : 3072.0));

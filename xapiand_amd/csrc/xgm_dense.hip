@@ -156,6 +156,7 @@ int xgm_build_dense(xgm_index* idx) {
     idx->view.dense_dir = (const uint32_t*)idx->d_dense_dir;
     idx->view.dense_data = (const unsigned char*)idx->d_dense_data;
     idx->view.n_dense = n_dense;
+    idx->dense_min_df = (uint64_t)min_avg * n_stripes;
     hipFree(d_terms); hipFree(d_cnt);
     return XGM_OK;
 fail:

@@ -49,6 +49,7 @@ struct xgm_index {
     void* d_dense_dir = nullptr;
     void* d_dense_data = nullptr;
     uint64_t dense_bytes = 0;
+    uint64_t dense_min_df = UINT64_MAX;   /* termfreq from which a term has probe containers */
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
