@@ -53,12 +53,14 @@ static int use_device(int device) {
 struct XgmScratch {
     hipStream_t stream = nullptr;
     /* device */
-    xgm_dev_query* d_queries = nullptr; size_t cap_queries = 0;
+    xgm_dev_query* d_queries = nullptr;                /* view into d_in */
     xgm_cand* d_cand = nullptr; size_t cap_cand = 0;
     xgm_group_hdr* d_ghdr = nullptr; size_t cap_ghdr = 0;
-    uint32_t* d_kq = nullptr; double* d_maxposs = nullptr; size_t cap_kq = 0;
-    xgm_work* d_work = nullptr; size_t cap_work = 0;
-    uint32_t* d_goff = nullptr; size_t cap_goff = 0;
+    uint32_t* d_kq = nullptr; double* d_maxposs = nullptr;   /* views into d_in */
+    uint32_t* d_mkq = nullptr; size_t cap_mkq = 0;     /* k[] of xgm_merge_shards_device */
+    xgm_work* d_work = nullptr;                        /* views into d_in */
+    uint32_t* d_goff = nullptr;
+    void* d_in = nullptr; size_t cap_in = 0;           /* all per-call inputs, one upload */
     xgm_hit* d_hits = nullptr; size_t cap_hits = 0;
     xgm_result_hdr* d_hdrs = nullptr; size_t cap_hdrs = 0;
     /* pinned host */
@@ -121,8 +123,8 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
-    hipFree(s->d_queries); hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_kq); hipFree(s->d_maxposs);
-    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_work); hipFree(s->d_goff);
+    hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq);
+    hipFree(s->d_hits); hipFree(s->d_hdrs);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
     if (s->h_work) hipHostFree(s->h_work);
@@ -508,30 +510,30 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     BatchPlan bp;
     if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp))) return rc;
     if (k_stride < bp.k_max) return xgm_set_error(XGM_E_INVALID, "k_stride %u < first+maxitems %u", k_stride, bp.k_max);
-    if ((rc = grow(&s->d_queries, &s->cap_queries, (size_t)nq))) return rc;
-    if (nq > s->cap_kq) {
-        if (s->d_kq) hipFree(s->d_kq);
-        if (s->d_maxposs) hipFree(s->d_maxposs);
-        s->d_kq = nullptr; s->d_maxposs = nullptr;
-        HIP_TRY(hipMalloc((void**)&s->d_kq, (size_t)nq * 4));
-        HIP_TRY(hipMalloc((void**)&s->d_maxposs, (size_t)nq * 8));
-        s->cap_kq = nq;
-    }
     if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)bp.n_work * bp.k_stride_c))) return rc;
     if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)bp.n_work))) return rc;
-    if ((rc = grow(&s->d_work, &s->cap_work, (size_t)bp.n_work))) return rc;
-    if ((rc = grow(&s->d_goff, &s->cap_goff, (size_t)nq + 1))) return rc;
-    {
-        const size_t wb = (size_t)bp.n_work * sizeof(xgm_work), gb = ((size_t)nq + 1) * 4;
-        if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, wb + gb))) return rc;
-        memcpy(s->h_work, bp.work.data(), wb);
-        memcpy((char*)s->h_work + wb, bp.goff.data(), gb);
-        HIP_TRY(hipMemcpyAsync(s->d_work, s->h_work, wb, hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(s->d_goff, (char*)s->h_work + wb, gb, hipMemcpyHostToDevice, stream));
-    }
-    HIP_TRY(hipMemcpyAsync(s->d_queries, h_dq, (size_t)nq * sizeof(xgm_dev_query), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(s->d_maxposs, h_mp, (size_t)nq * 8, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipMemcpyAsync(s->d_kq, h_kq, (size_t)nq * 4, hipMemcpyHostToDevice, stream));
+    /* every per-call input goes up in ONE copy: [dev queries | max_possible | work list | k | group offsets] */
+    const size_t o_dq = 0, b_dq = (size_t)nq * sizeof(xgm_dev_query);
+    const size_t o_mp = o_dq + b_dq, b_mp = (size_t)nq * 8;
+    const size_t o_wk = o_mp + b_mp, b_wk = (size_t)bp.n_work * sizeof(xgm_work);
+    const size_t o_kq = o_wk + b_wk, b_kq = (size_t)nq * 4;
+    const size_t o_go = o_kq + b_kq, b_go = ((size_t)nq + 1) * 4;
+    const size_t in_bytes = (o_go + b_go + 15) & ~(size_t)15;
+    if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
+    if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
+    unsigned char* hin = (unsigned char*)s->h_work;
+    memcpy(hin + o_dq, h_dq, b_dq);
+    memcpy(hin + o_mp, h_mp, b_mp);
+    memcpy(hin + o_wk, bp.work.data(), b_wk);
+    memcpy(hin + o_kq, h_kq, b_kq);
+    memcpy(hin + o_go, bp.goff.data(), b_go);
+    HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, stream));
+    unsigned char* din = (unsigned char*)s->d_in;
+    s->d_queries = (xgm_dev_query*)(din + o_dq);
+    s->d_maxposs = (double*)(din + o_mp);
+    s->d_work = (xgm_work*)(din + o_wk);
+    s->d_kq = (uint32_t*)(din + o_kq);
+    s->d_goff = (uint32_t*)(din + o_go);
 
     xgm_match_launch L;
     L.seg = idx->view;
@@ -575,15 +577,16 @@ extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq
     if ((rc = scratch_acquire(idx, &s))) return rc;
     hipStream_t stream = pick_stream(idx, s);
     do {
-        if ((rc = grow(&s->d_hits, &s->cap_hits, (size_t)nq * k_stride))) break;
-        if ((rc = grow(&s->d_hdrs, &s->cap_hdrs, (size_t)nq))) break;
-        size_t down = (size_t)nq * k_stride * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
+        /* hits and headers share one device buffer → one download */
+        const size_t n_hit = (size_t)nq * k_stride;
+        if ((rc = grow(&s->d_hits, &s->cap_hits, n_hit + (size_t)nq * 2))) break;
+        xgm_result_hdr* d_hdrs = reinterpret_cast<xgm_result_hdr*>(s->d_hits + n_hit);
+        const size_t down = n_hit * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
         if ((rc = grow_pinned(&s->h_down, &s->cap_down, down))) break;
-        if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, s->d_hdrs))) break;
+        if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, d_hdrs))) break;
         xgm_hit* h_hits = (xgm_hit*)s->h_down;
-        xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + (size_t)nq * k_stride);
-        hipError_t e = hipMemcpyAsync(h_hits, s->d_hits, (size_t)nq * k_stride * sizeof(xgm_hit), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_hdrs, s->d_hdrs, (size_t)nq * sizeof(xgm_result_hdr), hipMemcpyDeviceToHost, stream);
+        xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + n_hit);
+        hipError_t e = hipMemcpyAsync(h_hits, s->d_hits, down, hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
         if (e != hipSuccess) { rc = xgm_launch_error("result copy", (int)e, hipGetErrorString(e)); break; }
         memcpy(hdrs, h_hdrs, (size_t)nq * sizeof(xgm_result_hdr));
@@ -634,20 +637,12 @@ extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, c
         if (k_max > k_stride) { rc = xgm_set_error(XGM_E_INVALID, "k > k_stride"); break; }
         uint32_t cap = std::max(512u, next_pow2(n_shards * k_max));
         if (cap > XGM_MERGE_CAP) { rc = XGM_UNSUPPORTED; break; }
-        if (nq > s->cap_kq) {
-            if (s->d_kq) hipFree(s->d_kq);
-            if (s->d_maxposs) hipFree(s->d_maxposs);
-            s->d_kq = nullptr; s->d_maxposs = nullptr; s->cap_kq = 0;
-            hipError_t e = hipMalloc((void**)&s->d_kq, (size_t)nq * 4);
-            if (e == hipSuccess) e = hipMalloc((void**)&s->d_maxposs, (size_t)nq * 8);
-            if (e != hipSuccess) { rc = xgm_launch_error("hipMalloc", (int)e, hipGetErrorString(e)); break; }
-            s->cap_kq = nq;
-        }
+        if ((rc = grow(&s->d_mkq, &s->cap_mkq, (size_t)nq))) break;
         if ((rc = grow_pinned(&s->h_up, &s->cap_up, (size_t)nq * 4))) break;
         memcpy(s->h_up, k, (size_t)nq * 4);
-        hipError_t e = hipMemcpyAsync(s->d_kq, s->h_up, (size_t)nq * 4, hipMemcpyHostToDevice, stream);
+        hipError_t e = hipMemcpyAsync(s->d_mkq, s->h_up, (size_t)nq * 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { rc = xgm_launch_error("hipMemcpyAsync", (int)e, hipGetErrorString(e)); break; }
-        rc = xgm_launch_merge_shards((const xgm_hit*)d_all_hits, (const xgm_result_hdr*)d_all_hdrs, n_shards, nq, k_stride, s->d_kq,
+        rc = xgm_launch_merge_shards((const xgm_hit*)d_all_hits, (const xgm_result_hdr*)d_all_hdrs, n_shards, nq, k_stride, s->d_mkq,
                                      cap, (xgm_hit*)d_out_hits, (xgm_result_hdr*)d_out_hdrs, stream);
     } while (0);
     if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
