@@ -93,7 +93,12 @@ def main():
     db.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards): one all-reduce ----
-    pool = gen_queries(1100, args.terms, 8, 4096, QUERY_SEED)
+    if args.op == "PHRASE":
+        # C5: 2-3-grams that occur in a random document (tests/helpers.py restates the corpus in Python)
+        import helpers as H
+        pool = [q["terms"] for q in H.gen_phrase_queries(1100, n_docs_global, args.vocab, seed=QUERY_SEED)]
+    else:
+        pool = gen_queries(1100, args.terms, 8, 4096, QUERY_SEED)
     k = args.topk
     searcher = ShardedSearcher(db, rank, world, dev)
     plans = searcher.prepare([Query(args.op, terms) for terms in pool], 0, k)

@@ -15,7 +15,7 @@ XGM_OP_AND, XGM_OP_OR, XGM_OP_PHRASE = 1, 2, 3
 UINT64_MAX = (1 << 64) - 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxgm.so")
+LIB_PATH = os.environ.get("XGM_LIB_PATH") or os.path.join(_HERE, "csrc", "libxgm.so")   # override: A/B builds
 
 
 class RawPostings(C.Structure):

@@ -435,7 +435,13 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
      * about total/(units the chip holds) cost — heavy queries into many — bounded by the LDS run table
      * (8 B per term and stripe → at most spg_max stripes per unit) and by the merge kernel's sort
      * capacity (units × k candidates). */
-    const uint32_t spg_max = bp->andw ? 32u : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
+    uint32_t spg_max = bp->andw ? 32u : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
+    if (!bp->andw) {
+        /* the run table shares the 160 KiB with the tables (PHRASE position tables are large) */
+        const size_t base = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, 0);
+        if (base + 8u * bp->tab_terms + 64u > 160u * 1024u) return XGM_UNSUPPORTED;
+        spg_max = std::min<uint32_t>(spg_max, (uint32_t)((160u * 1024u - 64u - base) / (8u * bp->tab_terms)));
+    }
     const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
     /* few queries in flight (latency mode): a smaller merge (sort of <= 4096) beats more units */
     const uint32_t merge_budget = nq <= 4u ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;

@@ -1093,7 +1093,10 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
  * (top-k fill, threshold, coarse mask) lives in registers.  Used when first+maxitems <= kAndwMaxK. */
 constexpr uint32_t kAndwCand = 512;                  /* candidates per chunk = 4 blocks of term 0 */
 constexpr uint32_t kAndwChunkBlocks = kAndwCand / XGM_BLOCK;
-constexpr uint32_t kAndwMaxK = 192;                  /* top-k buffer cap 256 */
+constexpr uint32_t kAndwMaxK = 192;
+#ifndef XGM_ANDW_WAVES
+#define XGM_ANDW_WAVES 4           /* min waves per SIMD the register allocator must allow */
+#endif                  /* top-k buffer cap 256 */
 
 __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
@@ -1127,7 +1130,7 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
 }
 
 template <typename TabT>
-__global__ __launch_bounds__(XGM_WG, 4) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+__global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                               xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
