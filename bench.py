@@ -55,6 +55,15 @@ def gen_queries(n, n_terms, lo, hi, seed):
     return out
 
 
+def workload_name(args, world, n_docs_global, k):
+    """BASELINE.json config the run corresponds to (C2 is the one the metric is quoted on)."""
+    shape = {"AND": "%d-term conjunctive" % args.terms, "OR": "%d-term disjunctive" % args.terms, "PHRASE": "2-3-term phrase (positions)"}[args.op]
+    if world > 1:
+        return "C4 (weak-scaled): %dM-doc index sharded %d ways, %s BM25 top-%d, RCCL top-k all-gather" % (n_docs_global // 1000000, world, shape, k)
+    cfg = {"AND": "C2", "OR": "C3", "PHRASE": "C5"}[args.op]
+    return "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (cfg, args.docs_per_gpu // 1000000, args.vocab // 1000000, shape, k)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,7 +137,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kernel_ms = db.last_kernel_ms()            # mean xgm_match_kernel duration over the timed steps (HIP events)
+    kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed steps (HIP events)
+    kernel_name = db.last_kernel_name()
     db.set_profiling(False)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -165,12 +175,13 @@ def main():
     result = None
     if rank == 0:
         result = {
-            "metric": "queries/sec + p50 latency, 10M-doc synthetic index, 3-term AND, top-10",
+            "metric": "queries/sec + p50 latency, %dM-doc synthetic index, %s, top-%d" % (
+                args.docs_per_gpu // 1000000, {"AND": "%d-term AND" % args.terms, "OR": "%d-term OR" % args.terms,
+                                               "PHRASE": "2-3-term PHRASE"}[args.op], k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 postings + f64 BM25", "data": "synthetic",
-            "config": {"workload": ("C2: 10M-doc / 1M-term Zipf index, 3-term conjunctive BM25 top-10, 1 MI355X" if world == 1 else
-                                    "C4 (weak-scaled): %dM-doc index sharded %d ways, 3-term AND top-10, RCCL top-k all-gather" % (n_docs_global // 1000000, world)),
+            "config": {"workload": workload_name(args, world, n_docs_global, k),
                        "docs_per_gpu": args.docs_per_gpu, "docs_total": n_docs_global, "vocab": args.vocab, "op": args.op,
                        "terms_per_query": args.terms, "top_k": k, "batch": BATCH, "parallelism": "shard%d" % world,
                        "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED)},
@@ -178,7 +189,7 @@ def main():
             "p99_latency_us": lat[int(len(lat) * 0.99)] * 1e6 if lat else None,
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,
                       "device_bytes": info.device_bytes, "build_seconds": build_s},
-            "roofline": {"bound": "hbm", "kernel": ("xgm_andw_kernel" if args.op == "AND" and k <= 192 else "xgm_match_kernel"), "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel_ms": kernel_ms},
         }

@@ -249,6 +249,9 @@ int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_al
  * milliseconds (< 0 if none) and starts a new window. */
 int xgm_index_set_profiling(xgm_index*, int on);
 double xgm_last_kernel_ms(const xgm_index*);
+/* Name of the match kernel the last xgm_search* call on this index launched ("xgm_andw_kernel",
+ * "xgm_orw_kernel", "xgm_and_kernel", "xgm_match_kernel"; "" before the first search). */
+const char* xgm_last_kernel_name(const xgm_index*);
 
 /* Algorithmic bytes of a planned query on this shard, SURVEY.md §8(d):
  * Σ_t df_t·8 + S·4 (+ P·4) + k·16, with S and P taken from the last executed result header

@@ -1,0 +1,22 @@
+"""Every kernel variant must give the same answers: the fast paths (probe containers, wave-autonomous
+AND / OR kernels, MaxScore pruning) are optimisations of one semantics, so the parity suite is re-run
+with each of them switched off through the library's A/B environment switches (read once per
+process, hence the subprocesses)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELECT = "random_queries_vs_oracle or other_stripe_widths or edge_cases or batch_equals_single"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["XGM_NO_DENSE", "XGM_NO_ANDW", "XGM_NO_ORW", "XGM_NO_PRUNE"])
+def test_parity_with_fast_path_disabled(built, switch):
+    env = dict(os.environ)
+    env[switch] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
+                        "-k", SELECT, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "%s=1:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-2000:])

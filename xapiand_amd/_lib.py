@@ -99,6 +99,7 @@ _API = [
     ("xgm_merge_shards_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
     ("xgm_index_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_last_kernel_ms", C.c_double, [C.c_void_p]),
+    ("xgm_last_kernel_name", C.c_char_p, [C.c_void_p]),
     ("xgm_query_postings_bytes", C.c_uint64, [C.c_void_p, _P(Query)]),
     ("xgm_debug_decode_term_device", C.c_int64, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), C.c_uint64]),
     ("xgm_debug_read_doclen", C.c_int64, [C.c_void_p, _P(C.c_uint32), C.c_uint64]),

@@ -285,6 +285,8 @@ extern "C" double xgm_last_kernel_ms(const xgm_index* cidx) {
     return n ? sum / (double)n : -1.0;
 }
 
+extern "C" const char* xgm_last_kernel_name(const xgm_index* idx) { return idx ? idx->last_kernel : ""; }
+
 /* ------------------------------------------------------------------ dictionary --------------- */
 
 int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id) {
@@ -359,6 +361,12 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         uint32_t ub = idx->term_wdfub[q->terms[t].term_id];
         if (ub > 65534u) return 0;
         if (ub > 254u) width = 2;
+        /* leaf weight <= termweight * wdf_ub / (k1 * (min_normlen * b + 1 - b) + wdf_ub) <= termweight:
+         * every factor of BM25Weight::get_sumpart is monotone in wdf and in the normalised length */
+        double bound = q->terms[t].termweight;
+        const double denom_min = q->k1 * (q->min_normlen * q->b + (1.0 - q->b));
+        if (ub > 0 && denom_min > 0) bound = q->terms[t].termweight * ((double)ub / (denom_min + (double)ub));
+        d->ub[t] = bound * 1.000000001;
     }
     if (q->op == XGM_OP_PHRASE && q->phrase_active) {
         d->flags |= XGM_QF_PHRASE;
@@ -384,6 +392,16 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         }
     }
     if (sp != 1 || n_nodes != (int)q->n_terms - 1) return -1;
+    {
+        int slot_of[2 * XGM_MAX_TERMS];
+        for (uint32_t t = 0; t < q->n_terms; ++t) slot_of[t] = (int)t;
+        for (int j = 0; j < n_nodes; ++j) {
+            d->ip_a[j] = (uint8_t)slot_of[d->node_a[j]];
+            d->ip_b[j] = (uint8_t)slot_of[d->node_b[j]];
+            slot_of[q->n_terms + j] = slot_of[d->node_a[j]];
+        }
+        d->ip_root = (uint32_t)slot_of[q->n_terms + n_nodes - 1];
+    }
     return width;
 }
 
@@ -397,11 +415,13 @@ struct BatchPlan {
     bool phrase, wide;
     bool and_only;      /* every query is a plain conjunction of >= 2 terms → xgm_and_kernel */
     bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
+    bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
 };
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
                       BatchPlan* bp) {
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
+    bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
     if (no_and_kernel) bp->and_only = false;
     for (uint32_t i = 0; i < nq; ++i) {
@@ -412,6 +432,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         if (dq[i].k > XGM_MAX_K) return XGM_UNSUPPORTED;
         if (width == 2) bp->wide = true;
         if (dq[i].op != XGM_OP_AND || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE)) bp->and_only = false;
+        if (dq[i].op != XGM_OP_OR) or_only = false;
         if (dq[i].flags & XGM_QF_PHRASE) {
             if (dq[i].n_terms > XGM_PHRASE_MAX_TERMS) return XGM_UNSUPPORTED;
             bp->phrase = true;
@@ -429,14 +450,21 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
     const uint32_t k_pad = next_pow2(bp->k_max);
     bp->andw = bp->and_only && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP;
-    bp->cap = bp->andw ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
+    /* disjunctions: one wave per unit as well; a unit spans as many stripes as the merge capacity
+     * (units x k candidates per query) requires */
+    uint32_t orw_spg = 32u;
+    while ((uint64_t)((n_stripes + orw_spg - 1u) / orw_spg) * k_pad > XGM_MERGE_CAP && orw_spg < 4096u) orw_spg *= 2u;
+    bp->orw = or_only && (uint64_t)((n_stripes + orw_spg - 1u) / orw_spg) * k_pad <= XGM_MERGE_CAP &&
+              xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, orw_spg) <= 160u * 1024u;
+    const bool wave_units = bp->andw || bp->orw;
+    bp->cap = wave_units ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
      * plus about one partial block per stripe a term touches).  Every query is cut into units of
      * about total/(units the chip holds) cost — heavy queries into many — bounded by the LDS run table
      * (8 B per term and stripe → at most spg_max stripes per unit) and by the merge kernel's sort
      * capacity (units × k candidates). */
-    uint32_t spg_max = bp->andw ? 32u : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
-    if (!bp->andw) {
+    uint32_t spg_max = bp->andw ? 32u : bp->orw ? orw_spg : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
+    if (!wave_units) {
         /* the run table shares the 160 KiB with the tables (PHRASE position tables are large) */
         const size_t base = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, 0);
         if (base + 8u * bp->tab_terms + 64u > 160u * 1024u) return XGM_UNSUPPORTED;
@@ -470,9 +498,22 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         const double stripes = qs[i].op == XGM_OP_OR ? n_stripes : std::min<double>(n_stripes, min_df);
         const double cand_per_stripe = all_dense ? Wd * dens : (stripes > 0 ? min_df / stripes : 0.0);
         cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + 0.03 * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
+        if (bp->orw) {
+            /* every stripe: the terms' bitmaps / block decodes (twice where candidates remain) and a
+             * share of the union that survives the MaxScore pruning */
+            double sum_df = 0, blocks = 0;
+            for (uint32_t t = 0; t < qs[i].n_terms; ++t) {
+                uint32_t id = qs[i].terms[t].term_id;
+                if (id == UINT32_MAX) continue;
+                const double df = idx->term_df[id];
+                sum_df += df;
+                if (bp->wide || (uint64_t)idx->term_df[id] < idx->dense_min_df || idx->dense_min_df == 0) blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes);
+            }
+            cost[i] = n_stripes * (10.0 + 2.0 * qs[i].n_terms) + 1.8 * blocks + 0.004 * sum_df + 1.0;
+        }
         total_cost += cost[i];
     }
-    const double unit_cost = std::max(1.0, total_cost / (bp->andw ? 12288.0 : 3072.0));
+    const double unit_cost = std::max(1.0, total_cost / (wave_units ? 12288.0 : 3072.0));
     bp->goff.assign(nq + 1, 0);
     bp->work.clear();
     uint32_t spg_used = 1;
@@ -497,6 +538,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     uint32_t g_most = 0;
     for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
     const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
+                        : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
     bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));     /* fixed window of k_max per unit */
@@ -524,7 +566,8 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     const size_t o_wk = o_mp + b_mp, b_wk = (size_t)bp.n_work * sizeof(xgm_work);
     const size_t o_kq = o_wk + b_wk, b_kq = (size_t)nq * 4;
     const size_t o_go = o_kq + b_kq, b_go = ((size_t)nq + 1) * 4;
-    const size_t in_bytes = (o_go + b_go + 15) & ~(size_t)15;
+    const size_t o_tg = (o_go + b_go + 7) & ~(size_t)7, b_tg = bp.orw ? (size_t)nq * 8 : 0;   /* shared k-th weights, start at 0 */
+    const size_t in_bytes = (o_tg + b_tg + 15) & ~(size_t)15;
     if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
     if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
     unsigned char* hin = (unsigned char*)s->h_work;
@@ -533,6 +576,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     memcpy(hin + o_wk, bp.work.data(), b_wk);
     memcpy(hin + o_kq, h_kq, b_kq);
     memcpy(hin + o_go, bp.goff.data(), b_go);
+    memset(hin + o_tg, 0, b_tg);
     HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, stream));
     unsigned char* din = (unsigned char*)s->d_in;
     s->d_queries = (xgm_dev_query*)(din + o_dq);
@@ -562,8 +606,12 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
+    idx->last_kernel = bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = bp.andw ? xgm_launch_andw(L, stream) : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream))) return rc;
+    if ((rc = bp.andw ? xgm_launch_andw(L, stream)
+              : bp.orw ? xgm_launch_orw(L, (unsigned long long*)(din + o_tg), stream)
+              : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream)))
+        return rc;
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
                                d_hdrs, s->d_maxposs, stream)))

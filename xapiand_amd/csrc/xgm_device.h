@@ -28,6 +28,14 @@ typedef struct {
      * where val[0..n_terms) are the leaves and val[n_terms + j] the inner nodes; root = last node */
     uint8_t node_a[XGM_MAX_TERMS];
     uint8_t node_b[XGM_MAX_TERMS];
+    /* the same summation "in place": step j does val[ip_a[j]] += val[ip_b[j]] over the T leaf slots
+     * (an inner node lives in its left operand's slot); the root ends up in val[ip_root] */
+    uint8_t ip_a[XGM_MAX_TERMS];
+    uint8_t ip_b[XGM_MAX_TERMS];
+    uint32_t ip_root, pad1;
+    /* safe upper bound of leaf t's weight over the whole shard (0 for an absent term): drives the
+     * MaxScore pruning of xgm_orw_kernel; never part of a result */
+    double ub[XGM_MAX_TERMS];
 } xgm_dev_query;
 
 /* One top-k candidate: 16 bytes. */

@@ -53,6 +53,7 @@ struct xgm_index {
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
+    const char* last_kernel = "";      /* diagnostics: which match kernel the last batch used */
     std::vector<std::pair<void*, void*>> prof_events;   /* hipEvent_t pairs around the match kernel */
     size_t prof_used = 0;
     std::mutex scratch_mu;

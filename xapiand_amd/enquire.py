@@ -166,6 +166,9 @@ class Database:
     def last_kernel_ms(self):
         return _lib.lib().xgm_last_kernel_ms(self._h)
 
+    def last_kernel_name(self):
+        return (_lib.lib().xgm_last_kernel_name(self._h) or b"").decode()
+
 
 class MSetItem:
     __slots__ = ("docid", "weight", "rank", "percent", "subqs_matched")
