@@ -13,7 +13,7 @@ SELECT = "random_queries_vs_oracle or other_stripe_widths or edge_cases or batch
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["XGM_NO_DENSE", "XGM_NO_ANDW", "XGM_NO_ORW", "XGM_NO_PRUNE"])
+@pytest.mark.parametrize("switch", ["XGM_NO_DENSE", "XGM_NO_ANDW", "XGM_NO_ORW", "XGM_NO_PRUNE", "XGM_NO_PHASE_A", "XGM_NO_BOUND_SUM"])
 def test_parity_with_fast_path_disabled(built, switch):
     env = dict(os.environ)
     env[switch] = "1"

@@ -20,10 +20,10 @@ oc = enquire.Database.close
 
 def close(self):
     cap = 20000
-    buf = (C.c_ulonglong * (6 * cap))()
+    buf = (C.c_ulonglong * (8 * cap))()
     n = L.xgm_debug_last_units(self._h, buf, cap)
     if n > 0:
-        a = np.array(buf[:6 * n], dtype=np.uint64).reshape(n, 6)
+        a = np.array(buf[:8 * n], dtype=np.uint64).reshape(n, 8)
         t0 = a[:, 4].min()
         dur = (a[:, 5] - a[:, 4]).astype(np.float64)
         st = (a[:, 4] - t0).astype(np.float64)
@@ -35,6 +35,8 @@ def close(self):
         print("UNITS concurrency per decile", [int(((st < edges[i + 1]) & (en > edges[i])).sum()) for i in range(10)])
         stripes = (a[:, 2] - a[:, 1]).astype(np.float64)
         print("UNITS cycles/stripe mean", (dur / np.maximum(1, stripes)).mean(), "stripes/unit mean,max", stripes.mean(), stripes.max())
+        print("UNITS matches", int(a[:, 6].sum()), "documents weighed (xgm_orw_kernel only)", int(a[:, 7].sum()),
+              "ratio", float(a[:, 7].sum()) / max(1.0, float(a[:, 6].sum())))
         order = np.argsort(-dur)[:5]
         print("UNITS slowest (qi, s_begin, s_end, cycles, start)", [(int(a[i, 0]), int(a[i, 1]), int(a[i, 2]), int(dur[i]), int(st[i])) for i in order])
     oc(self)

@@ -58,6 +58,7 @@ struct XgmScratch {
     xgm_group_hdr* d_ghdr = nullptr; size_t cap_ghdr = 0;
     uint32_t* d_kq = nullptr; double* d_maxposs = nullptr;   /* views into d_in */
     uint32_t* d_mkq = nullptr; size_t cap_mkq = 0;     /* k[] of xgm_merge_shards_device */
+    uint32_t* d_hist = nullptr; size_t cap_hist = 0;   /* [nq][XGM_OR_HIST] weight histograms of xgm_orw_kernel */
     xgm_work* d_work = nullptr;                        /* views into d_in */
     uint32_t* d_goff = nullptr;
     void* d_in = nullptr; size_t cap_in = 0;           /* all per-call inputs, one upload */
@@ -123,7 +124,7 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
-    hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq);
+    hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
     hipFree(s->d_hits); hipFree(s->d_hdrs);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
@@ -566,8 +567,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     const size_t o_wk = o_mp + b_mp, b_wk = (size_t)bp.n_work * sizeof(xgm_work);
     const size_t o_kq = o_wk + b_wk, b_kq = (size_t)nq * 4;
     const size_t o_go = o_kq + b_kq, b_go = ((size_t)nq + 1) * 4;
-    const size_t o_tg = (o_go + b_go + 7) & ~(size_t)7, b_tg = bp.orw ? (size_t)nq * 8 : 0;   /* shared k-th weights, start at 0 */
-    const size_t in_bytes = (o_tg + b_tg + 15) & ~(size_t)15;
+    const size_t in_bytes = (o_go + b_go + 15) & ~(size_t)15;
     if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
     if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
     unsigned char* hin = (unsigned char*)s->h_work;
@@ -576,7 +576,6 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     memcpy(hin + o_wk, bp.work.data(), b_wk);
     memcpy(hin + o_kq, h_kq, b_kq);
     memcpy(hin + o_go, bp.goff.data(), b_go);
-    memset(hin + o_tg, 0, b_tg);
     HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, stream));
     unsigned char* din = (unsigned char*)s->d_in;
     s->d_queries = (xgm_dev_query*)(din + o_dq);
@@ -607,9 +606,13 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         ++idx->prof_used;
     }
     idx->last_kernel = bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    if (bp.orw) {
+        if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
+        HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
+    }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
     if ((rc = bp.andw ? xgm_launch_andw(L, stream)
-              : bp.orw ? xgm_launch_orw(L, (unsigned long long*)(din + o_tg), stream)
+              : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
               : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream)))
         return rc;
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
@@ -754,9 +757,12 @@ int xgm_phase_cycles_fetch(unsigned long long* out8);
 /* Diagnostics: per-phase s_memtime cycle sums of xgm_and_kernel (thread 0 of every workgroup) since
  * the last call; needs XGM_PHASE_TIMING=1 in the environment.  out[0..6] phases, out[7] stripes. */
 extern "C" int xgm_debug_phase_cycles(unsigned long long* out8) { return xgm_phase_cycles_fetch(out8); }
+int xgm_orw_cycles_fetch(unsigned long long* out8);
+extern "C" int xgm_debug_orw_phase_cycles(unsigned long long* out8) { return xgm_orw_cycles_fetch(out8); }
 
-/* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end) of the LAST batch launched on
- * this index from any thread; out is u64[6 * cap]; returns the number of units. */
+/* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end, matches, documents weighed)
+ * of the LAST batch launched on this index from any thread; out is u64[8 * cap]; returns the number
+ * of units. */
 extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out, uint64_t cap) {
     if (!idx || !out || !g_last_ghdr) return -1;
     hipDeviceSynchronize();
@@ -765,8 +771,9 @@ extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out,
     uint64_t n = std::min<uint64_t>(cap, g_last_work.size());
     for (uint64_t i = 0; i < n; ++i) {
         const xgm_work& w = g_last_work[i];
-        out[6 * i] = w.qi; out[6 * i + 1] = w.s_begin; out[6 * i + 2] = w.s_end; out[6 * i + 3] = w.slot;
-        out[6 * i + 4] = h[w.slot].t_start; out[6 * i + 5] = h[w.slot].t_end;
+        out[8 * i] = w.qi; out[8 * i + 1] = w.s_begin; out[8 * i + 2] = w.s_end; out[8 * i + 3] = w.slot;
+        out[8 * i + 4] = h[w.slot].t_start; out[8 * i + 5] = h[w.slot].t_end;
+        out[8 * i + 6] = h[w.slot].matches; out[8 * i + 7] = h[w.slot].pad;
     }
     return (int64_t)n;
 }

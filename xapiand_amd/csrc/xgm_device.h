@@ -10,6 +10,7 @@
 #define XGM_WG 256u                 /* threads per workgroup of the match kernel (4 waves)        */
 #define XGM_WAVES (XGM_WG / 64u)
 #define XGM_MERGE_CAP 8192u         /* candidates one merge workgroup can sort in LDS             */
+#define XGM_OR_HIST 256u            /* weight-histogram buckets per query of xgm_orw_kernel        */
 #define XGM_PHRASE_MAX_TERMS 3u     /* position tables are 4 B/slot/term: LDS bound */
 
 #define XGM_QF_PHRASE 1u            /* apply the positional filter                                 */

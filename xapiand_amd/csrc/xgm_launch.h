@@ -28,9 +28,9 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
 /* wave-autonomous variant: one wave per work unit, no workgroup barriers (first+maxitems <= 192) */
 size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
-/* disjunction-only batches: one wave per work unit, MaxScore pruning; theta_g = [nq] zeroed u64 */
+/* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
-int xgm_launch_orw(const xgm_match_launch& L, unsigned long long* theta_g, hipStream_t stream);
+int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream);
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream);

@@ -22,10 +22,15 @@
  *   3. BM25 (K4, fp64, bm25weight.cc:170-181) per present leaf, tree sum in the reference's
  *      association (absent leaf = -0.0, the identity of IEEE addition), top-k (K5) in the wave's LDS
  *      buffer under msetcmp_by_relevance<true> (msetcmp.cc:55-62).
- * The k-th best weight is shared between the units of a query through one 64-bit atomic max, so a
- * unit starts pruning with what the others have already seen.  Pruning never changes the result:
- * a skipped document's weight is provably below the final k-th weight (strict comparisons; ties are
- * always weighed).
+ * The pruning threshold is GLOBAL per query: every weighed document is counted in a 256-bucket
+ * histogram of weight bit patterns (32 buckets per octave below the query's weight upper bound) shared
+ * by all units of the query through global atomics; the highest bucket with >= k documents at or above
+ * it is a lower bound of the final k-th weight.  To make that bound tight early, a unit runs in two
+ * phases: A weighs only the documents of the term with the largest upper bound (the rarest one —
+ * where the top documents are), B weighs the remaining documents of the essential terms and counts
+ * the matches.  A and B partition the documents, so none is weighed twice.  Pruning never changes the
+ * result: a skipped document's weight is provably below the final k-th weight (strict comparisons;
+ * ties are always weighed).
  */
 #include <hip/hip_runtime.h>
 
@@ -38,10 +43,12 @@
 
 namespace {
 
-constexpr uint32_t kOrwCand = 1024;      /* candidates per scoring chunk: 8 lanes x 4 words x 32 slots */
-constexpr uint32_t kOrwChunkLanes = 8;
-constexpr uint32_t kOrwRegSparse = 4;    /* block-decoded terms whose headers are software-pipelined  */
+constexpr uint32_t kOrwCand = 512;       /* candidates per scoring chunk: 4 lanes x 4 words x 32 slots */
+constexpr uint32_t kOrwChunkLanes = 4;
+constexpr uint32_t kOrwRegSparse = 2;    /* block-decoded terms whose headers are software-pipelined  */
 constexpr uint32_t kNoDense = 0xFFFFFFFFu;
+constexpr uint32_t kQ = 64;              /* quantisation of a weight bound relative to the threshold  */
+constexpr uint32_t kHistShift = 47;      /* weight bits >> 47: sign, exponent, 5 mantissa bits         */
 
 __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
@@ -49,7 +56,8 @@ __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_
     off += (size_t)T * 64 * 8;                                 /* val: per-lane leaf / node weights */
     off += (size_t)cap * 4;                                    /* tk_d */
     off += (size_t)kStageWords * 4;                            /* stage */
-    off += (size_t)(W / 32u) * 4 * 2;                          /* bm_all, bm_ess */
+    off += (size_t)(W / 32u) * 4 * 4;                          /* bm_all, bm_ess, bm_ne, bm_r */
+    off += (size_t)XGM_OR_HIST * 4;                            /* lh: the wave's pending histogram counts */
     off += (size_t)2 * T * spg * 4;                            /* runs */
     off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
     off += (size_t)kOrwCand * 2;                               /* c_slot */
@@ -81,12 +89,12 @@ __device__ void orw_topk_sort(uint64_t* w, uint32_t* d, uint8_t* m, uint32_t cap
 }
 
 /* One posting block: payload (already loaded, 4 words per lane) -> LDS window -> two postings per lane.
- * SCATTER == false: set the docids' bits in bm_all (and bm_ess when the term is essential).
- * SCATTER == true : for postings that are candidates of the current chunk (bit set in bm_ess, word in
+ * SCATTER == false: set the docids' bits in bm_a and, when not null, bm_b / bm_c.
+ * SCATTER == true : for postings that are candidates of the current chunk (bit set in bm_a, word in
  *                   [wlo, whi)), store wdf+1 at the candidate's ordinal in `row`. */
 template <typename TabT, bool SCATTER>
 __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint32_t first, uint32_t* stage, uint32_t lane,
-                                          uint32_t stripe_base, uint32_t* bm_all, uint32_t* bm_ess, bool ess,
+                                          uint32_t stripe_base, uint32_t* bm_a, uint32_t* bm_b, uint32_t* bm_c,
                                           const uint16_t* rankw, TabT* row, uint32_t wlo, uint32_t whi) {
     if (lane * 4u < payload_words(meta)) {
         stage[lane * 4u] = pv.a; stage[lane * 4u + 1] = pv.b; stage[lane * 4u + 2] = pv.c; stage[lane * 4u + 3] = pv.d;
@@ -100,21 +108,23 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
         if (!v) continue;
         const uint32_t s = (h ? r.d1 : r.d0) - stripe_base, wd = s >> 5, bit = s & 31u;
         if (!SCATTER) {
-            atomicOr(&bm_all[wd], 1u << bit);
-            if (ess) atomicOr(&bm_ess[wd], 1u << bit);
+            atomicOr(&bm_a[wd], 1u << bit);
+            if (bm_b) atomicOr(&bm_b[wd], 1u << bit);
+            if (bm_c) atomicOr(&bm_c[wd], 1u << bit);
         } else if (wd >= wlo && wd < whi) {
-            const uint32_t bm = bm_ess[wd];
+            const uint32_t bm = bm_a[wd];
             if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)((h ? r.w1 : r.w0) + 1u);
         }
     }
 }
 
 template <typename TabT>
-__global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+__global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                          unsigned long long* __restrict__ theta_g, int prune,
-                                                          xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+                                                          uint32_t* __restrict__ hist_all, int prune_flags,
+                                                          xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out,
+                                                          unsigned long long* __restrict__ phase_cycles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
@@ -134,6 +144,9 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     uint32_t* stage = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kStageWords * 4;
     uint32_t* bm_all = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* bm_ess = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+    uint32_t* bm_ne = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+    uint32_t* bm_r = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+    uint32_t* lh = reinterpret_cast<uint32_t*>(base + off); off += (size_t)XGM_OR_HIST * 4;
     uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
     for (uint32_t i = lane; i < 2u * tab_terms * SPG; i += 64u) rs[i] = 0;        /* rs and re are adjacent */
     for (uint32_t i = lane; i < T * kOrwCand; i += 64u) c_w[i] = 0;
+    for (uint32_t i = lane; i < XGM_OR_HIST; i += 64u) lh[i] = 0;
     wave_lds_fence();
 
     /* lane t keeps term t's payload base, dense-container index and MaxScore prefix bound */
@@ -165,15 +179,29 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     const uint64_t present_mask = __ballot(present_reg);
     const uint64_t dense_mask = __ballot(present_reg && dense_reg != kNoDense);
     const uint64_t sparse_mask = present_mask & ~dense_mask;
-    double prefix_reg = 0.0;
+    /* MaxScore order: terms by ascending weight upper bound; prefix_reg = sum of the bounds up to and
+     * including this term's.  rank_reg = position in that order. */
+    double prefix_reg = 0.0, ub_reg = 0.0;
+    uint32_t rank_reg = 0;
+    const bool no_sum = (prune_flags & 4) != 0;                    /* A/B: term-level MaxScore only */
     if (lane < T) {
         const double my = q.ub[lane];
+        ub_reg = my;
         for (uint32_t j = 0; j < T; ++j) {
             const double uj = q.ub[j];
-            if (uj < my || (uj == my && j <= lane)) prefix_reg += uj;
+            if (uj < my || (uj == my && j <= lane)) { prefix_reg += uj; ++rank_reg; }
         }
         prefix_reg *= 1.000000001;                                 /* covers the rounding of any summation order */
     }
+    /* the term with the largest bound drives phase A; its prefix is the bound of any document's weight */
+    const uint64_t top_mask = __ballot(present_reg && rank_reg == T);
+    const uint32_t r_term = top_mask ? (uint32_t)__builtin_ctzll(top_mask) : 0u;
+    const uint64_t mp_bits = top_mask ? (((uint64_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)__double_as_longlong(prefix_reg) >> 32), r_term) << 32) |
+                                         __builtin_amdgcn_readlane((uint32_t)(uint64_t)__double_as_longlong(prefix_reg), r_term)) : 0ull;
+    const int hbase = (int)(mp_bits >> kHistShift) - (int)(XGM_OR_HIST - 1u);
+    const bool prune = (prune_flags & 1) && top_mask != 0ull && hbase > 0 && !empty;
+    const bool two_phase = prune && (prune_flags & 2) && __popcll(present_mask) >= 2;
+    uint32_t* hist_g = hist_all + (size_t)wk.qi * XGM_OR_HIST;
 
     /* block ranges of every block-decoded term inside the unit's docid range -> run table */
     for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
@@ -212,23 +240,11 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     bool theta_valid = false;
     uint64_t theta_w = 0;
     uint32_t theta_d = 0;
-    uint64_t theta_glob = 0;
+    uint64_t theta_glob = 0;                                       /* bit pattern; lower bound of the query's final k-th weight */
     unsigned long long matches = 0;                                /* per lane, reduced at the end */
+    uint32_t n_scored = 0;                                         /* diagnostics */
+    bool lh_dirty = false;
     const uint32_t n_local = empty ? 0u : s_end - s_begin;
-
-    auto next_active = [&](uint32_t from) {
-        if (dense_mask) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere */
-        uint32_t x = from;
-        for (; x < n_local; ++x) {
-            bool any = false;
-            for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
-                const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-                any = any || (re[t * SPG + x] != rs[t * SPG + x]);
-            }
-            if (any) break;
-        }
-        return x;
-    };
 
     /* software-pipelined per-stripe registers: lane j = block j of the pipelined terms' runs; lane t =
      * container offset of dense term t */
@@ -254,41 +270,58 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     uint32_t stripe_base = 0;
     uint32_t hc_cur = 0;
 
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};           /* diagnostics: cycles per section */
+    unsigned long long tmark = phase_cycles ? __builtin_readcyclecounter() : 0ull;
+#define ORW_PH(i) do { if (phase_cycles) { const unsigned long long n_ = __builtin_readcyclecounter(); pc[i] += n_ - tmark; tmark = n_; } } while (0)
+
     /* BM25 + tree sum + top-k for the n_c candidates of the chunk; clears c_w behind itself */
     auto score_candidates = [&](uint32_t n_c) {
+        n_scored += n_c;
+        uint32_t dl_next = lane < n_c ? seg.doclen[stripe_base + c_slot[lane]] : 1u;
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
             if (tkn + 64u > cap) {
                 orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
                 tkn = tkn < k ? tkn : k;
-                if (tkn == k) {
-                    theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1];
-                    if (prune && lane == 0) atomicMax(&theta_g[wk.qi], (unsigned long long)theta_w);
-                }
+                if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
                 for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
                 wave_lds_fence();
             }
             const uint32_t o = i0 + lane;
             const bool valid = o < n_c;
             const uint32_t did = stripe_base + (valid ? (uint32_t)c_slot[o] : 0u);
-            const uint32_t dlen = valid ? seg.doclen[did] : 1u;
+            const uint32_t dlen = dl_next;
+            {                                                       /* the next round's document lengths fly while this one is weighed */
+                const uint32_t on = o + 64u;
+                dl_next = on < n_c ? seg.doclen[stripe_base + c_slot[on]] : 1u;
+            }
             /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
             const double len = (double)dlen;
             double normlen = len * q.len_factor;
             normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
             const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
             uint32_t subqs = 0;
-            for (uint32_t t = 0; t < T; ++t) {
-                const uint32_t e = valid ? (uint32_t)c_w[(size_t)t * kOrwCand + o] : 0u;
-                double wt = -0.0;                                   /* absent leaf: x + (-0.0) == x */
-                if (__ballot(e != 0u)) {                            /* nobody in the round has the term: skip the divide */
-                    const double wdf = (double)(e - 1u);
-                    const double denom = denom_len + wdf;
-                    const double x = q.termweight[t] * (wdf / denom);
-                    wt = e ? x : -0.0;
-                    subqs += e ? 1u : 0u;
-                    if (e) c_w[(size_t)t * kOrwCand + o] = 0;
+            for (uint32_t t0 = 0; t0 < T; t0 += 4u) {              /* four leaves at a time: independent divide chains */
+                uint32_t ev[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) ev[u] = (t0 + u < T && valid) ? (uint32_t)c_w[(size_t)(t0 + u) * kOrwCand + o] : 0u;
+                double wt[4] = {-0.0, -0.0, -0.0, -0.0};            /* absent leaf: x + (-0.0) == x */
+                if (__ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {   /* nobody in the round has these terms: skip the divides */
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const double wdf = (double)(ev[u] - 1u);
+                        const double denom = denom_len + wdf;
+                        const double x = q.termweight[(t0 + u) & (XGM_MAX_TERMS - 1u)] * (wdf / denom);
+                        wt[u] = ev[u] ? x : -0.0;
+                        subqs += ev[u] ? 1u : 0u;
+                    }
                 }
-                val[t * 64u + lane] = wt;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    if (t0 + u < T) {
+                        val[(t0 + u) * 64u + lane] = wt[u];
+                        if (ev[u]) c_w[(size_t)(t0 + u) * kOrwCand + o] = 0;
+                    }
+                }
             }
             /* OrPostList::get_weight: l + r up the tree (in place: node j lands in its left operand's slot) */
             for (uint32_t j = 0; j + 1u < T; ++j) {
@@ -297,193 +330,179 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
             }
             const double weight = val[(uint32_t)q.ip_root * 64u + lane];
             const uint64_t wb = (uint64_t)__double_as_longlong(weight);
-            const bool take = valid && subqs != 0u && (!theta_valid || cand_before(wb, did, theta_w, theta_d)) && wb >= theta_glob;
+            const bool live = valid && subqs != 0u && wb >= theta_glob;
+            if (prune && live) {
+                int b = (int)(wb >> kHistShift) - hbase;
+                b = b < 0 ? 0 : (b > (int)XGM_OR_HIST - 1 ? (int)XGM_OR_HIST - 1 : b);
+                atomicAdd(&lh[b], 1u);
+            }
+            if (prune && __ballot(live)) lh_dirty = true;
+            const bool take = live && (!theta_valid || cand_before(wb, did, theta_w, theta_d));
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
         }
     };
 
-    uint32_t sl = next_active(0);
-    if (sl < n_local) issue_headers(sl);
-    while (sl < n_local) {
-        stripe_base = (s_begin + sl) << SB;
-        const uint32_t sl_next = next_active(sl + 1u);
-        hc_cur = hc_off;
-        /* this stripe's block headers (the registers are re-used for the next stripe's prefetch) */
-        uint32_t cm[kOrwRegSparse], cf[kOrwRegSparse], cw[kOrwRegSparse], cn[kOrwRegSparse], cnb[kOrwRegSparse];
-#pragma unroll
-        for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
-            cm[u] = hm[u]; cf[u] = hf[u]; cw[u] = hw[u]; cn[u] = hn[u];
-            cnb[u] = u < n_sp ? re[sp_t[u] * SPG + sl] - rs[sp_t[u] * SPG + sl] : 0u;
-        }
+    for (uint32_t phase = two_phase ? 0u : 1u; phase < 2u; ++phase) {
+        const bool phase_a = phase == 0u;
+        const bool split = two_phase && !phase_a;                  /* phase B after an A: r_term's documents are done */
+        const uint64_t memb_mask = phase_a ? (1ull << r_term) : present_mask;
 
-        /* ---- MaxScore: which terms are essential under the best threshold known ---- */
-        uint64_t ess_mask = present_mask;
-        if (prune) {
-            theta_glob = __hip_atomic_load(&theta_g[wk.qi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
-            const double th = __longlong_as_double((long long)th_bits);
-            ess_mask = __ballot(present_reg && !(prefix_reg < th));
-        }
+        auto next_active = [&](uint32_t from) {
+            if (dense_mask & memb_mask) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere */
+            uint32_t x = from;
+            for (; x < n_local; ++x) {
+                bool any = false;
+                for (uint64_t sm = sparse_mask & memb_mask; sm; sm &= sm - 1u) {
+                    const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+                    any = any || (re[t * SPG + x] != rs[t * SPG + x]);
+                }
+                if (any) break;
+            }
+            return x;
+        };
 
-        /* ---- 1a. dense terms: OR of the containers' bitmaps (4 words per lane) ---- */
-        uint32_t a[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
-        for (uint64_t dm = dense_mask; dm;) {
-            uint32_t tt[4], oo[4];
-            uint32_t x[4][4];
+        uint32_t sl = next_active(0);
+        if (sl < n_local) issue_headers(sl);
+        while (sl < n_local) {
+            ORW_PH(7);
+            stripe_base = (s_begin + sl) << SB;
+            const uint32_t sl_next = next_active(sl + 1u);
+            hc_cur = hc_off;
+            /* this stripe's block headers (the registers are re-used for the next stripe's prefetch) */
+            uint32_t cm[kOrwRegSparse], cf[kOrwRegSparse], cw[kOrwRegSparse], cn[kOrwRegSparse], cnb[kOrwRegSparse];
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                tt[u] = 0; oo[u] = 0;
-                if (dm) { tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u; oo[u] = __builtin_amdgcn_readlane(hc_cur, tt[u]); }
+            for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
+                cm[u] = hm[u]; cf[u] = hf[u]; cw[u] = hw[u]; cn[u] = hn[u];
+                cnb[u] = u < n_sp ? re[sp_t[u] * SPG + sl] - rs[sp_t[u] * SPG + sl] : 0u;
+            }
+
+            /* ---- global threshold: highest histogram bucket with >= k documents at or above it ---- */
+            uint32_t hc[4] = {0, 0, 0, 0};
+            if (prune) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+
+            /* ---- 1a. dense terms: union of the containers' bitmaps (4 words per lane) and, once a
+             * threshold is known, the bit-sliced sum of the present terms' quantised weight bounds:
+             * plane j of S holds bit j of min(sum, 63) for 32 documents, ovf = the sum reached kQ. ---- */
+            uint32_t a[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+            uint32_t S[6][4], ovf[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t j = 0; j < 6u; ++j) { S[j][0] = S[j][1] = S[j][2] = S[j][3] = 0; }
+            auto add_bound = [&](uint32_t qv, const uint32_t* B) {
+                if (qv >= kQ) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= B[i];
+                    return;
+                }
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
-                    x[u][i] = 0;
-                    const uint32_t w = lane * 4u + i;
-                    if (oo[u] && w < NW) x[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16)[w];
-                }
-            }
+                    uint32_t carry = 0;
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                const bool es = (ess_mask >> tt[u]) & 1ull;
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) { a[i] |= x[u][i]; if (es) e[i] |= x[u][i]; }
-            }
-        }
-        if (sparse_mask) {
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i) {
-                const uint32_t w = lane * 4u + i;
-                if (w < NW) { bm_all[w] = a[i]; bm_ess[w] = e[i]; }
-            }
-            wave_lds_fence();
-            /* ---- 1b. block-decoded terms: every block of the stripe ---- */
-            uint64_t bmask[kOrwRegSparse];
-#pragma unroll
-            for (uint32_t u = 0; u < kOrwRegSparse; ++u) bmask[u] = cnb[u] >= 64u ? ~0ull : ((1ull << cnb[u]) - 1ull);
-            while (true) {
-                uint64_t any = 0;
-#pragma unroll
-                for (uint32_t u = 0; u < kOrwRegSparse; ++u) any |= bmask[u];
-                if (!any) break;
-                uint32_t jj[kOrwRegSparse];
-                Words4 pv[kOrwRegSparse];
-                bool have[kOrwRegSparse];
-#pragma unroll
-                for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
-                    have[u] = bmask[u] != 0ull;
-                    jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
-                    if (have[u]) {
-                        jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
-                        bmask[u] &= bmask[u] - 1u;
-                        const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
-                        if (lane * 4u < payload_words(bm))
-                            pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
-                    if (have[u])
-                        orw_block<TabT, false>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
-                                               stripe_base, bm_all, bm_ess, (ess_mask >> sp_t[u]) & 1ull, rankw, c_w, 0u, 0u);
-                }
-            }
-            for (uint64_t sm = slow_sparse_mask; sm; sm &= sm - 1u) {
-                const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-                const uint32_t rb = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb;
-                for (uint32_t j = 0; j < nb; ++j) {
-                    const uint32_t meta = seg.blk_meta[rb + j], first = seg.blk_first[rb + j];
-                    Words4 pv = Words4{0, 0, 0, 0};
-                    if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb + j] + lane * 4u);
-                    orw_block<TabT, false>(pv, meta, first, stage, lane, stripe_base, bm_all, bm_ess, (ess_mask >> t) & 1ull, rankw, c_w, 0u, 0u);
-                }
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; ++i) {
-                const uint32_t w = lane * 4u + i;
-                if (w < NW) { a[i] = bm_all[w]; e[i] = bm_ess[w]; }
-            }
-        }
-
-        /* ---- exact match count; candidates = essential union ---- */
-        matches += (unsigned long long)(__popc(a[0]) + __popc(a[1]) + __popc(a[2]) + __popc(a[3]));
-        const uint32_t cnt = (uint32_t)(__popc(e[0]) + __popc(e[1]) + __popc(e[2]) + __popc(e[3]));
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
-        if (n_total == 0u) {
-            if (sl_next < n_local) issue_headers(sl_next);
-            sl = sl_next;
-            continue;
-        }
-        const bool single = n_total <= kOrwCand;
-        const uint32_t n_chunks = single ? 1u : 64u / kOrwChunkLanes;
-        for (uint32_t c = 0; c < n_chunks; ++c) {
-            const uint32_t lane_lo = single ? 0u : c * kOrwChunkLanes;
-            const uint32_t lane_hi = single ? 64u : lane_lo + kOrwChunkLanes;
-            const uint32_t ord_base = lane_lo ? __builtin_amdgcn_readlane(incl, lane_lo - 1u) : 0u;
-            const uint32_t n_c = __builtin_amdgcn_readlane(incl, lane_hi - 1u) - ord_base;
-            const bool last_chunk = c + 1u == n_chunks;
-            if (n_c == 0u) {
-                if (last_chunk && sl_next < n_local) issue_headers(sl_next);
-                continue;
-            }
-            const bool in_chunk = lane >= lane_lo && lane < lane_hi;
-            const uint32_t wlo = lane_lo * 4u, whi = lane_hi * 4u;
-            /* ---- 2a. enumerate the chunk's candidates in docid order ---- */
-            if (in_chunk) {
-                uint32_t o = incl - cnt - ord_base;
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint32_t w = lane * 4u + i;
-                    if (w < NW) rankw[w] = (uint16_t)o;
-                    uint32_t m = e[i];
-                    while (m) {
-                        const uint32_t bit = (uint32_t)__ffs(m) - 1u;
-                        c_slot[o] = (uint16_t)(w * 32u + bit);
-                        m &= m - 1u;
-                        ++o;
-                    }
-                }
-            }
-            const unsigned long long coarse = __ballot(in_chunk && cnt != 0u);   /* bit = 128-slot bucket with a candidate */
-            wave_lds_fence();
-
-            /* ---- 2b. wdf of the dense terms: one byte per candidate and term ---- */
-            for (uint32_t c0 = 0; c0 < n_c; c0 += 64u) {
-                const uint32_t o = c0 + lane;
-                const bool valid = o < n_c;
-                const uint32_t slot = valid ? c_slot[o] : 0u;
-                for (uint64_t dm = dense_mask; dm;) {
-                    uint32_t tt[4], wv[4];
-                    bool on[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) {
-                        tt[u] = 0; wv[u] = 0; on[u] = false;
-                        if (dm) {
-                            tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u;
-                            const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, tt[u]);
-                            on[u] = oo != 0u;
-                            if (on[u] && valid) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+                    for (uint32_t j = 0; j < 6u; ++j) {
+                        const uint32_t sj = S[j][i];
+                        if ((qv >> j) & 1u) {
+                            const uint32_t xo = sj ^ B[i];
+                            S[j][i] = xo ^ carry;
+                            carry = (sj & B[i]) | (carry & xo);
+                        } else {
+                            S[j][i] = sj ^ carry;
+                            carry &= sj;
                         }
                     }
+                    ovf[i] |= carry;
+                }
+            };
+            uint64_t ess_mask = present_mask;                       /* block-decoded terms whose documents are all candidates */
+            bool use_sum = false;                                   /* candidates of the dense terms come from the bound sum */
+            uint32_t q_reg = kQ;                                    /* lane t: quantised bound of term t */
+            uint32_t q_ne = 0;                                      /* ... of the non-essential block-decoded terms together */
+            bool first_group = true;
+            for (uint64_t dm = dense_mask & memb_mask; dm || first_group;) {
+                uint32_t tt[4], oo[4];
+                uint32_t x[4][4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u)
-                        if (on[u] && valid && wv[u]) c_w[(size_t)tt[u] * kOrwCand + o] = (TabT)wv[u];
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    tt[u] = 0; oo[u] = 0;
+                    if (dm) { tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u; oo[u] = __builtin_amdgcn_readlane(hc_cur, tt[u]); }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        x[u][i] = 0;
+                        const uint32_t w = lane * 4u + i;
+                        if (oo[u] && w < NW) x[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16)[w];
+                    }
+                }
+                if (first_group) {
+                    first_group = false;
+                    /* the histogram loads were issued before the bitmaps': consume them while those fly */
+                    if (prune) {
+                        const uint32_t s4 = hc[0] + hc[1] + hc[2] + hc[3];
+                        const uint32_t P = wave_incl_scan(s4);
+                        const uint32_t suf = __builtin_amdgcn_readlane(P, 63) - P + s4;       /* documents in buckets >= 4 * lane */
+                        const uint64_t okm = __ballot(suf >= k);
+                        if (okm) {
+                            const uint32_t Lh = 63u - (uint32_t)__builtin_clzll(okm);
+                            const uint32_t cum = __builtin_amdgcn_readlane(suf, Lh) - __builtin_amdgcn_readlane(s4, Lh);
+                            uint32_t bsel = 4u * Lh;
+                            const uint32_t c3 = __builtin_amdgcn_readlane(hc[3], Lh), c2 = __builtin_amdgcn_readlane(hc[2], Lh), c1 = __builtin_amdgcn_readlane(hc[1], Lh);
+                            if (cum + c3 >= k) bsel = 4u * Lh + 3u;
+                            else if (cum + c3 + c2 >= k) bsel = 4u * Lh + 2u;
+                            else if (cum + c3 + c2 + c1 >= k) bsel = 4u * Lh + 1u;
+                            if (bsel > 0u) {
+                                const uint64_t tb = (uint64_t)((uint32_t)hbase + bsel) << kHistShift;
+                                theta_glob = tb > theta_glob ? tb : theta_glob;
+                            }
+                        }
+                        if (phase_a) {
+                            ess_mask = 1ull << r_term;
+                        } else {
+                            const uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
+                            if (th_bits) {
+                                const double th = __longlong_as_double((long long)th_bits);
+                                ess_mask = __ballot(present_reg && !(prefix_reg < th));      /* MaxScore over all terms */
+                                use_sum = !no_sum;
+                                /* quantise UP: q >= ub * kQ / th, so sum(q) >= kQ whenever sum(ub) >= th */
+                                const double rq = ub_reg * (double)kQ / th;
+                                q_reg = rq >= (double)kQ ? kQ : (uint32_t)rq + 1u;
+                                double ne_sum = 0.0;
+                                for (uint64_t sm = sparse_mask & ~ess_mask; sm; sm &= sm - 1u) {
+                                    const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+                                    const uint64_t ubits = (uint64_t)__double_as_longlong(ub_reg);
+                                    ne_sum += __longlong_as_double((long long)(((uint64_t)__builtin_amdgcn_readlane((uint32_t)(ubits >> 32), t) << 32) |
+                                                                               __builtin_amdgcn_readlane((uint32_t)ubits, t)));
+                                }
+                                const double rn = ne_sum * (double)kQ / th;
+                                q_ne = ne_sum > 0.0 ? (rn >= (double)kQ ? kQ : (uint32_t)rn + 1u) : 0u;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const bool is_r = tt[u] == r_term;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) { a[i] |= x[u][i]; if (is_r) rb[i] |= x[u][i]; }
+                    if (use_sum && oo[u]) add_bound(__builtin_amdgcn_readlane(q_reg, tt[u]), x[u]);
                 }
             }
-
-            /* ---- 2c. wdf of the block-decoded terms: only blocks whose buckets hold a candidate ---- */
-            auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
-                const uint32_t lo = (first - stripe_base) >> 7;
-                const uint32_t hi = ((nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base) - 1u) >> 7;
-                const unsigned long long mm = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
-                return (coarse & mm) != 0ull;
-            };
-            if (sparse_mask) {
+            ORW_PH(0);
+            const uint64_t sp_memb = sparse_mask & memb_mask;
+            uint32_t es[4] = {0, 0, 0, 0}, ne[4] = {0, 0, 0, 0};   /* unions of the essential / other block-decoded terms */
+            if (sp_memb) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t w = lane * 4u + i;
+                    if (w < NW) { bm_all[w] = a[i]; bm_ess[w] = 0; bm_ne[w] = 0; bm_r[w] = rb[i]; }
+                }
+                wave_lds_fence();
+                /* ---- 1b. block-decoded terms: every block of the stripe ---- */
                 uint64_t bmask[kOrwRegSparse];
 #pragma unroll
-                for (uint32_t u = 0; u < kOrwRegSparse; ++u) bmask[u] = __ballot(lane < cnb[u] && bucket_need(cf[u], cn[u]));
+                for (uint32_t u = 0; u < kOrwRegSparse; ++u)
+                    bmask[u] = (u < n_sp && ((sp_memb >> sp_t[u]) & 1ull)) ? (cnb[u] >= 64u ? ~0ull : ((1ull << cnb[u]) - 1ull)) : 0ull;
                 while (true) {
                     uint64_t any = 0;
 #pragma unroll
@@ -507,40 +526,223 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
 #pragma unroll
                     for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
                         if (have[u])
-                            orw_block<TabT, true>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
-                                                  stripe_base, bm_all, bm_ess, false, rankw, c_w + (size_t)sp_t[u] * kOrwCand, wlo, whi);
+                            orw_block<TabT, false>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
+                                                   stripe_base, bm_all, ((ess_mask >> sp_t[u]) & 1ull) ? bm_ess : bm_ne,
+                                                   sp_t[u] == r_term ? bm_r : nullptr, rankw, c_w, 0u, 0u);
                     }
                 }
-                for (uint64_t sm = slow_sparse_mask; sm; sm &= sm - 1u) {
+                for (uint64_t sm = slow_sparse_mask & memb_mask; sm; sm &= sm - 1u) {
                     const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-                    const uint32_t rb = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb;
+                    const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
                     for (uint32_t j = 0; j < nb; ++j) {
-                        const uint32_t meta = seg.blk_meta[rb + j], first = seg.blk_first[rb + j];
-                        const uint32_t nfirst = j + 1u < nb ? seg.blk_first[rb + j + 1u] : 0xFFFFFFFFu;
-                        if (!bucket_need(first, nfirst)) continue;
+                        const uint32_t meta = seg.blk_meta[rb0 + j], first = seg.blk_first[rb0 + j];
                         Words4 pv = Words4{0, 0, 0, 0};
-                        if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb + j] + lane * 4u);
-                        orw_block<TabT, true>(pv, meta, first, stage, lane, stripe_base, bm_all, bm_ess, false, rankw, c_w + (size_t)t * kOrwCand, wlo, whi);
+                        if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
+                        orw_block<TabT, false>(pv, meta, first, stage, lane, stripe_base, bm_all, ((ess_mask >> t) & 1ull) ? bm_ess : bm_ne,
+                                               t == r_term ? bm_r : nullptr, rankw, c_w, 0u, 0u);
                     }
+                }
+                wave_lds_fence();
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t w = lane * 4u + i;
+                    if (w < NW) { a[i] = bm_all[w]; es[i] = bm_ess[w]; ne[i] = bm_ne[w]; rb[i] = bm_r[w]; }
                 }
             }
-            wave_lds_fence();
+            /* ---- candidates ---- */
+            if (phase_a) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) e[i] = rb[i];
+            } else if (use_sum) {
+                if (q_ne) add_bound(q_ne, ne);
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) e[i] = es[i] | ovf[i];
+            } else if (prune && ess_mask != present_mask) {
+                /* the bound sum is switched off (A/B): every document of an essential term */
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) e[i] = es[i];
+                for (uint64_t dm = dense_mask & ess_mask; dm; dm &= dm - 1u) {
+                    const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, (uint32_t)__builtin_ctzll(dm));
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t w = lane * 4u + i;
+                        if (oo && w < NW) e[i] |= reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo * 16)[w];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) e[i] = a[i];
+            }
+            if (split) {
+                /* r_term's documents were weighed in phase A */
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) e[i] &= ~rb[i];
+            }
+            /* the scatter of the block-decoded terms looks candidates up in bm_ess */
+            if (sparse_mask) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t w = lane * 4u + i;
+                    if (w < NW) bm_ess[w] = e[i];
+                }
+            }
+            ORW_PH(1);
 
-            /* headers of the next active stripe: in flight while this chunk is scored */
-            if (last_chunk && sl_next < n_local) issue_headers(sl_next);
+            /* ---- exact match count (phase B); candidates in docid order ---- */
+            if (!phase_a) matches += (unsigned long long)(__popc(a[0]) + __popc(a[1]) + __popc(a[2]) + __popc(a[3]));
+            const uint32_t cnt = (uint32_t)(__popc(e[0]) + __popc(e[1]) + __popc(e[2]) + __popc(e[3]));
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
+            if (n_total == 0u) {
+                if (sl_next < n_local) issue_headers(sl_next);
+                sl = sl_next;
+                continue;
+            }
+            /* chunks of consecutive lanes holding <= kOrwCand candidates (one lane owns <= 128) */
+            for (uint32_t lane_lo = 0; lane_lo < 64u;) {
+                const uint32_t ord_base = lane_lo ? __builtin_amdgcn_readlane(incl, lane_lo - 1u) : 0u;
+                if (ord_base == n_total) break;
+                const uint64_t fit = __ballot(incl - ord_base <= kOrwCand);          /* incl is monotone: bits up to the last lane that fits */
+                const uint32_t lane_hi = 64u - (uint32_t)__builtin_clzll(fit);
+                const uint32_t hi_incl = __builtin_amdgcn_readlane(incl, lane_hi - 1u);
+                const uint32_t n_c = hi_incl - ord_base;
+                const bool last_chunk = hi_incl == n_total;
+                const bool in_chunk = lane >= lane_lo && lane < lane_hi;
+                const uint32_t wlo = lane_lo * 4u, whi = lane_hi * 4u;
+                lane_lo = lane_hi;
+                /* ---- 2a. enumerate the chunk's candidates in docid order ---- */
+                if (in_chunk) {
+                    uint32_t o = incl - cnt - ord_base;
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t w = lane * 4u + i;
+                        if (w < NW) rankw[w] = (uint16_t)o;
+                        uint32_t m = e[i];
+                        while (m) {
+                            const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+                            c_slot[o] = (uint16_t)(w * 32u + bit);
+                            m &= m - 1u;
+                            ++o;
+                        }
+                    }
+                }
+                const unsigned long long coarse = __ballot(in_chunk && cnt != 0u);   /* bit = 128-slot bucket with a candidate */
+                wave_lds_fence();
+                ORW_PH(2);
 
-            /* ---- 3. BM25, tree sum, top-k ---- */
-            score_candidates(n_c);
-            wave_lds_fence();
+                /* ---- 2b. wdf of the dense terms: one byte per candidate and term, two rounds in flight ---- */
+                for (uint32_t c0 = 0; c0 < n_c; c0 += 128u) {
+                    const uint32_t o0 = c0 + lane, o1 = o0 + 64u;
+                    const bool v0 = o0 < n_c, v1 = o1 < n_c;
+                    const uint32_t slot0 = v0 ? c_slot[o0] : 0u, slot1 = v1 ? c_slot[o1] : 0u;
+                    for (uint64_t dm = dense_mask; dm;) {
+                        uint32_t tt[4], wv0[4], wv1[4];
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) {
+                            tt[u] = 0; wv0[u] = 0; wv1[u] = 0;
+                            if (dm) {
+                                tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u;
+                                const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, tt[u]);
+                                if (oo) {
+                                    const unsigned char* wb = seg.dense_data + (size_t)oo * 16 + (size_t)NW * 4;
+                                    if (v0) wv0[u] = wb[slot0];
+                                    if (v1) wv1[u] = wb[slot1];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) {
+                            if (wv0[u]) c_w[(size_t)tt[u] * kOrwCand + o0] = (TabT)wv0[u];
+                            if (wv1[u]) c_w[(size_t)tt[u] * kOrwCand + o1] = (TabT)wv1[u];
+                        }
+                    }
+                }
+                ORW_PH(3);
+
+                /* ---- 2c. wdf of the block-decoded terms: only blocks whose buckets hold a candidate ---- */
+                auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
+                    const uint32_t lo = (first - stripe_base) >> 7;
+                    const uint32_t hi = ((nfirst == 0xFFFFFFFFu ? W : nfirst - stripe_base) - 1u) >> 7;
+                    const unsigned long long mm = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
+                    return (coarse & mm) != 0ull;
+                };
+                if (sparse_mask) {
+                    uint64_t bmask[kOrwRegSparse];
+#pragma unroll
+                    for (uint32_t u = 0; u < kOrwRegSparse; ++u) bmask[u] = __ballot(lane < cnb[u] && bucket_need(cf[u], cn[u]));
+                    while (true) {
+                        uint64_t any = 0;
+#pragma unroll
+                        for (uint32_t u = 0; u < kOrwRegSparse; ++u) any |= bmask[u];
+                        if (!any) break;
+                        uint32_t jj[kOrwRegSparse];
+                        Words4 pv[kOrwRegSparse];
+                        bool have[kOrwRegSparse];
+#pragma unroll
+                        for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
+                            have[u] = bmask[u] != 0ull;
+                            jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                            if (have[u]) {
+                                jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
+                                bmask[u] &= bmask[u] - 1u;
+                                const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
+                                if (lane * 4u < payload_words(bm))
+                                    pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
+                            if (have[u])
+                                orw_block<TabT, true>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
+                                                      stripe_base, bm_ess, nullptr, nullptr, rankw, c_w + (size_t)sp_t[u] * kOrwCand, wlo, whi);
+                        }
+                    }
+                    for (uint64_t sm = slow_sparse_mask; sm; sm &= sm - 1u) {
+                        const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+                        const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
+                        for (uint32_t j = 0; j < nb; ++j) {
+                            const uint32_t meta = seg.blk_meta[rb0 + j], first = seg.blk_first[rb0 + j];
+                            const uint32_t nfirst = j + 1u < nb ? seg.blk_first[rb0 + j + 1u] : 0xFFFFFFFFu;
+                            if (!bucket_need(first, nfirst)) continue;
+                            Words4 pv = Words4{0, 0, 0, 0};
+                            if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
+                            orw_block<TabT, true>(pv, meta, first, stage, lane, stripe_base, bm_ess, nullptr, nullptr, rankw, c_w + (size_t)t * kOrwCand, wlo, whi);
+                        }
+                    }
+                }
+                wave_lds_fence();
+                ORW_PH(4);
+
+                /* headers of the next active stripe: in flight while this chunk is scored */
+                if (last_chunk && sl_next < n_local) issue_headers(sl_next);
+
+                /* ---- 3. BM25, tree sum, top-k ---- */
+                score_candidates(n_c);
+                wave_lds_fence();
+                ORW_PH(5);
+            }
+            /* publish this stripe's histogram counts */
+            if (lh_dirty) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t v = lh[lane * 4u + i];
+                    if (v) { atomicAdd(&hist_g[lane * 4u + i], v); lh[lane * 4u + i] = 0; }
+                }
+                lh_dirty = false;
+                wave_lds_fence();
+            }
+            ORW_PH(6);
+            sl = sl_next;
         }
-        sl = sl_next;
     }
+    ORW_PH(7);
+    if (phase_cycles && lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
+#undef ORW_PH
 
     /* ---- unit epilogue ---- */
     orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
     for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
     const uint32_t n_out = tkn < k ? tkn : k;
-    if (prune && n_out == k && lane == 0) atomicMax(&theta_g[wk.qi], (unsigned long long)tk_w[k - 1]);
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = lane; i < n_out; i += 64u) {
         xgm_cand c;
@@ -549,7 +751,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_orw_kernel(xgm_seg_dev seg, const 
     }
     if (lane == 0) {
         xgm_group_hdr h;
-        h.matches = matches; h.n_cand = n_out; h.pad = 0;
+        h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         ghdr_out[wk.slot] = h;
     }
@@ -566,12 +768,30 @@ int orw_ensure_dyn_smem(K kern, size_t smem, std::atomic<size_t>& seen) {
 
 }  // namespace
 
+static unsigned long long* g_orw_cycles = nullptr;          /* device buffer, diagnostics only */
+
+/* Diagnostics (XGM_PHASE_TIMING=1): cycle sums per section of xgm_orw_kernel since the last call:
+ * [0] threshold + dense bitmaps + bound sum, [1] block decode + candidate set, [2] enumerate,
+ * [3] dense probes, [4] block scatter, [5] BM25 + top-k, [6] histogram flush, [7] setup. */
+int xgm_orw_cycles_fetch(unsigned long long* out8) {
+    if (!g_orw_cycles) return -1;
+    (void)hipDeviceSynchronize();
+    hipMemcpy(out8, g_orw_cycles, 64, hipMemcpyDeviceToHost);
+    hipMemset(g_orw_cycles, 0, 64);
+    return 0;
+}
+
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg) {
     return XGM_WAVES * orw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg);
 }
 
-int xgm_launch_orw(const xgm_match_launch& L, unsigned long long* theta_g, hipStream_t stream) {
-    static const bool no_prune = getenv("XGM_NO_PRUNE") != nullptr;          /* A/B switch for measurements */
+int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream) {
+    static const bool no_prune = getenv("XGM_NO_PRUNE") != nullptr;          /* A/B switches for measurements */
+    static const bool no_phase_a = getenv("XGM_NO_PHASE_A") != nullptr;
+    static const bool no_sum = getenv("XGM_NO_BOUND_SUM") != nullptr;
+    static const bool timing = getenv("XGM_PHASE_TIMING") != nullptr;
+    if (timing && !g_orw_cycles) { hipMalloc((void**)&g_orw_cycles, 64); hipMemset(g_orw_cycles, 0, 64); }
+    const int flags = no_prune ? 0 : ((no_phase_a ? 1 : 3) | (no_sum ? 4 : 0));
     const size_t smem = xgm_orw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);
     static std::atomic<size_t> seen8{0}, seen16{0};
@@ -580,12 +800,12 @@ int xgm_launch_orw(const xgm_match_launch& L, unsigned long long* theta_g, hipSt
         auto kern = xgm_orw_kernel<uint16_t>;
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen16))) return rc;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap,
-                           L.k_stride, theta_g, no_prune ? 0 : 1, L.cand, L.ghdr);
+                           L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);
     } else {
         auto kern = xgm_orw_kernel<uint8_t>;
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen8))) return rc;
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap,
-                           L.k_stride, theta_g, no_prune ? 0 : 1, L.cand, L.ghdr);
+                           L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("xgm_orw_kernel launch", (int)e, hipGetErrorString(e));
