@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,7 +162,7 @@ def main():
 
     # ---- latency mode: one query in flight, host-timed around xgm_search (incl. H2D/D2H) -----------
     lat = []
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.no_latency:
         one_hits = (_lib.Hit * k)()
         one_hdr = _lib.ResultHdr()
         db.set_stream(0)

@@ -12,11 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELECT = "random_queries_vs_oracle or other_stripe_widths or edge_cases or batch_equals_single"
 
 
+PHRASE_SELECT = "phrase or other_stripe_widths or edge_cases"
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("switch", ["XGM_NO_DENSE", "XGM_NO_ANDW", "XGM_NO_ORW", "XGM_NO_PRUNE", "XGM_NO_PHASE_A", "XGM_NO_BOUND_SUM"])
-def test_parity_with_fast_path_disabled(built, switch):
+@pytest.mark.parametrize("switch,select", [("XGM_NO_DENSE", SELECT), ("XGM_NO_ANDW", SELECT + " or phrase"), ("XGM_NO_ORW", SELECT),
+                                           ("XGM_NO_PRUNE", SELECT), ("XGM_NO_PHASE_A", SELECT), ("XGM_NO_BOUND_SUM", SELECT),
+                                           ("XGM_NO_PHRASEW", PHRASE_SELECT)])
+def test_parity_with_fast_path_disabled(built, switch, select):
     env = dict(os.environ)
     env[switch] = "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
-                        "-k", SELECT, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        "-k", select, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "%s=1:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-2000:])

@@ -423,6 +423,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
                       BatchPlan* bp) {
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
+    bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
     static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
     if (no_and_kernel) bp->and_only = false;
     for (uint32_t i = 0; i < nq; ++i) {
@@ -434,6 +435,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         if (width == 2) bp->wide = true;
         if (dq[i].op != XGM_OP_AND || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE)) bp->and_only = false;
         if (dq[i].op != XGM_OP_OR) or_only = false;
+        if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_PHRASE) || dq[i].n_terms < 2) conj_only = false;
         if (dq[i].flags & XGM_QF_PHRASE) {
             if (dq[i].n_terms > XGM_PHRASE_MAX_TERMS) return XGM_UNSUPPORTED;
             bp->phrase = true;
@@ -450,7 +452,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     static const bool no_andw = getenv("XGM_NO_ANDW") != nullptr;                    /* A/B switch for measurements */
     const uint32_t n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
     const uint32_t k_pad = next_pow2(bp->k_max);
-    bp->andw = bp->and_only && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP;
+    static const bool no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr;           /* A/B switch for measurements */
+    const bool phrase_conj = conj_only && bp->phrase && !no_phrase_w && !no_and_kernel;
+    bp->andw = (bp->and_only || phrase_conj) && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP &&
+               xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, 32u, bp->phrase) <= 160u * 1024u;
     /* disjunctions: one wave per unit as well; a unit spans as many stripes as the merge capacity
      * (units x k candidates per query) requires */
     uint32_t orw_spg = 32u;
@@ -490,7 +495,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             uint32_t id = qs[i].terms[t].term_id;
             if (id == UINT32_MAX) { min_df = 0; all_dense = false; continue; }
             const double df = idx->term_df[id];
-            const bool dense = bp->andw && !bp->wide && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
+            const bool dense = bp->andw && !bp->wide && !bp->phrase && idx->dense_min_df && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
             if (!dense) { sparse_blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes); all_dense = false; }
             min_df = std::min(min_df, df);
             dens *= df / n_docs;
@@ -538,7 +543,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
     for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
-    const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
+    const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase)
                         : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;

@@ -943,14 +943,14 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
  * anywhere, so a CU keeps ~20 independent instruction streams in flight instead of 4-6 barrier-coupled
  * groups, and the per-stripe latency chain of one unit is covered by the others.  Wave-uniform state
  * (top-k fill, threshold, coarse mask) lives in registers.  Used when first+maxitems <= kAndwMaxK. */
-constexpr uint32_t kAndwCand = 512;                  /* candidates per chunk = 4 blocks of term 0 */
-constexpr uint32_t kAndwChunkBlocks = kAndwCand / XGM_BLOCK;
-constexpr uint32_t kAndwMaxK = 192;
+constexpr uint32_t kAndwCandPlain = 512;             /* candidates per chunk = 4 blocks of term 0 */
+constexpr uint32_t kAndwCandPhrase = 256;            /* with the 4-byte position offsets per candidate and term: 2 blocks */
 #ifndef XGM_ANDW_WAVES
 #define XGM_ANDW_WAVES 4           /* min waves per SIMD the register allocator must allow */
 #endif                  /* top-k buffer cap 256 */
 
-__host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
+__host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg, bool phrase) {
+    const uint32_t kAndwCand = phrase ? kAndwCandPhrase : kAndwCandPlain;
     size_t off = 0;
     off += (size_t)cap * 8;                                    /* tk_w */
     off += (size_t)cap * 4;                                    /* tk_d */
@@ -960,6 +960,7 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
     off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
     off += (size_t)kAndwCand * 2;                              /* c_slot */
     off += (size_t)T * kAndwCand * tab_elem;                   /* c_w */
+    off += phrase ? (size_t)T * kAndwCand * 4 : 0;             /* c_pos: position-list offset per candidate and term */
     return (off + 15) & ~(size_t)15;
 }
 
@@ -981,12 +982,14 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
     wave_lds_fence();
 }
 
-template <typename TabT>
-__global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+template <typename TabT, bool PHRASE>
+__global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                               xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr uint32_t CAND = PHRASE ? kAndwCandPhrase : kAndwCandPlain;     /* candidates per chunk */
+    constexpr uint32_t CHUNKB = CAND / XGM_BLOCK;                             /* = blocks of term 0 per chunk */
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
 
     /* private LDS slice */
-    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG);
+    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE);
     size_t off = 0;
     uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
     uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
@@ -1006,8 +1009,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
     uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
-    uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)kAndwCand * 2;
-    TabT* c_w = reinterpret_cast<TabT*>(base + off);
+    uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)CAND * 2;
+    TabT* c_w = reinterpret_cast<TabT*>(base + off); off += (size_t)tab_terms * CAND * sizeof(TabT);
+    uint32_t* c_pos = reinterpret_cast<uint32_t*>(base + off);     /* PHRASE only */
+    const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
     const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
@@ -1016,12 +1021,12 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
     for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
     for (uint32_t i = lane; i < 2u * tab_terms * SPG; i += 64u) rs[i] = 0;        /* rs and re are adjacent */
     for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
-    for (uint32_t i = lane; i < T * kAndwCand; i += 64u) c_w[i] = 0;
+    for (uint32_t i = lane; i < T * CAND; i += 64u) c_w[i] = 0;
     wave_lds_fence();
 
     /* block ranges of every term inside the unit's docid range → run table; lane t keeps term t's
      * payload base and dense-container index */
-    uint64_t tbase_reg = 0;
+    uint64_t tbase_reg = 0, tpos_reg = 0;
     uint32_t dense_reg = 0xFFFFFFFFu;
     if (!empty) {
         for (uint32_t t = 0; t < T; ++t) {
@@ -1031,7 +1036,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
             if (lane == t) {
                 tbase_reg = seg.term_word[id];
-                if (sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
+                if (PHRASE) tpos_reg = seg.term_pos[id];
+                /* the positional filter needs every term's position offsets, which only the block
+                 * decode yields: PHRASE batches take the block path for all terms */
+                if (!PHRASE && sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
             }
             for (uint32_t i = c + lane; i < e; i += 64u) {
                 const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
@@ -1071,15 +1079,16 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
 
     /* software-pipelined per-stripe registers: block headers of the sparse terms (lane j = block j of
      * the run) and, in lane t, the container offset of dense term t */
-    uint32_t h0_meta = 0, h0_first = 0, h0_word = 0;
-    uint32_t ha_meta = 0, ha_first = 0, ha_word = 0, ha_next = 0;
-    uint32_t hb_meta = 0, hb_first = 0, hb_word = 0, hb_next = 0;
+    uint32_t h0_meta = 0, h0_first = 0, h0_word = 0, h0_pos = 0;
+    uint32_t ha_meta = 0, ha_first = 0, ha_word = 0, ha_next = 0, ha_pos = 0;
+    uint32_t hb_meta = 0, hb_first = 0, hb_word = 0, hb_next = 0, hb_pos = 0;
     uint32_t hc_off = 0;
     auto issue_headers = [&](uint32_t x) {
         if (td > 0u) {
             const uint32_t r0 = rs[x], n0b = re[x] - r0;
-            if (lane < n0b && lane < kAndwChunkBlocks) {
+            if (lane < n0b && lane < CHUNKB) {
                 h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
+                if (PHRASE) h0_pos = seg.blk_pos[r0 + lane];
             }
         }
         if (td > 1u) {
@@ -1087,6 +1096,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             if (lane < nb) {
                 ha_meta = seg.blk_meta[rb + lane]; ha_first = seg.blk_first[rb + lane]; ha_word = seg.blk_word[rb + lane];
                 ha_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+                if (PHRASE) ha_pos = seg.blk_pos[rb + lane];
             }
         }
         if (td > 2u) {
@@ -1094,6 +1104,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             if (lane < nb) {
                 hb_meta = seg.blk_meta[rb + lane]; hb_first = seg.blk_first[rb + lane]; hb_word = seg.blk_word[rb + lane];
                 hb_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
+                if (PHRASE) hb_pos = seg.blk_pos[rb + lane];
             }
         }
         if (lane >= td && lane < T) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
@@ -1120,7 +1131,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u)
-                    if (valid && t0 + u < T) c_w[(size_t)(t0 + u) * kAndwCand + o] = (TabT)wv[u];
+                    if (valid && t0 + u < T) c_w[(size_t)(t0 + u) * CAND + o] = (TabT)wv[u];
             }
         }
         wave_lds_fence();
@@ -1142,7 +1153,17 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             uint32_t did = 0;
             if (o < n_c) {
                 bool pass = true;
-                for (uint32_t t = 0; t < T; ++t) pass = pass && c_w[(size_t)t * kAndwCand + o] != 0;
+                for (uint32_t t = 0; t < T; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
+                if (PHRASE && phrase && pass) {
+                    /* K6: ExactPhrasePostList / PhrasePostList::test_doc over the terms' position lists */
+                    PosList pl[XGM_PHRASE_MAX_TERMS];
+                    for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
+                        const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
+                        pl[t].p = seg.positions + tp + c_pos[(size_t)t * CAND + o];
+                        pl[t].n = (uint32_t)c_w[(size_t)t * CAND + o] - 1u;
+                    }
+                    pass = (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
+                }
                 if (pass) {
                     ++matches;
                     did = stripe_base + c_slot[o];
@@ -1161,14 +1182,14 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                     const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
                     double weight = 0.0;                       /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
                     for (uint32_t t = 0; t < T; ++t) {
-                        const double wdf = (double)((uint32_t)c_w[(size_t)t * kAndwCand + o] - 1u);
+                        const double wdf = (double)((uint32_t)c_w[(size_t)t * CAND + o] - 1u);
                         const double denom = denom_len + wdf;
                         weight = weight + q.termweight[t] * (wdf / denom);
                     }
                     wb = (uint64_t)__double_as_longlong(weight);
                     take = !theta_valid || cand_before(wb, did, theta_w, theta_d);
                 }
-                for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * kAndwCand + o] = 0;
+                for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * CAND + o] = 0;
             }
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; }
@@ -1202,10 +1223,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
             uint32_t o = incl - cnt;                                   /* this lane's next ordinal */
             if (sl_next < n_local) issue_headers(sl_next);             /* next stripe's offsets in flight (this stripe uses hc_cur) */
-            for (uint32_t lo = 0; lo < n_total; lo += kAndwCand) {
+            for (uint32_t lo = 0; lo < n_total; lo += CAND) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
-                    while (m[i] && o < lo + kAndwCand) {
+                    while (m[i] && o < lo + CAND) {
                         const uint32_t bit = (uint32_t)__ffs(m[i]) - 1u;
                         c_slot[o - lo] = (uint16_t)((lane * 4u + i) * 32u + bit);
                         m[i] &= m[i] - 1u;
@@ -1213,7 +1234,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                     }
                 }
                 wave_lds_fence();
-                const uint32_t n_c = n_total - lo < kAndwCand ? n_total - lo : kAndwCand;
+                const uint32_t n_c = n_total - lo < CAND ? n_total - lo : CAND;
                 probe_dense(0u, n_c);
                 score_candidates(n_c, false);
                 wave_lds_fence();
@@ -1223,21 +1244,22 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
         }
 
         const uint32_t r0 = rs[sl], r0e = re[sl];
-        for (uint32_t cb = r0; cb < r0e; cb += kAndwChunkBlocks) {
-            const uint32_t nblk0 = r0e - cb < kAndwChunkBlocks ? r0e - cb : kAndwChunkBlocks;
+        for (uint32_t cb = r0; cb < r0e; cb += CHUNKB) {
+            const uint32_t nblk0 = r0e - cb < CHUNKB ? r0e - cb : CHUNKB;
             /* ---- P1: term-0 blocks of the chunk → candidates (ordinals follow docid order) ---- */
-            uint32_t m0 = h0_meta, f0 = h0_first, w0 = h0_word;
+            uint32_t m0 = h0_meta, f0 = h0_first, w0 = h0_word, ps0 = h0_pos;
             if (cb != r0) {
                 m0 = lane < nblk0 ? seg.blk_meta[cb + lane] : 0u;
                 f0 = lane < nblk0 ? seg.blk_first[cb + lane] : 0u;
                 w0 = lane < nblk0 ? seg.blk_word[cb + lane] : 0u;
+                if (PHRASE) ps0 = lane < nblk0 ? seg.blk_pos[cb + lane] : 0u;
             }
             const uint32_t cnt0 = lane < nblk0 ? XGM_META_COUNT(m0) : 0u;
             const uint32_t incl = wave_incl_scan(cnt0);
             const uint32_t n_c = __builtin_amdgcn_readlane(incl, 63);
-            Words4 p0[kAndwChunkBlocks];
+            Words4 p0[CHUNKB];
 #pragma unroll
-            for (uint32_t j = 0; j < kAndwChunkBlocks; ++j) {
+            for (uint32_t j = 0; j < CHUNKB; ++j) {
                 p0[j] = Words4{0, 0, 0, 0};
                 if (j < nblk0) {
                     const uint32_t mj = __builtin_amdgcn_readlane(m0, j);
@@ -1246,7 +1268,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             }
             unsigned long long coarse = 0;
 #pragma unroll
-            for (uint32_t j = 0; j < kAndwChunkBlocks; ++j) {
+            for (uint32_t j = 0; j < CHUNKB; ++j) {
                 if (j < nblk0) {
                     const uint32_t meta = __builtin_amdgcn_readlane(m0, j);
                     const uint32_t obase = __builtin_amdgcn_readlane(incl, j) - XGM_META_COUNT(meta);
@@ -1255,8 +1277,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                         stage[lane * 4u] = p0[j].a; stage[lane * 4u + 1] = p0[j].b; stage[lane * 4u + 2] = p0[j].c; stage[lane * 4u + 3] = p0[j].d;
                     }
                     wave_lds_fence();
-                    DecodedPair r = unpack_staged<false>(stage, first, meta, lane);
+                    DecodedPair r = unpack_staged<PHRASE>(stage, first, meta, lane);
                     wave_lds_fence();
+                    const uint32_t pbase0 = PHRASE ? __builtin_amdgcn_readlane(ps0, j) : 0u;
                     const uint32_t s0 = r.d0 - stripe_base, s1 = r.d1 - stripe_base;
                     const uint32_t prev1 = (uint32_t)__shfl_up((int)s1, 1);
                     const uint32_t pw0 = lane == 0 ? 0xFFFFFFFFu : (prev1 >> 5);
@@ -1265,6 +1288,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                         const uint32_t o = obase + 2u * lane;
                         c_slot[o] = (uint16_t)s0;
                         c_w[o] = (TabT)(r.w0 + 1u);
+                        if (PHRASE) c_pos[o] = pbase0 + r.p0;
                         atomicOr(&bitmap[s0 >> 5], 1u << (s0 & 31u));
                         /* first candidate of its word inside this block; a later block can only add larger ordinals */
                         if ((s0 >> 5) != pw0 && rankw[s0 >> 5] == 0xFFFFu) rankw[s0 >> 5] = (uint16_t)o;
@@ -1274,6 +1298,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                         const uint32_t o = obase + 2u * lane + 1u;
                         c_slot[o] = (uint16_t)s1;
                         c_w[o] = (TabT)(r.w1 + 1u);
+                        if (PHRASE) c_pos[o] = pbase0 + r.p1;
                         atomicOr(&bitmap[s1 >> 5], 1u << (s1 & 31u));
                         if ((s1 >> 5) != (s0 >> 5) && rankw[s1 >> 5] == 0xFFFFu) rankw[s1 >> 5] = (uint16_t)o;
                         cbits |= 1ull << (s1 >> 7);
@@ -1303,31 +1328,36 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                 const uint32_t tb = ta + 1u;
                 const bool have_b = tb < td;
                 uint32_t a_meta, a_first, a_word, a_next, b_meta = 0, b_first = 0, b_word = 0, b_next = 0xFFFFFFFFu;
+                uint32_t a_pos = 0, b_pos = 0;
                 const uint32_t nba = re[ta * SPG + sl] - rs[ta * SPG + sl];
                 const uint32_t nbb = have_b ? re[tb * SPG + sl] - rs[tb * SPG + sl] : 0u;
                 if (ta == 1u) {
-                    a_meta = ha_meta; a_first = ha_first; a_word = ha_word; a_next = ha_next;
-                    b_meta = hb_meta; b_first = hb_first; b_word = hb_word; b_next = hb_next;
+                    a_meta = ha_meta; a_first = ha_first; a_word = ha_word; a_next = ha_next; a_pos = ha_pos;
+                    b_meta = hb_meta; b_first = hb_first; b_word = hb_word; b_next = hb_next; b_pos = hb_pos;
                 } else {
                     a_meta = a_first = a_word = 0; a_next = 0xFFFFFFFFu;
                     const uint32_t rba = rs[ta * SPG + sl];
                     if (lane < nba) {
                         a_meta = seg.blk_meta[rba + lane]; a_first = seg.blk_first[rba + lane]; a_word = seg.blk_word[rba + lane];
                         a_next = lane + 1u < nba ? seg.blk_first[rba + lane + 1u] : 0xFFFFFFFFu;
+                        if (PHRASE) a_pos = seg.blk_pos[rba + lane];
                     }
                     if (have_b) {
                         const uint32_t rbb = rs[tb * SPG + sl];
                         if (lane < nbb) {
                             b_meta = seg.blk_meta[rbb + lane]; b_first = seg.blk_first[rbb + lane]; b_word = seg.blk_word[rbb + lane];
                             b_next = lane + 1u < nbb ? seg.blk_first[rbb + lane + 1u] : 0xFFFFFFFFu;
+                            if (PHRASE) b_pos = seg.blk_pos[rbb + lane];
                         }
                     }
                 }
                 uint64_t mask_a = __ballot(lane < nba && bucket_need(a_first, a_next));
                 uint64_t mask_b = __ballot(have_b && lane < nbb && bucket_need(b_first, b_next));
                 const uint64_t tba = tbase(ta), tbb = have_b ? tbase(tb) : 0ull;
-                TabT* row_a = c_w + (size_t)ta * kAndwCand;
-                TabT* row_b = c_w + (size_t)tb * kAndwCand;
+                TabT* row_a = c_w + (size_t)ta * CAND;
+                TabT* row_b = c_w + (size_t)tb * CAND;
+                uint32_t* prow_a = c_pos + (size_t)ta * CAND;
+                uint32_t* prow_b = c_pos + (size_t)tb * CAND;
                 while (mask_a | mask_b) {
                     uint32_t jj[8], n_a = 0, n_b = 0;
                     Words4 pv[8];
@@ -1360,21 +1390,31 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
                             const uint32_t bmeta = __builtin_amdgcn_readlane(is_b ? b_meta : a_meta, jj[u]);
                             const uint32_t bfirst = __builtin_amdgcn_readlane(is_b ? b_first : a_first, jj[u]);
                             TabT* row = is_b ? row_b : row_a;
+                            uint32_t* prow = is_b ? prow_b : prow_a;
+                            const uint32_t bpos = PHRASE ? __builtin_amdgcn_readlane(is_b ? b_pos : a_pos, jj[u]) : 0u;
                             if (lane * 4u < payload_words(bmeta)) {
                                 stage[lane * 4u] = pv[u].a; stage[lane * 4u + 1] = pv[u].b; stage[lane * 4u + 2] = pv[u].c; stage[lane * 4u + 3] = pv[u].d;
                             }
                             wave_lds_fence();
-                            DecodedPair r = unpack_staged<false>(stage, bfirst, bmeta, lane);
+                            DecodedPair r = unpack_staged<PHRASE>(stage, bfirst, bmeta, lane);
                             wave_lds_fence();
                             if (r.v0) {
                                 const uint32_t sl0 = r.d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
                                 const uint32_t bm = bitmap[wd];
-                                if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w0 + 1u);
+                                if ((bm >> bit) & 1u) {
+                                    const uint32_t ord = (uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u));
+                                    row[ord] = (TabT)(r.w0 + 1u);
+                                    if (PHRASE) prow[ord] = bpos + r.p0;
+                                }
                             }
                             if (r.v1) {
                                 const uint32_t sl1 = r.d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
                                 const uint32_t bm = bitmap[wd];
-                                if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w1 + 1u);
+                                if ((bm >> bit) & 1u) {
+                                    const uint32_t ord = (uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u));
+                                    row[ord] = (TabT)(r.w1 + 1u);
+                                    if (PHRASE) prow[ord] = bpos + r.p1;
+                                }
                             }
                         }
                     }
@@ -1386,7 +1426,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_se
             if (td < T) probe_dense(td, n_c);
 
             /* headers of the next active stripe: in flight while this one is scored */
-            if (cb + kAndwChunkBlocks >= r0e && sl_next < n_local) issue_headers(sl_next);
+            if (cb + CHUNKB >= r0e && sl_next < n_local) issue_headers(sl_next);
 
             /* ---- P4 ---- */
             score_candidates(n_c, true);
@@ -1647,27 +1687,26 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream) {
     return 0;
 }
 
-size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg) {
-    return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg);
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase) {
+    return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg, phrase);
+}
+
+template <typename TabT, bool PHRASE>
+static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
+    const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
+    auto kern = xgm_andw_kernel<TabT, PHRASE>;
+    static std::atomic<size_t> seen{0};
+    if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
-    dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
-    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
+    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group, L.phrase);
     if (smem > 160u * 1024u) return xgm_launch_error("andw kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.wide) {
-        auto kern = xgm_andw_kernel<uint16_t>;
-        static std::atomic<size_t> seen{0};
-        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
-    } else {
-        auto kern = xgm_andw_kernel<uint8_t>;
-        static std::atomic<size_t> seen{0};
-        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
-    }
-    XGM_HIP_CHECK(hipGetLastError());
-    return 0;
+    if (L.phrase) return L.wide ? launch_andw_variant<uint16_t, true>(L, smem, stream) : launch_andw_variant<uint8_t, true>(L, smem, stream);
+    return L.wide ? launch_andw_variant<uint16_t, false>(L, smem, stream) : launch_andw_variant<uint8_t, false>(L, smem, stream);
 }
 
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,

@@ -25,8 +25,9 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
 size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
-/* wave-autonomous variant: one wave per work unit, no workgroup barriers (first+maxitems <= 192) */
-size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
+/* wave-autonomous variant: one wave per work unit, no workgroup barriers (first+maxitems <= 192);
+ * L.phrase selects the instantiation with the positional filter (every term block-decoded) */
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
 /* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
