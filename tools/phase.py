@@ -15,12 +15,12 @@ L.xgm_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
 from xapiand_amd import enquire
 oc = enquire.Database.close
 def close(self):
-    out = (C.c_ulonglong * 8)()
+    out = (C.c_ulonglong * 16)()
     L.xgm_debug_orw_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
     if L.xgm_debug_orw_phase_cycles(out) == 0 and sum(out):
         v = list(out)
         tot = sum(v) or 1
-        names = ["theta+bitmaps+sum", "decode+candset", "enumerate", "dense probes", "block scatter", "bm25+topk", "hist flush", "setup"]
+        names = ["theta+bitmaps+sum", "decode+candset", "enumerate", "dense probes", "block scatter", "score-loop", "hist flush", "setup", "sort", "dlen+leaves", "tree", "hist+insert", "-", "-", "-", "-"]
         print("ORW PHASES:", {n: round(100.0 * x / tot, 1) for n, x in zip(names, v)}, "total Gcycles", round(tot / 1e9, 2))
     out = (C.c_ulonglong * 8)()
     if L.xgm_debug_phase_cycles(out) == 0:

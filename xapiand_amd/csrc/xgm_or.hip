@@ -45,7 +45,16 @@ namespace {
 
 constexpr uint32_t kOrwCand = 512;       /* candidates per scoring chunk: 4 lanes x 4 words x 32 slots */
 constexpr uint32_t kOrwChunkLanes = 4;
-constexpr uint32_t kOrwRegSparse = 2;    /* block-decoded terms whose headers are software-pipelined  */
+#ifndef XGM_ORW_REGSPARSE
+#define XGM_ORW_REGSPARSE 2
+#endif
+#ifndef XGM_ORW_MINWG
+#define XGM_ORW_MINWG 2
+#endif
+#ifndef XGM_ORW_TIMERS
+#define XGM_ORW_TIMERS 0            /* section timers cost ~30 VGPRs: A/B builds only (tools/ab_build.sh) */
+#endif
+constexpr uint32_t kOrwRegSparse = XGM_ORW_REGSPARSE;   /* block-decoded terms whose headers are software-pipelined */
 constexpr uint32_t kNoDense = 0xFFFFFFFFu;
 constexpr uint32_t kQ = 64;              /* quantisation of a weight bound relative to the threshold  */
 constexpr uint32_t kHistShift = 47;      /* weight bits >> 47: sign, exponent, 5 mantissa bits         */
@@ -118,8 +127,10 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
     }
 }
 
+typedef double orw_d8 __attribute__((ext_vector_type(8)));
+
 template <typename TabT>
-__global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+__global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                           uint32_t* __restrict__ hist_all, int prune_flags,
@@ -134,6 +145,12 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
+    /* the in-place summation program of queries with <= 8 terms, in scalar registers */
+    const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
+    const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
+    const uint64_t prog_a = ((uint64_t)__builtin_amdgcn_readfirstlane(ipa32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipa32[0]);
+    const uint64_t prog_b = ((uint64_t)__builtin_amdgcn_readfirstlane(ipb32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipb32[0]);
+    const uint32_t prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
 
     /* private LDS slice */
     unsigned char* base = smem + (size_t)wave * orw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG);
@@ -270,15 +287,16 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
     uint32_t stripe_base = 0;
     uint32_t hc_cur = 0;
 
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};           /* diagnostics: cycles per section */
-    unsigned long long tmark = phase_cycles ? __builtin_readcyclecounter() : 0ull;
-#define ORW_PH(i) do { if (phase_cycles) { const unsigned long long n_ = __builtin_readcyclecounter(); pc[i] += n_ - tmark; tmark = n_; } } while (0)
+    unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};           /* diagnostics: cycles per section */
+    unsigned long long tmark = (XGM_ORW_TIMERS && phase_cycles) ? __builtin_readcyclecounter() : 0ull;
+#define ORW_PH(i) do { if (XGM_ORW_TIMERS && phase_cycles) { const unsigned long long n_ = __builtin_readcyclecounter(); pc[i] += n_ - tmark; tmark = n_; } } while (0)
 
     /* BM25 + tree sum + top-k for the n_c candidates of the chunk; clears c_w behind itself */
-    auto score_candidates = [&](uint32_t n_c) {
+    auto score_candidates = [&](uint32_t n_c, uint32_t dl_first) {
         n_scored += n_c;
-        uint32_t dl_next = lane < n_c ? seg.doclen[stripe_base + c_slot[lane]] : 1u;
+        uint32_t dl_next = dl_first;
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
+            ORW_PH(5);
             if (tkn + 64u > cap) {
                 orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
                 tkn = tkn < k ? tkn : k;
@@ -286,6 +304,7 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
                 for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
                 wave_lds_fence();
             }
+            ORW_PH(8);
             const uint32_t o = i0 + lane;
             const bool valid = o < n_c;
             const uint32_t did = stripe_base + (valid ? (uint32_t)c_slot[o] : 0u);
@@ -300,36 +319,72 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
             normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
             const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
             uint32_t subqs = 0;
-            for (uint32_t t0 = 0; t0 < T; t0 += 4u) {              /* four leaves at a time: independent divide chains */
-                uint32_t ev[4];
+            double weight;
+            if (T <= 8u) {
+                /* leaves and tree in registers: the node program is wave-uniform (SGPRs), so an operand is an
+                 * indexed register read (s_set_gpr_idx), not an LDS round trip */
+                orw_d8 v;
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) ev[u] = (t0 + u < T && valid) ? (uint32_t)c_w[(size_t)(t0 + u) * kOrwCand + o] : 0u;
-                double wt[4] = {-0.0, -0.0, -0.0, -0.0};            /* absent leaf: x + (-0.0) == x */
-                if (__ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {   /* nobody in the round has these terms: skip the divides */
+                for (uint32_t g = 0; g < 2u; ++g) {
+                    uint32_t ev[4];
 #pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) ev[u] = (g * 4u + u < T && valid) ? (uint32_t)c_w[(size_t)(g * 4u + u) * kOrwCand + o] : 0u;
+                    double wt[4] = {-0.0, -0.0, -0.0, -0.0};        /* absent leaf: x + (-0.0) == x */
+                    if (g * 4u < T && __ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {   /* nobody has these terms: skip the divides */
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) {
+                            const double wdf = (double)(ev[u] - 1u);
+                            const double denom = denom_len + wdf;
+                            const double x = q.termweight[g * 4u + u] * (wdf / denom);
+                            wt[u] = ev[u] ? x : -0.0;
+                            subqs += ev[u] ? 1u : 0u;
+                            if (ev[u]) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) v[g * 4u + u] = wt[u];
+                }
+                ORW_PH(9);
+                /* OrPostList::get_weight: l + r up the tree (in place: node j lands in its left operand's slot) */
+                for (uint32_t j = 0; j + 1u < T; ++j) {
+                    const uint32_t a = (uint32_t)(prog_a >> (8u * j)) & 7u, b = (uint32_t)(prog_b >> (8u * j)) & 7u;
+                    const double x = v[a] + v[b];
+                    v[a] = x;
+                }
+                weight = v[prog_root & 7u];
+            } else {
+                for (uint32_t t0 = 0; t0 < T; t0 += 4u) {          /* four leaves at a time: independent divide chains */
+                    uint32_t ev[4];
+    #pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) ev[u] = (t0 + u < T && valid) ? (uint32_t)c_w[(size_t)(t0 + u) * kOrwCand + o] : 0u;
+                    double wt[4] = {-0.0, -0.0, -0.0, -0.0};
+                    if (__ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {
+    #pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) {
+                            const double wdf = (double)(ev[u] - 1u);
+                            const double denom = denom_len + wdf;
+                            const double x = q.termweight[(t0 + u) & (XGM_MAX_TERMS - 1u)] * (wdf / denom);
+                            wt[u] = ev[u] ? x : -0.0;
+                            subqs += ev[u] ? 1u : 0u;
+                        }
+                    }
+    #pragma unroll
                     for (uint32_t u = 0; u < 4u; ++u) {
-                        const double wdf = (double)(ev[u] - 1u);
-                        const double denom = denom_len + wdf;
-                        const double x = q.termweight[(t0 + u) & (XGM_MAX_TERMS - 1u)] * (wdf / denom);
-                        wt[u] = ev[u] ? x : -0.0;
-                        subqs += ev[u] ? 1u : 0u;
+                        if (t0 + u < T) {
+                            val[(t0 + u) * 64u + lane] = wt[u];
+                            if (ev[u]) c_w[(size_t)(t0 + u) * kOrwCand + o] = 0;
+                        }
                     }
                 }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    if (t0 + u < T) {
-                        val[(t0 + u) * 64u + lane] = wt[u];
-                        if (ev[u]) c_w[(size_t)(t0 + u) * kOrwCand + o] = 0;
-                    }
+                ORW_PH(9);
+                for (uint32_t j = 0; j + 1u < T; ++j) {
+                    const uint32_t a = q.ip_a[j], b = q.ip_b[j];
+                    val[a * 64u + lane] = val[a * 64u + lane] + val[b * 64u + lane];
                 }
+                weight = val[(uint32_t)q.ip_root * 64u + lane];
             }
-            /* OrPostList::get_weight: l + r up the tree (in place: node j lands in its left operand's slot) */
-            for (uint32_t j = 0; j + 1u < T; ++j) {
-                const uint32_t a = q.ip_a[j], b = q.ip_b[j];
-                val[a * 64u + lane] = val[a * 64u + lane] + val[b * 64u + lane];
-            }
-            const double weight = val[(uint32_t)q.ip_root * 64u + lane];
             const uint64_t wb = (uint64_t)__double_as_longlong(weight);
+            ORW_PH(10);
             const bool live = valid && subqs != 0u && wb >= theta_glob;
             if (prune && live) {
                 int b = (int)(wb >> kHistShift) - hbase;
@@ -341,6 +396,7 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
+            ORW_PH(11);
         }
     };
 
@@ -628,6 +684,8 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
                 }
                 const unsigned long long coarse = __ballot(in_chunk && cnt != 0u);   /* bit = 128-slot bucket with a candidate */
                 wave_lds_fence();
+                /* document lengths of the first round: requested now, consumed after the probes */
+                const uint32_t dl_first = lane < n_c ? seg.doclen[stripe_base + c_slot[lane]] : 1u;
                 ORW_PH(2);
 
                 /* ---- 2b. wdf of the dense terms: one byte per candidate and term, two rounds in flight ---- */
@@ -717,7 +775,7 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
                 if (last_chunk && sl_next < n_local) issue_headers(sl_next);
 
                 /* ---- 3. BM25, tree sum, top-k ---- */
-                score_candidates(n_c);
+                score_candidates(n_c, dl_first);
                 wave_lds_fence();
                 ORW_PH(5);
             }
@@ -736,7 +794,7 @@ __global__ __launch_bounds__(XGM_WG, 2) void xgm_orw_kernel(xgm_seg_dev seg, con
         }
     }
     ORW_PH(7);
-    if (phase_cycles && lane == 0) { for (int i = 0; i < 8; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
+    if (XGM_ORW_TIMERS && phase_cycles && lane == 0) { for (int i = 0; i < 16; ++i) atomicAdd(&phase_cycles[i], pc[i]); }
 #undef ORW_PH
 
     /* ---- unit epilogue ---- */
@@ -772,12 +830,13 @@ static unsigned long long* g_orw_cycles = nullptr;          /* device buffer, di
 
 /* Diagnostics (XGM_PHASE_TIMING=1): cycle sums per section of xgm_orw_kernel since the last call:
  * [0] threshold + dense bitmaps + bound sum, [1] block decode + candidate set, [2] enumerate,
- * [3] dense probes, [4] block scatter, [5] BM25 + top-k, [6] histogram flush, [7] setup. */
+ * [3] dense probes, [4] block scatter, [5] scoring loop overhead, [6] histogram flush, [7] setup,
+ * [8] top-k sort, [9] doclen wait + leaf weights, [10] tree sum, [11] histogram + top-k insert.  out: u64[16]. */
 int xgm_orw_cycles_fetch(unsigned long long* out8) {
     if (!g_orw_cycles) return -1;
     (void)hipDeviceSynchronize();
-    hipMemcpy(out8, g_orw_cycles, 64, hipMemcpyDeviceToHost);
-    hipMemset(g_orw_cycles, 0, 64);
+    hipMemcpy(out8, g_orw_cycles, 128, hipMemcpyDeviceToHost);
+    hipMemset(g_orw_cycles, 0, 128);
     return 0;
 }
 
@@ -790,7 +849,7 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
     static const bool no_phase_a = getenv("XGM_NO_PHASE_A") != nullptr;
     static const bool no_sum = getenv("XGM_NO_BOUND_SUM") != nullptr;
     static const bool timing = getenv("XGM_PHASE_TIMING") != nullptr;
-    if (timing && !g_orw_cycles) { hipMalloc((void**)&g_orw_cycles, 64); hipMemset(g_orw_cycles, 0, 64); }
+    if (timing && !g_orw_cycles) { hipMalloc((void**)&g_orw_cycles, 128); hipMemset(g_orw_cycles, 0, 128); }
     const int flags = no_prune ? 0 : ((no_phase_a ? 1 : 3) | (no_sum ? 4 : 0));
     const size_t smem = xgm_orw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);
