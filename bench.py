@@ -100,7 +100,12 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     info = db.info()
-    db.set_stream(torch.cuda.current_stream().cuda_stream)
+    # One explicit (non-null) HIP stream for searches and collectives: xgm_search_batch_device is then
+    # asynchronous, so the host plans batch i+1 while the GPU runs batch i (a null stream handle means
+    # "the library's own stream, synchronised before returning").
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    db.set_stream(stream.cuda_stream)
 
     # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards): one all-reduce ----
     if args.op == "PHRASE":

@@ -94,22 +94,49 @@ static int grow_pinned(void** p, size_t* cap, size_t need) {
     return XGM_OK;
 }
 
+/* Scratch (per-call device/pinned buffers + a stream) comes from a small pool.  A scratch handed to
+ * an asynchronous call (xgm_search_batch_device) is still in use by the enqueued kernels when it
+ * returns to the pool ("pending"); the next call takes a FREE one, or creates another (up to
+ * XGM_MAX_SCRATCH), so the host plans batch i+1 while the GPU runs batch i.  Only when every scratch is
+ * busy does a call wait — for the oldest. */
+#define XGM_MAX_SCRATCH 4u
+
 static int scratch_acquire(xgm_index* idx, XgmScratch** out) {
     *out = nullptr;
+    XgmScratch* wait_for = nullptr;
     {
         std::lock_guard<std::mutex> lk(idx->scratch_mu);
-        if (!idx->scratch_pool.empty()) {
-            *out = idx->scratch_pool.back();
-            idx->scratch_pool.pop_back();
+        std::vector<XgmScratch*>& pool = idx->scratch_pool;
+        for (size_t i = pool.size(); i-- > 0;) {
+            XgmScratch* c = pool[i];
+            if (!c->pending || hipEventQuery(c->ev_done) == hipSuccess) {
+                c->pending = false;
+                pool.erase(pool.begin() + (ptrdiff_t)i);
+                *out = c;
+                break;
+            }
         }
+        if (!*out && !pool.empty() && idx->scratch_total >= XGM_MAX_SCRATCH) {
+            wait_for = pool.front();
+            pool.erase(pool.begin());
+        }
+        if (!*out && !wait_for) ++idx->scratch_total;
     }
-    if (*out) {
-        if ((*out)->pending) { hipEventSynchronize((*out)->ev_done); (*out)->pending = false; }
+    if (*out) return XGM_OK;
+    if (wait_for) {
+        hipEventSynchronize(wait_for->ev_done);
+        wait_for->pending = false;
+        *out = wait_for;
         return XGM_OK;
     }
     XgmScratch* s = new XgmScratch();
     hipError_t e = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete s; return xgm_launch_error("hipStreamCreate", (int)e, hipGetErrorString(e)); }
+    if (e != hipSuccess) {
+        delete s;
+        std::lock_guard<std::mutex> lk(idx->scratch_mu);
+        --idx->scratch_total;
+        return xgm_launch_error("hipStreamCreate", (int)e, hipGetErrorString(e));
+    }
     hipEventCreate(&s->ev0);
     hipEventCreate(&s->ev1);
     hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
@@ -581,7 +608,15 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     memcpy(hin + o_wk, bp.work.data(), b_wk);
     memcpy(hin + o_kq, h_kq, b_kq);
     memcpy(hin + o_go, bp.goff.data(), b_go);
-    HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, stream));
+    if (stream != s->stream) {
+        /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
+         * kernels of the previous batch still running on the caller's stream */
+        HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->ev0, s->stream));
+        HIP_TRY(hipStreamWaitEvent(stream, s->ev0, 0));
+    } else {
+        HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, stream));
+    }
     unsigned char* din = (unsigned char*)s->d_in;
     s->d_queries = (xgm_dev_query*)(din + o_dq);
     s->d_maxposs = (double*)(din + o_mp);

@@ -58,6 +58,7 @@ struct xgm_index {
     size_t prof_used = 0;
     std::mutex scratch_mu;
     std::vector<XgmScratch*> scratch_pool;
+    uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
 };
 
 int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id);

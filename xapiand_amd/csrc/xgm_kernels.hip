@@ -1456,6 +1456,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
 
 /* ---------------------------------------------------------------- merge kernel --------------- */
 
+constexpr uint32_t kMergeSel = 512;    /* survivors the selection path of the merge ranks by counting */
+
 /* One workgroup per query.  Sources: n_src candidate lists of up to k_stride entries
  * (groups of one shard, or shards after the all-gather).  did_mul/did_add remap shard-local
  * docids: global = (local - 1) * n_shards + shard + 1 (multi.h:69-73) when unshard != 0. */
@@ -1491,9 +1493,70 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         tk.w[x] = w; tk.d[x] = d; tk.m[x] = m;
     }
     __syncthreads();
-    topk_sort(tk, tid);
     const uint32_t k = kq[qi];
     const uint32_t n = fill < k ? fill : k;
+    /* Selection instead of a full sort when the query has at least k units (small k, many units — the
+     * conjunctive benchmark shape): the k-th best of the units' best candidates bounds the final k-th
+     * from below, so everything worse is dropped first; the few survivors are ranked by counting.
+     * (weight, docid) keys are distinct, so ranks are too. */
+    if (n_src >= k && k > 0 && fill > 0) {
+        uint64_t* sel_w = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 16 + 64);
+        uint32_t* sel_d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 64 + (size_t)kMergeSel * 8);
+        uint32_t* sel_m = sel_d + kMergeSel;
+        uint64_t& thr_w = *reinterpret_cast<uint64_t*>(smem + (size_t)cap * 16 + 16);
+        uint32_t& thr_d = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 24);
+        uint32_t& n_sel = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 28);
+        uint64_t& best_w = *reinterpret_cast<uint64_t*>(smem + (size_t)cap * 16 + 32);
+        uint32_t& best_m = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 40);
+        if (tid == 0) { thr_w = 0; thr_d = 0xFFFFFFFFu; n_sel = 0; best_w = 0; best_m = 0; }
+        __syncthreads();
+        for (uint32_t t = tid; t < n_src; t += XGM_WG) {
+            const uint64_t hw = tk.w[t * k_stride_in];
+            const uint32_t hd = tk.d[t * k_stride_in];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_src; ++j) rank += cand_before(tk.w[j * k_stride_in], tk.d[j * k_stride_in], hw, hd) ? 1u : 0u;
+            if (rank == k - 1u) { thr_w = hw; thr_d = hd; }        /* empty units tie on the sentinel: same value from all writers */
+        }
+        __syncthreads();
+        const uint64_t tw = thr_w;
+        const uint32_t td = thr_d;
+        for (uint32_t x = tid; x < cap; x += XGM_WG) {
+            const uint64_t w = tk.w[x];
+            const uint32_t d = tk.d[x];
+            if (d != 0xFFFFFFFFu && !cand_before(tw, td, w, d)) {
+                const uint32_t p = atomicAdd(&n_sel, 1u);
+                if (p < kMergeSel) { sel_w[p] = w; sel_d[p] = d; sel_m[p] = tk.m[x]; }
+            }
+        }
+        __syncthreads();
+        const uint32_t ns = n_sel;
+        if (ns <= kMergeSel) {
+            for (uint32_t i = tid; i < ns; i += XGM_WG) {
+                const uint64_t w = sel_w[i];
+                const uint32_t d = sel_d[i];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < ns; ++j) rank += cand_before(sel_w[j], sel_d[j], w, d) ? 1u : 0u;
+                if (rank < n) {
+                    xgm_hit hit;
+                    hit.docid = d; hit.subqs_matched = sel_m[i]; hit.weight = __longlong_as_double((long long)w);
+                    hits[(size_t)qi * k_stride_out + rank] = hit;
+                }
+                if (rank == 0u) { best_w = w; best_m = sel_m[i]; }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                xgm_result_hdr r;
+                r.n_hits = n;
+                r.max_weight_subqs_matched = best_m;
+                r.matches_exact = matches;
+                r.max_attained = __longlong_as_double((long long)best_w);
+                r.max_possible = max_possible ? max_possible[qi] : 0.0;
+                hdrs[qi] = r;
+            }
+            return;
+        }
+    }
+    topk_sort(tk, tid);
     for (uint32_t i = tid; i < n; i += XGM_WG) {
         xgm_hit hit;
         hit.docid = tk.d[i]; hit.subqs_matched = tk.m[i]; hit.weight = __longlong_as_double((long long)tk.w[i]);
@@ -1712,7 +1775,7 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream) {
-    const size_t smem = (size_t)cap * 16 + 64;
+    const size_t smem = (size_t)cap * 16 + 64 + (size_t)kMergeSel * 16;
     { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, goff, k_stride_in, kq, cap,
                        k_stride_out, hits, hdrs, max_possible);

@@ -291,10 +291,30 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     unsigned long long tmark = (XGM_ORW_TIMERS && phase_cycles) ? __builtin_readcyclecounter() : 0ull;
 #define ORW_PH(i) do { if (XGM_ORW_TIMERS && phase_cycles) { const unsigned long long n_ = __builtin_readcyclecounter(); pc[i] += n_ - tmark; tmark = n_; } } while (0)
 
-    /* BM25 + tree sum + top-k for the n_c candidates of the chunk; clears c_w behind itself */
-    auto score_candidates = [&](uint32_t n_c, uint32_t dl_first) {
+    /* One round (64 candidates) of gathers, issued a round ahead of its use: the document length and,
+     * for queries of <= 8 terms, the dense terms' wdf bytes straight from the probe containers (one
+     * byte per candidate and term; they never pass through LDS). */
+    const bool fast = T <= 8u;
+    uint32_t pf_dl = 1u, pf_pb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto prefetch_round = [&](uint32_t i0, uint32_t n_c) {
+        const uint32_t o = i0 + lane;
+        const bool valid = o < n_c;
+        const uint32_t slot = valid ? (uint32_t)c_slot[o] : 0u;
+        pf_dl = valid ? seg.doclen[stripe_base + slot] : 1u;
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; ++t) {
+            pf_pb[t] = 0;
+            if (fast && ((dense_mask >> t) & 1ull)) {
+                const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t);
+                if (oo && valid) pf_pb[t] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+            }
+        }
+    };
+
+    /* BM25 + tree sum + top-k for the n_c candidates of the chunk (round 0 already prefetched); clears
+     * c_w behind itself */
+    auto score_candidates = [&](uint32_t n_c) {
         n_scored += n_c;
-        uint32_t dl_next = dl_first;
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
             ORW_PH(5);
             if (tkn + 64u > cap) {
@@ -308,11 +328,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const uint32_t o = i0 + lane;
             const bool valid = o < n_c;
             const uint32_t did = stripe_base + (valid ? (uint32_t)c_slot[o] : 0u);
-            const uint32_t dlen = dl_next;
-            {                                                       /* the next round's document lengths fly while this one is weighed */
-                const uint32_t on = o + 64u;
-                dl_next = on < n_c ? seg.doclen[stripe_base + c_slot[on]] : 1u;
-            }
+            const uint32_t dlen = pf_dl;
+            uint32_t pb[8];
+#pragma unroll
+            for (uint32_t t = 0; t < 8u; ++t) pb[t] = pf_pb[t];
+            if (i0 + 64u < n_c) prefetch_round(i0 + 64u, n_c);       /* the next round's gathers fly while this one is weighed */
             /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
             const double len = (double)dlen;
             double normlen = len * q.len_factor;
@@ -328,7 +348,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 for (uint32_t g = 0; g < 2u; ++g) {
                     uint32_t ev[4];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) ev[u] = (g * 4u + u < T && valid) ? (uint32_t)c_w[(size_t)(g * 4u + u) * kOrwCand + o] : 0u;
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t t = g * 4u + u;
+                        ev[u] = ((dense_mask >> t) & 1ull) ? pb[t] : ((t < T && valid) ? (uint32_t)c_w[(size_t)t * kOrwCand + o] : 0u);
+                    }
                     double wt[4] = {-0.0, -0.0, -0.0, -0.0};        /* absent leaf: x + (-0.0) == x */
                     if (g * 4u < T && __ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {   /* nobody has these terms: skip the divides */
 #pragma unroll
@@ -338,7 +361,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             const double x = q.termweight[g * 4u + u] * (wdf / denom);
                             wt[u] = ev[u] ? x : -0.0;
                             subqs += ev[u] ? 1u : 0u;
-                            if (ev[u]) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
+                            if (ev[u] && !((dense_mask >> (g * 4u + u)) & 1ull)) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
                         }
                     }
 #pragma unroll
@@ -684,12 +707,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 }
                 const unsigned long long coarse = __ballot(in_chunk && cnt != 0u);   /* bit = 128-slot bucket with a candidate */
                 wave_lds_fence();
-                /* document lengths of the first round: requested now, consumed after the probes */
-                const uint32_t dl_first = lane < n_c ? seg.doclen[stripe_base + c_slot[lane]] : 1u;
+                prefetch_round(0u, n_c);                             /* requested now, consumed after the scatter */
                 ORW_PH(2);
 
                 /* ---- 2b. wdf of the dense terms: one byte per candidate and term, two rounds in flight ---- */
-                for (uint32_t c0 = 0; c0 < n_c; c0 += 128u) {
+                for (uint32_t c0 = 0; !fast && c0 < n_c; c0 += 128u) {       /* (> 8 terms: through c_w) */
                     const uint32_t o0 = c0 + lane, o1 = o0 + 64u;
                     const bool v0 = o0 < n_c, v1 = o1 < n_c;
                     const uint32_t slot0 = v0 ? c_slot[o0] : 0u, slot1 = v1 ? c_slot[o1] : 0u;
@@ -775,7 +797,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 if (last_chunk && sl_next < n_local) issue_headers(sl_next);
 
                 /* ---- 3. BM25, tree sum, top-k ---- */
-                score_candidates(n_c, dl_first);
+                score_candidates(n_c);
                 wave_lds_fence();
                 ORW_PH(5);
             }
