@@ -243,6 +243,19 @@ int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_al
                             uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* k,
                             void* d_out_hits, void* d_out_hdrs);
 
+/* The whole per-shard protocol of the reference for a node whose shards all live in THIS process
+ * (one xgm_index per shard, on any mix of devices): what DocMatcher does around Enquire in
+ * reference src/database/handler.cc:1485-1549 — prepare_mset on every shard and add_prepared_mset
+ * (merged statistics, src/xapian/api/enquire.cc:319-394), get_mset(0, first+maxitems) per shard,
+ * unshard_docids and merge_mset (src/xapian/api/mset.cc:367-395, src/xapian/matcher/matcher.cc:
+ * 653-781).  descs[q] is planned once per shard with the merged statistics; every shard searches its
+ * batch on its own device; the shards' top lists are copied to shards[0]'s device and merged there.
+ * hits is [nq][k_stride] with GLOBAL docids ((local-1)*n_shards + shard + 1), best first+maxitems of
+ * each query (the caller skips `first`, as with xgm_search); hdrs[q].matches_exact is the sum over
+ * the shards.  Returns XGM_UNSUPPORTED if any shard declines any query (caller: CPU matcher). */
+int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, const xgm_query_desc* descs,
+                       uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
+
 /* Kernel timing with HIP events on the launch stream.  xgm_index_set_profiling(idx, 1) makes every
  * later xgm_search* call record an event pair around the dominant kernel (xgm_match_kernel) without
  * synchronising; xgm_last_kernel_ms waits for the recorded launches, returns their MEAN duration in

@@ -1,0 +1,45 @@
+/* See xgm_posting_source.h. */
+#include "xgm_posting_source.h"
+
+#include <algorithm>
+
+GpuTopKPostingSource::GpuTopKPostingSource(xgm_index* idx, uint32_t op, const std::vector<std::string>& terms, uint32_t k, uint32_t window)
+    : idx_(idx), op_(op), terms_(terms), k_(k), window_(window) {}
+
+void GpuTopKPostingSource::init(const Xapian::Database&) {
+    by_docid_.clear();
+    pos_ = 0;
+    started_ = false;
+    matches_ = 0;
+    xgm_query_desc d = {};
+    d.op = op_;
+    d.n_terms = (uint32_t)terms_.size();
+    if (terms_.empty() || terms_.size() > XGM_MAX_TERMS) { status_ = XGM_UNSUPPORTED; set_maxweight(0.0); return; }
+    for (size_t i = 0; i < terms_.size(); ++i) { d.terms[i] = terms_[i].data(); d.term_len[i] = (uint32_t)terms_[i].size(); }
+    d.window = window_;
+    d.first = 0; d.maxitems = k_; d.check_at_least = 0;
+    d.k1 = 1; d.k2 = 0; d.k3 = 1; d.b = 0.5; d.min_normlen = 0.5;        /* BM25Weight defaults, weight.h:635-667 */
+    xgm_query q;
+    status_ = xgm_plan_query(idx_, &d, nullptr, &q);
+    if (status_ < 0) throw Xapian::DatabaseError(xgm_last_error());
+    if (status_ > 0) { set_maxweight(0.0); return; }
+    std::vector<xgm_hit> hits(std::max<uint32_t>(1u, q.first + q.maxitems));
+    xgm_result_hdr h;
+    status_ = xgm_search(idx_, &q, hits.data(), &h);
+    if (status_ < 0) throw Xapian::DatabaseError(xgm_last_error());
+    if (status_ > 0) { set_maxweight(0.0); return; }
+    hits.resize(h.n_hits);
+    std::sort(hits.begin(), hits.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+    by_docid_.swap(hits);
+    matches_ = (Xapian::doccount)h.matches_exact;
+    set_maxweight(h.max_possible);
+}
+
+void GpuTopKPostingSource::next(double) {
+    if (!started_) { started_ = true; pos_ = 0; } else if (pos_ < by_docid_.size()) ++pos_;
+}
+
+void GpuTopKPostingSource::skip_to(Xapian::docid did, double) {
+    if (!started_) { started_ = true; pos_ = 0; }
+    while (pos_ < by_docid_.size() && by_docid_[pos_].docid < did) ++pos_;
+}

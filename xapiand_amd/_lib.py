@@ -96,6 +96,7 @@ _API = [
     ("xgm_search", C.c_int, [C.c_void_p, _P(Query), _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch_device", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("xgm_search_sharded", C.c_int, [_P(C.c_void_p), C.c_uint32, _P(QueryDesc), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_merge_shards_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
     ("xgm_index_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_last_kernel_ms", C.c_double, [C.c_void_p]),

@@ -748,6 +748,105 @@ extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, c
     return rc;
 }
 
+extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, const xgm_query_desc* descs, uint32_t nq,
+                                  uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
+    if (!shards || !descs || !hits || !hdrs || n_shards == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    for (uint32_t s = 0; s < n_shards; ++s)
+        if (!shards[s]) return xgm_set_error(XGM_E_INVALID, "null shard");
+    if (nq == 0) return XGM_OK;
+    int rc;
+    /* merged statistics and per-shard plans (first = 0: a shard returns its best first+maxitems) */
+    std::vector<std::vector<xgm_query>> plans(n_shards, std::vector<xgm_query>(nq));
+    std::vector<uint32_t> kq(nq);
+    for (uint32_t i = 0; i < nq; ++i) {
+        xgm_query_desc d = descs[i];
+        if (d.n_terms == 0 || d.n_terms > XGM_MAX_TERMS) return XGM_UNSUPPORTED;
+        if ((uint64_t)d.first + d.maxitems > k_stride) return xgm_set_error(XGM_E_INVALID, "query %u: first+maxitems > k_stride", i);
+        xgm_global_stats gs;
+        memset(&gs, 0, sizeof gs);
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            gs.total_length += shards[s]->hdr.total_length;
+            gs.collection_size += shards[s]->hdr.doccount;
+            if (shards[s]->hdr.has_positions) gs.full_db_has_positions = 1;
+            for (uint32_t t = 0; t < d.n_terms; ++t) {
+                uint32_t tf = 0;
+                if (!d.terms[t]) return XGM_UNSUPPORTED;
+                if ((rc = xgm_lookup_term(shards[s], d.terms[t], d.term_len[t], nullptr, &tf, nullptr, nullptr))) return rc;
+                gs.termfreq[t] += tf;
+            }
+        }
+        d.maxitems = d.first + d.maxitems;
+        d.first = 0;
+        uint32_t k = 0;
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            if ((rc = xgm_plan_query(shards[s], &d, &gs, &plans[s][i]))) return rc;
+            k = std::max(k, plans[s][i].first + plans[s][i].maxitems);
+        }
+        kq[i] = std::min<uint32_t>(k, d.maxitems);
+    }
+    /* per-shard searches, each on its own device, results left in HBM */
+    const size_t n_hit = (size_t)nq * k_stride;
+    std::vector<xgm_hit*> d_hits(n_shards, nullptr);
+    std::vector<xgm_result_hdr*> d_hdrs(n_shards, nullptr);
+    xgm_hit *d_all_hits = nullptr, *d_out_hits = nullptr;
+    xgm_result_hdr *d_all_hdrs = nullptr, *d_out_hdrs = nullptr;
+    const int dev0 = shards[0]->device;
+    hipError_t e = hipSuccess;
+    rc = XGM_OK;
+    do {
+        if ((rc = use_device(dev0))) break;
+        if ((e = hipMalloc((void**)&d_all_hits, (size_t)n_shards * n_hit * sizeof(xgm_hit))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&d_all_hdrs, (size_t)n_shards * nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&d_out_hits, n_hit * sizeof(xgm_hit))) != hipSuccess) break;
+        if ((e = hipMalloc((void**)&d_out_hdrs, (size_t)nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
+        for (uint32_t s = 0; s < n_shards && rc == XGM_OK && e == hipSuccess; ++s) {
+            if (shards[s]->device == dev0) {                       /* straight into its slice of the gathered arrays */
+                d_hits[s] = d_all_hits + (size_t)s * n_hit;
+                d_hdrs[s] = d_all_hdrs + (size_t)s * nq;
+            } else {
+                if ((rc = use_device(shards[s]->device))) break;
+                if ((e = hipMalloc((void**)&d_hits[s], n_hit * sizeof(xgm_hit))) != hipSuccess) break;
+                if ((e = hipMalloc((void**)&d_hdrs[s], (size_t)nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
+            }
+            rc = xgm_search_batch_device(shards[s], plans[s].data(), nq, k_stride, d_hits[s], d_hdrs[s]);
+        }
+        if (rc != XGM_OK || e != hipSuccess) break;
+        /* the "all-gather": every shard's list to shards[0]'s device */
+        for (uint32_t s = 0; s < n_shards && e == hipSuccess; ++s) {
+            if ((rc = use_device(shards[s]->device))) break;
+            if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+            if (shards[s]->device != dev0) {
+                e = hipMemcpyPeer(d_all_hits + (size_t)s * n_hit, dev0, d_hits[s], shards[s]->device, n_hit * sizeof(xgm_hit));
+                if (e == hipSuccess)
+                    e = hipMemcpyPeer(d_all_hdrs + (size_t)s * nq, dev0, d_hdrs[s], shards[s]->device, (size_t)nq * sizeof(xgm_result_hdr));
+            }
+        }
+        if (rc != XGM_OK || e != hipSuccess) break;
+        if ((rc = use_device(dev0))) break;
+        if ((rc = xgm_merge_shards_device(shards[0], d_all_hits, d_all_hdrs, n_shards, nq, k_stride, kq.data(), d_out_hits, d_out_hdrs))) break;
+        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
+        std::vector<xgm_hit> h_hits(n_hit);
+        if ((e = hipMemcpy(h_hits.data(), d_out_hits, n_hit * sizeof(xgm_hit), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        if ((e = hipMemcpy(hdrs, d_out_hdrs, (size_t)nq * sizeof(xgm_result_hdr), hipMemcpyDeviceToHost)) != hipSuccess) break;
+        for (uint32_t i = 0; i < nq; ++i)        /* only the valid prefix of each row is defined on the device */
+            memcpy(hits + (size_t)i * k_stride, h_hits.data() + (size_t)i * k_stride, (size_t)hdrs[i].n_hits * sizeof(xgm_hit));
+    } while (0);
+    if (e != hipSuccess && rc == XGM_OK) rc = xgm_launch_error("xgm_search_sharded", (int)e, hipGetErrorString(e));
+    for (uint32_t s = 0; s < n_shards; ++s) {
+        if (shards[s]->device != dev0) {
+            hipSetDevice(shards[s]->device);
+            if (d_hits[s]) hipFree(d_hits[s]);
+            if (d_hdrs[s]) hipFree(d_hdrs[s]);
+        }
+    }
+    hipSetDevice(dev0);
+    if (d_all_hits) hipFree(d_all_hits);
+    if (d_all_hdrs) hipFree(d_all_hdrs);
+    if (d_out_hits) hipFree(d_out_hits);
+    if (d_out_hdrs) hipFree(d_out_hdrs);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ diagnostics -------------- */
 
 /* Decode one term's whole posting list on the DEVICE (K1 alone) into host arrays. */

@@ -44,7 +44,6 @@
 namespace {
 
 constexpr uint32_t kOrwCand = 512;       /* candidates per scoring chunk: 4 lanes x 4 words x 32 slots */
-constexpr uint32_t kOrwChunkLanes = 4;
 #ifndef XGM_ORW_REGSPARSE
 #define XGM_ORW_REGSPARSE 2
 #endif

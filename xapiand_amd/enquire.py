@@ -328,6 +328,27 @@ def merged_stats(dbs, query):
     return gs
 
 
+def search_sharded(dbs, queries, first, maxitems, check_at_least=0, weight=None):
+    """xgm_search_sharded: the whole per-shard protocol (merged statistics, per-shard plans and
+    searches, unshard + merge on the device) in ONE C call, for a batch of queries → [MSet]."""
+    weight = weight or BM25Weight()
+    nq = len(queries)
+    if nq == 0:
+        return []
+    descs = (_lib.QueryDesc * nq)()
+    keep = []
+    for i, q in enumerate(queries):
+        d = _desc(q, first, maxitems, check_at_least, weight)
+        keep.append(d)
+        descs[i] = d
+    k_stride = max(1, first + maxitems)
+    handles = (C.c_void_p * len(dbs))(*[db._h for db in dbs])
+    hits = (_lib.Hit * (nq * k_stride))()
+    hdrs = (_lib.ResultHdr * nq)()
+    _lib.check(_lib.lib().xgm_search_sharded(handles, len(dbs), descs, nq, k_stride, hits, hdrs))
+    return [MSet(first, [hits[i * k_stride + j] for j in range(hdrs[i].n_hits)], hdrs[i], len(queries[i].terms)) for i in range(nq)]
+
+
 def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None):
     """Xapiand's per-shard protocol (reference src/database/handler.cc:1485-1549) with every shard
     on the local device(s): merged stats → per-shard search for first+maxitems → unshard + merge
