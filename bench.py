@@ -178,6 +178,16 @@ def main():
                 lat.append(time.perf_counter() - a)
     lat.sort()
 
+    # ---- HBM traffic of the dominant kernel: from the committed PMC passes (tools/final.sh → profiles/traffic.json),
+    # which cannot be collected from inside this process; only quoted when measured on this very workload
+    traffic, traffic_note = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        for t in json.load(open(tpath)).get("entries", []):
+            if (t["kernel"] == kernel_name and t["op"] == args.op and t["docs_per_gpu"] == args.docs_per_gpu and t["top_k"] == k and
+                    t["terms"] == (args.terms if args.op != "PHRASE" else 0) and t["batch"] == BATCH):
+                traffic, traffic_note = t["hbm_bytes_per_launch"], t["note"]
+
     result = None
     if rank == 0:
         result = {
@@ -196,8 +206,8 @@ def main():
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,
                       "device_bytes": info.device_bytes, "build_seconds": build_s},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": None, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel_ms": kernel_ms},
+                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kernel_ms},
         }
 
     # ---- CPU baseline: the oracle port of the reference algorithm on a bounded sample --------------

@@ -24,35 +24,57 @@ def _hipcc():
     raise RuntimeError("hipcc not found: cannot build libxgm.so")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    """Content hash of the inputs of one build step.  Staleness is decided by content, not by mtime: the
+    tree is copied to the GPU box, where file times no longer say anything about build order."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _up_to_date(target, digest):
+    try:
+        return os.path.exists(target) and open(target + ".sha").read().strip() == digest
+    except OSError:
+        return False
 
 
 def build(force=False, verbose=False):
     """Compile every HIP/C++ source for gfx950 and link libxgm.so.  Returns the library path."""
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers += [os.path.join(HERE, "..", "include", "xgm.h"), os.path.join(HERE, "..", "tools", "xgm_corpus.h")]
-    objs = []
+    objs, digests = [], []
     hipcc = None
+    all_dg = [_digest([os.path.join(CSRC, src)] + headers, " ".join(FLAGS)) for src in SOURCES]
+    if not force and _up_to_date(LIB, _digest([], " ".join(all_dg))):
+        return LIB                      # the shipped library matches the sources (objects need not be present)
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
+        dg = _digest([s] + headers, " ".join(FLAGS))
+        digests.append(dg)
+        if force or not _up_to_date(o, dg):
             hipcc = hipcc or _hipcc()
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
-    if force or _stale(LIB, objs):
+            with open(o + ".sha", "w") as f:
+                f.write(dg)
+    link_dg = _digest([], " ".join(digests))
+    if force or not _up_to_date(LIB, link_dg):
         hipcc = hipcc or _hipcc()
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        with open(LIB + ".sha", "w") as f:
+            f.write(link_dg)
     return LIB
 
 

@@ -505,7 +505,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     }
     const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
     /* few queries in flight (latency mode): a smaller merge (sort of <= 4096) beats more units */
-    const uint32_t merge_budget = nq <= 4u ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;
+    const uint32_t merge_budget = (nq <= 4u && !bp->orw) ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;   /* (a disjunction's units are long: more of them wins) */
     const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
