@@ -1495,11 +1495,11 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     __syncthreads();
     const uint32_t k = kq[qi];
     const uint32_t n = fill < k ? fill : k;
-    /* Selection instead of a full sort when the query has at least k units (small k, many units — the
-     * conjunctive benchmark shape): the k-th best of the units' best candidates bounds the final k-th
-     * from below, so everything worse is dropped first; the few survivors are ranked by counting.
-     * (weight, docid) keys are distinct, so ranks are too. */
-    if (n_src >= k && k > 0 && fill > 0) {
+    /* Selection instead of a full sort: take the best r = ceil(k / units) candidates of every unit (each
+     * unit's list is sorted): those are >= k candidates, so their k-th best bounds the final k-th from
+     * below and everything worse is dropped; the few survivors are ranked by counting.  (weight, docid)
+     * keys are distinct, so ranks are too. */
+    if (k > 0 && fill > 0 && n_src > 0) {
         uint64_t* sel_w = reinterpret_cast<uint64_t*>(smem + (size_t)cap * 16 + 64);
         uint32_t* sel_d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 64 + (size_t)kMergeSel * 8);
         uint32_t* sel_m = sel_d + kMergeSel;
@@ -1510,12 +1510,17 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         uint32_t& best_m = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 40);
         if (tid == 0) { thr_w = 0; thr_d = 0xFFFFFFFFu; n_sel = 0; best_w = 0; best_m = 0; }
         __syncthreads();
-        for (uint32_t t = tid; t < n_src; t += XGM_WG) {
-            const uint64_t hw = tk.w[t * k_stride_in];
-            const uint32_t hd = tk.d[t * k_stride_in];
+        const uint32_t rows = (k + n_src - 1u) / n_src;               /* <= k <= k_stride_in */
+        const uint32_t n_h = n_src * rows;
+        for (uint32_t t = tid; t < n_h; t += XGM_WG) {
+            const uint32_t xt = (t / rows) * k_stride_in + (t % rows);
+            const uint64_t hw = tk.w[xt];
+            const uint32_t hd = tk.d[xt];
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < n_src; ++j) rank += cand_before(tk.w[j * k_stride_in], tk.d[j * k_stride_in], hw, hd) ? 1u : 0u;
-            if (rank == k - 1u) { thr_w = hw; thr_d = hd; }        /* empty units tie on the sentinel: same value from all writers */
+            for (uint32_t u = 0; u < n_src; ++u)
+                for (uint32_t j = 0; j < rows; ++j)
+                    rank += cand_before(tk.w[u * k_stride_in + j], tk.d[u * k_stride_in + j], hw, hd) ? 1u : 0u;
+            if (rank == k - 1u) { thr_w = hw; thr_d = hd; }        /* empty places tie on the sentinel: same value from all writers */
         }
         __syncthreads();
         const uint64_t tw = thr_w;
