@@ -6,6 +6,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ["XGM_DEBUG_UNITS"] = "1"
 import numpy as np  # noqa: E402
 
 import bench  # noqa: E402

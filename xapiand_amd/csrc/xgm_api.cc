@@ -628,7 +628,8 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     L.seg = idx->view;
     L.queries = s->d_queries;
     L.nq = nq; L.n_work = bp.n_work; L.work = s->d_work; L.stripes_per_group = bp.stripes_per_group;
-    if (nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
+    static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
+    if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
     L.phrase = bp.phrase; L.wide = bp.wide;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
