@@ -50,6 +50,14 @@ extern "C" {
 #define XGM_OP_AND 1
 #define XGM_OP_OR 2
 #define XGM_OP_PHRASE 3
+/* Two-sided operators (reference src/xapian/api/queryinternal.cc:2208-2283; Xapiand DSL _and_not /
+ * _and_maybe / _filter, src/query_dsl.cc:285-296): left = the AND of the first n_required terms,
+ * right = the other terms — any of them excludes the document (AND_NOT: AndNotPostList over an
+ * unweighted OR), each adds its weight where it matches (AND_MAYBE: AndMaybePostList over a weighted
+ * OR), all must match but carry no weight (FILTER: MultiAndPostList with an unweighted side). */
+#define XGM_OP_AND_NOT 4
+#define XGM_OP_AND_MAYBE 5
+#define XGM_OP_FILTER 6
 
 typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
 
@@ -160,6 +168,8 @@ typedef struct {
     uint32_t first, maxitems, check_at_least;
     /* BM25 parameters (reference src/xapian/weight.h:635-667 defaults 1, 0, 1, 0.5, 0.5) */
     double k1, k2, k3, b, min_normlen;
+    uint32_t n_required;                  /* XGM_OP_AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND (>= 1) */
+    uint32_t reserved;
 } xgm_query_desc;
 
 /* Collection statistics merged over all shards of the index, i.e. what Enquire::add_prepared_mset
@@ -194,6 +204,8 @@ typedef struct {
     double len_factor, k1, b, min_normlen;
     uint32_t first, maxitems, check_at_least;
     double max_possible;         /* Σ get_maxpart (bm25weight.cc:183-207); MSet field only         */
+    uint32_t req_mask;           /* bit p: terms[p] must index the document (all terms for AND / PHRASE, 0 for OR) */
+    uint32_t neg_mask;           /* bit p: terms[p] must NOT index it (right-hand side of AND_NOT)   */
 } xgm_query;
 
 /* Lower a query description to a plan against this shard.  Replaces, for the supported shapes,

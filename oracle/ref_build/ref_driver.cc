@@ -25,7 +25,9 @@
  *          builder consumes (format: include/xgm.h "raw postings").
  *
  * Query file: one query per line  "<AND|OR|PHRASE> <first> <maxitems> <window> term term ..."
- * (window is only used by PHRASE; 0 means "number of terms" = exact phrase).
+ * (window is only used by PHRASE; 0 means "number of terms" = exact phrase), or
+ * "<AND_NOT|AND_MAYBE|FILTER>:<n_required> <first> <maxitems> 0 term term ..." where the first n_required
+ * terms form the left-hand AND and the rest the right-hand side.
  * Output: "Q <idx> <n_hits> <matches_lower> <matches_est> <matches_upper> <max_possible %a> <max_attained %a>"
  * followed by n_hits lines "H <rank> <docid> <weight %a> <percent>".
  */
@@ -50,6 +52,7 @@ namespace {
 
 struct QuerySpec {
     std::string op;
+    unsigned n_required = 0;      /* AND_NOT / AND_MAYBE / FILTER: the first n_required terms are the left-hand AND */
     unsigned first = 0, maxitems = 10, window = 0;
     std::vector<std::string> terms;
 };
@@ -64,6 +67,8 @@ std::vector<QuerySpec> read_queries(const char* path) {
         std::istringstream ss(line);
         QuerySpec q;
         ss >> q.op >> q.first >> q.maxitems >> q.window;
+        size_t colon = q.op.find(':');
+        if (colon != std::string::npos) { q.n_required = (unsigned)strtoul(q.op.c_str() + colon + 1, nullptr, 10); q.op.resize(colon); }
         std::string t;
         while (ss >> t) q.terms.push_back(t);
         out.push_back(q);
@@ -83,6 +88,22 @@ Xapian::Query make_query(const QuerySpec& q) {
         for (auto& t : q.terms) psubs.emplace_back(t, 1, pos++);
         unsigned window = q.window ? q.window : (unsigned)q.terms.size();
         return Xapian::Query(Xapian::Query::OP_PHRASE, psubs.begin(), psubs.end(), window);
+    }
+    if (q.op == "AND_NOT" || q.op == "AND_MAYBE" || q.op == "FILTER") {
+        /* left: the AND of the first n_required terms (a bare term when it is one); right: the other terms —
+         * any of them excludes (AND_NOT), each adds weight when present (AND_MAYBE), all must match
+         * unweighted (FILTER).  These are the trees Xapiand's DSL builds for _and_not / _and_maybe /
+         * _filter (reference src/query_dsl.cc:285-296). */
+        unsigned nr = q.n_required ? q.n_required : 1;
+        if (nr >= subs.size()) { fprintf(stderr, "%s needs terms on both sides\n", q.op.c_str()); exit(2); }
+        Xapian::Query left = nr == 1 ? subs[0] : Xapian::Query(Xapian::Query::OP_AND, subs.begin(), subs.begin() + nr);
+        bool one = subs.size() - nr == 1;
+        if (q.op == "FILTER") {
+            Xapian::Query right = one ? subs[nr] : Xapian::Query(Xapian::Query::OP_AND, subs.begin() + nr, subs.end());
+            return Xapian::Query(Xapian::Query::OP_FILTER, left, right);
+        }
+        Xapian::Query right = one ? subs[nr] : Xapian::Query(Xapian::Query::OP_OR, subs.begin() + nr, subs.end());
+        return Xapian::Query(q.op == "AND_NOT" ? Xapian::Query::OP_AND_NOT : Xapian::Query::OP_AND_MAYBE, left, right);
     }
     fprintf(stderr, "unknown op %s\n", q.op.c_str());
     exit(2);

@@ -341,7 +341,8 @@ struct ProtoMSet {
 /* ----------------------------------------------------------------------------- query ----------- */
 
 struct QueryIn {
-    uint32_t op;                 /* 1 AND, 2 OR, 3 PHRASE */
+    uint32_t op;                 /* 1 AND, 2 OR, 3 PHRASE, 4 AND_NOT, 5 AND_MAYBE, 6 FILTER */
+    uint32_t n_required;         /* ops 4-6: the first n_required terms are the left-hand AND, the others the right-hand side */
     uint32_t n_terms;
     const char* const* terms; const uint32_t* term_len;
     uint32_t window, first, maxitems;
@@ -433,6 +434,13 @@ struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible
 
 int run_query(Index* ix, const QueryIn& q, Result* out) {
     const uint32_t n = q.n_terms;
+    /* AND_NOT / AND_MAYBE / FILTER (api/queryinternal.cc:2208-2283): l = postlist of subquery 0 (here the AND of
+     * the first nr terms), r = the remaining terms — an unweighted OR whose matches are excluded
+     * (AndNotPostList), a weighted OR whose weight is added where it matches (AndMaybePostList::get_weight,
+     * andmaybepostlist.cc:57-64), or unweighted required terms (QueryFilter: MultiAnd of {l, r x 0}). */
+    const bool sided = q.op >= 4 && q.op <= 6;
+    const uint32_t nr = sided ? q.n_required : n;
+    if (sided && (nr == 0 || nr >= n)) return -1;
     BM25 proto;
     const uint32_t N = q.use_global ? q.g_collection_size : ix->doccount;
     const uint64_t TL = q.use_global ? q.g_total_length : ix->total_length;
@@ -461,7 +469,40 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     std::vector<uint32_t> order(n);
     std::vector<std::pair<int, int>> nodes;
     int root = 0;
-    if (q.op == 2) {
+    /* Huffman-shaped OR tree over plan positions [lo, n) (OrContext::postlist); returns its root */
+    auto or_tree = [&](uint32_t lo) -> int {
+        const uint32_t m = n - lo;
+        if (m == 1) return (int)lo;
+        std::vector<HItem> h;
+        for (uint32_t p = lo; p < n; ++p) h.push_back(HItem{tf_local[order[p]], (int)p});
+        for (long s = (long)((m - 2) / 2); s >= 0; --s) sift_down(h, m, (size_t)s);
+        while (true) {
+            HItem r = h.front();
+            size_t len = h.size();
+            if (len > 1) { std::swap(h[0], h[len - 1]); sift_down(h, len - 1, 0); }
+            h.pop_back();
+            HItem l = h.front();
+            nodes.push_back({l.node, r.node});
+            int nid = (int)n + (int)nodes.size() - 1;
+            if (h.size() == 1) return nid;
+            h[0].node = nid; h[0].tf = l.tf + r.tf;
+            sift_down(h, h.size(), 0);
+        }
+    };
+    if (sided) {
+        /* left side: MultiAnd order among the required terms; right side: query order */
+        std::vector<Leaf> in(nr), sorted(nr);
+        for (uint32_t i = 0; i < nr; ++i) in[i] = Leaf{tf_local[i], i};
+        std::partial_sort_copy(in.begin(), in.end(), sorted.begin(), sorted.end(), TfAsc());
+        for (uint32_t i = 0; i < nr; ++i) order[i] = sorted[i].idx;
+        for (uint32_t i = nr; i < n; ++i) order[i] = i;
+        for (uint32_t p = 1; p < nr; ++p) { nodes.push_back({root, (int)p}); root = (int)n + (int)nodes.size() - 1; }
+        if (q.op == 5) {
+            int r_root = or_tree(nr);
+            nodes.push_back({root, r_root});                    /* l + r, andmaybepostlist.cc:57-64 */
+            root = (int)n + (int)nodes.size() - 1;
+        }
+    } else if (q.op == 2) {
         for (uint32_t i = 0; i < n; ++i) order[i] = i;
         if (n > 1) {
             std::vector<HItem> h;
@@ -549,6 +590,34 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
             for (uint32_t p = 0; p < n; ++p) present[p] = (!it[p].at_end() && it[p].did == did);
             score(did);
             for (uint32_t p = 0; p < n; ++p) if (present[p]) it[p].next();
+        }
+    } else if (sided) {
+        /* required: plan positions [0, nr) and, for FILTER, all the others as well */
+        std::vector<uint32_t> reqp;
+        for (uint32_t p = 0; p < n; ++p) if (p < nr || q.op == 6) reqp.push_back(p);
+        for (uint32_t p = nr; p < n; ++p) if (q.op != 6) it[p].next();
+        it[reqp[0]].next();
+        while (!it[reqp[0]].at_end()) {
+            uint32_t did = it[reqp[0]].did;
+            bool matched = true;
+            for (size_t x = 1; x < reqp.size(); ++x) {
+                GlassIter& o = it[reqp[x]];
+                o.skip_to(did);
+                if (o.at_end()) { matched = false; did = UINT32_MAX; break; }
+                if (o.did != did) { it[reqp[0]].skip_to(o.did); matched = false; break; }
+            }
+            if (did == UINT32_MAX) break;
+            if (!matched) continue;
+            std::fill(present.begin(), present.end(), 0);
+            for (uint32_t p = 0; p < nr; ++p) present[p] = 1;
+            bool excluded = false;
+            for (uint32_t p = nr; p < n && q.op != 6; ++p) {
+                if (!it[p].at_end() && it[p].did < did) it[p].skip_to(did);
+                const bool here = !it[p].at_end() && it[p].did == did;
+                if (q.op == 4) excluded = excluded || here; else present[p] = here;
+            }
+            if (!excluded) score(did);
+            it[reqp[0]].next();
         }
     } else {
         /* MultiAndPostList::find_next_match, multiandpostlist.cc:180-207 */
@@ -669,7 +738,8 @@ int xgo_search(void* ixv, uint32_t op, uint32_t n_terms, const char* const* term
                uint32_t first, uint32_t maxitems, uint32_t use_global, uint64_t g_total_length, uint32_t g_collection_size,
                uint32_t g_has_positions, const uint32_t* g_termfreq, uint32_t select_cache_bug, xgo_hit* hits,
                xgo_result_hdr* hdr) {
-    QueryIn q{op, n_terms, terms, term_len, window, first, maxitems, use_global, g_total_length, g_collection_size,
+    /* op: low byte = operator, bits 8.. = n_required of AND_NOT / AND_MAYBE / FILTER */
+    QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, first, maxitems, use_global, g_total_length, g_collection_size,
               g_has_positions, g_termfreq, select_cache_bug};
     Result r;
     int rc = run_query((Index*)ixv, q, &r);

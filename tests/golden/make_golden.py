@@ -6,8 +6,8 @@ Xapian of /root/reference compiled by oracle/ref_build/Makefile).  Run in the au
 Each fixture records the corpus parameters (tools/xgm_corpus.h), the queries, and for every query
 the reference MSet: (docid, weight as a C99 hex float) per rank plus max_possible / max_attained.
 Config C1 of BASELINE.json: 10k-doc synthetic index, 3-term AND BM25 top-10 through Enquire; the
-other fixtures cover OR-5 top-100, full-result PHRASE, paging (first > 0) and a 4-shard index run
-through Xapiand's prepare/merge protocol.
+other fixtures cover OR-5 top-100, full-result PHRASE, paging (first > 0), the two-sided operators
+(AND_NOT / AND_MAYBE / FILTER) and a 4-shard index run through Xapiand's prepare/merge protocol.
 """
 import json
 import os
@@ -44,6 +44,11 @@ def main():
             "or5_top100": H.gen_term_queries("OR", 30, 5, 8, 4096, maxitems=100, seed=21),
             "and_paging": H.gen_term_queries("AND", 10, 2, 1, 64, first=7, maxitems=10, seed=22),
             "phrase_full": H.gen_phrase_queries(30, N_DOCS, VOCAB, maxitems=N_DOCS, seed=23),
+            # the operators of Xapiand's _and_not / _and_maybe / _filter (left = AND of n_required terms)
+            "sided_top10": sum((H.gen_sided_queries(op, 12, 1, 1, 1, 300, maxitems=10, seed=sd) +
+                                H.gen_sided_queries(op, 12, 2, 2, 1, 64, 1, 600, maxitems=10, seed=sd + 1) +
+                                H.gen_sided_queries(op, 6, 3, 1, 1, 40, 1, 40, first=4, maxitems=10, seed=sd + 2)
+                                for op, sd in (("AND_NOT", 31), ("AND_MAYBE", 41), ("FILTER", 51))), []),
         }
         for name, qs in fixtures.items():
             with open(os.path.join(HERE, name + ".json"), "w") as f:

@@ -15,7 +15,8 @@ XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
 
 CORPUS_SEED = 0x5EED0001
 QUERY_SEED = 0x5EED0002
-OPS = {"AND": 1, "OR": 2, "PHRASE": 3}
+OPS = {"AND": 1, "OR": 2, "PHRASE": 3, "AND_NOT": 4, "AND_MAYBE": 5, "FILTER": 6}
+SIDED = ("AND_NOT", "AND_MAYBE", "FILTER")   # left = AND of the first n_required terms, right = the others
 
 
 class CorpusView(C.Structure):
@@ -131,9 +132,10 @@ class Corpus:
         return olib().xgo_index_termfreq(self.oracle_index(), t, len(t))
 
 
-def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=None, reference_select_bug=False):
+def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=None, reference_select_bug=False, n_required=0):
     """Run the CPU oracle.  Returns (list of (docid, weight, subqs), hdr)."""
     n = len(terms)
+    opcode = OPS[op] | ((n_required or 1) << 8 if op in SIDED else 0)
     tb = [t if isinstance(t, bytes) else t.encode() for t in terms]
     arr = (C.c_char_p * n)(*tb)
     lens = (C.c_uint32 * n)(*[len(t) for t in tb])
@@ -142,10 +144,10 @@ def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=Non
     hdr = OHdr()
     bug = 1 if reference_select_bug else 0
     if global_stats is None:
-        rc = olib().xgo_search(corpus.oracle_index(), OPS[op], n, arr, lens, window, first, maxitems, 0, 0, 0, 0, None, bug, hits, C.byref(hdr))
+        rc = olib().xgo_search(corpus.oracle_index(), opcode, n, arr, lens, window, first, maxitems, 0, 0, 0, 0, None, bug, hits, C.byref(hdr))
     else:
         tf = (C.c_uint32 * n)(*global_stats["termfreq"])
-        rc = olib().xgo_search(corpus.oracle_index(), OPS[op], n, arr, lens, window, first, maxitems, 1,
+        rc = olib().xgo_search(corpus.oracle_index(), opcode, n, arr, lens, window, first, maxitems, 1,
                                global_stats["total_length"], global_stats["collection_size"],
                                1 if global_stats["has_positions"] else 0, tf, bug, hits, C.byref(hdr))
     assert rc == 0
@@ -179,7 +181,8 @@ def xapian_ref(*args):
 def write_queries(path, queries):
     with open(path, "w") as f:
         for q in queries:
-            f.write("%s %d %d %d %s\n" % (q["op"], q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
+            op = q["op"] + (":%d" % (q.get("n_required") or 1) if q["op"] in SIDED else "")
+            f.write("%s %d %d %d %s\n" % (op, q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
 
 
 def parse_ref_output(path):
@@ -213,6 +216,25 @@ def gen_term_queries(op, n_queries, n_terms, rank_lo, rank_hi, first=0, maxitems
         ranks = list(ranks)
         rng.shuffle(ranks)
         qs.append(dict(op=op, terms=["t%d" % r for r in ranks], first=first, maxitems=maxitems, window=0))
+    return qs
+
+
+def gen_sided_queries(op, n_queries, n_required, n_other, rank_lo, rank_hi, other_lo=None, other_hi=None, first=0, maxitems=10, seed=QUERY_SEED):
+    """AND_NOT / AND_MAYBE / FILTER: the first n_required terms form the left-hand AND, n_other terms the
+    right-hand side (ranks from their own range when given)."""
+    rng = random.Random(seed)
+    qs = []
+    for _ in range(n_queries):
+        ranks = []
+        while len(ranks) < n_required:
+            r = max(1, log_uniform_rank(rng, rank_lo, rank_hi))
+            if r not in ranks:
+                ranks.append(r)
+        while len(ranks) < n_required + n_other:
+            r = max(1, log_uniform_rank(rng, other_lo or rank_lo, other_hi or rank_hi))
+            if r not in ranks:
+                ranks.append(r)
+        qs.append(dict(op=op, n_required=n_required, terms=["t%d" % r for r in ranks], first=first, maxitems=maxitems, window=0))
     return qs
 
 

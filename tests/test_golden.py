@@ -34,7 +34,7 @@ def test_oracle_matches_golden(path):
     for r in fx["results"]:
         q = r["query"]
         if fx["n_shards"] == 1:
-            hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0))
+            hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0))
             got = [(d, w) for d, w, _ in hits[q["first"]:]]
             assert hdr.max_possible == float.fromhex(r["max_possible"])
         else:

@@ -12,6 +12,7 @@ XGM_MAX_K = 1024
 XGM_OK, XGM_UNSUPPORTED = 0, 1
 XGM_E_INVALID, XGM_E_IO, XGM_E_NO_DEVICE, XGM_E_DEVICE, XGM_E_REVISION, XGM_E_NOMEM = -1, -2, -3, -4, -5, -6
 XGM_OP_AND, XGM_OP_OR, XGM_OP_PHRASE = 1, 2, 3
+XGM_OP_AND_NOT, XGM_OP_AND_MAYBE, XGM_OP_FILTER = 4, 5, 6
 UINT64_MAX = (1 << 64) - 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -47,7 +48,7 @@ class QueryDesc(C.Structure):
                 ("term_len", C.c_uint32 * XGM_MAX_TERMS), ("window", C.c_uint32), ("first", C.c_uint32),
                 ("maxitems", C.c_uint32), ("check_at_least", C.c_uint32),
                 ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double), ("b", C.c_double),
-                ("min_normlen", C.c_double)]
+                ("min_normlen", C.c_double), ("n_required", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GlobalStats(C.Structure):
@@ -64,7 +65,7 @@ class Query(C.Structure):
                 ("sum_prog", C.c_int8 * (2 * XGM_MAX_TERMS)), ("sum_len", C.c_uint32), ("window", C.c_uint32),
                 ("phrase_active", C.c_uint32), ("len_factor", C.c_double), ("k1", C.c_double), ("b", C.c_double),
                 ("min_normlen", C.c_double), ("first", C.c_uint32), ("maxitems", C.c_uint32),
-                ("check_at_least", C.c_uint32), ("max_possible", C.c_double)]
+                ("check_at_least", C.c_uint32), ("max_possible", C.c_double), ("req_mask", C.c_uint32), ("neg_mask", C.c_uint32)]
 
 
 class Hit(C.Structure):

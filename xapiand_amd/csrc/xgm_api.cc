@@ -383,7 +383,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         d->term_id[t] = q->terms[t].term_id;
         d->termweight[t] = q->terms[t].termweight;
         d->phrase_index[t] = (uint8_t)q->terms[t].phrase_index;
-        if (q->terms[t].term_id == UINT32_MAX) { any_absent = true; continue; }
+        if (q->terms[t].term_id == UINT32_MAX) { if (q->op == XGM_OP_OR || ((q->req_mask >> t) & 1u)) any_absent = true; continue; }
         all_absent = false;
         if (q->terms[t].term_id >= idx->hdr.n_terms) return -1;
         uint32_t ub = idx->term_wdfub[q->terms[t].term_id];
@@ -404,11 +404,12 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
     /* post-order program → node list */
     int stack[2 * XGM_MAX_TERMS];
     int sp = 0, n_nodes = 0;
-    if (q->sum_len != 2 * q->n_terms - 1) return -1;
+    if (q->sum_len == 0 || q->sum_len > 2 * q->n_terms - 1 || (q->sum_len & 1u) == 0) return -1;
     for (uint32_t i = 0; i < q->sum_len; ++i) {
         int8_t op = q->sum_prog[i];
         if (op >= 0) {
             if ((uint32_t)op >= q->n_terms) return -1;
+            d->score_mask |= 1u << op;
             stack[sp++] = op;
         } else {
             if (sp < 2) return -1;
@@ -419,7 +420,12 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
             ++n_nodes;
         }
     }
-    if (sp != 1 || n_nodes != (int)q->n_terms - 1) return -1;
+    if (sp != 1 || n_nodes != ((int)q->sum_len - 1) / 2) return -1;
+    d->n_nodes = (uint32_t)n_nodes;
+    d->sum_root = (uint32_t)stack[0];
+    d->req_mask = q->req_mask;
+    d->neg_mask = q->neg_mask;
+    if (q->op != XGM_OP_OR && (q->req_mask == 0 || (q->req_mask >> q->n_terms) != 0 || (q->req_mask & q->neg_mask))) return -1;
     {
         int slot_of[2 * XGM_MAX_TERMS];
         for (uint32_t t = 0; t < q->n_terms; ++t) slot_of[t] = (int)t;
@@ -428,7 +434,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
             d->ip_b[j] = (uint8_t)slot_of[d->node_b[j]];
             slot_of[q->n_terms + j] = slot_of[d->node_a[j]];
         }
-        d->ip_root = (uint32_t)slot_of[q->n_terms + n_nodes - 1];
+        d->ip_root = (uint32_t)slot_of[stack[0]];
     }
     return width;
 }

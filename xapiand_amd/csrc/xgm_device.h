@@ -33,7 +33,11 @@ typedef struct {
      * (an inner node lives in its left operand's slot); the root ends up in val[ip_root] */
     uint8_t ip_a[XGM_MAX_TERMS];
     uint8_t ip_b[XGM_MAX_TERMS];
-    uint32_t ip_root, pad1;
+    uint32_t ip_root;
+    uint32_t n_nodes;                     /* additions of the summation program (leaves in it - 1)      */
+    uint32_t sum_root;                    /* index (leaf or T + node) holding the document's weight     */
+    uint32_t req_mask, neg_mask;          /* term t must / must not index a matching document (non-OR)  */
+    uint32_t score_mask;                  /* term t is a weighted leaf (LeafPostList::count_matching_subqs) */
     /* safe upper bound of leaf t's weight over the whole shard (0 for an absent term): drives the
      * MaxScore pruning of xgm_orw_kernel; never part of a result */
     double ub[XGM_MAX_TERMS];

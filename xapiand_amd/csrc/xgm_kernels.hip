@@ -201,6 +201,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     const uint32_t W = 1u << SB;
     const uint32_t T = q.n_terms;
     const bool is_or = (q.op == XGM_OP_OR);
+    const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;      /* non-OR: who must / must not be present */
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
     const uint32_t k = q.k;
     const uint32_t SPG = stripes_per_group;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
         for (uint32_t t = 0; t < T; ++t) {
             uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
             total += cnt;
-            all = all && cnt != 0;
+            all = all && (cnt != 0 || !((req_mask >> t) & 1u));
         }
         if (is_or ? total == 0 : !all) continue;
         const uint32_t s = s_begin + sl;
@@ -347,11 +348,13 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                     uint32_t m[4];
                     m[0] = m[1] = m[2] = m[3] = is_or ? 0u : 0xFFFFFFFFu;
                     for (uint32_t t = 0; t < T; ++t) {
+                        const bool req = (req_mask >> t) & 1u, neg = (neg_mask >> t) & 1u;
+                        if (!is_or && !req && !neg) continue;               /* optional term: no say in matching */
                         uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)t * W + base);
                         uint32_t x[4] = {v.x, v.y, v.z, v.w};
                         for (int c = 0; c < 4; ++c) {
                             uint32_t nz = sizeof(TabT) == 1 ? nz_bytes(x[c]) : nz_halves(x[c]);
-                            m[c] = is_or ? (m[c] | nz) : (m[c] & nz);
+                            m[c] = is_or ? (m[c] | nz) : neg ? (m[c] & ~nz) : (m[c] & nz);
                         }
                     }
                     /* one flag bit per slot */
@@ -437,12 +440,12 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                             double wdf = (double)(e - 1u);
                             double denom = denom_len + wdf;
                             wt = q.termweight[t] * (wdf / denom);
-                            ++subqs;
+                            subqs += (q.score_mask >> t) & 1u;      /* weighted leaves only (leafpostlist.cc:88-91) */
                         }
                         val[t] = wt;
                     }
-                    for (uint32_t j = 0; j + 1u < T; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
-                    double weight = val[T == 1 ? 0 : 2u * T - 2u];
+                    for (uint32_t j = 0; j < q.n_nodes; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
+                    double weight = val[q.sum_root];
                     uint64_t wb = (uint64_t)__double_as_longlong(weight);
                     bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
                     if (take) {

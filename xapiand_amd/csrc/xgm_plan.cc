@@ -119,8 +119,13 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     if (!idx || !d || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
     memset(out, 0, sizeof *out);
     const uint32_t n = d->n_terms;
-    if (d->op != XGM_OP_AND && d->op != XGM_OP_OR && d->op != XGM_OP_PHRASE) return XGM_UNSUPPORTED;
+    if (d->op < XGM_OP_AND || d->op > XGM_OP_FILTER) return XGM_UNSUPPORTED;
     if (n == 0 || n > XGM_MAX_TERMS) return XGM_UNSUPPORTED;
+    /* AND_NOT / AND_MAYBE / FILTER: left = AND of the first nr terms, right = the others
+     * (QueryAndNot / QueryAndMaybe / QueryFilter::postlist, api/queryinternal.cc:2208-2283) */
+    const bool sided = d->op == XGM_OP_AND_NOT || d->op == XGM_OP_AND_MAYBE || d->op == XGM_OP_FILTER;
+    const uint32_t nr = sided ? d->n_required : n;
+    if (sided && (nr == 0 || nr >= n)) return xgm_set_error(XGM_E_INVALID, "n_required must leave terms on both sides");
     if (d->k2 != 0.0) return XGM_UNSUPPORTED;          /* would need ExtraWeightPostList (localsubmatch.cc:183-193) */
     if (!(d->k1 >= 0.0) || !(d->b >= 0.0 && d->b <= 1.0) || !(d->k3 >= 0.0) || !(d->min_normlen >= 0.0))
         return xgm_set_error(XGM_E_INVALID, "bad BM25 parameters");
@@ -202,11 +207,13 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     if (d->op == XGM_OP_OR) {
         for (uint32_t i = 0; i < n; ++i) order[i] = i;
     } else {
+        /* the AND side (all terms, or the left-hand nr) in MultiAnd order; a right-hand side keeps query order */
         Leaf in[XGM_MAX_TERMS], sorted[XGM_MAX_TERMS];
-        for (uint32_t i = 0; i < n; ++i) in[i] = Leaf{local_tf[i], i};
+        for (uint32_t i = 0; i < nr; ++i) in[i] = Leaf{local_tf[i], i};
         /* same library algorithm, same comparator shape as the reference → same tie behaviour */
-        std::partial_sort_copy(in, in + n, sorted, sorted + n, TfAscending());
-        for (uint32_t i = 0; i < n; ++i) order[i] = sorted[i].idx;
+        std::partial_sort_copy(in, in + nr, sorted, sorted + nr, TfAscending());
+        for (uint32_t i = 0; i < nr; ++i) order[i] = sorted[i].idx;
+        for (uint32_t i = nr; i < n; ++i) order[i] = i;
     }
     for (uint32_t p = 0; p < n; ++p) {
         uint32_t i = order[p];
@@ -218,9 +225,11 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     /* weight summation program + max_possible in the same association */
     std::vector<TreeNode> nodes;
     int root;
-    if (d->op == XGM_OP_OR && n > 1) {
+    /* Huffman-shaped OrPostList tree over plan positions [lo, n) (OrContext::postlist); returns its root */
+    auto or_tree = [&](uint32_t lo) -> int {
+        if (n - lo == 1) return (int)lo;
         std::vector<HeapItem> heap;
-        for (uint32_t p = 0; p < n; ++p) heap.push_back(HeapItem{local_tf[order[p]], (int)p});
+        for (uint32_t p = lo; p < n; ++p) heap.push_back(HeapItem{local_tf[order[p]], (int)p});
         heap_make(heap);
         while (true) {
             HeapItem r = heap.front();
@@ -228,16 +237,26 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
             HeapItem l = heap.front();
             nodes.push_back(TreeNode{l.node, r.node});
             int id = (int)n + (int)nodes.size() - 1;
-            if (heap.size() == 1) { root = id; break; }
+            if (heap.size() == 1) return id;
             heap[0].node = id;
             heap[0].tf = l.tf + r.tf;
             heap_sift_down(heap, heap.size(), 0);      /* Heap::replace */
         }
+    };
+    if (d->op == XGM_OP_OR && n > 1) {
+        root = or_tree(0);
     } else {
-        /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ...; 0 + w0 == w0 exactly */
+        /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ...; 0 + w0 == w0 exactly.  Only the AND side
+         * carries weight for AND_NOT / FILTER; AND_MAYBE adds the right-hand OR tree where it matches
+         * (AndMaybePostList::get_weight, andmaybepostlist.cc:57-64). */
         root = 0;
-        for (uint32_t p = 1; p < n; ++p) {
+        for (uint32_t p = 1; p < nr; ++p) {
             nodes.push_back(TreeNode{root, (int)p});
+            root = (int)n + (int)nodes.size() - 1;
+        }
+        if (d->op == XGM_OP_AND_MAYBE) {
+            int r_root = or_tree(nr);
+            nodes.push_back(TreeNode{root, r_root});
             root = (int)n + (int)nodes.size() - 1;
         }
     }
@@ -255,9 +274,17 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         out->max_possible = mp;
     }
 
+    /* who must / must not index a matching document */
+    out->req_mask = 0; out->neg_mask = 0;
+    for (uint32_t p = 0; p < n; ++p) {
+        if (d->op == XGM_OP_OR) break;
+        if (p < nr || d->op == XGM_OP_FILTER) out->req_mask |= 1u << p;
+        else if (d->op == XGM_OP_AND_NOT) out->neg_mask |= 1u << p;
+    }
     bool any_absent = false, all_absent = true;
     for (uint32_t p = 0; p < n; ++p) {
-        if (out->terms[p].term_id == UINT32_MAX) any_absent = true; else all_absent = false;
+        if (out->terms[p].term_id == UINT32_MAX) { if (d->op == XGM_OP_OR || ((out->req_mask >> p) & 1u)) any_absent = true; }
+        else all_absent = false;
     }
     if (d->op == XGM_OP_OR ? all_absent : any_absent) shard_empty = true;
     if (shard_empty) {

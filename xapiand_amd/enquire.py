@@ -23,12 +23,18 @@ DBL_EPSILON = sys.float_info.epsilon
 
 
 class Query:
-    """Subset of Xapian::Query (reference src/xapian/query.h:48-): a term, or AND/OR/PHRASE of terms."""
+    """Subset of Xapian::Query (reference src/xapian/query.h:48-): a term; AND / OR / PHRASE of terms; or
+    AND_NOT / AND_MAYBE / FILTER of (a term or an AND of terms, a term or an OR of terms — an AND for
+    FILTER), the trees Xapiand's DSL builds for _and_not / _and_maybe / _filter."""
     OP_AND, OP_OR, OP_PHRASE = "AND", "OR", "PHRASE"
+    OP_AND_NOT, OP_AND_MAYBE, OP_FILTER = "AND_NOT", "AND_MAYBE", "FILTER"
     LEAF_TERM = "TERM"
-    _OPS = {OP_AND: _lib.XGM_OP_AND, OP_OR: _lib.XGM_OP_OR, OP_PHRASE: _lib.XGM_OP_PHRASE}
+    _OPS = {OP_AND: _lib.XGM_OP_AND, OP_OR: _lib.XGM_OP_OR, OP_PHRASE: _lib.XGM_OP_PHRASE,
+            OP_AND_NOT: _lib.XGM_OP_AND_NOT, OP_AND_MAYBE: _lib.XGM_OP_AND_MAYBE, OP_FILTER: _lib.XGM_OP_FILTER}
+    _SIDED = (OP_AND_NOT, OP_AND_MAYBE, OP_FILTER)
 
-    def __init__(self, op_or_term, subqueries=None, window=0):
+    def __init__(self, op_or_term, subqueries=None, window=0, n_required=0):
+        self.n_required = 0
         if subqueries is None:
             self.op = Query.LEAF_TERM
             self.terms = [_as_bytes(op_or_term)]
@@ -36,6 +42,19 @@ class Query:
             return
         if op_or_term not in Query._OPS:
             raise ValueError("unsupported query operator %r" % (op_or_term,))
+        if op_or_term in Query._SIDED and not n_required:
+            # nested form: (left, right)
+            if len(subqueries) != 2:
+                raise Unsupported("%s takes a left and a right subquery" % op_or_term)
+            sides = []
+            for s, ok in zip(subqueries, ((Query.OP_AND,), (Query.OP_AND,) if op_or_term == Query.OP_FILTER else (Query.OP_OR,))):
+                if not isinstance(s, Query):
+                    s = Query(s)
+                if s.op != Query.LEAF_TERM and (s.op not in ok or len(s.terms) < 1):
+                    raise Unsupported("this shape of %s is not handled by the device path" % op_or_term)
+                sides.append(s.terms)
+            self.op, self.terms, self.window, self.n_required = op_or_term, sides[0] + sides[1], 0, len(sides[0])
+            return
         terms = []
         for s in subqueries:
             if isinstance(s, Query):
@@ -49,9 +68,20 @@ class Query:
         self.op = op_or_term
         self.terms = terms
         self.window = window
+        if op_or_term in Query._SIDED:
+            if not 1 <= n_required < len(terms):
+                raise ValueError("n_required must leave terms on both sides")
+            self.n_required = n_required
 
     def get_type(self):
         return self.op
+
+    def total_subqs(self):
+        """Weighted leaves of the query = what QueryOptimiser::inc_total_subqs counts (reference
+        src/xapian/api/queryinternal.cc:1049-1056): unweighted sides (AND_NOT, FILTER) do not count."""
+        if self.op in (Query.OP_AND_NOT, Query.OP_FILTER):
+            return self.n_required
+        return len(self.terms)
 
     def get_num_subqueries(self):
         return 0 if self.op == Query.LEAF_TERM else len(self.terms)
@@ -62,8 +92,12 @@ class Query:
     def get_description(self):
         if self.op == Query.LEAF_TERM:
             return "Query(%s)" % self.terms[0].decode("utf-8", "replace")
+        names = [t.decode("utf-8", "replace") for t in self.terms]
+        if self.op in Query._SIDED:
+            inner = "AND" if self.op == Query.OP_FILTER else "OR"
+            return "Query(((%s) %s (%s)))" % (" AND ".join(names[:self.n_required]), self.op, (" %s " % inner).join(names[self.n_required:]))
         sep = {"AND": " AND ", "OR": " OR ", "PHRASE": " PHRASE %d " % (self.window or len(self.terms))}[self.op]
-        return "Query((" + sep.join(t.decode("utf-8", "replace") for t in self.terms) + "))"
+        return "Query((" + sep.join(names) + "))"
 
 
 def _as_bytes(t):
@@ -255,6 +289,7 @@ def _desc(query, first, maxitems, check_at_least, weight):
         d.terms[i] = t
         d.term_len[i] = len(t)
     d.window = query.window
+    d.n_required = query.n_required
     d.first, d.maxitems, d.check_at_least = first, maxitems, check_at_least
     d.k1, d.k2, d.k3, d.b, d.min_normlen = weight.k1, weight.k2, weight.k3, weight.b, weight.min_normlen
     return d
@@ -313,7 +348,7 @@ class Enquire:
             return MSet(first, [], _lib.ResultHdr(), 0)
         p = plan(self._db, self._query, first, maxitems, check_at_least, self._weight)
         (hits, hdr), = search_batch(self._db, [p])
-        return MSet(p.first, hits, hdr, len(self._query.terms))
+        return MSet(p.first, hits, hdr, self._query.total_subqs())
 
 
 def merged_stats(dbs, query):
@@ -346,7 +381,7 @@ def search_sharded(dbs, queries, first, maxitems, check_at_least=0, weight=None)
     hits = (_lib.Hit * (nq * k_stride))()
     hdrs = (_lib.ResultHdr * nq)()
     _lib.check(_lib.lib().xgm_search_sharded(handles, len(dbs), descs, nq, k_stride, hits, hdrs))
-    return [MSet(first, [hits[i * k_stride + j] for j in range(hdrs[i].n_hits)], hdrs[i], len(queries[i].terms)) for i in range(nq)]
+    return [MSet(first, [hits[i * k_stride + j] for j in range(hdrs[i].n_hits)], hdrs[i], queries[i].total_subqs()) for i in range(nq)]
 
 
 def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None):
@@ -374,4 +409,4 @@ def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None)
     allhits.sort(key=lambda x: (-x.weight, x.docid))
     allhits = allhits[: first + maxitems]
     hdr.n_hits = len(allhits)
-    return MSet(first, allhits, hdr, len(query.terms))
+    return MSet(first, allhits, hdr, query.total_subqs())
