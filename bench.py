@@ -57,10 +57,11 @@ def gen_queries(n, n_terms, lo, hi, seed):
 
 def workload_name(args, world, n_docs_global, k):
     """BASELINE.json config the run corresponds to (C2 is the one the metric is quoted on)."""
-    shape = {"AND": "%d-term conjunctive" % args.terms, "OR": "%d-term disjunctive" % args.terms, "PHRASE": "2-3-term phrase (positions)"}[args.op]
+    shape = {"AND": "%d-term conjunctive" % args.terms, "OR": "%d-term disjunctive" % args.terms, "PHRASE": "2-3-term phrase (positions)"}.get(
+        args.op, "%s (%d-term AND, %d on the right)" % (args.op, args.required, args.terms - args.required))
     if world > 1:
         return "C4 (weak-scaled): %dM-doc index sharded %d ways, %s BM25 top-%d, RCCL top-k all-gather" % (n_docs_global // 1000000, world, shape, k)
-    cfg = {"AND": "C2", "OR": "C3", "PHRASE": "C5"}[args.op]
+    cfg = {"AND": "C2", "OR": "C3", "PHRASE": "C5"}.get(args.op, "next (SURVEY 8f.2)")
     return "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (cfg, args.docs_per_gpu // 1000000, args.vocab // 1000000, shape, k)
 
 
@@ -73,6 +74,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--op", default="AND")
     ap.add_argument("--terms", type=int, default=3)
+    ap.add_argument("--required", type=int, default=1, help="AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,7 +118,8 @@ def main():
         pool = gen_queries(1100, args.terms, 8, 4096, QUERY_SEED)
     k = args.topk
     searcher = ShardedSearcher(db, rank, world, dev)
-    plans = searcher.prepare([Query(args.op, terms) for terms in pool], 0, k)
+    sided = args.op in ("AND_NOT", "AND_MAYBE", "FILTER")
+    plans = searcher.prepare([Query(args.op, terms, n_required=args.required if sided else 0) for terms in pool], 0, k)
     warm_plans, timed_plans = plans[:100], plans[100:]
     n_batches = len(timed_plans) // BATCH
     batches = [(_lib.Query * BATCH)(*timed_plans[i * BATCH:(i + 1) * BATCH]) for i in range(n_batches)]
@@ -193,7 +196,7 @@ def main():
         result = {
             "metric": "queries/sec + p50 latency, %dM-doc synthetic index, %s, top-%d" % (
                 args.docs_per_gpu // 1000000, {"AND": "%d-term AND" % args.terms, "OR": "%d-term OR" % args.terms,
-                                               "PHRASE": "2-3-term PHRASE"}[args.op], k),
+                                               "PHRASE": "2-3-term PHRASE"}.get(args.op, "%d-term %s" % (args.terms, args.op)), k),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 postings + f64 BM25", "data": "synthetic",

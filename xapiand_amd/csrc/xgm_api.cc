@@ -372,7 +372,7 @@ static uint32_t next_pow2(uint32_t v) {
 /* xgm_query → device form; returns the wdf table width the query needs (1 or 2 bytes), 0 if too big */
 static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query* d) {
     memset(d, 0, sizeof *d);
-    d->op = q->op;
+    d->op = q->op == XGM_OP_FILTER ? XGM_OP_AND : q->op;       /* a FILTER is a conjunction some of whose leaves weigh nothing */
     d->n_terms = q->n_terms;
     d->k = q->first + q->maxitems;
     d->window = q->window;
@@ -409,7 +409,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         int8_t op = q->sum_prog[i];
         if (op >= 0) {
             if ((uint32_t)op >= q->n_terms) return -1;
-            d->score_mask |= 1u << op;
+            if (q->terms[op].termweight != 0.0) d->score_mask |= 1u << op;   /* a real term's BM25 weight is > 0; 0 marks an unweighted (FILTER) leaf */
             stack[sp++] = op;
         } else {
             if (sp < 2) return -1;

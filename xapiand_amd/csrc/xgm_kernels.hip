@@ -902,7 +902,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                         const bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
                         if (take) {
                             const uint32_t p = atomicAdd(&ctl.tkn, 1u);
-                            sm.tk.w[p] = wb; sm.tk.d[p] = did; sm.tk.m[p] = T;
+                            sm.tk.w[p] = wb; sm.tk.d[p] = did; sm.tk.m[p] = (uint32_t)__popc(q.score_mask);
                         }
                     }
                     for (uint32_t t = 1; t < T; ++t) c_w[(size_t)t * kAndCand + o] = 0;
@@ -1446,7 +1446,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = lane; i < n_out; i += 64u) {
         xgm_cand c;
-        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = T;
+        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = (uint32_t)__popc(q.score_mask);   /* weighted leaves: all match */
         out[i] = c;
     }
     if (lane == 0) {

@@ -214,12 +214,29 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         std::partial_sort_copy(in, in + nr, sorted, sorted + nr, TfAscending());
         for (uint32_t i = 0; i < nr; ++i) order[i] = sorted[i].idx;
         for (uint32_t i = nr; i < n; ++i) order[i] = i;
+        if (d->op == XGM_OP_FILTER) {
+            /* QueryFilter = MultiAnd{l, r x 0}: the document's weight is l's — the chain over the weighted
+             * leaves in THEIR MultiAnd order.  The unweighted leaves contribute +0.0 wherever they stand
+             * (x + 0.0 == x exactly for x >= +0.0), so they are merged in by termfreq: the plan is then
+             * ascending in termfreq like a plain conjunction's, which is what the conjunction kernels'
+             * rarest-term-first / dense-suffix layout expects. */
+            uint32_t merged[XGM_MAX_TERMS], a = 0, b = nr, m = 0;
+            uint32_t extra[XGM_MAX_TERMS];
+            for (uint32_t i = nr; i < n; ++i) extra[i] = i;
+            std::stable_sort(extra + nr, extra + n, [&](uint32_t x, uint32_t y) { return local_tf[x] < local_tf[y]; });
+            while (a < nr || b < n) {
+                if (b >= n || (a < nr && local_tf[order[a]] <= local_tf[extra[b]])) merged[m++] = order[a++];
+                else merged[m++] = extra[b++];
+            }
+            for (uint32_t i = 0; i < n; ++i) order[i] = merged[i];
+        }
     }
     for (uint32_t p = 0; p < n; ++p) {
         uint32_t i = order[p];
         out->terms[p].term_id = local_id[i];
         out->terms[p].phrase_index = i;
-        out->terms[p].termweight = tw[i];
+        out->terms[p].termweight = (d->op == XGM_OP_FILTER && i >= nr) ? 0.0 : tw[i];
+        if (d->op == XGM_OP_FILTER && i >= nr) maxpart[i] = 0.0;
     }
 
     /* weight summation program + max_possible in the same association */
@@ -250,7 +267,8 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
          * carries weight for AND_NOT / FILTER; AND_MAYBE adds the right-hand OR tree where it matches
          * (AndMaybePostList::get_weight, andmaybepostlist.cc:57-64). */
         root = 0;
-        for (uint32_t p = 1; p < nr; ++p) {
+        const uint32_t chain = d->op == XGM_OP_FILTER ? n : nr;     /* FILTER: the unweighted leaves ride along as +0.0 */
+        for (uint32_t p = 1; p < chain; ++p) {
             nodes.push_back(TreeNode{root, (int)p});
             root = (int)n + (int)nodes.size() - 1;
         }
@@ -278,7 +296,7 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     out->req_mask = 0; out->neg_mask = 0;
     for (uint32_t p = 0; p < n; ++p) {
         if (d->op == XGM_OP_OR) break;
-        if (p < nr || d->op == XGM_OP_FILTER) out->req_mask |= 1u << p;
+        if (d->op == XGM_OP_FILTER || p < nr) out->req_mask |= 1u << p;
         else if (d->op == XGM_OP_AND_NOT) out->neg_mask |= 1u << p;
     }
     bool any_absent = false, all_absent = true;
