@@ -425,6 +425,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
     d->sum_root = (uint32_t)stack[0];
     d->req_mask = q->req_mask;
     d->neg_mask = q->neg_mask;
+    d->n_req = (uint32_t)__builtin_popcount(q->req_mask);
     if (q->op != XGM_OP_OR && (q->req_mask == 0 || (q->req_mask >> q->n_terms) != 0 || (q->req_mask & q->neg_mask))) return -1;
     {
         int slot_of[2 * XGM_MAX_TERMS];
@@ -449,6 +450,7 @@ struct BatchPlan {
     bool phrase, wide;
     bool and_only;      /* every query is a plain conjunction of >= 2 terms → xgm_and_kernel */
     bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
+    bool sided;         /* andw batch that holds AND_NOT queries */
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
 };
 
@@ -457,6 +459,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
+    bool andnot_ok = true;       /* every query: AND or AND_NOT whose required terms are plan positions [0, n_req) */
     static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
     if (no_and_kernel) bp->and_only = false;
     for (uint32_t i = 0; i < nq; ++i) {
@@ -468,6 +471,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         if (width == 2) bp->wide = true;
         if (dq[i].op != XGM_OP_AND || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE)) bp->and_only = false;
         if (dq[i].op != XGM_OP_OR) or_only = false;
+        if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_AND_NOT) || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE) ||
+            dq[i].req_mask != (dq[i].n_req >= 32u ? 0xFFFFFFFFu : (1u << dq[i].n_req) - 1u) ||
+            (dq[i].op == XGM_OP_AND_NOT && (dq[i].req_mask | dq[i].neg_mask) != (1u << dq[i].n_terms) - 1u))
+            andnot_ok = false;
         if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_PHRASE) || dq[i].n_terms < 2) conj_only = false;
         if (dq[i].flags & XGM_QF_PHRASE) {
             if (dq[i].n_terms > XGM_PHRASE_MAX_TERMS) return XGM_UNSUPPORTED;
@@ -487,7 +494,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     const uint32_t k_pad = next_pow2(bp->k_max);
     static const bool no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr;           /* A/B switch for measurements */
     const bool phrase_conj = conj_only && bp->phrase && !no_phrase_w && !no_and_kernel;
-    bp->andw = (bp->and_only || phrase_conj) && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP &&
+    if (no_and_kernel) andnot_ok = false;
+    bp->sided = andnot_ok && !bp->and_only;
+    bp->andw = (bp->and_only || andnot_ok || phrase_conj) && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP &&
                xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, 32u, bp->phrase) <= 160u * 1024u;
     /* disjunctions: one wave per unit as well; a unit spans as many stripes as the merge capacity
      * (units x k candidates per query) requires */
@@ -637,7 +646,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
-    L.phrase = bp.phrase; L.wide = bp.wide;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw && bp.sided;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (idx->profiling) {

@@ -38,6 +38,7 @@ typedef struct {
     uint32_t sum_root;                    /* index (leaf or T + node) holding the document's weight     */
     uint32_t req_mask, neg_mask;          /* term t must / must not index a matching document (non-OR)  */
     uint32_t score_mask;                  /* term t is a weighted leaf (LeafPostList::count_matching_subqs) */
+    uint32_t n_req, pad1;                 /* popcount(req_mask): the required terms are plan positions [0, n_req) */
     /* safe upper bound of leaf t's weight over the whole shard (0 for an absent term): drives the
      * MaxScore pruning of xgm_orw_kernel; never part of a result */
     double ub[XGM_MAX_TERMS];

@@ -985,7 +985,9 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
     wave_lds_fence();
 }
 
-template <typename TabT, bool PHRASE>
+/* SIDED: the batch holds AND_NOT queries (excluded terms after the required ones); a separate instantiation,
+ * so that the plain conjunction pays nothing for it. */
+template <typename TabT, bool PHRASE, bool SIDED>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -1000,6 +1002,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     const xgm_dev_query& q = queries[wk.qi];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k, SPG = spg_max;
+    /* plan positions [0, TR) must index a document; [TR, T) — the right-hand side of an AND_NOT — must not
+     * (AndNotPostList).  A plain conjunction / FILTER has TR == T. */
+    const uint32_t TR = SIDED ? q.n_req : T;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
 
     /* private LDS slice */
@@ -1031,13 +1036,16 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
      * payload base and dense-container index */
     uint64_t tbase_reg = 0, tpos_reg = 0;
     uint32_t dense_reg = 0xFFFFFFFFu;
+    bool have_reg = false;                                         /* lane t: term t exists in this shard */
     if (!empty) {
         for (uint32_t t = 0; t < T; ++t) {
             const uint32_t id = q.term_id[t];
+            if (SIDED && id == 0xFFFFFFFFu) continue;              /* an excluded term the shard does not have */
             const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
             const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
             const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
             if (lane == t) {
+                have_reg = true;
                 tbase_reg = seg.term_word[id];
                 if (PHRASE) tpos_reg = seg.term_pos[id];
                 /* the positional filter needs every term's position offsets, which only the block
@@ -1060,8 +1068,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     /* Plan order is ascending termfreq and "dense" is a termfreq threshold, so the dense terms are a
      * suffix [td, T).  td == 0: every term is dense → candidates come from the AND of the bitmaps.
      * (With more than 4 terms term 0 is always decoded, to bound the registers of that path.) */
-    uint32_t td = (uint32_t)__popcll(__ballot(lane < T && dense_reg == 0xFFFFFFFFu));
-    if (td == 0 && T > 4u) td = 1;
+    uint32_t td = (uint32_t)__popcll(__ballot(lane < TR && dense_reg == 0xFFFFFFFFu));
+    /* excluded terms without containers are block-decoded against the candidates' bitmap (P3c), which only
+     * the decode path builds */
+    const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;
+    if (td == 0 && (TR > 4u || sparse_neg)) td = 1;
 
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
     bool theta_valid = false;
@@ -1074,7 +1085,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         uint32_t x = from;
         for (; x < n_local; ++x) {
             bool all = true;
-            for (uint32_t t = 0; t < T; ++t) all = all && (re[t * SPG + x] != rs[t * SPG + x]);
+            for (uint32_t t = 0; t < TR; ++t) all = all && (re[t * SPG + x] != rs[t * SPG + x]);
             if (all) break;
         }
         return x;
@@ -1110,7 +1121,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 if (PHRASE) hb_pos = seg.blk_pos[rb + lane];
             }
         }
-        if (lane >= td && lane < T) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
+        if (SIDED) hc_off = 0;                                     /* 0 = no container (for this term / in this stripe) */
+        if (lane >= td && lane < T && (!SIDED || dense_reg != 0xFFFFFFFFu)) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
     };
 
     uint32_t dl[4] = {0, 0, 0, 0};
@@ -1129,8 +1141,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     wv[u] = 0;
-                    if (t0 + u < T && valid)
-                        wv[u] = seg.dense_data[(size_t)__builtin_amdgcn_readlane(hc_cur, t0 + u) * 16 + (size_t)NW * 4 + slot];
+                    const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, (t0 + u) & 63u);
+                    if (t0 + u < T && valid && (!SIDED || oo))
+                        wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
                 }
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u)
@@ -1156,7 +1169,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             uint32_t did = 0;
             if (o < n_c) {
                 bool pass = true;
-                for (uint32_t t = 0; t < T; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
+                for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
+                for (uint32_t t = TR; t < T; ++t) pass = pass && c_w[(size_t)t * CAND + o] == 0;      /* AND_NOT */
                 if (PHRASE && phrase && pass) {
                     /* K6: ExactPhrasePostList / PhrasePostList::test_doc over the terms' position lists */
                     PosList pl[XGM_PHRASE_MAX_TERMS];
@@ -1184,7 +1198,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                     normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
                     const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
                     double weight = 0.0;                       /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
-                    for (uint32_t t = 0; t < T; ++t) {
+                    for (uint32_t t = 0; t < TR; ++t) {
                         const double wdf = (double)((uint32_t)c_w[(size_t)t * CAND + o] - 1u);
                         const double denom = denom_len + wdf;
                         weight = weight + q.termweight[t] * (wdf / denom);
@@ -1212,7 +1226,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             uint32_t m[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
-                if (t < T) {
+                if (t < TR) {
                     const uint32_t* bmp = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t) * 16);
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
@@ -1427,6 +1441,36 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
 
             /* ---- P3b: dense other terms [td, T): O(1) probes of their containers ---- */
             if (td < T) probe_dense(td, n_c);
+
+            /* ---- P3c: excluded terms without containers: the blocks whose buckets hold a candidate ---- */
+            for (uint64_t xm = sparse_neg; SIDED && xm; xm &= xm - 1u) {
+                const uint32_t t = (uint32_t)__builtin_ctzll(xm);
+                const uint32_t rbx = rs[t * SPG + sl], nbx = re[t * SPG + sl] - rbx;
+                TabT* row = c_w + (size_t)t * CAND;
+                for (uint32_t j = 0; j < nbx; ++j) {
+                    const uint32_t xmeta = seg.blk_meta[rbx + j], xfirst = seg.blk_first[rbx + j];
+                    const uint32_t xnext = j + 1u < nbx ? seg.blk_first[rbx + j + 1u] : 0xFFFFFFFFu;
+                    if (!bucket_need(xfirst, xnext)) continue;
+                    if (lane * 4u < payload_words(xmeta)) {
+                        const Words4 pvx = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rbx + j] + lane * 4u);
+                        stage[lane * 4u] = pvx.a; stage[lane * 4u + 1] = pvx.b; stage[lane * 4u + 2] = pvx.c; stage[lane * 4u + 3] = pvx.d;
+                    }
+                    wave_lds_fence();
+                    DecodedPair r = unpack_staged<false>(stage, xfirst, xmeta, lane);
+                    wave_lds_fence();
+                    if (r.v0) {
+                        const uint32_t sl0 = r.d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
+                        const uint32_t bm = bitmap[wd];
+                        if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w0 + 1u);
+                    }
+                    if (r.v1) {
+                        const uint32_t sl1 = r.d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
+                        const uint32_t bm = bitmap[wd];
+                        if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w1 + 1u);
+                    }
+                }
+            }
+            wave_lds_fence();
 
             /* headers of the next active stripe: in flight while this one is scored */
             if (cb + CHUNKB >= r0e && sl_next < n_local) issue_headers(sl_next);
@@ -1762,10 +1806,10 @@ size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t ca
     return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg, phrase);
 }
 
-template <typename TabT, bool PHRASE>
+template <typename TabT, bool PHRASE, bool SIDED>
 static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
     const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
-    auto kern = xgm_andw_kernel<TabT, PHRASE>;
+    auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED>;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
     hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
@@ -1776,8 +1820,9 @@ static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
     const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group, L.phrase);
     if (smem > 160u * 1024u) return xgm_launch_error("andw kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.phrase) return L.wide ? launch_andw_variant<uint16_t, true>(L, smem, stream) : launch_andw_variant<uint8_t, true>(L, smem, stream);
-    return L.wide ? launch_andw_variant<uint16_t, false>(L, smem, stream) : launch_andw_variant<uint8_t, false>(L, smem, stream);
+    if (L.phrase) return L.wide ? launch_andw_variant<uint16_t, true, false>(L, smem, stream) : launch_andw_variant<uint8_t, true, false>(L, smem, stream);
+    if (L.sided) return L.wide ? launch_andw_variant<uint16_t, false, true>(L, smem, stream) : launch_andw_variant<uint8_t, false, true>(L, smem, stream);
+    return L.wide ? launch_andw_variant<uint16_t, false, false>(L, smem, stream) : launch_andw_variant<uint8_t, false, false>(L, smem, stream);
 }
 
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
