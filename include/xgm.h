@@ -99,6 +99,18 @@ int xgm_segment_build(const xgm_raw_postings* raw, uint32_t stripe_bits, const c
 /* Same, reading the "XGMRAW1" file form. */
 int xgm_segment_build_from_file(const char* raw_path, uint32_t stripe_bits, const char* out_path);
 
+/* Export a committed glass shard of the reference straight from its on-disk B-trees (postlist.glass,
+ * position.glass, iamglass — formats: reference src/xapian/backends/glass/glass_table.h:62-330,
+ * glass_version.cc:100-235, glass_postlist.cc:677-695, glass_positionlist.cc:36-133, common/pack.h,
+ * common/bitstream.cc) into a device segment: the exporter without Xapian in the loop (a sequential
+ * scan of the leaf blocks instead of a B-tree cursor and a virtual call per posting).  The shard must
+ * not be modified while it is read (hold Xapiand's shard lock, or export a checked-in revision). */
+int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stripe_bits, const char* out_path);
+
+/* Same reader, writing the "XGMRAW1" file form (what the iterator-based exporter produces): used to
+ * verify the reader byte for byte against an export made through Xapian's public iterators. */
+int xgm_glass_export_raw(const char* glass_dir, const char* raw_path);
+
 /* Host-side decode of one term's postings out of a segment FILE (index utility used to verify an
  * export; not a search path).  Returns the number of postings written (<= cap) or < 0. */
 int64_t xgm_segment_decode_term(const char* segment_path, const char* term, size_t len,

@@ -19,6 +19,8 @@
  *   time   <queries.txt> <n_threads> <repeat> <dbdir> [<dbdir> ...]
  *          Time get_mset per query (steady_clock; Enquire construction and set_query excluded,
  *          prepare_mset included — BASELINE.md §3).  Prints one JSON line.
+ *   build_misc <dbdir>
+ *          A small database with the corner cases of the on-disk format (see cmd_build_misc).
  *   export <dbdir> <out.raw>
  *          Walk the public iterators (allterms_begin / postlist_begin / positionlist_begin /
  *          get_doclength) and write the raw-postings file that the segment
@@ -174,6 +176,40 @@ int cmd_build(int argc, char** argv) {
     return 0;
 }
 
+/* A small database that exercises the corners of the on-disk format for the native glass reader
+ * (tests/test_glass.py): several commits, deleted and replaced documents (docid gaps), docids beyond
+ * 0x8000 / 0x200000 (longer sort-preserving chunk keys), terms with embedded zero bytes, postings without
+ * positions, boolean terms (wdf 0), long posting lists (several chunks). */
+int cmd_build_misc(int argc, char** argv) {
+    if (argc < 3) return 2;
+    Xapian::WritableDatabase db(argv[2], Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
+    auto make = [](unsigned i) {
+        Xapian::Document doc;
+        unsigned pos = 1;
+        for (unsigned j = 0; j < 20 + i % 17; ++j) doc.add_posting("w" + std::to_string((i * 7 + j * j) % 60), pos++);
+        if (i % 3 == 0) doc.add_posting(std::string("z\0a", 3), pos++);
+        if (i % 5 == 0) doc.add_posting(std::string("z\0\xff" "b", 4), pos++);
+        if (i % 4 == 0) doc.add_term("nopos", 1 + i % 3);
+        if (i % 2 == 0) doc.add_boolean_term("Keven");
+        if (i % 11 == 0) { doc.add_term("mixed", 2); } else if (i % 11 == 1) { doc.add_posting("mixed", 500); }
+        return doc;
+    };
+    for (unsigned i = 1; i <= 3000; ++i) {
+        db.add_document(make(i));
+        if (i % 1000 == 0) db.commit();
+    }
+    for (unsigned d = 5; d <= 3000; d += 5) db.delete_document(d);
+    db.replace_document(7, make(9007));
+    db.commit();
+    db.replace_document(40000, make(40000));
+    db.replace_document(70001, make(70001));
+    db.replace_document(3000000, make(3000000));
+    for (unsigned i = 0; i < 2500; ++i) db.add_document(make(5000 + i));          /* docids 3000001.. : long docid gaps inside lists */
+    db.commit();
+    printf("{\"doccount\": %u, \"lastdocid\": %u}\n", db.get_doccount(), db.get_lastdocid());
+    return 0;
+}
+
 std::vector<Xapian::Database> open_dbs(int argc, char** argv, int from) {
     std::vector<Xapian::Database> dbs;
     for (int i = from; i < argc; ++i) dbs.emplace_back(argv[i]);
@@ -312,6 +348,7 @@ int main(int argc, char** argv) {
         else if (cmd == "query") rc = cmd_query(argc, argv);
         else if (cmd == "time") rc = cmd_time(argc, argv);
         else if (cmd == "export") rc = cmd_export(argc, argv);
+        else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
         if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());
         return rc;
     } catch (const Xapian::Error& e) {

@@ -1,0 +1,476 @@
+/* Native reader of the reference's on-disk shard format ("glass"): walks the postlist and position
+ * B-trees of a committed glass database directly — no Xapian in the loop — and hands the postings to
+ * the segment builder.  This is the exporter of SURVEY.md §8(f).1: the iterator-based export
+ * (Database::allterms_begin / postlist_begin / positionlist_begin) pays a B-tree
+ * cursor and a virtual call per posting; reading the leaf blocks in key order is a sequential scan.
+ *
+ * Formats restated from the reference (paths under /root/reference/src/xapian/):
+ *   version file  <dir>/iamglass: magic, format version, uuid, revision, one RootInfo per table,
+ *                 database statistics                          backends/glass/glass_version.cc:100-235, 423-468
+ *   B-tree block  REVISION u32 | LEVEL u8 | MAX_FREE u16 | TOTAL_FREE u16 | DIR_END u16 | directory of
+ *                 u16 item offsets from byte 11; all integers big-endian  backends/glass/glass_table.h:62-124
+ *   leaf item     I2 (size - 3 in the low 13 bits; 0x80 compressed, 0x40 last, 0x20 first component) |
+ *                 K1 key length | key | X2 component number (absent on the first) | tag piece   :138-215
+ *   branch item   u32 child block | K1 | key | X2                                               :268-330
+ *   postlist keys / chunk tags   common/pack.h:183-290, 520-594; backends/glass/glass_postlist.cc:100-150, 677-695
+ *   position keys / tags         backends/glass/glass_positionlist.h:39-44, glass_positionlist.cc:36-52, 96-133;
+ *                                interpolative code common/bitstream.cc:93-255
+ * The postlist and position tables are never compressed (compress_min 0, glass_version.cc:398-405).
+ */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "xgm_internal.h"
+
+namespace {
+
+constexpr int kDirStart = 11;
+constexpr unsigned kTablePostlist = 0, kTablePosition = 3, kTableCount = 6;
+
+inline uint32_t be16(const uint8_t* p) { return ((uint32_t)p[0] << 8) | p[1]; }
+inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+/* unpack_uint: 7 bits per byte, least significant group first, 0x80 = more follow (common/pack.h:325-389) */
+bool get_varint(const uint8_t** p, const uint8_t* end, uint64_t* out) {
+    uint64_t v = 0;
+    unsigned shift = 0;
+    while (*p < end) {
+        const uint8_t b = *(*p)++;
+        if (shift < 64) v |= (uint64_t)(b & 0x7F) << shift;
+        shift += 7;
+        if (!(b & 0x80)) { *out = v; return true; }
+    }
+    return false;
+}
+
+/* unpack_uint_preserving_sort (common/pack.h:232-283) */
+bool get_sortable_uint(const uint8_t** p, const uint8_t* end, uint64_t* out) {
+    if (*p >= end) return false;
+    uint8_t lb = *(*p)++;
+    if (lb < 0x80) {
+        if (*p >= end) return false;
+        *out = ((uint64_t)lb << 8) | *(*p)++;
+        return true;
+    }
+    if (lb == 0xFF) return false;
+    size_t len = 2;
+    for (uint8_t m = 0x40; lb & m; m >>= 1) ++len;
+    if ((size_t)(end - *p) < len || len > 8) return false;
+    const unsigned mask = 0xFFu << (9 - len);
+    uint64_t r = lb & ~mask & 0xFFu;
+    for (size_t i = 0; i < len; ++i) r = (r << 8) | *(*p)++;
+    *out = r;
+    return true;
+}
+
+struct RootInfo {
+    uint64_t root = 0, num_entries = 0, blocksize = 0;
+    unsigned level = 0;
+    bool fake = true;
+};
+
+struct GlassVersion {
+    uint64_t revision = 0, doccount = 0, last_docid = 0, total_doclen = 0;
+    RootInfo root[kTableCount];
+};
+
+int read_version(const std::string& dir, GlassVersion* v) {
+    const std::string path = dir + "/iamglass";
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
+    uint8_t buf[1024];
+    const size_t n = fread(buf, 1, sizeof buf, f);
+    fclose(f);
+    static const char magic[] = "\x0f\x0dXapian Glass";
+    if (n < 33 || memcmp(buf, magic, 14) != 0) return xgm_set_error(XGM_E_INVALID, "%s: not a glass version file", path.c_str());
+    const unsigned version = ((unsigned)buf[14] << 8) | buf[15];
+    const unsigned want = ((2016u - 2014u) << 9) | (3u << 5) | 14u;            /* DATE_TO_VERSION(2016,03,14), glass_version.cc:53-60 */
+    if (version != want) return xgm_set_error(XGM_E_INVALID, "%s: glass format version %u, expected %u", path.c_str(), version, want);
+    const uint8_t* p = buf + 16 + 16;                                            /* magic + version, uuid */
+    const uint8_t* end = buf + n;
+    if (!get_varint(&p, end, &v->revision)) return xgm_set_error(XGM_E_INVALID, "%s: truncated", path.c_str());
+    for (unsigned t = 0; t < kTableCount; ++t) {
+        uint64_t val, bs, cmin, fl_len;
+        RootInfo& r = v->root[t];
+        if (!get_varint(&p, end, &r.root) || !get_varint(&p, end, &val) || !get_varint(&p, end, &r.num_entries) ||
+            !get_varint(&p, end, &bs) || !get_varint(&p, end, &cmin) || !get_varint(&p, end, &fl_len) || (uint64_t)(end - p) < fl_len)
+            return xgm_set_error(XGM_E_INVALID, "%s: root info of table %u is truncated", path.c_str(), t);
+        p += fl_len;
+        r.level = (unsigned)(val >> 2);
+        r.fake = (val & 1) != 0;
+        r.blocksize = bs << 11;
+    }
+    uint64_t ld_minus, skip;
+    if (p == end) return XGM_OK;                                                 /* empty database: no statistics */
+    if (!get_varint(&p, end, &v->doccount) || !get_varint(&p, end, &ld_minus) || !get_varint(&p, end, &skip) /* doclen_lbound */ ||
+        !get_varint(&p, end, &skip) /* wdf_ubound */ || !get_varint(&p, end, &skip) /* doclen_ubound - wdf_ubound */ ||
+        !get_varint(&p, end, &skip) /* oldest_changeset */ || !get_varint(&p, end, &v->total_doclen))
+        return xgm_set_error(XGM_E_INVALID, "%s: database statistics are truncated", path.c_str());
+    v->last_docid = ld_minus + v->doccount;
+    return XGM_OK;
+}
+
+/* One table file, mapped read-only; walk() visits every (key, tag) of the committed tree in key order. */
+class Table {
+  public:
+    ~Table() { if (map_ && map_ != MAP_FAILED) munmap((void*)map_, size_); if (fd_ >= 0) close(fd_); }
+
+    int open(const std::string& path, const RootInfo& root) {
+        root_ = root;
+        path_ = path;
+        if (root.fake || root.num_entries == 0) return XGM_OK;                   /* nothing committed in this table */
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", path.c_str(), strerror(errno));
+        struct stat st;
+        if (fstat(fd_, &st) != 0) return xgm_set_error(XGM_E_IO, "cannot stat %s", path.c_str());
+        size_ = (size_t)st.st_size;
+        if (root.blocksize < 2048 || root.blocksize > 65536 || (root.root + 1) * root.blocksize > size_)
+            return xgm_set_error(XGM_E_INVALID, "%s: root block %llu outside the file", path.c_str(), (unsigned long long)root.root);
+        map_ = (const uint8_t*)mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
+        if (map_ == MAP_FAILED) return xgm_set_error(XGM_E_IO, "cannot map %s: %s", path.c_str(), strerror(errno));
+        madvise((void*)map_, size_, MADV_SEQUENTIAL);
+        return XGM_OK;
+    }
+
+    bool empty() const { return map_ == nullptr; }
+
+    template <class F>
+    int walk(F&& emit) {
+        if (empty()) return XGM_OK;
+        key_.clear(); tag_.clear(); in_item_ = false;
+        int rc = visit(root_.root, root_.level, emit);
+        if (rc == XGM_OK && in_item_) rc = xgm_set_error(XGM_E_INVALID, "%s: last tag is incomplete", path_.c_str());
+        return rc;
+    }
+
+  private:
+    template <class F>
+    int visit(uint64_t block, unsigned level, F& emit) {
+        if ((block + 1) * root_.blocksize > size_) return xgm_set_error(XGM_E_INVALID, "%s: block %llu outside the file", path_.c_str(), (unsigned long long)block);
+        const uint8_t* b = map_ + block * root_.blocksize;
+        if (b[4] != level) return xgm_set_error(XGM_E_INVALID, "%s: block %llu has level %u, expected %u", path_.c_str(), (unsigned long long)block, b[4], level);
+        const uint32_t dir_end = be16(b + 9);
+        if (dir_end < (uint32_t)kDirStart || dir_end > root_.blocksize) return xgm_set_error(XGM_E_INVALID, "%s: bad directory in block %llu", path_.c_str(), (unsigned long long)block);
+        for (uint32_t c = kDirStart; c < dir_end; c += 2) {
+            const uint32_t off = be16(b + c);
+            if (off + 3 > root_.blocksize) return xgm_set_error(XGM_E_INVALID, "%s: bad item offset in block %llu", path_.c_str(), (unsigned long long)block);
+            const uint8_t* it = b + off;
+            if (level > 0) {
+                int rc = visit(be32(it), level - 1, emit);                       /* BItem::block_given_by */
+                if (rc) return rc;
+                continue;
+            }
+            const uint32_t size = (be16(it) & 0x1FFFu) + 3u;                     /* LeafItem::size */
+            const bool compressed = it[0] & 0x80, last = it[0] & 0x40, first = it[0] & 0x20;
+            const uint32_t klen = it[2];
+            uint32_t cd = 3u + klen + (first ? 0u : 2u);
+            if (off + size > root_.blocksize || cd > size) return xgm_set_error(XGM_E_INVALID, "%s: bad item in block %llu", path_.c_str(), (unsigned long long)block);
+            if (compressed) return xgm_set_error(XGM_E_INVALID, "%s: compressed tag (not expected in this table)", path_.c_str());
+            if (first) {
+                if (in_item_) return xgm_set_error(XGM_E_INVALID, "%s: tag components out of sequence", path_.c_str());
+                key_.assign((const char*)it + 3, klen);
+                tag_.clear();
+                in_item_ = true;
+            } else if (!in_item_ || key_.size() != klen || memcmp(key_.data(), it + 3, klen) != 0) {
+                return xgm_set_error(XGM_E_INVALID, "%s: tag components out of sequence", path_.c_str());
+            }
+            tag_.append((const char*)it + cd, size - cd);
+            if (last) {
+                in_item_ = false;
+                if (key_.empty()) continue;          /* the null-key item that opens every tree (glass_table.cc: "dummy" first item) */
+                int rc = emit(key_, tag_);
+                if (rc) return rc;
+            }
+        }
+        return XGM_OK;
+    }
+
+    RootInfo root_;
+    std::string path_;
+    int fd_ = -1;
+    const uint8_t* map_ = nullptr;
+    size_t size_ = 0;
+    std::string key_, tag_;
+    bool in_item_ = false;
+};
+
+/* unpack_string_preserving_sort on a key prefix: term bytes up to the unescaped \0 (or the end of the key);
+ * *rest points after the terminator, or is NULL when the key ends with the term (first chunk of a list) */
+void split_term_key(const std::string& key, std::string* term, const uint8_t** rest) {
+    term->clear();
+    const uint8_t* p = (const uint8_t*)key.data();
+    const uint8_t* end = p + key.size();
+    *rest = nullptr;
+    while (p < end) {
+        const uint8_t ch = *p++;
+        if (ch == 0) {
+            if (p < end && *p == 0xFF) { ++p; term->push_back('\0'); continue; }
+            *rest = p;
+            return;
+        }
+        term->push_back((char)ch);
+    }
+}
+
+/* BitReader::read_bits / decode / decode_interpolative (common/bitstream.cc:174-255), recursive form */
+struct BitReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint64_t acc = 0;
+    int n_bits = 0;
+    bool ok = true;
+
+    uint64_t read_bits(int count) {
+        if (count > 32) { const uint64_t lo = read_bits(32); return lo | (read_bits(count - 32) << 32); }
+        while (n_bits < count) {
+            if (p >= end) { ok = false; return 0; }
+            acc |= (uint64_t)*p++ << n_bits;
+            n_bits += 8;
+        }
+        const uint64_t r = acc & ((1ull << count) - 1ull);
+        acc >>= count;
+        n_bits -= count;
+        return r;
+    }
+    uint32_t decode(uint32_t outof) {
+        int bits = 0;
+        for (uint32_t m = outof - 1u; m; m >>= 1) ++bits;                        /* highest_order_bit(outof - 1) */
+        const uint32_t spare = (bits >= 32 ? 0u : (1u << bits)) - outof;
+        const uint32_t mid_start = (outof - spare) / 2u;
+        uint32_t pos;
+        if (spare) {
+            pos = (uint32_t)read_bits(bits - 1);
+            if (pos < mid_start && read_bits(1)) pos += mid_start + spare;
+        } else {
+            pos = (uint32_t)read_bits(bits);
+        }
+        return pos;
+    }
+    void interpolative(uint32_t* pos, int j, int k) {
+        while (j + 1 < k && ok) {
+            const int mid = j + (k - j) / 2;
+            const uint32_t outof = pos[k] - pos[j] - (uint32_t)(k - j) + 1u;
+            pos[mid] = decode(outof) + pos[j] + (uint32_t)(mid - j);
+            interpolative(pos, j, mid);
+            j = mid;
+        }
+    }
+};
+
+struct Export {
+    GlassVersion ver;
+    std::vector<std::string> terms;
+    std::vector<uint32_t> df, did, wdf, doclen, pos;
+    std::vector<uint64_t> pos_off;
+    bool has_positions = false;
+    uint64_t doccount = 0, total_length = 0;
+};
+
+/* a chunk body: bool is_last, varint(last - first), wdf of the first entry, then (did increase - 1, wdf) pairs */
+template <class F>
+int read_chunk_body(const uint8_t* p, const uint8_t* end, uint64_t first_did, F&& entry) {
+    if (p >= end || (uint8_t)(*p - '0') > 1) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: bad header");
+    ++p;
+    uint64_t span, w;
+    if (!get_varint(&p, end, &span) || !get_varint(&p, end, &w)) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: truncated header");
+    uint64_t d = first_did;
+    entry(d, w);
+    while (p < end) {
+        uint64_t inc;
+        if (!get_varint(&p, end, &inc) || !get_varint(&p, end, &w)) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: truncated entry");
+        d += inc + 1;
+        entry(d, w);
+    }
+    if (d != first_did + span) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: last docid mismatch");
+    return XGM_OK;
+}
+
+int read_glass(const char* glass_dir, Export* ex) {
+    const std::string dir(glass_dir);
+    int rc = read_version(dir, &ex->ver);
+    if (rc) return rc;
+    if (ex->ver.last_docid > 0xFFFFFFFEull) return xgm_set_error(XGM_E_INVALID, "docids beyond 32 bits");
+    ex->doclen.assign((size_t)ex->ver.last_docid + 1, 0);
+
+    Table post;
+    if ((rc = post.open(dir + "/postlist.glass", ex->ver.root[kTablePostlist]))) return rc;
+    std::string term;
+    bool have_term = false;
+    rc = post.walk([&](const std::string& key, const std::string& tag) -> int {
+        const uint8_t* p = (const uint8_t*)tag.data();
+        const uint8_t* end = p + tag.size();
+        if (key.size() >= 2 && key[0] == '\0') {
+            const uint8_t k1 = (uint8_t)key[1];
+            if (k1 == 0xE0) {                                                   /* document lengths: wdf field = length */
+                uint64_t first;
+                if (key.size() == 2) {
+                    uint64_t n, cf;
+                    if (!get_varint(&p, end, &n) || !get_varint(&p, end, &cf) || !get_varint(&p, end, &first)) return xgm_set_error(XGM_E_INVALID, "doclen list: truncated");
+                    ++first;
+                } else {
+                    const uint8_t* kp = (const uint8_t*)key.data() + 2;
+                    if (!get_sortable_uint(&kp, (const uint8_t*)key.data() + key.size(), &first)) return xgm_set_error(XGM_E_INVALID, "doclen list: bad chunk key");
+                }
+                return read_chunk_body(p, end, first, [&](uint64_t d, uint64_t len) {
+                    if (d < ex->doclen.size()) ex->doclen[d] = (uint32_t)len;
+                    ++ex->doccount;
+                    ex->total_length += len;
+                });
+            }
+            if (k1 == 0xC0 || k1 == 0xD0 || k1 == 0xD8) return XGM_OK;         /* user metadata, value statistics, value chunks */
+        }
+        std::string t;
+        const uint8_t* rest;
+        split_term_key(key, &t, &rest);
+        uint64_t first;
+        if (!rest) {                                                            /* first chunk of a term */
+            uint64_t n, cf;
+            if (!get_varint(&p, end, &n) || !get_varint(&p, end, &cf) || !get_varint(&p, end, &first)) return xgm_set_error(XGM_E_INVALID, "postlist: truncated first chunk");
+            ++first;
+            ex->terms.push_back(t);
+            ex->df.push_back(0);
+            term = t;
+            have_term = true;
+        } else {
+            if (!have_term || t != term) return xgm_set_error(XGM_E_INVALID, "postlist: continuation chunk without a first chunk");
+            if (!get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &first)) return xgm_set_error(XGM_E_INVALID, "postlist: bad chunk key");
+        }
+        return read_chunk_body(p, end, first, [&](uint64_t d, uint64_t w) {
+            ex->did.push_back((uint32_t)d);
+            ex->wdf.push_back((uint32_t)w);
+            ++ex->df.back();
+        });
+    });
+    if (rc) return rc;
+
+    Table posn;
+    if ((rc = posn.open(dir + "/position.glass", ex->ver.root[kTablePosition]))) return rc;
+    ex->has_positions = !posn.empty();
+    if (ex->has_positions) {
+        /* the table is ordered by (term, docid) like the postings: merge in lockstep */
+        ex->pos_off.assign(1, 0);
+        size_t ti = 0;                       /* current term of the posting cursor */
+        uint64_t pi = 0, t_end = ex->terms.empty() ? 0 : ex->df[0];             /* posting ordinal, end of term ti */
+        std::vector<uint32_t> tmp;
+        rc = posn.walk([&](const std::string& key, const std::string& tag) -> int {
+            std::string t;
+            const uint8_t* rest;
+            split_term_key(key, &t, &rest);
+            uint64_t d;
+            if (!rest || !get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &d)) return xgm_set_error(XGM_E_INVALID, "position table: bad key");
+            /* advance the posting cursor to (t, d); postings passed over have no positions */
+            while (true) {
+                if (ti >= ex->terms.size()) return xgm_set_error(XGM_E_INVALID, "position table: entry without a posting");
+                const int c = ex->terms[ti].compare(t);
+                if (c > 0) return xgm_set_error(XGM_E_INVALID, "position table: entry without a posting");
+                if (c == 0 && pi < t_end && ex->did[pi] == d) break;
+                if (c == 0 && (pi >= t_end || ex->did[pi] > d)) return xgm_set_error(XGM_E_INVALID, "position table: entry without a posting");
+                if (pi < t_end) { ++pi; ex->pos_off.push_back(ex->pos.size()); }
+                else { ++ti; if (ti < ex->terms.size()) t_end += ex->df[ti]; }
+            }
+            const uint8_t* p = (const uint8_t*)tag.data();
+            const uint8_t* end = p + tag.size();
+            uint64_t last;
+            if (!get_varint(&p, end, &last)) return xgm_set_error(XGM_E_INVALID, "position list: truncated");
+            if (p == end) {
+                ex->pos.push_back((uint32_t)last);                               /* single entry */
+            } else {
+                BitReader rd{p, end};
+                const uint32_t first = rd.decode((uint32_t)last);
+                const uint32_t n = rd.decode((uint32_t)last - first) + 2u;
+                tmp.assign(n, 0);
+                tmp[0] = first; tmp[n - 1] = (uint32_t)last;
+                rd.interpolative(tmp.data(), 0, (int)n - 1);
+                if (!rd.ok) return xgm_set_error(XGM_E_INVALID, "position list: truncated bit stream");
+                ex->pos.insert(ex->pos.end(), tmp.begin(), tmp.end());
+            }
+            ++pi;
+            ex->pos_off.push_back(ex->pos.size());
+            return XGM_OK;
+        });
+        if (rc) return rc;
+        while (ex->pos_off.size() < ex->did.size() + 1) ex->pos_off.push_back(ex->pos.size());
+    }
+    if (ex->doccount != ex->ver.doccount || ex->total_length != ex->ver.total_doclen)
+        return xgm_set_error(XGM_E_INVALID, "glass statistics disagree with the document-length list (%llu/%llu docs, %llu/%llu length)",
+                             (unsigned long long)ex->doccount, (unsigned long long)ex->ver.doccount,
+                             (unsigned long long)ex->total_length, (unsigned long long)ex->ver.total_doclen);
+    return XGM_OK;
+}
+
+void fill_raw(const Export& ex, std::vector<const char*>* tp, std::vector<uint32_t>* tl, xgm_raw_postings* raw) {
+    tp->clear(); tl->clear();
+    for (const std::string& t : ex.terms) { tp->push_back(t.data()); tl->push_back((uint32_t)t.size()); }
+    memset(raw, 0, sizeof *raw);
+    raw->n_terms = (uint32_t)ex.terms.size();
+    raw->lastdocid = (uint32_t)ex.ver.last_docid;
+    raw->doccount = (uint32_t)ex.ver.doccount;
+    raw->has_positions = ex.has_positions ? 1u : 0u;
+    raw->total_length = ex.ver.total_doclen;
+    raw->n_postings = ex.did.size();
+    raw->n_positions = ex.pos.size();
+    raw->revision = ex.ver.revision;
+    raw->doclen = ex.doclen.data();
+    raw->terms = tp->data();
+    raw->term_len = tl->data();
+    raw->df = ex.df.data();
+    raw->did = ex.did.data();
+    raw->wdf = ex.wdf.data();
+    raw->pos_off = ex.has_positions ? ex.pos_off.data() : nullptr;
+    raw->pos = ex.has_positions ? ex.pos.data() : nullptr;
+}
+
+}  // namespace
+
+extern "C" int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stripe_bits, const char* out_path) {
+    if (!glass_dir || !out_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    Export ex;
+    int rc = read_glass(glass_dir, &ex);
+    if (rc) return rc;
+    std::vector<const char*> tp;
+    std::vector<uint32_t> tl;
+    xgm_raw_postings raw;
+    fill_raw(ex, &tp, &tl, &raw);
+    return xgm_segment_build(&raw, stripe_bits, out_path);
+}
+
+extern "C" int xgm_glass_export_raw(const char* glass_dir, const char* raw_path) {
+    if (!glass_dir || !raw_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    Export ex;
+    int rc = read_glass(glass_dir, &ex);
+    if (rc) return rc;
+    FILE* f = fopen(raw_path, "wb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s: %s", raw_path, strerror(errno));
+    bool ok = true;
+    auto put = [&](const void* p, size_t bytes) {
+        static const char zeros[8] = {0};
+        ok = ok && fwrite(p, 1, bytes, f) == bytes;
+        if (bytes % 8) ok = ok && fwrite(zeros, 1, 8 - bytes % 8, f) == 8 - bytes % 8;
+    };
+    uint64_t str_total = 0;
+    std::vector<uint32_t> lens;
+    for (const std::string& t : ex.terms) { lens.push_back((uint32_t)t.size()); str_total += t.size(); }
+    const uint32_t h32[4] = {(uint32_t)ex.terms.size(), (uint32_t)ex.ver.last_docid, (uint32_t)ex.ver.doccount, ex.has_positions ? 1u : 0u};
+    const uint64_t h64[5] = {ex.ver.total_doclen, ex.did.size(), ex.pos.size(), ex.ver.revision, str_total};
+    ok = fwrite("XGMRAW1", 1, 8, f) == 8 && fwrite(h32, 4, 4, f) == 4 && fwrite(h64, 8, 5, f) == 5;
+    put(ex.doclen.data(), ex.doclen.size() * 4);
+    put(ex.df.data(), ex.df.size() * 4);
+    put(ex.did.data(), ex.did.size() * 4);
+    put(ex.wdf.data(), ex.wdf.size() * 4);
+    if (ex.has_positions) {
+        put(ex.pos_off.data(), ex.pos_off.size() * 8);
+        put(ex.pos.data(), ex.pos.size() * 4);
+    }
+    put(lens.data(), lens.size() * 4);
+    for (const std::string& t : ex.terms) ok = ok && fwrite(t.data(), 1, t.size(), f) == t.size();
+    if (fclose(f) != 0 || !ok) return xgm_set_error(XGM_E_IO, "short write on %s", raw_path);
+    return XGM_OK;
+}
