@@ -450,7 +450,7 @@ struct BatchPlan {
     bool phrase, wide;
     bool and_only;      /* every query is a plain conjunction of >= 2 terms → xgm_and_kernel */
     bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
-    bool sided;         /* andw batch that holds AND_NOT queries */
+    int sided;          /* andw batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
 };
 
@@ -459,7 +459,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
-    bool andnot_ok = true;       /* every query: AND or AND_NOT whose required terms are plan positions [0, n_req) */
+    bool andnot_ok = true;       /* every query: AND, AND_NOT or AND_MAYBE whose required terms are plan positions [0, n_req) */
     static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
     if (no_and_kernel) bp->and_only = false;
     for (uint32_t i = 0; i < nq; ++i) {
@@ -471,8 +471,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         if (width == 2) bp->wide = true;
         if (dq[i].op != XGM_OP_AND || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE)) bp->and_only = false;
         if (dq[i].op != XGM_OP_OR) or_only = false;
-        if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_AND_NOT) || dq[i].n_terms < 2 || (dq[i].flags & XGM_QF_PHRASE) ||
-            dq[i].req_mask != (dq[i].n_req >= 32u ? 0xFFFFFFFFu : (1u << dq[i].n_req) - 1u) ||
+        if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_AND_NOT && dq[i].op != XGM_OP_AND_MAYBE) || dq[i].n_terms < 2 ||
+            (dq[i].flags & XGM_QF_PHRASE) || dq[i].req_mask != (dq[i].n_req >= 32u ? 0xFFFFFFFFu : (1u << dq[i].n_req) - 1u) ||
+            (dq[i].op != XGM_OP_AND && dq[i].n_terms > 8u) ||                       /* the wave kernel sums <= 8 leaves in registers */
             (dq[i].op == XGM_OP_AND_NOT && (dq[i].req_mask | dq[i].neg_mask) != (1u << dq[i].n_terms) - 1u))
             andnot_ok = false;
         if ((dq[i].op != XGM_OP_AND && dq[i].op != XGM_OP_PHRASE) || dq[i].n_terms < 2) conj_only = false;
@@ -495,9 +496,12 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     static const bool no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr;           /* A/B switch for measurements */
     const bool phrase_conj = conj_only && bp->phrase && !no_phrase_w && !no_and_kernel;
     if (no_and_kernel) andnot_ok = false;
-    bp->sided = andnot_ok && !bp->and_only;
+    if (!bp->and_only && bp->tab_terms > 8u) andnot_ok = false;      /* a SIDED launch sums every query's leaves in 8 registers */
+    bool any_maybe = false;
+    for (uint32_t i = 0; i < nq; ++i) any_maybe = any_maybe || dq[i].op == XGM_OP_AND_MAYBE;
+    bp->sided = (andnot_ok && !bp->and_only) ? (any_maybe ? 2 : 1) : 0;
     bp->andw = (bp->and_only || andnot_ok || phrase_conj) && !no_andw && bp->k_max <= 192u && (uint64_t)((n_stripes + 31u) / 32u) * k_pad <= XGM_MERGE_CAP &&
-               xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, 32u, bp->phrase) <= 160u * 1024u;
+               xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, 32u, bp->phrase, bp->sided == 2) <= 160u * 1024u;
     /* disjunctions: one wave per unit as well; a unit spans as many stripes as the merge capacity
      * (units x k candidates per query) requires */
     uint32_t orw_spg = 32u;
@@ -585,7 +589,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
     for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
-    const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase)
+    const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase, bp->sided == 2)
                         : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
@@ -646,7 +650,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
-    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw && bp.sided;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (idx->profiling) {

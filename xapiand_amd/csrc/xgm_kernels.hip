@@ -952,7 +952,7 @@ constexpr uint32_t kAndwCandPhrase = 256;            /* with the 4-byte position
 #define XGM_ANDW_WAVES 4           /* min waves per SIMD the register allocator must allow */
 #endif                  /* top-k buffer cap 256 */
 
-__host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg, bool phrase) {
+__host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg, bool phrase, bool sided) {
     const uint32_t kAndwCand = phrase ? kAndwCandPhrase : kAndwCandPlain;
     size_t off = 0;
     off += (size_t)cap * 8;                                    /* tk_w */
@@ -964,8 +964,33 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
     off += (size_t)kAndwCand * 2;                              /* c_slot */
     off += (size_t)T * kAndwCand * tab_elem;                   /* c_w */
     off += phrase ? (size_t)T * kAndwCand * 4 : 0;             /* c_pos: position-list offset per candidate and term */
+    off += sided ? (size_t)cap : 0;                            /* tk_m: weighted subqueries matched, per top-k entry */
     return (off + 15) & ~(size_t)15;
 }
+
+/* the same with a byte of payload per entry (weighted subqueries matched) */
+__device__ void wave_topk_sort_m(uint64_t* w, uint32_t* d, uint8_t* m, uint32_t cap, uint32_t lane) {
+    for (uint32_t size = 2; size <= cap; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            wave_lds_fence();
+            for (uint32_t i = lane; i < (cap >> 1); i += 64u) {
+                const uint32_t lo = 2u * i - (i & (stride - 1u)), hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const uint64_t aw = w[lo], bw = w[hi];
+                const uint32_t ad = d[lo], bd = d[hi];
+                const bool swap = asc ? cand_before(bw, bd, aw, ad) : cand_before(aw, ad, bw, bd);
+                if (swap) {
+                    w[lo] = bw; w[hi] = aw; d[lo] = bd; d[hi] = ad;
+                    const uint8_t am = m[lo], bm = m[hi];
+                    m[lo] = bm; m[hi] = am;
+                }
+            }
+        }
+    }
+    wave_lds_fence();
+}
+
+typedef double andw_d8 __attribute__((ext_vector_type(8)));
 
 /* bitonic sort of cap (power of two, >= 128) candidates by one wave; best first */
 __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t lane) {
@@ -985,9 +1010,10 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
     wave_lds_fence();
 }
 
-/* SIDED: the batch holds AND_NOT queries (excluded terms after the required ones); a separate instantiation,
- * so that the plain conjunction pays nothing for it. */
-template <typename TabT, bool PHRASE, bool SIDED>
+/* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
+ * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
+ * instantiations, so that the plain conjunction pays nothing for them. */
+template <typename TabT, bool PHRASE, int SIDED>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -1002,13 +1028,14 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     const xgm_dev_query& q = queries[wk.qi];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k, SPG = spg_max;
-    /* plan positions [0, TR) must index a document; [TR, T) — the right-hand side of an AND_NOT — must not
-     * (AndNotPostList).  A plain conjunction / FILTER has TR == T. */
+    /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not
+     * index it: AndNotPostList) or of an AND_MAYBE (add their weight where they do: AndMaybePostList).  A plain
+     * conjunction / FILTER has TR == T. */
     const uint32_t TR = SIDED ? q.n_req : T;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
 
     /* private LDS slice */
-    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE);
+    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2);
     size_t off = 0;
     uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
     uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
@@ -1020,13 +1047,25 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)CAND * 2;
     TabT* c_w = reinterpret_cast<TabT*>(base + off); off += (size_t)tab_terms * CAND * sizeof(TabT);
     uint32_t* c_pos = reinterpret_cast<uint32_t*>(base + off);     /* PHRASE only */
+    constexpr bool MAYBE = SIDED == 2;
+    uint8_t* tk_m = reinterpret_cast<uint8_t*>(base + off);        /* MAYBE only (never with PHRASE) */
+    /* SIDED: the in-place summation program (<= 8 terms) in scalar registers */
+    uint64_t prog_a = 0, prog_b = 0;
+    uint32_t prog_root = 0;
+    if (MAYBE) {
+        const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
+        const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
+        prog_a = ((uint64_t)__builtin_amdgcn_readfirstlane(ipa32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipa32[0]);
+        prog_b = ((uint64_t)__builtin_amdgcn_readfirstlane(ipb32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipb32[0]);
+        prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
+    }
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
     const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
     const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
 
-    for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; if (MAYBE) tk_m[i] = 0; }
     for (uint32_t i = lane; i < 2u * tab_terms * SPG; i += 64u) rs[i] = 0;        /* rs and re are adjacent */
     for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
     for (uint32_t i = lane; i < T * CAND; i += 64u) c_w[i] = 0;
@@ -1071,7 +1110,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     uint32_t td = (uint32_t)__popcll(__ballot(lane < TR && dense_reg == 0xFFFFFFFFu));
     /* excluded terms without containers are block-decoded against the candidates' bitmap (P3c), which only
      * the decode path builds */
-    const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;
+    const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;   /* right-hand terms without containers */
     if (td == 0 && (TR > 4u || sparse_neg)) td = 1;
 
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
@@ -1157,20 +1196,20 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
             if (tkn + 64u > cap) {
-                wave_topk_sort(tk_w, tk_d, cap, lane);
+                if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
                 tkn = tkn < k ? tkn : k;
                 if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
-                for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; }
+                for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; if (MAYBE) tk_m[i] = 0; }
                 wave_lds_fence();
             }
             const uint32_t o = i0 + lane;
             bool take = false;
             uint64_t wb = 0;
-            uint32_t did = 0;
+            uint32_t did = 0, subqs = 0;
             if (o < n_c) {
                 bool pass = true;
                 for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
-                for (uint32_t t = TR; t < T; ++t) pass = pass && c_w[(size_t)t * CAND + o] == 0;      /* AND_NOT */
+                for (uint32_t t = TR; t < T; ++t) pass = pass && (!((q.neg_mask >> t) & 1u) || c_w[(size_t)t * CAND + o] == 0);   /* AND_NOT */
                 if (PHRASE && phrase && pass) {
                     /* K6: ExactPhrasePostList / PhrasePostList::test_doc over the terms' position lists */
                     PosList pl[XGM_PHRASE_MAX_TERMS];
@@ -1198,10 +1237,34 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                     normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
                     const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
                     double weight = 0.0;                       /* MultiAndPostList::get_weight: ((0 + w0) + w1) + ... */
-                    for (uint32_t t = 0; t < TR; ++t) {
-                        const double wdf = (double)((uint32_t)c_w[(size_t)t * CAND + o] - 1u);
-                        const double denom = denom_len + wdf;
-                        weight = weight + q.termweight[t] * (wdf / denom);
+                    if (MAYBE && q.op == XGM_OP_AND_MAYBE) {
+                        /* leaves in registers, summed by the query's in-place program: the chain of the required
+                         * terms, plus — AND_MAYBE — the OR tree of the optional ones (absent leaf = -0.0) */
+                        andw_d8 v;
+#pragma unroll
+                        for (uint32_t t = 0; t < 8u; ++t) {
+                            double wt = -0.0;
+                            const uint32_t e = t < T ? (uint32_t)c_w[(size_t)t * CAND + o] : 0u;
+                            if (e) {
+                                const double wdf = (double)(e - 1u);
+                                wt = q.termweight[t] * (wdf / (denom_len + wdf));
+                                subqs += (q.score_mask >> t) & 1u;
+                            }
+                            v[t] = wt;
+                        }
+                        for (uint32_t j = 0; j < q.n_nodes; ++j) {
+                            const uint32_t a = (uint32_t)(prog_a >> (8u * j)) & 7u, b = (uint32_t)(prog_b >> (8u * j)) & 7u;
+                            const double x = v[a] + v[b];
+                            v[a] = x;
+                        }
+                        weight = v[prog_root & 7u];
+                    } else {
+                        subqs = (uint32_t)__popc(q.score_mask);
+                        for (uint32_t t = 0; t < TR; ++t) {
+                            const double wdf = (double)((uint32_t)c_w[(size_t)t * CAND + o] - 1u);
+                            const double denom = denom_len + wdf;
+                            weight = weight + q.termweight[t] * (wdf / denom);
+                        }
                     }
                     wb = (uint64_t)__double_as_longlong(weight);
                     take = !theta_valid || cand_before(wb, did, theta_w, theta_d);
@@ -1209,7 +1272,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * CAND + o] = 0;
             }
             const uint64_t tm = __ballot(take);
-            if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; }
+            if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; if (MAYBE) tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
         }
     };
@@ -1484,13 +1547,13 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     }
 
     /* ---- unit epilogue ---- */
-    wave_topk_sort(tk_w, tk_d, cap, lane);
+    if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
     for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
     const uint32_t n_out = tkn < k ? tkn : k;
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = lane; i < n_out; i += 64u) {
         xgm_cand c;
-        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = (uint32_t)__popc(q.score_mask);   /* weighted leaves: all match */
+        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = MAYBE ? (uint32_t)tk_m[i] : (uint32_t)__popc(q.score_mask);   /* plain: the weighted leaves all match */
         out[i] = c;
     }
     if (lane == 0) {
@@ -1802,11 +1865,11 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream) {
     return 0;
 }
 
-size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase) {
-    return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg, phrase);
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase, bool sided) {
+    return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg, phrase, sided);
 }
 
-template <typename TabT, bool PHRASE, bool SIDED>
+template <typename TabT, bool PHRASE, int SIDED>
 static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
     const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
     auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED>;
@@ -1818,11 +1881,12 @@ static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream
 }
 
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
-    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group, L.phrase);
+    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group, L.phrase, L.sided == 2);
     if (smem > 160u * 1024u) return xgm_launch_error("andw kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.phrase) return L.wide ? launch_andw_variant<uint16_t, true, false>(L, smem, stream) : launch_andw_variant<uint8_t, true, false>(L, smem, stream);
-    if (L.sided) return L.wide ? launch_andw_variant<uint16_t, false, true>(L, smem, stream) : launch_andw_variant<uint8_t, false, true>(L, smem, stream);
-    return L.wide ? launch_andw_variant<uint16_t, false, false>(L, smem, stream) : launch_andw_variant<uint8_t, false, false>(L, smem, stream);
+    if (L.phrase) return L.wide ? launch_andw_variant<uint16_t, true, 0>(L, smem, stream) : launch_andw_variant<uint8_t, true, 0>(L, smem, stream);
+    if (L.sided == 2) return L.wide ? launch_andw_variant<uint16_t, false, 2>(L, smem, stream) : launch_andw_variant<uint8_t, false, 2>(L, smem, stream);
+    if (L.sided == 1) return L.wide ? launch_andw_variant<uint16_t, false, 1>(L, smem, stream) : launch_andw_variant<uint8_t, false, 1>(L, smem, stream);
+    return L.wide ? launch_andw_variant<uint16_t, false, 0>(L, smem, stream) : launch_andw_variant<uint8_t, false, 0>(L, smem, stream);
 }
 
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,

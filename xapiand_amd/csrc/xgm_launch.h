@@ -16,7 +16,7 @@ struct xgm_match_launch {
     uint32_t cap;                     /* top-k buffer capacity, power of two >= k_max + XGM_WG    */
     uint32_t k_stride;                /* candidates reserved per (query, group)                   */
     bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
-    bool sided = false;               /* conjunction batch with AND_NOT queries (excluded terms)    */
+    int sided = 0;                    /* conjunction batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
     xgm_group_hdr* ghdr;              /* device, [n_work]                                         */
 };
@@ -28,7 +28,7 @@ size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap
 int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
 /* wave-autonomous variant: one wave per work unit, no workgroup barriers (first+maxitems <= 192);
  * L.phrase selects the instantiation with the positional filter (every term block-decoded) */
-size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase);
+size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase, bool sided);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
 /* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
