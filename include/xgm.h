@@ -60,6 +60,7 @@ extern "C" {
 #define XGM_OP_FILTER 6
 
 typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
+#define XGM_DEVICE_NONE (-1)
 
 /* ---- raw postings: what the exporter hands to the segment builder -----------------------------
  * Produced by walking Xapian's public iterators over a glass shard (Database::allterms_begin /
@@ -119,7 +120,9 @@ int64_t xgm_segment_decode_term(const char* segment_path, const char* term, size
 /* ---- index lifetime ---------------------------------------------------------------------------*/
 
 /* Load a segment file into HBM on `device`.  `revision` must equal the segment's revision unless it
- * is UINT64_MAX (don't care).  Replaces: opening GlassPostList cursors per query
+ * is UINT64_MAX (don't care).  device == XGM_DEVICE_NONE loads the dictionary and statistics only
+ * (host memory): xgm_lookup_term / xgm_index_termfreqs / xgm_plan_query work — a front end can plan
+ * where no GPU is — and every search returns XGM_E_NO_DEVICE.  Replaces: opening GlassPostList cursors per query
  * (reference src/xapian/backends/glass/glass_database.cc:861-877, glass_postlist.cc:696-747). */
 int xgm_index_open(const char* segment_path, int device, uint64_t revision, xgm_index** out);
 

@@ -1,0 +1,89 @@
+"""CPU-only: the host side of the path — xgm_plan_query (reference: BM25Weight::init, MultiAndPostList leaf
+order, OrContext's Huffman tree, Enquire::get_mset's clamping, get_maxpart summation) — on a HOST-ONLY index
+(xgm_index_open with XGM_DEVICE_NONE: dictionary and statistics, no HBM).  Every plan's max_possible must equal,
+bit for bit, what the REAL reference reported in the committed golden fixtures; the planned leaf order and
+summation program must be what the oracle restates; and a search on such an index must fail loudly."""
+import json
+import os
+
+import pytest
+
+import helpers as H
+from xapiand_amd import Database, Query, _lib
+from xapiand_amd.enquire import merged_stats, plan, search_batch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def host_env(built, tmp_path_factory):
+    d = tmp_path_factory.mktemp("planner")
+    c1 = H.Corpus(10000, 1000000)
+    db1 = Database(c1.build_segment(str(d / "c1.seg")), device=_lib.XGM_DEVICE_NONE)
+    shards = [H.Corpus(10000, 1000000, n_shards=4, shard=s) for s in range(4)]
+    dbs = [Database(c.build_segment(str(d / ("s%d.seg" % s))), device=_lib.XGM_DEVICE_NONE) for s, c in enumerate(shards)]
+    yield c1, db1, shards, dbs
+    db1.close()
+    for x in dbs:
+        x.close()
+
+
+def q_of(q):
+    return Query(q["op"], q["terms"], window=q.get("window", 0), n_required=q.get("n_required", 0))
+
+
+@pytest.mark.parametrize("name", ["c1_and3_top10", "or5_top100", "and_paging", "phrase_full", "sided_top10"])
+def test_max_possible_matches_reference(host_env, name):
+    _, db1, _, _ = host_env
+    fx = json.load(open(os.path.join(GOLDEN_DIR, name + ".json")))
+    for r in fx["results"]:
+        q = r["query"]
+        p = plan(db1, q_of(q), q["first"], min(q["maxitems"], 1000))      # (max_possible does not depend on maxitems)
+        assert p.max_possible == float.fromhex(r["max_possible"]), q
+
+
+def test_sharded_plans_use_merged_statistics(host_env):
+    """Per-shard plans with the merged statistics: the reference's merged MSet reports the max over the shards."""
+    _, _, _, dbs = host_env
+    fx = json.load(open(os.path.join(GOLDEN_DIR, "sharded4_and3_top10.json")))
+    for r in fx["results"]:
+        q = r["query"]
+        gs = merged_stats(dbs, q_of(q))
+        mp = max(plan(db, q_of(q), 0, q["first"] + q["maxitems"], global_stats=gs).max_possible for db in dbs)
+        assert mp == float.fromhex(r["max_possible"]), q
+
+
+def test_plan_shapes(host_env):
+    c1, db1, _, _ = host_env
+    # AND: leaves in ascending shard-local termfreq (MultiAndPostList), left-deep chain
+    p = plan(db1, Query("AND", ["t3", "t200", "t17"]), 0, 10)
+    tfs = [c1.termfreq(t) for t in ("t3", "t200", "t17")]
+    order = [p.terms[i].phrase_index for i in range(3)]
+    assert [tfs[i] for i in order] == sorted(tfs)
+    assert list(p.sum_prog[:p.sum_len]) == [0, 1, -1, 2, -1]
+    assert p.req_mask == 0b111 and p.neg_mask == 0
+    # OR: query order, a full binary tree over the 4 leaves
+    p = plan(db1, Query("OR", ["t3", "t200", "t17", "t9"]), 0, 10)
+    assert [p.terms[i].phrase_index for i in range(4)] == [0, 1, 2, 3] and p.sum_len == 7 and p.req_mask == 0
+    # AND_NOT: required terms first (by termfreq), excluded ones after; only the left side is summed
+    p = plan(db1, Query("AND_NOT", ["t200", "t3", "t17"], n_required=2), 0, 10)
+    assert p.req_mask == 0b011 and p.neg_mask == 0b100 and list(p.sum_prog[:p.sum_len]) == [0, 1, -1]
+    # AND_MAYBE: chain + OR tree of the optional terms
+    p = plan(db1, Query("AND_MAYBE", ["t200", "t3", "t17"], n_required=1), 0, 10)
+    assert p.req_mask == 0b001 and p.neg_mask == 0 and p.sum_len == 5
+    # FILTER: a conjunction whose right-hand leaves weigh nothing, merged in by termfreq
+    p = plan(db1, Query("FILTER", ["t200", "t3"], n_required=1), 0, 10)
+    assert p.req_mask == 0b11 and sorted(p.terms[i].termweight == 0.0 for i in range(2)) == [False, True]
+    # declined shapes: repeated term, phrase of more than 3 terms, first + maxitems beyond the device top-k
+    for bad, first, k in ((Query("AND", ["t3", "t3"]), 0, 10), (Query("PHRASE", ["t1", "t2", "t3", "t4"]), 0, 10),
+                          (Query("AND", ["t3", "t17"]), 1000, 100)):
+        with pytest.raises(_lib.XgmUnsupported):
+            plan(db1, bad, first, k)
+
+
+def test_host_only_index_cannot_search(host_env):
+    _, db1, _, _ = host_env
+    p = plan(db1, Query("AND", ["t3", "t17"]), 0, 10)
+    with pytest.raises(_lib.XgmError) as e:
+        search_batch(db1, [p])
+    assert e.value.code == _lib.XGM_E_NO_DEVICE

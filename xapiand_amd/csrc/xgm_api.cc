@@ -209,6 +209,16 @@ extern "C" int xgm_index_open(const char* segment_path, int device, uint64_t rev
         return xgm_set_error(XGM_E_REVISION, "segment revision %llu != requested %llu", (unsigned long long)h->revision,
                              (unsigned long long)revision);
     if (h->n_blocks >= 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "segment has too many blocks");
+    if (device == XGM_DEVICE_NONE) {
+        /* dictionary and statistics only: lookups and query planning work, every search fails with
+         * XGM_E_NO_DEVICE (there is no CPU search path) */
+        xgm_index* hidx = new xgm_index();
+        hidx->device = XGM_DEVICE_NONE;
+        hidx->hdr = *h;
+        adopt_host_dictionary(hidx, blob);
+        *out = hidx;
+        return XGM_OK;
+    }
     rc = use_device(device);
     if (rc) return rc;
     xgm_index* idx = new xgm_index();
@@ -229,6 +239,7 @@ extern "C" int xgm_index_open(const char* segment_path, int device, uint64_t rev
 
 extern "C" void xgm_index_close(xgm_index* idx) {
     if (!idx) return;
+    if (idx->device == XGM_DEVICE_NONE) { delete idx; return; }
     hipSetDevice(idx->device);
     hipDeviceSynchronize();
     for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
