@@ -46,3 +46,20 @@ def test_search_fails_loudly_without_device(built, tmp_path):
     rc = _lib.lib().xgm_index_open(seg.encode(), 0, _lib.UINT64_MAX, C.byref(h))
     assert rc == _lib.XGM_E_NO_DEVICE          # no CPU fallback
     assert b"HIP" in _lib.lib().xgm_last_error()
+
+
+def test_header_is_plain_c_and_the_example_links(built, tmp_path):
+    """include/xgm.h must be a C header (the drop-in boundary is `extern "C"`, plain pointers and sizes):
+    examples/xgm_search.c is compiled as pedantic C99 and linked against libxgm.so."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    src = os.path.join(ROOT, "examples", "xgm_search.c")
+    exe = str(tmp_path / "xgm_search")
+    libdir = os.path.join(ROOT, "xapiand_amd", "csrc")
+    subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), src,
+                    "-L", libdir, "-lxgm", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
