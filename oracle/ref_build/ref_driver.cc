@@ -19,8 +19,9 @@
  *   time   <queries.txt> <n_threads> <repeat> <dbdir> [<dbdir> ...]
  *          Time get_mset per query (steady_clock; Enquire construction and set_query excluded,
  *          prepare_mset included — BASELINE.md §3).  Prints one JSON line.
- *   build_misc <dbdir>
- *          A small database with the corner cases of the on-disk format (see cmd_build_misc).
+ *   build_misc <dbdir> [empty|nopos]
+ *          A small database with the corner cases of the on-disk format (see cmd_build_misc); "empty": no
+ *          documents at all, "nopos": documents indexed without positions.
  *   export <dbdir> <out.raw>
  *          Walk the public iterators (allterms_begin / postlist_begin / positionlist_begin /
  *          get_doclength) and write the raw-postings file that the segment
@@ -183,6 +184,22 @@ int cmd_build(int argc, char** argv) {
 int cmd_build_misc(int argc, char** argv) {
     if (argc < 3) return 2;
     Xapian::WritableDatabase db(argv[2], Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
+    const std::string variant = argc > 3 ? argv[3] : "";
+    if (variant == "empty") {                                   /* committed, but no document ever added */
+        db.commit();
+        printf("{\"doccount\": 0, \"lastdocid\": 0}\n");
+        return 0;
+    }
+    if (variant == "nopos") {                                   /* no positional information anywhere */
+        for (unsigned i = 1; i <= 500; ++i) {
+            Xapian::Document doc;
+            for (unsigned j = 0; j < 5 + i % 7; ++j) doc.add_term("n" + std::to_string((i + j * 3) % 40), 1 + j % 3);
+            db.add_document(doc);
+        }
+        db.commit();
+        printf("{\"doccount\": %u, \"lastdocid\": %u}\n", db.get_doccount(), db.get_lastdocid());
+        return 0;
+    }
     auto make = [](unsigned i) {
         Xapian::Document doc;
         unsigned pos = 1;

@@ -37,6 +37,15 @@ def test_native_reader_format_corners(built, tmp_path):
     assert a == b
 
 
+@pytest.mark.parametrize("variant", ["empty", "nopos"])
+def test_native_reader_degenerate_databases(built, tmp_path, variant):
+    """A committed database without documents, and one without any positional information."""
+    db = str(tmp_path / variant)
+    H.xapian_ref("build_misc", db, variant)
+    a, b = both_exports(tmp_path, db)
+    assert a == b
+
+
 def test_native_reader_rejects_garbage(built, tmp_path):
     d = tmp_path / "notglass"
     d.mkdir()
