@@ -108,6 +108,12 @@ int xgm_segment_build_from_file(const char* raw_path, uint32_t stripe_bits, cons
  * not be modified while it is read (hold Xapiand's shard lock, or export a checked-in revision). */
 int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stripe_bits, const char* out_path);
 
+/* The committed revision and statistics of a glass shard, from its version file alone (what
+ * Database::get_revision / get_doccount / get_lastdocid / get_total_length would answer): the key under
+ * which an exported segment is cached, cheap enough to poll.  Any output pointer may be NULL. */
+int xgm_glass_info(const char* glass_dir, uint64_t* revision, uint32_t* doccount, uint32_t* lastdocid,
+                   uint64_t* total_length);
+
 /* Same reader, writing the "XGMRAW1" file form (what the iterator-based exporter produces): used to
  * verify the reader byte for byte against an export made through Xapian's public iterators. */
 int xgm_glass_export_raw(const char* glass_dir, const char* raw_path);

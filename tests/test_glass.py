@@ -1,6 +1,8 @@
 """CPU-only: the native glass reader (xapiand_amd/csrc/xgm_glass.cc — postlist / position B-trees read
 straight from the reference's on-disk format) must produce, byte for byte, what the export through the
 REAL reference's public iterators produces (oracle/_ref/xapian_ref export), and the same device segment."""
+import os
+
 import pytest
 
 import helpers as H
@@ -26,6 +28,25 @@ def test_native_reader_matches_iterator_export(built, tmp_path):
     _lib.check(_lib.lib().xgm_segment_build_from_file(str(tmp_path / "iter.raw").encode(), 0, seg_a.encode()))
     _lib.check(_lib.lib().xgm_segment_build_from_glass(db.encode(), 0, seg_b.encode()))
     assert open(seg_a, "rb").read() == open(seg_b, "rb").read()
+
+
+def test_glass_info_and_export_cli(built, tmp_path):
+    """xgm_glass_info reads what the reference reports for the shard, and the command-line exporter writes a
+    segment carrying that revision."""
+    import ctypes as C
+    import json
+    import subprocess
+    import sys
+    db = str(tmp_path / "db")
+    ref = json.loads(H.xapian_ref("build", db, H.CORPUS_SEED, 700, 5000, 50, 150))
+    rev, dc, ld, tl = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+    _lib.check(_lib.lib().xgm_glass_info(db.encode(), C.byref(rev), C.byref(dc), C.byref(ld), C.byref(tl)))
+    assert (dc.value, ld.value, tl.value) == (ref["doccount"], ref["lastdocid"], ref["total_length"])
+    seg = str(tmp_path / "cli.seg")
+    r = subprocess.run([sys.executable, "-m", "xapiand_amd.export", db, seg], capture_output=True, text=True, cwd=H.ROOT)
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["revision"] == rev.value and out["doccount"] == ref["doccount"] and os.path.getsize(seg) == out["segment_bytes"]
 
 
 def test_native_reader_format_corners(built, tmp_path):

@@ -442,6 +442,18 @@ extern "C" int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stri
     return xgm_segment_build(&raw, stripe_bits, out_path);
 }
 
+extern "C" int xgm_glass_info(const char* glass_dir, uint64_t* revision, uint32_t* doccount, uint32_t* lastdocid, uint64_t* total_length) {
+    if (!glass_dir) return xgm_set_error(XGM_E_INVALID, "null argument");
+    GlassVersion v;
+    int rc = read_version(glass_dir, &v);
+    if (rc) return rc;
+    if (revision) *revision = v.revision;
+    if (doccount) *doccount = (uint32_t)v.doccount;
+    if (lastdocid) *lastdocid = (uint32_t)v.last_docid;
+    if (total_length) *total_length = v.total_doclen;
+    return XGM_OK;
+}
+
 extern "C" int xgm_glass_export_raw(const char* glass_dir, const char* raw_path) {
     if (!glass_dir || !raw_path) return xgm_set_error(XGM_E_INVALID, "null argument");
     Export ex;
