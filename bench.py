@@ -223,30 +223,25 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_all_cores(shim, sample, op, k, seconds):
-    """The same port on every host core at once (one thread per core, queries striped across threads, the
-    oracle index is read-only once warmed; ctypes releases the GIL inside the call): aggregate queries/s."""
-    import threading
+def cpu_all_cores(shim, sample, op, k, seconds, n_required=0):
+    """The same port on every host core at once: oracle/xgm_oracle.cc::xgo_search_many runs one C++ thread per
+    core (queries striped across threads, the index is read-only once every list is built): aggregate queries/s."""
     import helpers as H
     n_threads = max(1, os.cpu_count() or 1)
-    counts = [0] * n_threads
-    stop = time.perf_counter() + seconds
-
-    def worker(t):
-        i = t
-        while time.perf_counter() < stop:
-            H.oracle_search(shim, op, sample[i % len(sample)], 0, k)
-            counts[t] += 1
-            i += n_threads
-
-    t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    wall = time.perf_counter() - t0
-    return {"value": sum(counts) / wall, "unit": "queries/s", "cores": n_threads, "seconds": wall}
+    flat = [t.encode() for q in sample for t in q]
+    n_terms = (C.c_uint32 * len(sample))(*[len(q) for q in sample])
+    terms = (C.c_char_p * len(flat))(*flat)
+    lens = (C.c_uint32 * len(flat))(*[len(t) for t in flat])
+    done, wall = C.c_uint64(), C.c_double()
+    ol = H.olib()
+    ol.xgo_search_many.restype = C.c_int
+    ol.xgo_search_many.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
+                                   C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
+    opcode = H.OPS[op] | ((n_required or 1) << 8 if op in H.SIDED else 0)
+    rc = ol.xgo_search_many(shim.oracle_index(), opcode, len(sample), n_terms, terms, lens, 0, k, n_threads, float(seconds),
+                            C.byref(done), C.byref(wall))
+    assert rc == 0
+    return {"value": done.value / wall.value, "unit": "queries/s", "cores": n_threads, "seconds": wall.value}
 
 
 def cpu_baseline(db, term_lists, args, k, timed_plans):
@@ -291,6 +286,7 @@ def cpu_baseline(db, term_lists, args, k, timed_plans):
         def oracle_index(self):
             return oidx
     shim = Shim()
+    n_required = args.required if args.op in H.SIDED else 0
     done, spent, checked, passes = 0, 0.0, 0, 0
     one_hits = (_lib.Hit * k)()
     one_hdr = _lib.ResultHdr()
@@ -298,7 +294,7 @@ def cpu_baseline(db, term_lists, args, k, timed_plans):
     while spent < args.cpu_seconds and passes < 50:
         for qi, q in enumerate(sample):
             a = time.perf_counter()
-            hits, _ = H.oracle_search(shim, args.op, q, 0, k)
+            hits, _ = H.oracle_search(shim, args.op, q, 0, k, n_required=n_required)
             dt = time.perf_counter() - a
             spent += dt
             lat.append(dt)
@@ -309,7 +305,7 @@ def cpu_baseline(db, term_lists, args, k, timed_plans):
                 assert got == [(d, w) for d, w, _ in hits], "GPU/CPU parity failure on bench query %d" % qi
                 checked += 1
         passes += 1
-    many = cpu_all_cores(shim, sample, args.op, k, min(5.0, args.cpu_seconds))
+    many = cpu_all_cores(shim, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
     ol.xgo_index_free(oidx)
     lat.sort()
     return {"value": done / spent, "unit": "queries/s", "cores": 1, "kind": "port", "all_cores": many,

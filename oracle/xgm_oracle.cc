@@ -35,6 +35,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../tools/xgm_corpus.h"
@@ -747,6 +748,46 @@ int xgo_search(void* ixv, uint32_t op, uint32_t n_terms, const char* const* term
     hdr->n_hits = (uint32_t)r.hits.size(); hdr->max_subqs = r.max_subqs; hdr->matches = r.matches;
     hdr->max_attained = r.max_attained; hdr->max_possible = r.max_possible;
     for (size_t i = 0; i < r.hits.size(); ++i) { hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight; }
+    return 0;
+}
+
+/* Throughput of the port on several host threads at once (bench.py's cpu_baseline.all_cores): thread t answers
+ * queries t, t + n_threads, ... of the list, round and round, until `seconds` have passed.  The index is
+ * read-only once every term's list is built, which is done here first (index-build work, not timed).
+ * terms / term_len are the queries' terms back to back; n_terms[q] says how many belong to query q. */
+int xgo_search_many(void* ixv, uint32_t op, uint32_t n_queries, const uint32_t* n_terms, const char* const* terms,
+                    const uint32_t* term_len, uint32_t first, uint32_t maxitems, uint32_t n_threads, double seconds,
+                    uint64_t* done_out, double* wall_out) {
+    Index* ix = (Index*)ixv;
+    if (!ix || n_queries == 0 || n_threads == 0) return -1;
+    std::vector<uint64_t> start(n_queries + 1, 0);
+    for (uint32_t q = 0; q < n_queries; ++q) start[q + 1] = start[q] + n_terms[q];
+    for (uint64_t i = 0; i < start[n_queries]; ++i) {
+        auto it = ix->dict.find(std::string(terms[i], term_len[i]));
+        if (it != ix->dict.end()) ix->list(it->second);
+    }
+    std::vector<uint64_t> counts(n_threads, 0);
+    std::vector<int> rcs(n_threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    const auto deadline = t0 + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(seconds));
+    std::vector<std::thread> threads;
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        threads.emplace_back([&, t]() {
+            for (uint64_t i = t; std::chrono::steady_clock::now() < deadline; i += n_threads) {
+                const uint32_t q = (uint32_t)(i % n_queries);
+                QueryIn in{op & 0xFFu, op >> 8, n_terms[q], terms + start[q], term_len + start[q], 0, first, maxitems, 0, 0, 0, 0, nullptr, 0};
+                Result r;
+                if (run_query(ix, in, &r)) { rcs[t] = -1; return; }
+                ++counts[t];
+            }
+        });
+    }
+    for (auto& th : threads) th.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    uint64_t done = 0;
+    for (uint32_t t = 0; t < n_threads; ++t) { if (rcs[t]) return rcs[t]; done += counts[t]; }
+    *done_out = done;
+    *wall_out = wall;
     return 0;
 }
 
