@@ -930,6 +930,27 @@ extern "C" int xgm_debug_phase_cycles(unsigned long long* out8) { return xgm_pha
 int xgm_orw_cycles_fetch(unsigned long long* out8);
 extern "C" int xgm_debug_orw_phase_cycles(unsigned long long* out8) { return xgm_orw_cycles_fetch(out8); }
 
+/* Diagnostics (host only — works on an XGM_DEVICE_NONE index): the decomposition a batch would be launched with.
+ * kernel[32] receives the match kernel's name (and ":sided1" / ":sided2" / ":phrase" for the conjunction kernel's
+ * instantiation); units receives (qi, s_begin, s_end, slot) per work unit in launch order; returns the number of
+ * units (possibly > cap: only cap are written), or < 0 / XGM_UNSUPPORTED like a search would. */
+extern "C" int64_t xgm_debug_plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, char* kernel, uint32_t* units, uint64_t cap) {
+    if (!idx || !qs || !kernel || (!units && cap)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (nq == 0) return 0;
+    std::vector<xgm_dev_query> dq(nq);
+    std::vector<uint32_t> kq(nq);
+    std::vector<double> mp(nq);
+    BatchPlan bp;
+    int rc = plan_batch(idx, qs, nq, dq.data(), kq.data(), mp.data(), &bp);
+    if (rc) return rc;
+    snprintf(kernel, 32, "%s%s", bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel",
+             bp.andw && bp.phrase ? ":phrase" : bp.andw && bp.sided == 2 ? ":sided2" : bp.andw && bp.sided == 1 ? ":sided1" : "");
+    for (uint64_t i = 0; i < bp.work.size() && i < cap; ++i) {
+        units[4 * i] = bp.work[i].qi; units[4 * i + 1] = bp.work[i].s_begin; units[4 * i + 2] = bp.work[i].s_end; units[4 * i + 3] = bp.work[i].slot;
+    }
+    return (int64_t)bp.work.size();
+}
+
 /* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end, matches, documents weighed)
  * of the LAST batch launched on this index from any thread; out is u64[8 * cap]; returns the number
  * of units. */
