@@ -19,6 +19,8 @@
  *          the top-k set or the weights, only how many documents get scored)
  *   - PHRASE: ExactPhrasePostList / PhrasePostList:    matcher/exactphrasepostlist.cc:75-133,
  *                                                      matcher/phrasepostlist.cc:60-90
+ *   - AND_NOT / AND_MAYBE / FILTER (left AND of terms, right terms): api/queryinternal.cc:2208-2283,
+ *                                                      matcher/andmaybepostlist.cc:57-64, andnotpostlist.cc
  *   - top-k: ProtoMSet::add min-heap + final sort:      matcher/protomset.h:340-400, 657;
  *                                                      order matcher/msetcmp.cc:55-62
  *   - multi-shard protocol: merged stats, unshard, merge: api/enquire.cc:385-394, backends/multi.h:69-73,
