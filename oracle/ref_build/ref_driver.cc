@@ -27,8 +27,8 @@
  *          get_doclength) and write the raw-postings file that the segment
  *          builder consumes (format: include/xgm.h "raw postings").
  *
- * Query file: one query per line  "<AND|OR|PHRASE> <first> <maxitems> <window> term term ..."
- * (window is only used by PHRASE; 0 means "number of terms" = exact phrase), or
+ * Query file: one query per line  "<AND|OR|PHRASE|NEAR> <first> <maxitems> <window> term term ..."
+ * (window is only used by PHRASE / NEAR; 0 means "number of terms" = exact phrase), or
  * "<AND_NOT|AND_MAYBE|FILTER>:<n_required> <first> <maxitems> 0 term term ..." where the first n_required
  * terms form the left-hand AND and the rest the right-hand side.
  * Output: "Q <idx> <n_hits> <matches_lower> <matches_est> <matches_upper> <max_possible %a> <max_attained %a>"
@@ -91,6 +91,13 @@ Xapian::Query make_query(const QuerySpec& q) {
         for (auto& t : q.terms) psubs.emplace_back(t, 1, pos++);
         unsigned window = q.window ? q.window : (unsigned)q.terms.size();
         return Xapian::Query(Xapian::Query::OP_PHRASE, psubs.begin(), psubs.end(), window);
+    }
+    if (q.op == "NEAR") {
+        std::vector<Xapian::Query> psubs;
+        unsigned pos = 1;
+        for (auto& t : q.terms) psubs.emplace_back(t, 1, pos++);
+        unsigned window = q.window ? q.window : (unsigned)q.terms.size();
+        return Xapian::Query(Xapian::Query::OP_NEAR, psubs.begin(), psubs.end(), window);
     }
     if (q.op == "AND_NOT" || q.op == "AND_MAYBE" || q.op == "FILTER") {
         /* left: the AND of the first n_required terms (a bare term when it is one); right: the other terms —

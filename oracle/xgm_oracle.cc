@@ -344,7 +344,7 @@ struct ProtoMSet {
 /* ----------------------------------------------------------------------------- query ----------- */
 
 struct QueryIn {
-    uint32_t op;                 /* 1 AND, 2 OR, 3 PHRASE, 4 AND_NOT, 5 AND_MAYBE, 6 FILTER */
+    uint32_t op;                 /* 1 AND, 2 OR, 3 PHRASE, 4 AND_NOT, 5 AND_MAYBE, 6 FILTER, 7 NEAR (oracle only so far) */
     uint32_t n_required;         /* ops 4-6: the first n_required terms are the left-hand AND, the others the right-hand side */
     uint32_t n_terms;
     const char* const* terms; const uint32_t* term_len;
@@ -433,6 +433,22 @@ bool window_phrase(std::vector<PosCursor>& pl, uint32_t window) {
     return false;
 }
 
+/* NearPostList::test_doc (matcher/nearpostlist.cc:60-160) for DISTINCT terms: one position of every term inside a
+ * span shorter than `window`, in any order.  The reference keeps the lists' heads in a heap and advances the
+ * smallest one past (largest - window); with distinct terms no two heads can coincide, so its duplicate-position
+ * handling never engages and the test is exactly "max(head) - min(head) < window for some alignment". */
+bool near_window(std::vector<PosCursor>& pl, uint32_t window) {
+    const size_t n = pl.size();
+    for (size_t i = 0; i < n; ++i) if (!pl[i].next()) return false;
+    while (true) {
+        size_t lo = 0;
+        uint32_t hi = pl[0].get();
+        for (size_t i = 1; i < n; ++i) { if (pl[i].get() < pl[lo].get()) lo = i; if (pl[i].get() > hi) hi = pl[i].get(); }
+        if (hi - pl[lo].get() < window) return true;
+        if (!pl[lo].skip_to(hi - window + 1)) return false;
+    }
+}
+
 struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0; };
 
 int run_query(Index* ix, const QueryIn& q, Result* out) {
@@ -464,7 +480,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
         wt[i] = proto;
         wt[i].init(N, q.use_global ? q.g_termfreq[i] : tf_local[i], avg);
     }
-    bool phrase = q.op == 3 && n > 1 && full_pos;
+    bool phrase = (q.op == 3 || q.op == 7) && n > 1 && full_pos;     /* positional filter over the AND: PHRASE or NEAR */
     if (phrase && !ix->has_positions) { out->hits.clear(); return 0; }
     uint32_t window = q.window ? q.window : n;
 
@@ -662,7 +678,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
                     pl[i] = PosCursor{ix->pos + ix->pos_off[ord], (uint32_t)(ix->pos_off[ord + 1] - ix->pos_off[ord]), 0, false};
                     wdfs[i] = it[p].wdf;
                 }
-                ok = (window == n) ? exact_phrase(pl, wdfs) : window_phrase(pl, window);
+                ok = q.op == 7 ? near_window(pl, window) : (window == n) ? exact_phrase(pl, wdfs) : window_phrase(pl, window);
             }
             if (ok) {
                 if (cached_weight >= 0) {

@@ -15,7 +15,7 @@ XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
 
 CORPUS_SEED = 0x5EED0001
 QUERY_SEED = 0x5EED0002
-OPS = {"AND": 1, "OR": 2, "PHRASE": 3, "AND_NOT": 4, "AND_MAYBE": 5, "FILTER": 6}
+OPS = {"AND": 1, "OR": 2, "PHRASE": 3, "AND_NOT": 4, "AND_MAYBE": 5, "FILTER": 6, "NEAR": 7}   # NEAR: oracle only so far
 SIDED = ("AND_NOT", "AND_MAYBE", "FILTER")   # left = AND of the first n_required terms, right = the others
 
 
