@@ -2,24 +2,39 @@
 """Benchmark of the match/rank hot path (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
 
-Workload (N = 1, BASELINE.json configs[1], "C2"): 10 M-doc / 1 M-term Zipf synthetic index resident
-in HBM, 3-term conjunctive BM25 queries, top-10.  One "step" = one pass of the hot path over one
-batch of 256 planned queries (xgm_search_batch_device: decode → intersect → BM25 → top-k → merge).
-N > 1 is configs[3] scaled ("C4"): the corpus has 10 M × N documents sharded N ways exactly like the
-reference (global doc g → shard (g-1) % N, src/xapian/backends/multi.h:38-73), every rank searches
-its shard with the MERGED collection statistics, then one RCCL all-gather of the per-shard top-k
-records + a device-side merge (xgm_merge_shards_device).  Weak scaling: per-GPU work is fixed.
+N > 1 needs one process per GPU: when started as a plain `python bench.py --gpus N` the script re-executes
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (the form
+the driver uses directly), so both invocations work.
 
-Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (algorithmic bytes
-of the dominant kernel ÷ its HIP-event-measured duration vs 8 TB/s) and `cpu_baseline` (the CPU
-oracle port of the reference algorithm timed on a bounded sample of the same queries, N = 1 only).
+Workload (N = 1, BASELINE.json configs[1], "C2"): 10 M-doc / 1 M-term Zipf synthetic index resident in HBM,
+3-term conjunctive BM25 queries, top-10.  One "step" = one pass of the hot path over one batch of 256 queries
+AS THE MATCHER HOOK RECEIVES THEM (terms, operator, first/maxitems, BM25 parameters, merged statistics):
+xgm_get_mset_batch_device = dictionary lookups + BM25Weight::init + leaf ordering (xgm_plan_query) → decode →
+intersect → BM25 → top-k → merge.  N > 1 is configs[3] scaled ("C4"): the corpus has 10 M × N documents sharded
+N ways exactly like the reference (global doc g → shard (g-1) % N, src/xapian/backends/multi.h:38-73), every rank
+searches its shard with the MERGED collection statistics, then one RCCL all-gather of the per-shard top-k records
++ a device-side merge (xgm_merge_shards_device).  Weak scaling: per-GPU work is fixed.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` and `cpu_baseline`:
+
+roofline.achieved / frac  — bytes the dominant kernel MOVED per launch ÷ its HIP-event duration ÷ 8 TB/s.  The
+    bytes are the HBM traffic from the committed PMC passes (profiles/traffic.json, `basis: "pmc"`) when they exist
+    for this very workload, else the kernel's own request tallies at memory-sector granularity (`basis: "model"`,
+    measured live: xgm_last_batch_traffic).  roofline.algorithmic carries SURVEY §8(d)'s format-independent
+    figure (Σ df·8 + S·4 + P·4 + k·16 per query) ÷ the same duration: the probe containers answer "is d in t, with
+    which wdf" in one byte, so that figure can exceed what any kernel that READ those bytes could reach — it is a
+    speed-up over the posting-scan algorithm, not evidence of HBM efficiency, and is reported as such.
+cpu_baseline — the REAL reference (oracle/_ref/xapian_ref = the vendored Xapian's Enquire::get_mset) timed on this
+    box's host cores on a glass index of the same corpus built here with the reference's own WritableDatabase
+    (1/10 of the configuration's documents: indexing is the reference's bottleneck, see tools/ref_index.py), the
+    oracle port timed on the identical index (→ port_over_reference) and the port at the full 10 M documents.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,32 +42,44 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-from xapiand_amd import Database, Query, _lib  # noqa: E402
-from xapiand_amd.distributed import ShardedSearcher  # noqa: E402
-
 HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+SECTOR = 64                # bytes one random gather costs at the memory side (tools/fetch_calib.hip, profiles/)
 CORPUS_SEED = 0x5EED0001
 QUERY_SEED = 0x5EED0002
 BATCH = 256
 
 
-def gen_queries(n, n_terms, lo, hi, seed):
-    import math
-    import random
-    rng = random.Random(seed)
-    out = []
-    for _ in range(n):
-        ranks = set()
-        while len(ranks) < n_terms:
-            ranks.add(max(1, int(round(math.exp(rng.uniform(math.log(lo), math.log(hi)))))))
-        ranks = list(ranks)
-        rng.shuffle(ranks)
-        out.append(["t%d" % r for r in ranks])
-    return out
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    ap.add_argument("--op", default="AND")
+    ap.add_argument("--terms", type=int, default=3)
+    ap.add_argument("--required", type=int, default=1, help="AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND")
+    ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--stripe-bits", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--ref-docs", type=int, default=1_000_000, help="documents of the reference glass index built on this box (0: skip the reference leg)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
+    ap.add_argument("--threads", type=int, default=0, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight")
+    return ap.parse_args()
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks under torch.distributed.run."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def workload_name(args, world, n_docs_global, k):
@@ -66,28 +93,21 @@ def workload_name(args, world, n_docs_global, k):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
-    ap.add_argument("--vocab", type=int, default=1_000_000)
-    ap.add_argument("--op", default="AND")
-    ap.add_argument("--terms", type=int, default=3)
-    ap.add_argument("--required", type=int, default=1, help="AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND")
-    ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--stripe-bits", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
-    args = ap.parse_args()
+    args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import helpers as H        # query pool shared with tests/test_gpu_configs.py (PHRASE: the corpus restated in Python)
+    from xapiand_amd import Database, Query, _lib
+    from xapiand_amd.distributed import ShardedSearcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -102,42 +122,42 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     info = db.info()
-    # One explicit (non-null) HIP stream for searches and collectives: xgm_search_batch_device is then
-    # asynchronous, so the host plans batch i+1 while the GPU runs batch i (a null stream handle means
-    # "the library's own stream, synchronised before returning").
+    # One explicit (non-null) HIP stream for searches and collectives: the xgm_*_device calls are then asynchronous,
+    # so the host plans batch i+1 while the GPU runs batch i (ShardedSearcher binds the index to torch's current stream).
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
-    db.set_stream(stream.cuda_stream)
 
     # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards): one all-reduce ----
-    if args.op == "PHRASE":
-        # C5: 2-3-grams that occur in a random document (tests/helpers.py restates the corpus in Python)
-        import helpers as H
-        pool = [q["terms"] for q in H.gen_phrase_queries(1100, n_docs_global, args.vocab, seed=QUERY_SEED)]
-    else:
-        pool = gen_queries(1100, args.terms, 8, 4096, QUERY_SEED)
+    pool = H.bench_pool(args.op, args.terms, args.required, n_docs_global, args.vocab, seed=QUERY_SEED)
     k = args.topk
     searcher = ShardedSearcher(db, rank, world, dev)
     sided = args.op in ("AND_NOT", "AND_MAYBE", "FILTER")
-    plans = searcher.prepare([Query(args.op, terms, n_required=args.required if sided else 0) for terms in pool], 0, k)
-    warm_plans, timed_plans = plans[:100], plans[100:]
-    n_batches = len(timed_plans) // BATCH
-    batches = [(_lib.Query * BATCH)(*timed_plans[i * BATCH:(i + 1) * BATCH]) for i in range(n_batches)]
-    warm_batch = (_lib.Query * BATCH)(*(warm_plans * 3)[:BATCH])
+    qobjs = [Query(q["op"], q["terms"], n_required=args.required if sided else 0) for q in pool]
+    descs, gstats = searcher.describe(qobjs, 0, k)                 # what the hook is handed per get_mset
+    plans = searcher.prepare(qobjs, 0, k)                          # bookkeeping only (algorithmic bytes, parity leg)
     L = _lib.lib()
-    state = {}
+    n_timed = len(pool) - 100
+    n_batches = n_timed // BATCH
 
-    def step(batch):
-        # xgm_search_batch_device (+ RCCL all-gather of top-k + xgm_merge_shards_device when sharded)
-        state["hits"], state["hdrs"] = searcher.run_batch(batch, BATCH, k)
+    def batch_of(lo):
+        d = (_lib.QueryDesc * BATCH)(*[descs[(lo + i) % len(pool)] for i in range(BATCH)])
+        g = (_lib.GlobalStats * BATCH)(*[gstats[(lo + i) % len(pool)] for i in range(BATCH)])
+        return d, g
+    batches = [batch_of(100 + b * BATCH) for b in range(n_batches)]
+    warm = batch_of(0)
+    timed_plans = plans[100:]
+
+    def step(b):
+        # plan + search (+ RCCL all-gather of top-k + xgm_merge_shards_device when sharded)
+        return searcher.run_descs(b[0], b[1], BATCH, k)
 
     for _ in range(args.warmup):
-        step(warm_batch)
+        step(warm)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    db.set_profiling(True)
+    db.set_profiling(1)
     t0 = time.perf_counter()
     for s in range(args.steps):
         step(batches[s % n_batches])
@@ -148,51 +168,79 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed steps (HIP events)
     kernel_name = db.last_kernel_name()
-    db.set_profiling(False)
+    db.set_profiling(0)
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     qps = args.steps * BATCH / elapsed             # queries answered over the WHOLE (sharded) index per second
 
-    # ---- algorithmic bytes per launch: Σ_t df_t·8 + S·4 + k·16 per query ----------
-    alg_bytes = []
+    # ---- per-launch byte counts, outside the timed region ------------------------------------------------------
+    # algorithmic: Σ_t df_t·8 + S·4 + P·4 + k·16 per query; model: the kernel's own request tallies
+    db.set_profiling(2)                            # the tallying instantiation of the wave kernels
+    alg_bytes, model_sector, model_useful, tallies = [], [], [], []
     for b in range(n_batches):
         step(batches[b])
         torch.cuda.synchronize()
         h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
         matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in timed_plans[b * BATCH:(b + 1) * BATCH])
-        alg_bytes.append(post + int(matches.sum()) * 4 + BATCH * k * 16)
-    used = [alg_bytes[s % n_batches] for s in range(args.steps)]
-    bytes_per_launch = float(np.mean(used))
-    achieved = bytes_per_launch / (kernel_ms * 1e-3) if kernel_ms and kernel_ms > 0 else 0.0
+        tl = (C.c_uint64 * 10)()
+        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel")
+        bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
+        alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
+        if have_tally:
+            stream_b = 4 * bmpw + 4 * blkw + 12 * hdrs_ + 4 * aux + 16 * cands + 4 * npos
+            model_sector.append(stream_b + SECTOR * (probes + dls))
+            model_useful.append(stream_b + probes_raw + 4 * dls_raw)
+            tallies.append(dict(bitmap_words=bmpw, probe_sectors=probes, probes=probes_raw, payload_words=blkw, block_headers=hdrs_,
+                                doclen_sectors=dls, doclen_gathers=dls_raw, aux_words=aux, candidates_out=cands, positions=npos))
+    db.set_profiling(0)
+    used = [s % n_batches for s in range(args.steps)]
+    bytes_per_launch = float(np.mean([alg_bytes[i] for i in used]))
+    kt = kernel_ms * 1e-3 if kernel_ms and kernel_ms > 0 else None
+    alg_rate = bytes_per_launch / kt if kt else 0.0
+    model_bytes = float(np.mean([model_sector[i] for i in used])) if model_sector else None
+    useful_bytes = float(np.mean([model_useful[i] for i in used])) if model_useful else None
 
-    # ---- latency mode: one query in flight, host-timed around xgm_search (incl. H2D/D2H) -----------
+    # ---- planning cost (inside every timed step): host microseconds per query ------------------------------------
+    plan_us = L.xgm_debug_plan_us(db._h, batches[0][0], batches[0][1], BATCH, 20)
+
+    # ---- latency mode: one query in flight, host-timed around plan + search incl. H2D/D2H ---------------------
     lat = []
     if (rank == 0 or world > 1) and not args.no_latency:
         one_hits = (_lib.Hit * k)()
         one_hdr = _lib.ResultHdr()
         db.set_stream(0)
-        for i, p in enumerate(timed_plans[:1000]):        # 1 000 queries (the first 20 warm up)
+        for i in range(min(1000, n_timed)):                 # 1 000 queries (the first 20 warm up)
+            d1 = (_lib.QueryDesc * 1)(descs[100 + i])
+            g1 = (_lib.GlobalStats * 1)(gstats[100 + i])
             a = time.perf_counter()
-            _lib.check(L.xgm_search(db._h, C.byref(p), one_hits, C.byref(one_hdr)))
+            _lib.check(L.xgm_get_mset_batch(db._h, d1, g1, 1, k, one_hits, C.byref(one_hdr)))
             if i >= 20:
                 lat.append(time.perf_counter() - a)
     lat.sort()
 
+    # ---- server mode: T host threads, each with ONE query in flight (Xapiand's http_client_pool shape) ----------
+    server = None
+    if rank == 0 and world == 1 and args.threads > 0:
+        server = server_leg(db, descs, gstats, k, args.threads, n_timed)
+
     # ---- HBM traffic of the dominant kernel: from the committed PMC passes (tools/final.sh → profiles/traffic.json),
     # which cannot be collected from inside this process; only quoted when measured on this very workload
     traffic, traffic_note = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
-        for t in json.load(open(tpath)).get("entries", []):
-            if (t["kernel"] == kernel_name and t["op"] == args.op and t["docs_per_gpu"] == args.docs_per_gpu and t["top_k"] == k and
-                    t["terms"] == (args.terms if args.op != "PHRASE" else 0) and t["batch"] == BATCH):
-                traffic, traffic_note = t["hbm_bytes_per_launch"], t["note"]
+        for tr in json.load(open(tpath)).get("entries", []):
+            if (tr["kernel"] == kernel_name and tr["op"] == args.op and tr["docs_per_gpu"] == args.docs_per_gpu and tr["top_k"] == k and
+                    tr["terms"] == (args.terms if args.op != "PHRASE" else 0) and tr["batch"] == BATCH and tr.get("required", 1) == (args.required if sided else 1)):
+                traffic, traffic_note = tr["hbm_bytes_per_launch"], tr["note"]
 
     result = None
     if rank == 0:
+        basis = "pmc" if traffic else ("model" if model_bytes else "algorithmic")
+        moved = traffic if traffic else (model_bytes if model_bytes else bytes_per_launch)
+        achieved = moved / kt if kt else 0.0
         result = {
             "metric": "queries/sec + p50 latency, %dM-doc synthetic index, %s, top-%d" % (
                 args.docs_per_gpu // 1000000, {"AND": "%d-term AND" % args.terms, "OR": "%d-term OR" % args.terms,
@@ -203,17 +251,29 @@ def main():
             "config": {"workload": workload_name(args, world, n_docs_global, k),
                        "docs_per_gpu": args.docs_per_gpu, "docs_total": n_docs_global, "vocab": args.vocab, "op": args.op,
                        "terms_per_query": args.terms, "top_k": k, "batch": BATCH, "parallelism": "shard%d" % world,
-                       "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED)},
+                       "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED),
+                       "step": "xgm_get_mset_batch_device: plan (lookups, BM25 init, leaf order) + match + merge, 256 queries"},
             "p50_latency_us": lat[len(lat) // 2] * 1e6 if lat else None,
             "p99_latency_us": lat[int(len(lat) * 0.99)] * 1e6 if lat else None,
+            "plan_us_per_query": plan_us,
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,
-                      "device_bytes": info.device_bytes, "build_seconds": build_s},
+                      "device_bytes": info.device_bytes, "bytes_per_posting": info.device_bytes / max(1, info.n_postings),
+                      "build_seconds": build_s},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_note": traffic_note,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "kernel_ms": kernel_ms},
+                         "frac": achieved / HBM_PEAK, "basis": basis, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel_ms": kernel_ms,
+                         "model_min_bytes": model_bytes, "model_useful_bytes": useful_bytes,
+                         "model_frac": (model_bytes / kt / HBM_PEAK) if (model_bytes and kt) else None,
+                         "model_note": "requests tallied by the kernel itself (xgm_last_batch_traffic): streamed words at 4 B + %d B per DISTINCT "
+                                       "memory sector a round of one-byte container probes / doclen gathers touches" % SECTOR,
+                         "model_counts": tallies[0] if tallies else None,
+                         "algorithmic": {"bytes_per_launch": bytes_per_launch, "achieved": alg_rate / 1e9, "frac": alg_rate / HBM_PEAK,
+                                         "note": "SURVEY 8(d): sum df*8 + S*4 + P*4 + k*16 per query; not bytes this design reads"}},
         }
+        if server:
+            result["server_mode"] = server
 
-    # ---- CPU baseline: the oracle port of the reference algorithm on a bounded sample --------------
+    # ---- CPU baseline: the real reference + the oracle port, on this box's host cores -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(db, pool[100:], args, k, timed_plans)
     if rank == 0:
@@ -223,13 +283,64 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_all_cores(shim, sample, op, k, seconds, n_required=0):
-    """The same port on every host core at once: oracle/xgm_oracle.cc::xgo_search_many runs one C++ thread per
-    core (queries striped across threads, the index is read-only once every list is built): aggregate queries/s."""
+def server_leg(db, descs, gstats, k, n_threads, n_timed):
+    """T Python threads, each issuing xgm_get_mset_batch(nq = 1) back to back (ctypes releases the GIL for the call):
+    the shape of Xapiand's HTTP worker pool (reference src/manager.cc:161), without caller-side batching."""
+    import threading
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    db.set_stream(0)
+    per = max(8, min(200, n_timed // n_threads))
+    lats = [[] for _ in range(n_threads)]
+    start = threading.Barrier(n_threads + 1)
+
+    def worker(t):
+        hits = (_lib.Hit * k)()
+        hdr = _lib.ResultHdr()
+        qs = [((_lib.QueryDesc * 1)(descs[100 + (t * per + i) % n_timed]), (_lib.GlobalStats * 1)(gstats[100 + (t * per + i) % n_timed])) for i in range(per)]
+        start.wait()
+        for d1, g1 in qs:
+            a = time.perf_counter()
+            L.xgm_get_mset_batch(db._h, d1, g1, 1, k, hits, C.byref(hdr))
+            lats[t].append(time.perf_counter() - a)
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
+    for th in ths:
+        th.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for th in ths:
+        th.join()
+    wall = time.perf_counter() - t0
+    allv = sorted(x for l in lats for x in l)
+    return {"threads": n_threads, "queries": len(allv), "value": len(allv) / wall, "unit": "queries/s",
+            "p50_us": allv[len(allv) // 2] * 1e6, "p99_us": allv[int(len(allv) * 0.99)] * 1e6}
+
+
+def time_port(ora, sample, op, k, seconds, n_required, checker=None):
+    """oracle/xgm_oracle.cc (the reference algorithm restated) on 1 thread over `sample`, repeated for ~seconds."""
+    import helpers as H
+    done, spent, passes, lat = 0, 0.0, 0, []
+    while spent < seconds and passes < 50:
+        for qi, q in enumerate(sample):
+            a = time.perf_counter()
+            hits, _ = H.oracle_search(ora, op, q["terms"], 0, k, n_required=n_required)
+            dt = time.perf_counter() - a
+            spent += dt
+            lat.append(dt)
+            done += 1
+            if passes == 0 and checker:
+                checker(qi, hits)
+        passes += 1
+    lat.sort()
+    return dict(value=done / spent, unit="queries/s", cores=1, p50_ms=lat[len(lat) // 2] * 1e3, seconds=spent, passes=passes)
+
+
+def port_all_cores(ora, sample, op, k, seconds, n_required=0):
+    """The same port on every host core at once (oracle/xgm_oracle.cc::xgo_search_many, one C++ thread per core)."""
     import helpers as H
     n_threads = max(1, os.cpu_count() or 1)
-    flat = [t.encode() for q in sample for t in q]
-    n_terms = (C.c_uint32 * len(sample))(*[len(q) for q in sample])
+    flat = [t.encode() for q in sample for t in q["terms"]]
+    n_terms = (C.c_uint32 * len(sample))(*[len(q["terms"]) for q in sample])
     terms = (C.c_char_p * len(flat))(*flat)
     lens = (C.c_uint32 * len(flat))(*[len(t) for t in flat])
     done, wall = C.c_uint64(), C.c_double()
@@ -238,80 +349,109 @@ def cpu_all_cores(shim, sample, op, k, seconds, n_required=0):
     ol.xgo_search_many.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32),
                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_uint64), C.POINTER(C.c_double)]
     opcode = H.OPS[op] | ((n_required or 1) << 8 if op in H.SIDED else 0)
-    rc = ol.xgo_search_many(shim.oracle_index(), opcode, len(sample), n_terms, terms, lens, 0, k, n_threads, float(seconds),
+    rc = ol.xgo_search_many(ora.oracle_index(), opcode, len(sample), n_terms, terms, lens, 0, k, n_threads, float(seconds),
                             C.byref(done), C.byref(wall))
     assert rc == 0
     return {"value": done.value / wall.value, "unit": "queries/s", "cores": n_threads, "seconds": wall.value}
 
 
-def cpu_baseline(db, term_lists, args, k, timed_plans):
-    """Times oracle/libxgm_oracle.so (glass-format varint chunks, MultiAnd leapfrog, doclen-list
-    lookups, fp64 BM25, ProtoMSet heap — the reference's algorithm restated, 1 thread) on the first
-    queries of the timed pool, over the SAME 10M-doc postings (copied back from HBM), and checks the
-    GPU results against it."""
+def reference_leg(args, sample, k, n_required):
+    """The real reference on this box: build a glass index of the first --ref-docs documents of the corpus with
+    the reference's own WritableDatabase (parallel slices + Database::compact, tools/ref_index.py), time
+    Enquire::get_mset on 1 thread and on every core (one Database handle per thread) with
+    `oracle/_ref/xapian_ref time`, then time the port on the identical postings."""
+    import shutil
+    import tempfile
     import helpers as H
-    L = _lib.lib()
-    sample = term_lists[:128]
-    terms = sorted({t.encode() for q in sample for t in q})
-    info = db.info()
-    doclen = np.zeros(info.lastdocid + 1, dtype=np.uint32)
-    _lib.check(min(0, L.xgm_debug_read_doclen(db._h, doclen.ctypes.data_as(C.POINTER(C.c_uint32)), doclen.size)))
-    dids, wdfs, dfs = [], [], []
-    for t in terms:
-        tid, tf = C.c_uint32(), C.c_uint32()
-        _lib.check(L.xgm_lookup_term(db._h, t, len(t), C.byref(tid), C.byref(tf), None, None))
-        d = np.zeros(tf.value, dtype=np.uint32)
-        w = np.zeros(tf.value, dtype=np.uint32)
-        if tf.value:
-            n = L.xgm_debug_decode_term_device(db._h, tid.value, d.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                               w.ctypes.data_as(C.POINTER(C.c_uint32)), tf.value)
-            assert n == tf.value, L.xgm_last_error()
-        dids.append(d); wdfs.append(w); dfs.append(tf.value)
-    keep = [i for i, n in enumerate(dfs) if n > 0]
-    terms = [terms[i] for i in keep]
-    did = np.concatenate([dids[i] for i in keep]) if keep else np.zeros(0, dtype=np.uint32)
-    wdf = np.concatenate([wdfs[i] for i in keep]) if keep else np.zeros(0, dtype=np.uint32)
-    df = np.array([dfs[i] for i in keep], dtype=np.uint32)
-    tlen = np.array([len(t) for t in terms], dtype=np.uint32)
-    tarr = (C.c_char_p * len(terms))(*terms)
-    u32p = C.POINTER(C.c_uint32)
-    ol = H.olib()
-    oidx = ol.xgo_index_from_raw(len(terms), info.lastdocid, info.doccount, info.total_length, doclen.ctypes.data_as(u32p),
-                                 C.cast(tarr, C.POINTER(C.c_char_p)), tlen.ctypes.data_as(u32p), df.ctypes.data_as(u32p),
-                                 did.ctypes.data_as(u32p), wdf.ctypes.data_as(u32p), None, None)
-    for t in terms:
-        ol.xgo_index_warm(oidx, t, len(t))          # glass chunk encoding is index-build work: not timed
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_index
+    from xapiand_amd import Database
+    if not H.have_xapian_ref() or args.ref_docs <= 0:
+        return None
+    tmp = tempfile.mkdtemp(prefix="xgm_ref_")
+    try:
+        dbdir = os.path.join(tmp, "glass")
+        binfo = ref_index.build(dbdir, args.ref_docs, nopos=args.op != "PHRASE", vocab=args.vocab)
+        qfile = os.path.join(tmp, "q.txt")
+        H.write_queries(qfile, [dict(q, first=0, maxitems=k) for q in sample])
+        cores = max(1, os.cpu_count() or 1)
+        one = json.loads(H.xapian_ref("time", qfile, 1, 2, dbdir))
+        # enough repeats that every thread answers a few dozen queries
+        rep = max(2, (cores * 24 + len(sample) - 1) // len(sample))
+        many = json.loads(H.xapian_ref("time", qfile, cores, rep, dbdir))
+        # the port on the same postings: the same corpus generated on the GPU at the reference index's size
+        small = Database.synthetic(CORPUS_SEED, args.ref_docs, args.vocab, device=0, with_positions=args.op == "PHRASE")
+        ora = H.DeviceOracle(small, [t for q in sample for t in q["terms"]], positions=args.op == "PHRASE")
+        ora.warm()
+        port = time_port(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
+        # parity of port and reference on the sampled queries, on this index
+        ref_out = os.path.join(tmp, "ref_out.txt")
+        H.xapian_ref("query", qfile, ref_out, dbdir)
+        ref_res = H.parse_ref_output(ref_out)
+        checked = 0
+        if args.op != "PHRASE":                                  # (PHRASE top-k: the reference's stale-weight quirk, DESIGN.md §7)
+            want = H.oracle_search_batch(ora, sample, 0, k)
+            for (rows, _), rr in zip(want, ref_res):
+                assert [(d, w) for d, w, _ in rows] == [(d, w) for d, w, _ in rr["hits"]], "port/reference parity failure on the reference index"
+                checked += 1
+        ora.close()
+        small.close()
+        return {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
+                "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3},
+                "docs": args.ref_docs, "index_build": binfo, "port_same_index": port,
+                "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
-    class Shim:            # what helpers.oracle_search needs
-        def oracle_index(self):
-            return oidx
-    shim = Shim()
+
+def cpu_baseline(db, pool_q, args, k, timed_plans):
+    """`value` is the REAL reference when oracle/_ref/xapian_ref is present (kind "reference": Enquire::get_mset of the
+    vendored Xapian on a --ref-docs glass index built on this box), else the port (kind "port").  Always also: the
+    port at the configuration's full size on the postings copied back from HBM, 1 thread and all cores, with the GPU
+    answers checked against it on every sampled query."""
+    import helpers as H
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    sample = pool_q[:128]
     n_required = args.required if args.op in H.SIDED else 0
-    done, spent, checked, passes = 0, 0.0, 0, 0
+    ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]], positions=args.op == "PHRASE")
+    ora.warm()
     one_hits = (_lib.Hit * k)()
     one_hdr = _lib.ResultHdr()
-    lat = []
-    while spent < args.cpu_seconds and passes < 50:
-        for qi, q in enumerate(sample):
-            a = time.perf_counter()
-            hits, _ = H.oracle_search(shim, args.op, q, 0, k, n_required=n_required)
-            dt = time.perf_counter() - a
-            spent += dt
-            lat.append(dt)
-            done += 1
-            if passes == 0:          # parity of the GPU answer on every sampled query, outside the timing
-                _lib.check(L.xgm_search(db._h, C.byref(timed_plans[qi]), one_hits, C.byref(one_hdr)))
-                got = [(one_hits[j].docid, one_hits[j].weight) for j in range(one_hdr.n_hits)]
-                assert got == [(d, w) for d, w, _ in hits], "GPU/CPU parity failure on bench query %d" % qi
-                checked += 1
-        passes += 1
-    many = cpu_all_cores(shim, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
-    ol.xgo_index_free(oidx)
-    lat.sort()
-    return {"value": done / spent, "unit": "queries/s", "cores": 1, "kind": "port", "all_cores": many,
-            "sample": "first %d queries of the timed pool x %d passes (same 10M-doc postings, copied back from HBM), %.1f s of CPU work; "
-                      "oracle/xgm_oracle.cc = the reference's glass-chunk/MultiAnd/BM25/ProtoMSet algorithm, 1 thread" % (len(sample), passes, spent),
-            "p50_ms": lat[len(lat) // 2] * 1e3, "parity_checked_queries": checked}
+    checked = [0]
+
+    def checker(qi, hits):          # parity of the GPU answer on every sampled query, outside the timing
+        _lib.check(L.xgm_search(db._h, C.byref(timed_plans[qi]), one_hits, C.byref(one_hdr)))
+        got = [(one_hits[j].docid, one_hits[j].weight) for j in range(one_hdr.n_hits)]
+        assert got == [(d, w) for d, w, _ in hits], "GPU/CPU parity failure on bench query %d" % qi
+        checked[0] += 1
+    db.set_stream(0)
+    full = time_port(ora, sample, args.op, k, args.cpu_seconds, n_required, checker)
+    full["all_cores"] = port_all_cores(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
+    full["docs"] = db.info().doccount
+    ora.close()
+    sample_txt = ("first %d queries of the timed pool; port = oracle/xgm_oracle.cc (the reference's glass-chunk / MultiAnd / BM25 / "
+                  "ProtoMSet algorithm restated) on the same %d-doc postings copied back from HBM, %.1f s of CPU work" % (len(sample), full["docs"], full["seconds"]))
+    ref = None
+    try:
+        ref = reference_leg(args, sample, k, n_required)
+    except Exception as e:       # the reference leg is best effort (disk space, missing binary): say why it is absent
+        ref = None
+        sample_txt += "; reference leg failed: %r" % (e,)
+    if ref:
+        out = dict(ref)
+        out["port_full_size"] = full
+        out["reference_full_size_estimate"] = {"value": full["value"] / ref["port_over_reference"], "unit": "queries/s", "cores": 1,
+                                               "note": "port at %d docs / port_over_reference; a measured full-size reference run, when one was made "
+                                                       "on this box type, is under profiles/ (r02_reference_full.json)" % full["docs"]}
+        out["sample"] = ("Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time), glass index of the first %d documents of the same "
+                         "corpus built on this box (%.0f s on %d cores + %.0f s compact), same queries; " % (ref["docs"], ref["index_build"]["build_s"],
+                                                                                                       ref["index_build"]["procs"], ref["index_build"]["compact_s"])) + sample_txt
+        out["parity_checked_queries"] = checked[0]
+        return out
+    out = dict(full)
+    out.update(kind="port", sample=sample_txt, parity_checked_queries=checked[0])
+    return out
 
 
 if __name__ == "__main__":

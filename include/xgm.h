@@ -267,6 +267,16 @@ int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_st
 int xgm_search_batch_device(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
                             void* d_hits, void* d_hdrs);
 
+/* The body of Enquire::get_mset for a batch, in one call: lower every description against this shard
+ * (xgm_plan_query, with gs[q] = the merged statistics of query q when gs != NULL — what
+ * Enquire::set_prepared_mset installed, reference src/xapian/api/enquire.cc:378-394) and search.  This is what
+ * the matcher hook calls per shard; bench.py times it, so that dictionary lookups, BM25Weight::init and leaf
+ * ordering are inside the measured step.  Returns XGM_UNSUPPORTED if any query's shape is declined. */
+int xgm_get_mset_batch(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq,
+                       uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
+int xgm_get_mset_batch_device(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq,
+                              uint32_t k_stride, void* d_hits, void* d_hdrs);
+
 /* Merge per-shard results after the all-gather.  d_all_hits is [n_shards][nq][k_stride], d_all_hdrs
  * [n_shards][nq] (device); output [nq][k_stride] / [nq] (device) with GLOBAL docids
  * did = (local-1)*n_shards + shard + 1.  Replaces MSet::unshard_docids + Matcher::merge_mset +
@@ -282,22 +292,45 @@ int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_al
  * (merged statistics, src/xapian/api/enquire.cc:319-394), get_mset(0, first+maxitems) per shard,
  * unshard_docids and merge_mset (src/xapian/api/mset.cc:367-395, src/xapian/matcher/matcher.cc:
  * 653-781).  descs[q] is planned once per shard with the merged statistics; every shard searches its
- * batch on its own device; the shards' top lists are copied to shards[0]'s device and merged there.
+ * batch on its own device, all launched before anything is waited for; the shards' top lists reach shards[0]'s
+ * device through an RCCL all-gather (one shard per device: a communicator the library owns, librccl loaded on
+ * first use; XGM_SHARDED_RCCL=0 disables it, =force uses it even on one device) or peer copies (several shards per
+ * device), and are merged there.  Buffers, streams and the communicator persist between calls.
  * hits is [nq][k_stride] with GLOBAL docids ((local-1)*n_shards + shard + 1), best first+maxitems of
  * each query (the caller skips `first`, as with xgm_search); hdrs[q].matches_exact is the sum over
  * the shards.  Returns XGM_UNSUPPORTED if any shard declines any query (caller: CPU matcher). */
 int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, const xgm_query_desc* descs,
                        uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
 
+/* Diagnostics: out4 = {calls, calls whose exchange was an RCCL all-gather, devices, shards} of the shard list whose
+ * shards[0] is this index. */
+int xgm_debug_sharded_info(const xgm_index* shards0, uint64_t* out4);
+
 /* Kernel timing with HIP events on the launch stream.  xgm_index_set_profiling(idx, 1) makes every
  * later xgm_search* call record an event pair around the dominant kernel (xgm_match_kernel) without
  * synchronising; xgm_last_kernel_ms waits for the recorded launches, returns their MEAN duration in
  * milliseconds (< 0 if none) and starts a new window. */
+/* on: bit 0 = record the event pairs; bit 1 = launch the wave kernels' TALLYING instantiation, which also counts
+ * what each work unit requests from memory (xgm_last_batch_traffic) — the same code plus scalar tallies; never
+ * combined with a timing run. */
 int xgm_index_set_profiling(xgm_index*, int on);
 double xgm_last_kernel_ms(const xgm_index*);
 /* Name of the match kernel the last xgm_search* call on this index launched ("xgm_andw_kernel",
  * "xgm_orw_kernel", "xgm_and_kernel", "xgm_match_kernel"; "" before the first search). */
 const char* xgm_last_kernel_name(const xgm_index*);
+
+/* Traffic model of the LAST batch launched on this index while the tallying instantiation was selected
+ * (xgm_index_set_profiling bit 1): what the wave kernels requested from memory, tallied per work unit and summed
+ * here (waits for the device).  out[0..n), n <= XGM_TRAFFIC_FIELDS:
+ * [0] container bitmap words (4 B each, streamed)       [1] distinct 64-B sectors touched by the container probes
+ * [2] posting-block payload words (4 B)                 [3] 12-byte block headers
+ * [4] distinct 64-B sectors touched by doclen gathers   [5] other streamed 4-byte words (run table, directory, histogram)
+ * [6] candidates written (16 B each)                    [7] PHRASE: positions of every query term in every
+ *                                                           conjunction survivor (P of SURVEY.md §8(d))
+ * [8] container probes issued (lanes, 1 B each)         [9] doclen gathers issued (lanes, 4 B each)
+ * bench.py turns these into roofline.model_min_bytes. */
+#define XGM_TRAFFIC_FIELDS 10
+int xgm_last_batch_traffic(xgm_index*, uint64_t* out, uint32_t n);
 
 /* Algorithmic bytes of a planned query on this shard, SURVEY.md §8(d):
  * Σ_t df_t·8 + S·4 (+ P·4) + k·16, with S and P taken from the last executed result header
@@ -310,6 +343,13 @@ int64_t xgm_debug_decode_term_device(xgm_index*, uint32_t term_id, uint32_t* did
 
 /* Diagnostics: copy the dense doclen array (u32[lastdocid+1]) to the host; returns its length. */
 int64_t xgm_debug_read_doclen(xgm_index*, uint32_t* out, uint64_t cap);
+
+/* Diagnostics: copy one term's positions (flat u32, posting order, Σ wdf entries) to the host; returns
+ * their number (0 when the segment has no positions) or < 0. */
+int64_t xgm_debug_read_positions(xgm_index*, uint32_t term_id, uint32_t* out, uint64_t cap);
+
+/* Diagnostics: mean host time of xgm_plan_query per query (microseconds) over `reps` passes of descs[0..nq). */
+double xgm_debug_plan_us(const xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t reps);
 
 const char* xgm_last_error(void);
 const char* xgm_version(void);

@@ -184,6 +184,56 @@ int cmd_build(int argc, char** argv) {
     return 0;
 }
 
+/* build_range <dbdir> <seed> <g_first> <g_last> <vocab> <len_lo> <len_hi> [nopos]
+ * One contiguous slice [g_first, g_last] of the global corpus as its own glass DB (local docids 1..n in global
+ * order).  Slices built by parallel processes and merged with `compact` give exactly the database a sequential
+ * `build` produces (same documents under the same docids), in a fraction of the wall time — how bench.py gets a
+ * reference index onto the GPU box's host cores.  "nopos": wdf only (add_term), for baselines that need no
+ * positions. */
+int cmd_build_range(int argc, char** argv) {
+    if (argc < 9) return 2;
+    const char* dir = argv[2];
+    xgm_corpus_params cp;
+    cp.seed = strtoull(argv[3], nullptr, 0);
+    const uint64_t g0 = strtoull(argv[4], nullptr, 0), g1 = strtoull(argv[5], nullptr, 0);
+    cp.vocab = (uint32_t)strtoul(argv[6], nullptr, 0);
+    cp.len_lo = (uint32_t)strtoul(argv[7], nullptr, 0);
+    cp.len_hi = (uint32_t)strtoul(argv[8], nullptr, 0);
+    const bool nopos = argc > 9 && std::string(argv[9]) == "nopos";
+    std::vector<uint64_t> thr(cp.vocab);
+    xgm_zipf_thresholds(cp.vocab, thr.data());
+    Xapian::WritableDatabase db(dir, Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
+    char name[16];
+    uint64_t added = 0;
+    for (uint64_t g = g0; g <= g1; ++g) {
+        Xapian::Document doc;
+        uint32_t len = xgm_doc_len(&cp, g);
+        for (uint32_t pos = 1; pos <= len; ++pos) {
+            snprintf(name, sizeof name, "t%u", xgm_token(&cp, thr.data(), g, pos));
+            if (nopos) doc.add_term(name, 1); else doc.add_posting(name, pos);
+        }
+        db.add_document(doc);
+        if (++added % 100000 == 0) db.commit();
+    }
+    db.commit();
+    printf("{\"doccount\": %u, \"lastdocid\": %u, \"total_length\": %" PRIu64 "}\n", db.get_doccount(),
+           db.get_lastdocid(), (uint64_t)db.get_total_length());
+    return 0;
+}
+
+/* compact <outdir> <dbdir> [<dbdir> ...]: Database::compact of the sources in order (docids renumbered by the
+ * running lastdocid offset, reference src/xapian/api/compactor.cc / backends/glass/glass_compact.cc). */
+int cmd_compact(int argc, char** argv) {
+    if (argc < 4) return 2;
+    Xapian::Database src;
+    for (int i = 3; i < argc; ++i) src.add_database(Xapian::Database(argv[i]));
+    src.compact(argv[2], Xapian::DBCOMPACT_MULTIPASS * 0);
+    Xapian::Database out(argv[2]);
+    printf("{\"doccount\": %u, \"lastdocid\": %u, \"total_length\": %" PRIu64 "}\n", out.get_doccount(), out.get_lastdocid(),
+           (uint64_t)out.get_total_length());
+    return 0;
+}
+
 /* A small database that exercises the corners of the on-disk format for the native glass reader
  * (tests/test_glass.py): several commits, deleted and replaced documents (docid gaps), docids beyond
  * 0x8000 / 0x200000 (longer sort-preserving chunk keys), terms with embedded zero bytes, postings without
@@ -373,6 +423,8 @@ int main(int argc, char** argv) {
         else if (cmd == "time") rc = cmd_time(argc, argv);
         else if (cmd == "export") rc = cmd_export(argc, argv);
         else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
+        else if (cmd == "build_range") rc = cmd_build_range(argc, argv);
+        else if (cmd == "compact") rc = cmd_compact(argc, argv);
         if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());
         return rc;
     } catch (const Xapian::Error& e) {

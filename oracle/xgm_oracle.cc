@@ -809,6 +809,54 @@ int xgo_search_many(void* ixv, uint32_t op, uint32_t n_queries, const uint32_t* 
     return 0;
 }
 
+/* Every query of a list answered once, on n_threads host threads (config-scale parity tests: the expected
+ * results of a few hundred 10 M-document queries without minutes of single-threaded CPU time on the GPU box).
+ * ops[q] as in xgo_search (operator | n_required << 8); hits is [n_queries][cap], cap >= first + maxitems.
+ * The terms' glass lists are encoded first, also in parallel (distinct terms dealt to the threads). */
+int xgo_search_batch(void* ixv, uint32_t n_queries, const uint32_t* ops, const uint32_t* n_terms, const uint32_t* windows,
+                     const char* const* terms, const uint32_t* term_len, uint32_t first, uint32_t maxitems, uint32_t cap,
+                     uint32_t n_threads, uint32_t select_cache_bug, xgo_hit* hits, xgo_result_hdr* hdrs) {
+    Index* ix = (Index*)ixv;
+    if (!ix || n_threads == 0 || cap < first + maxitems) return -1;
+    std::vector<uint64_t> start(n_queries + 1, 0);
+    for (uint32_t q = 0; q < n_queries; ++q) start[q + 1] = start[q] + n_terms[q];
+    std::vector<uint32_t> ids;
+    for (uint64_t i = 0; i < start[n_queries]; ++i) {
+        auto it = ix->dict.find(std::string(terms[i], term_len[i]));
+        if (it != ix->dict.end()) ids.push_back(it->second);
+    }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t]() { for (size_t i = t; i < ids.size(); i += n_threads) ix->list(ids[i]); });
+        for (auto& x : th) x.join();
+    }
+    std::vector<int> rcs(n_threads, 0);
+    std::vector<std::thread> th;
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        th.emplace_back([&, t]() {
+            for (uint32_t q = t; q < n_queries; q += n_threads) {
+                QueryIn in{ops[q] & 0xFFu, ops[q] >> 8, n_terms[q], terms + start[q], term_len + start[q], windows ? windows[q] : 0u, first, maxitems,
+                           0, 0, 0, 0, nullptr, select_cache_bug};
+                Result r;
+                if (run_query(ix, in, &r)) { rcs[t] = -1; return; }
+                xgo_result_hdr& h = hdrs[q];
+                h.n_hits = (uint32_t)r.hits.size(); h.max_subqs = r.max_subqs; h.matches = r.matches;
+                h.max_attained = r.max_attained; h.max_possible = r.max_possible;
+                for (size_t i = 0; i < r.hits.size(); ++i) {
+                    xgo_hit& o = hits[(size_t)q * cap + i];
+                    o.docid = r.hits[i].did; o.subqs = r.hits[i].subqs; o.weight = r.hits[i].weight;
+                }
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return rcs[t];
+    return 0;
+}
+
 /* Matcher::merge_mset + unshard_docids for per-shard result lists (already sorted). */
 int xgo_merge(uint32_t n_shards, const xgo_hit* const* shard_hits, const uint32_t* n_hits, uint32_t first, uint32_t maxitems,
               xgo_hit* out) {

@@ -302,6 +302,26 @@ def gen_phrase_queries(n_queries, n_docs_global, vocab, len_lo=50, len_hi=150, c
     return qs
 
 
+def bench_pool(op, n_terms=3, n_required=1, n_docs_global=10_000_000, vocab=1_000_000, n=1100, seed=QUERY_SEED, maxitems=10):
+    """The query pool of bench.py (ranks log-uniform in [8, 4096], no repetition inside a query; PHRASE:
+    2-3-grams that occur in a random document) as query dicts.  bench.py warms up on the first 100 and times the
+    rest; the config-scale parity tests check the first queries of the timed part."""
+    import math
+    if op == "PHRASE":
+        return gen_phrase_queries(n, n_docs_global, vocab, seed=seed, maxitems=maxitems)
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        ranks = set()
+        while len(ranks) < n_terms:
+            ranks.add(max(1, int(round(math.exp(rng.uniform(math.log(8), math.log(4096)))))))
+        ranks = list(ranks)
+        rng.shuffle(ranks)
+        out.append(dict(op=op, terms=["t%d" % r for r in ranks], first=0, maxitems=maxitems, window=0,
+                        n_required=n_required if op in SIDED else 0))
+    return out
+
+
 class ManualCorpus(Corpus):
     """Hand-made postings: {term: [(docid, wdf, [positions...]), ...]} plus doc lengths.  Same
     interface as Corpus so it can feed both the oracle and the segment builder."""
@@ -353,3 +373,99 @@ class ManualCorpus(Corpus):
 
     def terms(self):
         return list(self._term_bytes)
+
+
+# ---- oracle over postings copied back from a device-resident index (config-scale parity, bench cpu_baseline) ----
+
+class DeviceOracle:
+    """A CPU-oracle index over the postings of `terms` as the DEVICE holds them (decoded by K1 on the GPU and copied
+    back, with the positions when `positions`), so that the oracle answers on exactly the index the HIP path
+    searches — at any size, without re-inverting the corpus on the host.  Same interface as Corpus for
+    oracle_search / oracle_search_batch (oracle_index())."""
+
+    def __init__(self, db, terms, positions=False):
+        from xapiand_amd import _lib
+        L = _lib.lib()
+        info = db.info()
+        terms = sorted({t if isinstance(t, bytes) else t.encode() for t in terms})
+        u32p = C.POINTER(C.c_uint32)
+        self.doclen = np.zeros(info.lastdocid + 1, dtype=np.uint32)
+        _lib.check(min(0, L.xgm_debug_read_doclen(db._h, self.doclen.ctypes.data_as(u32p), self.doclen.size)))
+        dids, wdfs, poss, keep = [], [], [], []
+        for t in terms:
+            tid, tf = C.c_uint32(), C.c_uint32()
+            _lib.check(L.xgm_lookup_term(db._h, t, len(t), C.byref(tid), C.byref(tf), None, None))
+            if tf.value == 0:
+                continue
+            d = np.zeros(tf.value, dtype=np.uint32)
+            w = np.zeros(tf.value, dtype=np.uint32)
+            n = L.xgm_debug_decode_term_device(db._h, tid.value, d.ctypes.data_as(u32p), w.ctypes.data_as(u32p), tf.value)
+            assert n == tf.value, L.xgm_last_error()
+            if positions:
+                p = np.zeros(int(w.sum(dtype=np.uint64)), dtype=np.uint32)
+                n = L.xgm_debug_read_positions(db._h, tid.value, p.ctypes.data_as(u32p), p.size)
+                assert n == p.size, L.xgm_last_error()
+                poss.append(p)
+            keep.append(t); dids.append(d); wdfs.append(w)
+        self.terms = keep
+        self.did = np.concatenate(dids) if keep else np.zeros(0, dtype=np.uint32)
+        self.wdf = np.concatenate(wdfs) if keep else np.zeros(0, dtype=np.uint32)
+        self.df = np.array([d.size for d in dids], dtype=np.uint32)
+        self.tlen = np.array([len(t) for t in keep], dtype=np.uint32)
+        self._tarr = (C.c_char_p * len(keep))(*keep)
+        pos_off_p, pos_p = None, None
+        if positions:
+            self.pos = np.concatenate(poss) if keep else np.zeros(1, dtype=np.uint32)
+            self.pos_off = np.zeros(self.wdf.size + 1, dtype=np.uint64)
+            np.cumsum(self.wdf, dtype=np.uint64, out=self.pos_off[1:])
+            pos_off_p, pos_p = self.pos_off.ctypes.data_as(C.POINTER(C.c_uint64)), self.pos.ctypes.data_as(u32p)
+        self._oidx = olib().xgo_index_from_raw(len(keep), info.lastdocid, info.doccount, info.total_length, self.doclen.ctypes.data_as(u32p),
+                                               C.cast(self._tarr, C.POINTER(C.c_char_p)), self.tlen.ctypes.data_as(u32p),
+                                               self.df.ctypes.data_as(u32p), self.did.ctypes.data_as(u32p), self.wdf.ctypes.data_as(u32p),
+                                               pos_off_p, pos_p)
+
+    def oracle_index(self):
+        return self._oidx
+
+    def warm(self):
+        for t in self.terms:
+            olib().xgo_index_warm(self._oidx, t, len(t))          # glass chunk encoding is index-build work
+
+    def close(self):
+        if self._oidx:
+            olib().xgo_index_free(self._oidx)
+            self._oidx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def oracle_search_batch(corpus, queries, first, maxitems, n_threads=None, reference_select_bug=False):
+    """Every query once on n_threads host threads (oracle/xgm_oracle.cc::xgo_search_batch) → [(rows, hdr dict)]."""
+    ol = olib()
+    nq = len(queries)
+    n_threads = n_threads or max(1, min(os.cpu_count() or 1, nq))
+    flat = [(t if isinstance(t, bytes) else t.encode()) for q in queries for t in q["terms"]]
+    ops = (C.c_uint32 * nq)(*[OPS[q["op"]] | (((q.get("n_required") or 1) << 8) if q["op"] in SIDED else 0) for q in queries])
+    nts = (C.c_uint32 * nq)(*[len(q["terms"]) for q in queries])
+    wins = (C.c_uint32 * nq)(*[q.get("window", 0) for q in queries])
+    terms = (C.c_char_p * len(flat))(*flat)
+    lens = (C.c_uint32 * len(flat))(*[len(t) for t in flat])
+    cap = max(1, first + maxitems)
+    hits = (OHit * (nq * cap))()
+    hdrs = (OHdr * nq)()
+    ol.xgo_search_batch.restype = C.c_int
+    ol.xgo_search_batch.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(OHit), C.POINTER(OHdr)]
+    rc = ol.xgo_search_batch(corpus.oracle_index(), nq, ops, nts, wins, terms, lens, first, maxitems, cap, n_threads, 1 if reference_select_bug else 0, hits, hdrs)
+    assert rc == 0
+    out = []
+    for i in range(nq):
+        h = hdrs[i]
+        rows = [(hits[i * cap + j].docid, hits[i * cap + j].weight, hits[i * cap + j].subqs) for j in range(h.n_hits)]
+        out.append((rows, dict(n_hits=h.n_hits, matches=h.matches, max_attained=h.max_attained, max_possible=h.max_possible, max_subqs=h.max_subqs)))
+    return out

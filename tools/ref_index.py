@@ -1,0 +1,68 @@
+"""Build a glass index of the synthetic corpus with the REAL reference (oracle/_ref/xapian_ref) on many host cores:
+contiguous slices of the corpus are indexed by parallel `xapian_ref build_range` processes (Xapian's
+WritableDatabase::add_document is single-threaded: ~1.7 k documents/s per core) and merged with
+`xapian_ref compact` (Database::compact), which yields the same documents under the same docids as one sequential
+build (checked in tests/test_oracle_vs_reference.py).  Test/bench infrastructure only — bench.py's cpu_baseline leg
+uses it to put a reference index next to the GPU on the box it runs on.
+
+    python tools/ref_index.py <outdir> <n_docs> [--procs P] [--nopos] [--vocab V]
+"""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
+CORPUS_SEED = 0x5EED0001
+
+
+def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, len_hi=150, seed=CORPUS_SEED, keep_parts=False):
+    """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced."""
+    if not os.path.exists(XAPIAN_REF):
+        raise RuntimeError("oracle/_ref/xapian_ref is not built")
+    procs = procs or max(1, min((os.cpu_count() or 1) - 2, (n_docs + 19999) // 20000))
+    parts_dir = outdir.rstrip("/") + ".parts"
+    shutil.rmtree(parts_dir, ignore_errors=True)
+    shutil.rmtree(outdir, ignore_errors=True)
+    os.makedirs(parts_dir)
+    per = (n_docs + procs - 1) // procs
+    t0 = time.time()
+    running, parts = [], []
+    for i in range(procs):
+        g0, g1 = i * per + 1, min(n_docs, (i + 1) * per)
+        if g0 > g1:
+            break
+        d = os.path.join(parts_dir, "p%04d" % i)
+        parts.append(d)
+        cmd = [XAPIAN_REF, "build_range", d, hex(seed), str(g0), str(g1), str(vocab), str(len_lo), str(len_hi)] + (["nopos"] if nopos else [])
+        running.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL))
+    for p in running:
+        if p.wait() != 0:
+            raise RuntimeError("xapian_ref build_range failed")
+    t1 = time.time()
+    if len(parts) == 1:
+        os.rename(parts[0], outdir)
+        info = dict(doccount=n_docs)
+    else:
+        out = subprocess.run([XAPIAN_REF, "compact", outdir] + parts, check=True, capture_output=True, text=True).stdout
+        info = json.loads(out)
+    t2 = time.time()
+    if not keep_parts:
+        shutil.rmtree(parts_dir, ignore_errors=True)
+    assert info["doccount"] == n_docs, info
+    return dict(doccount=n_docs, build_s=t1 - t0, compact_s=t2 - t1, procs=len(parts), positions=not nopos)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("outdir")
+    ap.add_argument("n_docs", type=int)
+    ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--nopos", action="store_true")
+    ap.add_argument("--vocab", type=int, default=1_000_000)
+    a = ap.parse_args()
+    print(json.dumps(build(a.outdir, a.n_docs, a.procs or None, a.nopos, a.vocab)))

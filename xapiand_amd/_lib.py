@@ -101,14 +101,20 @@ _API = [
     ("xgm_search", C.c_int, [C.c_void_p, _P(Query), _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch_device", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    ("xgm_get_mset_batch", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
+    ("xgm_get_mset_batch_device", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     ("xgm_search_sharded", C.c_int, [_P(C.c_void_p), C.c_uint32, _P(QueryDesc), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
+    ("xgm_debug_sharded_info", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("xgm_merge_shards_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
     ("xgm_index_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_last_kernel_ms", C.c_double, [C.c_void_p]),
     ("xgm_last_kernel_name", C.c_char_p, [C.c_void_p]),
+    ("xgm_last_batch_traffic", C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_uint32]),
     ("xgm_query_postings_bytes", C.c_uint64, [C.c_void_p, _P(Query)]),
     ("xgm_debug_decode_term_device", C.c_int64, [C.c_void_p, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32), C.c_uint64]),
     ("xgm_debug_read_doclen", C.c_int64, [C.c_void_p, _P(C.c_uint32), C.c_uint64]),
+    ("xgm_debug_read_positions", C.c_int64, [C.c_void_p, C.c_uint32, _P(C.c_uint32), C.c_uint64]),
+    ("xgm_debug_plan_us", C.c_double, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]

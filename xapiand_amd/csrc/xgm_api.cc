@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdlib>
 #include <cmath>
@@ -165,6 +166,8 @@ static void scratch_destroy(XgmScratch* s) {
 
 /* ------------------------------------------------------------------ index lifetime ----------- */
 
+void xgm_shard_ctx_destroy(XgmShardCtx* c);
+
 static void fill_view(xgm_index* idx) {
     xgm_seg_dev& v = idx->view;
     v.doclen = (const uint32_t*)idx->d_sections[XGM_S_DOCLEN];
@@ -242,6 +245,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->device == XGM_DEVICE_NONE) { delete idx; return; }
     hipSetDevice(idx->device);
     hipDeviceSynchronize();
+    if (idx->shard_ctx) { xgm_shard_ctx_destroy(idx->shard_ctx); idx->shard_ctx = nullptr; hipSetDevice(idx->device); }
     for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
     for (auto& pr : idx->prof_events) { hipEventDestroy((hipEvent_t)pr.first); hipEventDestroy((hipEvent_t)pr.second); }
     if (idx->sections_owned) {
@@ -301,7 +305,8 @@ extern "C" int xgm_index_set_stream(xgm_index* idx, void* hip_stream) {
 extern "C" int xgm_index_set_profiling(xgm_index* idx, int on) {
     if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(idx->scratch_mu);
-    idx->profiling = on != 0;
+    idx->profiling = (on & 1) != 0;
+    idx->tally = (on & 2) != 0;
     idx->prof_used = 0;
     return XGM_OK;
 }
@@ -328,19 +333,42 @@ extern "C" const char* xgm_last_kernel_name(const xgm_index* idx) { return idx ?
 
 /* ------------------------------------------------------------------ dictionary --------------- */
 
-int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id) {
-    uint32_t lo = 0, hi = idx->hdr.n_terms;
+/* Dictionary lookup: an open-addressing hash over the sorted term table (built once, lazily and thread-safely),
+ * ~2 cache misses per term instead of the ~40 of a binary search over a million strings — the lookups are part of
+ * every get_mset (reference: one B-tree descent per term, glass_postlist.cc:151-192). */
+static inline uint64_t term_hash(const char* p, size_t n) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ (n * 0xFF51AFD7ED558CCDull);
+    while (n >= 8) { uint64_t v; memcpy(&v, p, 8); h = (h ^ v) * 0xD6E8FEB86659FD93ull; h ^= h >> 32; p += 8; n -= 8; }
+    uint64_t v = 0;
+    memcpy(&v, p, n);
+    h = (h ^ v) * 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 29);
+}
+
+static void build_term_hash(xgm_index* idx) {
+    const uint32_t T = idx->hdr.n_terms;
+    uint32_t cap = 16;
+    while (cap < 2u * T + 2u) cap <<= 1;
+    idx->term_hash.assign(cap, UINT32_MAX);
     const uint64_t* so = idx->str_off.data();
     const char* sb = idx->str_bytes.data();
-    while (lo < hi) {
-        uint32_t mid = lo + (hi - lo) / 2;
-        size_t ml = (size_t)(so[mid + 1] - so[mid]);
-        int c = memcmp(sb + so[mid], term, std::min(ml, len));
-        if (c < 0 || (c == 0 && ml < len)) lo = mid + 1; else hi = mid;
+    for (uint32_t t = 0; t < T; ++t) {
+        uint32_t i = (uint32_t)term_hash(sb + so[t], (size_t)(so[t + 1] - so[t])) & (cap - 1u);
+        while (idx->term_hash[i] != UINT32_MAX) i = (i + 1u) & (cap - 1u);
+        idx->term_hash[i] = t;
     }
-    if (lo < idx->hdr.n_terms && (size_t)(so[lo + 1] - so[lo]) == len && memcmp(sb + so[lo], term, len) == 0) {
-        *id = lo;
-        return 1;
+}
+
+int xgm_lookup_term_id(const xgm_index* cidx, const char* term, size_t len, uint32_t* id) {
+    xgm_index* idx = const_cast<xgm_index*>(cidx);
+    std::call_once(idx->term_hash_once, build_term_hash, idx);
+    const uint64_t* so = idx->str_off.data();
+    const char* sb = idx->str_bytes.data();
+    const uint32_t mask = (uint32_t)idx->term_hash.size() - 1u;
+    for (uint32_t i = (uint32_t)term_hash(term, len) & mask;; i = (i + 1u) & mask) {
+        const uint32_t t = idx->term_hash[i];
+        if (t == UINT32_MAX) break;
+        if ((size_t)(so[t + 1] - so[t]) == len && memcmp(sb + so[t], term, len) == 0) { *id = t; return 1; }
     }
     *id = UINT32_MAX;
     return 0;
@@ -662,6 +690,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0;
+    L.tally = idx->tally;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
     if (idx->profiling) {
@@ -677,6 +706,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         ++idx->prof_used;
     }
     idx->last_kernel = bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw) {
         if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
         HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
@@ -732,33 +762,72 @@ extern "C" int xgm_search(xgm_index* idx, const xgm_query* q, xgm_hit* hits, xgm
     return xgm_search_batch(idx, q, 1, k ? k : 1, hits, hdr);
 }
 
-extern "C" int xgm_search_batch_device(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, void* d_hits,
-                                       void* d_hdrs) {
-    if (!idx || !qs || !d_hits || !d_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+/* Enqueue a batch on `stream` (NULL: the index's stream, or the scratch's own one followed by a host wait). */
+static int search_batch_device_on(xgm_index* idx, hipStream_t on, const xgm_query* qs, uint32_t nq, uint32_t k_stride, void* d_hits,
+                                  void* d_hdrs) {
     if (nq == 0) return XGM_OK;
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
     if ((rc = scratch_acquire(idx, &s))) return rc;
-    hipStream_t stream = pick_stream(idx, s);
+    hipStream_t stream = on ? on : pick_stream(idx, s);
     rc = run_batch(idx, s, stream, qs, nq, k_stride, (xgm_hit*)d_hits, (xgm_result_hdr*)d_hdrs);
     /* the scratch (queries, candidates) is still in use by the enqueued kernels: mark it pending so
      * the next acquire waits for them. */
     if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
-    if (!idx->stream) hipStreamSynchronize(stream);
+    if (!on && !idx->stream) hipStreamSynchronize(stream);
     scratch_release(idx, s);
     return rc;
 }
 
+extern "C" int xgm_search_batch_device(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, void* d_hits,
+                                       void* d_hdrs) {
+    if (!idx || !qs || !d_hits || !d_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    return search_batch_device_on(idx, nullptr, qs, nq, k_stride, d_hits, d_hdrs);
+}
+
+/* plan (xgm_plan_query per description, with that query's merged statistics when given) + search, results in HBM */
+extern "C" int xgm_get_mset_batch_device(xgm_index* idx, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq,
+                                         uint32_t k_stride, void* d_hits, void* d_hdrs) {
+    if (!idx || !descs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    static thread_local std::vector<xgm_query> plans;
+    plans.resize(nq);
+    for (uint32_t i = 0; i < nq; ++i) {
+        int rc = xgm_plan_query(idx, &descs[i], gs ? &gs[i] : nullptr, &plans[i]);
+        if (rc) return rc;
+    }
+    return xgm_search_batch_device(idx, plans.data(), nq, k_stride, d_hits, d_hdrs);
+}
+
+extern "C" int xgm_get_mset_batch(xgm_index* idx, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq,
+                                  uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
+    if (!idx || !descs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    static thread_local std::vector<xgm_query> plans;
+    plans.resize(nq);
+    for (uint32_t i = 0; i < nq; ++i) {
+        int rc = xgm_plan_query(idx, &descs[i], gs ? &gs[i] : nullptr, &plans[i]);
+        if (rc) return rc;
+    }
+    return xgm_search_batch(idx, plans.data(), nq, k_stride, hits, hdrs);
+}
+
+static int merge_shards_device_on(xgm_index* idx, hipStream_t on, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
+                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs);
+
 extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
                                        uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
     if (!idx || !d_all_hits || !d_all_hdrs || !k || !d_out_hits || !d_out_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    return merge_shards_device_on(idx, nullptr, d_all_hits, d_all_hdrs, n_shards, nq, k_stride, k, d_out_hits, d_out_hdrs);
+}
+
+static int merge_shards_device_on(xgm_index* idx, hipStream_t on, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
+                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
     if (nq == 0) return XGM_OK;
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
     if ((rc = scratch_acquire(idx, &s))) return rc;
-    hipStream_t stream = pick_stream(idx, s);
+    hipStream_t stream = on ? on : pick_stream(idx, s);
     do {
         uint32_t k_max = 1;
         for (uint32_t i = 0; i < nq; ++i) k_max = std::max(k_max, k[i]);
@@ -774,21 +843,179 @@ extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, c
                                      cap, (xgm_hit*)d_out_hits, (xgm_result_hdr*)d_out_hdrs, stream);
     } while (0);
     if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
-    if (!idx->stream) hipStreamSynchronize(stream);
+    if (!on && !idx->stream) hipStreamSynchronize(stream);
     scratch_release(idx, s);
     return rc;
+}
+
+/* ---- several shards in one process ----------------------------------------------------------------------------
+ * Persistent context of one shard list, owned by shards[0]: per DEVICE a stream, an event and the gathered arrays
+ * ([n_shards][nq][k_stride] hits, [n_shards][nq] headers; the device's shards write their slices in place), and the
+ * exchange step that brings every slice to shards[0]'s device:
+ *   - RCCL: ncclAllGather over a communicator the library owns (ncclCommInitAll on the shard devices, librccl.so.1
+ *     loaded with dlopen on first use so that a single-GPU host never needs it) when every shard has its own device —
+ *     the 8 x MI355X layout of BASELINE.json's C4;
+ *   - otherwise (several shards per device, or no RCCL): hipMemcpyPeerAsync of the remote slices, ordered by events.
+ * Nothing is allocated and no device is synchronised per call: launches on all shards first, then one wait for the
+ * merged result.  Calls on the same shard list are serialised by the context's mutex (the per-index scratch pools
+ * keep independent lists concurrent). */
+#include <dlfcn.h>
+
+namespace {
+
+typedef void* xgm_nccl_comm;
+struct RcclApi {
+    void* lib = nullptr;
+    int (*CommInitAll)(xgm_nccl_comm*, int, const int*) = nullptr;
+    int (*CommDestroy)(xgm_nccl_comm) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, xgm_nccl_comm, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    bool ok = false;
+};
+
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        const char* off = getenv("XGM_SHARDED_RCCL");
+        if (off && off[0] == '0') return;
+        /* RTLD_LOCAL: a host that already carries another copy of RCCL (PyTorch bundles one) keeps its own symbols */
+        api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!api.lib) api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!api.lib) return;
+        api.CommInitAll = (int (*)(xgm_nccl_comm*, int, const int*))dlsym(api.lib, "ncclCommInitAll");
+        api.CommDestroy = (int (*)(xgm_nccl_comm))dlsym(api.lib, "ncclCommDestroy");
+        api.AllGather = (int (*)(const void*, void*, size_t, int, xgm_nccl_comm, hipStream_t))dlsym(api.lib, "ncclAllGather");
+        api.GroupStart = (int (*)())dlsym(api.lib, "ncclGroupStart");
+        api.GroupEnd = (int (*)())dlsym(api.lib, "ncclGroupEnd");
+        api.ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd;
+    });
+    return api;
+}
+
+struct ShardDev {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev = nullptr;
+    xgm_hit* all_hits = nullptr;          /* [n_shards][nq_cap * k_cap] gathered array on this device */
+    xgm_result_hdr* all_hdrs = nullptr;   /* [n_shards][nq_cap] */
+    xgm_nccl_comm comm = nullptr;
+};
+
+}  // namespace
+
+struct XgmShardCtx {
+    std::mutex mu;
+    std::vector<xgm_index*> shards;
+    std::vector<int> dev_of;              /* shard -> index into devs */
+    std::vector<ShardDev> devs;           /* devs[0] = shards[0]'s device */
+    size_t cap_hit = 0, cap_nq = 0;       /* per-shard capacities of the gathered arrays */
+    xgm_hit* d_out_hits = nullptr; xgm_result_hdr* d_out_hdrs = nullptr;
+    void* h_out = nullptr; size_t cap_hout = 0;
+    bool use_rccl = false, rccl_tried = false;
+    uint64_t calls = 0, rccl_calls = 0;
+};
+
+static void shard_ctx_free_buffers(XgmShardCtx* c) {
+    for (ShardDev& d : c->devs) {
+        if (hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.all_hits) hipFree(d.all_hits);
+        if (d.all_hdrs) hipFree(d.all_hdrs);
+        d.all_hits = nullptr; d.all_hdrs = nullptr;
+    }
+    if (!c->devs.empty() && hipSetDevice(c->devs[0].device) == hipSuccess) {
+        if (c->d_out_hits) hipFree(c->d_out_hits);
+        if (c->d_out_hdrs) hipFree(c->d_out_hdrs);
+    }
+    c->d_out_hits = nullptr; c->d_out_hdrs = nullptr;
+    c->cap_hit = c->cap_nq = 0;
+}
+
+void xgm_shard_ctx_destroy(XgmShardCtx* c) {
+    if (!c) return;
+    shard_ctx_free_buffers(c);
+    for (ShardDev& d : c->devs) {
+        if (hipSetDevice(d.device) != hipSuccess) continue;
+        if (d.comm && rccl_api().ok) rccl_api().CommDestroy(d.comm);
+        if (d.ev) hipEventDestroy(d.ev);
+        if (d.stream) hipStreamDestroy(d.stream);
+    }
+    if (c->h_out) hipHostFree(c->h_out);
+    delete c;
+}
+
+static int shard_ctx_get(xgm_index* const* shards, uint32_t n_shards, XgmShardCtx** out) {
+    xgm_index* owner = shards[0];
+    std::lock_guard<std::mutex> lk(owner->scratch_mu);
+    XgmShardCtx* c = owner->shard_ctx;
+    bool same = c && c->shards.size() == n_shards && std::equal(c->shards.begin(), c->shards.end(), shards);
+    for (uint32_t s = 0; same && s < n_shards; ++s) same = c->devs[c->dev_of[s]].device == shards[s]->device;
+    if (c && !same) {
+        xgm_shard_ctx_destroy(c);
+        c = owner->shard_ctx = nullptr;
+    }
+    if (!c) {
+        c = new XgmShardCtx();
+        c->shards.assign(shards, shards + n_shards);
+        for (uint32_t s = 0; s < n_shards; ++s) {
+            int di = -1;
+            for (size_t j = 0; j < c->devs.size(); ++j) if (c->devs[j].device == shards[s]->device) di = (int)j;
+            if (di < 0) {
+                ShardDev d;
+                d.device = shards[s]->device;
+                int rc = use_device(d.device);
+                if (rc) { xgm_shard_ctx_destroy(c); return rc; }
+                if (hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&d.ev, hipEventDisableTiming) != hipSuccess) {
+                    xgm_shard_ctx_destroy(c);
+                    return xgm_set_error(XGM_E_DEVICE, "cannot create the shard stream on device %d", d.device);
+                }
+                c->devs.push_back(d);
+                di = (int)c->devs.size() - 1;
+            }
+            c->dev_of.push_back(di);
+        }
+        owner->shard_ctx = c;
+    }
+    *out = c;
+    return XGM_OK;
+}
+
+/* One shard per device and more than one device (or XGM_SHARDED_RCCL=force on a single device: a 1-rank communicator,
+ * which is how the single-GPU test box executes this path): the exchange is an RCCL all-gather. */
+static void shard_ctx_try_rccl(XgmShardCtx* c) {
+    if (c->rccl_tried) return;
+    c->rccl_tried = true;
+    const char* mode = getenv("XGM_SHARDED_RCCL");
+    const bool force = mode && !strcmp(mode, "force");
+    if (c->devs.size() != c->shards.size() || (c->devs.size() < 2 && !force)) return;
+    RcclApi& api = rccl_api();
+    if (!api.ok) return;
+    std::vector<int> devlist;
+    for (ShardDev& d : c->devs) devlist.push_back(d.device);
+    std::vector<xgm_nccl_comm> comms(devlist.size(), nullptr);
+    if (api.CommInitAll(comms.data(), (int)devlist.size(), devlist.data()) != 0) return;
+    for (size_t i = 0; i < comms.size(); ++i) c->devs[i].comm = comms[i];
+    c->use_rccl = true;
 }
 
 extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, const xgm_query_desc* descs, uint32_t nq,
                                   uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
     if (!shards || !descs || !hits || !hdrs || n_shards == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
-    for (uint32_t s = 0; s < n_shards; ++s)
+    for (uint32_t s = 0; s < n_shards; ++s) {
         if (!shards[s]) return xgm_set_error(XGM_E_INVALID, "null shard");
+        if (shards[s]->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "shard %u was opened without a device", s);
+    }
     if (nq == 0) return XGM_OK;
     int rc;
     /* merged statistics and per-shard plans (first = 0: a shard returns its best first+maxitems) */
-    std::vector<std::vector<xgm_query>> plans(n_shards, std::vector<xgm_query>(nq));
+    static thread_local std::vector<std::vector<xgm_query>> plans;
+    plans.resize(n_shards);
+    for (auto& v : plans) v.resize(nq);
     std::vector<uint32_t> kq(nq);
+    uint64_t docs_total = 0;
+    for (uint32_t s = 0; s < n_shards; ++s) docs_total += shards[s]->hdr.doccount;
     for (uint32_t i = 0; i < nq; ++i) {
         xgm_query_desc d = descs[i];
         if (d.n_terms == 0 || d.n_terms > XGM_MAX_TERMS) return XGM_UNSUPPORTED;
@@ -808,74 +1035,107 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
         }
         d.maxitems = d.first + d.maxitems;
         d.first = 0;
-        uint32_t k = 0;
-        for (uint32_t s = 0; s < n_shards; ++s) {
+        for (uint32_t s = 0; s < n_shards; ++s)
             if ((rc = xgm_plan_query(shards[s], &d, &gs, &plans[s][i]))) return rc;
-            k = std::max(k, plans[s][i].first + plans[s][i].maxitems);
-        }
-        kq[i] = std::min<uint32_t>(k, d.maxitems);
+        /* Enquire::merge_mset clamps against the SUMMED doccount (enquire.cc:486-488); each shard's own plan is
+         * clamped to that shard's doccount, and the merge keeps min(available, k) */
+        kq[i] = (uint32_t)std::min<uint64_t>(d.maxitems, docs_total);
     }
-    /* per-shard searches, each on its own device, results left in HBM */
+
+    XgmShardCtx* c;
+    if ((rc = shard_ctx_get(shards, n_shards, &c))) return rc;
+    std::lock_guard<std::mutex> lk(c->mu);
     const size_t n_hit = (size_t)nq * k_stride;
-    std::vector<xgm_hit*> d_hits(n_shards, nullptr);
-    std::vector<xgm_result_hdr*> d_hdrs(n_shards, nullptr);
-    xgm_hit *d_all_hits = nullptr, *d_out_hits = nullptr;
-    xgm_result_hdr *d_all_hdrs = nullptr, *d_out_hdrs = nullptr;
-    const int dev0 = shards[0]->device;
     hipError_t e = hipSuccess;
-    rc = XGM_OK;
-    do {
-        if ((rc = use_device(dev0))) break;
-        if ((e = hipMalloc((void**)&d_all_hits, (size_t)n_shards * n_hit * sizeof(xgm_hit))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&d_all_hdrs, (size_t)n_shards * nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&d_out_hits, n_hit * sizeof(xgm_hit))) != hipSuccess) break;
-        if ((e = hipMalloc((void**)&d_out_hdrs, (size_t)nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
-        for (uint32_t s = 0; s < n_shards && rc == XGM_OK && e == hipSuccess; ++s) {
-            if (shards[s]->device == dev0) {                       /* straight into its slice of the gathered arrays */
-                d_hits[s] = d_all_hits + (size_t)s * n_hit;
-                d_hdrs[s] = d_all_hdrs + (size_t)s * nq;
-            } else {
-                if ((rc = use_device(shards[s]->device))) break;
-                if ((e = hipMalloc((void**)&d_hits[s], n_hit * sizeof(xgm_hit))) != hipSuccess) break;
-                if ((e = hipMalloc((void**)&d_hdrs[s], (size_t)nq * sizeof(xgm_result_hdr))) != hipSuccess) break;
-            }
-            rc = xgm_search_batch_device(shards[s], plans[s].data(), nq, k_stride, d_hits[s], d_hdrs[s]);
+    /* grow the persistent buffers (first call, or a larger batch than ever before) */
+    if (n_hit > c->cap_hit || nq > c->cap_nq) {
+        for (ShardDev& d : c->devs) { if (hipSetDevice(d.device) == hipSuccess) hipDeviceSynchronize(); }
+        shard_ctx_free_buffers(c);
+        const size_t ch = std::max(n_hit, c->cap_hit), cn = std::max<size_t>(nq, c->cap_nq);
+        for (ShardDev& d : c->devs) {
+            if ((rc = use_device(d.device))) return rc;
+            if ((e = hipMalloc((void**)&d.all_hits, (size_t)n_shards * ch * sizeof(xgm_hit))) != hipSuccess) break;
+            if ((e = hipMalloc((void**)&d.all_hdrs, (size_t)n_shards * cn * sizeof(xgm_result_hdr))) != hipSuccess) break;
         }
-        if (rc != XGM_OK || e != hipSuccess) break;
-        /* the "all-gather": every shard's list to shards[0]'s device */
-        for (uint32_t s = 0; s < n_shards && e == hipSuccess; ++s) {
-            if ((rc = use_device(shards[s]->device))) break;
-            if ((e = hipDeviceSynchronize()) != hipSuccess) break;
-            if (shards[s]->device != dev0) {
-                e = hipMemcpyPeer(d_all_hits + (size_t)s * n_hit, dev0, d_hits[s], shards[s]->device, n_hit * sizeof(xgm_hit));
-                if (e == hipSuccess)
-                    e = hipMemcpyPeer(d_all_hdrs + (size_t)s * nq, dev0, d_hdrs[s], shards[s]->device, (size_t)nq * sizeof(xgm_result_hdr));
-            }
+        if (e == hipSuccess && !(rc = use_device(c->devs[0].device))) {
+            if ((e = hipMalloc((void**)&c->d_out_hits, ch * sizeof(xgm_hit))) == hipSuccess)
+                e = hipMalloc((void**)&c->d_out_hdrs, cn * sizeof(xgm_result_hdr));
         }
-        if (rc != XGM_OK || e != hipSuccess) break;
-        if ((rc = use_device(dev0))) break;
-        if ((rc = xgm_merge_shards_device(shards[0], d_all_hits, d_all_hdrs, n_shards, nq, k_stride, kq.data(), d_out_hits, d_out_hdrs))) break;
-        if ((e = hipDeviceSynchronize()) != hipSuccess) break;
-        std::vector<xgm_hit> h_hits(n_hit);
-        if ((e = hipMemcpy(h_hits.data(), d_out_hits, n_hit * sizeof(xgm_hit), hipMemcpyDeviceToHost)) != hipSuccess) break;
-        if ((e = hipMemcpy(hdrs, d_out_hdrs, (size_t)nq * sizeof(xgm_result_hdr), hipMemcpyDeviceToHost)) != hipSuccess) break;
-        for (uint32_t i = 0; i < nq; ++i)        /* only the valid prefix of each row is defined on the device */
-            memcpy(hits + (size_t)i * k_stride, h_hits.data() + (size_t)i * k_stride, (size_t)hdrs[i].n_hits * sizeof(xgm_hit));
-    } while (0);
-    if (e != hipSuccess && rc == XGM_OK) rc = xgm_launch_error("xgm_search_sharded", (int)e, hipGetErrorString(e));
+        if (rc) return rc;
+        if (e != hipSuccess) { shard_ctx_free_buffers(c); return xgm_launch_error("hipMalloc(shard buffers)", (int)e, hipGetErrorString(e)); }
+        c->cap_hit = ch; c->cap_nq = cn;
+    }
+    const size_t down = n_hit * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
+    if ((rc = grow_pinned(&c->h_out, &c->cap_hout, down))) return rc;
+    shard_ctx_try_rccl(c);
+    ++c->calls;
+
+    /* the gathered arrays of THIS call are dense [n_shards][nq][k_stride] / [n_shards][nq] at the head of the buffers */
+    /* 1. every shard's search, enqueued on its device's stream — nothing waits yet */
     for (uint32_t s = 0; s < n_shards; ++s) {
-        if (shards[s]->device != dev0) {
-            hipSetDevice(shards[s]->device);
-            if (d_hits[s]) hipFree(d_hits[s]);
-            if (d_hdrs[s]) hipFree(d_hdrs[s]);
+        ShardDev& d = c->devs[c->dev_of[s]];
+        if ((rc = search_batch_device_on(shards[s], d.stream, plans[s].data(), nq, k_stride, d.all_hits + (size_t)s * n_hit,
+                                         d.all_hdrs + (size_t)s * nq)))
+            break;
+    }
+    /* 2. the exchange */
+    ShardDev& d0 = c->devs[0];
+    if (rc == XGM_OK && c->use_rccl) {
+        RcclApi& api = rccl_api();
+        int nrc = api.GroupStart();
+        for (size_t r = 0; r < c->devs.size() && nrc == 0; ++r) {
+            ShardDev& d = c->devs[r];
+            nrc = api.AllGather(d.all_hits + r * n_hit, d.all_hits, n_hit * sizeof(xgm_hit), /*ncclUint8*/ 1, d.comm, d.stream);
+            if (nrc == 0) nrc = api.AllGather(d.all_hdrs + r * nq, d.all_hdrs, (size_t)nq * sizeof(xgm_result_hdr), 1, d.comm, d.stream);
+        }
+        const int nrc2 = api.GroupEnd();
+        if (nrc || nrc2) rc = xgm_set_error(XGM_E_DEVICE, "ncclAllGather failed (%d)", nrc ? nrc : nrc2);
+        ++c->rccl_calls;
+    } else if (rc == XGM_OK) {
+        for (uint32_t s = 0; s < n_shards && e == hipSuccess; ++s) {
+            ShardDev& d = c->devs[c->dev_of[s]];
+            if (c->dev_of[s] == 0) continue;
+            if ((e = hipMemcpyPeerAsync(d0.all_hits + (size_t)s * n_hit, d0.device, d.all_hits + (size_t)s * n_hit, d.device,
+                                        n_hit * sizeof(xgm_hit), d.stream)) != hipSuccess) break;
+            e = hipMemcpyPeerAsync(d0.all_hdrs + (size_t)s * nq, d0.device, d.all_hdrs + (size_t)s * nq, d.device,
+                                   (size_t)nq * sizeof(xgm_result_hdr), d.stream);
+        }
+        for (size_t r = 1; r < c->devs.size() && e == hipSuccess; ++r) {
+            if (hipSetDevice(c->devs[r].device) != hipSuccess) { e = hipErrorInvalidDevice; break; }
+            if ((e = hipEventRecord(c->devs[r].ev, c->devs[r].stream)) != hipSuccess) break;
+        }
+        if (e == hipSuccess && !(rc = use_device(d0.device)))
+            for (size_t r = 1; r < c->devs.size() && e == hipSuccess; ++r) e = hipStreamWaitEvent(d0.stream, c->devs[r].ev, 0);
+    }
+    /* 3. merge on shards[0]'s device, one download, ONE wait */
+    if (rc == XGM_OK && e == hipSuccess && !(rc = use_device(d0.device))) {
+        rc = merge_shards_device_on(shards[0], d0.stream, d0.all_hits, d0.all_hdrs, n_shards, nq, k_stride, kq.data(), c->d_out_hits, c->d_out_hdrs);
+        xgm_hit* h_hits = (xgm_hit*)c->h_out;
+        xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + n_hit);
+        if (rc == XGM_OK) e = hipMemcpyAsync(h_hits, c->d_out_hits, n_hit * sizeof(xgm_hit), hipMemcpyDeviceToHost, d0.stream);
+        if (rc == XGM_OK && e == hipSuccess) e = hipMemcpyAsync(h_hdrs, c->d_out_hdrs, (size_t)nq * sizeof(xgm_result_hdr), hipMemcpyDeviceToHost, d0.stream);
+        if (rc == XGM_OK && e == hipSuccess) e = hipStreamSynchronize(d0.stream);
+        if (rc == XGM_OK && e == hipSuccess) {
+            memcpy(hdrs, h_hdrs, (size_t)nq * sizeof(xgm_result_hdr));
+            for (uint32_t i = 0; i < nq; ++i)        /* only the valid prefix of each row is defined on the device */
+                memcpy(hits + (size_t)i * k_stride, h_hits + (size_t)i * k_stride, (size_t)hdrs[i].n_hits * sizeof(xgm_hit));
         }
     }
-    hipSetDevice(dev0);
-    if (d_all_hits) hipFree(d_all_hits);
-    if (d_all_hdrs) hipFree(d_all_hdrs);
-    if (d_out_hits) hipFree(d_out_hits);
-    if (d_out_hdrs) hipFree(d_out_hdrs);
+    if (rc != XGM_OK || e != hipSuccess) {
+        /* leave no work in flight behind a failed call */
+        for (ShardDev& d : c->devs) { if (hipSetDevice(d.device) == hipSuccess) hipStreamSynchronize(d.stream); }
+        if (rc == XGM_OK) rc = xgm_launch_error("xgm_search_sharded", (int)e, hipGetErrorString(e));
+    }
     return rc;
+}
+
+/* Diagnostics: how the last xgm_search_sharded on this shard list exchanged the per-shard lists.
+ * out[0] calls, out[1] calls that used the RCCL all-gather, out[2] devices, out[3] shards. */
+extern "C" int xgm_debug_sharded_info(const xgm_index* owner, uint64_t* out4) {
+    if (!owner || !out4 || !owner->shard_ctx) return xgm_set_error(XGM_E_INVALID, "no sharded search has run from this index");
+    const XgmShardCtx* c = owner->shard_ctx;
+    out4[0] = c->calls; out4[1] = c->rccl_calls; out4[2] = c->devs.size(); out4[3] = c->shards.size();
+    return XGM_OK;
 }
 
 /* ------------------------------------------------------------------ diagnostics -------------- */
@@ -921,6 +1181,54 @@ extern "C" int64_t xgm_debug_read_doclen(xgm_index* idx, uint32_t* out, uint64_t
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, idx->d_sections[XGM_S_DOCLEN], n * 4, hipMemcpyDeviceToHost));
     return (int64_t)n;
+}
+
+/* Copy one term's positions (flat, in posting order: Σ wdf entries) to the host; returns their number. */
+extern "C" int64_t xgm_debug_read_positions(xgm_index* idx, uint32_t term_id, uint32_t* out, uint64_t cap) {
+    if (!idx || (!out && cap)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (term_id >= idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "term id out of range");
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    if (!idx->hdr.has_positions) return 0;
+    uint64_t tp[2];
+    HIP_TRY(hipMemcpy(tp, (const uint64_t*)idx->d_sections[XGM_S_TERM_POS] + term_id, sizeof tp, hipMemcpyDeviceToHost));
+    const uint64_t n = tp[1] - tp[0];
+    if (cap < n) return xgm_set_error(XGM_E_INVALID, "buffer too small");
+    if (n) HIP_TRY(hipMemcpy(out, (const uint32_t*)idx->d_sections[XGM_S_POSITIONS] + tp[0], n * 4, hipMemcpyDeviceToHost));
+    return (int64_t)n;
+}
+
+/* Traffic model of the LAST batch launched on this index (wave kernels, tallying instantiation: xgm_index_set_profiling
+ * bit 1): the per-unit tallies of what the match kernel requested from memory, summed over the batch's work units.
+ * Waits for the device.  Layout of out[0..n): include/xgm.h. */
+extern "C" int xgm_last_batch_traffic(xgm_index* idx, uint64_t* out, uint32_t n) {
+    if (!idx || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    uint64_t t[XGM_TRAFFIC_FIELDS] = {};
+    if (!idx->last_ghdr || idx->last_n_work == 0) return xgm_set_error(XGM_E_INVALID, "no batch has run on this index");
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<xgm_group_hdr> h(idx->last_n_work);
+    HIP_TRY(hipMemcpy(h.data(), idx->last_ghdr, h.size() * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));
+    for (const xgm_group_hdr& g : h) {
+        t[0] += g.c_bmp_words; t[1] += g.c_probes; t[2] += g.c_blk_words; t[3] += g.c_hdrs;
+        t[4] += g.c_doclen; t[5] += g.c_aux_words; t[6] += g.n_cand; t[7] += g.c_pos;
+        t[8] += g.c_probes_raw; t[9] += g.c_doclen_raw;
+    }
+    for (uint32_t i = 0; i < n && i < XGM_TRAFFIC_FIELDS; ++i) out[i] = t[i];
+    return XGM_OK;
+}
+
+/* Diagnostics: mean host time of xgm_plan_query per query, in microseconds, over `reps` passes of the list. */
+extern "C" double xgm_debug_plan_us(const xgm_index* idx, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t reps) {
+    if (!idx || !descs || nq == 0 || reps == 0) return -1.0;
+    xgm_query q;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t r = 0; r < reps; ++r)
+        for (uint32_t i = 0; i < nq; ++i)
+            if (xgm_plan_query(idx, &descs[i], gs ? &gs[i] : nullptr, &q) < 0) return -1.0;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    return us / ((double)nq * reps);
 }
 
 int xgm_phase_cycles_fetch(unsigned long long* out8);

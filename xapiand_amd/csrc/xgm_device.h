@@ -67,6 +67,19 @@ typedef struct {
     uint32_t n_cand;
     uint32_t pad;
     uint64_t t_start, t_end;   /* s_memtime at unit start / end (diagnostics: occupancy timeline) */
+    /* Traffic model of the wave kernels: what the unit REQUESTED from memory, tallied in scalar registers
+     * (wave-uniform counts, no vector register cost).  Host: xgm_last_batch_traffic → bench.py's
+     * roofline.model_min_bytes. */
+    uint64_t c_pos;            /* PHRASE: positions of the query's terms in the conjunction's survivors (P of SURVEY §8(d)) */
+    uint32_t c_bmp_words;      /* container bitmap words read (streamed, 16 B per lane)                         */
+    uint32_t c_probes;         /* distinct 64-B memory sectors touched by the one-byte container probes (per round and term) */
+    uint32_t c_blk_words;      /* bit-packed payload words of the posting blocks decoded (streamed)             */
+    uint32_t c_hdrs;           /* 12-byte block headers read                                                     */
+    uint32_t c_doclen;         /* distinct 64-B sectors touched by the doclen[] gathers (per round)              */
+    uint32_t c_aux_words;      /* other streamed words: run-table pass over blk_first, container directory, histogram */
+    uint32_t c_probes_raw;     /* container probes issued (lanes)                                                  */
+    uint32_t c_doclen_raw;     /* doclen gathers issued (lanes)                                                    */
+    uint32_t c_pad[2];
 } xgm_group_hdr;
 
 #endif

@@ -30,6 +30,7 @@ int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes);
 
 /* Per-thread scratch for searches (device + pinned host buffers), see xgm_api.cc. */
 struct XgmScratch;
+struct XgmShardCtx;      /* persistent buffers / streams / RCCL communicator of one shard list (xgm_search_sharded) */
 
 struct xgm_index {
     int device = -1;
@@ -39,6 +40,8 @@ struct xgm_index {
     std::vector<uint64_t> term_blk, term_word;
     std::vector<uint64_t> str_off;
     std::vector<char> str_bytes;
+    std::vector<uint32_t> term_hash;   /* open-addressing table over the term strings → term id (xgm_lookup_term_id) */
+    std::once_flag term_hash_once;
     /* device */
     void* d_blob = nullptr;            /* whole segment (file-loaded) or nullptr when sections are separate */
     void* d_sections[XGM_S_COUNT] = {};/* device pointer of each device-resident section             */
@@ -53,12 +56,16 @@ struct xgm_index {
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
+    bool tally = false;                /* launch the wave kernels' tallying instantiation (xgm_index_set_profiling bit 1) */
     const char* last_kernel = "";      /* diagnostics: which match kernel the last batch used */
+    void* last_ghdr = nullptr;         /* device: per-unit summaries of the last batch (xgm_last_batch_traffic) */
+    uint32_t last_n_work = 0;
     std::vector<std::pair<void*, void*>> prof_events;   /* hipEvent_t pairs around the match kernel */
     size_t prof_used = 0;
     std::mutex scratch_mu;
     std::vector<XgmScratch*> scratch_pool;
     uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
+    XgmShardCtx* shard_ctx = nullptr;  /* when this index is shards[0] of an xgm_search_sharded list */
 };
 
 int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id);

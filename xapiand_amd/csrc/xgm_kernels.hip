@@ -474,7 +474,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
         out[i] = c;
     }
     if (tid == 0) {
-        xgm_group_hdr h;
+        xgm_group_hdr h = {};
         h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
         h.t_start = 0; h.t_end = 0;
         ghdr_out[wk.slot] = h;
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
         out[i] = c;
     }
     if (tid == 0) {
-        xgm_group_hdr h;
+        xgm_group_hdr h = {};
         h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         ghdr_out[wk.slot] = h;
@@ -1013,7 +1013,7 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
  * instantiations, so that the plain conjunction pays nothing for them. */
-template <typename TabT, bool PHRASE, int SIDED>
+template <typename TabT, bool PHRASE, int SIDED, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -1033,6 +1033,15 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
      * conjunction / FILTER has TR == T. */
     const uint32_t TR = SIDED ? q.n_req : T;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
+    /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
+    uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
+    unsigned long long cn_pos = 0;                                 /* PHRASE only, per lane */
+    /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
+    auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+        return (uint32_t)__popcll(__ballot(valid && (lane == 0u || (prev >> sh) != (key >> sh))));
+    };
+#define XGM_SU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
 
     /* private LDS slice */
     unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2);
@@ -1083,6 +1092,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
             const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
             const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+            if (TALLY) { cn_aux += e - c; }
             if (lane == t) {
                 have_reg = true;
                 tbase_reg = seg.term_word[id];
@@ -1139,6 +1149,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     auto issue_headers = [&](uint32_t x) {
         if (td > 0u) {
             const uint32_t r0 = rs[x], n0b = re[x] - r0;
+            if (TALLY) { cn_hdr += XGM_SU(n0b < CHUNKB ? n0b : CHUNKB); }
             if (lane < n0b && lane < CHUNKB) {
                 h0_meta = seg.blk_meta[r0 + lane]; h0_first = seg.blk_first[r0 + lane]; h0_word = seg.blk_word[r0 + lane];
                 if (PHRASE) h0_pos = seg.blk_pos[r0 + lane];
@@ -1146,6 +1157,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         }
         if (td > 1u) {
             const uint32_t rb = rs[1u * SPG + x], nb = re[1u * SPG + x] - rb;
+            if (TALLY) { cn_hdr += XGM_SU(nb); }
             if (lane < nb) {
                 ha_meta = seg.blk_meta[rb + lane]; ha_first = seg.blk_first[rb + lane]; ha_word = seg.blk_word[rb + lane];
                 ha_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
@@ -1154,6 +1166,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         }
         if (td > 2u) {
             const uint32_t rb = rs[2u * SPG + x], nb = re[2u * SPG + x] - rb;
+            if (TALLY) { cn_hdr += XGM_SU(nb); }
             if (lane < nb) {
                 hb_meta = seg.blk_meta[rb + lane]; hb_first = seg.blk_first[rb + lane]; hb_word = seg.blk_word[rb + lane];
                 hb_next = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
@@ -1161,6 +1174,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             }
         }
         if (SIDED) hc_off = 0;                                     /* 0 = no container (for this term / in this stripe) */
+        if (TALLY) { cn_aux += T - td; }
         if (lane >= td && lane < T && (!SIDED || dense_reg != 0xFFFFFFFFu)) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
     };
 
@@ -1175,12 +1189,14 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             const uint32_t o = c0 + lane;
             const bool valid = o < n_c;
             const uint32_t slot = valid ? c_slot[o] : 0u;
+            const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
             for (uint32_t t0 = t_lo; t0 < T; t0 += 4u) {
                 uint32_t wv[4];
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; ++u) {
                     wv[u] = 0;
                     const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, (t0 + u) & 63u);
+                    if (TALLY) { if (t0 + u < T && (!SIDED || oo)) { cn_probe += sec; cn_probe_raw += n_c - c0 < 64u ? n_c - c0 : 64u; } }
                     if (t0 + u < T && valid && (!SIDED || oo))
                         wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
                 }
@@ -1206,13 +1222,15 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             bool take = false;
             uint64_t wb = 0;
             uint32_t did = 0, subqs = 0;
+            bool pass = false;
             if (o < n_c) {
-                bool pass = true;
+                pass = true;
                 for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
                 for (uint32_t t = TR; t < T; ++t) pass = pass && (!((q.neg_mask >> t) & 1u) || c_w[(size_t)t * CAND + o] == 0);   /* AND_NOT */
                 if (PHRASE && phrase && pass) {
                     /* K6: ExactPhrasePostList / PhrasePostList::test_doc over the terms' position lists */
                     PosList pl[XGM_PHRASE_MAX_TERMS];
+                    if (TALLY) { for (uint32_t t = 0; t < T; ++t) cn_pos += (uint32_t)c_w[(size_t)t * CAND + o] - 1u; }
                     for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
                         const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
                         pl[t].p = seg.positions + tp + c_pos[(size_t)t * CAND + o];
@@ -1271,6 +1289,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 }
                 for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * CAND + o] = 0;
             }
+            if (TALLY) { if (!(dl_ready && i0 < 256u)) { const uint32_t n_ = (uint32_t)__popcll(__ballot(pass)); cn_dl += n_; cn_dl_raw += n_; } }
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; if (MAYBE) tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
@@ -1287,6 +1306,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         if (td == 0u) {
             /* ---- every term dense: candidates = AND of the containers' bitmaps (4 words per lane) ---- */
             uint32_t m[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (TALLY) { cn_bmpw += (TR < 4u ? TR : 4u) * NW; }
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
                 if (t < TR) {
@@ -1329,6 +1349,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             /* ---- P1: term-0 blocks of the chunk → candidates (ordinals follow docid order) ---- */
             uint32_t m0 = h0_meta, f0 = h0_first, w0 = h0_word, ps0 = h0_pos;
             if (cb != r0) {
+                if (TALLY) { cn_hdr += XGM_SU(nblk0); }
                 m0 = lane < nblk0 ? seg.blk_meta[cb + lane] : 0u;
                 f0 = lane < nblk0 ? seg.blk_first[cb + lane] : 0u;
                 w0 = lane < nblk0 ? seg.blk_word[cb + lane] : 0u;
@@ -1343,6 +1364,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 p0[j] = Words4{0, 0, 0, 0};
                 if (j < nblk0) {
                     const uint32_t mj = __builtin_amdgcn_readlane(m0, j);
+                    if (TALLY) { cn_blkw += payload_words(mj) - 2u; }
                     if (lane * 4u < payload_words(mj)) p0[j] = *reinterpret_cast<const Words4*>(seg.words + tbase(0) + __builtin_amdgcn_readlane(w0, j) + lane * 4u);
                 }
             }
@@ -1395,7 +1417,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             for (uint32_t c = 0; c < 4u; ++c) {
                 const uint32_t o = lane + c * 64u;
                 dl[c] = o < n_c ? seg.doclen[stripe_base + c_slot[o]] : 0u;
+                if (TALLY) { cn_dl += tally_sectors(o < n_c, o < n_c ? (uint32_t)c_slot[o] : 0u, 4u); }
             }
+            if (TALLY) { cn_dl_raw += n_c < 256u ? n_c : 256u; }
 
             /* ---- P3a: sparse other terms [1, td), two at a time; only blocks whose 128-slot buckets hold a candidate ---- */
             auto bucket_need = [&](uint32_t first, uint32_t nfirst) {
@@ -1416,6 +1440,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                     b_meta = hb_meta; b_first = hb_first; b_word = hb_word; b_next = hb_next; b_pos = hb_pos;
                 } else {
                     a_meta = a_first = a_word = 0; a_next = 0xFFFFFFFFu;
+                    if (TALLY) { cn_hdr += XGM_SU(nba + nbb); }
                     const uint32_t rba = rs[ta * SPG + sl];
                     if (lane < nba) {
                         a_meta = seg.blk_meta[rba + lane]; a_first = seg.blk_first[rba + lane]; a_word = seg.blk_word[rba + lane];
@@ -1448,6 +1473,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                             jj[u] = (uint32_t)__builtin_ctzll(mask_a);
                             mask_a &= mask_a - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(a_meta, jj[u]);
+                            if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
                             if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tba + __builtin_amdgcn_readlane(a_word, jj[u]) + lane * 4u);
                             n_a = u + 1u;
                         }
@@ -1459,6 +1485,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                             jj[u] = (uint32_t)__builtin_ctzll(mask_b);
                             mask_b &= mask_b - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(b_meta, jj[u]);
+                            if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
                             if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbb + __builtin_amdgcn_readlane(b_word, jj[u]) + lane * 4u);
                             n_b = u - 3u;
                         }
@@ -1513,7 +1540,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 for (uint32_t j = 0; j < nbx; ++j) {
                     const uint32_t xmeta = seg.blk_meta[rbx + j], xfirst = seg.blk_first[rbx + j];
                     const uint32_t xnext = j + 1u < nbx ? seg.blk_first[rbx + j + 1u] : 0xFFFFFFFFu;
+                    if (TALLY) { cn_hdr += 1u; }
                     if (!bucket_need(xfirst, xnext)) continue;
+                    if (TALLY) { cn_blkw += XGM_SU(payload_words(xmeta)) - 2u; }
                     if (lane * 4u < payload_words(xmeta)) {
                         const Words4 pvx = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rbx + j] + lane * 4u);
                         stage[lane * 4u] = pvx.a; stage[lane * 4u + 1] = pvx.b; stage[lane * 4u + 2] = pvx.c; stage[lane * 4u + 3] = pvx.d;
@@ -1549,6 +1578,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     /* ---- unit epilogue ---- */
     if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
     for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
+    if (PHRASE && TALLY) { for (int sh = 32; sh > 0; sh >>= 1) cn_pos += (unsigned long long)__shfl_xor((long long)cn_pos, sh); }
     const uint32_t n_out = tkn < k ? tkn : k;
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = lane; i < n_out; i += 64u) {
@@ -1560,8 +1590,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         xgm_group_hdr h;
         h.matches = matches; h.n_cand = n_out; h.pad = 0;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
+        h.c_pos = cn_pos; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
+        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = h.c_pad[1] = 0;
         ghdr_out[wk.slot] = h;
     }
+#undef XGM_SU
 }
 
 /* ---------------------------------------------------------------- merge kernel --------------- */
@@ -1869,15 +1902,22 @@ size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t ca
     return XGM_WAVES * andw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg, phrase, sided);
 }
 
-template <typename TabT, bool PHRASE, int SIDED>
-static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
+template <typename TabT, bool PHRASE, int SIDED, bool TALLY>
+static int launch_andw_inst(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
     const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
-    auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED>;
+    auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED, TALLY>;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
     hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
+}
+
+/* L.tally: the instantiation that also fills the traffic tallies of xgm_group_hdr (xgm_last_batch_traffic) — a
+ * measurement build of the same code; the production instantiation carries none of it */
+template <typename TabT, bool PHRASE, int SIDED>
+static int launch_andw_variant(const xgm_match_launch& L, size_t smem, hipStream_t stream) {
+    return L.tally ? launch_andw_inst<TabT, PHRASE, SIDED, true>(L, smem, stream) : launch_andw_inst<TabT, PHRASE, SIDED, false>(L, smem, stream);
 }
 
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {

@@ -16,6 +16,7 @@ struct xgm_match_launch {
     uint32_t cap;                     /* top-k buffer capacity, power of two >= k_max + XGM_WG    */
     uint32_t k_stride;                /* candidates reserved per (query, group)                   */
     bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
+    bool tally = false;               /* wave kernels: also fill the traffic tallies of xgm_group_hdr (measurement)  */
     int sided = 0;                    /* conjunction batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
     xgm_group_hdr* ghdr;              /* device, [n_work]                                         */

@@ -128,7 +128,7 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
 
 typedef double orw_d8 __attribute__((ext_vector_type(8)));
 
-template <typename TabT>
+template <typename TabT, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -144,6 +144,14 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
+    /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
+    uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
+    /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
+    auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+        return (uint32_t)__popcll(__ballot(valid && (lane == 0u || (prev >> sh) != (key >> sh))));
+    };
+#define XGM_SU(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
     /* the in-place summation program of queries with <= 8 terms, in scalar registers */
     const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
     const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
@@ -226,6 +234,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
         const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
         const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+        if (TALLY) { cn_aux += e - c; }
         for (uint32_t i = c + lane; i < e; i += 64u) {
             const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
             const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
@@ -273,6 +282,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
             if (u < n_sp) {
                 const uint32_t rb = rs[sp_t[u] * SPG + x], nb = re[sp_t[u] * SPG + x] - rb;
+                if (TALLY) { cn_hdr += XGM_SU(nb); }
                 if (lane < nb) {
                     hm[u] = seg.blk_meta[rb + lane]; hf[u] = seg.blk_first[rb + lane]; hw[u] = seg.blk_word[rb + lane];
                     hn[u] = lane + 1u < nb ? seg.blk_first[rb + lane + 1u] : 0xFFFFFFFFu;
@@ -280,6 +290,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             }
         }
         hc_off = 0;
+        if (TALLY) { cn_aux += (uint32_t)__popcll(dense_mask); }
         if (present_reg && dense_reg != kNoDense) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
     };
 
@@ -300,11 +311,15 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         const bool valid = o < n_c;
         const uint32_t slot = valid ? (uint32_t)c_slot[o] : 0u;
         pf_dl = valid ? seg.doclen[stripe_base + slot] : 1u;
+        const uint32_t n_valid = n_c - i0 < 64u ? n_c - i0 : 64u;
+        const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
+        if (TALLY) { cn_dl += tally_sectors(valid, slot, 4u); cn_dl_raw += n_valid; }
 #pragma unroll
         for (uint32_t t = 0; t < 8u; ++t) {
             pf_pb[t] = 0;
             if (fast && ((dense_mask >> t) & 1ull)) {
                 const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t);
+                if (TALLY) { if (oo) { cn_probe += sec; cn_probe_raw += n_valid; } }
                 if (oo && valid) pf_pb[t] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
             }
         }
@@ -459,6 +474,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             /* ---- global threshold: highest histogram bucket with >= k documents at or above it ---- */
             uint32_t hc[4] = {0, 0, 0, 0};
             if (prune) {
+                if (TALLY) { cn_aux += XGM_OR_HIST; }
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -506,6 +522,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 for (uint32_t u = 0; u < 4u; ++u) {
                     tt[u] = 0; oo[u] = 0;
                     if (dm) { tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u; oo[u] = __builtin_amdgcn_readlane(hc_cur, tt[u]); }
+                    if (TALLY) { if (oo[u]) cn_bmpw += NW; }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
                         x[u][i] = 0;
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
                             bmask[u] &= bmask[u] - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
+                            if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
                             if (lane * 4u < payload_words(bm))
                                 pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
                         }
@@ -614,6 +632,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
                     for (uint32_t j = 0; j < nb; ++j) {
                         const uint32_t meta = seg.blk_meta[rb0 + j], first = seg.blk_first[rb0 + j];
+                        if (TALLY) { cn_hdr += 1u; cn_blkw += XGM_SU(payload_words(meta)) - 2u; }
                         Words4 pv = Words4{0, 0, 0, 0};
                         if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
                         orw_block<TabT, false>(pv, meta, first, stage, lane, stripe_base, bm_all, ((ess_mask >> t) & 1ull) ? bm_ess : bm_ne,
@@ -641,6 +660,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 for (uint32_t i = 0; i < 4u; ++i) e[i] = es[i];
                 for (uint64_t dm = dense_mask & ess_mask; dm; dm &= dm - 1u) {
                     const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, (uint32_t)__builtin_ctzll(dm));
+                    if (TALLY) { if (oo) cn_bmpw += NW; }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
                         const uint32_t w = lane * 4u + i;
@@ -723,6 +743,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                 tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u;
                                 const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, tt[u]);
                                 if (oo) {
+                                    if (TALLY) { cn_probe += tally_sectors(v0, slot0, 6u) + tally_sectors(v1, slot1, 6u); cn_probe_raw += n_c - c0 < 128u ? n_c - c0 : 128u; }
                                     const unsigned char* wb = seg.dense_data + (size_t)oo * 16 + (size_t)NW * 4;
                                     if (v0) wv0[u] = wb[slot0];
                                     if (v1) wv1[u] = wb[slot1];
@@ -765,6 +786,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                 jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
                                 bmask[u] &= bmask[u] - 1u;
                                 const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
+                                if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
                                 if (lane * 4u < payload_words(bm))
                                     pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
                             }
@@ -782,7 +804,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         for (uint32_t j = 0; j < nb; ++j) {
                             const uint32_t meta = seg.blk_meta[rb0 + j], first = seg.blk_first[rb0 + j];
                             const uint32_t nfirst = j + 1u < nb ? seg.blk_first[rb0 + j + 1u] : 0xFFFFFFFFu;
+                            if (TALLY) { cn_hdr += 1u; }
                             if (!bucket_need(first, nfirst)) continue;
+                            if (TALLY) { cn_blkw += XGM_SU(payload_words(meta)) - 2u; }
                             Words4 pv = Words4{0, 0, 0, 0};
                             if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
                             orw_block<TabT, true>(pv, meta, first, stage, lane, stripe_base, bm_ess, nullptr, nullptr, rankw, c_w + (size_t)t * kOrwCand, wlo, whi);
@@ -832,8 +856,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         xgm_group_hdr h;
         h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
+        h.c_pos = 0; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
+        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = h.c_pad[1] = 0;
         ghdr_out[wk.slot] = h;
     }
+#undef XGM_SU
 }
 
 template <class K>
@@ -874,19 +901,19 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
     const int flags = no_prune ? 0 : ((no_phase_a ? 1 : 3) | (no_sum ? 4 : 0));
     const size_t smem = xgm_orw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);
-    static std::atomic<size_t> seen8{0}, seen16{0};
-    int rc;
-    if (L.wide) {
-        auto kern = xgm_orw_kernel<uint16_t>;
-        if ((rc = orw_ensure_dyn_smem(kern, smem, seen16))) return rc;
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap,
-                           L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);
-    } else {
-        auto kern = xgm_orw_kernel<uint8_t>;
-        if ((rc = orw_ensure_dyn_smem(kern, smem, seen8))) return rc;
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap,
-                           L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);
-    }
+    int rc = XGM_OK;
+#define ORW_LAUNCH(TABT, TL)                                                                                                         \
+    do {                                                                                                                             \
+        auto kern = xgm_orw_kernel<TABT, TL>;                                                                                        \
+        static std::atomic<size_t> seen{0};                                                                                          \
+        if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
+                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
+    } while (0)
+    /* L.tally: the instantiation that also fills the traffic tallies of xgm_group_hdr (measurement only) */
+    if (L.wide) { if (L.tally) ORW_LAUNCH(uint16_t, true); else ORW_LAUNCH(uint16_t, false); }
+    else { if (L.tally) ORW_LAUNCH(uint8_t, true); else ORW_LAUNCH(uint8_t, false); }
+#undef ORW_LAUNCH
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("xgm_orw_kernel launch", (int)e, hipGetErrorString(e));
     return XGM_OK;

@@ -23,12 +23,24 @@ HDR_F64 = 4      # an xgm_result_hdr is 32 bytes
 
 
 class ShardedSearcher:
-    def __init__(self, shard, rank, world, device, group=None, search_fn=None, merge_fn=None):
-        """`shard` exposes get_doccount/get_total_length/has_positions/get_termfreq (a Database does)."""
+    def __init__(self, shard, rank, world, device, group=None, search_fn=None, merge_fn=None, force_collective=False):
+        """`shard` exposes get_doccount/get_total_length/has_positions/get_termfreq (a Database does).
+        force_collective: take the all-gather + merge path even with world == 1 (a 1-rank RCCL group on a
+        single-GPU box exercises exactly the code the 8-GPU run uses).
+
+        Stream discipline of the device path: every xgm_* call of a batch is enqueued on torch's CURRENT stream of
+        `device` (bound per call with xgm_index_set_stream), the stream the collectives are ordered against, so the
+        merge cannot read the gathered records before the all-gather has produced them."""
         self.shard, self.rank, self.world, self.device, self.group = shard, rank, world, device, group
         self.search_fn = search_fn or self._device_search
         self.merge_fn = merge_fn or self._device_merge
+        self.force_collective = force_collective
         self._bufs = {}
+        self._host_collectives = False
+        if world > 1 or force_collective:
+            # gloo has no device all-gather: stage the (tiny) records through pinned host memory — the path of the
+            # single-GPU test that runs two ranks on one device
+            self._host_collectives = torch.device(device).type == "cuda" and dist.get_backend(group) == "gloo"
 
     # -- statistics ---------------------------------------------------------------------------------
     def merged_stats(self, queries):
@@ -36,7 +48,7 @@ class ShardedSearcher:
         terms = sorted({t for q in queries for t in q.terms})
         vec = [self.shard.get_total_length(), self.shard.get_doccount(), 1 if self.shard.has_positions() else 0]
         vec += [self.shard.get_termfreq(t) for t in terms]
-        t = torch.tensor(vec, dtype=torch.int64, device=self.device)
+        t = torch.tensor(vec, dtype=torch.int64, device="cpu" if self._host_collectives else self.device)
         if self.world > 1:
             dist.all_reduce(t, group=self.group)
         vals = t.tolist()
@@ -55,6 +67,22 @@ class ShardedSearcher:
         stats = self.merged_stats(queries)
         return [plan(self.shard, q, 0, first + maxitems, global_stats=gs) for q, gs in zip(queries, stats)]
 
+    def describe(self, queries, first, maxitems):
+        """The queries as the hook receives them, plus their merged statistics: ((xgm_query_desc * n), (xgm_global_stats * n))
+        for run_descs.  The per-shard request is (0, first + maxitems) exactly as Xapiand issues it (handler.cc:1532-1549)."""
+        from .enquire import BM25Weight, _desc
+        stats = self.merged_stats(queries)
+        n = len(queries)
+        descs = (_lib.QueryDesc * n)()
+        gs = (_lib.GlobalStats * n)()
+        self._keep = []
+        for i, q in enumerate(queries):
+            d = _desc(q, 0, first + maxitems, 0, BM25Weight())
+            self._keep.append(d)
+            descs[i] = d
+            gs[i] = stats[i]
+        return descs, gs
+
     # -- one batch ----------------------------------------------------------------------------------
     def _buffers(self, nq, k):
         key = (nq, k)
@@ -69,19 +97,51 @@ class ShardedSearcher:
         Returns (hits, hdrs) tensors holding the merged result with GLOBAL docids on every rank."""
         b = self._buffers(nq, k)
         self.search_fn(batch, nq, k, b["hits"], b["hdrs"])
-        if self.world == 1:
+        return self._gather_merge(b, nq, k)
+
+    def run_descs(self, descs, gstats, nq, k):
+        """Like run_batch, from query DESCRIPTIONS: planning (dictionary lookups, BM25Weight::init, leaf order) happens
+        inside the call (xgm_get_mset_batch_device) — what the matcher hook does per get_mset.  descs: (xgm_query_desc * nq),
+        gstats: (xgm_global_stats * nq) merged statistics or None."""
+        b = self._buffers(nq, k)
+        self._bind_stream()
+        _lib.check(_lib.lib().xgm_get_mset_batch_device(self.shard._h, descs, gstats, nq, k, b["hits"].data_ptr(), b["hdrs"].data_ptr()))
+        return self._gather_merge(b, nq, k)
+
+    def _gather_merge(self, b, nq, k):
+        if self.world == 1 and not self.force_collective:
             return b["hits"], b["hdrs"]
         # output = concatenation of the ranks' inputs along dim 0 (the layout both RCCL and gloo accept)
-        dist.all_gather_into_tensor(b["all_hits"].view(self.world * nq, k, HIT_F64), b["hits"], group=self.group)
-        dist.all_gather_into_tensor(b["all_hdrs"].view(self.world * nq, HDR_F64), b["hdrs"], group=self.group)
+        if self._host_collectives:
+            hh, hd = b["hits"].cpu(), b["hdrs"].cpu()
+            ah = torch.empty((self.world * nq, k, HIT_F64), dtype=torch.float64)
+            ad = torch.empty((self.world * nq, HDR_F64), dtype=torch.float64)
+            dist.all_gather_into_tensor(ah, hh, group=self.group)
+            dist.all_gather_into_tensor(ad, hd, group=self.group)
+            b["all_hits"].view(self.world * nq, k, HIT_F64).copy_(ah)
+            b["all_hdrs"].view(self.world * nq, HDR_F64).copy_(ad)
+        else:
+            dist.all_gather_into_tensor(b["all_hits"].view(self.world * nq, k, HIT_F64), b["hits"], group=self.group)
+            dist.all_gather_into_tensor(b["all_hdrs"].view(self.world * nq, HDR_F64), b["hdrs"], group=self.group)
         self.merge_fn(b["all_hits"], b["all_hdrs"], self.world, nq, k, b["out_hits"], b["out_hdrs"])
         return b["out_hits"], b["out_hdrs"]
 
     # -- defaults: the HIP path ---------------------------------------------------------------------
+    def _bind_stream(self):
+        """Run the index's work on torch's current stream (see __init__).  The null stream is a special case of the C
+        ABI (handle 0 = "the library's own stream, synchronised before the call returns"): then the gathered records are
+        made visible by synchronising the current stream before the merge."""
+        h = torch.cuda.current_stream(self.device).cuda_stream
+        self.shard.set_stream(h)
+        return h
+
     def _device_search(self, batch, nq, k, hits, hdrs):
+        self._bind_stream()
         _lib.check(_lib.lib().xgm_search_batch_device(self.shard._h, batch, nq, k, hits.data_ptr(), hdrs.data_ptr()))
 
     def _device_merge(self, all_hits, all_hdrs, n_shards, nq, k, out_hits, out_hdrs):
+        if self._bind_stream() == 0:
+            torch.cuda.current_stream(self.device).synchronize()
         ks = (C.c_uint32 * nq)(*([k] * nq))
         _lib.check(_lib.lib().xgm_merge_shards_device(self.shard._h, all_hits.data_ptr(), all_hdrs.data_ptr(), n_shards, nq, k, ks,
                                                       out_hits.data_ptr(), out_hdrs.data_ptr()))
