@@ -63,7 +63,8 @@ def parse_args():
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
-    ap.add_argument("--ref-docs", type=int, default=1_000_000, help="documents of the reference glass index built on this box (0: skip the reference leg)")
+    ap.add_argument("--ref-docs", type=int, default=-1, help="documents of the reference glass index built on this box (0: skip the reference leg; "
+                    "default: the configuration's full size, 1/10 of it for PHRASE whose index carries positions)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
     ap.add_argument("--threads", type=int, default=0, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight")
     return ap.parse_args()
@@ -355,7 +356,7 @@ def port_all_cores(ora, sample, op, k, seconds, n_required=0):
     return {"value": done.value / wall.value, "unit": "queries/s", "cores": n_threads, "seconds": wall.value}
 
 
-def reference_leg(args, sample, k, n_required):
+def reference_leg(args, sample, k, n_required, full, ora_full):
     """The real reference on this box: build a glass index of the first --ref-docs documents of the corpus with
     the reference's own WritableDatabase (parallel slices + Database::compact, tools/ref_index.py), time
     Enquire::get_mset on 1 thread and on every core (one Database handle per thread) with
@@ -366,12 +367,13 @@ def reference_leg(args, sample, k, n_required):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ref_index
     from xapiand_amd import Database
-    if not H.have_xapian_ref() or args.ref_docs <= 0:
+    ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu)
+    if not H.have_xapian_ref() or ref_docs <= 0:
         return None
     tmp = tempfile.mkdtemp(prefix="xgm_ref_")
     try:
         dbdir = os.path.join(tmp, "glass")
-        binfo = ref_index.build(dbdir, args.ref_docs, nopos=args.op != "PHRASE", vocab=args.vocab)
+        binfo = ref_index.build(dbdir, ref_docs, nopos=args.op != "PHRASE", vocab=args.vocab)
         qfile = os.path.join(tmp, "q.txt")
         H.write_queries(qfile, [dict(q, first=0, maxitems=k) for q in sample])
         cores = max(1, os.cpu_count() or 1)
@@ -380,10 +382,14 @@ def reference_leg(args, sample, k, n_required):
         rep = max(2, (cores * 24 + len(sample) - 1) // len(sample))
         many = json.loads(H.xapian_ref("time", qfile, cores, rep, dbdir))
         # the port on the same postings: the same corpus generated on the GPU at the reference index's size
-        small = Database.synthetic(CORPUS_SEED, args.ref_docs, args.vocab, device=0, with_positions=args.op == "PHRASE")
-        ora = H.DeviceOracle(small, [t for q in sample for t in q["terms"]], positions=args.op == "PHRASE")
-        ora.warm()
-        port = time_port(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
+        small = None
+        if ref_docs == full["docs"]:
+            ora, port = ora_full, full                           # the full-size index and timing of cpu_baseline()
+        else:
+            small = Database.synthetic(CORPUS_SEED, ref_docs, args.vocab, device=0, with_positions=args.op == "PHRASE")
+            ora = H.DeviceOracle(small, [t for q in sample for t in q["terms"]], positions=args.op == "PHRASE")
+            ora.warm()
+            port = time_port(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
         # parity of port and reference on the sampled queries, on this index
         ref_out = os.path.join(tmp, "ref_out.txt")
         H.xapian_ref("query", qfile, ref_out, dbdir)
@@ -394,11 +400,12 @@ def reference_leg(args, sample, k, n_required):
             for (rows, _), rr in zip(want, ref_res):
                 assert [(d, w) for d, w, _ in rows] == [(d, w) for d, w, _ in rr["hits"]], "port/reference parity failure on the reference index"
                 checked += 1
-        ora.close()
-        small.close()
+        if small is not None:
+            ora.close()
+            small.close()
         return {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
                 "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3},
-                "docs": args.ref_docs, "index_build": binfo, "port_same_index": port,
+                "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
                 "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
@@ -429,21 +436,21 @@ def cpu_baseline(db, pool_q, args, k, timed_plans):
     full = time_port(ora, sample, args.op, k, args.cpu_seconds, n_required, checker)
     full["all_cores"] = port_all_cores(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
     full["docs"] = db.info().doccount
-    ora.close()
     sample_txt = ("first %d queries of the timed pool; port = oracle/xgm_oracle.cc (the reference's glass-chunk / MultiAnd / BM25 / "
                   "ProtoMSet algorithm restated) on the same %d-doc postings copied back from HBM, %.1f s of CPU work" % (len(sample), full["docs"], full["seconds"]))
     ref = None
     try:
-        ref = reference_leg(args, sample, k, n_required)
+        ref = reference_leg(args, sample, k, n_required, full, ora)
     except Exception as e:       # the reference leg is best effort (disk space, missing binary): say why it is absent
         ref = None
         sample_txt += "; reference leg failed: %r" % (e,)
+    ora.close()
     if ref:
         out = dict(ref)
         out["port_full_size"] = full
-        out["reference_full_size_estimate"] = {"value": full["value"] / ref["port_over_reference"], "unit": "queries/s", "cores": 1,
-                                               "note": "port at %d docs / port_over_reference; a measured full-size reference run, when one was made "
-                                                       "on this box type, is under profiles/ (r02_reference_full.json)" % full["docs"]}
+        if ref["docs"] != full["docs"]:
+            out["reference_full_size_estimate"] = {"value": full["value"] / ref["port_over_reference"], "unit": "queries/s", "cores": 1,
+                                                   "note": "port at %d docs / port_over_reference" % full["docs"]}
         out["sample"] = ("Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time), glass index of the first %d documents of the same "
                          "corpus built on this box (%.0f s on %d cores + %.0f s compact), same queries; " % (ref["docs"], ref["index_build"]["build_s"],
                                                                                                        ref["index_build"]["procs"], ref["index_build"]["compact_s"])) + sample_txt

@@ -1,0 +1,188 @@
+/* Seam B1: see xgm_matcher_hook.h.  Built only together with the reference's sources (oracle/ref_build/Makefile
+ * target xapian_hook_b1); a maintainer adds this file and the patch to src/xapian/matcher/. */
+#include "config.h"          /* as every translation unit of the library: the rare() / usual() macros etc. */
+
+#include "xgm_matcher_hook.h"
+
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#include "xapian/error.h"
+#include "xapian/api/msetinternal.h"
+#include "xapian/api/queryinternal.h"
+#include "xapian/api/result.h"
+#include "xapian/common/serialise-double.h"
+#include "xapian/weight/weightinternal.h"
+
+namespace xgm_hook {
+
+namespace {
+
+struct Shard { xgm_index* idx; Xapian::rev revision; };
+std::mutex g_mu;
+std::map<std::string, Shard> g_shards;
+std::atomic<bool> g_enabled{true}, g_decline_positional{false};
+std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0};
+
+struct Lowered {
+    xgm_query_desc d;
+    std::vector<std::string> terms;     /* owns the bytes d.terms[] points at */
+    uint32_t total_subqs = 0;            /* weighted leaves: what QueryOptimiser::inc_total_subqs counts */
+};
+
+/* a leaf the device path takes: a term with wqf 1 (MatchAll and scaled leaves are declined) */
+bool leaf_term(const Xapian::Query& q, std::string* term) {
+    if (q.get_type() != Xapian::Query::LEAF_TERM) return false;
+    const auto* t = static_cast<const Xapian::Internal::QueryTerm*>(q.internal.get());
+    if (!t || t->get_wqf() != 1 || t->get_term().empty()) return false;
+    *term = t->get_term();
+    return true;
+}
+
+/* a term, or `op` over >= 1 terms → appended to out */
+bool terms_of(const Xapian::Query& q, Xapian::Query::op op, std::vector<std::string>* out) {
+    std::string t;
+    if (leaf_term(q, &t)) { out->push_back(t); return true; }
+    if (q.get_type() != op || q.get_num_subqueries() == 0) return false;
+    for (size_t i = 0; i < q.get_num_subqueries(); ++i) {
+        if (!leaf_term(q.get_subquery(i), &t)) return false;
+        out->push_back(t);
+    }
+    return true;
+}
+
+/* Xapian::Query → xgm_query_desc for the shapes of SURVEY §8 (a3) and (f).2; false = decline */
+bool lower(const Xapian::Query& q, Lowered* L) {
+    memset(&L->d, 0, sizeof L->d);
+    L->terms.clear();
+    const Xapian::Query::op op = q.get_type();
+    std::string t;
+    if (leaf_term(q, &t)) {
+        L->d.op = XGM_OP_AND;
+        L->terms.push_back(t);
+        L->total_subqs = 1;
+    } else if (op == Xapian::Query::OP_AND || op == Xapian::Query::OP_OR) {
+        if (!terms_of(q, op, &L->terms)) return false;
+        L->d.op = op == Xapian::Query::OP_AND ? XGM_OP_AND : XGM_OP_OR;
+        L->total_subqs = (uint32_t)L->terms.size();
+    } else if (op == Xapian::Query::OP_PHRASE) {
+        if (g_decline_positional.load(std::memory_order_relaxed)) return false;
+        const size_t n = q.get_num_subqueries();
+        for (size_t i = 0; i < n; ++i) {
+            const Xapian::Query s = q.get_subquery(i);
+            if (!leaf_term(s, &t)) return false;         /* phrase offsets are the subquery ORDER (exactphrasepostlist.cc:75-133) */
+            L->terms.push_back(t);
+        }
+        L->d.op = XGM_OP_PHRASE;
+        const auto* w = static_cast<const Xapian::Internal::QueryWindowed*>(q.internal.get());
+        L->d.window = (uint32_t)w->get_window();
+        L->total_subqs = (uint32_t)n;
+    } else if (op == Xapian::Query::OP_AND_NOT || op == Xapian::Query::OP_AND_MAYBE || op == Xapian::Query::OP_FILTER) {
+        if (q.get_num_subqueries() != 2) return false;
+        if (!terms_of(q.get_subquery(0), Xapian::Query::OP_AND, &L->terms)) return false;
+        L->d.n_required = (uint32_t)L->terms.size();
+        if (!terms_of(q.get_subquery(1), op == Xapian::Query::OP_FILTER ? Xapian::Query::OP_AND : Xapian::Query::OP_OR, &L->terms)) return false;
+        L->d.op = op == Xapian::Query::OP_AND_NOT ? XGM_OP_AND_NOT : op == Xapian::Query::OP_AND_MAYBE ? XGM_OP_AND_MAYBE : XGM_OP_FILTER;
+        L->total_subqs = op == Xapian::Query::OP_AND_MAYBE ? (uint32_t)L->terms.size() : L->d.n_required;
+    } else {
+        return false;
+    }
+    if (L->terms.empty() || L->terms.size() > XGM_MAX_TERMS) return false;
+    L->d.n_terms = (uint32_t)L->terms.size();
+    for (size_t i = 0; i < L->terms.size(); ++i) { L->d.terms[i] = L->terms[i].data(); L->d.term_len[i] = (uint32_t)L->terms[i].size(); }
+    return true;
+}
+
+}  // namespace
+
+void register_shard(const Xapian::Database& db, xgm_index* idx) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_shards[db.get_uuid()] = Shard{idx, db.get_revision()};
+}
+
+void unregister_shard(const Xapian::Database& db) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_shards.erase(db.get_uuid());
+}
+
+void set_enabled(bool on) { g_enabled.store(on); }
+void set_decline_positional(bool on) { g_decline_positional.store(on); }
+Counters counters() { return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load()}; }
+
+bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const Xapian::Weight::Internal& stats,
+                  const Xapian::Weight& wtscheme, bool full_db_has_positions, Xapian::doccount first,
+                  Xapian::doccount maxitems, Xapian::doccount check_at_least, const Xapian::MatchDecider* mdecider,
+                  const Xapian::KeyMaker* sorter, Xapian::doccount collapse_max, int percent_threshold,
+                  double weight_threshold, Xapian::Enquire::docid_order order, bool sort_by_rel, double time_limit,
+                  size_t n_matchspies, Xapian::MSet& out) {
+    if (!g_enabled.load(std::memory_order_relaxed)) return false;
+    /* eligibility */
+    if (db.size() != 1 || !sort_by_rel || order == Xapian::Enquire::DESCENDING || collapse_max != 0 || percent_threshold != 0 ||
+        weight_threshold != 0.0 || mdecider || sorter || n_matchspies != 0 || stats.rset_size != 0 || time_limit != 0.0 ||
+        wtscheme.name() != "Xapian::BM25Weight") {
+        ++g_shape;
+        return false;
+    }
+    Lowered L;
+    if (!lower(query, &L)) { ++g_shape; return false; }
+    Shard sh;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(db.get_uuid());
+        if (it == g_shards.end()) { ++g_unreg; return false; }
+        sh = it->second;
+    }
+    if (sh.revision != db.get_revision()) { ++g_rev; return false; }      /* the segment is of another revision: CPU until refreshed */
+
+    /* BM25 parameters: the scheme's own serialisation (bm25weight.cc:145-153) */
+    {
+        const std::string ser = wtscheme.serialise();
+        const char* p = ser.data();
+        const char* end = p + ser.size();
+        L.d.k1 = unserialise_double(&p, end); L.d.k2 = unserialise_double(&p, end); L.d.k3 = unserialise_double(&p, end);
+        L.d.b = unserialise_double(&p, end); L.d.min_normlen = unserialise_double(&p, end);
+    }
+    L.d.first = first; L.d.maxitems = maxitems; L.d.check_at_least = check_at_least;
+
+    /* merged statistics, exactly what the CPU matcher would weigh with (weightinternal.h:72-111) */
+    xgm_global_stats gs;
+    memset(&gs, 0, sizeof gs);
+    gs.total_length = stats.total_length;
+    gs.collection_size = stats.collection_size;
+    gs.full_db_has_positions = full_db_has_positions ? 1u : 0u;
+    for (size_t i = 0; i < L.terms.size(); ++i) {
+        auto it = stats.termfreqs.find(L.terms[i]);
+        if (it == stats.termfreqs.end()) { ++g_shape; return false; }
+        gs.termfreq[i] = it->second.termfreq;
+    }
+
+    const uint32_t k = first + maxitems;
+    std::vector<xgm_hit> hits(k ? k : 1);
+    xgm_result_hdr hdr;
+    memset(&hdr, 0, sizeof hdr);
+    const int rc = xgm_get_mset_batch(sh.idx, &L.d, &gs, 1, k ? k : 1, hits.data(), &hdr);
+    if (rc > 0) { ++g_dev; return false; }                                   /* declined by the planner: CPU matcher */
+    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+
+    /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682).  matches_*: exact counts
+     * (the reference's are estimates; documented exception). */
+    std::vector<Result> items;
+    const uint32_t skip = std::min<uint32_t>(first, hdr.n_hits);
+    items.reserve(hdr.n_hits - skip);
+    for (uint32_t i = skip; i < hdr.n_hits; ++i) items.emplace_back(hits[i].weight, hits[i].docid);
+    double percent_scale = 0.0;
+    if (hdr.n_hits && hdr.max_attained > 0.0 && L.total_subqs) {
+        percent_scale = hdr.max_weight_subqs_matched / double(L.total_subqs);
+        percent_scale /= hdr.max_attained;
+    }
+    const Xapian::doccount m = (Xapian::doccount)hdr.matches_exact;
+    out = Xapian::MSet(new Xapian::MSet::Internal(first, m, m, m, m, m, m, hdr.max_possible, hdr.max_attained, std::move(items),
+                                                   percent_scale * 100.0));
+    ++g_answered;
+    return true;
+}
+
+}  // namespace xgm_hook

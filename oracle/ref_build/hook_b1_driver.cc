@@ -1,0 +1,138 @@
+/* xapian_hook_b1 — seam B1 compiled and run: the REAL vendored Xapian with
+ * integration/matcher_hook.patch applied to its Matcher::get_mset and integration/xgm_matcher_hook.cc linked in.
+ * Every query goes through the reference's own Enquire::get_mset TWICE — hook off (CPU matcher) and hook on (libxgm
+ * behind the matcher) — on one shard and, with several <dbdir>s, through Xapiand's per-shard protocol
+ * (prepare_mset → add_prepared_mset → set_prepared_mset → get_mset → unshard_docids → merge_mset; reference
+ * src/database/handler.cc:1250-1343, 1532-1549), and the two MSets must agree: size, firstitem, docid and weight
+ * BITS at every rank, percentages (single shard), max_possible, max_attained.  matches_* are exact counts on the
+ * device path (documented exception); they are checked against the CPU matcher's bounds: lower <= exact <= upper.
+ *
+ *   xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]
+ * Each shard's segment is exported from its glass directory by the native reader (xgm_segment_build_from_glass) and
+ * loaded onto device 0.  --stale registers every shard under a wrong revision: every search must then be declined
+ * (CPU path) and still answer identically.  Test infrastructure (tests/test_gpu_hook_b1.py); query file format as
+ * xapian_ref. */
+#define XGM_REF_DRIVER_NO_MAIN
+#include "ref_driver.cc"
+
+#include <unistd.h>
+
+#include "../../integration/xgm_matcher_hook.h"
+
+namespace {
+
+bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std::string* why) {
+    if (a.size() != b.size()) { *why = "size"; return false; }
+    if (a.get_firstitem() != b.get_firstitem()) { *why = "firstitem"; return false; }
+    auto x = a.begin();
+    auto y = b.begin();
+    for (; x != a.end(); ++x, ++y) {
+        const double wa = x.get_weight(), wb = y.get_weight();
+        if (*x != *y) { *why = "docid"; return false; }
+        if (memcmp(&wa, &wb, sizeof wa) != 0) { *why = "weight bits"; return false; }
+        if (percents && x.get_percent() != y.get_percent()) { *why = "percent"; return false; }
+    }
+    const double pa = a.get_max_possible(), pb = b.get_max_possible(), ma = a.get_max_attained(), mb = b.get_max_attained();
+    if (memcmp(&pa, &pb, 8) != 0) { *why = "max_possible"; return false; }
+    if (a.size() && memcmp(&ma, &mb, 8) != 0) { *why = "max_attained"; return false; }
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int a = 1;
+    bool stale = false;
+    for (; a < argc && argv[a][0] == '-'; ++a) {
+        if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_decline_positional(true);
+        else if (!strcmp(argv[a], "--stale")) stale = true;
+    }
+    if (argc - a < 2) { fprintf(stderr, "usage: xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]\n"); return 2; }
+    try {
+        auto queries = read_queries(argv[a]);
+        std::vector<Xapian::Database> dbs;
+        std::vector<xgm_index*> idx;
+        for (int i = a + 1; i < argc; ++i) {
+            dbs.emplace_back(argv[i]);
+            char seg[64];
+            snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%d.seg", (int)getpid(), i);
+            if (xgm_segment_build_from_glass(argv[i], 0, seg) != XGM_OK) { fprintf(stderr, "export %s: %s\n", argv[i], xgm_last_error()); return 1; }
+            xgm_index* h = nullptr;
+            const uint64_t rev = dbs.back().get_revision();
+            if (xgm_index_open(seg, 0, rev, &h) != XGM_OK) { fprintf(stderr, "xgm_index_open: %s\n", xgm_last_error()); return 1; }
+            unlink(seg);
+            idx.push_back(h);
+            xgm_hook::register_shard(dbs.back(), h);
+        }
+        unsigned refreshed = 0;
+        auto export_and_register = [&](size_t i, const char* dir) -> int {
+            char seg[64];
+            snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%zu.seg", (int)getpid(), i);
+            if (xgm_segment_build_from_glass(dir, 0, seg) != XGM_OK) { fprintf(stderr, "export %s: %s\n", dir, xgm_last_error()); return 1; }
+            xgm_index* h = nullptr;
+            if (xgm_index_open(seg, 0, dbs[i].get_revision(), &h) != XGM_OK) { fprintf(stderr, "xgm_index_open: %s\n", xgm_last_error()); return 1; }
+            unlink(seg);
+            if (idx[i]) xgm_index_close(idx[i]);
+            idx[i] = h;
+            xgm_hook::register_shard(dbs[i], h);
+            return 0;
+        };
+        if (stale) {
+            /* The shards move on to a new revision behind the registered segments (one more document each, committed
+             * through the reference's WritableDatabase); the re-opened Database handles then carry a revision the
+             * registry does not know: every search must be DECLINED (CPU matcher) ... */
+            for (size_t i = 0; i < dbs.size(); ++i) {
+                {
+                    Xapian::WritableDatabase w(argv[a + 1 + i], Xapian::DB_OPEN);
+                    Xapian::Document doc;
+                    doc.add_posting("t1", 1); doc.add_posting("t2", 2); doc.add_posting("t3", 3);
+                    w.add_document(doc);
+                    w.commit();
+                }
+                dbs[i] = Xapian::Database(argv[a + 1 + i]);
+            }
+            const xgm_hook::Counters before = xgm_hook::counters();
+            for (size_t qi = 0; qi < queries.size() && qi < 8; ++qi) (void)run_query(dbs, make_query(queries[qi]), queries[qi].first, queries[qi].maxitems);
+            const xgm_hook::Counters after = xgm_hook::counters();
+            if (after.answered != before.answered || after.declined_revision == before.declined_revision) {
+                printf("STALE: searches on a moved-on revision were not declined (answered %llu -> %llu, declined_revision %llu -> %llu)\n",
+                       (unsigned long long)before.answered, (unsigned long long)after.answered, (unsigned long long)before.declined_revision,
+                       (unsigned long long)after.declined_revision);
+                return 1;
+            }
+            /* ... until the refreshed segments (keyed by the new revision) are registered */
+            for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i])) return 1; ++refreshed; }
+        }
+        unsigned bad = 0, bounds_bad = 0;
+        const bool percents = dbs.size() == 1;
+        for (size_t qi = 0; qi < queries.size(); ++qi) {
+            const QuerySpec& q = queries[qi];
+            const Xapian::Query query = make_query(q);
+            xgm_hook::set_enabled(false);
+            Xapian::MSet want = run_query(dbs, query, q.first, q.maxitems);
+            xgm_hook::set_enabled(true);
+            Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems);
+            std::string why;
+            if (!same_mset(want, got, percents, &why)) {
+                ++bad;
+                printf("MISMATCH query %zu (%s): %s; cpu %u hits, hook %u hits\n", qi, q.op.c_str(), why.c_str(), want.size(), got.size());
+            }
+            if (dbs.size() == 1 && !(want.get_matches_lower_bound() <= got.get_matches_estimated() && got.get_matches_estimated() <= want.get_matches_upper_bound())) {
+                ++bounds_bad;
+                printf("BOUNDS query %zu: exact %u outside the CPU matcher's [%u, %u]\n", qi, got.get_matches_estimated(), want.get_matches_lower_bound(),
+                       want.get_matches_upper_bound());
+            }
+        }
+        const xgm_hook::Counters c = xgm_hook::counters();
+        printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
+               "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u}\n",
+               queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
+               (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed);
+        for (auto& d : dbs) xgm_hook::unregister_shard(d);
+        for (auto* h : idx) xgm_index_close(h);
+        return (bad || bounds_bad) ? 1 : 0;
+    } catch (const Xapian::Error& e) {
+        fprintf(stderr, "Xapian error: %s\n", e.get_description().c_str());
+        return 1;
+    }
+}

@@ -413,6 +413,7 @@ int cmd_export(int argc, char** argv) {
 
 }  // namespace
 
+#ifndef XGM_REF_DRIVER_NO_MAIN
 int main(int argc, char** argv) {
     if (argc < 2) { fprintf(stderr, "usage: xapian_ref build|query|time|export ...\n"); return 2; }
     try {
@@ -432,3 +433,4 @@ int main(int argc, char** argv) {
         return 1;
     }
 }
+#endif

@@ -1,0 +1,103 @@
+"""Seam B1 compiled and run: oracle/_ref/xapian_hook_b1 is the reference's own
+Xapian with integration/matcher_hook.patch applied to Matcher::get_mset (src/xapian/matcher/matcher.cc:543-609) and
+integration/xgm_matcher_hook.cc linked in.  It runs every query through the reference's Enquire::get_mset with the
+hook off (CPU matcher) and on (libxgm behind the matcher) and requires identical MSets: size, firstitem, docids,
+weight bits, percentages, max_possible, max_attained — on one shard and through Xapiand's per-shard protocol
+(prepare_mset / add_prepared_mset / set_prepared_mset / get_mset / merge_mset) over three shards.  The JSON summary
+also proves that the answers really came from the device (answered_on_device) and that unsupported shapes fell
+through to the CPU matcher untouched."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+HOOK_B1 = os.path.join(H.ROOT, "oracle", "_ref", "xapian_hook_b1")
+N_DOCS, VOCAB = 30000, 20000
+
+
+def run_b1(*args):
+    r = subprocess.run([HOOK_B1] + [str(a) for a in args], capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-3000:] + r.stderr[-2000:]
+    return json.loads(line[-1])
+
+
+@pytest.fixture(scope="module")
+def glass(tmp_path_factory):
+    if not (H.have_xapian_ref() and os.path.exists(HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    d = tmp_path_factory.mktemp("b1")
+    one = str(d / "one")
+    H.xapian_ref("build", one, hex(H.CORPUS_SEED), N_DOCS, VOCAB, 50, 150)
+    shards = []
+    for s in range(3):
+        p = str(d / ("shard%d" % s))
+        H.xapian_ref("build", p, hex(H.CORPUS_SEED), N_DOCS, VOCAB, 50, 150, 3, s)
+        shards.append(p)
+    return d, one, shards
+
+
+def supported_queries():
+    qs = (H.gen_term_queries("AND", 40, 3, 1, 200, maxitems=10, seed=11) + H.gen_term_queries("AND", 10, 2, 1, 60, first=7, maxitems=5, seed=12) +
+          H.gen_term_queries("OR", 30, 5, 1, 3000, maxitems=100, seed=13) + H.gen_term_queries("OR", 10, 3, 1, 500, first=20, maxitems=10, seed=14) +
+          H.gen_term_queries("AND", 6, 1, 1, 100, maxitems=10, seed=15) +
+          H.gen_sided_queries("AND_NOT", 12, 2, 2, 1, 100, maxitems=10, seed=16) + H.gen_sided_queries("AND_MAYBE", 12, 2, 2, 1, 100, maxitems=10, seed=17) +
+          H.gen_sided_queries("FILTER", 12, 2, 1, 1, 100, maxitems=10, seed=18))
+    return qs
+
+
+def test_hook_on_equals_hook_off_single_shard(built, glass):
+    d, one, _ = glass
+    qs = supported_queries()
+    # PHRASE with maxitems >= matches: where the reference's stale-weight quirk cannot engage
+    qs += [dict(q, maxitems=1000) for q in H.gen_phrase_queries(20, N_DOCS, VOCAB, seed=19)]
+    qf = str(d / "q1.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] == len(qs), out          # every one of them ran on the GPU when the hook was on
+
+
+def test_hook_on_equals_hook_off_xapiand_protocol(built, glass):
+    d, _, shards = glass
+    qs = supported_queries()
+    qf = str(d / "q3.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, *shards)
+    assert out["mismatches"] == 0, out
+    assert out["shards"] == 3 and out["answered_on_device"] == 3 * len(qs), out     # one device search per shard and query
+
+
+def test_unsupported_shapes_fall_through_to_the_cpu_matcher(built, glass):
+    d, one, _ = glass
+    qs = [dict(op="NEAR", terms=["t1", "t2"], first=0, maxitems=10, window=4),         # not on the device path yet
+          dict(op="AND", terms=["t3", "t3"], first=0, maxitems=10, window=0)]           # repeated term (wqf merging)
+    qs += H.gen_term_queries("AND", 4, 3, 1, 100, maxitems=10, seed=21)
+    qf = str(d / "qu.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0, out
+    assert out["answered_on_device"] == 4 and out["declined_shape"] + out["declined_by_planner"] >= 2, out
+    # byte-compatibility switch: positional queries are declined when asked to
+    ph = str(d / "qp.txt")
+    H.write_queries(ph, H.gen_phrase_queries(6, N_DOCS, VOCAB, seed=22))
+    out = run_b1("--decline-positional", ph, one)
+    assert out["mismatches"] == 0 and out["answered_on_device"] == 0 and out["declined_shape"] == 6, out
+
+
+def test_moved_on_revision_is_declined_until_the_segment_is_refreshed(built, glass):
+    d, one, _ = glass
+    copy = str(d / "one_copy")
+    shutil.copytree(one, copy)
+    qf = str(d / "qs.txt")
+    qs = H.gen_term_queries("AND", 16, 2, 1, 100, maxitems=10, seed=23)
+    H.write_queries(qf, qs)
+    out = run_b1("--stale", qf, copy)
+    assert out["mismatches"] == 0 and out["declined_revision"] >= 8 and out["refreshed_shards"] == 1, out
+    assert out["answered_on_device"] == len(qs), out

@@ -10,17 +10,18 @@ import sys
 known = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
 pmc = {}
 for l in open(sys.argv[2]):
-    m = re.match(r"PMC (\S+)\s+(\S+)\s+mean (\S+) over", l)
+    m = re.match(r"PMC (.{40}) (\S+)\s+mean (\S+) over", l)
     if m:
-        pmc[(re.sub(r"\(.*", "", m.group(1)), m.group(2))] = float(m.group(3))
+        pmc[(re.sub(r"[(<].*", "", m.group(1)).strip(), m.group(2))] = float(m.group(3))
 dur = {}
 for f in glob.glob(os.path.join(sys.argv[3], "**", "*kernel_stats.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
-        dur[re.sub(r"\(.*", "", row["Name"])] = float(row["AverageNs"])
+        dur[re.sub(r"[(<].*", "", row["Name"]).strip()] = float(row["AverageNs"])
 rows = [("stream16", known["stream16_bytes"], "bytes streamed"), ("gather1", known["gather1_accesses"], "1-byte gathers"),
         ("probe8k_spread", known["probe8k_spread_sectors"], "distinct sectors (64 lanes -> 64 lines)"),
         ("probe8k_dense", known["probe8k_dense_sectors"], "distinct sectors (64 lanes -> 8 sectors)"),
-        ("gather4", known["gather4_accesses"], "4-byte gathers"), ("write16", known["write16_bytes"], "bytes stored"),
+        ("gather4", known["gather4_accesses"], "4-byte gathers"), ("gather_pair", known.get("gather_pair_lines", 1), "128-B lines, both halves read"),
+        ("write16", known["write16_bytes"], "bytes stored"),
         ("scratch96", known["scratch_lanes"] * 96 * known["scratch_rounds"], "scratch bytes stored (and reloaded)")]
 print("%-16s %14s  %-42s %14s %12s %14s %12s %10s" % ("kernel", "known", "unit", "FETCH_SIZE B", "per unit", "WRITE_SIZE B", "per unit", "avg ms"))
 for name, n, unit in rows:

@@ -11,6 +11,7 @@
  *   probe8k    : one byte per lane, the 64 lanes of a wave at sorted random slots of ONE random 8 KiB array
  *                (a round of container probes: candidates of a stripe, ascending) — known distinct 64-B sectors
  *   gather4    : 4 B per lane at a random place                                  (a doclen gather)
+ *   gather_pair: byte 0, then byte 64 of the same random 128-B line             (is a miss a 64-B or a 128-B fill?)
  *   write16    : 16 B per lane, coalesced stores                                 (candidate output)
  *   scratch96  : every lane stores and reloads 96 B of private (scratch) memory  (the spill of the 128-VGPR bound)
  *
@@ -81,16 +82,32 @@ __global__ void write16(uint4* __restrict__ p, size_t n16) {
         p[i] = make_uint4((uint32_t)i, 1u, 2u, 3u);
 }
 
-/* 24 dwords of private memory per lane, indexed dynamically so that they live in scratch */
+/* 256 dwords of private memory per lane (too much for registers or an LDS promotion: it lives in scratch), of which
+ * every round stores and reloads 24 dwords = 96 B per lane */
 __global__ void scratch96(const uint32_t* __restrict__ idx, size_t rounds, unsigned long long* sink) {
-    uint32_t priv[24];
+    uint32_t priv[256];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t acc = 0;
     for (size_t r = 0; r < rounds; ++r) {
+        const uint32_t o = (uint32_t)(r * 24u) & 255u;
 #pragma unroll 1
-        for (uint32_t i = 0; i < 24u; ++i) priv[(i + idx[(r + i) & 1023u]) % 24u] = t + i + (uint32_t)r;
+        for (uint32_t i = 0; i < 24u; ++i) priv[(o + i + idx[(r + i) & 1023u]) & 255u] = t + i + (uint32_t)r;
 #pragma unroll 1
-        for (uint32_t i = 0; i < 24u; ++i) acc += priv[(i * 7u + idx[(r + 2u * i) & 1023u]) % 24u];
+        for (uint32_t i = 0; i < 24u; ++i) acc += priv[(o + i * 7u + idx[(r + 2u * i) & 1023u]) & 255u];
+    }
+    if (acc == 0x12345678u) atomicAdd(sink, 1ull);
+}
+
+/* Is an L2 miss a 64-B or a 128-B fill?  Every lane reads byte 0 of a random 128-B line and then byte 64 of the SAME
+ * line.  128-B fills: the second read hits → as many requests as gather1 over the same number of lines;
+ * 64-B fills: twice as many. */
+__global__ void gather_pair(const unsigned char* __restrict__ p, size_t bytes, size_t n_access, unsigned long long* sink) {
+    uint32_t acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_access; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t line = (mix(i) % (bytes >> 7)) << 7;
+        const uint32_t a = p[line];
+        acc += a;
+        acc += p[line + 64 + (a & 1u)];               /* depends on the first load: issued after it returned */
     }
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);
 }
@@ -116,13 +133,14 @@ int main(int argc, char** argv) {
         hipLaunchKernelGGL(probe8k_spread, grid, block, 0, 0, buf, bytes, rounds, sink);
         hipLaunchKernelGGL(probe8k_dense, grid, block, 0, 0, buf, bytes, rounds, sink);
         hipLaunchKernelGGL(gather4, grid, block, 0, 0, (const uint32_t*)buf, bytes / 4, n_access, sink);
+        hipLaunchKernelGGL(gather_pair, grid, block, 0, 0, buf, bytes, n_access, sink);
         hipLaunchKernelGGL(write16, grid, block, 0, 0, (uint4*)buf, bytes / 16);
         hipLaunchKernelGGL(scratch96, grid, block, 0, 0, idx, (size_t)64, sink);
         CK(hipDeviceSynchronize());
     }
     printf("{\"region_bytes\": %zu, \"stream16_bytes\": %zu, \"gather1_accesses\": %zu, \"probe8k_rounds\": %zu, "
            "\"probe8k_spread_sectors\": %zu, \"probe8k_dense_sectors\": %zu, \"gather4_accesses\": %zu, \"write16_bytes\": %zu, "
-           "\"scratch_lanes\": %zu, \"scratch_bytes_per_lane_round\": 96, \"scratch_rounds\": 64}\n",
-           bytes, bytes, n_access, rounds * waves, rounds * waves * 64, rounds * waves * 8, n_access, bytes, (size_t)grid.x * block.x);
+           "\"scratch_lanes\": %zu, \"scratch_bytes_per_lane_round\": 96, \"scratch_rounds\": 64, \"gather_pair_lines\": %zu}\n",
+           bytes, bytes, n_access, rounds * waves, rounds * waves * 64, rounds * waves * 8, n_access, bytes, (size_t)grid.x * block.x, n_access);
     return 0;
 }

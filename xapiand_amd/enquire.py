@@ -195,7 +195,8 @@ class Database:
         _lib.check(_lib.lib().xgm_index_set_stream(self._h, C.c_void_p(hip_stream)))
 
     def set_profiling(self, on):
-        _lib.check(_lib.lib().xgm_index_set_profiling(self._h, 1 if on else 0))
+        """on: bit 0 = time the match kernel with HIP events, bit 1 = launch the tallying instantiation (xgm.h)."""
+        _lib.check(_lib.lib().xgm_index_set_profiling(self._h, int(on)))
 
     def last_kernel_ms(self):
         return _lib.lib().xgm_last_kernel_ms(self._h)
