@@ -370,7 +370,8 @@ def reference_leg(args, sample, k, n_required, full, ora_full):
     ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu)
     if not H.have_xapian_ref() or ref_docs <= 0:
         return None
-    tmp = tempfile.mkdtemp(prefix="xgm_ref_")
+    # the index lives in memory-backed storage when there is one: indexing through WritableDatabase is write-heavy
+    tmp = tempfile.mkdtemp(prefix="xgm_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
     try:
         dbdir = os.path.join(tmp, "glass")
         binfo = ref_index.build(dbdir, ref_docs, nopos=args.op != "PHRASE", vocab=args.vocab)

@@ -90,6 +90,12 @@ typedef struct {
     const uint32_t* wdf;         /* [n_postings]                                                   */
     const uint64_t* pos_off;     /* [n_postings+1] or NULL                                         */
     const uint32_t* pos;         /* [n_positions] or NULL                                          */
+    /* Database-wide statistics bounds as the backend reports them (Database::get_doclength_lower_bound /
+     * get_wdf_upper_bound; glass keeps them in its version file and never tightens them when documents are deleted
+     * or replaced).  0 = derive the tight bound from the postings.  They only enter BM25Weight::get_maxpart, i.e.
+     * MSet::get_max_possible (and the pruning bounds never exceed them). */
+    uint32_t doclen_lower_bound;
+    uint32_t wdf_upper_bound;
 } xgm_raw_postings;
 
 /* Build the block-compressed device segment from raw postings on the host and write
@@ -350,6 +356,10 @@ int64_t xgm_debug_read_positions(xgm_index*, uint32_t term_id, uint32_t* out, ui
 
 /* Diagnostics: mean host time of xgm_plan_query per query (microseconds) over `reps` passes of descs[0..nq). */
 double xgm_debug_plan_us(const xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t reps);
+
+/* Diagnostics (host only, works on an XGM_DEVICE_NONE index): the launches a batch of planned queries is cut into,
+ * one per kernel class present, as "<kernel>[:variant]*<queries>;..." in launch order; returns their number. */
+int xgm_debug_batch_launches(const xgm_index*, const xgm_query* qs, uint32_t nq, char* out, uint32_t cap);
 
 const char* xgm_last_error(void);
 const char* xgm_version(void);

@@ -60,9 +60,10 @@ int main(int argc, char** argv) {
             Xapian::MSet want = cpu.get_mset(q.first, q.maxitems);
 
             const uint32_t op = q.op == "AND" ? XGM_OP_AND : q.op == "OR" ? XGM_OP_OR : XGM_OP_PHRASE;
-            auto* src = new GpuTopKPostingSource(idx, op, q.terms, q.first + q.maxitems, q.window);
+            /* eligibility first: a declined shape keeps the original Xapian::Query (and the CPU matcher) */
+            auto* src = GpuTopKPostingSource::create(idx, op, q.terms, q.first + q.maxitems, q.window);
             Xapian::Enquire gpu(db);
-            gpu.set_query(Xapian::Query(src->release()));
+            if (src) gpu.set_query(Xapian::Query(src->release())); else { gpu.set_query(cpu_query(q)); ++declined; }
             Xapian::MSet got = gpu.get_mset(q.first, q.maxitems);
             ++n;
             bool ok = want.size() == got.size();

@@ -221,6 +221,18 @@ int cmd_build_range(int argc, char** argv) {
     return 0;
 }
 
+/* info <dbdir> [term ...]: the statistics bounds the reference's weighting schemes see (Database::get_doclength_lower_bound,
+ * get_wdf_upper_bound(term) — glass keeps them in its version file and never tightens them on delete / replace). */
+int cmd_info(int argc, char** argv) {
+    if (argc < 3) return 2;
+    Xapian::Database db(argv[2]);
+    printf("{\"doccount\": %u, \"lastdocid\": %u, \"revision\": %" PRIu64 ", \"doclength_lower_bound\": %u, \"doclength_upper_bound\": %u, \"wdf_upper_bound\": {",
+           db.get_doccount(), db.get_lastdocid(), (uint64_t)db.get_revision(), db.get_doclength_lower_bound(), db.get_doclength_upper_bound());
+    for (int i = 3; i < argc; ++i) printf("%s\"%s\": %u", i > 3 ? ", " : "", argv[i], db.get_wdf_upper_bound(argv[i]));
+    printf("}}\n");
+    return 0;
+}
+
 /* compact <outdir> <dbdir> [<dbdir> ...]: Database::compact of the sources in order (docids renumbered by the
  * running lastdocid offset, reference src/xapian/api/compactor.cc / backends/glass/glass_compact.cc). */
 int cmd_compact(int argc, char** argv) {
@@ -426,6 +438,7 @@ int main(int argc, char** argv) {
         else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
         else if (cmd == "build_range") rc = cmd_build_range(argc, argv);
         else if (cmd == "compact") rc = cmd_compact(argc, argv);
+        else if (cmd == "info") rc = cmd_info(argc, argv);
         if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());
         return rc;
     } catch (const Xapian::Error& e) {

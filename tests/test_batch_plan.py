@@ -74,7 +74,7 @@ def test_kernel_dispatch(host_db):
     AND, OR = term_queries("AND", 6, 3, 11), term_queries("OR", 6, 4, 12)
     assert plan_batch(host_db, AND)[0] == "xgm_andw_kernel"
     assert plan_batch(host_db, OR, 0, 100)[0] == "xgm_orw_kernel"
-    assert plan_batch(host_db, AND + OR)[0] == "xgm_match_kernel"                         # mixed shapes: the general kernel
+    assert plan_batch(host_db, AND + OR)[0] == "xgm_match_kernel"                         # ONE launch for mixed shapes: the general kernel
     assert plan_batch(host_db, AND, 0, 500)[0] == "xgm_and_kernel"                        # k beyond the wave kernel's buffer
     assert plan_batch(host_db, term_queries("AND", 2, 1, 13))[0] == "xgm_match_kernel"    # single-term queries
     phrase = [Query("PHRASE", q["terms"]) for q in H.gen_phrase_queries(4, 120000, 200000, seed=14)]
@@ -85,3 +85,27 @@ def test_kernel_dispatch(host_db):
     assert plan_batch(host_db, sided_queries("FILTER", 4, 2, 1, 18))[0] == "xgm_andw_kernel"   # a FILTER is a conjunction
     assert plan_batch(host_db, sided_queries("AND_MAYBE", 2, 3, 6, 19))[0] == "xgm_match_kernel"  # 9 terms: beyond the register program
     assert plan_batch(host_db, sided_queries("AND_NOT", 2, 2, 1, 20) + OR)[0] == "xgm_match_kernel"
+
+
+def launches(db, queries, first=0, maxitems=10):
+    plans = [plan(db, q, first, maxitems) for q in queries]
+    arr = (_lib.Query * len(plans))(*plans)
+    out = C.create_string_buffer(512)
+    n = _lib.lib().xgm_debug_batch_launches(db._h, arr, len(plans), out, 512)
+    assert n >= 0
+    return out.value.decode().split(";")
+
+
+def test_heterogeneous_batch_is_cut_by_kernel_class(host_db):
+    """A server's natural batch mixes shapes: xgm_search_batch launches one kernel per class present instead of sending
+    everything to the general workgroup kernel."""
+    AND, OR = term_queries("AND", 6, 3, 11), term_queries("OR", 5, 4, 12)
+    phrase = [Query("PHRASE", q["terms"]) for q in H.gen_phrase_queries(4, 120000, 200000, seed=14)]
+    an, am = sided_queries("AND_NOT", 3, 2, 2, 15), sided_queries("AND_MAYBE", 2, 2, 2, 16)
+    single = term_queries("AND", 2, 1, 13)
+    assert launches(host_db, AND) == ["xgm_andw_kernel*6"]
+    mixed = [AND[0], OR[0], phrase[0], an[0], AND[1], am[0], OR[1], single[0]] + AND[2:] + OR[2:] + phrase[1:] + an[1:] + am[1:] + single[1:]
+    assert launches(host_db, mixed) == ["xgm_andw_kernel*6", "xgm_andw_kernel:sided1*3", "xgm_andw_kernel:sided2*2", "xgm_andw_kernel:phrase*4",
+                                        "xgm_orw_kernel*5", "xgm_match_kernel*2"]
+    big = sided_queries("AND_MAYBE", 2, 3, 6, 19)                   # 9 terms: beyond the register program → the general kernel
+    assert launches(host_db, AND + big) == ["xgm_andw_kernel*6", "xgm_match_kernel*2"]

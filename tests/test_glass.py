@@ -73,3 +73,29 @@ def test_native_reader_rejects_garbage(built, tmp_path):
     (d / "iamglass").write_bytes(b"definitely not a glass version file" * 3)
     assert _lib.lib().xgm_glass_export_raw(str(d).encode(), str(tmp_path / "x.raw").encode()) == _lib.XGM_E_INVALID
     assert _lib.lib().xgm_glass_export_raw(str(tmp_path / "missing").encode(), str(tmp_path / "x.raw").encode()) == _lib.XGM_E_IO
+
+
+def test_statistics_bounds_are_glass_own(built, tmp_path):
+    """After deletes / replaces glass keeps its (now loose) doclength lower bound and wdf upper bound; the reference's
+    BM25Weight::get_maxpart — hence MSet::get_max_possible — is computed from those.  The exporter carries them from the
+    version file into the segment: the planner's per-term wdf bound and the doclen bound must equal what
+    the reference reports, not the tight bounds of the live postings."""
+    import ctypes as C
+    import json
+    db = str(tmp_path / "misc")
+    H.xapian_ref("build_misc", db)
+    terms = ["w1", "w7", "w33", "mixed", "nopos", "Keven"]
+    ref = json.loads(H.xapian_ref("info", db, *terms))
+    seg = str(tmp_path / "misc.seg")
+    _lib.check(_lib.lib().xgm_segment_build_from_glass(db.encode(), 0, seg.encode()))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().xgm_index_open(seg.encode(), _lib.XGM_DEVICE_NONE, _lib.UINT64_MAX, C.byref(h)))
+    info = _lib.IndexInfo()
+    _lib.check(_lib.lib().xgm_index_get_info(h, C.byref(info)))
+    assert info.doclen_lower_bound == ref["doclength_lower_bound"]
+    assert info.revision == ref["revision"]
+    for t in terms:
+        ub = C.c_uint32()
+        _lib.check(_lib.lib().xgm_lookup_term(h, t.encode(), len(t), None, None, None, C.byref(ub)))
+        assert ub.value == ref["wdf_upper_bound"][t], t
+    _lib.lib().xgm_index_close(h)

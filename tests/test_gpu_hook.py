@@ -34,9 +34,10 @@ def test_reference_enquire_with_gpu_posting_source(built, tmp_path):
         if H.oracle_search(corpus, q["op"], q["terms"], 0, 150, window=q.get("window", 0))[1].matches <= 150:
             qs.append(q)
     assert sum(q["op"] == "PHRASE" for q in qs) >= 10
+    qs.append(dict(op="AND", terms=["t5", "t5"], first=0, maxitems=10))          # a shape the device path declines: stays on the CPU matcher
     qfile = tmp_path / "q.txt"
     qfile.write_text("".join("%s %d %d %d %s\n" % (q["op"], q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])) for q in qs))
     r = subprocess.run([HOOK, db, seg, str(qfile)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["queries"] == len(qs) and out["mismatches"] == 0, out
+    assert out["queries"] == len(qs) and out["mismatches"] == 0 and out["declined"] == 1, out

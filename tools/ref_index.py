@@ -24,7 +24,9 @@ def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, l
     """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced."""
     if not os.path.exists(XAPIAN_REF):
         raise RuntimeError("oracle/_ref/xapian_ref is not built")
-    procs = procs or max(1, min((os.cpu_count() or 1) - 2, (n_docs + 19999) // 20000))
+    # more writers than ~1/2 of the cores fight each other (measured on the 256-core MI355X host: 254 processes index
+    # 10 M documents in 185 s, 50 processes 1 M in 9.5 s)
+    procs = procs or max(1, min((os.cpu_count() or 2) // 2, (n_docs + 19999) // 20000))
     parts_dir = outdir.rstrip("/") + ".parts"
     shutil.rmtree(parts_dir, ignore_errors=True)
     shutil.rmtree(outdir, ignore_errors=True)

@@ -27,7 +27,8 @@ class RawPostings(C.Structure):
                 ("doclen", C.POINTER(C.c_uint32)), ("terms", C.POINTER(C.c_char_p)),
                 ("term_len", C.POINTER(C.c_uint32)), ("df", C.POINTER(C.c_uint32)),
                 ("did", C.POINTER(C.c_uint32)), ("wdf", C.POINTER(C.c_uint32)),
-                ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint32))]
+                ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint32)),
+                ("doclen_lower_bound", C.c_uint32), ("wdf_upper_bound", C.c_uint32)]
 
 
 class SynthParams(C.Structure):
@@ -115,6 +116,7 @@ _API = [
     ("xgm_debug_read_doclen", C.c_int64, [C.c_void_p, _P(C.c_uint32), C.c_uint64]),
     ("xgm_debug_read_positions", C.c_int64, [C.c_void_p, C.c_uint32, _P(C.c_uint32), C.c_uint64]),
     ("xgm_debug_plan_us", C.c_double, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32]),
+    ("xgm_debug_batch_launches", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_char_p, C.c_uint32]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <string>
 
 #include "xgm_internal.h"
 #include "xgm_launch.h"
@@ -100,7 +101,7 @@ static int grow_pinned(void** p, size_t* cap, size_t need) {
  * returns to the pool ("pending"); the next call takes a FREE one, or creates another (up to
  * XGM_MAX_SCRATCH), so the host plans batch i+1 while the GPU runs batch i.  Only when every scratch is
  * busy does a call wait — for the oldest. */
-#define XGM_MAX_SCRATCH 4u
+#define XGM_MAX_SCRATCH 8u
 
 static int scratch_acquire(xgm_index* idx, XgmScratch** out) {
     *out = nullptr;
@@ -637,9 +638,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     return XGM_OK;
 }
 
-/* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`. */
-static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
-                     xgm_hit* d_hits, xgm_result_hdr* d_hdrs) {
+/* Runs one batch of ONE kernel class (or a batch whose mix plan_batch resolves by itself); results land in rows
+ * rows[i] (i when rows == NULL) of d_hits / d_hdrs (device).  Asynchronous on `stream`. */
+static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
+                           xgm_hit* d_hits, xgm_result_hdr* d_hdrs, const uint32_t* rows) {
     int rc;
     size_t up_bytes = (size_t)nq * (sizeof(xgm_dev_query) + sizeof(uint32_t) + sizeof(double));
     if ((rc = grow_pinned(&s->h_up, &s->cap_up, up_bytes))) return rc;
@@ -657,7 +659,8 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     const size_t o_wk = o_mp + b_mp, b_wk = (size_t)bp.n_work * sizeof(xgm_work);
     const size_t o_kq = o_wk + b_wk, b_kq = (size_t)nq * 4;
     const size_t o_go = o_kq + b_kq, b_go = ((size_t)nq + 1) * 4;
-    const size_t in_bytes = (o_go + b_go + 15) & ~(size_t)15;
+    const size_t o_ro = o_go + b_go, b_ro = rows ? (size_t)nq * 4 : 0;
+    const size_t in_bytes = (o_ro + b_ro + 15) & ~(size_t)15;
     if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
     if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
     unsigned char* hin = (unsigned char*)s->h_work;
@@ -666,6 +669,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     memcpy(hin + o_wk, bp.work.data(), b_wk);
     memcpy(hin + o_kq, h_kq, b_kq);
     memcpy(hin + o_go, bp.goff.data(), b_go);
+    if (rows) memcpy(hin + o_ro, rows, b_ro);
     if (stream != s->stream) {
         /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
          * kernels of the previous batch still running on the caller's stream */
@@ -718,9 +722,60 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         return rc;
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
-                               d_hdrs, s->d_maxposs, stream)))
+                               d_hdrs, s->d_maxposs, rows ? (const uint32_t*)(din + o_ro) : nullptr, stream)))
         return rc;
     return XGM_OK;
+}
+
+/* Kernel class of a planned query: which match kernel serves it best.  A server's natural batch is heterogeneous
+ * (Xapiand's HTTP threads issue whatever the clients send): run_batch cuts it into one launch per class present instead
+ * of sending the whole batch to the slowest common denominator. */
+enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_COUNT };
+
+static int classify_query(const xgm_query& q) {
+    const uint32_t T = q.n_terms;
+    const uint32_t prefix = q.req_mask && !(q.req_mask & (q.req_mask + 1u));            /* required terms = plan positions [0, n_req) */
+    switch (q.op) {
+    case XGM_OP_OR: return XGM_CLS_OR;
+    case XGM_OP_PHRASE: return (q.phrase_active && T >= 2u) ? XGM_CLS_PHRASE : XGM_CLS_OTHER;
+    case XGM_OP_AND:
+    case XGM_OP_FILTER: return T >= 2u ? XGM_CLS_AND : XGM_CLS_OTHER;
+    case XGM_OP_AND_NOT: return (T >= 2u && T <= 8u && prefix && (q.req_mask | q.neg_mask) == (1u << T) - 1u) ? XGM_CLS_SIDED1 : XGM_CLS_OTHER;
+    case XGM_OP_AND_MAYBE: return (T >= 2u && T <= 8u && prefix) ? XGM_CLS_SIDED2 : XGM_CLS_OTHER;
+    default: return XGM_CLS_OTHER;
+    }
+}
+
+/* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`. */
+static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
+                     xgm_hit* d_hits, xgm_result_hdr* d_hdrs) {
+    static const bool no_split = getenv("XGM_NO_CLASS_SPLIT") != nullptr;          /* A/B switch for measurements */
+    uint32_t count[XGM_CLS_COUNT] = {};
+    static thread_local std::vector<uint8_t> cls;
+    cls.resize(nq);
+    uint32_t present = 0;
+    for (uint32_t i = 0; i < nq; ++i) { cls[i] = (uint8_t)classify_query(qs[i]); if (count[cls[i]]++ == 0) ++present; }
+    if (present <= 1u || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
+    /* one launch per class present, all on `stream`; the first uses the caller's scratch, the others take their own
+     * from the pool (each is marked pending behind its launch) */
+    static thread_local std::vector<xgm_query> sub;
+    static thread_local std::vector<uint32_t> rows;
+    bool first = true;
+    int rc = XGM_OK;
+    for (int c = 0; c < XGM_CLS_COUNT && rc == XGM_OK; ++c) {
+        if (!count[c]) continue;
+        sub.clear(); rows.clear();
+        for (uint32_t i = 0; i < nq; ++i) if (cls[i] == c) { sub.push_back(qs[i]); rows.push_back(i); }
+        XgmScratch* sc = s;
+        if (!first && (rc = scratch_acquire(idx, &sc))) break;
+        rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows.data());
+        if (sc != s) {
+            if (hipEventRecord(sc->ev_done, stream) == hipSuccess) sc->pending = true; else hipStreamSynchronize(stream);
+            scratch_release(idx, sc);
+        }
+        first = false;
+    }
+    return rc;
 }
 
 static hipStream_t pick_stream(xgm_index* idx, XgmScratch* s) { return idx->stream ? (hipStream_t)idx->stream : s->stream; }
@@ -1257,6 +1312,29 @@ extern "C" int64_t xgm_debug_plan_batch(const xgm_index* idx, const xgm_query* q
         units[4 * i] = bp.work[i].qi; units[4 * i + 1] = bp.work[i].s_begin; units[4 * i + 2] = bp.work[i].s_end; units[4 * i + 3] = bp.work[i].slot;
     }
     return (int64_t)bp.work.size();
+}
+
+/* Diagnostics (host only): the launches a batch is cut into — one per kernel class present (run_batch) — as
+ * "<kernel>[:variant]*<queries>" joined by ';' in launch order; returns the number of launches, or < 0 /
+ * XGM_UNSUPPORTED like a search would. */
+extern "C" int xgm_debug_batch_launches(const xgm_index* idx, const xgm_query* qs, uint32_t nq, char* out, uint32_t cap) {
+    if (!idx || !qs || !out || cap == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    out[0] = 0;
+    std::vector<std::vector<xgm_query>> by(XGM_CLS_COUNT);
+    for (uint32_t i = 0; i < nq; ++i) by[classify_query(qs[i])].push_back(qs[i]);
+    int n = 0;
+    std::string acc;
+    for (auto& v : by) {
+        if (v.empty()) continue;
+        char name[32];
+        int64_t rc = xgm_debug_plan_batch(idx, v.data(), (uint32_t)v.size(), name, nullptr, 0);
+        if (rc < 0 || rc == XGM_UNSUPPORTED) return (int)rc;
+        if (n++) acc += ";";
+        acc += name;
+        acc += "*" + std::to_string(v.size());
+    }
+    snprintf(out, cap, "%s", acc.c_str());
+    return n;
 }
 
 /* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end, matches, documents weighed)

@@ -27,6 +27,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
 int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vector<const char*>* term_ptrs,
                       std::vector<uint32_t>* term_lens, xgm_raw_postings* raw);
 int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes);
+int xgm_validate_blob(const XgmSegmentBlob& blob);
 
 /* Per-thread scratch for searches (device + pinned host buffers), see xgm_api.cc. */
 struct XgmScratch;

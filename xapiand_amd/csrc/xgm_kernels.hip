@@ -1607,9 +1607,12 @@ constexpr uint32_t kMergeSel = 512;    /* survivors the selection path of the me
 __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __restrict__ cand, const xgm_group_hdr* __restrict__ ghdr,
                                                             const uint32_t* __restrict__ goff, uint32_t k_stride_in, const uint32_t* __restrict__ kq,
                                                             uint32_t cap, uint32_t k_stride_out, xgm_hit* __restrict__ hits,
-                                                            xgm_result_hdr* __restrict__ hdrs, const double* __restrict__ max_possible) {
+                                                            xgm_result_hdr* __restrict__ hdrs, const double* __restrict__ max_possible,
+                                                            const uint32_t* __restrict__ row_of) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+    /* a heterogeneous batch runs one launch per kernel class: query qi of this launch is row row_of[qi] of the caller's batch */
+    const uint32_t orow = row_of ? row_of[qi] : qi;
     TopK tk;
     tk.w = reinterpret_cast<uint64_t*>(smem);
     tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
@@ -1687,7 +1690,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 if (rank < n) {
                     xgm_hit hit;
                     hit.docid = d; hit.subqs_matched = sel_m[i]; hit.weight = __longlong_as_double((long long)w);
-                    hits[(size_t)qi * k_stride_out + rank] = hit;
+                    hits[(size_t)orow * k_stride_out + rank] = hit;
                 }
                 if (rank == 0u) { best_w = w; best_m = sel_m[i]; }
             }
@@ -1699,7 +1702,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 r.matches_exact = matches;
                 r.max_attained = __longlong_as_double((long long)best_w);
                 r.max_possible = max_possible ? max_possible[qi] : 0.0;
-                hdrs[qi] = r;
+                hdrs[orow] = r;
             }
             return;
         }
@@ -1708,7 +1711,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     for (uint32_t i = tid; i < n; i += XGM_WG) {
         xgm_hit hit;
         hit.docid = tk.d[i]; hit.subqs_matched = tk.m[i]; hit.weight = __longlong_as_double((long long)tk.w[i]);
-        hits[(size_t)qi * k_stride_out + i] = hit;
+        hits[(size_t)orow * k_stride_out + i] = hit;
     }
     if (tid == 0) {
         xgm_result_hdr r;
@@ -1717,7 +1720,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         r.matches_exact = matches;
         r.max_attained = fill ? __longlong_as_double((long long)tk.w[0]) : 0.0;
         r.max_possible = max_possible ? max_possible[qi] : 0.0;
-        hdrs[qi] = r;
+        hdrs[orow] = r;
     }
 }
 
@@ -1931,11 +1934,11 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
 
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
-                     xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream) {
+                     xgm_result_hdr* hdrs, const double* max_possible, const uint32_t* row_of, hipStream_t stream) {
     const size_t smem = (size_t)cap * 16 + 64 + (size_t)kMergeSel * 16;
     { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_kernel, dim3(nq), dim3(XGM_WG), smem, stream, cand, ghdr, goff, k_stride_in, kq, cap,
-                       k_stride_out, hits, hdrs, max_possible);
+                       k_stride_out, hits, hdrs, max_possible, row_of);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

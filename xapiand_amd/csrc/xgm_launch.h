@@ -36,7 +36,7 @@ size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap
 int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream);
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
-                     xgm_result_hdr* hdrs, const double* max_possible, hipStream_t stream);
+                     xgm_result_hdr* hdrs, const double* max_possible, const uint32_t* row_of, hipStream_t stream);
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
                             hipStream_t stream);

@@ -36,6 +36,8 @@ struct BitWriter {
 
 }  // namespace
 
+/* A segment file is untrusted input: everything the loader, the planner and the kernels index by header counts is
+ * checked against the section sizes here, with overflow-safe arithmetic, before the blob is adopted. */
 int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes) {
     if (memcmp(h->magic, XGM_SEG_MAGIC, 8) != 0) return xgm_set_error(XGM_E_INVALID, "not an XGMSEG1 segment");
     if (h->version != XGM_SEG_VERSION) return xgm_set_error(XGM_E_INVALID, "segment version %u unsupported", h->version);
@@ -44,7 +46,60 @@ int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes) {
         return xgm_set_error(XGM_E_INVALID, "segment stripe_bits %u out of range", h->stripe_bits);
     if (h->file_bytes > avail_bytes) return xgm_set_error(XGM_E_INVALID, "segment truncated");
     for (int s = 0; s < XGM_S_COUNT; ++s)
-        if (h->sec_off[s] + h->sec_bytes[s] > h->file_bytes) return xgm_set_error(XGM_E_INVALID, "segment section %d out of bounds", s);
+        if (h->sec_off[s] > h->file_bytes || h->sec_bytes[s] > h->file_bytes - h->sec_off[s] || (h->sec_off[s] & 7u))
+            return xgm_set_error(XGM_E_INVALID, "segment section %d out of bounds", s);
+    /* section sizes against the element counts */
+    const uint64_t T = h->n_terms, B = h->n_blocks;
+    if (B >= 0xFFFFFFFFull || h->n_words >= (1ull << 40) || h->n_positions >= (1ull << 40))
+        return xgm_set_error(XGM_E_INVALID, "segment counts out of range");
+    const struct { int sec; uint64_t need; } want[] = {
+        {XGM_S_DOCLEN, ((uint64_t)h->lastdocid + 1) * 4}, {XGM_S_TERM_DF, T * 4}, {XGM_S_TERM_CF, T * 4}, {XGM_S_TERM_WDFUB, T * 4},
+        {XGM_S_TERM_FLAGS, T * 4}, {XGM_S_TERM_BLK, (T + 1) * 8}, {XGM_S_TERM_WORD, (T + 1) * 8}, {XGM_S_TERM_POS, (T + 1) * 8},
+        {XGM_S_BLK_FIRST, B * 4}, {XGM_S_BLK_META, B * 4}, {XGM_S_BLK_WORD, B * 4}, {XGM_S_BLK_POS, B * 4},
+        {XGM_S_WORDS, (h->n_words + XGM_WORD_PAD) * 4}, {XGM_S_POSITIONS, h->n_positions * 4}, {XGM_S_STR_OFF, (T + 1) * 8}};
+    for (const auto& w : want)
+        if (h->sec_bytes[w.sec] < w.need) return xgm_set_error(XGM_E_INVALID, "segment section %d is smaller than its header counts imply", w.sec);
+    if (h->doccount > h->lastdocid) return xgm_set_error(XGM_E_INVALID, "segment doccount exceeds lastdocid");
+    return XGM_OK;
+}
+
+/* The tables behind the header: monotone offsets ending at the section sizes, blocks inside their term's payload and
+ * docid range.  O(n_terms + n_blocks) once per load. */
+int xgm_validate_blob(const XgmSegmentBlob& blob) {
+    const xgm_seg_header* h = blob.header();
+    const uint32_t T = h->n_terms;
+    const uint64_t B = h->n_blocks;
+    const uint64_t* so = blob.section<uint64_t>(XGM_S_STR_OFF);
+    const uint64_t* tb = blob.section<uint64_t>(XGM_S_TERM_BLK);
+    const uint64_t* tw = blob.section<uint64_t>(XGM_S_TERM_WORD);
+    const uint64_t* tp = blob.section<uint64_t>(XGM_S_TERM_POS);
+    if (so[0] != 0 || tb[0] != 0 || tw[0] != 0 || tp[0] != 0) return xgm_set_error(XGM_E_INVALID, "segment tables do not start at 0");
+    for (uint32_t t = 0; t < T; ++t)
+        if (so[t + 1] < so[t] || tb[t + 1] < tb[t] || tw[t + 1] < tw[t] || tp[t + 1] < tp[t])
+            return xgm_set_error(XGM_E_INVALID, "segment term table %u is not monotone", t);
+    if (so[T] > h->sec_bytes[XGM_S_STR_BYTES] || tb[T] != B || tw[T] != h->n_words || tp[T] > h->n_positions)
+        return xgm_set_error(XGM_E_INVALID, "segment term tables do not end at the section sizes");
+    const uint32_t* bf = blob.section<uint32_t>(XGM_S_BLK_FIRST);
+    const uint32_t* bm = blob.section<uint32_t>(XGM_S_BLK_META);
+    const uint32_t* bw = blob.section<uint32_t>(XGM_S_BLK_WORD);
+    const uint32_t* bp = blob.section<uint32_t>(XGM_S_BLK_POS);
+    const uint32_t* df = blob.section<uint32_t>(XGM_S_TERM_DF);
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint64_t words_t = tw[t + 1] - tw[t], pos_t = tp[t + 1] - tp[t];
+        uint64_t n = 0;
+        uint32_t prev = 0;
+        for (uint64_t b = tb[t]; b < tb[t + 1]; ++b) {
+            const uint32_t meta = bm[b], cnt = XGM_META_COUNT(meta), g = XGM_META_BWG(meta), w = XGM_META_BWW(meta);
+            if (cnt > XGM_BLOCK || g > 32u || w > 32u) return xgm_set_error(XGM_E_INVALID, "segment block %llu: bad meta", (unsigned long long)b);
+            const uint64_t pw = (((uint64_t)cnt * g + 31u) >> 5) + (((uint64_t)cnt * w + 31u) >> 5);
+            if ((uint64_t)bw[b] + pw > words_t) return xgm_set_error(XGM_E_INVALID, "segment block %llu: payload outside its term", (unsigned long long)b);
+            if (bf[b] == 0 || bf[b] > h->lastdocid || (b > tb[t] && bf[b] <= prev)) return xgm_set_error(XGM_E_INVALID, "segment block %llu: docids out of order", (unsigned long long)b);
+            if (pos_t && bp[b] > pos_t) return xgm_set_error(XGM_E_INVALID, "segment block %llu: positions outside its term", (unsigned long long)b);
+            prev = bf[b];
+            n += cnt;
+        }
+        if (n != df[t]) return xgm_set_error(XGM_E_INVALID, "segment term %u: block counts (%llu) != termfreq (%u)", t, (unsigned long long)n, df[t]);
+    }
     return XGM_OK;
 }
 
@@ -71,6 +126,9 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
         if (l && (doclen_lb == 0 || l < doclen_lb)) doclen_lb = l;
     }
     for (uint64_t i = 0; i < raw->n_postings; ++i) wdf_ub_db = std::max(wdf_ub_db, raw->wdf[i]);
+    /* the backend's own (looser) bounds win when given: they are what the reference's BM25Weight sees */
+    if (raw->doclen_lower_bound && (doclen_lb == 0 || raw->doclen_lower_bound <= doclen_lb)) doclen_lb = raw->doclen_lower_bound;
+    if (raw->wdf_upper_bound >= wdf_ub_db && raw->wdf_upper_bound) wdf_ub_db = raw->wdf_upper_bound;
 
     uint64_t p0 = 0;
     BitWriter bw(words);
@@ -294,7 +352,8 @@ int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob) {
     int rc = read_whole(path, &blob->bytes);
     if (rc) return rc;
     if (blob->bytes.size() < sizeof(xgm_seg_header)) return xgm_set_error(XGM_E_INVALID, "%s too small", path);
-    return xgm_validate_header(blob->header(), blob->bytes.size());
+    if ((rc = xgm_validate_header(blob->header(), blob->bytes.size()))) return rc;
+    return xgm_validate_blob(*blob);
 }
 
 static uint32_t get_bits(const uint32_t* w, uint32_t i, uint32_t bw) {
