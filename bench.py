@@ -64,7 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--ref-docs", type=int, default=-1, help="documents of the reference glass index built on this box (0: skip the reference leg; "
-                    "default: the configuration's full size, 1/10 of it for PHRASE whose index carries positions)")
+                    "default: 1/5 of the configuration's documents — indexing 10 M documents through the reference's WritableDatabase takes "
+                    "~3.5 min even on 128 cores; `--ref-docs 10000000` reproduces profiles/r02_reference_full.json)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
     ap.add_argument("--threads", type=int, default=0, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight")
     return ap.parse_args()
@@ -367,7 +368,7 @@ def reference_leg(args, sample, k, n_required, full, ora_full):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ref_index
     from xapiand_amd import Database
-    ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu)
+    ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu // 5)
     if not H.have_xapian_ref() or ref_docs <= 0:
         return None
     # the index lives in memory-backed storage when there is one: indexing through WritableDatabase is write-heavy
@@ -452,6 +453,12 @@ def cpu_baseline(db, pool_q, args, k, timed_plans):
         if ref["docs"] != full["docs"]:
             out["reference_full_size_estimate"] = {"value": full["value"] / ref["port_over_reference"], "unit": "queries/s", "cores": 1,
                                                    "note": "port at %d docs / port_over_reference" % full["docs"]}
+            rpath = os.path.join(ROOT, "profiles", "r02_reference_full.json")
+            if args.op == "AND" and args.terms == 3 and k == 10 and full["docs"] == 10_000_000 and os.path.exists(rpath):
+                # the same leg run ONCE at the full size on this box type (too long for every default run)
+                r = json.load(open(rpath))
+                out["reference_full_size_measured"] = {"value": r["one_thread"]["value"], "unit": "queries/s", "cores": 1, "all_cores": r["all_cores"],
+                                                       "docs": r["docs"], "source": "profiles/r02_reference_full.json (python bench.py --ref-docs 10000000)"}
         out["sample"] = ("Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time), glass index of the first %d documents of the same "
                          "corpus built on this box (%.0f s on %d cores + %.0f s compact), same queries; " % (ref["docs"], ref["index_build"]["build_s"],
                                                                                                        ref["index_build"]["procs"], ref["index_build"]["compact_s"])) + sample_txt

@@ -58,6 +58,9 @@ extern "C" {
 #define XGM_OP_AND_NOT 4
 #define XGM_OP_AND_MAYBE 5
 #define XGM_OP_FILTER 6
+/* OP_NEAR (reference src/xapian/matcher/nearpostlist.cc:60-160): the AND of the terms, filtered to documents where one
+ * occurrence of every term falls inside a span shorter than `window`, in any order.  Distinct terms only. */
+#define XGM_OP_NEAR 7
 
 typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
 #define XGM_DEVICE_NONE (-1)
@@ -191,7 +194,7 @@ typedef struct {
     uint32_t n_terms;
     const char* terms[XGM_MAX_TERMS];     /* in QUERY order (phrase order for PHRASE)              */
     uint32_t term_len[XGM_MAX_TERMS];
-    uint32_t window;                      /* PHRASE: 0 = n_terms (exact phrase)                    */
+    uint32_t window;                      /* PHRASE / NEAR: 0 = n_terms (exact phrase)             */
     uint32_t first, maxitems, check_at_least;
     /* BM25 parameters (reference src/xapian/weight.h:635-667 defaults 1, 0, 1, 0.5, 0.5) */
     double k1, k2, k3, b, min_normlen;

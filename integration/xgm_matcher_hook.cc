@@ -68,7 +68,7 @@ bool lower(const Xapian::Query& q, Lowered* L) {
         if (!terms_of(q, op, &L->terms)) return false;
         L->d.op = op == Xapian::Query::OP_AND ? XGM_OP_AND : XGM_OP_OR;
         L->total_subqs = (uint32_t)L->terms.size();
-    } else if (op == Xapian::Query::OP_PHRASE) {
+    } else if (op == Xapian::Query::OP_PHRASE || op == Xapian::Query::OP_NEAR) {
         if (g_decline_positional.load(std::memory_order_relaxed)) return false;
         const size_t n = q.get_num_subqueries();
         for (size_t i = 0; i < n; ++i) {
@@ -76,7 +76,7 @@ bool lower(const Xapian::Query& q, Lowered* L) {
             if (!leaf_term(s, &t)) return false;         /* phrase offsets are the subquery ORDER (exactphrasepostlist.cc:75-133) */
             L->terms.push_back(t);
         }
-        L->d.op = XGM_OP_PHRASE;
+        L->d.op = op == Xapian::Query::OP_PHRASE ? XGM_OP_PHRASE : XGM_OP_NEAR;
         const auto* w = static_cast<const Xapian::Internal::QueryWindowed*>(q.internal.get());
         L->d.window = (uint32_t)w->get_window();
         L->total_subqs = (uint32_t)n;

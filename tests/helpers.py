@@ -284,7 +284,7 @@ def doc_tokens(seed, vocab, len_lo, len_hi, g):
 
 
 def gen_phrase_queries(n_queries, n_docs_global, vocab, len_lo=50, len_hi=150, corpus_seed=CORPUS_SEED, seed=QUERY_SEED,
-                       maxitems=10, window_extra=0):
+                       maxitems=10, window_extra=0, lengths=(2, 3), op="PHRASE"):
     """2-3-grams that actually occur in a random document (so results are non-empty); n-grams with a
     repeated term are skipped (the device path declines them, like any other unsupported shape)."""
     rng = random.Random(seed)
@@ -292,12 +292,12 @@ def gen_phrase_queries(n_queries, n_docs_global, vocab, len_lo=50, len_hi=150, c
     while len(qs) < n_queries:
         g = rng.randint(1, n_docs_global)
         toks = doc_tokens(corpus_seed, vocab, len_lo, len_hi, g)
-        n = rng.choice([2, 3])
+        n = rng.choice(list(lengths))
         i = rng.randint(0, len(toks) - n)
         gram = toks[i:i + n]
         if len(set(gram)) != n:
             continue
-        qs.append(dict(op="PHRASE", terms=["t%d" % r for r in gram], first=0, maxitems=maxitems,
+        qs.append(dict(op=op, terms=["t%d" % r for r in gram], first=0, maxitems=maxitems,
                        window=(n + window_extra) if window_extra else 0))
     return qs
 

@@ -55,8 +55,14 @@ def supported_queries():
 def test_hook_on_equals_hook_off_single_shard(built, glass):
     d, one, _ = glass
     qs = supported_queries()
-    # PHRASE with maxitems >= matches: where the reference's stale-weight quirk cannot engage
-    qs += [dict(q, maxitems=1000) for q in H.gen_phrase_queries(20, N_DOCS, VOCAB, seed=19)]
+    n_plain = len(qs)
+    # PHRASE / NEAR with maxitems >= matches: where the reference's stale-weight quirk cannot engage
+    corpus = H.Corpus(N_DOCS, VOCAB)
+    for q in (H.gen_phrase_queries(30, N_DOCS, VOCAB, seed=19, lengths=(2, 3, 4)) + H.gen_phrase_queries(12, N_DOCS, VOCAB, seed=20, window_extra=3) +
+              H.gen_phrase_queries(12, N_DOCS, VOCAB, seed=24, window_extra=4, op="NEAR")):
+        if H.oracle_search(corpus, q["op"], q["terms"], 0, 150, window=q.get("window", 0))[1].matches <= 150:
+            qs.append(dict(q, maxitems=150))
+    assert len(qs) - n_plain >= 30
     qf = str(d / "q1.txt")
     H.write_queries(qf, qs)
     out = run_b1(qf, one)
@@ -76,8 +82,8 @@ def test_hook_on_equals_hook_off_xapiand_protocol(built, glass):
 
 def test_unsupported_shapes_fall_through_to_the_cpu_matcher(built, glass):
     d, one, _ = glass
-    qs = [dict(op="NEAR", terms=["t1", "t2"], first=0, maxitems=10, window=4),         # not on the device path yet
-          dict(op="AND", terms=["t3", "t3"], first=0, maxitems=10, window=0)]           # repeated term (wqf merging)
+    qs = [dict(op="AND", terms=["t3", "t3"], first=0, maxitems=10, window=0),           # repeated term (wqf merging)
+          dict(op="OR", terms=["t%d" % i for i in range(1, 19)], first=0, maxitems=10, window=0)]     # 18 leaves: beyond XGM_MAX_TERMS
     qs += H.gen_term_queries("AND", 4, 3, 1, 100, maxitems=10, seed=21)
     qf = str(d / "qu.txt")
     H.write_queries(qf, qs)

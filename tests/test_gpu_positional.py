@@ -1,0 +1,74 @@
+"""The positional filter (K6) in all its forms against the CPU oracle (pinned to the compiled reference by
+tests/test_oracle_vs_reference.py): exact phrases of 2-8 terms, windowed phrases, NEAR (any order, span < window),
+documents with more positions of a term than the LDS fast path holds, and terms whose positions need 4 bytes.
+Reference: src/xapian/matcher/exactphrasepostlist.cc:75-133, phrasepostlist.cc:60-90, nearpostlist.cc:60-160."""
+import random
+
+import pytest
+
+import helpers as H
+from xapiand_amd import Database, Query, plan, search_batch
+
+pytestmark = pytest.mark.gpu
+
+N_DOCS, VOCAB = 60000, 3000          # a small vocabulary: long n-grams recur, windows have real work to do
+
+
+def check(db, corpus, qs):
+    plans = [plan(db, Query(q["op"], q["terms"], window=q.get("window", 0)), q["first"], q["maxitems"]) for q in qs]
+    got = search_batch(db, plans)
+    n_hits = 0
+    for q, (hits, hdr) in zip(qs, got):
+        want, oh = H.oracle_search(corpus, q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0))
+        assert [(h.docid, h.weight) for h in hits] == [(d, w) for d, w, _ in want], q
+        assert hdr.matches_exact == oh.matches, q
+        n_hits += len(want)
+    return n_hits
+
+
+def test_phrase_near_window_and_long_phrases(built, tmp_path):
+    c = H.Corpus(N_DOCS, VOCAB)
+    db = Database(c.build_segment(str(tmp_path / "p.seg")))
+    qs = (H.gen_phrase_queries(40, N_DOCS, VOCAB, seed=1, lengths=(2, 3)) + H.gen_phrase_queries(40, N_DOCS, VOCAB, seed=2, lengths=(4, 5, 6, 8)) +
+          H.gen_phrase_queries(30, N_DOCS, VOCAB, seed=3, window_extra=3, lengths=(2, 3, 4)) +
+          H.gen_phrase_queries(40, N_DOCS, VOCAB, seed=4, window_extra=2, lengths=(2, 3, 5), op="NEAR") +
+          H.gen_phrase_queries(20, N_DOCS, VOCAB, seed=5, window_extra=12, lengths=(2, 3), op="NEAR"))
+    # NEAR is order-free: shuffle the terms of half of them
+    rng = random.Random(9)
+    for q in qs:
+        if q["op"] == "NEAR" and rng.random() < 0.5:
+            rng.shuffle(q["terms"])
+    for q in qs:
+        q["maxitems"] = 200 if rng.random() < 0.3 else 10
+    assert check(db, c, qs) > 500
+    # and in one heterogeneous batch with plain conjunctions (kernel classes are cut apart, results are not)
+    mixed = qs[:20] + [dict(q, window=0) for q in H.gen_term_queries("AND", 10, 3, 1, 300, seed=6)]
+    check(db, c, mixed)
+    db.close()
+
+
+def test_slow_path_many_positions_and_wide_positions(built, tmp_path):
+    """wdf > 16 (more than the fast path stages per document and term) and positions >= 65 536 (4-byte lists)."""
+    rng = random.Random(3)
+    post = {"a": [], "b": [], "c": [], "w": [], "x": []}
+    doclen = {}
+    for d in range(1, 4001):
+        na, nb = rng.choice([1, 3, 9, 17, 20, 40]), rng.choice([1, 2, 8, 16, 18, 33])
+        pa = sorted(rng.sample(range(1, 400), na))
+        pb = sorted(set(min(399, p + rng.choice([1, 1, 2, 5])) for p in rng.sample(pa, min(len(pa), nb))) | set(rng.sample(range(1, 400), max(0, nb - na))))
+        pc = sorted(rng.sample(range(1, 400), rng.choice([1, 2, 5])))
+        post["a"].append((d, len(pa), pa)); post["b"].append((d, len(pb), pb)); post["c"].append((d, len(pc), pc))
+        # wide positions: a long document
+        pw = sorted(rng.sample(range(60000, 70000), rng.choice([1, 3, 6])))
+        px = sorted(set(p + 1 for p in pw[: rng.choice([0, 1, 2])]) | set(rng.sample(range(60000, 70000), 2)))
+        post["w"].append((d, len(pw), pw)); post["x"].append((d, len(px), px))
+        doclen[d] = 70000
+    c = H.ManualCorpus(post, doclen)
+    db = Database(c.build_segment(str(tmp_path / "s.seg")))
+    qs = []
+    for terms in (["a", "b"], ["b", "a"], ["a", "b", "c"], ["w", "x"], ["a", "w"], ["x", "w", "a"]):
+        for op, win in (("PHRASE", 0), ("PHRASE", len(terms) + 3), ("NEAR", len(terms) + 2), ("NEAR", 40)):
+            qs.append(dict(op=op, terms=terms, first=0, maxitems=150, window=win))
+            qs.append(dict(op=op, terms=terms, first=0, maxitems=10, window=win))
+    assert check(db, c, qs) > 50
+    db.close()

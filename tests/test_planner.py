@@ -74,8 +74,13 @@ def test_plan_shapes(host_env):
     # FILTER: a conjunction whose right-hand leaves weigh nothing, merged in by termfreq
     p = plan(db1, Query("FILTER", ["t200", "t3"], n_required=1), 0, 10)
     assert p.req_mask == 0b11 and sorted(p.terms[i].termweight == 0.0 for i in range(2)) == [False, True]
-    # declined shapes: repeated term, phrase of more than 3 terms, first + maxitems beyond the device top-k
-    for bad, first, k in ((Query("AND", ["t3", "t3"]), 0, 10), (Query("PHRASE", ["t1", "t2", "t3", "t4"]), 0, 10),
+    # PHRASE of up to 8 terms and NEAR are planned like a conjunction with a positional filter
+    p = plan(db1, Query("PHRASE", ["t1", "t2", "t3", "t4"]), 0, 10)
+    assert p.phrase_active == 1 and p.window == 4 and p.req_mask == 0b1111
+    p = plan(db1, Query("NEAR", ["t1", "t2", "t3"], window=7), 0, 10)
+    assert p.op == _lib.XGM_OP_NEAR and p.phrase_active == 1 and p.window == 7
+    # declined shapes: repeated term, phrase of more than 8 terms, first + maxitems beyond the device top-k
+    for bad, first, k in ((Query("AND", ["t3", "t3"]), 0, 10), (Query("PHRASE", ["t%d" % i for i in range(1, 10)]), 0, 10),
                           (Query("AND", ["t3", "t17"]), 1000, 100)):
         with pytest.raises(_lib.XgmUnsupported):
             plan(db1, bad, first, k)

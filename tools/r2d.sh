@@ -1,0 +1,13 @@
+# Round-2 run D: positional filter v2 (format v2, LDS-staged K6, NEAR, long phrases): tests + C5 bench
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+tag=$1
+timeout 1200 python -m pytest tests/test_gpu_positional.py tests/test_gpu_builder.py tests/test_gpu_parity.py tests/test_gpu_mixed.py tests/test_gpu_hook_b1.py tests/test_gpu_hook.py tests/test_gpu_variants.py "tests/test_gpu_configs.py::test_config_scale_parity[C5_phrase_top10]" -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; tail -25 gpurun_out/${tag}_pytest.log
+timeout 400 python bench.py --op PHRASE --topk 10 --steps 10 --warmup 2 --ref-docs 0 --cpu-seconds 3 > gpurun_out/${tag}_bench_phrase.json 2>gpurun_out/${tag}_phrase.err; tail -2 gpurun_out/${tag}_phrase.err
+python - <<PY
+import json
+for n in ('phrase',):
+    try:
+        d=json.load(open('gpurun_out/${tag}_bench_%s.json'%n)); r=d['roofline']
+        print(n,round(d['value']),r['kernel'],r['kernel_ms'],d['p50_latency_us'],'frac',r['frac'],r['basis'],'alg',r['algorithmic']['frac'],'parity',d['cpu_baseline']['parity_checked_queries'],r['model_counts'])
+    except Exception as e: print(n,'failed',e)
+PY

@@ -180,7 +180,8 @@ static void fill_view(xgm_index* idx) {
     v.blk_word = (const uint32_t*)idx->d_sections[XGM_S_BLK_WORD];
     v.blk_pos = (const uint32_t*)idx->d_sections[XGM_S_BLK_POS];
     v.words = (const uint32_t*)idx->d_sections[XGM_S_WORDS];
-    v.positions = (const uint32_t*)idx->d_sections[XGM_S_POSITIONS];
+    v.positions = (const unsigned char*)idx->d_sections[XGM_S_POSITIONS];
+    v.term_flags = (const uint32_t*)idx->d_sections[XGM_S_TERM_FLAGS];
     v.stripe_bits = idx->hdr.stripe_bits;
     v.lastdocid = idx->hdr.lastdocid;
     v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0;
@@ -412,7 +413,8 @@ static uint32_t next_pow2(uint32_t v) {
 /* xgm_query → device form; returns the wdf table width the query needs (1 or 2 bytes), 0 if too big */
 static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query* d) {
     memset(d, 0, sizeof *d);
-    d->op = q->op == XGM_OP_FILTER ? XGM_OP_AND : q->op;       /* a FILTER is a conjunction some of whose leaves weigh nothing */
+    d->op = q->op == XGM_OP_FILTER ? XGM_OP_AND : q->op == XGM_OP_NEAR ? XGM_OP_PHRASE : q->op;   /* a FILTER is a conjunction some of whose leaves weigh
+                                                                                                      nothing; NEAR = PHRASE with another predicate */
     d->n_terms = q->n_terms;
     d->k = q->first + q->maxitems;
     d->window = q->window;
@@ -436,9 +438,10 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         if (ub > 0 && denom_min > 0) bound = q->terms[t].termweight * ((double)ub / (denom_min + (double)ub));
         d->ub[t] = bound * 1.000000001;
     }
-    if (q->op == XGM_OP_PHRASE && q->phrase_active) {
+    if ((q->op == XGM_OP_PHRASE || q->op == XGM_OP_NEAR) && q->phrase_active) {
         d->flags |= XGM_QF_PHRASE;
-        if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
+        if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR;
+        else if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
     }
     if (q->op == XGM_OP_OR ? all_absent : any_absent) d->flags |= XGM_QF_EMPTY;
     /* post-order program → node list */
@@ -737,7 +740,8 @@ static int classify_query(const xgm_query& q) {
     const uint32_t prefix = q.req_mask && !(q.req_mask & (q.req_mask + 1u));            /* required terms = plan positions [0, n_req) */
     switch (q.op) {
     case XGM_OP_OR: return XGM_CLS_OR;
-    case XGM_OP_PHRASE: return (q.phrase_active && T >= 2u) ? XGM_CLS_PHRASE : XGM_CLS_OTHER;
+    case XGM_OP_PHRASE:
+    case XGM_OP_NEAR: return (q.phrase_active && T >= 2u) ? XGM_CLS_PHRASE : XGM_CLS_OTHER;
     case XGM_OP_AND:
     case XGM_OP_FILTER: return T >= 2u ? XGM_CLS_AND : XGM_CLS_OTHER;
     case XGM_OP_AND_NOT: return (T >= 2u && T <= 8u && prefix && (q.req_mask | q.neg_mask) == (1u << T) - 1u) ? XGM_CLS_SIDED1 : XGM_CLS_OTHER;
@@ -1238,18 +1242,24 @@ extern "C" int64_t xgm_debug_read_doclen(xgm_index* idx, uint32_t* out, uint64_t
     return (int64_t)n;
 }
 
-/* Copy one term's positions (flat, in posting order: Σ wdf entries) to the host; returns their number. */
+/* Copy one term's positions (flat, in posting order: Σ wdf entries, widened to u32) to the host; returns their number. */
 extern "C" int64_t xgm_debug_read_positions(xgm_index* idx, uint32_t term_id, uint32_t* out, uint64_t cap) {
     if (!idx || (!out && cap)) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (term_id >= idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "term id out of range");
     int rc = use_device(idx->device);
     if (rc) return rc;
-    if (!idx->hdr.has_positions) return 0;
-    uint64_t tp[2];
-    HIP_TRY(hipMemcpy(tp, (const uint64_t*)idx->d_sections[XGM_S_TERM_POS] + term_id, sizeof tp, hipMemcpyDeviceToHost));
-    const uint64_t n = tp[1] - tp[0];
+    if (!idx->hdr.has_positions || !(idx->term_flags[term_id] & XGM_TF_POS_OK)) return 0;
+    uint64_t tp;
+    HIP_TRY(hipMemcpy(&tp, (const uint64_t*)idx->d_sections[XGM_S_TERM_POS] + term_id, sizeof tp, hipMemcpyDeviceToHost));
+    const uint64_t n = idx->term_cf[term_id];                       /* POS_OK: every posting has exactly wdf positions */
     if (cap < n) return xgm_set_error(XGM_E_INVALID, "buffer too small");
-    if (n) HIP_TRY(hipMemcpy(out, (const uint32_t*)idx->d_sections[XGM_S_POSITIONS] + tp[0], n * 4, hipMemcpyDeviceToHost));
+    if (idx->term_flags[term_id] & XGM_TF_POS16) {
+        std::vector<uint16_t> tmp(n);
+        if (n) HIP_TRY(hipMemcpy(tmp.data(), (const char*)idx->d_sections[XGM_S_POSITIONS] + tp, n * 2, hipMemcpyDeviceToHost));
+        for (uint64_t i = 0; i < n; ++i) out[i] = tmp[i];
+    } else if (n) {
+        HIP_TRY(hipMemcpy(out, (const char*)idx->d_sections[XGM_S_POSITIONS] + tp, n * 4, hipMemcpyDeviceToHost));
+    }
     return (int64_t)n;
 }
 

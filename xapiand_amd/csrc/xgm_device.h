@@ -11,11 +11,13 @@
 #define XGM_WAVES (XGM_WG / 64u)
 #define XGM_MERGE_CAP 8192u         /* candidates one merge workgroup can sort in LDS             */
 #define XGM_OR_HIST 256u            /* weight-histogram buckets per query of xgm_orw_kernel        */
-#define XGM_PHRASE_MAX_TERMS 3u     /* position tables are 4 B/slot/term: LDS bound */
+#define XGM_PHRASE_MAX_TERMS 8u     /* terms of a PHRASE / NEAR on the wave kernel (per-lane cursors: 5 bits each in one register) */
+#define XGM_PHRASE_MAX_TERMS_WG 3u  /* ... on the workgroup kernel: position tables are 4 B/slot/term of LDS */
 
 #define XGM_QF_PHRASE 1u            /* apply the positional filter                                 */
 #define XGM_QF_EXACT 2u             /* window == n_terms: ExactPhrasePostList semantics            */
 #define XGM_QF_EMPTY 4u             /* provably no match on this shard (absent AND term, ...)      */
+#define XGM_QF_NEAR 8u              /* the positional filter is NearPostList's (any order, span < window) */
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */
 typedef struct {

@@ -123,16 +123,27 @@ __device__ __forceinline__ uint32_t nz_halves(uint32_t x) {
 
 /* ---------------------------------------------------------------- K6: positional filter ------ */
 
-struct PosList { const uint32_t* p; uint32_t n; };
+/* One document's positions of one term, in HBM: 2 or 4 bytes per entry (XGM_TF_POS16). */
+struct PosList {
+    const unsigned char* p; uint32_t n; uint32_t w16;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const {
+        return w16 ? (uint32_t)reinterpret_cast<const uint16_t*>(p)[i] : reinterpret_cast<const uint32_t*>(p)[i];
+    }
+};
+
+/* The three positional predicates straight from HBM, one document per lane with serial dependent reads: the SLOW
+ * path — documents with more than kPosFast positions of a term, 4-byte position lists, and the workgroup kernel.
+ * The wave kernel's fast path (positions staged in LDS by vector loads) is posfilter_lds below. */
 
 /* ExactPhrasePostList::test_doc: is there a base with term i at base + phrase_index[i] for all i? */
 __device__ bool phrase_exact(const PosList* pl, const uint8_t* pidx, uint32_t n_terms) {
     /* drive from the shortest list */
     uint32_t drv = 0;
     for (uint32_t t = 1; t < n_terms; ++t) if (pl[t].n < pl[drv].n) drv = t;
-    uint32_t cursor[XGM_PHRASE_MAX_TERMS] = {0, 0, 0};
+    uint32_t cursor[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) cursor[t] = 0;
     for (uint32_t i = 0; i < pl[drv].n; ++i) {
-        uint32_t x = pl[drv].p[i];
+        uint32_t x = pl[drv].at(i);
         if (x < pidx[drv]) continue;
         uint32_t base = x - pidx[drv];
         bool ok = true;
@@ -140,9 +151,9 @@ __device__ bool phrase_exact(const PosList* pl, const uint8_t* pidx, uint32_t n_
             if (t == drv) continue;
             uint32_t want = base + pidx[t];
             uint32_t c = cursor[t];
-            while (c < pl[t].n && pl[t].p[c] < want) ++c;
+            while (c < pl[t].n && pl[t].at(c) < want) ++c;
             cursor[t] = c;
-            ok = (c < pl[t].n) && (pl[t].p[c] == want);
+            ok = (c < pl[t].n) && (pl[t].at(c) == want);
         }
         if (ok) return true;
     }
@@ -154,12 +165,13 @@ __device__ bool phrase_window(const PosList* pl_plan, const uint8_t* pidx, uint3
     /* reorder to phrase order: terms[i] of the reference is the i-th word of the phrase */
     PosList pl[XGM_PHRASE_MAX_TERMS];
     for (uint32_t t = 0; t < n_terms; ++t) pl[pidx[t]] = pl_plan[t];
-    uint32_t cur[XGM_PHRASE_MAX_TERMS] = {0, 0, 0};
-    bool started[XGM_PHRASE_MAX_TERMS] = {false, false, false};
+    uint32_t cur[XGM_PHRASE_MAX_TERMS];
+    bool started[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) { cur[t] = 0; started[t] = false; }
     if (pl[0].n == 0) return false;               /* poslists[0]->next() */
     uint32_t b;
     while (true) {
-        uint32_t base = pl[0].p[cur[0]];
+        uint32_t base = pl[0].at(cur[0]);
         uint32_t pos = base;
         uint32_t i = 0;
         while (true) {
@@ -167,20 +179,160 @@ __device__ bool phrase_window(const PosList* pl_plan, const uint8_t* pidx, uint3
             /* skip_to(pos + 1) on a forward-only list: never moves backwards */
             uint32_t c = cur[i];
             if (!started[i]) { started[i] = true; c = 0; }
-            while (c < pl[i].n && pl[i].p[c] < pos + 1u) ++c;
+            while (c < pl[i].n && pl[i].at(c) < pos + 1u) ++c;
             cur[i] = c;
             if (c >= pl[i].n) return false;
-            pos = pl[i].p[c];
+            pos = pl[i].at(c);
             b = pos + (n_terms - i);
             if (!(b - base <= window)) break;
         }
         uint32_t want = b - window;
         uint32_t c0 = cur[0];
-        while (c0 < pl[0].n && pl[0].p[c0] < want) ++c0;
+        while (c0 < pl[0].n && pl[0].at(c0) < want) ++c0;
         cur[0] = c0;
         if (c0 >= pl[0].n) return false;
     }
 }
+
+/* NearPostList::test_doc (reference src/xapian/matcher/nearpostlist.cc:60-160) for DISTINCT terms: one position of
+ * every term inside a span shorter than `window`, in any order — advance the list with the smallest head past
+ * (largest head - window) until the heads fit or a list runs out. */
+__device__ bool near_window(const PosList* pl, uint32_t n_terms, uint32_t window) {
+    uint32_t cur[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) cur[t] = 0;
+    for (uint32_t t = 0; t < n_terms; ++t) if (pl[t].n == 0) return false;
+    while (true) {
+        uint32_t lo = 0, lo_v = pl[0].at(cur[0]), hi_v = lo_v;
+        for (uint32_t t = 1; t < n_terms; ++t) {
+            const uint32_t v = pl[t].at(cur[t]);
+            if (v < lo_v) { lo_v = v; lo = t; }
+            if (v > hi_v) hi_v = v;
+        }
+        if (hi_v - lo_v < window) return true;
+        const uint32_t want = hi_v - window + 1u;
+        uint32_t c = cur[lo];
+        while (c < pl[lo].n && pl[lo].at(c) < want) ++c;
+        if (c >= pl[lo].n) return false;
+        cur[lo] = c;
+    }
+}
+
+__device__ __forceinline__ bool posfilter_slow(const PosList* pl, const xgm_dev_query& q, uint32_t T) {
+    if (q.flags & XGM_QF_NEAR) return near_window(pl, T, q.window);
+    return (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
+}
+
+/* ---- K6 fast path: positions staged in the wave's LDS ------------------------------------------------------------
+ * lp[(t * kPosFast + j) * 64 + lane] = j-th position (u16) of plan term t in the lane's document; cnt(t) = how many.
+ * The same three predicates as above, on LDS data with per-lane cursors packed 5 bits per term into one 64-bit
+ * register; every loop over terms is unrolled (T is wave-uniform), so nothing is indexed dynamically in registers.
+ * Bank conflicts: lanes l and l' collide only if (j * 32 + l / 2) = (j' * 32 + l' / 2) mod 64 with (j, l/2) != (j', l'/2),
+ * which needs l/2 and l'/2 to differ by 32: never. */
+constexpr uint32_t kPosFast = 16;          /* positions per (document, term) the fast path holds: 32 bytes = 2 vector loads */
+
+struct LdsPos {
+    const uint16_t* lp; uint32_t lane;
+    __device__ __forceinline__ uint32_t at(uint32_t t, uint32_t j) const { return lp[(t * kPosFast + j) * 64u + lane]; }
+};
+__device__ __forceinline__ uint32_t cur_get(uint64_t c, uint32_t t) { return (uint32_t)(c >> (5u * t)) & 31u; }
+__device__ __forceinline__ uint64_t cur_set(uint64_t c, uint32_t t, uint32_t v) { return (c & ~(31ull << (5u * t))) | ((uint64_t)v << (5u * t)); }
+
+template <typename CntF>
+__device__ bool lds_phrase_exact(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T) {
+    /* driven from plan term 0 (the rarest term of the collection); the predicate does not depend on the driver */
+    const uint32_t n0 = cnt(0u), p0 = pidx[0];
+    uint64_t cur = 0;
+    for (uint32_t i = 0; i < n0; ++i) {
+        const uint32_t x = L.at(0u, i);
+        if (x < p0) continue;
+        const uint32_t base = x - p0;
+        bool ok = true;
+#pragma unroll
+        for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
+            if (t < T && ok) {
+                const uint32_t want = base + pidx[t], nt = cnt(t);
+                uint32_t c = cur_get(cur, t);
+                while (c < nt && L.at(t, c) < want) ++c;
+                cur = cur_set(cur, t, c);
+                ok = c < nt && L.at(t, c) == want;
+            }
+        }
+        if (ok) return true;
+    }
+    return false;
+}
+
+template <typename CntF>
+__device__ bool lds_phrase_window(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T, uint32_t window) {
+    /* inv[i] = plan term that is the i-th word of the phrase (wave-uniform) */
+    uint32_t inv[XGM_PHRASE_MAX_TERMS];
+#pragma unroll
+    for (uint32_t i = 0; i < XGM_PHRASE_MAX_TERMS; ++i) inv[i] = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t)
+        if (t < T) {
+#pragma unroll
+            for (uint32_t i = 0; i < XGM_PHRASE_MAX_TERMS; ++i) if (pidx[t] == i) inv[i] = t;
+        }
+    const uint32_t n0 = cnt(inv[0]);
+    if (n0 == 0) return false;
+    uint64_t cur = 0;                              /* cursor of phrase word i at bits 5i; all lists start at their first entry */
+    while (true) {
+        const uint32_t base = L.at(inv[0], cur_get(cur, 0u));
+        uint32_t pos = base, b = 0;
+        bool fits = true, out = false;
+#pragma unroll
+        for (uint32_t i = 1; i < XGM_PHRASE_MAX_TERMS; ++i) {
+            if (i < T && fits && !out) {
+                const uint32_t ni = cnt(inv[i]);
+                uint32_t c = cur_get(cur, i);
+                while (c < ni && L.at(inv[i], c) < pos + 1u) ++c;
+                cur = cur_set(cur, i, c);
+                if (c >= ni) { out = true; }
+                else {
+                    pos = L.at(inv[i], c);
+                    b = pos + (T - i);
+                    fits = b - base <= window;
+                }
+            }
+        }
+        if (out) return false;
+        if (fits) return true;
+        const uint32_t want = b - window;
+        uint32_t c0 = cur_get(cur, 0u);
+        while (c0 < n0 && L.at(inv[0], c0) < want) ++c0;
+        if (c0 >= n0) return false;
+        cur = cur_set(cur, 0u, c0);
+    }
+}
+
+template <typename CntF>
+__device__ bool lds_near_window(const LdsPos& L, CntF cnt, uint32_t T, uint32_t window) {
+    uint64_t cur = 0;
+    bool empty = false;
+#pragma unroll
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) if (t < T && cnt(t) == 0u) empty = true;
+    if (empty) return false;
+    while (true) {
+        uint32_t lo = 0, lo_v = L.at(0u, cur_get(cur, 0u)), hi_v = lo_v;
+#pragma unroll
+        for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
+            if (t < T) {
+                const uint32_t v = L.at(t, cur_get(cur, t));
+                if (v < lo_v) { lo_v = v; lo = t; }
+                if (v > hi_v) hi_v = v;
+            }
+        }
+        if (hi_v - lo_v < window) return true;
+        const uint32_t want = hi_v - window + 1u, nl = cnt(lo);
+        uint32_t c = cur_get(cur, lo);
+        while (c < nl && L.at(lo, c) < want) ++c;
+        if (c >= nl) return false;
+        cur = cur_set(cur, lo, c);
+    }
+}
+
+struct __attribute__((packed, aligned(2))) Pos8 { uint32_t a, b, c, d; };        /* 8 u16 positions, 2-byte aligned in HBM */
 
 /* ---------------------------------------------------------------- the match kernel ----------- */
 
@@ -418,11 +570,12 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                 if (phrase) {
                     PosList pl[XGM_PHRASE_MAX_TERMS];
                     for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
-                        pl[t].p = seg.positions + seg.term_pos[q.term_id[t]] + sm.ptab[(size_t)t * W + slot];
+                        const uint32_t w16 = seg.term_flags[q.term_id[t]] & XGM_TF_POS16;
+                        pl[t].p = seg.positions + seg.term_pos[q.term_id[t]] + (size_t)sm.ptab[(size_t)t * W + slot] * (w16 ? 2u : 4u);
                         pl[t].n = (uint32_t)tab[(size_t)t * W + slot] - 1u;
+                        pl[t].w16 = w16;
                     }
-                    pass = (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T)
-                                                    : phrase_window(pl, q.phrase_index, T, q.window);
+                    pass = posfilter_slow(pl, q, T);
                 }
                 if (pass) {
                     ++my_matches;
@@ -947,7 +1100,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
  * groups, and the per-stripe latency chain of one unit is covered by the others.  Wave-uniform state
  * (top-k fill, threshold, coarse mask) lives in registers.  Used when first+maxitems <= kAndwMaxK. */
 constexpr uint32_t kAndwCandPlain = 512;             /* candidates per chunk = 4 blocks of term 0 */
-constexpr uint32_t kAndwCandPhrase = 256;            /* with the 4-byte position offsets per candidate and term: 2 blocks */
+constexpr uint32_t kAndwCandPhrase = 128;            /* with the position offsets and the K6 staging area: 1 block (3 workgroups per CU at 3 terms) */
 #ifndef XGM_ANDW_WAVES
 #define XGM_ANDW_WAVES 4           /* min waves per SIMD the register allocator must allow */
 #endif                  /* top-k buffer cap 256 */
@@ -964,6 +1117,7 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
     off += (size_t)kAndwCand * 2;                              /* c_slot */
     off += (size_t)T * kAndwCand * tab_elem;                   /* c_w */
     off += phrase ? (size_t)T * kAndwCand * 4 : 0;             /* c_pos: position-list offset per candidate and term */
+    off += phrase ? (size_t)T * kPosFast * 64 * 2 : 0;         /* lpos: the round's positions, u16 [T][kPosFast][64 lanes] */
     off += sided ? (size_t)cap : 0;                            /* tk_m: weighted subqueries matched, per top-k entry */
     return (off + 15) & ~(size_t)15;
 }
@@ -1056,6 +1210,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)CAND * 2;
     TabT* c_w = reinterpret_cast<TabT*>(base + off); off += (size_t)tab_terms * CAND * sizeof(TabT);
     uint32_t* c_pos = reinterpret_cast<uint32_t*>(base + off);     /* PHRASE only */
+    uint16_t* lpos = reinterpret_cast<uint16_t*>(base + off + (PHRASE ? (size_t)tab_terms * CAND * 4 : 0));   /* PHRASE only: K6 staging */
     constexpr bool MAYBE = SIDED == 2;
     uint8_t* tk_m = reinterpret_cast<uint8_t*>(base + off);        /* MAYBE only (never with PHRASE) */
     /* SIDED: the in-place summation program (<= 8 terms) in scalar registers */
@@ -1083,6 +1238,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     /* block ranges of every term inside the unit's docid range → run table; lane t keeps term t's
      * payload base and dense-container index */
     uint64_t tbase_reg = 0, tpos_reg = 0;
+    uint32_t tflag_reg = 0;                                         /* lane t: term t's flags (PHRASE: position width) */
     uint32_t dense_reg = 0xFFFFFFFFu;
     bool have_reg = false;                                         /* lane t: term t exists in this shard */
     if (!empty) {
@@ -1096,7 +1252,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             if (lane == t) {
                 have_reg = true;
                 tbase_reg = seg.term_word[id];
-                if (PHRASE) tpos_reg = seg.term_pos[id];
+                if (PHRASE) { tpos_reg = seg.term_pos[id]; tflag_reg = seg.term_flags[id]; }
                 /* the positional filter needs every term's position offsets, which only the block
                  * decode yields: PHRASE batches take the block path for all terms */
                 if (!PHRASE && sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
@@ -1227,17 +1383,69 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 pass = true;
                 for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
                 for (uint32_t t = TR; t < T; ++t) pass = pass && (!((q.neg_mask >> t) & 1u) || c_w[(size_t)t * CAND + o] == 0);   /* AND_NOT */
-                if (PHRASE && phrase && pass) {
-                    /* K6: ExactPhrasePostList / PhrasePostList::test_doc over the terms' position lists */
+            }
+            if (PHRASE && phrase && __ballot(pass)) {
+                /* K6: ExactPhrasePostList / PhrasePostList / NearPostList::test_doc for the round's 64 documents.
+                 * Stage: every lane fetches up to kPosFast positions of each term of ITS document with two 16-byte
+                 * loads (independent of any control flow: all of them are in flight together, two terms at a time) and
+                 * the wave parks them in LDS; then each lane runs the predicate on LDS data.  Documents with more
+                 * positions of a term, or a term with 4-byte positions, take the serial path straight from HBM. */
+                auto cnt = [&](uint32_t t) { return (uint32_t)c_w[(size_t)t * CAND + (o < CAND ? o : 0u)] - 1u; };
+                bool slow = false;
+                if (TALLY) { if (pass) { for (uint32_t t = 0; t < T; ++t) cn_pos += cnt(t); } }
+                for (uint32_t t0 = 0; t0 < T; t0 += 2u) {
+                    Pos8 ra[2][2];
+                    uint32_t jmax = 0;
+#pragma unroll
+                    for (uint32_t u = 0; u < 2u; ++u) {
+                        const uint32_t t = t0 + u;
+                        ra[u][0] = Pos8{0, 0, 0, 0}; ra[u][1] = Pos8{0, 0, 0, 0};
+                        if (t < T) {
+                            const uint32_t w16 = __builtin_amdgcn_readlane(tflag_reg, t) & XGM_TF_POS16;
+                            const uint32_t nt = pass ? cnt(t) : 0u;
+                            const bool fast = w16 != 0u && nt <= kPosFast;
+                            slow = slow || (pass && !fast);
+                            if (pass && fast) {
+                                const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
+                                const unsigned char* src = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * 2u;
+                                if (nt > 0u) ra[u][0] = *reinterpret_cast<const Pos8*>(src);
+                                if (nt > 8u) ra[u][1] = *reinterpret_cast<const Pos8*>(src + 16);
+                            }
+                            const uint32_t tier = __ballot(fast && nt > 8u) ? 16u : (__ballot(fast && nt > 4u) ? 8u : 4u);
+                            jmax = tier > jmax ? tier : jmax;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 2u; ++u) {
+                        const uint32_t t = t0 + u;
+                        if (t < T) {
+                            const uint32_t r8[8] = {ra[u][0].a, ra[u][0].b, ra[u][0].c, ra[u][0].d, ra[u][1].a, ra[u][1].b, ra[u][1].c, ra[u][1].d};
+#pragma unroll
+                            for (uint32_t j = 0; j < kPosFast; ++j)
+                                if (j < jmax) lpos[(t * kPosFast + j) * 64u + lane] = (uint16_t)((j & 1u) ? (r8[j >> 1] >> 16) : (r8[j >> 1] & 0xFFFFu));
+                        }
+                    }
+                }
+                wave_lds_fence();
+                if (pass && !slow) {
+                    const LdsPos L{lpos, lane};
+                    pass = (q.flags & XGM_QF_NEAR) ? lds_near_window(L, cnt, T, q.window)
+                         : (q.flags & XGM_QF_EXACT) ? lds_phrase_exact(L, cnt, q.phrase_index, T)
+                                                    : lds_phrase_window(L, cnt, q.phrase_index, T, q.window);
+                } else if (pass) {
                     PosList pl[XGM_PHRASE_MAX_TERMS];
-                    if (TALLY) { for (uint32_t t = 0; t < T; ++t) cn_pos += (uint32_t)c_w[(size_t)t * CAND + o] - 1u; }
                     for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
                         const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
-                        pl[t].p = seg.positions + tp + c_pos[(size_t)t * CAND + o];
-                        pl[t].n = (uint32_t)c_w[(size_t)t * CAND + o] - 1u;
+                        const uint32_t w16 = __builtin_amdgcn_readlane(tflag_reg, t) & XGM_TF_POS16;
+                        pl[t].p = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * (w16 ? 2u : 4u);
+                        pl[t].n = cnt(t);
+                        pl[t].w16 = w16;
                     }
-                    pass = (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
+                    pass = posfilter_slow(pl, q, T);
                 }
+                wave_lds_fence();
+            }
+            if (o < n_c) {
                 if (pass) {
                     ++matches;
                     did = stripe_base + c_slot[o];

@@ -119,7 +119,7 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     if (!idx || !d || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
     memset(out, 0, sizeof *out);
     const uint32_t n = d->n_terms;
-    if (d->op < XGM_OP_AND || d->op > XGM_OP_FILTER) return XGM_UNSUPPORTED;
+    if (d->op < XGM_OP_AND || d->op > XGM_OP_NEAR) return XGM_UNSUPPORTED;
     if (n == 0 || n > XGM_MAX_TERMS) return XGM_UNSUPPORTED;
     /* AND_NOT / AND_MAYBE / FILTER: left = AND of the first nr terms, right = the others
      * (QueryAndNot / QueryAndMaybe / QueryFilter::postlist, api/queryinternal.cc:2208-2283) */
@@ -187,7 +187,8 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     /* positional filter */
     bool phrase_active = false;
     bool shard_empty = false;
-    if (d->op == XGM_OP_PHRASE && n > 1) {
+    const bool positional = d->op == XGM_OP_PHRASE || d->op == XGM_OP_NEAR;      /* QueryWindowed::postlist_windowed, queryinternal.cc:2300-2354 */
+    if (positional && n > 1) {
         if (full_db_has_positions) {
             if (!idx->hdr.has_positions) {
                 shard_empty = true;                    /* queryinternal.cc:2308-2318 */
@@ -198,7 +199,7 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
             }
         }
     }
-    out->window = d->op == XGM_OP_PHRASE ? (d->window ? d->window : n) : 0;
+    out->window = positional ? (d->window ? d->window : n) : 0;
     out->phrase_active = phrase_active ? 1u : 0u;
     if (phrase_active && out->window < n) return XGM_UNSUPPORTED;   /* Xapian rejects/normalises this upstream */
 
@@ -309,6 +310,6 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         /* mark: n_terms stays, every leaf absent → the kernel exits at once */
         for (uint32_t p = 0; p < n; ++p) out->terms[p].term_id = UINT32_MAX;
     }
-    if (phrase_active && n > 3) return XGM_UNSUPPORTED;   /* XGM_PHRASE_MAX_TERMS: LDS position tables */
+    if (phrase_active && n > 8) return XGM_UNSUPPORTED;   /* XGM_PHRASE_MAX_TERMS: per-lane cursors of the positional filter */
     return XGM_OK;
 }

@@ -6,8 +6,11 @@
  *   - a posting list is a sequence of BLOCKS of <= 128 postings that never straddle a stripe;
  *   - a block stores its first docid in a header array and the rest as frame-of-reference bit-packed
  *     (gap-1) values plus bit-packed wdf values in a contiguous little-endian u32 payload;
- *   - positions (when present) are a flat u32 array; a posting's positions start at
- *     term_pos[t] + blk_pos[b] + Σ wdf of the earlier postings in its block.
+ *   - positions (when present) are one array per term, 2 bytes wide when every position of the term fits
+ *     (XGM_TF_POS16 — any document shorter than 65 536 tokens) and 4 bytes otherwise; the array of term t starts
+ *     at BYTE term_pos[t] of the section, and a posting's positions start at entry
+ *     blk_pos[b] + Σ wdf of the earlier postings in its block.  The section ends with XGM_POS_PAD spare bytes
+ *     so that the positional filter may fetch a whole 32-byte window per (document, term).
  *
  * This replaces, for the query path, glass's chunked-varint posting lists and doclen list
  * (reference src/xapian/backends/glass/glass_postlist.cc:677-695 format comment) and its
@@ -19,7 +22,7 @@
 #include <stdint.h>
 
 #define XGM_SEG_MAGIC "XGMSEG1"
-#define XGM_SEG_VERSION 1u
+#define XGM_SEG_VERSION 2u             /* 2: positions stored 2 or 4 bytes wide per term, term_pos in bytes */
 #define XGM_BLOCK 128u                 /* postings per block (two per lane of a wave64)          */
 #define XGM_DEFAULT_STRIPE_BITS 13u    /* 8192 docids per stripe                                  */
 #define XGM_MIN_STRIPE_BITS 8u
@@ -34,6 +37,8 @@
 
 /* term_flags */
 #define XGM_TF_POS_OK 1u               /* every posting has exactly wdf positions → phrase capable */
+#define XGM_TF_POS16 2u                /* the term's positions are stored as u16 (else u32)         */
+#define XGM_POS_PAD 32u                /* spare bytes after the positions                           */
 
 enum xgm_section {
     XGM_S_DOCLEN = 0,   /* u32[lastdocid+1]                                    */
@@ -43,13 +48,13 @@ enum xgm_section {
     XGM_S_TERM_FLAGS,   /* u32[n_terms]                                         */
     XGM_S_TERM_BLK,     /* u64[n_terms+1] first block of each term              */
     XGM_S_TERM_WORD,    /* u64[n_terms+1] first payload word of each term       */
-    XGM_S_TERM_POS,     /* u64[n_terms+1] first position of each term           */
+    XGM_S_TERM_POS,     /* u64[n_terms+1] BYTE offset of each term's position array */
     XGM_S_BLK_FIRST,    /* u32[n_blocks]  first docid of the block              */
     XGM_S_BLK_META,     /* u32[n_blocks]                                        */
     XGM_S_BLK_WORD,     /* u32[n_blocks]  payload word offset, relative to term */
-    XGM_S_BLK_POS,      /* u32[n_blocks]  position offset, relative to term     */
+    XGM_S_BLK_POS,      /* u32[n_blocks]  position ENTRY offset, relative to term */
     XGM_S_WORDS,        /* u32[n_words + XGM_WORD_PAD]                          */
-    XGM_S_POSITIONS,    /* u32[n_positions]                                     */
+    XGM_S_POSITIONS,    /* per-term u16 / u32 arrays + XGM_POS_PAD bytes         */
     XGM_S_STR_OFF,      /* u64[n_terms+1] (host only)                           */
     XGM_S_STR_BYTES,    /* term bytes, sorted (host only)                       */
     XGM_S_COUNT
@@ -77,7 +82,8 @@ typedef struct {
     const uint32_t* blk_word;
     const uint32_t* blk_pos;
     const uint32_t* words;
-    const uint32_t* positions;
+    const unsigned char* positions;
+    const uint32_t* term_flags;
     uint32_t stripe_bits;
     uint32_t lastdocid;
     /* Probe containers (built in HBM when the index is opened, never stored in the segment file): for

@@ -56,7 +56,7 @@ int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes) {
         {XGM_S_DOCLEN, ((uint64_t)h->lastdocid + 1) * 4}, {XGM_S_TERM_DF, T * 4}, {XGM_S_TERM_CF, T * 4}, {XGM_S_TERM_WDFUB, T * 4},
         {XGM_S_TERM_FLAGS, T * 4}, {XGM_S_TERM_BLK, (T + 1) * 8}, {XGM_S_TERM_WORD, (T + 1) * 8}, {XGM_S_TERM_POS, (T + 1) * 8},
         {XGM_S_BLK_FIRST, B * 4}, {XGM_S_BLK_META, B * 4}, {XGM_S_BLK_WORD, B * 4}, {XGM_S_BLK_POS, B * 4},
-        {XGM_S_WORDS, (h->n_words + XGM_WORD_PAD) * 4}, {XGM_S_POSITIONS, h->n_positions * 4}, {XGM_S_STR_OFF, (T + 1) * 8}};
+        {XGM_S_WORDS, (h->n_words + XGM_WORD_PAD) * 4}, {XGM_S_POSITIONS, h->n_positions * 2 + (h->n_positions ? XGM_POS_PAD : 0)}, {XGM_S_STR_OFF, (T + 1) * 8}};
     for (const auto& w : want)
         if (h->sec_bytes[w.sec] < w.need) return xgm_set_error(XGM_E_INVALID, "segment section %d is smaller than its header counts imply", w.sec);
     if (h->doccount > h->lastdocid) return xgm_set_error(XGM_E_INVALID, "segment doccount exceeds lastdocid");
@@ -77,15 +77,18 @@ int xgm_validate_blob(const XgmSegmentBlob& blob) {
     for (uint32_t t = 0; t < T; ++t)
         if (so[t + 1] < so[t] || tb[t + 1] < tb[t] || tw[t + 1] < tw[t] || tp[t + 1] < tp[t])
             return xgm_set_error(XGM_E_INVALID, "segment term table %u is not monotone", t);
-    if (so[T] > h->sec_bytes[XGM_S_STR_BYTES] || tb[T] != B || tw[T] != h->n_words || tp[T] > h->n_positions)
+    if (so[T] > h->sec_bytes[XGM_S_STR_BYTES] || tb[T] != B || tw[T] != h->n_words || (tp[T] && tp[T] + XGM_POS_PAD > h->sec_bytes[XGM_S_POSITIONS]))
         return xgm_set_error(XGM_E_INVALID, "segment term tables do not end at the section sizes");
     const uint32_t* bf = blob.section<uint32_t>(XGM_S_BLK_FIRST);
     const uint32_t* bm = blob.section<uint32_t>(XGM_S_BLK_META);
     const uint32_t* bw = blob.section<uint32_t>(XGM_S_BLK_WORD);
     const uint32_t* bp = blob.section<uint32_t>(XGM_S_BLK_POS);
     const uint32_t* df = blob.section<uint32_t>(XGM_S_TERM_DF);
+    const uint32_t* tf = blob.section<uint32_t>(XGM_S_TERM_FLAGS);
     for (uint32_t t = 0; t < T; ++t) {
-        const uint64_t words_t = tw[t + 1] - tw[t], pos_t = tp[t + 1] - tp[t];
+        const uint64_t pwid = (tf[t] & XGM_TF_POS16) ? 2u : 4u;
+        if ((tf[t] & XGM_TF_POS_OK) && (tp[t] % pwid)) return xgm_set_error(XGM_E_INVALID, "segment term %u: misaligned positions", t);
+        const uint64_t words_t = tw[t + 1] - tw[t], pos_t = (tp[t + 1] - tp[t]) / pwid;
         uint64_t n = 0;
         uint32_t prev = 0;
         for (uint64_t b = tb[t]; b < tb[t + 1]; ++b) {
@@ -114,7 +117,9 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
 
     std::vector<uint32_t> term_cf(T), term_wdfub(T), term_flags(T);
     std::vector<uint64_t> term_blk(T + 1), term_word(T + 1), term_pos(T + 1);
-    std::vector<uint32_t> blk_first, blk_meta, blk_word, blk_pos, words, positions;
+    std::vector<uint32_t> blk_first, blk_meta, blk_word, blk_pos, words;
+    std::vector<uint8_t> positions;              /* per term: u16 or u32 entries (XGM_TF_POS16) */
+    uint64_t n_pos_entries = 0;
     std::vector<uint64_t> str_off(T + 1);
     std::vector<char> str_bytes;
 
@@ -147,7 +152,6 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
         if (p0 + df > raw->n_postings) return xgm_set_error(XGM_E_INVALID, "df overruns postings");
         term_blk[t] = blk_first.size();
         term_word[t] = words.size();
-        term_pos[t] = positions.size();
         uint64_t cf = 0;
         bool pos_ok = has_pos;
         for (uint32_t i = 0; i < df; ++i) {
@@ -163,7 +167,14 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
         uint32_t first_wdf = raw->wdf[p0];
         uint32_t ub = (cf == 0 || df == 1) ? (uint32_t)cf : std::max((uint32_t)cf - first_wdf, first_wdf);
         term_wdfub[t] = std::min(ub, wdf_ub_db);
-        term_flags[t] = pos_ok ? XGM_TF_POS_OK : 0u;
+        bool pos16 = pos_ok;
+        if (pos_ok)
+            for (uint64_t q = raw->pos_off[p0]; pos16 && q < raw->pos_off[p0 + df]; ++q) pos16 = raw->pos[q] < 65536u;
+        term_flags[t] = pos_ok ? (XGM_TF_POS_OK | (pos16 ? XGM_TF_POS16 : 0u)) : 0u;
+        const size_t pw = pos16 ? 2u : 4u;
+        positions.resize((positions.size() + pw - 1) / pw * pw, 0);          /* the term's array is aligned to its entry width */
+        term_pos[t] = positions.size();
+        uint64_t term_entries = 0;
 
         /* cut into blocks: same stripe, <= XGM_BLOCK postings */
         uint32_t i = 0;
@@ -178,7 +189,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
             }
             uint32_t bwg = xgm_bits_needed(maxgap), bww = xgm_bits_needed(maxwdf);
             uint64_t woff = words.size() - term_word[t];
-            uint64_t poff = positions.size() - term_pos[t];
+            uint64_t poff = term_entries;
             if (woff > 0xFFFFFFFFull || poff > 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "term %u too large for 32-bit block offsets", t);
             blk_first.push_back(raw->did[p0 + i]);
             blk_meta.push_back(XGM_META(n, bwg, bww));
@@ -190,7 +201,12 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
             for (uint32_t j = 0; j < n; ++j) bw.put(j, bww, raw->wdf[p0 + i + j]);
             if (pos_ok) {
                 for (uint32_t j = 0; j < n; ++j)
-                    for (uint64_t q = raw->pos_off[p0 + i + j]; q < raw->pos_off[p0 + i + j + 1]; ++q) positions.push_back(raw->pos[q]);
+                    for (uint64_t q = raw->pos_off[p0 + i + j]; q < raw->pos_off[p0 + i + j + 1]; ++q) {
+                        const uint32_t v = raw->pos[q];
+                        positions.push_back((uint8_t)v); positions.push_back((uint8_t)(v >> 8));
+                        if (!pos16) { positions.push_back((uint8_t)(v >> 16)); positions.push_back((uint8_t)(v >> 24)); }
+                        ++term_entries; ++n_pos_entries;
+                    }
             }
             i += n;
         }
@@ -200,6 +216,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
     term_blk[T] = blk_first.size();
     term_word[T] = words.size();
     term_pos[T] = positions.size();
+    if (has_pos) positions.resize(positions.size() + XGM_POS_PAD, 0);
     str_off[T] = str_bytes.size();
     const uint64_t n_words = words.size();
     words.resize(n_words + XGM_WORD_PAD, 0u);
@@ -219,7 +236,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
     h.total_length = raw->total_length;
     h.revision = raw->revision;
     h.n_postings = raw->n_postings;
-    h.n_positions = positions.size();
+    h.n_positions = n_pos_entries;
     h.n_blocks = blk_first.size();
     h.n_words = n_words;
 
@@ -238,7 +255,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
         {XGM_S_BLK_WORD, blk_word.data(), blk_word.size() * 4},
         {XGM_S_BLK_POS, blk_pos.data(), blk_pos.size() * 4},
         {XGM_S_WORDS, words.data(), words.size() * 4},
-        {XGM_S_POSITIONS, positions.data(), positions.size() * 4},
+        {XGM_S_POSITIONS, positions.data(), positions.size()},
         {XGM_S_STR_OFF, str_off.data(), (uint64_t)(T + 1) * 8},
         {XGM_S_STR_BYTES, str_bytes.data(), str_bytes.size()},
     };

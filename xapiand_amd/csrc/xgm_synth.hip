@@ -72,10 +72,10 @@ __global__ void k_posting_flags(const uint64_t* __restrict__ keys, uint64_t n, u
 
 /* per posting: (sid, doc) and the index of its first token */
 __global__ void k_postings(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ flag, const uint32_t* __restrict__ pidx, uint64_t n,
-                           uint32_t* __restrict__ p_sid, uint32_t* __restrict__ p_doc, uint64_t* __restrict__ p_tok, uint32_t* __restrict__ positions) {
+                           uint32_t* __restrict__ p_sid, uint32_t* __restrict__ p_doc, uint64_t* __restrict__ p_tok, uint16_t* __restrict__ positions) {
     for (uint64_t i = blockIdx.x * (uint64_t)TB + threadIdx.x; i < n; i += (uint64_t)gridDim.x * TB) {
         uint64_t k = keys[i];
-        if (positions) positions[i] = (uint32_t)(k & 0xFFu);
+        if (positions) positions[i] = (uint16_t)(k & 0xFFu);       /* synthetic documents are < 256 tokens: every term is XGM_TF_POS16 */
         if (flag[i]) {
             uint32_t p = pidx[i];
             p_sid[p] = key_sid(k);
@@ -212,16 +212,16 @@ __global__ void k_term_tables(const uint64_t* __restrict__ term_pstart, const ui
         t_df[t] = df;
         t_cf[t] = cf32;
         t_wdfub[t] = min(ub, wdf_ub_db);
-        t_flags[t] = with_pos ? XGM_TF_POS_OK : 0u;
+        t_flags[t] = with_pos ? (XGM_TF_POS_OK | XGM_TF_POS16) : 0u;
         uint64_t blk = pblk[a];
         t_blk[t] = blk;
         t_word[t] = blk_goff[blk];
-        t_pos[t] = with_pos ? ta : 0;
+        t_pos[t] = with_pos ? ta * 2u : 0;                    /* byte offset of the term's u16 position array */
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         t_blk[T] = n_blk;
         t_word[T] = n_words;
-        t_pos[T] = with_pos ? n_tok : 0;
+        t_pos[T] = with_pos ? n_tok * 2u : 0;
     }
 }
 
@@ -234,7 +234,7 @@ __global__ void k_block_relative(const uint64_t* __restrict__ blk_p, uint64_t n_
         uint64_t p0 = blk_p[b];
         uint32_t t = newid[p_sid[p0]];
         uint64_t wo = blk_goff[b] - t_word[t];
-        uint64_t po = with_pos ? p_tok[p0] - t_pos[t] : 0;
+        uint64_t po = with_pos ? p_tok[p0] - t_pos[t] / 2u : 0;    /* entries */
         if (wo > 0xFFFFFFFFull || po > 0xFFFFFFFFull) *overflow = 1;
         blk_word[b] = (uint32_t)wo;
         blk_pos[b] = (uint32_t)po;
@@ -364,9 +364,12 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
     SY_TRY(d_psid.alloc((size_t)n_post * 4));
     SY_TRY(d_pdoc.alloc((size_t)n_post * 4));
     SY_TRY(d_ptok.alloc(((size_t)n_post + 1) * 8));
-    if (with_pos) SY_TRY(hipMalloc(&S[XGM_S_POSITIONS], (size_t)n_tok * 4));
+    if (with_pos) {
+        SY_TRY(hipMalloc(&S[XGM_S_POSITIONS], (size_t)n_tok * 2 + XGM_POS_PAD));
+        SY_TRY(hipMemset((char*)S[XGM_S_POSITIONS] + (size_t)n_tok * 2, 0, XGM_POS_PAD));
+    }
     hipLaunchKernelGGL(k_postings, dim3(grid_for(n_tok)), dim3(TB), 0, 0, d_keys2.as<uint64_t>(), d_flag.as<uint32_t>(), d_pidx.as<uint32_t>(), n_tok,
-                       d_psid.as<uint32_t>(), d_pdoc.as<uint32_t>(), d_ptok.as<uint64_t>(), with_pos ? (uint32_t*)S[XGM_S_POSITIONS] : nullptr);
+                       d_psid.as<uint32_t>(), d_pdoc.as<uint32_t>(), d_ptok.as<uint64_t>(), with_pos ? (uint16_t*)S[XGM_S_POSITIONS] : nullptr);
     SY_TRY(hipGetLastError());
     SY_TRY(hipDeviceSynchronize());
     d_keys2.reset(); d_flag.reset(); d_pidx.reset();
@@ -494,13 +497,13 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
         sz[XGM_S_TERM_BLK] = sz[XGM_S_TERM_WORD] = sz[XGM_S_TERM_POS] = ((uint64_t)T + 1) * 8;
         sz[XGM_S_BLK_FIRST] = sz[XGM_S_BLK_META] = sz[XGM_S_BLK_WORD] = sz[XGM_S_BLK_POS] = n_blk * 4;
         sz[XGM_S_WORDS] = (n_words + XGM_WORD_PAD) * 4;
-        sz[XGM_S_POSITIONS] = with_pos ? n_tok * 4 : 0;
+        sz[XGM_S_POSITIONS] = with_pos ? n_tok * 2 + XGM_POS_PAD : 0;
         sz[XGM_S_STR_OFF] = ((uint64_t)T + 1) * 8;
         sz[XGM_S_STR_BYTES] = idx->str_bytes.size();
         idx->device_bytes = 0;
         for (int s = 0; s < XGM_S_COUNT; ++s) if (s != XGM_S_STR_OFF && s != XGM_S_STR_BYTES) idx->device_bytes += sz[s];
     }
-    if (!with_pos) SY_TRY(hipMalloc(&S[XGM_S_POSITIONS], 8));
+    if (!with_pos) SY_TRY(hipMalloc(&S[XGM_S_POSITIONS], 64));
     SY_TRY(hipDeviceSynchronize());
     {
         xgm_seg_dev& v = idx->view;
@@ -513,7 +516,8 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
         v.blk_word = (const uint32_t*)S[XGM_S_BLK_WORD];
         v.blk_pos = (const uint32_t*)S[XGM_S_BLK_POS];
         v.words = (const uint32_t*)S[XGM_S_WORDS];
-        v.positions = (const uint32_t*)S[XGM_S_POSITIONS];
+        v.positions = (const unsigned char*)S[XGM_S_POSITIONS];
+        v.term_flags = (const uint32_t*)S[XGM_S_TERM_FLAGS];
         v.stripe_bits = sb;
         v.lastdocid = n_local;
     }

@@ -26,10 +26,10 @@ class Query:
     """Subset of Xapian::Query (reference src/xapian/query.h:48-): a term; AND / OR / PHRASE of terms; or
     AND_NOT / AND_MAYBE / FILTER of (a term or an AND of terms, a term or an OR of terms — an AND for
     FILTER), the trees Xapiand's DSL builds for _and_not / _and_maybe / _filter."""
-    OP_AND, OP_OR, OP_PHRASE = "AND", "OR", "PHRASE"
+    OP_AND, OP_OR, OP_PHRASE, OP_NEAR = "AND", "OR", "PHRASE", "NEAR"
     OP_AND_NOT, OP_AND_MAYBE, OP_FILTER = "AND_NOT", "AND_MAYBE", "FILTER"
     LEAF_TERM = "TERM"
-    _OPS = {OP_AND: _lib.XGM_OP_AND, OP_OR: _lib.XGM_OP_OR, OP_PHRASE: _lib.XGM_OP_PHRASE,
+    _OPS = {OP_AND: _lib.XGM_OP_AND, OP_OR: _lib.XGM_OP_OR, OP_PHRASE: _lib.XGM_OP_PHRASE, OP_NEAR: _lib.XGM_OP_NEAR,
             OP_AND_NOT: _lib.XGM_OP_AND_NOT, OP_AND_MAYBE: _lib.XGM_OP_AND_MAYBE, OP_FILTER: _lib.XGM_OP_FILTER}
     _SIDED = (OP_AND_NOT, OP_AND_MAYBE, OP_FILTER)
 
@@ -96,7 +96,8 @@ class Query:
         if self.op in Query._SIDED:
             inner = "AND" if self.op == Query.OP_FILTER else "OR"
             return "Query(((%s) %s (%s)))" % (" AND ".join(names[:self.n_required]), self.op, (" %s " % inner).join(names[self.n_required:]))
-        sep = {"AND": " AND ", "OR": " OR ", "PHRASE": " PHRASE %d " % (self.window or len(self.terms))}[self.op]
+        sep = {"AND": " AND ", "OR": " OR ", "PHRASE": " PHRASE %d " % (self.window or len(self.terms)),
+               "NEAR": " NEAR %d " % (self.window or len(self.terms))}[self.op]
         return "Query((" + sep.join(names) + "))"
 
 
