@@ -67,7 +67,7 @@ def parse_args():
                     "default: 1/5 of the configuration's documents — indexing 10 M documents through the reference's WritableDatabase takes "
                     "~3.5 min even on 128 cores; `--ref-docs 10000000` reproduces profiles/r02_reference_full.json)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
-    ap.add_argument("--threads", type=int, default=0, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight")
+    ap.add_argument("--threads", type=int, default=64, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight (0: skip)")
     return ap.parse_args()
 
 
@@ -286,36 +286,30 @@ def main():
 
 
 def server_leg(db, descs, gstats, k, n_threads, n_timed):
-    """T Python threads, each issuing xgm_get_mset_batch(nq = 1) back to back (ctypes releases the GIL for the call):
-    the shape of Xapiand's HTTP worker pool (reference src/manager.cc:161), without caller-side batching."""
-    import threading
+    """Xapiand's shape of load (reference src/manager.cc:161): T host threads, each answering ONE query at a time through
+    xgm_get_mset_batch(nq = 1) (plan + search), without any caller-side batching — native threads
+    (xgm_debug_concurrent_searches), first with every call launching on its own, then with the index's opt-in
+    micro-batching queue (xgm_index_set_batching) that lets concurrent single-query calls share launches."""
     from xapiand_amd import _lib
     L = _lib.lib()
     db.set_stream(0)
-    per = max(8, min(200, n_timed // n_threads))
-    lats = [[] for _ in range(n_threads)]
-    start = threading.Barrier(n_threads + 1)
-
-    def worker(t):
-        hits = (_lib.Hit * k)()
-        hdr = _lib.ResultHdr()
-        qs = [((_lib.QueryDesc * 1)(descs[100 + (t * per + i) % n_timed]), (_lib.GlobalStats * 1)(gstats[100 + (t * per + i) % n_timed])) for i in range(per)]
-        start.wait()
-        for d1, g1 in qs:
-            a = time.perf_counter()
-            L.xgm_get_mset_batch(db._h, d1, g1, 1, k, hits, C.byref(hdr))
-            lats[t].append(time.perf_counter() - a)
-    ths = [threading.Thread(target=worker, args=(t,)) for t in range(n_threads)]
-    for th in ths:
-        th.start()
-    start.wait()
-    t0 = time.perf_counter()
-    for th in ths:
-        th.join()
-    wall = time.perf_counter() - t0
-    allv = sorted(x for l in lats for x in l)
-    return {"threads": n_threads, "queries": len(allv), "value": len(allv) / wall, "unit": "queries/s",
-            "p50_us": allv[len(allv) // 2] * 1e6, "p99_us": allv[int(len(allv) * 0.99)] * 1e6}
+    per = max(8, min(200, n_timed // max(1, n_threads) * 4))
+    d0 = C.cast(C.byref(descs, 100 * C.sizeof(_lib.QueryDesc)), C.POINTER(_lib.QueryDesc))
+    g0 = C.cast(C.byref(gstats, 100 * C.sizeof(_lib.GlobalStats)), C.POINTER(_lib.GlobalStats))
+    out = {"threads": n_threads, "queries_per_thread": per}
+    for name, max_batch in (("unbatched", 0), ("batched", 256)):
+        _lib.check(L.xgm_index_set_batching(db._h, max_batch))
+        lat = (C.c_double * (n_threads * per))()
+        L.xgm_debug_concurrent_searches(db._h, d0, g0, n_timed, n_threads, 8, k, lat)            # warm-up
+        wall = L.xgm_debug_concurrent_searches(db._h, d0, g0, n_timed, n_threads, per, k, lat)
+        v = sorted(lat)
+        out[name] = {"value": len(v) / wall if wall > 0 else None, "unit": "queries/s", "p50_us": v[len(v) // 2], "p99_us": v[int(len(v) * 0.99)]}
+        if max_batch:
+            info = (C.c_uint64 * 3)()
+            L.xgm_debug_batching_info(db._h, info)
+            out[name]["mean_batch"] = info[1] / max(1, info[0])
+    _lib.check(L.xgm_index_set_batching(db._h, 0))
+    return out
 
 
 def time_port(ora, sample, op, k, seconds, n_required, checker=None):

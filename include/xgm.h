@@ -175,6 +175,13 @@ int xgm_index_get_info(const xgm_index*, xgm_index_info* out);
  * its copies/collectives without extra synchronisation. */
 int xgm_index_set_stream(xgm_index*, void* hip_stream);
 
+/* Server mode (opt-in): Xapiand's HTTP worker threads call get_mset one query at a time (reference src/manager.cc:161,
+ * src/database/handler.cc:1338).  With max_batch > 0, single-query calls (xgm_search, xgm_search_batch / xgm_get_mset_batch
+ * with nq == 1) from any number of threads are queued and a dispatcher thread owned by the index launches whatever has
+ * accumulated — up to max_batch queries, of any mix of shapes — as one batch, then returns each caller its own hits and
+ * return code.  No timer: while one batch runs the next one fills.  max_batch == 0 switches it off (the default). */
+int xgm_index_set_batching(xgm_index*, uint32_t max_batch);
+
 /* Dictionary lookup.  Replaces GlassPostListTable::get_freqs
  * (reference src/xapian/backends/glass/glass_postlist.cc:151-192) and get_wdf_upper_bound
  * (glass_database.cc:823-830).  Returns XGM_OK and termfreq 0 when the term is absent. */
@@ -363,6 +370,13 @@ double xgm_debug_plan_us(const xgm_index*, const xgm_query_desc* descs, const xg
 /* Diagnostics (host only, works on an XGM_DEVICE_NONE index): the launches a batch of planned queries is cut into,
  * one per kernel class present, as "<kernel>[:variant]*<queries>;..." in launch order; returns their number. */
 int xgm_debug_batch_launches(const xgm_index*, const xgm_query* qs, uint32_t nq, char* out, uint32_t cap);
+
+/* Diagnostics: out3 = {batches the dispatcher launched, requests it served, max_batch}. */
+int xgm_debug_batching_info(const xgm_index*, uint64_t* out3);
+/* Diagnostics / bench.py's server leg: n_threads host threads, each answering per_thread queries one at a time through
+ * xgm_get_mset_batch(nq = 1); lat_us gets n_threads * per_thread latencies; returns the wall time in seconds (< 0: error). */
+double xgm_debug_concurrent_searches(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t n,
+                                     uint32_t n_threads, uint32_t per_thread, uint32_t k, double* lat_us);
 
 const char* xgm_last_error(void);
 const char* xgm_version(void);

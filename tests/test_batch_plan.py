@@ -109,3 +109,9 @@ def test_heterogeneous_batch_is_cut_by_kernel_class(host_db):
                                         "xgm_orw_kernel*5", "xgm_match_kernel*2"]
     big = sided_queries("AND_MAYBE", 2, 3, 6, 19)                   # 9 terms: beyond the register program → the general kernel
     assert launches(host_db, AND + big) == ["xgm_andw_kernel*6", "xgm_match_kernel*2"]
+    # deep pages (first + maxitems > 192) leave the wave kernels without taking the shallow ones along
+    plans = [plan(host_db, q, 0, 10) for q in AND[:4]] + [plan(host_db, q, 0, 500) for q in AND[4:]]
+    arr = (_lib.Query * len(plans))(*plans)
+    out = C.create_string_buffer(512)
+    assert _lib.lib().xgm_debug_batch_launches(host_db._h, arr, len(plans), out, 512) == 2
+    assert out.value.decode().split(";") == ["xgm_andw_kernel*4", "xgm_and_kernel*2"]

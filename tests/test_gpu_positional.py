@@ -39,7 +39,7 @@ def test_phrase_near_window_and_long_phrases(built, tmp_path):
         if q["op"] == "NEAR" and rng.random() < 0.5:
             rng.shuffle(q["terms"])
     for q in qs:
-        q["maxitems"] = 200 if rng.random() < 0.3 else 10
+        q["maxitems"] = 150 if rng.random() < 0.3 else 10
     assert check(db, c, qs) > 500
     # and in one heterogeneous batch with plain conjunctions (kernel classes are cut apart, results are not)
     mixed = qs[:20] + [dict(q, window=0) for q in H.gen_term_queries("AND", 10, 3, 1, 300, seed=6)]

@@ -4,7 +4,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
 #include <cstdarg>
 #include <cstdlib>
 #include <cmath>
@@ -168,6 +172,7 @@ static void scratch_destroy(XgmScratch* s) {
 /* ------------------------------------------------------------------ index lifetime ----------- */
 
 void xgm_shard_ctx_destroy(XgmShardCtx* c);
+void xgm_batcher_destroy(xgm_index* idx);
 
 static void fill_view(xgm_index* idx) {
     xgm_seg_dev& v = idx->view;
@@ -184,7 +189,7 @@ static void fill_view(xgm_index* idx) {
     v.term_flags = (const uint32_t*)idx->d_sections[XGM_S_TERM_FLAGS];
     v.stripe_bits = idx->hdr.stripe_bits;
     v.lastdocid = idx->hdr.lastdocid;
-    v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0;
+    v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.pad_ = 0;
     v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
@@ -247,6 +252,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->device == XGM_DEVICE_NONE) { delete idx; return; }
     hipSetDevice(idx->device);
     hipDeviceSynchronize();
+    xgm_batcher_destroy(idx);
     if (idx->shard_ctx) { xgm_shard_ctx_destroy(idx->shard_ctx); idx->shard_ctx = nullptr; hipSetDevice(idx->device); }
     for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
     for (auto& pr : idx->prof_events) { hipEventDestroy((hipEvent_t)pr.first); hipEventDestroy((hipEvent_t)pr.second); }
@@ -584,7 +590,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             uint32_t id = qs[i].terms[t].term_id;
             if (id == UINT32_MAX) { min_df = 0; all_dense = false; continue; }
             const double df = idx->term_df[id];
-            const bool dense = bp->andw && !bp->wide && !bp->phrase && idx->dense_min_df && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
+            const bool dense = bp->andw && !bp->wide && (!bp->phrase || idx->view.dense_pos) && idx->dense_min_df && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
             if (!dense) { sparse_blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes); all_dense = false; }
             min_df = std::min(min_df, df);
             dens *= df / n_docs;
@@ -733,10 +739,13 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
 /* Kernel class of a planned query: which match kernel serves it best.  A server's natural batch is heterogeneous
  * (Xapiand's HTTP threads issue whatever the clients send): run_batch cuts it into one launch per class present instead
  * of sending the whole batch to the slowest common denominator. */
-enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_COUNT };
+enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_BIGK, XGM_CLS_COUNT };
 
 static int classify_query(const xgm_query& q) {
     const uint32_t T = q.n_terms;
+    /* the wave kernels keep first + maxitems <= 192 candidates per unit: deeper pages go together to the workgroup kernels
+     * instead of dragging a whole class there */
+    if (q.op != XGM_OP_OR && q.first + q.maxitems > 192u) return XGM_CLS_BIGK;
     const uint32_t prefix = q.req_mask && !(q.req_mask & (q.req_mask + 1u));            /* required terms = plan positions [0, n_req) */
     switch (q.op) {
     case XGM_OP_OR: return XGM_CLS_OR;
@@ -784,10 +793,20 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
 
 static hipStream_t pick_stream(xgm_index* idx, XgmScratch* s) { return idx->stream ? (hipStream_t)idx->stream : s->stream; }
 
+static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr);
+
+static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
+
 extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits,
                                 xgm_result_hdr* hdrs) {
     if (!idx || !qs || !hits || !hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (nq == 0) return XGM_OK;
+    /* server mode: single-query calls of many host threads ride in shared launches (xgm_index_set_batching) */
+    if (nq == 1 && idx->batcher) return batcher_submit(idx, qs, k_stride, hits, hdrs);
+    return search_batch_now(idx, qs, nq, k_stride, hits, hdrs);
+}
+
+static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
@@ -813,6 +832,149 @@ extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq
     } while (0);
     scratch_release(idx, s);
     return rc;
+}
+
+/* ---- opt-in micro-batching (server mode) -----------------------------------------------------------------------------
+ * Xapiand's HTTP worker threads issue ONE get_mset each (reference src/manager.cc:161, src/database/handler.cc:1338);
+ * a GPU wants hundreds of queries per launch.  With xgm_index_set_batching(idx, max_batch) single-query calls are
+ * queued, and a dispatcher thread owned by the index launches whatever has accumulated — up to max_batch — as one
+ * heterogeneous batch, then hands every caller its rows.  "Natural" batching: nothing waits on a timer; while one batch
+ * runs the next one fills, so batches grow with the offered load and an idle server adds no latency. */
+struct XgmBatchReq {
+    const xgm_query* q; uint32_t k_stride; xgm_hit* hits; xgm_result_hdr* hdr;
+    int rc = 0; bool done = false; char err[192];
+};
+
+struct XgmBatcher {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<XgmBatchReq*> queue;
+    std::thread th;
+    bool stop = false;
+    uint32_t max_batch = 256;
+    uint64_t batches = 0, requests = 0;
+};
+
+static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
+    std::vector<XgmBatchReq*> take;
+    std::vector<xgm_query> qs;
+    std::vector<xgm_hit> hits;
+    std::vector<xgm_result_hdr> hdrs;
+    while (true) {
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv_work.wait(lk, [&] { return b->stop || !b->queue.empty(); });
+            if (b->stop && b->queue.empty()) return;
+            take.clear();
+            while (!b->queue.empty() && take.size() < b->max_batch) { take.push_back(b->queue.front()); b->queue.pop_front(); }
+        }
+        const uint32_t n = (uint32_t)take.size();
+        uint32_t ks = 1;
+        qs.resize(n);
+        for (uint32_t i = 0; i < n; ++i) { qs[i] = *take[i]->q; ks = std::max(ks, take[i]->k_stride); }
+        hits.resize((size_t)n * ks);
+        hdrs.resize(n);
+        int rc = search_batch_now(idx, qs.data(), n, ks, hits.data(), hdrs.data());
+        if (rc != XGM_OK && n > 1) {
+            /* one query of the batch was declined or failed: answer each on its own so that only that caller sees it */
+            for (uint32_t i = 0; i < n; ++i) {
+                take[i]->rc = search_batch_now(idx, take[i]->q, 1, take[i]->k_stride, take[i]->hits, take[i]->hdr);
+                if (take[i]->rc < 0) snprintf(take[i]->err, sizeof take[i]->err, "%s", xgm_last_error());
+            }
+        } else {
+            for (uint32_t i = 0; i < n; ++i) {
+                take[i]->rc = rc;
+                if (rc < 0) snprintf(take[i]->err, sizeof take[i]->err, "%s", xgm_last_error());
+                if (rc == XGM_OK) {
+                    *take[i]->hdr = hdrs[i];
+                    memcpy(take[i]->hits, hits.data() + (size_t)i * ks, (size_t)hdrs[i].n_hits * sizeof(xgm_hit));
+                }
+            }
+        }
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            for (XgmBatchReq* r : take) r->done = true;
+            ++b->batches; b->requests += n;
+        }
+        b->cv_done.notify_all();
+    }
+}
+
+static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr) {
+    XgmBatcher* b = idx->batcher;
+    XgmBatchReq r;
+    r.q = q; r.k_stride = k_stride; r.hits = hits; r.hdr = hdr; r.err[0] = 0;
+    {
+        std::unique_lock<std::mutex> lk(b->mu);
+        b->queue.push_back(&r);
+        b->cv_work.notify_one();
+        b->cv_done.wait(lk, [&] { return r.done; });
+    }
+    if (r.rc < 0) return xgm_set_error(r.rc, "%s", r.err);
+    return r.rc;
+}
+
+void xgm_batcher_destroy(xgm_index* idx) {
+    XgmBatcher* b = idx->batcher;
+    if (!b) return;
+    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
+    b->cv_work.notify_all();
+    if (b->th.joinable()) b->th.join();
+    idx->batcher = nullptr;
+    delete b;
+}
+
+extern "C" int xgm_index_set_batching(xgm_index* idx, uint32_t max_batch) {
+    if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "the index was opened without a device");
+    xgm_batcher_destroy(idx);
+    if (max_batch == 0) return XGM_OK;
+    XgmBatcher* b = new XgmBatcher();
+    b->max_batch = std::min<uint32_t>(max_batch, 1024u);
+    idx->batcher = b;
+    b->th = std::thread(batcher_loop, idx, b);
+    return XGM_OK;
+}
+
+/* out3 = {batches launched, requests served, current max_batch} */
+extern "C" int xgm_debug_batching_info(const xgm_index* idx, uint64_t* out3) {
+    if (!idx || !out3 || !idx->batcher) return xgm_set_error(XGM_E_INVALID, "batching is off");
+    std::lock_guard<std::mutex> lk(idx->batcher->mu);
+    out3[0] = idx->batcher->batches; out3[1] = idx->batcher->requests; out3[2] = idx->batcher->max_batch;
+    return XGM_OK;
+}
+
+/* Diagnostics / bench: n_threads host threads, each answering `per_thread` queries ONE AT A TIME through
+ * xgm_get_mset_batch(nq = 1) — plan + search, the call a matcher hook makes — picking descs[(t * per_thread + i) % n].
+ * lat_us receives n_threads * per_thread latencies (microseconds); returns the wall time in seconds (< 0 on error). */
+extern "C" double xgm_debug_concurrent_searches(xgm_index* idx, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t n,
+                                                uint32_t n_threads, uint32_t per_thread, uint32_t k, double* lat_us) {
+    if (!idx || !descs || !n || !n_threads || !per_thread || !lat_us) return -1.0;
+    std::vector<std::thread> th;
+    std::atomic<int> bad{0};
+    std::atomic<uint32_t> ready{0};
+    std::atomic<bool> go{false};
+    for (uint32_t t = 0; t < n_threads; ++t) {
+        th.emplace_back([&, t]() {
+            std::vector<xgm_hit> hits(k ? k : 1);
+            xgm_result_hdr hdr;
+            ++ready;
+            while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+            for (uint32_t i = 0; i < per_thread; ++i) {
+                const uint32_t j = (t * per_thread + i) % n;
+                const auto a = std::chrono::steady_clock::now();
+                const int rc = xgm_get_mset_batch(idx, &descs[j], gs ? &gs[j] : nullptr, 1, k ? k : 1, hits.data(), &hdr);
+                lat_us[(size_t)t * per_thread + i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+                if (rc != XGM_OK) ++bad;
+            }
+        });
+    }
+    while (ready.load() < n_threads) std::this_thread::yield();
+    const auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (auto& x : th) x.join();
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return bad.load() ? -1.0 : wall;
 }
 
 extern "C" int xgm_search(xgm_index* idx, const xgm_query* q, xgm_hit* hits, xgm_result_hdr* hdr) {

@@ -46,8 +46,9 @@ __global__ void k_dense_count(xgm_seg_dev seg, const uint32_t* __restrict__ dens
 
 /* one workgroup per (stripe, dense term): decode the run, write the bitmap and the per-slot wdf+1 bytes */
 __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint32_t* __restrict__ dense_terms, uint32_t n_stripes,
-                                                    const uint32_t* __restrict__ dir, unsigned char* __restrict__ data) {
+                                                    const uint32_t* __restrict__ dir, unsigned char* __restrict__ data, int with_pos) {
     __shared__ uint32_t bitmap[256];
+    __shared__ uint32_t pbase[128];       /* with_pos: position-entry offset (relative to the term) of the first posting of every 64-slot bucket */
     __shared__ uint32_t stage_all[4 * kStage];
     __shared__ uint32_t run[2];
     const uint32_t s = blockIdx.x, d = blockIdx.y, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     unsigned char* cont = data + (size_t)off * 16;
     unsigned char* wdf_out = cont + (size_t)NW * 4;
     if (tid < NW) bitmap[tid] = 0;
+    if (tid < 128u) pbase[tid] = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < W / 16u; i += 256u) reinterpret_cast<uint4*>(wdf_out)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) {                       /* the run's blocks: binary search on the term's block firsts */
         uint32_t lo = b0, hi = b1;
@@ -89,13 +91,17 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
         const uint32_t local = g0 + g1;
         const uint32_t excl = dn_scan(local) - local;
         const uint32_t d0 = first + excl + g0, d1 = d0 + g1;
+        /* a posting's positions start at entry blk_pos + Σ wdf of the earlier postings of its block */
+        const uint32_t lw = w0 + w1;
+        const uint32_t pex = with_pos ? seg.blk_pos[b] + dn_scan(lw) - lw : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w0 + 1u); }
-        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w1 + 1u); }
+        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w0 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex); }
+        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w1 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex + w0); }
     }
     __syncthreads();
     if (tid < NW) reinterpret_cast<uint32_t*>(cont)[tid] = bitmap[tid];
+    if (with_pos && tid < W / 64u) reinterpret_cast<uint32_t*>(wdf_out + W)[tid] = pbase[tid];
 }
 
 }  // namespace
@@ -108,6 +114,9 @@ int xgm_build_dense(xgm_index* idx) {
     idx->view.n_stripes = n_stripes;
     if (getenv("XGM_NO_DENSE")) return XGM_OK;                          /* A/B switch for measurements */
     const uint32_t NW = (1u << SB) / 32u;
+    /* indexes with positions: the containers also carry, per 64-slot bucket, where the bucket's first posting keeps its
+     * positions, so that the positional filter can use the probe path (the wdf bytes of the bucket give the rest) */
+    const int with_pos = idx->hdr.has_positions ? 1 : 0;
     const uint32_t min_avg = getenv("XGM_DENSE_MIN_AVG") ? (uint32_t)atoi(getenv("XGM_DENSE_MIN_AVG")) : XGM_DENSE_MIN_AVG;   /* tuning knob */
     std::vector<uint32_t> dense_terms;
     std::vector<uint32_t> dense_id(idx->hdr.n_terms, 0xFFFFFFFFu);
@@ -139,7 +148,7 @@ int xgm_build_dense(xgm_index* idx) {
         if (!cnt[i]) continue;
         if (units > 0xFFFFFFFFull) { rc = xgm_set_error(XGM_E_INVALID, "dense containers exceed the 32-bit directory"); goto fail; }
         dir[i] = (uint32_t)units;
-        units += ((uint64_t)NW * 4 + ((uint64_t)NW * 32)) / 16;            /* bitmap + one byte per slot */
+        units += ((uint64_t)NW * 4 + ((uint64_t)NW * 32) + (with_pos ? (uint64_t)NW * 2 : 0)) / 16;   /* bitmap + one byte per slot (+ a position base per 64 slots) */
     }
     DN_TRY(hipMalloc(&idx->d_dense_id, dense_id.size() * 4));
     DN_TRY(hipMalloc(&idx->d_dense_dir, dir.size() * 4));
@@ -147,7 +156,7 @@ int xgm_build_dense(xgm_index* idx) {
     DN_TRY(hipMemcpy(idx->d_dense_id, dense_id.data(), dense_id.size() * 4, hipMemcpyHostToDevice));
     DN_TRY(hipMemcpy(idx->d_dense_dir, dir.data(), dir.size() * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_dense_fill, dim3(n_stripes, n_dense), dim3(256), 0, 0, idx->view, d_terms, n_stripes, (const uint32_t*)idx->d_dense_dir,
-                       (unsigned char*)idx->d_dense_data);
+                       (unsigned char*)idx->d_dense_data, with_pos);
     DN_TRY(hipGetLastError());
     DN_TRY(hipDeviceSynchronize());
     idx->dense_bytes = dense_id.size() * 4 + dir.size() * 4 + units * 16;
@@ -156,6 +165,7 @@ int xgm_build_dense(xgm_index* idx) {
     idx->view.dense_dir = (const uint32_t*)idx->d_dense_dir;
     idx->view.dense_data = (const unsigned char*)idx->d_dense_data;
     idx->view.n_dense = n_dense;
+    idx->view.dense_pos = (uint32_t)with_pos;
     idx->dense_min_df = (uint64_t)min_avg * n_stripes;
     hipFree(d_terms); hipFree(d_cnt);
     return XGM_OK;

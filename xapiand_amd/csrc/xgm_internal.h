@@ -31,6 +31,7 @@ int xgm_validate_blob(const XgmSegmentBlob& blob);
 
 /* Per-thread scratch for searches (device + pinned host buffers), see xgm_api.cc. */
 struct XgmScratch;
+struct XgmBatcher;       /* opt-in micro-batching queue + dispatcher thread (xgm_index_set_batching) */
 struct XgmShardCtx;      /* persistent buffers / streams / RCCL communicator of one shard list (xgm_search_sharded) */
 
 struct xgm_index {
@@ -66,6 +67,7 @@ struct xgm_index {
     std::mutex scratch_mu;
     std::vector<XgmScratch*> scratch_pool;
     uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
+    XgmBatcher* batcher = nullptr;
     XgmShardCtx* shard_ctx = nullptr;  /* when this index is shards[0] of an xgm_search_sharded list */
 };
 

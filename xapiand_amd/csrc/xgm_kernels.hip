@@ -1253,9 +1253,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 have_reg = true;
                 tbase_reg = seg.term_word[id];
                 if (PHRASE) { tpos_reg = seg.term_pos[id]; tflag_reg = seg.term_flags[id]; }
-                /* the positional filter needs every term's position offsets, which only the block
-                 * decode yields: PHRASE batches take the block path for all terms */
-                if (!PHRASE && sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
+                /* the positional filter needs every term's position offsets: the block decode yields them, and so do
+                 * containers that carry the buckets' position bases (seg.dense_pos) */
+                if ((!PHRASE || seg.dense_pos) && sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
             }
             for (uint32_t i = c + lane; i < e; i += 64u) {
                 const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
@@ -1346,6 +1346,36 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             const bool valid = o < n_c;
             const uint32_t slot = valid ? c_slot[o] : 0u;
             const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
+            if (PHRASE) {
+                /* with positions: the candidate's whole 64-byte sector of wdf+1 bytes (the memory transaction the one-byte
+                 * probe costs anyway) gives its wdf AND, summed over the bucket's earlier slots, where its positions start
+                 * behind the bucket's base: entry = pos_base[slot / 64] + Σ wdf of the slots before it in the bucket */
+                for (uint32_t t = t_lo; t < T; ++t) {
+                    const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t & 63u);
+                    if (TALLY) { cn_probe += sec; cn_probe_raw += n_c - c0 < 64u ? n_c - c0 : 64u; cn_aux += sec; }
+                    uint32_t wdf1 = 0, pos = 0;
+                    if (valid) {
+                        const unsigned char* wbytes = seg.dense_data + (size_t)oo * 16 + (size_t)NW * 4;
+                        const uint4* sp = reinterpret_cast<const uint4*>(wbytes + (slot & ~63u));
+                        const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+                        pos = reinterpret_cast<const uint32_t*>(wbytes + W)[slot >> 6];
+                        const uint32_t wv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+                        const uint32_t kk = slot & 63u;
+#pragma unroll
+                        for (uint32_t j = 0; j < 16u; ++j) {
+                            const uint32_t x = wv[j];
+                            const uint32_t nz1 = ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;     /* 1 in every present slot's byte */
+                            const int rel = (int)kk - (int)(4u * j);                                             /* bytes of this word before the slot */
+                            const uint32_t m = rel >= 4 ? 0xFFFFFFFFu : (rel <= 0 ? 0u : ((1u << (8u * (uint32_t)rel)) - 1u));
+                            pos = __builtin_amdgcn_sad_u8((x - nz1) & m, 0u, pos);                               /* += Σ (wdf+1-1) of those bytes */
+                            if ((kk >> 2) == j) wdf1 = (x >> (8u * (kk & 3u))) & 0xFFu;
+                        }
+                        c_w[(size_t)t * CAND + o] = (TabT)wdf1;
+                        c_pos[(size_t)t * CAND + o] = pos;
+                    }
+                }
+                continue;
+            }
             for (uint32_t t0 = t_lo; t0 < T; t0 += 4u) {
                 uint32_t wv[4];
 #pragma unroll

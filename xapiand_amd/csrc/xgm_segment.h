@@ -98,6 +98,9 @@ typedef struct {
     const unsigned char* dense_data;
     uint32_t n_dense;
     uint32_t n_stripes;
+    uint32_t dense_pos;             /* the containers end with u32 pos_base[W/64]: position-entry offset (relative to the term) of the
+                                       first posting of each 64-slot bucket — the positional filter on the probe path */
+    uint32_t pad_;
 } xgm_seg_dev;
 
 #define XGM_DENSE_MIN_AVG 32u          /* postings per stripe (on average) that make a term dense     */
