@@ -1274,10 +1274,10 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
      * suffix [td, T).  td == 0: every term is dense → candidates come from the AND of the bitmaps.
      * (With more than 4 terms term 0 is always decoded, to bound the registers of that path.) */
     uint32_t td = (uint32_t)__popcll(__ballot(lane < TR && dense_reg == 0xFFFFFFFFu));
-    /* excluded terms without containers are block-decoded against the candidates' bitmap (P3c), which only
-     * the decode path builds */
+    /* right-hand terms without containers are block-decoded against the candidates' bitmap + rank table (P3c): the
+     * decode path builds them while it enumerates term 0, the all-dense path writes them from the AND of the bitmaps */
     const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;   /* right-hand terms without containers */
-    if (td == 0 && (TR > 4u || sparse_neg)) td = 1;
+    if (td == 0 && TR > 4u) td = 1;
 
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
     bool theta_valid = false;
@@ -1534,6 +1534,78 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         }
     };
 
+    /* P3c: wdf of the right-hand terms WITHOUT containers (AND_NOT: excluded, AND_MAYBE: optional) for the candidates
+     * whose ordinals are [lo, lo + CAND): per term the run's block headers in ONE load per field (lane j = block j),
+     * a ballot of the blocks whose 128-slot buckets hold a candidate, then their payloads four at a time in flight;
+     * every decoded posting that is a candidate (bitmap) is scattered to its ordinal (rank table) — as P3a does for
+     * the required terms.  `coarse`: bit b = bucket b of the stripe holds a candidate. */
+    auto scatter_sparse_rhs = [&](uint32_t sl_, unsigned long long coarse_, uint32_t lo_) {
+        for (uint64_t xm = sparse_neg; xm; xm &= xm - 1u) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(xm);
+            const uint32_t rbx = rs[t * SPG + sl_], nbx = re[t * SPG + sl_] - rbx;
+            TabT* row = c_w + (size_t)t * CAND;
+            const uint64_t tbx = tbase(t);
+            for (uint32_t j0 = 0; j0 < nbx; j0 += 64u) {
+                const uint32_t nb = nbx - j0 < 64u ? nbx - j0 : 64u;
+                uint32_t x_meta = 0, x_first = 0, x_word = 0, x_next = 0xFFFFFFFFu;
+                if (lane < nb) {
+                    x_meta = seg.blk_meta[rbx + j0 + lane]; x_first = seg.blk_first[rbx + j0 + lane]; x_word = seg.blk_word[rbx + j0 + lane];
+                    x_next = j0 + lane + 1u < nbx ? seg.blk_first[rbx + j0 + lane + 1u] : 0xFFFFFFFFu;
+                }
+                if (TALLY) { cn_hdr += XGM_SU(nb); }
+                bool need = false;
+                if (lane < nb) {
+                    const uint32_t blo = (x_first - stripe_base) >> 7;
+                    const uint32_t bhi = ((x_next == 0xFFFFFFFFu ? W : x_next - stripe_base) - 1u) >> 7;
+                    const unsigned long long mm = (bhi >= 63u ? ~0ull : ((1ull << (bhi + 1u)) - 1ull)) & ~((1ull << blo) - 1ull);
+                    need = (coarse_ & mm) != 0ull;
+                }
+                uint64_t mask = __ballot(need);
+                while (mask) {
+                    uint32_t jj[4], nn = 0;
+                    Words4 pv[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
+                        if (mask) {
+                            jj[u] = (uint32_t)__builtin_ctzll(mask);
+                            mask &= mask - 1u;
+                            const uint32_t bm = __builtin_amdgcn_readlane(x_meta, jj[u]);
+                            if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbx + __builtin_amdgcn_readlane(x_word, jj[u]) + lane * 4u);
+                            nn = u + 1u;
+                        }
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        if (u < nn) {
+                            const uint32_t bmeta = __builtin_amdgcn_readlane(x_meta, jj[u]);
+                            const uint32_t bfirst = __builtin_amdgcn_readlane(x_first, jj[u]);
+                            if (lane * 4u < payload_words(bmeta)) {
+                                stage[lane * 4u] = pv[u].a; stage[lane * 4u + 1] = pv[u].b; stage[lane * 4u + 2] = pv[u].c; stage[lane * 4u + 3] = pv[u].d;
+                            }
+                            wave_lds_fence();
+                            const DecodedPair r = unpack_staged<false>(stage, bfirst, bmeta, lane);
+                            wave_lds_fence();
+#pragma unroll
+                            for (uint32_t h = 0; h < 2u; ++h) {
+                                if (h ? r.v1 : r.v0) {
+                                    const uint32_t sx = (h ? r.d1 : r.d0) - stripe_base, wd = sx >> 5, bit = sx & 31u;
+                                    const uint32_t bm = bitmap[wd];
+                                    if ((bm >> bit) & 1u) {
+                                        const uint32_t ord = (uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u)) - lo_;
+                                        if (ord < CAND) row[ord] = (TabT)((h ? r.w1 : r.w0) + 1u);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+    };
+
     uint32_t sl = next_active(0);
     if (sl < n_local) issue_headers(sl);
     while (sl < n_local) {
@@ -1561,6 +1633,20 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
             uint32_t o = incl - cnt;                                   /* this lane's next ordinal */
             if (sl_next < n_local) issue_headers(sl_next);             /* next stripe's offsets in flight (this stripe uses hc_cur) */
+            const bool rhs_sparse = SIDED && sparse_neg != 0ull && n_total != 0u;
+            unsigned long long coarse0 = 0ull;
+            if (rhs_sparse) {
+                /* the AND of the bitmaps IS the candidates' bitmap; ordinals follow from the same prefix sums */
+                uint32_t run = o;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t w = lane * 4u + i;
+                    if (w < NW) { bitmap[w] = m[i]; rankw[w] = (uint16_t)run; }
+                    run += (uint32_t)__popc(m[i]);
+                }
+                coarse0 = __ballot((m[0] | m[1] | m[2] | m[3]) != 0u);      /* lane l owns words 4l..4l+3 = the 128 slots of bucket l */
+                wave_lds_fence();
+            }
             for (uint32_t lo = 0; lo < n_total; lo += CAND) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
@@ -1574,7 +1660,12 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 wave_lds_fence();
                 const uint32_t n_c = n_total - lo < CAND ? n_total - lo : CAND;
                 probe_dense(0u, n_c);
+                if (rhs_sparse) scatter_sparse_rhs(sl, coarse0, lo);
                 score_candidates(n_c, false);
+                wave_lds_fence();
+            }
+            if (rhs_sparse) {
+                for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
                 wave_lds_fence();
             }
             sl = sl_next;
@@ -1770,36 +1861,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             /* ---- P3b: dense other terms [td, T): O(1) probes of their containers ---- */
             if (td < T) probe_dense(td, n_c);
 
-            /* ---- P3c: excluded terms without containers: the blocks whose buckets hold a candidate ---- */
-            for (uint64_t xm = sparse_neg; SIDED && xm; xm &= xm - 1u) {
-                const uint32_t t = (uint32_t)__builtin_ctzll(xm);
-                const uint32_t rbx = rs[t * SPG + sl], nbx = re[t * SPG + sl] - rbx;
-                TabT* row = c_w + (size_t)t * CAND;
-                for (uint32_t j = 0; j < nbx; ++j) {
-                    const uint32_t xmeta = seg.blk_meta[rbx + j], xfirst = seg.blk_first[rbx + j];
-                    const uint32_t xnext = j + 1u < nbx ? seg.blk_first[rbx + j + 1u] : 0xFFFFFFFFu;
-                    if (TALLY) { cn_hdr += 1u; }
-                    if (!bucket_need(xfirst, xnext)) continue;
-                    if (TALLY) { cn_blkw += XGM_SU(payload_words(xmeta)) - 2u; }
-                    if (lane * 4u < payload_words(xmeta)) {
-                        const Words4 pvx = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rbx + j] + lane * 4u);
-                        stage[lane * 4u] = pvx.a; stage[lane * 4u + 1] = pvx.b; stage[lane * 4u + 2] = pvx.c; stage[lane * 4u + 3] = pvx.d;
-                    }
-                    wave_lds_fence();
-                    DecodedPair r = unpack_staged<false>(stage, xfirst, xmeta, lane);
-                    wave_lds_fence();
-                    if (r.v0) {
-                        const uint32_t sl0 = r.d0 - stripe_base, wd = sl0 >> 5, bit = sl0 & 31u;
-                        const uint32_t bm = bitmap[wd];
-                        if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w0 + 1u);
-                    }
-                    if (r.v1) {
-                        const uint32_t sl1 = r.d1 - stripe_base, wd = sl1 >> 5, bit = sl1 & 31u;
-                        const uint32_t bm = bitmap[wd];
-                        if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(r.w1 + 1u);
-                    }
-                }
-            }
+            /* ---- P3c: right-hand terms without containers: the blocks whose buckets hold a candidate ---- */
+            if (SIDED && sparse_neg) scatter_sparse_rhs(sl, coarse, 0u);
             wave_lds_fence();
 
             /* headers of the next active stripe: in flight while this one is scored */
