@@ -115,6 +115,39 @@ Xapian::Query make_query(const QuerySpec& q) {
         Xapian::Query right = one ? subs[nr] : Xapian::Query(Xapian::Query::OP_OR, subs.begin() + nr, subs.end());
         return Xapian::Query(q.op == "AND_NOT" ? Xapian::Query::OP_AND_NOT : Xapian::Query::OP_AND_MAYBE, left, right);
     }
+    if (q.op == "RPN") {
+        /* a nested query in post-order: "term[#wqf]" pushes a leaf; "&n" / "|n" / "=n" AND / OR / SYNONYM of the last n;
+         * "-n" AND_NOT and "?n" AND_MAYBE (first of the last n = left side, the others the right side); "!" FILTER of
+         * the last 2; "*f" OP_SCALE_WEIGHT of the top by f */
+        std::vector<Xapian::Query> st;
+        for (auto& tok : q.terms) {
+            const char c = tok[0];
+            if (c == '&' || c == '|' || c == '=' || c == '-' || c == '?') {
+                const size_t n = strtoul(tok.c_str() + 1, nullptr, 10);
+                if (n == 0 || n > st.size()) { fprintf(stderr, "bad RPN arity in %s\n", tok.c_str()); exit(2); }
+                const Xapian::Query::op op = c == '&' ? Xapian::Query::OP_AND : c == '|' ? Xapian::Query::OP_OR : c == '=' ? Xapian::Query::OP_SYNONYM
+                                             : c == '-' ? Xapian::Query::OP_AND_NOT : Xapian::Query::OP_AND_MAYBE;
+                Xapian::Query r(op, st.end() - n, st.end());
+                st.resize(st.size() - n);
+                st.push_back(r);
+            } else if (c == '!') {
+                if (st.size() < 2) { fprintf(stderr, "bad RPN: FILTER needs 2\n"); exit(2); }
+                Xapian::Query r(Xapian::Query::OP_FILTER, st[st.size() - 2], st[st.size() - 1]);
+                st.resize(st.size() - 2);
+                st.push_back(r);
+            } else if (c == '*') {
+                if (st.empty()) { fprintf(stderr, "bad RPN: SCALE needs 1\n"); exit(2); }
+                Xapian::Query r(Xapian::Query::OP_SCALE_WEIGHT, st.back(), strtod(tok.c_str() + 1, nullptr));
+                st.back() = r;
+            } else {
+                const size_t h = tok.find('#');
+                const unsigned wqf = h == std::string::npos ? 1u : (unsigned)strtoul(tok.c_str() + h + 1, nullptr, 10);
+                st.emplace_back(tok.substr(0, h), wqf);
+            }
+        }
+        if (st.size() != 1) { fprintf(stderr, "bad RPN: %zu values left\n", st.size()); exit(2); }
+        return st[0];
+    }
     fprintf(stderr, "unknown op %s\n", q.op.c_str());
     exit(2);
 }

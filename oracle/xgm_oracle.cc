@@ -271,11 +271,11 @@ Index* index_from_raw(uint32_t n_terms, uint32_t lastdocid, uint32_t doccount, u
 struct BM25 {
     double k1 = 1, k2 = 0, k3 = 1, b = 0.5, min_normlen = 0.5;
     double termweight = 0, len_factor = 0;
-    void init(uint32_t collection_size, uint32_t tf, double avg_len) {       /* bm25weight.cc:46-130 */
+    void init(uint32_t collection_size, uint32_t tf, double avg_len, uint32_t wqf = 1, double factor = 1.0) {   /* bm25weight.cc:46-130 */
         double tw = (collection_size - tf + 0.5) / (tf + 0.5);
         if (tw < 2) tw = tw * 0.5 + 1;
-        termweight = std::log(tw) * 1.0;
-        if (k3 != 0) { double wqf_double = 1; termweight *= (k3 + 1) * wqf_double / (k3 + wqf_double); }
+        termweight = std::log(tw) * factor;
+        if (k3 != 0) { double wqf_double = wqf; termweight *= (k3 + 1) * wqf_double / (k3 + wqf_double); }
         termweight *= (k1 + 1);
         if (k2 == 0 && (b == 0 || k1 == 0)) len_factor = 0;
         else { len_factor = avg_len; if (len_factor != 0) len_factor = 1 / len_factor; }
@@ -701,6 +701,276 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     return 0;
 }
 
+/* ----------------------------------------------------------------------------- nested queries ---------- */
+/* General operator trees, restated from the reference's Query → PostList lowering (api/queryinternal.cc):
+ *   QueryTerm::postlist :1049-1056, QueryScaleWeight::postlist :1076-1080 (factor multiplies down),
+ *   QueryAndLike::postlist / postlist_sub_and_like :2083-2103 (nested ANDs and FILTERs flatten into one AndContext →
+ *     ONE MultiAndPostList whose children are ordered by get_termfreq_est, multiandpostlist.h:117-130),
+ *   QueryOr / do_or_like :1790-1820, 2193-2206 (nested ORs flatten into one OrContext → Huffman tree, :440-489),
+ *   QueryAndNot::postlist :2208-2225 (right side: unweighted OR of the other subqueries),
+ *   QueryAndMaybe::postlist :2248-2269 (right side: weighted OR; an unweighted AND_MAYBE is its left branch),
+ *   QueryFilter::postlist :2271-2283 (MultiAnd{l, r x 0}),  QuerySynonym / do_synonym :1822-1898, 2386-2397 with
+ *   LocalSubMatch::make_synonym_postlist (matcher/localsubmatch.cc:199-229) and SynonymPostList::get_weight
+ *   (matcher/synonympostlist.cc:62-95): ONE BM25 weight over Σ wdf of the matching members, its termfreq the
+ *   independence estimate of BoolOrPostList::get_termfreq_est_using_stats (matcher/boolorpostlist.cc:192-230).
+ * Estimates that order the children: leafpostlist.cc:51-54, orpostlist.cc:365-384, multiandpostlist.cc:92-105,
+ * andnotpostlist.cc:50-61, AndMaybe = its left side, Synonym = BoolOrPostList::get_termfreq_est :175-190.
+ * Weights: multiandpostlist.cc:150-160, orpostlist.cc:94-103, andmaybepostlist.cc:57-64, leafpostlist.cc:57-65.
+ * count_matching_subqs: leafpostlist.cc:88-91 (weighted leaves), synonym = 1, sums / left side as in each PostList.
+ * Evaluation is exhaustive, document at a time over dense per-term wdf arrays: test sizes only. */
+enum { T_TERM = 0, T_AND = 1, T_OR = 2, T_AND_NOT = 3, T_AND_MAYBE = 4, T_FILTER = 5, T_SYNONYM = 6, T_SCALE = 7 };
+
+struct TreeIn {
+    uint32_t n_terms; const char* const* terms; const uint32_t* term_len; const uint32_t* wqf;
+    uint32_t n_ops; const uint8_t* kind; const uint8_t* arity; const uint16_t* term; const double* scale;
+    uint32_t first, maxitems;
+    uint32_t use_global; uint64_t g_total_length; uint32_t g_collection_size; const uint32_t* g_termfreq;
+};
+
+struct ANode { int kind; std::vector<int> kids; int term = -1; double scale = 1.0; };
+
+enum { P_LEAF = 0, P_SYN, P_MAND, P_OR, P_ANDNOT, P_MAYBE };
+struct PNode {
+    int type; std::vector<int> kids; int term = -1; std::vector<int> members; double factor = 1.0;
+    uint32_t est = 0; BM25 wt; bool weighted = false; double maxw = 0.0;
+};
+
+struct TreeEval {
+    Index* ix; const TreeIn& q;
+    std::vector<ANode> ast; std::vector<PNode> pl;
+    std::vector<uint32_t> id, tf_local, tf_global;
+    uint32_t N, db_size; double avg; uint32_t doclen_ub = 0; uint32_t total_subqs = 0;
+    std::vector<std::vector<uint32_t>> wdf_of;          /* per term: wdf + 1 by docid, 0 = absent */
+    TreeEval(Index* ix_, const TreeIn& q_) : ix(ix_), q(q_) {}
+
+    int add(PNode&& n) { pl.push_back(std::move(n)); return (int)pl.size() - 1; }
+    int leaf(int t, double factor) {
+        PNode n; n.type = P_LEAF; n.term = t; n.factor = factor; n.weighted = factor != 0.0;
+        n.est = tf_local[t];
+        n.wt.init(N, tf_global[t], avg, q.wqf ? std::max(1u, q.wqf[t]) : 1u, factor);
+        if (n.weighted) { ++total_subqs; n.maxw = n.wt.maxpart(id[t] == UINT32_MAX ? 0 : ix->wdf_ub[id[t]], ix->doclen_lb); }
+        return add(std::move(n));
+    }
+    int synonym(const std::vector<int>& terms, double factor) {
+        PNode n; n.type = P_SYN; n.members = terms; n.factor = factor; n.weighted = factor != 0.0;
+        {   /* BoolOrPostList::get_termfreq_est on the shard, :175-190 */
+            const double scale = db_size ? 1.0 / db_size : 0.0;
+            double P = tf_local[terms[0]] * scale;
+            for (size_t i = 1; i < terms.size(); ++i) { double Pi = tf_local[terms[i]] * scale; P += Pi - P * Pi; }
+            n.est = db_size ? (uint32_t)(P * db_size + 0.5) : 0u;
+        }
+        uint32_t tf_syn = 0;
+        if (N) {  /* get_termfreq_est_using_stats with the merged statistics, :192-230 */
+            const double scale = 1.0 / N;
+            double P = tf_global[terms[0]] * scale;
+            for (size_t i = 1; i < terms.size(); ++i) { double Pi = tf_global[terms[i]] * scale; P += Pi - P * Pi; }
+            tf_syn = (uint32_t)(P * N + 0.5);
+        }
+        n.wt.init(N, tf_syn, avg, 1u, factor);
+        if (n.weighted) { ++total_subqs; n.maxw = n.wt.maxpart(doclen_ub, ix->doclen_lb); }     /* Weight::init_ synonym case: wdf bound = doclength bound */
+        return add(std::move(n));
+    }
+    int mand(std::vector<int> ctx) {
+        PNode n; n.type = P_MAND;
+        std::vector<Leaf> in(ctx.size()), sorted(ctx.size());
+        for (size_t i = 0; i < ctx.size(); ++i) in[i] = Leaf{pl[ctx[i]].est, (uint32_t)i};
+        std::partial_sort_copy(in.begin(), in.end(), sorted.begin(), sorted.end(), TfAsc());
+        for (auto& l : sorted) n.kids.push_back(ctx[l.idx]);
+        double r = pl[n.kids[0]].est;
+        for (size_t i = 1; i < n.kids.size(); ++i) r = (r * pl[n.kids[i]].est) / db_size;
+        n.est = db_size ? (uint32_t)(r + 0.5) : 0u;
+        double m = 0.0;
+        for (int k : n.kids) m += pl[k].maxw;                     /* MultiAndPostList::recalc_maxweight, :169-179 */
+        n.maxw = m;
+        return add(std::move(n));
+    }
+    int or2(int l, int r) {
+        PNode n; n.type = P_OR; n.kids = {l, r};
+        const double a = pl[l].est, b = pl[r].est, nn = db_size;
+        n.est = nn == 0.0 ? 0u : (uint32_t)(a + b - (a * b / nn) + 0.5);
+        n.maxw = pl[l].maxw + pl[r].maxw;
+        return add(std::move(n));
+    }
+    int or_tree(std::vector<int> ctx) {
+        if (ctx.empty()) return -1;
+        if (ctx.size() == 1) return ctx[0];
+        std::vector<HItem> h;
+        for (int c : ctx) h.push_back(HItem{pl[c].est, c});
+        const size_t m = h.size();
+        for (long s2 = (long)((m - 2) / 2); s2 >= 0; --s2) sift_down(h, m, (size_t)s2);
+        while (true) {
+            HItem r = h.front();
+            size_t len = h.size();
+            if (len > 1) { std::swap(h[0], h[len - 1]); sift_down(h, len - 1, 0); }
+            h.pop_back();
+            HItem l = h.front();
+            int nid = or2(l.node, r.node);
+            if (h.size() == 1) return nid;
+            h[0].node = nid; h[0].tf = l.tf + r.tf;
+            sift_down(h, h.size(), 0);
+        }
+    }
+    void sub_and_like(int a, std::vector<int>& ctx, double factor) {
+        const ANode& n = ast[a];
+        if (n.kind == T_AND) { for (int k : n.kids) sub_and_like(k, ctx, factor); return; }
+        if (n.kind == T_FILTER) { for (int k : n.kids) { sub_and_like(k, ctx, factor); factor = 0.0; } return; }
+        ctx.push_back(postlist(a, factor));
+    }
+    void sub_or_like(int a, std::vector<int>& ctx, double factor) {
+        const ANode& n = ast[a];
+        if (n.kind == T_OR) { for (int k : n.kids) sub_or_like(k, ctx, factor); return; }
+        ctx.push_back(postlist(a, factor));
+    }
+    int postlist(int a, double factor) {
+        const ANode& n = ast[a];
+        switch (n.kind) {
+        case T_TERM: return leaf(n.term, factor);
+        case T_SCALE: return postlist(n.kids[0], factor * n.scale);
+        case T_AND: { std::vector<int> ctx; sub_and_like(a, ctx, factor); return mand(ctx); }
+        case T_FILTER: { int l = postlist(n.kids[0], factor); int r = postlist(n.kids[1], 0.0); return mand({l, r}); }
+        case T_OR: { std::vector<int> ctx; sub_or_like(a, ctx, factor); return or_tree(ctx); }
+        case T_AND_NOT: {
+            int l = postlist(n.kids[0], factor);
+            std::vector<int> ctx;
+            for (size_t i = 1; i < n.kids.size(); ++i) sub_or_like(n.kids[i], ctx, 0.0);
+            int r = or_tree(ctx);
+            if (r < 0) return l;
+            PNode p; p.type = P_ANDNOT; p.kids = {l, r};
+            double e = pl[l].est;
+            e = (e * (db_size - (double)pl[r].est)) / db_size;
+            p.est = db_size ? (uint32_t)(e + 0.5) : 0u;
+            p.maxw = pl[l].maxw;
+            return add(std::move(p));
+        }
+        case T_AND_MAYBE: {
+            int l = postlist(n.kids[0], factor);
+            if (factor == 0.0) return l;
+            std::vector<int> ctx;
+            for (size_t i = 1; i < n.kids.size(); ++i) sub_or_like(n.kids[i], ctx, factor);
+            int r = or_tree(ctx);
+            if (r < 0) return l;
+            PNode p; p.type = P_MAYBE; p.kids = {l, r}; p.est = pl[l].est; p.maxw = pl[l].maxw + pl[r].maxw;
+            return add(std::move(p));
+        }
+        case T_SYNONYM: {
+            std::vector<int> terms;
+            for (int k : n.kids) terms.push_back(ast[k].term);
+            if (terms.size() == 1) return leaf(terms[0], factor);          /* QuerySynonym::done: a synonym of one term is the term */
+            return synonym(terms, factor);
+        }
+        }
+        return -1;
+    }
+    struct Val { bool p; double w; uint32_t c; };
+    Val eval(int x, uint32_t did, uint32_t len) const {
+        const PNode& n = pl[x];
+        switch (n.type) {
+        case P_LEAF: {
+            uint32_t e = wdf_of[n.term].empty() ? 0u : wdf_of[n.term][did];
+            if (!e) return Val{false, 0.0, 0};
+            return Val{true, n.weighted ? n.wt.sumpart(e - 1, len) : 0.0, n.weighted ? 1u : 0u};
+        }
+        case P_SYN: {
+            bool any = false; uint32_t wdf = 0;
+            for (int t : n.members) { uint32_t e = wdf_of[t].empty() ? 0u : wdf_of[t][did]; if (e) { any = true; wdf += e - 1; } }
+            if (!any) return Val{false, 0.0, 0};
+            return Val{true, n.weighted ? n.wt.sumpart(wdf, len) : 0.0, n.weighted ? 1u : 0u};
+        }
+        case P_MAND: {
+            double w = 0.0; uint32_t c = 0;
+            for (int k : n.kids) { Val v = eval(k, did, len); if (!v.p) return Val{false, 0.0, 0}; w += v.w; c += v.c; }
+            return Val{true, w, c};
+        }
+        case P_OR: {
+            Val l = eval(n.kids[0], did, len), r = eval(n.kids[1], did, len);
+            if (l.p && r.p) return Val{true, l.w + r.w, l.c + r.c};
+            if (l.p) return l;
+            if (r.p) return r;
+            return Val{false, 0.0, 0};
+        }
+        case P_ANDNOT: {
+            Val l = eval(n.kids[0], did, len);
+            if (!l.p) return l;
+            Val r = eval(n.kids[1], did, len);
+            return r.p ? Val{false, 0.0, 0} : l;
+        }
+        case P_MAYBE: {
+            Val l = eval(n.kids[0], did, len);
+            if (!l.p) return l;
+            Val r = eval(n.kids[1], did, len);
+            return r.p ? Val{true, l.w + r.w, l.c + r.c} : l;
+        }
+        }
+        return Val{false, 0.0, 0};
+    }
+};
+
+int run_tree(Index* ix, const TreeIn& q, Result* out, uint32_t* total_subqs_out) {
+    TreeEval ev(ix, q);
+    /* post-order program → AST */
+    std::vector<int> stack;
+    for (uint32_t i = 0; i < q.n_ops; ++i) {
+        ANode n; n.kind = q.kind[i];
+        if (n.kind == T_TERM) { if (q.term[i] >= q.n_terms) return -1; n.term = q.term[i]; }
+        else {
+            const uint32_t ar = n.kind == T_SCALE ? 1u : q.arity[i];
+            if (ar == 0 || stack.size() < ar) return -1;
+            n.kids.assign(stack.end() - ar, stack.end());
+            stack.resize(stack.size() - ar);
+            if (n.kind == T_SCALE) n.scale = q.scale[i];
+            if (n.kind == T_SYNONYM) for (int k : n.kids) if (ev.ast[k].kind != T_TERM) return -1;
+            if ((n.kind == T_FILTER) && ar != 2) return -1;
+            if ((n.kind == T_AND_NOT || n.kind == T_AND_MAYBE) && ar < 2) return -1;
+        }
+        ev.ast.push_back(n);
+        stack.push_back((int)ev.ast.size() - 1);
+        /* QueryAndLike / OrLike::done: one subquery → that subquery */
+        if ((n.kind == T_AND || n.kind == T_OR) && n.kids.size() == 1) { stack.back() = n.kids[0]; }
+    }
+    if (stack.size() != 1) return -1;
+    const uint32_t n = q.n_terms;
+    ev.N = q.use_global ? q.g_collection_size : ix->doccount;
+    const uint64_t TL = q.use_global ? q.g_total_length : ix->total_length;
+    ev.avg = ev.N == 0 ? 0.0 : (double)TL / ev.N;
+    ev.db_size = ix->doccount;
+    ev.id.resize(n); ev.tf_local.resize(n); ev.tf_global.resize(n); ev.wdf_of.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        auto it = ix->dict.find(std::string(q.terms[i], q.term_len[i]));
+        ev.id[i] = it == ix->dict.end() ? UINT32_MAX : it->second;
+        ev.tf_local[i] = ev.id[i] == UINT32_MAX ? 0 : ix->df[ev.id[i]];
+        ev.tf_global[i] = q.use_global ? q.g_termfreq[i] : ev.tf_local[i];
+        if (ev.id[i] != UINT32_MAX) {
+            ev.wdf_of[i].assign((size_t)ix->lastdocid + 1, 0u);
+            for (uint64_t p = ix->term_start[ev.id[i]]; p < ix->term_start[ev.id[i] + 1]; ++p) ev.wdf_of[i][ix->did[p]] = ix->wdf[p] + 1u;
+        }
+    }
+    for (uint32_t d = 1; d <= ix->lastdocid; ++d) ev.doclen_ub = std::max(ev.doclen_ub, ix->doclen_dense[d]);
+    const int root = ev.postlist(stack[0], 1.0);
+    if (root < 0) return -1;
+    uint32_t docs = ix->doccount;
+    uint32_t first = std::min(q.first, docs);
+    uint32_t maxitems = std::min(q.maxitems, docs - first);
+    ProtoMSet pm((size_t)first + maxitems);
+    uint64_t matches = 0;
+    for (uint32_t d = 1; d <= ix->lastdocid; ++d) {
+        const uint32_t len = ix->doclen_dense[d];
+        if (!len && !ix->doclen_dense.empty() && ix->doclen_dense[d] == 0) { /* absent docid (or empty document): no leaf can index it */ }
+        TreeEval::Val v = ev.eval(root, d, len);
+        if (!v.p) continue;
+        ++matches;
+        if (v.w < pm.min_weight) continue;
+        pm.add(Hit{d, v.c, v.w});
+    }
+    pm.finalise();
+    out->hits = pm.results;
+    out->matches = matches;
+    out->max_possible = ev.pl[root].maxw;
+    out->max_attained = pm.results.empty() ? 0.0 : pm.results[0].weight;
+    out->max_subqs = pm.results.empty() ? 0 : pm.results[0].subqs;
+    if (total_subqs_out) *total_subqs_out = ev.total_subqs;
+    return 0;
+}
+
 }  // namespace
 
 /* ----------------------------------------------------------------------------- C ABI ----------- */
@@ -854,6 +1124,21 @@ int xgo_search_batch(void* ixv, uint32_t n_queries, const uint32_t* ops, const u
     }
     for (auto& x : th) x.join();
     for (uint32_t t = 0; t < n_threads; ++t) if (rcs[t]) return rcs[t];
+    return 0;
+}
+
+/* A nested query: terms[] + a post-order program (kind / arity / term index / scale per op), see run_tree. */
+int xgo_search_tree(void* ixv, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, const uint32_t* wqf,
+                    uint32_t n_ops, const uint8_t* kind, const uint8_t* arity, const uint16_t* term, const double* scale,
+                    uint32_t first, uint32_t maxitems, uint32_t use_global, uint64_t g_total_length, uint32_t g_collection_size,
+                    const uint32_t* g_termfreq, xgo_hit* hits, xgo_result_hdr* hdr, uint32_t* total_subqs) {
+    TreeIn q{n_terms, terms, term_len, wqf, n_ops, kind, arity, term, scale, first, maxitems, use_global, g_total_length, g_collection_size, g_termfreq};
+    Result r;
+    int rc = run_tree((Index*)ixv, q, &r, total_subqs);
+    if (rc) return rc;
+    hdr->n_hits = (uint32_t)r.hits.size(); hdr->max_subqs = r.max_subqs; hdr->matches = r.matches;
+    hdr->max_attained = r.max_attained; hdr->max_possible = r.max_possible;
+    for (size_t i = 0; i < r.hits.size(); ++i) { hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight; }
     return 0;
 }
 

@@ -469,3 +469,133 @@ def oracle_search_batch(corpus, queries, first, maxitems, n_threads=None, refere
         rows = [(hits[i * cap + j].docid, hits[i * cap + j].weight, hits[i * cap + j].subqs) for j in range(h.n_hits)]
         out.append((rows, dict(n_hits=h.n_hits, matches=h.matches, max_attained=h.max_attained, max_possible=h.max_possible, max_subqs=h.max_subqs)))
     return out
+
+
+# ---- nested queries: a tree of tuples <-> the post-order token form of xapian_ref's "RPN" queries ----
+#   tree := "term" | ("term", wqf) | ("AND", t, t, ...) | ("OR", ...) | ("SYN", term, ...) | ("AND_NOT", left, right...) |
+#           ("AND_MAYBE", left, right...) | ("FILTER", left, right) | ("SCALE", factor, t)
+T_KIND = {"TERM": 0, "AND": 1, "OR": 2, "AND_NOT": 3, "AND_MAYBE": 4, "FILTER": 5, "SYN": 6, "SCALE": 7}
+_RPN_SIGN = {"AND": "&", "OR": "|", "SYN": "=", "AND_NOT": "-", "AND_MAYBE": "?"}
+
+
+def tree_from_json(t):
+    """JSON turns the tuples of a tree into lists: back to tuples (a ["term", wqf] pair stays a pair)."""
+    if isinstance(t, list):
+        return tuple(tree_from_json(x) for x in t)
+    return t
+
+
+def tree_rpn(tree):
+    """Post-order token list of a tree (the query-file form)."""
+    if isinstance(tree, str):
+        return [tree]
+    if len(tree) == 2 and isinstance(tree[1], int) and isinstance(tree[0], str) and tree[0] not in T_KIND:
+        return ["%s#%d" % tree]
+    op = tree[0]
+    if op == "SCALE":
+        return tree_rpn(tree[2]) + ["*%r" % float(tree[1])]
+    toks = [x for k in tree[1:] for x in tree_rpn(k)]
+    if op == "FILTER":
+        return toks + ["!"]
+    return toks + ["%s%d" % (_RPN_SIGN[op], len(tree) - 1)]
+
+
+def tree_program(tree):
+    """(terms, wqf, ops) with ops = [(kind, arity, term index, scale)] in post-order; terms distinct, in first-use order."""
+    terms, wqf, ops = [], [], []
+
+    def walk(t):
+        if isinstance(t, str) or (len(t) == 2 and isinstance(t[1], int) and t[0] not in T_KIND):
+            name, w = (t, 1) if isinstance(t, str) else t
+            if name in terms:
+                raise ValueError("repeated term %s" % name)
+            terms.append(name); wqf.append(w)
+            ops.append((T_KIND["TERM"], 0, len(terms) - 1, 1.0))
+            return
+        op = t[0]
+        if op == "SCALE":
+            walk(t[2])
+            ops.append((T_KIND["SCALE"], 1, 0, float(t[1])))
+            return
+        for k in t[1:]:
+            walk(k)
+        ops.append((T_KIND[op], len(t) - 1, 0, 1.0))
+    walk(tree)
+    return terms, wqf, ops
+
+
+def oracle_search_tree(corpus, tree, first, maxitems, global_stats=None):
+    """The CPU oracle on a nested query.  Returns (rows, hdr, total_subqs)."""
+    ol = olib()
+    terms, wqf, ops = tree_program(tree)
+    tb = [t.encode() for t in terms]
+    n = len(tb)
+    arr = (C.c_char_p * n)(*tb)
+    lens = (C.c_uint32 * n)(*[len(t) for t in tb])
+    wq = (C.c_uint32 * n)(*wqf)
+    m = len(ops)
+    kind = (C.c_uint8 * m)(*[o[0] for o in ops])
+    arity = (C.c_uint8 * m)(*[o[1] for o in ops])
+    tix = (C.c_uint16 * m)(*[o[2] for o in ops])
+    scale = (C.c_double * m)(*[o[3] for o in ops])
+    cap = max(1, first + maxitems)
+    hits = (OHit * cap)()
+    hdr = OHdr()
+    tot = C.c_uint32()
+    ol.xgo_search_tree.restype = C.c_int
+    ol.xgo_search_tree.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_uint32,
+                                   C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint16), C.POINTER(C.c_double), C.c_uint32, C.c_uint32,
+                                   C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(OHit), C.POINTER(OHdr), C.POINTER(C.c_uint32)]
+    if global_stats is None:
+        rc = ol.xgo_search_tree(corpus.oracle_index(), n, arr, lens, wq, m, kind, arity, tix, scale, first, maxitems, 0, 0, 0, None, hits, C.byref(hdr), C.byref(tot))
+    else:
+        tf = (C.c_uint32 * n)(*[global_stats["termfreq"][t] for t in terms])
+        rc = ol.xgo_search_tree(corpus.oracle_index(), n, arr, lens, wq, m, kind, arity, tix, scale, first, maxitems, 1,
+                                global_stats["total_length"], global_stats["collection_size"], tf, hits, C.byref(hdr), C.byref(tot))
+    assert rc == 0, rc
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs) for i in range(hdr.n_hits)], hdr, tot.value
+
+
+def gen_tree_queries(n_queries, rank_lo=1, rank_hi=300, seed=QUERY_SEED):
+    """Random nested queries over distinct terms: the shapes Xapiand's DSL builds (boolean combinations, _filter / _and_not /
+    _and_maybe around them, synonym groups from wildcards, boosts)."""
+    rng = random.Random(seed)
+
+    def terms(k, used):
+        out = []
+        while len(out) < k:
+            t = "t%d" % max(1, log_uniform_rank(rng, rank_lo, rank_hi))
+            if t not in used:
+                used.add(t); out.append(t)
+        return out
+    qs = []
+    for i in range(n_queries):
+        used = set()
+        shape = i % 12
+        a = terms(8, used)
+        if shape == 0:
+            tree = ("AND", ("OR", a[0], a[1]), a[2])
+        elif shape == 1:
+            tree = ("OR", ("AND", a[0], a[1]), a[2], ("AND", a[3], a[4]))
+        elif shape == 2:
+            tree = ("AND", ("OR", a[0], a[1], a[2]), ("OR", a[3], a[4]), a[5])
+        elif shape == 3:
+            tree = ("AND_NOT", ("OR", a[0], a[1]), ("AND", a[2], a[3]))
+        elif shape == 4:
+            tree = ("AND_MAYBE", ("AND", a[0], a[1]), ("OR", a[2], ("AND", a[3], a[4])))
+        elif shape == 5:
+            tree = ("FILTER", ("OR", a[0], a[1], a[2]), ("OR", a[3], a[4]))
+        elif shape == 6:
+            tree = ("OR", ("SYN", a[0], a[1], a[2]), a[3])
+        elif shape == 7:
+            tree = ("AND", ("SYN", a[0], a[1]), ("SCALE", 2.5, a[2]), (a[3], 3))
+        elif shape == 8:
+            tree = ("SCALE", 0.5, ("OR", a[0], ("SCALE", 3.0, ("AND", a[1], a[2])), a[3]))
+        elif shape == 9:
+            tree = ("AND", ("AND", a[0], ("OR", a[1], a[2])), ("FILTER", a[3], ("OR", a[4], a[5])))
+        elif shape == 10:
+            tree = ("OR", ("AND_NOT", a[0], a[1]), ("AND_MAYBE", a[2], a[3]), (a[4], 2))
+        else:
+            tree = ("AND_MAYBE", ("SYN", a[0], a[1]), ("SYN", a[2], a[3], a[4]), a[5])
+        qs.append(dict(op="RPN", tree=tree, terms=tree_rpn(tree), first=0, maxitems=10, window=0))
+    return qs

@@ -33,7 +33,11 @@ def test_oracle_matches_golden(path):
     assert fx["results"]
     for r in fx["results"]:
         q = r["query"]
-        if fx["n_shards"] == 1:
+        if q["op"] == "RPN":
+            rows, hdr, _ = H.oracle_search_tree(shards[0], H.tree_from_json(q["tree"]), q["first"], q["maxitems"])
+            got = [(d, w) for d, w, _ in rows[q["first"]:]]
+            assert hdr.max_possible == float.fromhex(r["max_possible"])
+        elif fx["n_shards"] == 1:
             hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0))
             got = [(d, w) for d, w, _ in hits[q["first"]:]]
             assert hdr.max_possible == float.fromhex(r["max_possible"])

@@ -588,10 +588,13 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         bool all_dense = bp->andw;
         for (uint32_t t = 0; t < qs[i].n_terms; ++t) {
             uint32_t id = qs[i].terms[t].term_id;
-            if (id == UINT32_MAX) { min_df = 0; all_dense = false; continue; }
+            /* the candidates are the conjunction of the REQUIRED terms; right-hand terms (excluded / optional) are only probed */
+            const bool required = qs[i].op == XGM_OP_OR || ((qs[i].req_mask >> t) & 1u);
+            if (id == UINT32_MAX) { if (required) { min_df = 0; all_dense = false; } continue; }
             const double df = idx->term_df[id];
             const bool dense = bp->andw && !bp->wide && (!bp->phrase || idx->view.dense_pos) && idx->dense_min_df && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
-            if (!dense) { sparse_blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes); all_dense = false; }
+            if (!dense) { sparse_blocks += (required ? 1.0 : 0.25) * (df / XGM_BLOCK + std::min<double>(df, n_stripes)); if (required) all_dense = false; }
+            if (!required) continue;
             min_df = std::min(min_df, df);
             dens *= df / n_docs;
         }
