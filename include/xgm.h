@@ -62,6 +62,23 @@ extern "C" {
  * occurrence of every term falls inside a span shorter than `window`, in any order.  Distinct terms only. */
 #define XGM_OP_NEAR 7
 
+/* Nested queries (reference src/xapian/api/queryinternal.cc: the trees Xapiand's DSL builds, src/query_dsl.cc:188-432):
+ * a post-order program over desc->terms[].  XGM_T_TERM pushes terms[term]; the operators pop `arity` values:
+ * AND / OR of >= 1, SYNONYM of >= 1 TERMS (OP_SYNONYM: one BM25 weight over the summed wdf, queryinternal.cc:1822-1898),
+ * AND_NOT / AND_MAYBE of >= 2 (first = left side, the others the right side), FILTER of 2, SCALE of 1
+ * (OP_SCALE_WEIGHT by tree_scale[i]).  Terms must be distinct; no positional operators inside a tree. */
+#define XGM_OP_TREE 8
+#define XGM_MAX_TREE 40
+#define XGM_T_TERM 0
+#define XGM_T_AND 1
+#define XGM_T_OR 2
+#define XGM_T_AND_NOT 3
+#define XGM_T_AND_MAYBE 4
+#define XGM_T_FILTER 5
+#define XGM_T_SYNONYM 6
+#define XGM_T_SCALE 7
+typedef struct { uint8_t kind, arity; uint16_t term; } xgm_tree_op;
+
 typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
 #define XGM_DEVICE_NONE (-1)
 
@@ -99,6 +116,8 @@ typedef struct {
      * MSet::get_max_possible (and the pruning bounds never exceed them). */
     uint32_t doclen_lower_bound;
     uint32_t wdf_upper_bound;
+    uint32_t doclen_upper_bound;
+    uint32_t reserved;
 } xgm_raw_postings;
 
 /* Build the block-compressed device segment from raw postings on the host and write
@@ -206,7 +225,10 @@ typedef struct {
     /* BM25 parameters (reference src/xapian/weight.h:635-667 defaults 1, 0, 1, 0.5, 0.5) */
     double k1, k2, k3, b, min_normlen;
     uint32_t n_required;                  /* XGM_OP_AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND (>= 1) */
-    uint32_t reserved;
+    uint32_t n_tree;                      /* XGM_OP_TREE: ops of the post-order program below                       */
+    uint32_t wqf[XGM_MAX_TERMS];          /* within-query frequency of terms[i] (QueryTerm::get_wqf); 0 = 1         */
+    xgm_tree_op tree[XGM_MAX_TREE];
+    double tree_scale[XGM_MAX_TREE];      /* XGM_T_SCALE ops: the factor                                            */
 } xgm_query_desc;
 
 /* Collection statistics merged over all shards of the index, i.e. what Enquire::add_prepared_mset
@@ -243,7 +265,23 @@ typedef struct {
     double max_possible;         /* Σ get_maxpart (bm25weight.cc:183-207); MSet field only         */
     uint32_t req_mask;           /* bit p: terms[p] must index the document (all terms for AND / PHRASE, 0 for OR) */
     uint32_t neg_mask;           /* bit p: terms[p] must NOT index it (right-hand side of AND_NOT)   */
+    /* XGM_OP_TREE: the leaves of the lowered tree are GROUPS of terms — a term, or the members of an OP_SYNONYM that
+     * share one weight over their summed wdf — combined by binary nodes in evaluation order.  Operand < n_groups: a
+     * group, else n_groups + an earlier node.  A node's value is (matches, weight, weighted leaves matched):
+     *   AND  l & r,  l + r          OR   l | r,  l + r (an absent side adds nothing)      AND_NOT  l & !r,  l
+     *   MAYBE  l,  l + r where r matches (AndMaybePostList::get_weight, andmaybepostlist.cc:57-64)
+     * n-ary conjunctions are chains in MultiAndPostList order, disjunctions the Huffman tree of OrContext::postlist, both
+     * ordered by the sub-trees' termfreq ESTIMATES as the reference does. */
+    uint32_t tree_len, n_groups, tree_root, total_subqs;
+    uint32_t group_scored;       /* bit g: group g carries weight (counts in percentages)          */
+    uint8_t group_of[XGM_MAX_TERMS];
+    double group_weight[XGM_MAX_TERMS];
+    uint8_t tree_op[XGM_MAX_TREE], tree_a[XGM_MAX_TREE], tree_b[XGM_MAX_TREE];
 } xgm_query;
+#define XGM_N_AND 1
+#define XGM_N_OR 2
+#define XGM_N_ANDNOT 3
+#define XGM_N_MAYBE 4
 
 /* Lower a query description to a plan against this shard.  Replaces, for the supported shapes,
  * LocalSubMatch::get_postlist / open_post_list (reference src/xapian/matcher/localsubmatch.cc:164-

@@ -54,8 +54,55 @@ bool terms_of(const Xapian::Query& q, Xapian::Query::op op, std::vector<std::str
     return true;
 }
 
-/* Xapian::Query → xgm_query_desc for the shapes of SURVEY §8 (a3) and (f).2; false = decline */
-bool lower(const Xapian::Query& q, Lowered* L) {
+/* A nested query → the post-order program of xgm_query_desc (XGM_OP_TREE): AND / OR / AND_NOT / AND_MAYBE / FILTER over
+ * sub-trees, OP_SYNONYM of terms, OP_SCALE_WEIGHT, leaves with their wqf.  false = a shape the device path declines. */
+bool lower_tree_node(const Xapian::Query& q, Lowered* L) {
+    xgm_query_desc& d = L->d;
+    const Xapian::Query::op op = q.get_type();
+    if (op == Xapian::Query::LEAF_TERM) {
+        const auto* t = static_cast<const Xapian::Internal::QueryTerm*>(q.internal.get());
+        if (!t || t->get_term().empty() || L->terms.size() >= XGM_MAX_TERMS || d.n_tree >= XGM_MAX_TREE) return false;
+        d.wqf[L->terms.size()] = t->get_wqf();
+        d.tree[d.n_tree].kind = XGM_T_TERM; d.tree[d.n_tree].arity = 0; d.tree[d.n_tree].term = (uint16_t)L->terms.size();
+        ++d.n_tree;
+        L->terms.push_back(t->get_term());
+        return true;
+    }
+    uint8_t kind;
+    switch (op) {
+    case Xapian::Query::OP_AND: kind = XGM_T_AND; break;
+    case Xapian::Query::OP_OR: kind = XGM_T_OR; break;
+    case Xapian::Query::OP_AND_NOT: kind = XGM_T_AND_NOT; break;
+    case Xapian::Query::OP_AND_MAYBE: kind = XGM_T_AND_MAYBE; break;
+    case Xapian::Query::OP_FILTER: kind = XGM_T_FILTER; break;
+    case Xapian::Query::OP_SYNONYM: kind = XGM_T_SYNONYM; break;
+    case Xapian::Query::OP_SCALE_WEIGHT: kind = XGM_T_SCALE; break;
+    default: return false;
+    }
+    const size_t n = q.get_num_subqueries();
+    if (n == 0 || n > 255) return false;
+    for (size_t i = 0; i < n; ++i) {
+        const Xapian::Query sub = q.get_subquery(i);
+        if (kind == XGM_T_SYNONYM && sub.get_type() != Xapian::Query::LEAF_TERM) return false;
+        if (!lower_tree_node(sub, L)) return false;
+    }
+    if (d.n_tree >= XGM_MAX_TREE) return false;
+    d.tree[d.n_tree].kind = kind; d.tree[d.n_tree].arity = (uint8_t)n; d.tree[d.n_tree].term = 0;
+    if (kind == XGM_T_SCALE) {
+        /* QueryScaleWeight keeps its factor private; its serialisation is one tag byte + serialise_double(factor)
+         * (api/queryinternal.cc: QueryScaleWeight::serialise) */
+        std::string ser;
+        q.internal->serialise(ser);
+        if (ser.size() < 2) return false;
+        const char* p = ser.data() + 1;
+        d.tree_scale[d.n_tree] = unserialise_double(&p, ser.data() + ser.size());
+    }
+    ++d.n_tree;
+    return true;
+}
+
+/* Xapian::Query → xgm_query_desc for the FLAT shapes of SURVEY §8 (a3) and (f).2 (each has its own fast kernel) */
+bool lower_flat(const Xapian::Query& q, Lowered* L) {
     memset(&L->d, 0, sizeof L->d);
     L->terms.clear();
     const Xapian::Query::op op = q.get_type();
@@ -91,6 +138,19 @@ bool lower(const Xapian::Query& q, Lowered* L) {
         return false;
     }
     if (L->terms.empty() || L->terms.size() > XGM_MAX_TERMS) return false;
+    L->d.n_terms = (uint32_t)L->terms.size();
+    for (size_t i = 0; i < L->terms.size(); ++i) { L->d.terms[i] = L->terms[i].data(); L->d.term_len[i] = (uint32_t)L->terms[i].size(); }
+    return true;
+}
+
+/* flat shape, else the general tree (nested operators, OP_SYNONYM, OP_SCALE_WEIGHT, wqf != 1); false = decline */
+bool lower(const Xapian::Query& q, Lowered* L) {
+    if (lower_flat(q, L)) return true;
+    memset(&L->d, 0, sizeof L->d);
+    L->terms.clear();
+    if (!lower_tree_node(q, L)) return false;
+    L->d.op = XGM_OP_TREE;
+    L->total_subqs = 0;                     /* comes back from the planner (xgm_query.total_subqs) */
     L->d.n_terms = (uint32_t)L->terms.size();
     for (size_t i = 0; i < L->terms.size(); ++i) { L->d.terms[i] = L->terms[i].data(); L->d.term_len[i] = (uint32_t)L->terms[i].size(); }
     return true;
@@ -163,9 +223,12 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     std::vector<xgm_hit> hits(k ? k : 1);
     xgm_result_hdr hdr;
     memset(&hdr, 0, sizeof hdr);
-    const int rc = xgm_get_mset_batch(sh.idx, &L.d, &gs, 1, k ? k : 1, hits.data(), &hdr);
+    xgm_query plan;
+    int rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
+    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
     if (rc > 0) { ++g_dev; return false; }                                   /* declined by the planner: CPU matcher */
     if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    if (L.d.op == XGM_OP_TREE) L.total_subqs = plan.total_subqs;
 
     /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682).  matches_*: exact counts
      * (the reference's are estimates; documented exception). */

@@ -8,6 +8,8 @@ import ctypes as C
 import os
 
 XGM_MAX_TERMS = 16
+XGM_MAX_TREE = 40
+XGM_OP_TREE = 8
 XGM_MAX_K = 1024
 XGM_OK, XGM_UNSUPPORTED = 0, 1
 XGM_E_INVALID, XGM_E_IO, XGM_E_NO_DEVICE, XGM_E_DEVICE, XGM_E_REVISION, XGM_E_NOMEM = -1, -2, -3, -4, -5, -6
@@ -28,7 +30,8 @@ class RawPostings(C.Structure):
                 ("term_len", C.POINTER(C.c_uint32)), ("df", C.POINTER(C.c_uint32)),
                 ("did", C.POINTER(C.c_uint32)), ("wdf", C.POINTER(C.c_uint32)),
                 ("pos_off", C.POINTER(C.c_uint64)), ("pos", C.POINTER(C.c_uint32)),
-                ("doclen_lower_bound", C.c_uint32), ("wdf_upper_bound", C.c_uint32)]
+                ("doclen_lower_bound", C.c_uint32), ("wdf_upper_bound", C.c_uint32),
+                ("doclen_upper_bound", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class SynthParams(C.Structure):
@@ -45,12 +48,17 @@ class IndexInfo(C.Structure):
                 ("block_size", C.c_uint32), ("doclen_lower_bound", C.c_uint32), ("wdf_upper_bound", C.c_uint32)]
 
 
+class TreeOp(C.Structure):
+    _fields_ = [("kind", C.c_uint8), ("arity", C.c_uint8), ("term", C.c_uint16)]
+
+
 class QueryDesc(C.Structure):
     _fields_ = [("op", C.c_uint32), ("n_terms", C.c_uint32), ("terms", C.c_char_p * XGM_MAX_TERMS),
                 ("term_len", C.c_uint32 * XGM_MAX_TERMS), ("window", C.c_uint32), ("first", C.c_uint32),
                 ("maxitems", C.c_uint32), ("check_at_least", C.c_uint32),
                 ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double), ("b", C.c_double),
-                ("min_normlen", C.c_double), ("n_required", C.c_uint32), ("reserved", C.c_uint32)]
+                ("min_normlen", C.c_double), ("n_required", C.c_uint32), ("n_tree", C.c_uint32),
+                ("wqf", C.c_uint32 * XGM_MAX_TERMS), ("tree", TreeOp * XGM_MAX_TREE), ("tree_scale", C.c_double * XGM_MAX_TREE)]
 
 
 class GlobalStats(C.Structure):
@@ -67,7 +75,10 @@ class Query(C.Structure):
                 ("sum_prog", C.c_int8 * (2 * XGM_MAX_TERMS)), ("sum_len", C.c_uint32), ("window", C.c_uint32),
                 ("phrase_active", C.c_uint32), ("len_factor", C.c_double), ("k1", C.c_double), ("b", C.c_double),
                 ("min_normlen", C.c_double), ("first", C.c_uint32), ("maxitems", C.c_uint32),
-                ("check_at_least", C.c_uint32), ("max_possible", C.c_double), ("req_mask", C.c_uint32), ("neg_mask", C.c_uint32)]
+                ("check_at_least", C.c_uint32), ("max_possible", C.c_double), ("req_mask", C.c_uint32), ("neg_mask", C.c_uint32),
+                ("tree_len", C.c_uint32), ("n_groups", C.c_uint32), ("tree_root", C.c_uint32), ("total_subqs", C.c_uint32),
+                ("group_scored", C.c_uint32), ("group_of", C.c_uint8 * XGM_MAX_TERMS), ("group_weight", C.c_double * XGM_MAX_TERMS),
+                ("tree_op", C.c_uint8 * XGM_MAX_TREE), ("tree_a", C.c_uint8 * XGM_MAX_TREE), ("tree_b", C.c_uint8 * XGM_MAX_TREE)]
 
 
 class Hit(C.Structure):

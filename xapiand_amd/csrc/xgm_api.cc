@@ -449,6 +449,20 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR;
         else if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
     }
+    if (q->op == XGM_OP_TREE) {
+        /* a nested query: groups + binary nodes straight from the plan; the match kernel evaluates them per document */
+        if (q->n_groups == 0 || q->n_groups > XGM_MAX_TERMS || q->tree_len > XGM_MAX_TREE || q->tree_root >= q->n_groups + q->tree_len) return -1;
+        d->flags |= XGM_QF_TREE;
+        d->tree_len = q->tree_len; d->n_groups = q->n_groups; d->tree_root = q->tree_root; d->group_scored = q->group_scored;
+        for (uint32_t t = 0; t < q->n_terms; ++t) { if (q->group_of[t] >= q->n_groups) return -1; d->group_of[t] = q->group_of[t]; }
+        for (uint32_t g = 0; g < q->n_groups; ++g) d->termweight[g] = q->group_weight[g];
+        for (uint32_t j = 0; j < q->tree_len; ++j) {
+            if (q->tree_a[j] >= q->n_groups + j || q->tree_b[j] >= q->n_groups + j || q->tree_op[j] < XGM_N_AND || q->tree_op[j] > XGM_N_MAYBE) return -1;
+            d->tnode_op[j] = q->tree_op[j]; d->tnode_a[j] = q->tree_a[j]; d->tnode_b[j] = q->tree_b[j];
+        }
+        d->score_mask = 0; d->req_mask = 0; d->neg_mask = 0; d->n_req = 0;
+        return width;
+    }
     if (q->op == XGM_OP_OR ? all_absent : any_absent) d->flags |= XGM_QF_EMPTY;
     /* post-order program → node list */
     int stack[2 * XGM_MAX_TERMS];

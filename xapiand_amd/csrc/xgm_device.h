@@ -18,6 +18,7 @@
 #define XGM_QF_EXACT 2u             /* window == n_terms: ExactPhrasePostList semantics            */
 #define XGM_QF_EMPTY 4u             /* provably no match on this shard (absent AND term, ...)      */
 #define XGM_QF_NEAR 8u              /* the positional filter is NearPostList's (any order, span < window) */
+#define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */
 typedef struct {
@@ -44,6 +45,10 @@ typedef struct {
     /* safe upper bound of leaf t's weight over the whole shard (0 for an absent term): drives the
      * MaxScore pruning of xgm_orw_kernel; never part of a result */
     double ub[XGM_MAX_TERMS];
+    /* XGM_QF_TREE (include/xgm.h, xgm_query): termweight[g] is then the weight of GROUP g */
+    uint32_t tree_len, n_groups, tree_root, group_scored;
+    uint8_t group_of[XGM_MAX_TERMS];
+    uint8_t tnode_op[XGM_MAX_TREE], tnode_a[XGM_MAX_TREE], tnode_b[XGM_MAX_TREE];
 } xgm_dev_query;
 
 /* One top-k candidate: 16 bytes. */

@@ -79,6 +79,7 @@ struct RootInfo {
 
 struct GlassVersion {
     uint64_t revision = 0, doccount = 0, last_docid = 0, total_doclen = 0;
+    uint64_t doclen_ubound_delta = 0;
     uint64_t doclen_lbound = 0, wdf_ubound = 0;      /* glass's own, never tightened on delete / replace (glass_version.h:252-270) */
     RootInfo root[kTableCount];
 };
@@ -112,7 +113,7 @@ int read_version(const std::string& dir, GlassVersion* v) {
     uint64_t ld_minus, skip;
     if (p == end) return XGM_OK;                                                 /* empty database: no statistics */
     if (!get_varint(&p, end, &v->doccount) || !get_varint(&p, end, &ld_minus) || !get_varint(&p, end, &v->doclen_lbound) ||
-        !get_varint(&p, end, &v->wdf_ubound) || !get_varint(&p, end, &skip) /* doclen_ubound - wdf_ubound */ ||
+        !get_varint(&p, end, &v->wdf_ubound) || !get_varint(&p, end, &v->doclen_ubound_delta) /* doclen_ubound - wdf_ubound */ ||
         !get_varint(&p, end, &skip) /* oldest_changeset */ || !get_varint(&p, end, &v->total_doclen))
         return xgm_set_error(XGM_E_INVALID, "%s: database statistics are truncated", path.c_str());
     v->last_docid = ld_minus + v->doccount;
@@ -419,6 +420,7 @@ void fill_raw(const Export& ex, std::vector<const char*>* tp, std::vector<uint32
      * postings give, and BM25Weight::get_maxpart — hence MSet::get_max_possible — uses glass's */
     raw->doclen_lower_bound = (uint32_t)ex.ver.doclen_lbound;
     raw->wdf_upper_bound = (uint32_t)ex.ver.wdf_ubound;
+    raw->doclen_upper_bound = (uint32_t)(ex.ver.wdf_ubound + ex.ver.doclen_ubound_delta);
     raw->has_positions = ex.has_positions ? 1u : 0u;
     raw->total_length = ex.ver.total_doclen;
     raw->n_postings = ex.did.size();

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
     const uint32_t SB = seg.stripe_bits;
     const uint32_t W = 1u << SB;
     const uint32_t T = q.n_terms;
-    const bool is_or = (q.op == XGM_OP_OR);
+    const bool is_tree = (q.flags & XGM_QF_TREE) != 0;               /* nested query: candidates = any term, then the node program decides */
+    const bool is_or = (q.op == XGM_OP_OR) || is_tree;
     const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;      /* non-OR: who must / must not be present */
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
     const uint32_t k = q.k;
@@ -524,6 +525,24 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                         }
                     }
                 }
+                if (is_tree && bits) {
+                    /* which of the slots that hold any term satisfy the tree: presence of every group, then of every node */
+                    uint32_t keep = 0;
+                    const uint32_t G = q.n_groups;
+                    for (uint32_t bb = bits; bb; bb &= bb - 1u) {
+                        const uint32_t bit = (uint32_t)__ffs(bb) - 1u, slot = base + bit;
+                        uint64_t pm = 0;
+                        for (uint32_t t = 0; t < T; ++t) if (tab[(size_t)t * W + slot]) pm |= 1ull << q.group_of[t];
+                        for (uint32_t j = 0; j < q.tree_len; ++j) {
+                            const uint64_t a = (pm >> q.tnode_a[j]) & 1ull, b = (pm >> q.tnode_b[j]) & 1ull;
+                            const uint32_t op = q.tnode_op[j];
+                            const uint64_t r = op == XGM_N_AND ? (a & b) : op == XGM_N_OR ? (a | b) : op == XGM_N_ANDNOT ? (a & (b ^ 1ull)) : a;
+                            pm |= r << (G + j);
+                        }
+                        if ((pm >> q.tree_root) & 1ull) keep |= 1u << bit;
+                    }
+                    bits = keep;
+                }
                 uint32_t cnt = (uint32_t)__popc(bits);
                 uint32_t incl = wave_incl_scan(cnt);
                 uint32_t wtotal = __builtin_amdgcn_readlane(incl, 63);
@@ -584,8 +603,43 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                     double normlen = len * q.len_factor;
                     normlen = normlen > q.min_normlen ? normlen : q.min_normlen;   /* std::max(a, b) */
                     const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
-                    double val[2 * XGM_MAX_TERMS];
+                    double val[XGM_MAX_TERMS + XGM_MAX_TREE];
                     uint32_t subqs = 0;
+                    double weight;
+                    if (is_tree) {
+                        /* groups: one BM25 weight over the summed wdf of the members that index the document (a term, or an
+                         * OP_SYNONYM: SynonymPostList::get_weight, synonympostlist.cc:62-95); nodes: (matches, weight, weighted
+                         * leaves) by the rules of include/xgm.h — an absent value weighs -0.0, the identity of IEEE addition */
+                        const uint32_t G = q.n_groups;
+                        uint32_t gsum[XGM_MAX_TERMS];
+                        uint8_t cnt[XGM_MAX_TERMS + XGM_MAX_TREE];
+                        uint64_t pm = 0;
+                        for (uint32_t g = 0; g < G; ++g) gsum[g] = 0;
+                        for (uint32_t t = 0; t < T; ++t) {
+                            const uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
+                            if (e) { pm |= 1ull << q.group_of[t]; gsum[q.group_of[t]] += e - 1u; }
+                        }
+                        for (uint32_t g = 0; g < G; ++g) {
+                            const bool here = (pm >> g) & 1ull;
+                            const double wdf = (double)gsum[g];
+                            val[g] = here ? q.termweight[g] * (wdf / (denom_len + wdf)) : -0.0;
+                            cnt[g] = (uint8_t)(here ? (q.group_scored >> g) & 1u : 0u);
+                        }
+                        for (uint32_t j = 0; j < q.tree_len; ++j) {
+                            const uint32_t a = q.tnode_a[j], b = q.tnode_b[j], op = q.tnode_op[j];
+                            const bool pa = (pm >> a) & 1ull, pb = (pm >> b) & 1ull;
+                            bool pr; double w; uint32_t c;
+                            if (op == XGM_N_AND) { pr = pa && pb; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }
+                            else if (op == XGM_N_OR) { pr = pa || pb; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }
+                            else if (op == XGM_N_ANDNOT) { pr = pa && !pb; w = val[a]; c = cnt[a]; }
+                            else { pr = pa; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }      /* MAYBE: val[b] is -0.0 where r is absent */
+                            val[G + j] = pr ? w : -0.0;
+                            cnt[G + j] = (uint8_t)(pr ? c : 0u);
+                            if (pr) pm |= 1ull << (G + j);
+                        }
+                        weight = val[q.tree_root];
+                        subqs = cnt[q.tree_root];
+                    } else {
                     for (uint32_t t = 0; t < T; ++t) {
                         uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
                         double wt = -0.0;                       /* absent leaf: x + (-0.0) == x */
@@ -598,7 +652,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                         val[t] = wt;
                     }
                     for (uint32_t j = 0; j < q.n_nodes; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
-                    double weight = val[q.sum_root];
+                    weight = val[q.sum_root];
+                    }
                     uint64_t wb = (uint64_t)__double_as_longlong(weight);
                     bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
                     if (take) {

@@ -85,13 +85,13 @@ void emit_postorder(const std::vector<TreeNode>& nodes, int n_leaves, int id, xg
     q->sum_prog[q->sum_len++] = XGM_SUM_ADD;
 }
 
-/* BM25Weight::init, bm25weight.cc:46-130 with rset_size == 0, factor == 1, wqf == 1. */
-double bm25_termweight(uint32_t collection_size, uint32_t termfreq, double k1, double k3) {
+/* BM25Weight::init, bm25weight.cc:46-130 with rset_size == 0. */
+double bm25_termweight(uint32_t collection_size, uint32_t termfreq, double k1, double k3, uint32_t wqf = 1, double factor = 1.0) {
     double tw = (collection_size - termfreq + 0.5) / (termfreq + 0.5);   /* unsigned subtraction as in the reference */
     if (tw < 2) tw = tw * 0.5 + 1;
-    double termweight = std::log(tw) * 1.0;
+    double termweight = std::log(tw) * factor;
     if (k3 != 0) {
-        double wqf_double = 1;
+        double wqf_double = wqf;
         termweight *= (k3 + 1) * wqf_double / (k3 + wqf_double);
     }
     termweight *= (k1 + 1);
@@ -113,14 +113,249 @@ double bm25_maxpart(double termweight, double len_factor, double k1, double b, d
     return termweight * (wdf_max / denom);
 }
 
+
+/* ---- nested queries (XGM_OP_TREE) ------------------------------------------------------------------------------------
+ * The reference's Query → PostList lowering restated for trees (api/queryinternal.cc): QueryTerm / QueryScaleWeight
+ * (:1049-1080: the factor multiplies down into BM25Weight::init), QueryAndLike::postlist_sub_and_like (:2083-2103: nested
+ * ANDs and FILTERs flatten into ONE MultiAndPostList, children in ascending termfreq ESTIMATE, multiandpostlist.h:117-130),
+ * do_or_like (:1790-1820: nested ORs flatten into one Huffman tree, :440-489), QueryAndNot / QueryAndMaybe / QueryFilter
+ * (:2208-2283), do_synonym + LocalSubMatch::make_synonym_postlist (:1822-1898, matcher/localsubmatch.cc:199-229).
+ * Estimates: leafpostlist.cc:51-54, orpostlist.cc:365-384, multiandpostlist.cc:92-105, andnotpostlist.cc:50-61,
+ * boolorpostlist.cc:175-230. */
+struct ANode { int kind; std::vector<int> kids; int term = -1; double scale = 1.0; };
+enum { P_GROUP = 0, P_MAND, P_OR, P_ANDNOT, P_MAYBE };
+struct PNode { int type; std::vector<int> kids; int group = -1; uint32_t est = 0; double maxw = 0.0; int dev = -1; /* operand id on the device */ };
+
+struct TreePlanner {
+    const xgm_index* idx; const xgm_query_desc* d; const xgm_global_stats* gs; xgm_query* out;
+    std::vector<ANode> ast; std::vector<PNode> pl;
+    uint32_t N = 0, db_size = 0; double len_factor = 0;
+    uint32_t local_id[XGM_MAX_TERMS], tf_local[XGM_MAX_TERMS], tf_global[XGM_MAX_TERMS];
+    bool used[XGM_MAX_TERMS] = {};
+    int rc = XGM_OK;
+
+    int add(PNode&& n) { pl.push_back(std::move(n)); return (int)pl.size() - 1; }
+    int new_group(double weight, bool scored, double maxw, uint32_t est) {
+        if (out->n_groups >= XGM_MAX_TERMS) { rc = XGM_UNSUPPORTED; return -1; }
+        const uint32_t g = out->n_groups++;
+        out->group_weight[g] = weight;
+        if (scored) { out->group_scored |= 1u << g; ++out->total_subqs; }
+        PNode n; n.type = P_GROUP; n.group = (int)g; n.est = est; n.maxw = maxw;
+        return add(std::move(n));
+    }
+    int leaf(int t, double factor) {
+        const bool weighted = factor != 0.0;
+        const double w = bm25_termweight(N, tf_global[t], d->k1, d->k3, d->wqf[t] ? d->wqf[t] : 1u, factor);
+        const uint32_t wdf_ub = local_id[t] == UINT32_MAX ? 0u : idx->term_wdfub[local_id[t]];
+        const int x = new_group(weighted ? w : 0.0, weighted, weighted ? bm25_maxpart(w, len_factor, d->k1, d->b, d->min_normlen, wdf_ub, idx->hdr.doclen_lower_bound) : 0.0, tf_local[t]);
+        if (x >= 0) out->group_of[t] = (uint8_t)pl[x].group;
+        return x;
+    }
+    int synonym(const std::vector<int>& terms, double factor) {
+        const bool weighted = factor != 0.0;
+        uint32_t est = 0, tf_syn = 0;
+        if (db_size) {
+            const double scale = 1.0 / db_size;
+            double P = tf_local[terms[0]] * scale;
+            for (size_t i = 1; i < terms.size(); ++i) { const double Pi = tf_local[terms[i]] * scale; P += Pi - P * Pi; }
+            est = (uint32_t)(P * db_size + 0.5);
+        }
+        if (N) {
+            const double scale = 1.0 / N;
+            double P = tf_global[terms[0]] * scale;
+            for (size_t i = 1; i < terms.size(); ++i) { const double Pi = tf_global[terms[i]] * scale; P += Pi - P * Pi; }
+            tf_syn = (uint32_t)(P * N + 0.5);
+        }
+        const double w = bm25_termweight(N, tf_syn, d->k1, d->k3, 1u, factor);
+        /* Weight::init_ (synonym case, weight.cc:86-115): the wdf bound of a synonym is the doclength upper bound */
+        const int x = new_group(weighted ? w : 0.0, weighted,
+                                weighted ? bm25_maxpart(w, len_factor, d->k1, d->b, d->min_normlen, idx->hdr.doclen_upper_bound, idx->hdr.doclen_lower_bound) : 0.0, est);
+        if (x >= 0) for (int t : terms) out->group_of[t] = (uint8_t)pl[x].group;
+        return x;
+    }
+    int mand(const std::vector<int>& ctx) {
+        PNode n; n.type = P_MAND;
+        std::vector<Leaf> in(ctx.size()), sorted(ctx.size());
+        for (size_t i = 0; i < ctx.size(); ++i) in[i] = Leaf{pl[ctx[i]].est, (uint32_t)i};
+        std::partial_sort_copy(in.begin(), in.end(), sorted.begin(), sorted.end(), TfAscending());
+        for (const Leaf& l : sorted) n.kids.push_back(ctx[l.idx]);
+        double r = pl[n.kids[0]].est;
+        for (size_t i = 1; i < n.kids.size(); ++i) r = (r * pl[n.kids[i]].est) / db_size;
+        n.est = db_size ? (uint32_t)(r + 0.5) : 0u;
+        double m = 0.0;
+        for (int k : n.kids) m += pl[k].maxw;
+        n.maxw = m;
+        return add(std::move(n));
+    }
+    int or2(int l, int r) {
+        PNode n; n.type = P_OR; n.kids = {l, r};
+        const double a = pl[l].est, b = pl[r].est, nn = db_size;
+        n.est = nn == 0.0 ? 0u : (uint32_t)(a + b - (a * b / nn) + 0.5);
+        n.maxw = pl[l].maxw + pl[r].maxw;
+        return add(std::move(n));
+    }
+    int or_tree(const std::vector<int>& ctx) {
+        if (ctx.empty()) return -1;
+        if (ctx.size() == 1) return ctx[0];
+        std::vector<HeapItem> heap;
+        for (int c : ctx) heap.push_back(HeapItem{pl[c].est, c});
+        heap_make(heap);
+        while (true) {
+            HeapItem r = heap.front();
+            heap_pop(heap);
+            HeapItem l = heap.front();
+            const int id = or2(l.node, r.node);
+            if (heap.size() == 1) return id;
+            heap[0].node = id;
+            heap[0].tf = l.tf + r.tf;
+            heap_sift_down(heap, heap.size(), 0);
+        }
+    }
+    void sub_and_like(int a, std::vector<int>& ctx, double factor) {
+        const ANode& n = ast[a];
+        if (n.kind == XGM_T_AND) { for (int k : n.kids) sub_and_like(k, ctx, factor); return; }
+        if (n.kind == XGM_T_FILTER) { for (int k : n.kids) { sub_and_like(k, ctx, factor); factor = 0.0; } return; }
+        ctx.push_back(postlist(a, factor));
+    }
+    void sub_or_like(int a, std::vector<int>& ctx, double factor) {
+        const ANode& n = ast[a];
+        if (n.kind == XGM_T_OR) { for (int k : n.kids) sub_or_like(k, ctx, factor); return; }
+        ctx.push_back(postlist(a, factor));
+    }
+    int postlist(int a, double factor) {
+        if (rc) return -1;
+        const ANode& n = ast[a];
+        switch (n.kind) {
+        case XGM_T_TERM: return leaf(n.term, factor);
+        case XGM_T_SCALE: return postlist(n.kids[0], factor * n.scale);
+        case XGM_T_AND: { std::vector<int> ctx; sub_and_like(a, ctx, factor); return rc ? -1 : mand(ctx); }
+        case XGM_T_FILTER: { const int l = postlist(n.kids[0], factor); const int r = postlist(n.kids[1], 0.0); return rc ? -1 : mand({l, r}); }
+        case XGM_T_OR: { std::vector<int> ctx; sub_or_like(a, ctx, factor); return rc ? -1 : or_tree(ctx); }
+        case XGM_T_AND_NOT: {
+            const int l = postlist(n.kids[0], factor);
+            std::vector<int> ctx;
+            for (size_t i = 1; i < n.kids.size(); ++i) sub_or_like(n.kids[i], ctx, 0.0);
+            if (rc) return -1;
+            const int r = or_tree(ctx);
+            PNode p; p.type = P_ANDNOT; p.kids = {l, r};
+            double e = pl[l].est;
+            e = (e * (db_size - (double)pl[r].est)) / db_size;
+            p.est = db_size ? (uint32_t)(e + 0.5) : 0u;
+            p.maxw = pl[l].maxw;
+            return add(std::move(p));
+        }
+        case XGM_T_AND_MAYBE: {
+            const int l = postlist(n.kids[0], factor);
+            if (factor == 0.0) return l;
+            std::vector<int> ctx;
+            for (size_t i = 1; i < n.kids.size(); ++i) sub_or_like(n.kids[i], ctx, factor);
+            if (rc) return -1;
+            const int r = or_tree(ctx);
+            PNode p; p.type = P_MAYBE; p.kids = {l, r}; p.est = pl[l].est; p.maxw = pl[l].maxw + pl[r].maxw;
+            return add(std::move(p));
+        }
+        case XGM_T_SYNONYM: {
+            std::vector<int> terms;
+            for (int k : n.kids) terms.push_back(ast[k].term);
+            if (terms.size() == 1) return leaf(terms[0], factor);          /* QuerySynonym::done */
+            return synonym(terms, factor);
+        }
+        }
+        rc = XGM_UNSUPPORTED;
+        return -1;
+    }
+    /* lowered tree → the device's binary nodes, children first; returns the operand id */
+    int emit(int x) {
+        PNode& n = pl[x];
+        if (n.dev >= 0) return n.dev;
+        if (n.type == P_GROUP) return n.dev = n.group;
+        auto node = [&](int op, int a, int b) {
+            if (out->tree_len >= XGM_MAX_TREE) { rc = XGM_UNSUPPORTED; return 0; }
+            const uint32_t j = out->tree_len++;
+            out->tree_op[j] = (uint8_t)op; out->tree_a[j] = (uint8_t)a; out->tree_b[j] = (uint8_t)b;
+            return (int)(XGM_MAX_TERMS + j);          /* provisional id: nodes are renumbered to n_groups + j at the end */
+        };
+        if (n.type == P_MAND) {
+            int acc = emit(n.kids[0]);                /* 0.0 + w0 == w0 exactly */
+            for (size_t i = 1; i < n.kids.size(); ++i) acc = node(XGM_N_AND, acc, emit(n.kids[i]));
+            return n.dev = acc;
+        }
+        const int a = emit(n.kids[0]), b = emit(n.kids[1]);
+        return n.dev = node(n.type == P_OR ? XGM_N_OR : n.type == P_ANDNOT ? XGM_N_ANDNOT : XGM_N_MAYBE, a, b);
+    }
+};
+
+int plan_tree(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_stats* gs, xgm_query* out) {
+    const uint32_t n = d->n_terms;
+    if (n == 0 || n > XGM_MAX_TERMS || d->n_tree == 0 || d->n_tree > XGM_MAX_TREE) return XGM_UNSUPPORTED;
+    TreePlanner tp;
+    tp.idx = idx; tp.d = d; tp.gs = gs; tp.out = out;
+    /* post-order program → AST (QueryAndLike / OrLike::done: one subquery is that subquery) */
+    std::vector<int> stack;
+    for (uint32_t i = 0; i < d->n_tree; ++i) {
+        ANode nd; nd.kind = d->tree[i].kind;
+        if (nd.kind == XGM_T_TERM) {
+            if (d->tree[i].term >= n || tp.used[d->tree[i].term]) return XGM_UNSUPPORTED;     /* a term twice: wqf merging / shared postlists */
+            tp.used[d->tree[i].term] = true;
+            nd.term = d->tree[i].term;
+        } else {
+            const uint32_t ar = nd.kind == XGM_T_SCALE ? 1u : d->tree[i].arity;
+            if (nd.kind > XGM_T_SCALE || ar == 0 || stack.size() < ar) return xgm_set_error(XGM_E_INVALID, "malformed query tree");
+            if (nd.kind == XGM_T_FILTER && ar != 2) return xgm_set_error(XGM_E_INVALID, "FILTER takes two subqueries");
+            if ((nd.kind == XGM_T_AND_NOT || nd.kind == XGM_T_AND_MAYBE) && ar < 2) return xgm_set_error(XGM_E_INVALID, "AND_NOT / AND_MAYBE take a left and a right side");
+            nd.kids.assign(stack.end() - ar, stack.end());
+            stack.resize(stack.size() - ar);
+            if (nd.kind == XGM_T_SCALE) { nd.scale = d->tree_scale[i]; if (!(nd.scale > 0.0)) return XGM_UNSUPPORTED; }   /* a zero scale makes the subtree boolean */
+            if (nd.kind == XGM_T_SYNONYM) for (int k : nd.kids) if (tp.ast[k].kind != XGM_T_TERM) return XGM_UNSUPPORTED;
+        }
+        tp.ast.push_back(nd);
+        stack.push_back((int)tp.ast.size() - 1);
+        if ((nd.kind == XGM_T_AND || nd.kind == XGM_T_OR) && nd.kids.size() == 1) stack.back() = nd.kids[0];
+    }
+    if (stack.size() != 1) return xgm_set_error(XGM_E_INVALID, "malformed query tree");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!d->terms[i] || d->term_len[i] == 0 || !tp.used[i]) return XGM_UNSUPPORTED;
+        for (uint32_t j = 0; j < i; ++j)
+            if (d->term_len[i] == d->term_len[j] && memcmp(d->terms[i], d->terms[j], d->term_len[i]) == 0) return XGM_UNSUPPORTED;
+    }
+    tp.N = gs ? gs->collection_size : idx->hdr.doccount;
+    tp.db_size = idx->hdr.doccount;
+    tp.len_factor = out->len_factor;
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t id = UINT32_MAX;
+        xgm_lookup_term_id(idx, d->terms[i], d->term_len[i], &id);
+        tp.local_id[i] = id;
+        tp.tf_local[i] = id == UINT32_MAX ? 0u : idx->term_df[id];
+        tp.tf_global[i] = gs ? gs->termfreq[i] : tp.tf_local[i];
+        if (tp.tf_global[i] < tp.tf_local[i] || tp.tf_global[i] > tp.N) return xgm_set_error(XGM_E_INVALID, "inconsistent global statistics");
+        out->terms[i].term_id = id;
+        out->terms[i].phrase_index = i;
+    }
+    out->op = XGM_OP_TREE;
+    out->n_terms = n;
+    const int root = tp.postlist(stack[0], 1.0);
+    if (tp.rc) return tp.rc;
+    const int dev_root = tp.emit(root);
+    if (tp.rc) return tp.rc;
+    /* renumber the provisional node ids now that the number of groups is known */
+    const uint32_t G = out->n_groups;
+    auto fix = [&](int x) { return (uint8_t)(x >= (int)XGM_MAX_TERMS ? G + (uint32_t)(x - (int)XGM_MAX_TERMS) : (uint32_t)x); };
+    for (uint32_t j = 0; j < out->tree_len; ++j) { out->tree_a[j] = fix(out->tree_a[j]); out->tree_b[j] = fix(out->tree_b[j]); }
+    out->tree_root = fix(dev_root);
+    out->max_possible = tp.pl[root].maxw;
+    for (uint32_t i = 0; i < n; ++i) out->terms[i].termweight = out->group_weight[out->group_of[i]];
+    return XGM_OK;
+}
+
 }  // namespace
 
 extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_stats* gs, xgm_query* out) {
     if (!idx || !d || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
     memset(out, 0, sizeof *out);
     const uint32_t n = d->n_terms;
-    if (d->op < XGM_OP_AND || d->op > XGM_OP_NEAR) return XGM_UNSUPPORTED;
+    if (d->op < XGM_OP_AND || d->op > XGM_OP_TREE) return XGM_UNSUPPORTED;
     if (n == 0 || n > XGM_MAX_TERMS) return XGM_UNSUPPORTED;
+    const bool is_tree = d->op == XGM_OP_TREE;
     /* AND_NOT / AND_MAYBE / FILTER: left = AND of the first nr terms, right = the others
      * (QueryAndNot / QueryAndMaybe / QueryFilter::postlist, api/queryinternal.cc:2208-2283) */
     const bool sided = d->op == XGM_OP_AND_NOT || d->op == XGM_OP_AND_MAYBE || d->op == XGM_OP_FILTER;
@@ -129,7 +364,7 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     if (d->k2 != 0.0) return XGM_UNSUPPORTED;          /* would need ExtraWeightPostList (localsubmatch.cc:183-193) */
     if (!(d->k1 >= 0.0) || !(d->b >= 0.0 && d->b <= 1.0) || !(d->k3 >= 0.0) || !(d->min_normlen >= 0.0))
         return xgm_set_error(XGM_E_INVALID, "bad BM25 parameters");
-    for (uint32_t i = 0; i < n; ++i) {
+    for (uint32_t i = 0; i < n && !is_tree; ++i) {
         if (!d->terms[i] || d->term_len[i] == 0) return XGM_UNSUPPORTED;     /* empty term = MatchAll */
         for (uint32_t j = 0; j < i; ++j)
             if (d->term_len[i] == d->term_len[j] && memcmp(d->terms[i], d->terms[j], d->term_len[i]) == 0)
@@ -168,6 +403,8 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         out->len_factor = avg != 0 ? 1 / avg : 0;
     }
 
+    if (is_tree) return plan_tree(idx, d, gs, out);
+
     uint32_t local_id[XGM_MAX_TERMS], local_tf[XGM_MAX_TERMS];
     double tw[XGM_MAX_TERMS], maxpart[XGM_MAX_TERMS];
     bool wide_needed = false;
@@ -178,7 +415,7 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         local_tf[i] = id == UINT32_MAX ? 0u : idx->term_df[id];
         uint32_t global_tf = gs ? gs->termfreq[i] : local_tf[i];
         if (global_tf < local_tf[i] || global_tf > collection_size) return xgm_set_error(XGM_E_INVALID, "inconsistent global statistics");
-        tw[i] = bm25_termweight(collection_size, global_tf, d->k1, d->k3);
+        tw[i] = bm25_termweight(collection_size, global_tf, d->k1, d->k3, d->wqf[i] ? d->wqf[i] : 1u);
         uint32_t wdf_ub = id == UINT32_MAX ? 0u : idx->term_wdfub[id];
         maxpart[i] = bm25_maxpart(tw[i], out->len_factor, d->k1, d->b, d->min_normlen, wdf_ub, idx->hdr.doclen_lower_bound);
         (void)wide_needed;

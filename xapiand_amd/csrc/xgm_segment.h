@@ -64,7 +64,7 @@ typedef struct {
     char magic[8];
     uint32_t version, stripe_bits, block_size, n_terms;
     uint32_t lastdocid, doccount, has_positions, doclen_lower_bound;
-    uint32_t wdf_upper_bound, reserved0;
+    uint32_t wdf_upper_bound, doclen_upper_bound;    /* (doclen_upper_bound: the wdf bound of an OP_SYNONYM, weight.cc:86-115) */
     uint64_t total_length, revision, n_postings, n_positions, n_blocks, n_words;
     uint64_t file_bytes;
     uint64_t sec_off[XGM_S_COUNT];     /* byte offset from the start of the blob, 256-B aligned   */

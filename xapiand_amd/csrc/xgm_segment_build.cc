@@ -125,11 +125,13 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
 
     /* DB-wide bounds the way glass tracks them (reference glass_version.h:252-270):
      * doclen lower bound = smallest non-zero length, wdf upper bound = largest wdf. */
-    uint32_t doclen_lb = 0, wdf_ub_db = 0;
+    uint32_t doclen_lb = 0, doclen_ub = 0, wdf_ub_db = 0;
     for (uint64_t d = 1; d <= raw->lastdocid; ++d) {
         uint32_t l = raw->doclen[d];
         if (l && (doclen_lb == 0 || l < doclen_lb)) doclen_lb = l;
+        doclen_ub = std::max(doclen_ub, l);
     }
+    if (raw->doclen_upper_bound > doclen_ub) doclen_ub = raw->doclen_upper_bound;
     for (uint64_t i = 0; i < raw->n_postings; ++i) wdf_ub_db = std::max(wdf_ub_db, raw->wdf[i]);
     /* the backend's own (looser) bounds win when given: they are what the reference's BM25Weight sees */
     if (raw->doclen_lower_bound && (doclen_lb == 0 || raw->doclen_lower_bound <= doclen_lb)) doclen_lb = raw->doclen_lower_bound;
@@ -232,6 +234,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
     h.doccount = raw->doccount;
     h.has_positions = has_pos ? 1u : 0u;
     h.doclen_lower_bound = doclen_lb;
+    h.doclen_upper_bound = doclen_ub;
     h.wdf_upper_bound = wdf_ub_db;
     h.total_length = raw->total_length;
     h.revision = raw->revision;

@@ -302,7 +302,7 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
     DevBuf d_thr, d_r2s, d_len64, d_tokstart, d_keys, d_keys2, d_tmp, d_flag, d_pidx, d_psid, d_pdoc, d_ptok, d_wdf, d_tps, d_mark,
         d_bflag, d_bidx, d_blkp, d_nwords, d_goff, d_has, d_newid, d_pblk, d_scalar;
     uint64_t n_tok = 0, n_post = 0, n_blk = 0, n_words = 0;
-    uint32_t T = 0, wdf_ub_db = 0, doclen_lb = 0, overflow = 0;
+    uint32_t T = 0, wdf_ub_db = 0, doclen_lb = 0, doclen_ub = 0, overflow = 0;
     uint64_t total_len = 0;
     void** S = idx->d_sections;
 
@@ -331,6 +331,12 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
         uint64_t mn = 0;
         SY_TRY(hipMemcpy(&mn, d_scalar.p, 8, hipMemcpyDeviceToHost));
         doclen_lb = (uint32_t)mn;
+        /* max document length (the wdf bound of an OP_SYNONYM) */
+        SY_TRY(hipcub::DeviceReduce::Max(nullptr, bytes, d_len64.as<uint64_t>(), d_scalar.as<uint64_t>(), (int)n_local));
+        SY_TRY(d_tmp.alloc(bytes));
+        SY_TRY(hipcub::DeviceReduce::Max(d_tmp.p, bytes, d_len64.as<uint64_t>(), d_scalar.as<uint64_t>(), (int)n_local));
+        SY_TRY(hipMemcpy(&mn, d_scalar.p, 8, hipMemcpyDeviceToHost));
+        doclen_ub = (uint32_t)mn;
     }
     if (n_tok >= 0x7FFFFFFFull) { rc = xgm_set_error(XGM_E_INVALID, "shard too large for the synthetic builder (%llu tokens)", (unsigned long long)n_tok); goto fail; }
     d_len64.reset();
@@ -489,6 +495,7 @@ extern "C" int xgm_index_build_synthetic(const xgm_synth_params* sp, int device,
         memcpy(h.magic, XGM_SEG_MAGIC, 8);
         h.version = XGM_SEG_VERSION; h.stripe_bits = sb; h.block_size = XGM_BLOCK; h.n_terms = T;
         h.lastdocid = n_local; h.doccount = n_local; h.has_positions = (uint32_t)with_pos; h.doclen_lower_bound = doclen_lb;
+        h.doclen_upper_bound = doclen_ub;
         h.wdf_upper_bound = wdf_ub_db; h.total_length = total_len; h.revision = 1; h.n_postings = n_post;
         h.n_positions = with_pos ? n_tok : 0; h.n_blocks = n_blk; h.n_words = n_words;
         uint64_t* sz = h.sec_bytes;

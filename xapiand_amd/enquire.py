@@ -73,11 +73,41 @@ class Query:
                 raise ValueError("n_required must leave terms on both sides")
             self.n_required = n_required
 
+    # -- nested queries ---------------------------------------------------------------------------------------------
+    _T = {"AND": 1, "OR": 2, "AND_NOT": 3, "AND_MAYBE": 4, "FILTER": 5, "SYN": 6, "SYNONYM": 6, "SCALE": 7}
+
+    @classmethod
+    def tree(cls, spec):
+        """A nested query from tuples: "term" | ("term", wqf) | ("AND", q, q, ...) | ("OR", ...) | ("SYNONYM", term, ...) |
+        ("AND_NOT", left, right...) | ("AND_MAYBE", left, right...) | ("FILTER", left, right) | ("SCALE", factor, q) —
+        the Xapian::Query trees Xapiand's DSL builds (reference src/query_dsl.cc:188-432), lowered by xgm_plan_query like
+        src/xapian/api/queryinternal.cc does."""
+        q = cls.__new__(cls)
+        q.op, q.terms, q.window, q.n_required = "TREE", [], 0, 0
+        q.wqf, q.ops = [], []
+
+        def walk(t):
+            if isinstance(t, (str, bytes)) or (len(t) == 2 and isinstance(t[1], int) and t[0] not in cls._T):
+                name, w = (t, 1) if isinstance(t, (str, bytes)) else t
+                q.terms.append(_as_bytes(name)); q.wqf.append(w)
+                q.ops.append((0, 0, len(q.terms) - 1, 1.0))
+                return
+            if t[0] == "SCALE":
+                walk(t[2])
+                q.ops.append((7, 1, 0, float(t[1])))
+                return
+            for k in t[1:]:
+                walk(k)
+            q.ops.append((cls._T[t[0]], len(t) - 1, 0, 1.0))
+        walk(spec)
+        return q
+
     def get_type(self):
         return self.op
 
     def total_subqs(self):
-        """Weighted leaves of the query = what QueryOptimiser::inc_total_subqs counts (reference
+        """(flat shapes; a nested query's count comes back in its plan: xgm_query.total_subqs)
+        Weighted leaves of the query = what QueryOptimiser::inc_total_subqs counts (reference
         src/xapian/api/queryinternal.cc:1049-1056): unweighted sides (AND_NOT, FILTER) do not count."""
         if self.op in (Query.OP_AND_NOT, Query.OP_FILTER):
             return self.n_required
@@ -282,6 +312,16 @@ def _desc(query, first, maxitems, check_at_least, weight):
     d = _lib.QueryDesc()
     if query.op == Query.LEAF_TERM:
         d.op = _lib.XGM_OP_AND
+    elif query.op == "TREE":
+        d.op = _lib.XGM_OP_TREE
+        if len(query.ops) > _lib.XGM_MAX_TREE:
+            raise Unsupported("query tree too large")
+        d.n_tree = len(query.ops)
+        for i, (kind, arity, term, scale) in enumerate(query.ops):
+            d.tree[i].kind, d.tree[i].arity, d.tree[i].term = kind, arity, term
+            d.tree_scale[i] = scale
+        for i, w in enumerate(query.wqf):
+            d.wqf[i] = w
     else:
         d.op = Query._OPS[query.op]
     if n > _lib.XGM_MAX_TERMS:
@@ -350,7 +390,7 @@ class Enquire:
             return MSet(first, [], _lib.ResultHdr(), 0)
         p = plan(self._db, self._query, first, maxitems, check_at_least, self._weight)
         (hits, hdr), = search_batch(self._db, [p])
-        return MSet(p.first, hits, hdr, self._query.total_subqs())
+        return MSet(p.first, hits, hdr, p.total_subqs if self._query.op == "TREE" else self._query.total_subqs())
 
 
 def merged_stats(dbs, query):
