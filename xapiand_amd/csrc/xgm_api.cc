@@ -615,7 +615,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         /* AND visits only stripes where the rarest term has postings */
         const double stripes = qs[i].op == XGM_OP_OR ? n_stripes : std::min<double>(n_stripes, min_df);
         const double cand_per_stripe = all_dense ? Wd * dens : (stripes > 0 ? min_df / stripes : 0.0);
-        cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + 0.03 * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
+        /* a candidate of a positional query costs a 64-byte sector per term, its positions and the predicate on top of the probe */
+        static const double phrase_cand = getenv("XGM_PHRASE_CAND_COST") ? atof(getenv("XGM_PHRASE_CAND_COST")) : 0.25;
+        const double per_cand = bp->phrase ? phrase_cand : 0.03;
+        cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + per_cand * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
         if (bp->orw) {
             /* every stripe: the terms' bitmaps / block decodes (twice where candidates remain) and a
              * share of the union that survives the MaxScore pruning */
