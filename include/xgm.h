@@ -277,7 +277,13 @@ typedef struct {
     uint8_t group_of[XGM_MAX_TERMS];
     double group_weight[XGM_MAX_TERMS];
     uint8_t tree_op[XGM_MAX_TREE], tree_a[XGM_MAX_TREE], tree_b[XGM_MAX_TREE];
+    /* PostList::get_termfreq_min / _est / _max of the tree the reference builds for this query on this shard — the
+     * static inputs of MSet::get_matches_lower_bound / _estimated / _upper_bound (protomset.h:484-619; xgm_mset_bounds) */
+    uint32_t est_min, est_est, est_max;
+    uint32_t reserved2;
 } xgm_query;
+
+
 #define XGM_N_AND 1
 #define XGM_N_OR 2
 #define XGM_N_ANDNOT 3
@@ -305,6 +311,14 @@ typedef struct {
     double max_attained;         /* weight of the best doc, 0 if none                              */
     double max_possible;
 } xgm_result_hdr;                /* 32 bytes                                                        */
+
+/* MSet::get_matches_lower_bound / _estimated / _upper_bound as ProtoMSet::finalise derives them (protomset.h:484-619, no
+ * collapsing / decider / percent cut-off) from the plan's static bounds and the search result.  The reference's
+ * known_matching_docs — how many documents its matcher happened to weigh before pruning — depends on its traversal and is
+ * not reproduced: the number of documents RETURNED stands in for it (never larger), so the upper bound is the reference's,
+ * the estimate is the reference's whenever its static estimate dominates (the common case), and the lower bound is valid
+ * but may be looser.  The exact count is in hdr->matches_exact. */
+void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper);
 
 /* One query on one shard: hits[0 .. first+maxitems) sorted by (weight desc, docid asc) — the order
  * of msetcmp_by_relevance<true> (reference src/xapian/matcher/msetcmp.cc:55-62); the caller drops

@@ -241,8 +241,12 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         percent_scale = hdr.max_weight_subqs_matched / double(L.total_subqs);
         percent_scale /= hdr.max_attained;
     }
-    const Xapian::doccount m = (Xapian::doccount)hdr.matches_exact;
-    out = Xapian::MSet(new Xapian::MSet::Internal(first, m, m, m, m, m, m, hdr.max_possible, hdr.max_attained, std::move(items),
+    /* bounds and estimate as ProtoMSet::finalise derives them from the tree's static termfreq bounds (xgm_mset_bounds: the
+     * upper bound is the reference's; the lower bound and the estimate use the number of documents returned where the
+     * reference uses how many its matcher happened to weigh — DESIGN.md) */
+    uint32_t lb = 0, est = 0, ub = 0;
+    xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
+    out = Xapian::MSet(new Xapian::MSet::Internal(first, ub, lb, est, ub, lb, est, hdr.max_possible, hdr.max_attained, std::move(items),
                                                    percent_scale * 100.0));
     ++g_answered;
     return true;

@@ -92,3 +92,40 @@ def test_host_only_index_cannot_search(host_env):
     with pytest.raises(_lib.XgmError) as e:
         search_batch(db1, [p])
     assert e.value.code == _lib.XGM_E_NO_DEVICE
+
+
+def test_static_match_bounds_equal_the_references(built, tmp_path):
+    """The planner's get_termfreq_min / _est / _max of the tree the reference would build: the UPPER bound
+    of every MSet equals the compiled reference's for all operators and nested trees, the static lower bound never
+    exceeds the reference's (which adds the documents its matcher happened to weigh), and xgm_mset_bounds keeps
+    lower <= estimate <= upper."""
+    import ctypes as C
+    if not H.have_xapian_ref():
+        pytest.skip("oracle/_ref not built")
+    n_docs, vocab = 12000, 20000
+    db = str(tmp_path / "db")
+    H.xapian_ref("build", db, hex(H.CORPUS_SEED), n_docs, vocab, 50, 150)
+    c = H.Corpus(n_docs, vocab)
+    hdb = Database(c.build_segment(str(tmp_path / "c.seg")), device=_lib.XGM_DEVICE_NONE)
+    qs = (H.gen_term_queries("AND", 30, 3, 1, 200, maxitems=10, seed=1) + H.gen_term_queries("OR", 30, 4, 1, 2000, maxitems=10, seed=3) +
+          H.gen_sided_queries("AND_NOT", 12, 2, 2, 1, 100, seed=4) + H.gen_sided_queries("AND_MAYBE", 12, 2, 2, 1, 100, seed=5) +
+          H.gen_sided_queries("FILTER", 12, 2, 2, 1, 100, seed=6) + H.gen_phrase_queries(16, n_docs, vocab, seed=7) +
+          H.gen_phrase_queries(8, n_docs, vocab, seed=9, window_extra=3, op="NEAR") + H.gen_tree_queries(48, 1, 300, seed=10))
+    qf, of = str(tmp_path / "q.txt"), str(tmp_path / "o.txt")
+    H.write_queries(qf, qs)
+    H.xapian_ref("query", qf, of, db)
+    n_full = 0
+    for q, r in zip(qs, H.parse_ref_output(of)):
+        pq = Query.tree(q["tree"]) if q["op"] == "RPN" else Query(q["op"], q["terms"], window=q.get("window", 0), n_required=q.get("n_required", 0))
+        p = plan(hdb, pq, q["first"], q["maxitems"])
+        assert p.est_min <= p.est_est <= p.est_max, q
+        if r["n"] == q["maxitems"]:                      # a full MSet: the reference reports its tree's static upper bound
+            n_full += 1
+            assert p.est_max == r["ub"], (q, p.est_max, r["ub"])
+            assert p.est_min <= r["lb"], q
+        hdr = _lib.ResultHdr()
+        hdr.n_hits = r["n"]
+        lb, est, ub = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.lib().xgm_mset_bounds(C.byref(p), C.byref(hdr), C.byref(lb), C.byref(est), C.byref(ub))
+        assert lb.value <= est.value <= ub.value and lb.value <= r["lb"] and ub.value == r["ub"], (q, lb.value, est.value, ub.value, r)
+    assert n_full > 100

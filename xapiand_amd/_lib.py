@@ -78,7 +78,8 @@ class Query(C.Structure):
                 ("check_at_least", C.c_uint32), ("max_possible", C.c_double), ("req_mask", C.c_uint32), ("neg_mask", C.c_uint32),
                 ("tree_len", C.c_uint32), ("n_groups", C.c_uint32), ("tree_root", C.c_uint32), ("total_subqs", C.c_uint32),
                 ("group_scored", C.c_uint32), ("group_of", C.c_uint8 * XGM_MAX_TERMS), ("group_weight", C.c_double * XGM_MAX_TERMS),
-                ("tree_op", C.c_uint8 * XGM_MAX_TREE), ("tree_a", C.c_uint8 * XGM_MAX_TREE), ("tree_b", C.c_uint8 * XGM_MAX_TREE)]
+                ("tree_op", C.c_uint8 * XGM_MAX_TREE), ("tree_a", C.c_uint8 * XGM_MAX_TREE), ("tree_b", C.c_uint8 * XGM_MAX_TREE),
+                ("est_min", C.c_uint32), ("est_est", C.c_uint32), ("est_max", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
 class Hit(C.Structure):
@@ -110,6 +111,7 @@ _API = [
     ("xgm_lookup_term", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     ("xgm_index_termfreqs", C.c_int, [C.c_void_p, _P(C.c_uint32), C.c_uint32]),
     ("xgm_plan_query", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), _P(Query)]),
+    ("xgm_mset_bounds", None, [_P(Query), _P(ResultHdr), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     ("xgm_search", C.c_int, [C.c_void_p, _P(Query), _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch_device", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

@@ -114,6 +114,97 @@ double bm25_maxpart(double termweight, double len_factor, double k1, double b, d
 }
 
 
+/* ---- match-count bounds and estimate -------------------------------------------------------------------
+ * PostList::get_termfreq_min / _est / _max of the tree the reference would build, from the shard's own termfreqs —
+ * what Matcher::get_local_mset hands to ProtoMSet::finalise (matcher.cc:432-434, protomset.h:484-619):
+ * leafpostlist.cc:51-54, multiandpostlist.cc:55-105, orpostlist.cc:80-83, 353-384, andnotpostlist.cc:30-61,
+ * boolorpostlist.cc:44-52, 158-190, AndMaybe = its left side, Exact phrase / Phrase / Near = the AND's estimate / 4, / 3, / 2
+ * with a lower bound of 0 (exactphrasepostlist.cc:149-160, phrasepostlist.cc:108-114, nearpostlist.cc:203-210). */
+struct Est { uint32_t mn, est, mx; };
+
+Est est_leaf(uint32_t tf) { return Est{tf, tf, tf}; }
+
+Est est_mand(const std::vector<Est>& k, uint32_t db_size) {          /* kids in MultiAnd (plist) order */
+    Est r;
+    uint32_t sum = k[0].mn;
+    if (sum) {
+        for (size_t i = 1; i < k.size(); ++i) {
+            const uint32_t sum_old = sum;
+            sum += k[i].mn;
+            if (sum >= sum_old && sum <= db_size) { sum = 0; break; }
+            sum -= db_size;
+        }
+    }
+    r.mn = sum;
+    r.mx = k[0].mx;
+    for (size_t i = 1; i < k.size(); ++i) r.mx = std::min(r.mx, k[i].mx);
+    double e = k[0].est;
+    for (size_t i = 1; i < k.size(); ++i) e = (e * k[i].est) / db_size;
+    r.est = db_size ? (uint32_t)(e + 0.5) : 0u;
+    return r;
+}
+
+Est est_or(const Est& l, const Est& r, uint32_t db_size) {
+    Est o;
+    o.mn = std::max(l.mn, r.mn);
+    uint32_t mx = l.mx + r.mx;
+    if (mx > db_size || mx < l.mx) mx = db_size;
+    o.mx = mx;
+    const double a = l.est, b = r.est, n = db_size;
+    o.est = n == 0.0 ? 0u : (uint32_t)(a + b - (a * b / n) + 0.5);
+    return o;
+}
+
+Est est_andnot(const Est& l, const Est& r, uint32_t db_size) {
+    Est o;
+    o.mn = l.mn <= r.mx ? 0u : l.mn - r.mx;
+    o.mx = std::min(db_size - r.mn, l.mx);
+    double e = l.est;
+    e = (e * (db_size - (double)r.est)) / db_size;
+    o.est = db_size ? (uint32_t)(e + 0.5) : 0u;
+    return o;
+}
+
+Est est_boolor(const std::vector<Est>& k, uint32_t db_size) {        /* an OP_SYNONYM's BoolOrPostList, kids in query order */
+    Est o;
+    o.mn = k[0].mn;
+    for (size_t i = 1; i < k.size(); ++i) o.mn = std::max(o.mn, k[i].mn);
+    uint32_t mx = k[0].mx;
+    bool capped = false;
+    for (size_t i = 1; i < k.size() && !capped; ++i) {
+        const uint32_t old = mx;
+        mx += k[i].mx;
+        if (mx >= db_size || mx < old) { mx = db_size; capped = true; }
+    }
+    o.mx = mx;
+    if (!db_size) { o.est = 0; return o; }
+    const double scale = 1.0 / db_size;
+    double P = k[0].est * scale;
+    for (size_t i = 1; i < k.size(); ++i) { const double Pi = k[i].est * scale; P += Pi - P * Pi; }
+    o.est = (uint32_t)(P * db_size + 0.5);
+    return o;
+}
+
+/* the Huffman-shaped OrPostList tree over `leaves` (OrContext::postlist): its estimate triple */
+Est est_or_tree(const std::vector<Est>& leaves, uint32_t db_size) {
+    if (leaves.size() == 1) return leaves[0];
+    std::vector<Est> val(leaves);
+    std::vector<HeapItem> heap;
+    for (size_t i = 0; i < leaves.size(); ++i) heap.push_back(HeapItem{leaves[i].est, (int)i});
+    heap_make(heap);
+    while (true) {
+        HeapItem r = heap.front();
+        heap_pop(heap);
+        HeapItem l = heap.front();
+        val.push_back(est_or(val[(size_t)l.node], val[(size_t)r.node], db_size));
+        const int id = (int)val.size() - 1;
+        if (heap.size() == 1) return val[(size_t)id];
+        heap[0].node = id;
+        heap[0].tf = l.tf + r.tf;
+        heap_sift_down(heap, heap.size(), 0);
+    }
+}
+
 /* ---- nested queries (XGM_OP_TREE) ------------------------------------------------------------------------------------
  * The reference's Query → PostList lowering restated for trees (api/queryinternal.cc): QueryTerm / QueryScaleWeight
  * (:1049-1080: the factor multiplies down into BM25Weight::init), QueryAndLike::postlist_sub_and_like (:2083-2103: nested
@@ -124,7 +215,7 @@ double bm25_maxpart(double termweight, double len_factor, double k1, double b, d
  * boolorpostlist.cc:175-230. */
 struct ANode { int kind; std::vector<int> kids; int term = -1; double scale = 1.0; };
 enum { P_GROUP = 0, P_MAND, P_OR, P_ANDNOT, P_MAYBE };
-struct PNode { int type; std::vector<int> kids; int group = -1; uint32_t est = 0; double maxw = 0.0; int dev = -1; /* operand id on the device */ };
+struct PNode { int type; std::vector<int> kids; int group = -1; uint32_t est = 0; double maxw = 0.0; int dev = -1; /* operand id on the device */ Est e{0, 0, 0}; };
 
 struct TreePlanner {
     const xgm_index* idx; const xgm_query_desc* d; const xgm_global_stats* gs; xgm_query* out;
@@ -140,7 +231,7 @@ struct TreePlanner {
         const uint32_t g = out->n_groups++;
         out->group_weight[g] = weight;
         if (scored) { out->group_scored |= 1u << g; ++out->total_subqs; }
-        PNode n; n.type = P_GROUP; n.group = (int)g; n.est = est; n.maxw = maxw;
+        PNode n; n.type = P_GROUP; n.group = (int)g; n.est = est; n.maxw = maxw; n.e = Est{est, est, est};
         return add(std::move(n));
     }
     int leaf(int t, double factor) {
@@ -170,7 +261,12 @@ struct TreePlanner {
         /* Weight::init_ (synonym case, weight.cc:86-115): the wdf bound of a synonym is the doclength upper bound */
         const int x = new_group(weighted ? w : 0.0, weighted,
                                 weighted ? bm25_maxpart(w, len_factor, d->k1, d->b, d->min_normlen, idx->hdr.doclen_upper_bound, idx->hdr.doclen_lower_bound) : 0.0, est);
-        if (x >= 0) for (int t : terms) out->group_of[t] = (uint8_t)pl[x].group;
+        if (x >= 0) {
+            for (int t : terms) out->group_of[t] = (uint8_t)pl[x].group;
+            std::vector<Est> k;
+            for (int t : terms) k.push_back(est_leaf(tf_local[t]));
+            pl[x].e = est_boolor(k, db_size);
+        }
         return x;
     }
     int mand(const std::vector<int>& ctx) {
@@ -185,12 +281,15 @@ struct TreePlanner {
         double m = 0.0;
         for (int k : n.kids) m += pl[k].maxw;
         n.maxw = m;
+        std::vector<Est> ke;
+        for (int k : n.kids) ke.push_back(pl[k].e);
+        n.e = est_mand(ke, db_size);
         return add(std::move(n));
     }
     int or2(int l, int r) {
         PNode n; n.type = P_OR; n.kids = {l, r};
-        const double a = pl[l].est, b = pl[r].est, nn = db_size;
-        n.est = nn == 0.0 ? 0u : (uint32_t)(a + b - (a * b / nn) + 0.5);
+        n.e = est_or(pl[l].e, pl[r].e, db_size);
+        n.est = n.e.est;
         n.maxw = pl[l].maxw + pl[r].maxw;
         return add(std::move(n));
     }
@@ -242,6 +341,7 @@ struct TreePlanner {
             e = (e * (db_size - (double)pl[r].est)) / db_size;
             p.est = db_size ? (uint32_t)(e + 0.5) : 0u;
             p.maxw = pl[l].maxw;
+            p.e = est_andnot(pl[l].e, pl[r].e, db_size);
             return add(std::move(p));
         }
         case XGM_T_AND_MAYBE: {
@@ -251,7 +351,7 @@ struct TreePlanner {
             for (size_t i = 1; i < n.kids.size(); ++i) sub_or_like(n.kids[i], ctx, factor);
             if (rc) return -1;
             const int r = or_tree(ctx);
-            PNode p; p.type = P_MAYBE; p.kids = {l, r}; p.est = pl[l].est; p.maxw = pl[l].maxw + pl[r].maxw;
+            PNode p; p.type = P_MAYBE; p.kids = {l, r}; p.est = pl[l].est; p.maxw = pl[l].maxw + pl[r].maxw; p.e = pl[l].e;
             return add(std::move(p));
         }
         case XGM_T_SYNONYM: {
@@ -343,6 +443,7 @@ int plan_tree(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_st
     for (uint32_t j = 0; j < out->tree_len; ++j) { out->tree_a[j] = fix(out->tree_a[j]); out->tree_b[j] = fix(out->tree_b[j]); }
     out->tree_root = fix(dev_root);
     out->max_possible = tp.pl[root].maxw;
+    out->est_min = tp.pl[root].e.mn; out->est_est = tp.pl[root].e.est; out->est_max = tp.pl[root].e.mx;
     for (uint32_t i = 0; i < n; ++i) out->terms[i].termweight = out->group_weight[out->group_of[i]];
     return XGM_OK;
 }
@@ -530,6 +631,54 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
         out->max_possible = mp;
     }
 
+    /* match-count bounds / estimate of the tree the reference builds for this shape */
+    {
+        const uint32_t db = idx->hdr.doccount;
+        auto leaf_q = [&](uint32_t i) { return est_leaf(local_tf[i]); };           /* by QUERY index */
+        auto and_of = [&](uint32_t lo, uint32_t hi) {                              /* MultiAnd over plan positions [lo, hi) */
+            std::vector<Est> k;
+            for (uint32_t p = lo; p < hi; ++p) k.push_back(leaf_q(order[p]));
+            return k.size() == 1 ? k[0] : est_mand(k, db);
+        };
+        auto or_of = [&](uint32_t lo, uint32_t hi) {                               /* Huffman OR over query positions [lo, hi) */
+            std::vector<Est> k;
+            for (uint32_t i = lo; i < hi; ++i) k.push_back(leaf_q(i));
+            return est_or_tree(k, db);
+        };
+        Est e;
+        if (d->op == XGM_OP_OR) e = or_of(0, n);
+        else if (d->op == XGM_OP_AND_NOT) e = est_andnot(and_of(0, nr), or_of(nr, n), db);
+        else if (d->op == XGM_OP_AND_MAYBE) e = and_of(0, nr);
+        else if (d->op == XGM_OP_FILTER) {
+            /* QueryFilter::postlist: MultiAnd{l, r}, l and r being whole postlists (an inner MultiAnd each when they are ANDs) */
+            std::vector<Leaf> in, sorted;
+            std::vector<Est> sides;
+            {
+                std::vector<Est> k;
+                for (uint32_t p = 0; p < n; ++p) if (order[p] < nr) k.push_back(leaf_q(order[p]));      /* plan order restricted to the left side = its MultiAnd order */
+                sides.push_back(k.size() == 1 ? k[0] : est_mand(k, db));
+                std::vector<Leaf> rin, rs;
+                for (uint32_t i = nr; i < n; ++i) rin.push_back(Leaf{local_tf[i], i});
+                rs.resize(rin.size());
+                std::partial_sort_copy(rin.begin(), rin.end(), rs.begin(), rs.end(), TfAscending());
+                std::vector<Est> rk;
+                for (const Leaf& l : rs) rk.push_back(leaf_q(l.idx));
+                sides.push_back(rk.size() == 1 ? rk[0] : est_mand(rk, db));
+            }
+            in = {Leaf{sides[0].est, 0}, Leaf{sides[1].est, 1}};
+            sorted.resize(2);
+            std::partial_sort_copy(in.begin(), in.end(), sorted.begin(), sorted.end(), TfAscending());
+            e = est_mand({sides[sorted[0].idx], sides[sorted[1].idx]}, db);
+        } else {
+            e = and_of(0, n);
+            if (phrase_active) {
+                const uint32_t div = d->op == XGM_OP_NEAR ? 2u : (out->window == n ? 4u : 3u);
+                e.mn = 0; e.est /= div;
+            }
+        }
+        out->est_min = e.mn; out->est_est = e.est; out->est_max = e.mx;
+    }
+
     /* who must / must not index a matching document */
     out->req_mask = 0; out->neg_mask = 0;
     for (uint32_t p = 0; p < n; ++p) {
@@ -549,4 +698,22 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     }
     if (phrase_active && n > 8) return XGM_UNSUPPORTED;   /* XGM_PHRASE_MAX_TERMS: per-lane cursors of the positional filter */
     return XGM_OK;
+}
+
+extern "C" void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper) {
+    uint32_t lb = plan->est_min, est = plan->est_est, ub = plan->est_max;
+    const uint32_t want = plan->first + plan->maxitems;
+    if (hdr->n_hits < want) {
+        /* ProtoMSet not full: we got all there are (protomset.h:497-503) */
+        lb = est = ub = hdr->n_hits;
+    } else {
+        const uint32_t known = hdr->n_hits;                 /* stand-in for known_matching_docs (see xgm.h) */
+        if (known > lb) lb = known;
+        if (known > est) est = known;
+        if (est < lb) est = lb;
+        if (ub < est) ub = est;
+    }
+    if (lower) *lower = lb;
+    if (estimated) *estimated = est;
+    if (upper) *upper = ub;
 }

@@ -250,8 +250,13 @@ class MSet:
     """Mirror of Xapian::MSet for the fields the path produces.  matches_* are EXACT here (the
     reference estimates them, protomset.h:497-619) — documented parity exception."""
 
-    def __init__(self, first, hits, hdr, total_subqs):
+    def __init__(self, first, hits, hdr, total_subqs, plan=None):
         self._first = first
+        self._bounds = None
+        if plan is not None:
+            lb, est, ub = C.c_uint32(), C.c_uint32(), C.c_uint32()
+            _lib.lib().xgm_mset_bounds(C.byref(plan), C.byref(hdr), C.byref(lb), C.byref(est), C.byref(ub))
+            self._bounds = (lb.value, est.value, ub.value)
         # MSet::Internal percent_scale_factor, protomset.h:466-471 and :682
         if hdr.n_hits and hdr.max_attained != 0.0 and total_subqs:
             scale = hdr.max_weight_subqs_matched / float(total_subqs)
@@ -294,11 +299,19 @@ class MSet:
     def get_firstitem(self):
         return self._first
 
-    def get_matches_estimated(self):
+    def get_matches_exact(self):
+        """The exact number of matching documents (the reference only bounds and estimates it)."""
         return self._matches
 
-    get_matches_lower_bound = get_matches_estimated
-    get_matches_upper_bound = get_matches_estimated
+    def get_matches_estimated(self):
+        return self._bounds[1] if self._bounds else self._matches
+
+    def get_matches_lower_bound(self):
+        return self._bounds[0] if self._bounds else self._matches
+
+    def get_matches_upper_bound(self):
+        """Static bound of the postlist tree the reference would build: identical to Xapian's (xgm_mset_bounds)."""
+        return self._bounds[2] if self._bounds else self._matches
 
     def get_max_possible(self):
         return self._max_possible
@@ -390,7 +403,7 @@ class Enquire:
             return MSet(first, [], _lib.ResultHdr(), 0)
         p = plan(self._db, self._query, first, maxitems, check_at_least, self._weight)
         (hits, hdr), = search_batch(self._db, [p])
-        return MSet(p.first, hits, hdr, p.total_subqs if self._query.op == "TREE" else self._query.total_subqs())
+        return MSet(p.first, hits, hdr, p.total_subqs if self._query.op == "TREE" else self._query.total_subqs(), plan=p)
 
 
 def merged_stats(dbs, query):
