@@ -1,20 +1,43 @@
-# Round-end evidence run: tests, headline bench (+cpu baseline), rocprofv3 stats, HBM traffic PMC, C3/C5 side numbers
+# Round evidence run: usage tools/final.sh <tag>   (one MI355X, ~12 min)
+#   full GPU test suite; headline bench (C2: reference leg, server leg); rocprofv3 kernel stats; counter calibration; PMC passes
+#   (FETCH_SIZE, WRITE_SIZE, SQ) for the conjunction, disjunction and positional kernels → traffic entries; C3 / C5 / sided lines with parity
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
-timeout 900 python -m pytest tests -m gpu -q > gpurun_out/${tag}_pytest.log 2>&1; tail -1 gpurun_out/${tag}_pytest.log
-# HBM traffic first (bench.py reads profiles/traffic.json when present; this run refreshes the numbers)
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "xgm_andw" --output-format csv -d gpurun_out/${tag}_pmc_$c -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency > gpurun_out/${tag}_pmc_$c.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
+bash tools/calib.sh $tag > gpurun_out/${tag}_calib.out 2>&1; tail -11 gpurun_out/${tag}_calib.out
+: > gpurun_out/${tag}_traffic_entries.jsonl
+for w in "and3 andw" "or5 orw --op OR --terms 5 --topk 100" "phrase andw --op PHRASE --topk 10"; do
+  set -- $w; n=$1; rx=$2; shift 2
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_$c -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_$c.log 2>&1
+  done
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_SQ -- python bench.py --steps 6 --warmup 1 --no-cpu-baseline --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_SQ.log 2>&1
+  python tools/pmc_parse.py gpurun_out/${tag}_pmc_${n}_FETCH_SIZE gpurun_out/${tag}_pmc_${n}_WRITE_SIZE gpurun_out/${tag}_pmc_${n}_SQ > gpurun_out/${tag}_pmc_${n}.txt
+  timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-latency --threads 0 $* > gpurun_out/${tag}_model_${n}.json 2>/dev/null
+  python tools/traffic.py gpurun_out/${tag}_pmc_${n}.txt gpurun_out/${tag}_model_${n}.json xgm_$rx >> gpurun_out/${tag}_traffic_entries.jsonl
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_${n} -- python bench.py --steps 20 --no-cpu-baseline --no-latency --threads 0 $* > gpurun_out/${tag}_prof_${n}.log 2>&1
 done
-python tools/pmc_parse.py gpurun_out/${tag}_pmc_FETCH_SIZE gpurun_out/${tag}_pmc_WRITE_SIZE | tee gpurun_out/${tag}_pmc.txt
-timeout 400 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; python -c "import json;d=json.load(open('gpurun_out/${tag}_bench.json'));print('AND3',round(d['value']),d['ms_per_step'],d['roofline']['kernel_ms'],d['p50_latency_us'],d['roofline']['frac'],d['cpu_baseline']['value'])"
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof -- python bench.py --steps 20 --no-cpu-baseline --no-latency > gpurun_out/${tag}_prof.log 2>&1
-timeout 300 python bench.py --op OR --terms 5 --topk 100 --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_or5.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/${tag}_bench_or5.json'));print('OR5',round(d['value']),d['roofline']['kernel_ms'],d['p50_latency_us'],d['roofline']['frac'])"
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_or5 -- python bench.py --op OR --terms 5 --topk 100 --steps 10 --no-cpu-baseline --no-latency > gpurun_out/${tag}_prof_or5.log 2>&1
-timeout 300 python bench.py --op PHRASE --topk 10 --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_phrase.json 2>gpurun_out/${tag}_phrase.err; python -c "import json;d=json.load(open('gpurun_out/${tag}_bench_phrase.json'));print('PHRASE',round(d['value']),d['roofline']['kernel_ms'],d['p50_latency_us'],d['roofline']['frac'])"; tail -2 gpurun_out/${tag}_phrase.err
-timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_phrase -- python bench.py --op PHRASE --topk 10 --steps 6 --no-cpu-baseline --no-latency > gpurun_out/${tag}_prof_phrase.log 2>&1
-for a in "AND_NOT --terms 4 --required 2" "AND_MAYBE --terms 4 --required 2" "FILTER --terms 3 --required 2"; do
-  n=$(echo $a | cut -d" " -f1 | tr A-Z a-z)
-  timeout 300 python bench.py --op $a --steps 20 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_bench_$n.json 2>/dev/null; python -c "import json;d=json.load(open('gpurun_out/${tag}_bench_$n.json'));print('$n',round(d['value']),d['roofline']['kernel'],d['roofline']['kernel_ms'],d['p50_latency_us'],d['roofline']['frac'])"
+python - <<PY
+import json
+ents=[json.loads(l) for l in open('gpurun_out/${tag}_traffic_entries.jsonl')]
+json.dump({"entries":ents}, open('profiles/traffic.json','w'), indent=1)      # bench.py below quotes these
+json.dump({"entries":ents}, open('gpurun_out/${tag}_traffic.json','w'), indent=1)
+for e in ents: print('traffic',e['op'],e['kernel'],round(e['hbm_bytes_per_launch']/1e9,3),'GB/launch')
+PY
+timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err
+timeout 400 python bench.py --op OR --terms 5 --topk 100 --steps 20 --warmup 2 --ref-docs 0 --cpu-seconds 4 --threads 0 > gpurun_out/${tag}_bench_or5.json 2>gpurun_out/${tag}_or5.err
+timeout 400 python bench.py --op PHRASE --topk 10 --steps 10 --warmup 2 --ref-docs 0 --cpu-seconds 4 --threads 0 > gpurun_out/${tag}_bench_phrase.json 2>gpurun_out/${tag}_phrase.err
+for a in "AND_NOT --terms 4 --required 2" "AND_MAYBE --terms 4 --required 2" "FILTER --terms 3 --required 2" "AND --terms 2"; do
+  n=$(echo $a | tr -d '-' | tr ' ' '_' | tr A-Z a-z)
+  timeout 300 python bench.py --op $a --steps 20 --warmup 2 --ref-docs 0 --cpu-seconds 3 --threads 0 > gpurun_out/${tag}_bench_$n.json 2>gpurun_out/${tag}_$n.err
 done
-find gpurun_out/${tag}_prof* -name "*kernel_stats.csv" | head
+python - <<PY
+import json,glob
+for f in sorted(glob.glob('gpurun_out/${tag}_bench*.json')):
+    try:
+        d=json.load(open(f)); r=d['roofline']; c=d.get('cpu_baseline',{})
+        print(f.split('/')[-1],round(d['value']),r['kernel'],'kernel_ms',round(r['kernel_ms'],3),'p50',d['p50_latency_us'],'frac',round(r['frac'],3),r['basis'],'model',r['model_frac'] and round(r['model_frac'],3),'alg',round(r['algorithmic']['frac'],3),'parity',c.get('parity_checked_queries'),'cpu',c.get('kind'),c.get('value'))
+    except Exception as e: print(f,'failed',e)
+d=json.load(open('gpurun_out/${tag}_bench.json')); print(json.dumps(d.get('server_mode'))); print(json.dumps({k:v for k,v in d['cpu_baseline'].items() if k!='sample'})[:1500])
+PY
+find gpurun_out/${tag}_prof_* -name "*kernel_stats.csv" | head
