@@ -43,7 +43,10 @@
 
 namespace {
 
-constexpr uint32_t kOrwCand = 512;       /* candidates per scoring chunk: 4 lanes x 4 words x 32 slots */
+#ifndef XGM_ORW_CAND
+#define XGM_ORW_CAND 512
+#endif
+constexpr uint32_t kOrwCand = XGM_ORW_CAND;   /* candidates per scoring chunk */
 #ifndef XGM_ORW_REGSPARSE
 #define XGM_ORW_REGSPARSE 2
 #endif
@@ -61,7 +64,7 @@ constexpr uint32_t kHistShift = 47;      /* weight bits >> 47: sign, exponent, 5
 __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
     off += (size_t)cap * 8;                                    /* tk_w */
-    off += (size_t)T * 64 * 8;                                 /* val: per-lane leaf / node weights */
+    off += T > 8u ? (size_t)T * 64 * 8 : 0;                    /* val: per-lane leaf / node weights (queries of > 8 terms only: fewer sum in registers) */
     off += (size_t)cap * 4;                                    /* tk_d */
     off += (size_t)kStageWords * 4;                            /* stage */
     off += (size_t)(W / 32u) * 4 * 4;                          /* bm_all, bm_ess, bm_ne, bm_r */
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     unsigned char* base = smem + (size_t)wave * orw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG);
     size_t off = 0;
     uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
-    double* val = reinterpret_cast<double*>(base + off); off += (size_t)tab_terms * 64 * 8;
+    double* val = reinterpret_cast<double*>(base + off); off += tab_terms > 8u ? (size_t)tab_terms * 64 * 8 : 0;
     uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
     uint32_t* stage = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kStageWords * 4;
     uint32_t* bm_all = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
