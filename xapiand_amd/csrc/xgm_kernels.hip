@@ -1662,32 +1662,49 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     };
 
     uint32_t sl = next_active(0);
-    if (sl < n_local) issue_headers(sl);
-    while (sl < n_local) {
-        stripe_base = (s_begin + sl) << SB;
-        const uint32_t sl_next = next_active(sl + 1u);
-        hc_cur = hc_off;
-
-        if (td == 0u) {
-            /* ---- every term dense: candidates = AND of the containers' bitmaps (4 words per lane) ---- */
-            uint32_t m[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (td == 0u) {
+        /* ---- every required term dense: candidates = AND of the containers' bitmaps (one 16-byte load per lane and
+         * term).  Software pipeline, ONE exposed memory latency per stripe instead of three: the container offsets run two
+         * stripes ahead, the NEXT stripe's bitmaps are requested before this stripe's probes and ANDed after them, and the
+         * candidates' document lengths travel with their wdf probes (without a positional filter nearly every candidate
+         * of this path is a match). */
+        typedef uint32_t andw_u4 __attribute__((ext_vector_type(4)));
+        auto load_dir = [&](uint32_t x) {
+            uint32_t v = 0u;
+            if (TALLY) { cn_aux += T; }
+            if (lane < T && (!SIDED || dense_reg != 0xFFFFFFFFu)) v = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
+            return v;
+        };
+        auto load_bitmaps = [&](uint32_t hc, andw_u4 (&raw)[4]) {
             if (TALLY) { cn_bmpw += (TR < 4u ? TR : 4u) * NW; }
 #pragma unroll
             for (uint32_t t = 0; t < 4u; ++t) {
+                raw[t] = andw_u4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (t < TR) {
-                    const uint32_t* bmp = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc_cur, t) * 16);
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        const uint32_t w = lane * 4u + i;
-                        m[i] &= w < NW ? bmp[w] : 0u;
-                    }
+                    const andw_u4* bmp = reinterpret_cast<const andw_u4*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc, t) * 16);
+                    raw[t] = lane * 4u < NW ? bmp[lane] : andw_u4{0u, 0u, 0u, 0u};
                 }
             }
+        };
+        uint32_t sl1 = sl < n_local ? next_active(sl + 1u) : n_local;
+        uint32_t hcA = sl < n_local ? load_dir(sl) : 0u;
+        uint32_t hcB = sl1 < n_local ? load_dir(sl1) : 0u;
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+        if (sl < n_local) {
+            andw_u4 raw[4];
+            load_bitmaps(hcA, raw);
+            const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+        }
+        while (sl < n_local) {
+            stripe_base = (s_begin + sl) << SB;
+            hc_cur = hcA;
+            const uint32_t sl2 = sl1 < n_local ? next_active(sl1 + 1u) : n_local;
+            uint32_t hcC = 0u;                                         /* container offsets two stripes ahead: requested below */
             const uint32_t cnt = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
             uint32_t o = incl - cnt;                                   /* this lane's next ordinal */
-            if (sl_next < n_local) issue_headers(sl_next);             /* next stripe's offsets in flight (this stripe uses hc_cur) */
             const bool rhs_sparse = SIDED && sparse_neg != 0ull && n_total != 0u;
             unsigned long long coarse0 = 0ull;
             if (rhs_sparse) {
@@ -1702,30 +1719,113 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 coarse0 = __ballot((m[0] | m[1] | m[2] | m[3]) != 0u);      /* lane l owns words 4l..4l+3 = the 128 slots of bucket l */
                 wave_lds_fence();
             }
-            for (uint32_t lo = 0; lo < n_total; lo += CAND) {
+            const bool pre = sl1 < n_local;
+            uint32_t mn[4] = {0u, 0u, 0u, 0u};
+            /* the common stripe holds at most one round of candidates: their document lengths, their wdf bytes AND the next
+             * stripe's bitmaps are all requested before anything is waited for */
+            const bool one_round = !PHRASE && n_total <= 64u;
+            if (one_round) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
-                    while (m[i] && o < lo + CAND) {
+                    while (m[i]) {
                         const uint32_t bit = (uint32_t)__ffs(m[i]) - 1u;
-                        c_slot[o - lo] = (uint16_t)((lane * 4u + i) * 32u + bit);
+                        c_slot[o] = (uint16_t)((lane * 4u + i) * 32u + bit);
                         m[i] &= m[i] - 1u;
                         ++o;
                     }
                 }
                 wave_lds_fence();
+                const bool valid = lane < n_total;
+                const uint32_t slot = valid ? c_slot[lane] : 0u;
+                uint32_t wv[4] = {0u, 0u, 0u, 0u};
+                uint32_t wx[4] = {0u, 0u, 0u, 0u};
+                const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
+                if (TALLY) { if (n_total) { cn_dl += tally_sectors(valid, slot, 4u); cn_dl_raw += n_total; } }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t oo = __builtin_amdgcn_readlane(hcA, u);
+                    if (TALLY) { if (u < T && n_total && (!SIDED || oo)) { cn_probe += sec; cn_probe_raw += n_total; } }
+                    if (u < T && valid && (!SIDED || oo)) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+                }
+                if (SIDED) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const uint32_t oo = __builtin_amdgcn_readlane(hcA, 4u + u);
+                        if (TALLY) { if (4u + u < T && n_total && oo) { cn_probe += sec; cn_probe_raw += n_total; } }
+                        if (4u + u < T && valid && oo) wx[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+                    }
+                }
+                {
+                    andw_u4 raw[4];
+                    if (pre) load_bitmaps(hcB, raw);
+                    if (sl2 < n_local) hcC = load_dir(sl2);
+                    dl[0] = valid ? seg.doclen[stripe_base + slot] : 0u;       /* last: everything above is in flight by now */
+                    if (pre) {
+                        const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+                        mn[0] = a.x; mn[1] = a.y; mn[2] = a.z; mn[3] = a.w;
+                    }
+                }
+                if (valid) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) if (u < T) c_w[(size_t)u * CAND + lane] = (TabT)wv[u];
+                    if (SIDED) {
+#pragma unroll
+                        for (uint32_t u = 0; u < 4u; ++u) if (4u + u < T) c_w[(size_t)(4u + u) * CAND + lane] = (TabT)wx[u];
+                    }
+                }
+                wave_lds_fence();
+            } else {
+                if (sl2 < n_local) hcC = load_dir(sl2);
+            }
+            if (!one_round && pre) {
+                andw_u4 raw[4];
+                load_bitmaps(hcB, raw);
+                const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+                mn[0] = a.x; mn[1] = a.y; mn[2] = a.z; mn[3] = a.w;
+            }
+            for (uint32_t lo = 0; lo < n_total; lo += CAND) {
                 const uint32_t n_c = n_total - lo < CAND ? n_total - lo : CAND;
-                probe_dense(0u, n_c);
+                if (!one_round) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        while (m[i] && o < lo + CAND) {
+                            const uint32_t bit = (uint32_t)__ffs(m[i]) - 1u;
+                            c_slot[o - lo] = (uint16_t)((lane * 4u + i) * 32u + bit);
+                            m[i] &= m[i] - 1u;
+                            ++o;
+                        }
+                    }
+                    wave_lds_fence();
+                    if (!PHRASE) {
+                        /* document lengths of the first 256 candidates: requested with their probes */
+#pragma unroll
+                        for (uint32_t c = 0; c < 4u; ++c) {
+                            const uint32_t oc = lane + c * 64u;
+                            dl[c] = oc < n_c ? seg.doclen[stripe_base + c_slot[oc]] : 0u;
+                            if (TALLY) { cn_dl += tally_sectors(oc < n_c, oc < n_c ? (uint32_t)c_slot[oc] : 0u, 4u); }
+                        }
+                        if (TALLY) { cn_dl_raw += n_c < 256u ? n_c : 256u; }
+                    }
+                    probe_dense(0u, n_c);
+                }
                 if (rhs_sparse) scatter_sparse_rhs(sl, coarse0, lo);
-                score_candidates(n_c, false);
+                score_candidates(n_c, !PHRASE);
                 wave_lds_fence();
             }
             if (rhs_sparse) {
                 for (uint32_t i = lane; i < NW; i += 64u) { bitmap[i] = 0; rankw[i] = 0xFFFFu; }
                 wave_lds_fence();
             }
-            sl = sl_next;
-            continue;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) m[i] = mn[i];
+            sl = sl1; sl1 = sl2; hcA = hcB; hcB = hcC;
         }
+    }
+    if (td != 0u && sl < n_local) issue_headers(sl);
+    while (sl < n_local) {
+        stripe_base = (s_begin + sl) << SB;
+        const uint32_t sl_next = next_active(sl + 1u);
+        hc_cur = hc_off;
 
         const uint32_t r0 = rs[sl], r0e = re[sl];
         for (uint32_t cb = r0; cb < r0e; cb += CHUNKB) {
