@@ -38,6 +38,13 @@ def close(self):
         print("UNITS cycles/stripe mean", (dur / np.maximum(1, stripes)).mean(), "stripes/unit mean,max", stripes.mean(), stripes.max())
         print("UNITS matches", int(a[:, 6].sum()), "documents weighed (xgm_orw_kernel only)", int(a[:, 7].sum()),
               "ratio", float(a[:, 7].sum()) / max(1.0, float(a[:, 6].sum())))
+        # least-squares fit of the unit time: cycles = a * stripes + b * matches + c (the planner's cost model, xgm_api.cc)
+        A = np.stack([stripes, a[:, 6].astype(np.float64), np.ones(n)], axis=1)
+        coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+        print("UNITS fit cycles = %.1f * stripes + %.2f * matches + %.0f; residual rms %.0f" % (coef[0], coef[1], coef[2], float(np.sqrt(((A @ coef - dur) ** 2).mean()))))
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        np.save(os.path.join(out, "units_%s.npy" % os.environ.get("XGM_UNITS_TAG", "last")), a)
         order = np.argsort(-dur)[:5]
         print("UNITS slowest (qi, s_begin, s_end, cycles, start)", [(int(a[i, 0]), int(a[i, 1]), int(a[i, 2]), int(dur[i]), int(st[i])) for i in order])
     oc(self)

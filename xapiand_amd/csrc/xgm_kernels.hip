@@ -1300,10 +1300,6 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         for (uint32_t t = 0; t < T; ++t) {
             const uint32_t id = q.term_id[t];
             if (SIDED && id == 0xFFFFFFFFu) continue;              /* an excluded term the shard does not have */
-            const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
-            const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
-            const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
-            if (TALLY) { cn_aux += e - c; }
             if (lane == t) {
                 have_reg = true;
                 tbase_reg = seg.term_word[id];
@@ -1312,6 +1308,34 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                  * containers that carry the buckets' position bases (seg.dense_pos) */
                 if ((!PHRASE || seg.dense_pos) && sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
             }
+        }
+    }
+    /* Plan order is ascending termfreq and "dense" is a termfreq threshold, so the dense terms are a
+     * suffix [td, T).  td == 0: every term is dense → candidates come from the AND of the bitmaps.
+     * (With more than 4 terms term 0 is always decoded, to bound the registers of that path.) */
+    uint32_t td = (uint32_t)__popcll(__ballot(lane < TR && dense_reg == 0xFFFFFFFFu));
+    /* right-hand terms without containers are block-decoded against the candidates' bitmap + rank table (P3c): the
+     * decode path builds them while it enumerates term 0, the all-dense path writes them from the AND of the bitmaps */
+    const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;   /* right-hand terms without containers */
+    if (td == 0 && TR > 4u) td = 1;
+    /* the queue path (below): every term that takes part has containers and there is no positional filter — the unit
+     * never looks at a block, so the table holds the containers' offsets instead of block ranges */
+    const bool qpath = !PHRASE && !empty && td == 0u && sparse_neg == 0ull;
+    if (qpath) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t d = __builtin_amdgcn_readlane(dense_reg, t);
+            if (d == 0xFFFFFFFFu) continue;                        /* a right-hand term the shard does not have */
+            if (TALLY) { cn_aux += s_end - s_begin; }
+            for (uint32_t x = lane; x < s_end - s_begin; x += 64u) rs[t * SPG + x] = seg.dense_dir[(size_t)d * seg.n_stripes + (s_begin + x)];
+        }
+    } else if (!empty) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t id = q.term_id[t];
+            if (SIDED && id == 0xFFFFFFFFu) continue;
+            const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+            const uint32_t c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+            const uint32_t e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+            if (TALLY) { cn_aux += e - c; }
             for (uint32_t i = c + lane; i < e; i += 64u) {
                 const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
                 const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
@@ -1325,15 +1349,6 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     auto tbase = [&](uint32_t t) {
         return ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tbase_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tbase_reg, t);
     };
-    /* Plan order is ascending termfreq and "dense" is a termfreq threshold, so the dense terms are a
-     * suffix [td, T).  td == 0: every term is dense → candidates come from the AND of the bitmaps.
-     * (With more than 4 terms term 0 is always decoded, to bound the registers of that path.) */
-    uint32_t td = (uint32_t)__popcll(__ballot(lane < TR && dense_reg == 0xFFFFFFFFu));
-    /* right-hand terms without containers are block-decoded against the candidates' bitmap + rank table (P3c): the
-     * decode path builds them while it enumerates term 0, the all-dense path writes them from the AND of the bitmaps */
-    const uint64_t sparse_neg = SIDED ? __ballot(lane >= TR && lane < T && have_reg && dense_reg == 0xFFFFFFFFu) : 0ull;   /* right-hand terms without containers */
-    if (td == 0 && TR > 4u) td = 1;
-
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
     bool theta_valid = false;
     uint64_t theta_w = 0;
@@ -1449,6 +1464,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         wave_lds_fence();
     };
 
+    bool q_mode = false;                                           /* queue path: the round's docids are in q_did (one per lane) */
+    uint32_t q_did = 0;
     /* candidates present in every term are matches: BM25 + top-k, 64 per round; also clears c_w */
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
@@ -1533,7 +1550,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             if (o < n_c) {
                 if (pass) {
                     ++matches;
-                    did = stripe_base + c_slot[o];
+                    did = q_mode ? q_did : stripe_base + c_slot[o];
                     uint32_t dlen;
                     if (dl_ready && i0 < 256u) {
                         dlen = dl[0];
@@ -1661,8 +1678,122 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
         wave_lds_fence();
     };
 
-    uint32_t sl = next_active(0);
-    if (td == 0u) {
+    if (qpath) {
+        /* ---- queue path.  Every term that takes part has containers: per stripe only the AND of the bitmaps and the
+         * enumeration of its bits run; the candidates — (stripe, slot) pairs — queue up in LDS across stripes, and
+         * whenever 64 of them wait, ONE round probes their wdf bytes and document lengths (each lane its own stripe's
+         * containers) and weighs them with every lane busy.  At ~8 matches per stripe (C2) the per-stripe path spent
+         * most of its issue slots weighing 8 documents on 64 lanes.  The next stripe's bitmaps are requested before
+         * this stripe's bits are enumerated. */
+        typedef uint32_t andw_u4 __attribute__((ext_vector_type(4)));
+        uint32_t* ring = reinterpret_cast<uint32_t*>(c_slot);      /* CAND u16 = 256 u32 entries: (local stripe << 16) | slot */
+        constexpr uint32_t QCAP = CAND / 2u;
+        uint32_t pend = 0u, head = 0u;
+        auto next_q = [&](uint32_t from) {
+            uint32_t x = from;
+            for (; x < n_local; ++x) {
+                bool all = true;
+                for (uint32_t t = 0; t < TR; ++t) all = all && rs[t * SPG + x] != 0u;
+                if (all) break;
+            }
+            return x;
+        };
+        auto load_bitmaps = [&](uint32_t x, andw_u4 (&raw)[4]) {
+            if (TALLY) { cn_bmpw += (TR < 4u ? TR : 4u) * NW; }
+#pragma unroll
+            for (uint32_t t = 0; t < 4u; ++t) {
+                raw[t] = andw_u4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                if (t < TR) {
+                    const uint32_t off = XGM_SU(rs[t * SPG + x]);
+                    const andw_u4* bmp = reinterpret_cast<const andw_u4*>(seg.dense_data + (size_t)off * 16);
+                    raw[t] = lane * 4u < NW ? bmp[lane] : andw_u4{0u, 0u, 0u, 0u};
+                }
+            }
+        };
+        /* weigh the first n (<= 64) queued candidates */
+        auto round = [&](uint32_t n) {
+            const bool valid = lane < n;
+            const uint32_t e = valid ? ring[(head + lane) & (QCAP - 1u)] : 0u;
+            const uint32_t x = e >> 16, slot = e & 0xFFFFu;
+            const uint32_t did = ((s_begin + x) << SB) + slot;
+            uint32_t wv[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+            const uint32_t sec = TALLY ? tally_sectors(valid, e, 6u) : 0u;
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t oo = (u < T && valid) ? rs[u * SPG + x] : 0u;
+                if (TALLY) { if (u < T && __ballot(oo != 0u)) { cn_probe += sec; cn_probe_raw += n; } }
+                if (oo) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+            }
+            if (SIDED) {
+#pragma unroll
+                for (uint32_t u = 4; u < 8u; ++u) {
+                    const uint32_t oo = (u < T && valid) ? rs[u * SPG + x] : 0u;
+                    if (TALLY) { if (u < T) { cn_probe += sec; cn_probe_raw += n; } }
+                    if (oo) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+                }
+            }
+            dl[0] = valid ? seg.doclen[did] : 0u;
+            if (TALLY) { cn_dl += tally_sectors(valid, did, 4u); cn_dl_raw += n; }
+            if (valid) {
+#pragma unroll
+                for (uint32_t u = 0; u < (SIDED ? 8u : 4u); ++u) if (u < T) c_w[(size_t)u * CAND + lane] = (TabT)wv[u];
+            }
+            wave_lds_fence();
+            q_mode = true; q_did = did;
+            score_candidates(n, true);
+            q_mode = false;
+            wave_lds_fence();
+            head = (head + n) & (QCAP - 1u);
+            pend -= n;
+        };
+        uint32_t sl = next_q(0);
+        uint32_t m[4] = {0u, 0u, 0u, 0u};
+        if (sl < n_local) {
+            andw_u4 raw[4];
+            load_bitmaps(sl, raw);
+            const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+        }
+        while (sl < n_local) {
+            const uint32_t sl1 = next_q(sl + 1u);
+            const bool pre = sl1 < n_local;
+            andw_u4 raw[4];
+            if (pre) load_bitmaps(sl1, raw);                           /* in flight while this stripe's bits are enumerated */
+            const uint32_t cnt = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
+            uint32_t o = incl - cnt;                                   /* this lane's next ordinal in the stripe */
+            uint32_t done = 0u;
+            do {
+                const uint32_t room = QCAP - pend;
+                const uint32_t take_n = n_total - done < room ? n_total - done : room;
+                const uint32_t lim = done + take_n;
+                const uint32_t wbase = head + pend - done;             /* ring position of ordinal 0 (mod QCAP) */
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    while (m[i] && o < lim) {
+                        const uint32_t bit = (uint32_t)__ffs(m[i]) - 1u;
+                        ring[(wbase + o) & (QCAP - 1u)] = (sl << 16) | ((lane * 4u + i) * 32u + bit);
+                        m[i] &= m[i] - 1u;
+                        ++o;
+                    }
+                }
+                pend += take_n;
+                done = lim;
+                wave_lds_fence();
+                /* full rounds; after the unit's last stripe also the remainder */
+                const uint32_t least = (!pre && done == n_total) ? 1u : 64u;
+                while (pend >= least) round(pend < 64u ? pend : 64u);
+            } while (done < n_total);
+            if (pre) {
+                const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+            }
+            sl = sl1;
+        }
+    }
+    uint32_t sl = qpath ? n_local : next_active(0);
+    if ((PHRASE || SIDED) && td == 0u && !qpath) {             /* (a plain conjunction with td == 0 always takes the queue path) */
         /* ---- every required term dense: candidates = AND of the containers' bitmaps (one 16-byte load per lane and
          * term).  Software pipeline, ONE exposed memory latency per stripe instead of three: the container offsets run two
          * stripes ahead, the NEXT stripe's bitmaps are requested before this stripe's probes and ANDed after them, and the
