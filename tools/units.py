@@ -42,6 +42,9 @@ def close(self):
         A = np.stack([stripes, a[:, 6].astype(np.float64), np.ones(n)], axis=1)
         coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
         print("UNITS fit cycles = %.1f * stripes + %.2f * matches + %.0f; residual rms %.0f" % (coef[0], coef[1], coef[2], float(np.sqrt(((A @ coef - dur) ** 2).mean()))))
+        ph_a = (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64) * 64.0
+        ph_b = (a[:, 3] >> np.uint64(32)).astype(np.float64) * 64.0
+        print("UNITS conjunction queue path: share of unit cycles in probe rounds %.3f, in weigh rounds %.3f (tallying build)" % (ph_a.sum() / dur.sum(), ph_b.sum() / dur.sum()))
         out = os.path.join(ROOT, "gpurun_out")
         os.makedirs(out, exist_ok=True)
         np.save(os.path.join(out, "units_%s.npy" % os.environ.get("XGM_UNITS_TAG", "last")), a)

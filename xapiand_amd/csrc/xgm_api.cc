@@ -600,6 +600,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     for (uint32_t i = 0; i < nq; ++i) {
         double sparse_blocks = 0, min_df = 1e30, dens = 1.0;
         bool all_dense = bp->andw;
+        uint32_t sparse_req = 0;                     /* required terms without containers */
+        bool sparse_rhs = false;                     /* ... right-hand terms without them */
         for (uint32_t t = 0; t < qs[i].n_terms; ++t) {
             uint32_t id = qs[i].terms[t].term_id;
             /* the candidates are the conjunction of the REQUIRED terms; right-hand terms (excluded / optional) are only probed */
@@ -608,6 +610,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             const double df = idx->term_df[id];
             const bool dense = bp->andw && !bp->wide && (!bp->phrase || idx->view.dense_pos) && idx->dense_min_df && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
             if (!dense) { sparse_blocks += (required ? 1.0 : 0.25) * (df / XGM_BLOCK + std::min<double>(df, n_stripes)); if (required) all_dense = false; }
+            if (!dense) { if (required) ++sparse_req; else sparse_rhs = true; }
             if (!required) continue;
             min_df = std::min(min_df, df);
             dens *= df / n_docs;
@@ -619,6 +622,17 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         static const double phrase_cand = getenv("XGM_PHRASE_CAND_COST") ? atof(getenv("XGM_PHRASE_CAND_COST")) : 0.25;
         const double per_cand = bp->phrase ? phrase_cand : 0.03;
         cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + per_cand * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
+        if (bp->andw && !bp->phrase && min_df > 0 && sparse_req <= 1 && !sparse_rhs && qs[i].n_terms <= 8) {
+            /* the conjunction kernel's queue path (measured per unit on MI355X, tools/units.py, in ~1k cycles of a wave
+             * at 4 waves per SIMD): the producer costs ~8 per stripe when the candidates are the AND of the bitmaps and
+             * ~0.05 per posting when they are the rarest term's postings; a probed candidate ~0.11, a weighed match
+             * ~0.15 (more with optional terms to sum) */
+            const double cands = sparse_req ? min_df : Wd * dens * n_stripes;
+            const double matches = sparse_req ? min_df * dens / std::max(1e-12, min_df / n_docs) : cands;
+            cost[i] = (sparse_req ? 4.0 + 0.3 * stripes : 8.0 * stripes) + 0.16 * cands + (bp->sided == 2 ? 0.22 : 0.15) * matches + 1.0;
+        } else if (bp->andw && !bp->phrase) {
+            cost[i] = stripes * 28.0 + 0.9 * sparse_blocks + per_cand * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
+        }
         if (bp->orw) {
             /* every stripe: the terms' bitmaps / block decodes (twice where candidates remain) and a
              * share of the union that survives the MaxScore pruning */
@@ -634,7 +648,17 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         }
         total_cost += cost[i];
     }
-    const double unit_cost = std::max(1.0, total_cost / (wave_units ? 12288.0 : 3072.0));
+    double unit_cost = std::max(1.0, total_cost / (wave_units ? 12288.0 : 3072.0));
+    if (wave_units) {
+        /* the floor of g_min units per query (the LDS table bounds a unit's stripes) eats part of the budget: raise the
+         * unit cost until the batch fits ~12288 units again (3 per wave slot of the chip) */
+        for (int it = 0; it < 8; ++it) {
+            double units = 0;
+            for (uint32_t i = 0; i < nq; ++i) units += std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
+            if (units <= 12288.0 * 1.03) break;
+            unit_cost *= std::max(1.02, units / 12288.0);
+        }
+    }
     bp->goff.assign(nq + 1, 0);
     bp->work.clear();
     uint32_t spg_used = 1;
@@ -1540,7 +1564,7 @@ extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out,
     uint64_t n = std::min<uint64_t>(cap, g_last_work.size());
     for (uint64_t i = 0; i < n; ++i) {
         const xgm_work& w = g_last_work[i];
-        out[8 * i] = w.qi; out[8 * i + 1] = w.s_begin; out[8 * i + 2] = w.s_end; out[8 * i + 3] = w.slot;
+        out[8 * i] = w.qi; out[8 * i + 1] = w.s_begin; out[8 * i + 2] = w.s_end; out[8 * i + 3] = (uint64_t)h[w.slot].c_pad[0] | ((uint64_t)h[w.slot].c_pad[1] << 32);   /* phase clocks (units of 64 cycles) of the tallying build */
         out[8 * i + 4] = h[w.slot].t_start; out[8 * i + 5] = h[w.slot].t_end;
         out[8 * i + 6] = h[w.slot].matches; out[8 * i + 7] = h[w.slot].pad;
     }

@@ -1166,9 +1166,9 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
     off += (size_t)cap * 8;                                    /* tk_w */
     off += (size_t)cap * 4;                                    /* tk_d */
     off += (size_t)kStageWords * 4;                            /* stage */
-    off += (size_t)(W / 32u) * 4;                              /* bitmap */
+    off += (size_t)(W / 32u > 128u ? W / 32u : 128u) * 4;      /* bitmap (queue path: the match stack's 128 docids) */
     off += (size_t)2 * T * spg * 4;                            /* runs */
-    off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
+    off += (size_t)(W / 32u > 256u ? W / 32u : 256u) * 2;      /* rankw (u16; queue path: 256 wdf entries) */
     off += (size_t)kAndwCand * 2;                              /* c_slot */
     off += (size_t)T * kAndwCand * tab_elem;                   /* c_w */
     off += phrase ? (size_t)T * kAndwCand * 4 : 0;             /* c_pos: position-list offset per candidate and term */
@@ -1245,6 +1245,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
     uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
     unsigned long long cn_pos = 0;                                 /* PHRASE only, per lane */
+    uint32_t q_cands = 0;                                          /* TALLY: candidates the queue path produced */
+    unsigned long long ph_a = 0, ph_b = 0;                         /* TALLY: cycles spent in the queue path's probe / weigh rounds */
     /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
     auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
         const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
@@ -1258,10 +1260,10 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
     uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
     uint32_t* stage = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kStageWords * 4;
-    uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+    uint32_t* bitmap = reinterpret_cast<uint32_t*>(base + off); off += (size_t)(NW > 128u ? NW : 128u) * 4;
     uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
-    uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
+    uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)(NW > 256u ? NW : 256u) * 2;
     uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)CAND * 2;
     TabT* c_w = reinterpret_cast<TabT*>(base + off); off += (size_t)tab_terms * CAND * sizeof(TabT);
     uint32_t* c_pos = reinterpret_cast<uint32_t*>(base + off);     /* PHRASE only */
@@ -1320,13 +1322,20 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     if (td == 0 && TR > 4u) td = 1;
     /* the queue path (below): every term that takes part has containers and there is no positional filter — the unit
      * never looks at a block, so the table holds the containers' offsets instead of block ranges */
-    const bool qpath = !PHRASE && !empty && td == 0u && sparse_neg == 0ull;
+    const bool qpath = !PHRASE && !empty && td <= 1u && sparse_neg == 0ull && T <= 8u;
+    uint32_t q_b0 = 0u, q_b1 = 0u;                                 /* td == 1: term 0's blocks inside the unit's docid range */
     if (qpath) {
-        for (uint32_t t = 0; t < T; ++t) {
+        for (uint32_t t = td; t < T; ++t) {
             const uint32_t d = __builtin_amdgcn_readlane(dense_reg, t);
             if (d == 0xFFFFFFFFu) continue;                        /* a right-hand term the shard does not have */
             if (TALLY) { cn_aux += s_end - s_begin; }
             for (uint32_t x = lane; x < s_end - s_begin; x += 64u) rs[t * SPG + x] = seg.dense_dir[(size_t)d * seg.n_stripes + (s_begin + x)];
+        }
+        if (td == 1u) {
+            const uint32_t id = q.term_id[0];
+            const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+            q_b0 = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+            q_b1 = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, q_b0, b1, s_end << SB, lane);
         }
     } else if (!empty) {
         for (uint32_t t = 0; t < T; ++t) {
@@ -1466,6 +1475,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
 
     bool q_mode = false;                                           /* queue path: the round's docids are in q_did (one per lane) */
     uint32_t q_did = 0;
+    uint32_t q_off = 0;                                            /* ... and their rows start at c_w[..][q_off] */
     /* candidates present in every term are matches: BM25 + top-k, 64 per round; also clears c_w */
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
@@ -1476,12 +1486,12 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; if (MAYBE) tk_m[i] = 0; }
                 wave_lds_fence();
             }
-            const uint32_t o = i0 + lane;
+            const uint32_t oi = i0 + lane, o = q_off + oi;
             bool take = false;
             uint64_t wb = 0;
             uint32_t did = 0, subqs = 0;
             bool pass = false;
-            if (o < n_c) {
+            if (oi < n_c) {
                 pass = true;
                 for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
                 for (uint32_t t = TR; t < T; ++t) pass = pass && (!((q.neg_mask >> t) & 1u) || c_w[(size_t)t * CAND + o] == 0);   /* AND_NOT */
@@ -1547,7 +1557,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 }
                 wave_lds_fence();
             }
-            if (o < n_c) {
+            if (oi < n_c) {
                 if (pass) {
                     ++matches;
                     did = q_mode ? q_did : stripe_base + c_slot[o];
@@ -1679,16 +1689,23 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     };
 
     if (qpath) {
-        /* ---- queue path.  Every term that takes part has containers: per stripe only the AND of the bitmaps and the
-         * enumeration of its bits run; the candidates — (stripe, slot) pairs — queue up in LDS across stripes, and
-         * whenever 64 of them wait, ONE round probes their wdf bytes and document lengths (each lane its own stripe's
-         * containers) and weighs them with every lane busy.  At ~8 matches per stripe (C2) the per-stripe path spent
-         * most of its issue slots weighing 8 documents on 64 lanes.  The next stripe's bitmaps are requested before
-         * this stripe's bits are enumerated. */
+        /* ---- queue path: units that never need a per-stripe table.  Either every required term has containers
+         * (td == 0: the candidates of a stripe are the bits of the AND of the bitmaps) or only the rarest one is
+         * block-coded (td == 1: its postings are the candidates, unpacked 64 at a time ACROSS block and stripe
+         * boundaries — a tail term has a handful of postings per block).  Candidates — (stripe, slot) pairs — queue up
+         * in LDS across stripes.  Round A takes 64 of them, probes the containers (each lane its own stripe's) and
+         * pushes the survivors with their wdf bytes on a match stack; round B pops 64 matches, gathers their document
+         * lengths and weighs them with every lane busy.  The per-stripe path spent most of its issue slots weighing a
+         * few documents on 64 lanes and paid a memory latency chain per stripe. */
         typedef uint32_t andw_u4 __attribute__((ext_vector_type(4)));
         uint32_t* ring = reinterpret_cast<uint32_t*>(c_slot);      /* CAND u16 = 256 u32 entries: (local stripe << 16) | slot */
+        uint16_t* ring_w = rankw;                                  /* td == 1: wdf + 1 of term 0, same index */
+        uint32_t* st_did = bitmap;                                 /* match stack: docids (rows of c_w hold the wdf bytes) */
+        uint32_t* st_dl = stage;                                   /* ... and, td == 0, their document lengths */
+        const bool dl_in_a = td == 0u;                             /* nearly every candidate of an all-container unit is a match: its document
+                                                                      length travels with the probes instead of waiting for round B */
         constexpr uint32_t QCAP = CAND / 2u;
-        uint32_t pend = 0u, head = 0u;
+        uint32_t pend = 0u, head = 0u, nB = 0u;
         auto next_q = [&](uint32_t from) {
             uint32_t x = from;
             for (; x < n_local; ++x) {
@@ -1710,65 +1727,102 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 }
             }
         };
-        /* weigh the first n (<= 64) queued candidates */
-        auto round = [&](uint32_t n) {
+        /* round A: probe the first n (<= 64) queued candidates, push the matches */
+        auto round_a = [&](uint32_t n) {
             const bool valid = lane < n;
-            const uint32_t e = valid ? ring[(head + lane) & (QCAP - 1u)] : 0u;
+            const uint32_t ri = (head + lane) & (QCAP - 1u);
+            const uint32_t e = valid ? ring[ri] : 0u;
             const uint32_t x = e >> 16, slot = e & 0xFFFFu;
-            const uint32_t did = ((s_begin + x) << SB) + slot;
             uint32_t wv[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
             const uint32_t sec = TALLY ? tally_sectors(valid, e, 6u) : 0u;
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) {
-                const uint32_t oo = (u < T && valid) ? rs[u * SPG + x] : 0u;
+            for (uint32_t u = 0; u < 8u; ++u) {
+                const uint32_t oo = (u < T && u >= td && valid) ? rs[u * SPG + x] : 0u;
                 if (TALLY) { if (u < T && __ballot(oo != 0u)) { cn_probe += sec; cn_probe_raw += n; } }
                 if (oo) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
             }
-            if (SIDED) {
-#pragma unroll
-                for (uint32_t u = 4; u < 8u; ++u) {
-                    const uint32_t oo = (u < T && valid) ? rs[u * SPG + x] : 0u;
-                    if (TALLY) { if (u < T) { cn_probe += sec; cn_probe_raw += n; } }
-                    if (oo) wv[u] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
-                }
+            uint32_t dlv = 0u;
+            if (dl_in_a) {
+                dlv = valid ? seg.doclen[((s_begin + x) << SB) + slot] : 0u;
+                if (TALLY) { cn_dl += tally_sectors(valid, ((s_begin + x) << SB) + slot, 4u); cn_dl_raw += n; }
             }
-            dl[0] = valid ? seg.doclen[did] : 0u;
-            if (TALLY) { cn_dl += tally_sectors(valid, did, 4u); cn_dl_raw += n; }
-            if (valid) {
+            if (td == 1u && valid) wv[0] = ring_w[ri];
+            bool pass = valid;
 #pragma unroll
-                for (uint32_t u = 0; u < (SIDED ? 8u : 4u); ++u) if (u < T) c_w[(size_t)u * CAND + lane] = (TabT)wv[u];
+            for (uint32_t u = 0; u < 8u; ++u) {
+                if (u < TR) pass = pass && wv[u] != 0u;
+                else if (SIDED && u < T) pass = pass && (!((q.neg_mask >> u) & 1u) || wv[u] == 0u);       /* AND_NOT */
             }
-            wave_lds_fence();
-            q_mode = true; q_did = did;
-            score_candidates(n, true);
-            q_mode = false;
-            wave_lds_fence();
+            const uint64_t pm = __ballot(pass);
+            if (pass) {
+                const uint32_t pos = nB + mbcnt(pm);
+                st_did[pos] = ((s_begin + x) << SB) + slot;
+                if (dl_in_a) st_dl[pos] = dlv;
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; ++u) if (u < T) c_w[(size_t)u * CAND + pos] = (TabT)wv[u];
+            }
+            nB += (uint32_t)__popcll(pm);
             head = (head + n) & (QCAP - 1u);
             pend -= n;
+            wave_lds_fence();
         };
-        uint32_t sl = next_q(0);
+        /* round B: weigh the top n (<= 64) matches of the stack */
+        auto round_b = [&](uint32_t n) {
+            q_off = nB - n;
+            const bool valid = lane < n;
+            const uint32_t did = valid ? st_did[q_off + lane] : 0u;
+            if (dl_in_a) {
+                dl[0] = valid ? st_dl[q_off + lane] : 0u;
+            } else {
+                dl[0] = valid ? seg.doclen[did] : 0u;
+                if (TALLY) { cn_dl += tally_sectors(valid, did, 4u); cn_dl_raw += n; }
+            }
+            q_mode = true; q_did = did;
+            score_candidates(n, true);
+            q_mode = false; q_off = 0u;
+            nB -= n;
+            wave_lds_fence();
+        };
+        /* producer state, td == 0: the stripe whose bits are being enumerated */
+        uint32_t sl = td == 0u ? next_q(0) : n_local;
         uint32_t m[4] = {0u, 0u, 0u, 0u};
+        uint32_t o = 0u, n_total = 0u, done = 0u;
+        bool fresh = true;                                         /* m holds a stripe whose bits have not been counted yet */
         if (sl < n_local) {
             andw_u4 raw[4];
             load_bitmaps(sl, raw);
             const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
             m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
         }
-        while (sl < n_local) {
-            const uint32_t sl1 = next_q(sl + 1u);
-            const bool pre = sl1 < n_local;
-            andw_u4 raw[4];
-            if (pre) load_bitmaps(sl1, raw);                           /* in flight while this stripe's bits are enumerated */
-            const uint32_t cnt = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
-            const uint32_t incl = wave_incl_scan(cnt);
-            const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
-            uint32_t o = incl - cnt;                                   /* this lane's next ordinal in the stripe */
-            uint32_t done = 0u;
-            do {
+        /* producer state, td == 1: lane j holds the header of block bb + j of the batch; p0 = postings of the batch consumed */
+        uint32_t b_next = q_b0, nbat = 0u, p_tot = 0u, p0 = 0u, carry = 0u;
+        uint32_t bj_first = 0u, bj_meta = 0u, bj_word = 0u, bj_p = 0u;
+        const uint64_t tb0 = tbase(0);
+        bool more = td == 0u ? sl < n_local : b_next < q_b1;
+        while (more || pend || nB) {
+            if (more && td == 0u) {
+                /* one stripe (or what fits of it): its bits go to the queue; the next stripe's bitmaps are in flight meanwhile */
+                andw_u4 raw[4];
+                uint32_t sl1 = n_local;
+                bool pre = false;
+                if (fresh) {
+                    const uint32_t cnt = (uint32_t)(__popc(m[0]) + __popc(m[1]) + __popc(m[2]) + __popc(m[3]));
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    n_total = __builtin_amdgcn_readlane(incl, 63);
+                    o = incl - cnt;                                /* this lane's next ordinal in the stripe */
+                    done = 0u;
+                    fresh = false;
+                }
                 const uint32_t room = QCAP - pend;
                 const uint32_t take_n = n_total - done < room ? n_total - done : room;
                 const uint32_t lim = done + take_n;
-                const uint32_t wbase = head + pend - done;             /* ring position of ordinal 0 (mod QCAP) */
+                const bool last_piece = lim == n_total;
+                if (last_piece) {
+                    sl1 = next_q(sl + 1u);
+                    pre = sl1 < n_local;
+                    if (pre) load_bitmaps(sl1, raw);
+                }
+                const uint32_t wbase = head + pend - done;         /* ring position of ordinal 0 (mod QCAP) */
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
                     while (m[i] && o < lim) {
@@ -1779,17 +1833,82 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                     }
                 }
                 pend += take_n;
+                if (TALLY) { q_cands += take_n; }
                 done = lim;
+                if (last_piece) {
+                    if (pre) {
+                        const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
+                        m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+                    }
+                    sl = sl1;
+                    fresh = true;
+                    more = pre;
+                }
                 wave_lds_fence();
-                /* full rounds; after the unit's last stripe also the remainder */
-                const uint32_t least = (!pre && done == n_total) ? 1u : 64u;
-                while (pend >= least) round(pend < 64u ? pend : 64u);
-            } while (done < n_total);
-            if (pre) {
-                const andw_u4 a = raw[0] & raw[1] & raw[2] & raw[3];
-                m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w;
+            } else if (more) {
+                /* 64 postings of term 0, one per lane, across block boundaries */
+                if (p0 >= p_tot) {
+                    nbat = q_b1 - b_next < 64u ? q_b1 - b_next : 64u;
+                    bj_meta = bj_first = bj_word = 0u;
+                    if (lane < nbat) { bj_meta = seg.blk_meta[b_next + lane]; bj_first = seg.blk_first[b_next + lane]; bj_word = seg.blk_word[b_next + lane]; }
+                    const uint32_t cj = lane < nbat ? XGM_META_COUNT(bj_meta) : 0u;
+                    const uint32_t incl = wave_incl_scan(cj);
+                    bj_p = incl - cj;
+                    p_tot = __builtin_amdgcn_readlane(incl, 63);
+                    p0 = 0u;
+                    b_next += nbat;
+                    if (TALLY) {
+                        cn_hdr += nbat;
+                        const uint32_t wj = lane < nbat ? payload_words(bj_meta) - 2u : 0u;
+                        cn_blkw += __builtin_amdgcn_readlane(wave_incl_scan(wj), 63);
+                    }
+                }
+                const uint32_t p = p0 + lane;
+                const bool valid = p < p_tot;
+                uint32_t j = 0u;                                   /* the block that holds posting p: the last j with bj_p[j] <= p */
+#pragma unroll
+                for (uint32_t sft = 32u; sft; sft >>= 1) {
+                    const uint32_t cj = j + sft;
+                    const uint32_t pc = (uint32_t)__shfl((int)bj_p, (int)(cj & 63u));
+                    if (cj < nbat && pc <= p) j = cj;
+                }
+                const uint32_t pj = (uint32_t)__shfl((int)bj_p, (int)j);
+                const uint32_t first = (uint32_t)__shfl((int)bj_first, (int)j);
+                const uint32_t meta = (uint32_t)__shfl((int)bj_meta, (int)j);
+                const uint32_t word = (uint32_t)__shfl((int)bj_word, (int)j);
+                const uint32_t i = p - pj;
+                const uint32_t nj = XGM_META_COUNT(meta), bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta);
+                const uint32_t* pw = seg.words + tb0 + word;
+                uint32_t gap = 0u, wdf = 0u;
+                if (valid) {
+                    if (i > 0u) gap = extract_bits(pw, i, bwg) + 1u;
+                    wdf = extract_bits(pw + ((nj * bwg + 31u) >> 5), i, bww);
+                }
+                const uint32_t sc = wave_incl_scan(gap);
+                /* docid = first docid of the block + the gaps since; a block that began in an earlier step continues from
+                 * the last docid of that step */
+                const bool began_here = pj >= p0;
+                const uint32_t s_at = (uint32_t)__shfl((int)sc, (int)((pj - p0) & 63u));
+                const uint32_t did = began_here ? first + (sc - s_at) : carry + sc;
+                carry = __builtin_amdgcn_readlane(did, 63);
+                if (valid) {
+                    const uint32_t ri = (head + pend + lane) & (QCAP - 1u);
+                    const uint32_t x = (did >> SB) - s_begin;
+                    ring[ri] = (x << 16) | (did & (W - 1u));
+                    ring_w[ri] = (uint16_t)(wdf + 1u);
+                }
+                pend += p_tot - p0 < 64u ? p_tot - p0 : 64u;
+                if (TALLY) { q_cands += p_tot - p0 < 64u ? p_tot - p0 : 64u; }
+                p0 += 64u;
+                more = p0 < p_tot || b_next < q_b1;
+                wave_lds_fence();
             }
-            sl = sl1;
+            /* consumers: full rounds while the producer has more, the remainders after it */
+            unsigned long long ph_t = TALLY ? __builtin_readcyclecounter() : 0ull;
+            if (pend >= 64u || (!more && pend)) round_a(pend < 64u ? pend : 64u);
+            if (TALLY) { const unsigned long long t1 = __builtin_readcyclecounter(); ph_a += t1 - ph_t; ph_t = t1; }
+            if (nB >= 64u || (!more && !pend && nB)) round_b(nB < 64u ? nB : 64u);
+            if (TALLY) { ph_b += __builtin_readcyclecounter() - ph_t; }
         }
     }
     uint32_t sl = qpath ? n_local : next_active(0);
@@ -2175,10 +2294,10 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     }
     if (lane == 0) {
         xgm_group_hdr h;
-        h.matches = matches; h.n_cand = n_out; h.pad = 0;
+        h.matches = matches; h.n_cand = n_out; h.pad = TALLY ? q_cands : 0u;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         h.c_pos = cn_pos; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
-        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = h.c_pad[1] = 0;
+        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = (uint32_t)(ph_a >> 6); h.c_pad[1] = (uint32_t)(ph_b >> 6);
         ghdr_out[wk.slot] = h;
     }
 #undef XGM_SU
