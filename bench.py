@@ -160,14 +160,23 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     db.set_profiling(1)
+    L.xgm_debug_host_ns((C.c_uint64 * 8)())           # reset the host-side section timers
     t0 = time.perf_counter()
+    host_s = 0.0                                   # time the host spends inside the (asynchronous) calls: plan + enqueue
     for s in range(args.steps):
+        h0 = time.perf_counter()
         step(batches[s % n_batches])
+        host_s += time.perf_counter() - h0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    hn = (C.c_uint64 * 8)()
+    L.xgm_debug_host_ns(hn)
+    n_launch = max(1, int(hn[3]))
+    host_sections = {"plan_queries": round(hn[0] / 1e3 / args.steps, 1), "plan_batch": round(hn[1] / 1e3 / n_launch, 1),
+                     "stage_enqueue_launch": round(hn[2] / 1e3 / n_launch, 1), "staging_memcpy": round(hn[4] / 1e3 / n_launch, 1), "upload_enqueue": round(hn[5] / 1e3 / n_launch, 1), "match_launch": round(hn[6] / 1e3 / n_launch, 1), "merge_launch": round(hn[7] / 1e3 / n_launch, 1), "launches_per_step": round(n_launch / args.steps, 2)}
     kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed steps (HIP events)
     kernel_name = db.last_kernel_name()
     db.set_profiling(0)
@@ -255,7 +264,7 @@ def main():
                        "terms_per_query": args.terms, "top_k": k, "batch": BATCH, "parallelism": "shard%d" % world,
                        "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED),
                        "step": "xgm_get_mset_batch_device: plan (lookups, BM25 init, leaf order) + match + merge, 256 queries"},
-            "p50_latency_us": lat[len(lat) // 2] * 1e6 if lat else None,
+            "host_ms_per_step": round(1e3 * host_s / args.steps, 4), "host_us_per_step": host_sections, "p50_latency_us": lat[len(lat) // 2] * 1e6 if lat else None,
             "p99_latency_us": lat[int(len(lat) * 0.99)] * 1e6 if lat else None,
             "plan_us_per_query": plan_us,
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,

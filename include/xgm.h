@@ -423,6 +423,12 @@ double xgm_debug_plan_us(const xgm_index*, const xgm_query_desc* descs, const xg
  * one per kernel class present, as "<kernel>[:variant]*<queries>;..." in launch order; returns their number. */
 int xgm_debug_batch_launches(const xgm_index*, const xgm_query* qs, uint32_t nq, char* out, uint32_t cap);
 
+/* Diagnostics: nanoseconds the calling threads spent on the host side of batch calls since the last fetch:
+ * out8[0] planning the descriptions (xgm_plan_query), [1] cutting the batch into work units, [2] staging, copies
+ * and launches ([4] staging memcpys, [5] upload enqueue + events, [6] match launch, [7] merge launch), [3] number
+ * of launches. */
+int xgm_debug_host_ns(uint64_t* out8);
+
 /* Diagnostics: out3 = {batches the dispatcher launched, requests it served, max_batch}. */
 int xgm_debug_batching_info(const xgm_index*, uint64_t* out3);
 /* Diagnostics / bench.py's server leg: n_threads host threads, each answering per_thread queries one at a time through

@@ -132,6 +132,7 @@ _API = [
     ("xgm_debug_batch_launches", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_char_p, C.c_uint32]),
     ("xgm_index_set_batching", C.c_int, [C.c_void_p, C.c_uint32]),
     ("xgm_debug_batching_info", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    ("xgm_debug_host_ns", C.c_int, [_P(C.c_uint64)]),
     ("xgm_debug_concurrent_searches", C.c_double, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_double)]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
