@@ -192,7 +192,7 @@ static void fill_view(xgm_index* idx) {
     v.term_flags = (const uint32_t*)idx->d_sections[XGM_S_TERM_FLAGS];
     v.stripe_bits = idx->hdr.stripe_bits;
     v.lastdocid = idx->hdr.lastdocid;
-    v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.pad_ = 0;
+    v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.dense_plane = 0;
     v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
@@ -419,6 +419,40 @@ static uint32_t next_pow2(uint32_t v) {
     return p;
 }
 
+/* A first guess of a disjunction's final k-th weight (xgm_dev_query::theta_seed).  A document that indexes exactly the terms S weighs at
+ * least wlow(S) = Σ_{t in S} weight(wdf = 1, the longest document) — BM25 is monotone in both.  With independent terms N · Π p_t · Π (1 - p_t)
+ * documents match exactly S; the guess is the largest wlow(S) such that the subsets at or above it are expected to hold a few times k
+ * documents.  It only steers which documents are weighed first: xgm_orw_kernel weighs everything whose BOUND reaches the guess and, should
+ * fewer than k of those reach it (correlated terms, tiny shards), goes round again below it. */
+static double or_theta_seed(const xgm_index* idx, const xgm_query* q, const xgm_dev_query* d) {
+    struct Tm { double p, wlow, ub; };
+    Tm tm[XGM_MAX_TERMS];
+    uint32_t n = 0;
+    const double N = (double)idx->hdr.doccount;
+    const double nl_ub = std::max((double)idx->hdr.doclen_upper_bound * q->len_factor, q->min_normlen);
+    const double denom_max = q->k1 * (nl_ub * q->b + (1.0 - q->b));
+    for (uint32_t t = 0; t < q->n_terms; ++t) {
+        const uint32_t id = q->terms[t].term_id;
+        if (id == UINT32_MAX || !(q->terms[t].termweight > 0.0)) continue;
+        tm[n++] = Tm{std::min(1.0, (double)idx->term_df[id] / N), q->terms[t].termweight * (1.0 / (denom_max + 1.0)), d->ub[t]};
+    }
+    if (n == 0) return 0.0;
+    std::sort(tm, tm + n, [](const Tm& a, const Tm& b) { return a.ub > b.ub; });
+    if (n > 8u) n = 8u;                     /* the eight terms with the largest bounds; whatever else a document indexes only adds weight */
+    std::pair<double, double> sub[256];     /* (wlow, expected documents) */
+    const uint32_t ns = 1u << n;
+    for (uint32_t S = 1; S < ns; ++S) {
+        double p = N, w = 0.0;
+        for (uint32_t i = 0; i < n; ++i) { if ((S >> i) & 1u) { p *= tm[i].p; w += tm[i].wlow; } else p *= 1.0 - tm[i].p; }
+        sub[S - 1] = std::make_pair(w, p);
+    }
+    std::sort(sub, sub + (ns - 1u), [](const std::pair<double, double>& a, const std::pair<double, double>& b) { return a.first > b.first; });
+    const double need = 3.0 * (double)d->k;
+    double acc = 0.0;
+    for (uint32_t i = 0; i + 1u < ns; ++i) { acc += sub[i].second; if (acc >= need) return sub[i].first; }
+    return 0.0;
+}
+
 /* xgm_query → device form; returns the wdf table width the query needs (1 or 2 bytes), 0 if too big */
 static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query* d) {
     memset(d, 0, sizeof *d);
@@ -442,10 +476,18 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
         if (ub > 254u) width = 2;
         /* leaf weight <= termweight * wdf_ub / (k1 * (min_normlen * b + 1 - b) + wdf_ub) <= termweight:
          * every factor of BM25Weight::get_sumpart is monotone in wdf and in the normalised length */
-        double bound = q->terms[t].termweight;
-        const double denom_min = q->k1 * (q->min_normlen * q->b + (1.0 - q->b));
-        if (ub > 0 && denom_min > 0) bound = q->terms[t].termweight * ((double)ub / (denom_min + (double)ub));
+        double bound = q->terms[t].termweight, bound1 = bound;
+        const double nl_lb = std::max((double)idx->hdr.doclen_lower_bound * q->len_factor, q->min_normlen);     /* normlen of any document is at least this */
+        const double denom_min = q->k1 * (nl_lb * q->b + (1.0 - q->b));
+        const uint32_t wmax = idx->term_wdfmax.empty() ? ub : std::min(ub, idx->term_wdfmax[q->terms[t].term_id]);   /* the true largest wdf where known */
+        if (wmax > 0 && denom_min > 0) { bound = q->terms[t].termweight * ((double)wmax / (denom_min + (double)wmax)); bound1 = q->terms[t].termweight * (1.0 / (denom_min + 1.0)); }
         d->ub[t] = bound * 1.000000001;
+        d->ub1[t] = std::min(bound1, bound) * 1.000000001;
+    }
+    if (q->op == XGM_OP_OR && d->k > 0 && idx->hdr.doccount > 0) {
+        /* A/B switch (variant tests): scale the guess — far too high forces the kernel's second pass everywhere, 0 switches it off */
+        static const double seed_scale = getenv("XGM_OR_SEED_SCALE") ? atof(getenv("XGM_OR_SEED_SCALE")) : 1.0;
+        d->theta_seed = or_theta_seed(idx, q, d) * seed_scale;
     }
     if ((q->op == XGM_OP_PHRASE || q->op == XGM_OP_NEAR) && q->phrase_active) {
         d->flags |= XGM_QF_PHRASE;
@@ -652,7 +694,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
                 sum_df += df;
                 if (bp->wide || (uint64_t)idx->term_df[id] < idx->dense_min_df || idx->dense_min_df == 0) blocks += df / XGM_BLOCK + std::min<double>(df, n_stripes);
             }
-            cost[i] = n_stripes * (10.0 + 2.0 * qs[i].n_terms) + 1.8 * blocks + 0.004 * sum_df + 1.0;
+            /* (the documents weighed are a small share of the union since the threshold starts at the planner's guess) */
+            cost[i] = n_stripes * (10.0 + 3.0 * qs[i].n_terms) + 1.8 * blocks + 0.001 * sum_df + 1.0;
         }
         total_cost += cost[i];
     }
@@ -1568,6 +1611,18 @@ extern "C" int64_t xgm_debug_plan_batch(const xgm_index* idx, const xgm_query* q
     return (int64_t)bp.work.size();
 }
 
+/* Diagnostics (host only): the disjunction kernel's pruning inputs of one planned query — the guess of the final k-th weight and the
+ * per-term weight bounds (largest wdf / wdf = 1), in plan order. */
+extern "C" int xgm_debug_or_bounds(const xgm_index* idx, const xgm_query* q, double* seed, double* ub, double* ub1) {
+    if (!idx || !q) return xgm_set_error(XGM_E_INVALID, "null argument");
+    xgm_dev_query d;
+    const int w = to_dev_query(idx, q, &d);
+    if (w <= 0) return XGM_UNSUPPORTED;
+    if (seed) *seed = d.theta_seed;
+    for (uint32_t t = 0; t < q->n_terms; ++t) { if (ub) ub[t] = d.ub[t]; if (ub1) ub1[t] = d.ub1[t]; }
+    return XGM_OK;
+}
+
 /* Diagnostics (host only): the launches a batch is cut into — one per kernel class present (run_batch) — as
  * "<kernel>[:variant]*<queries>" joined by ';' in launch order; returns the number of launches, or < 0 /
  * XGM_UNSUPPORTED like a search would. */
@@ -1594,7 +1649,11 @@ extern "C" int xgm_debug_batch_launches(const xgm_index* idx, const xgm_query* q
 /* Diagnostics: per work-unit (qi, s_begin, s_end, slot, t_start, t_end, matches, documents weighed)
  * of the LAST batch launched on this index from any thread; out is u64[8 * cap]; returns the number
  * of units. */
-extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out, uint64_t cap) {
+static int64_t debug_last_units(xgm_index* idx, unsigned long long* out, unsigned long long* out_pos, uint64_t cap);
+extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out, uint64_t cap) { return debug_last_units(idx, out, nullptr, cap); }
+/* ... plus the units' c_pos field (xgm_orw_kernel's tallying build: bit 63 = the unit went round a second time, low bits = documents of essential block-decoded terms) */
+extern "C" int64_t xgm_debug_last_units2(xgm_index* idx, unsigned long long* out, unsigned long long* out_pos, uint64_t cap) { return debug_last_units(idx, out, out_pos, cap); }
+static int64_t debug_last_units(xgm_index* idx, unsigned long long* out, unsigned long long* out_pos, uint64_t cap) {
     if (!idx || !out || !g_last_ghdr) return -1;
     hipDeviceSynchronize();
     std::vector<xgm_group_hdr> h(g_last_work.size());
@@ -1605,6 +1664,7 @@ extern "C" int64_t xgm_debug_last_units(xgm_index* idx, unsigned long long* out,
         out[8 * i] = w.qi; out[8 * i + 1] = w.s_begin; out[8 * i + 2] = w.s_end; out[8 * i + 3] = (uint64_t)h[w.slot].c_pad[0] | ((uint64_t)h[w.slot].c_pad[1] << 32);   /* phase clocks (units of 64 cycles) of the tallying build */
         out[8 * i + 4] = h[w.slot].t_start; out[8 * i + 5] = h[w.slot].t_end;
         out[8 * i + 6] = h[w.slot].matches; out[8 * i + 7] = h[w.slot].pad;
+        if (out_pos) out_pos[i] = h[w.slot].c_pos;
     }
     return (int64_t)n;
 }

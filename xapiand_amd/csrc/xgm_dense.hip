@@ -46,8 +46,11 @@ __global__ void k_dense_count(xgm_seg_dev seg, const uint32_t* __restrict__ dens
 
 /* one workgroup per (stripe, dense term): decode the run, write the bitmap and the per-slot wdf+1 bytes */
 __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint32_t* __restrict__ dense_terms, uint32_t n_stripes,
-                                                    const uint32_t* __restrict__ dir, unsigned char* __restrict__ data, int with_pos) {
+                                                    const uint32_t* __restrict__ dir, unsigned char* __restrict__ data, int with_pos,
+                                                    uint32_t* __restrict__ wdf_max) {
     __shared__ uint32_t bitmap[256];
+    __shared__ uint32_t bitmap2[256];     /* wdf >= 2 */
+    __shared__ uint32_t wmax_s;
     __shared__ uint32_t pbase[128];       /* with_pos: position-entry offset (relative to the term) of the first posting of every 64-slot bucket */
     __shared__ uint32_t stage_all[4 * kStage];
     __shared__ uint32_t run[2];
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     const uint32_t b0 = (uint32_t)seg.term_blk[t], b1 = (uint32_t)seg.term_blk[t + 1];
     unsigned char* cont = data + (size_t)off * 16;
     unsigned char* wdf_out = cont + (size_t)NW * 4;
-    if (tid < NW) bitmap[tid] = 0;
+    if (tid < NW) { bitmap[tid] = 0; bitmap2[tid] = 0; }
+    if (tid == 0) wmax_s = 0;
     if (tid < 128u) pbase[tid] = 0xFFFFFFFFu;
     for (uint32_t i = tid; i < W / 16u; i += 256u) reinterpret_cast<uint4*>(wdf_out)[i] = make_uint4(0, 0, 0, 0);
     if (tid == 0) {                       /* the run's blocks: binary search on the term's block firsts */
@@ -74,6 +78,7 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     __syncthreads();
     const uint32_t rb = run[0], nb = run[1] - rb;
     uint32_t* stage = stage_all + wave * kStage;
+    uint32_t wmax = 0;
     for (uint32_t j = wave; j < nb; j += 4u) {
         const uint32_t b = rb + j, meta = seg.blk_meta[b], first = seg.blk_first[b];
         const uint32_t n = XGM_META_COUNT(meta), bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta);
@@ -96,19 +101,24 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
         const uint32_t pex = with_pos ? seg.blk_pos[b] + dn_scan(lw) - lw : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w0 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex); }
-        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w1 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex + w0); }
+        if (v0) { const uint32_t sl = d0 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); if (w0 >= 2u) atomicOr(&bitmap2[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w0 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex); }
+        if (v1) { const uint32_t sl = d1 & (W - 1u); atomicOr(&bitmap[sl >> 5], 1u << (sl & 31u)); if (w1 >= 2u) atomicOr(&bitmap2[sl >> 5], 1u << (sl & 31u)); wdf_out[sl] = (unsigned char)(w1 + 1u); if (with_pos) atomicMin(&pbase[sl >> 6], pex + w0); }
+        wmax = max(wmax, max(w0, w1));
     }
+    if (wmax) atomicMax(&wmax_s, wmax);
     __syncthreads();
     if (tid < NW) reinterpret_cast<uint32_t*>(cont)[tid] = bitmap[tid];
     if (with_pos && tid < W / 64u) reinterpret_cast<uint32_t*>(wdf_out + W)[tid] = pbase[tid];
+    if (tid < NW) reinterpret_cast<uint32_t*>(wdf_out + W + (with_pos ? NW * 2u : 0u))[tid] = bitmap2[tid];
+    if (tid == 0 && wmax_s) atomicMax(&wdf_max[d], wmax_s);            /* the term's true largest wdf: the disjunction's pruning bound */
 }
 
 }  // namespace
 
 int xgm_build_dense(xgm_index* idx) {
     idx->view.dense_id = nullptr; idx->view.dense_dir = nullptr; idx->view.dense_data = nullptr;
-    idx->view.n_dense = 0;
+    idx->view.n_dense = 0; idx->view.dense_plane = 0;
+    idx->term_wdfmax.clear();
     const uint32_t SB = idx->hdr.stripe_bits;
     const uint32_t n_stripes = (idx->hdr.lastdocid >> SB) + 1u;
     idx->view.n_stripes = n_stripes;
@@ -131,7 +141,9 @@ int xgm_build_dense(xgm_index* idx) {
     const uint32_t n_dense = (uint32_t)dense_terms.size();
     if (n_dense == 0) return XGM_OK;
     int rc = XGM_OK;
-    uint32_t *d_terms = nullptr, *d_cnt = nullptr;
+    uint32_t *d_terms = nullptr, *d_cnt = nullptr, *d_wmax = nullptr;
+    std::vector<uint32_t> wmax;
+    const uint32_t plane_off = NW * 4u + NW * 32u + (with_pos ? NW * 2u : 0u);
     std::vector<uint32_t> cnt((size_t)n_dense * n_stripes), dir((size_t)n_dense * n_stripes, 0u);
     uint64_t units = 1;                                                  /* 16-byte units; offset 0 means "no container" */
     DN_TRY(hipMalloc((void**)&d_terms, (size_t)n_dense * 4));
@@ -148,17 +160,24 @@ int xgm_build_dense(xgm_index* idx) {
         if (!cnt[i]) continue;
         if (units > 0xFFFFFFFFull) { rc = xgm_set_error(XGM_E_INVALID, "dense containers exceed the 32-bit directory"); goto fail; }
         dir[i] = (uint32_t)units;
-        units += ((uint64_t)NW * 4 + ((uint64_t)NW * 32) + (with_pos ? (uint64_t)NW * 2 : 0)) / 16;   /* bitmap + one byte per slot (+ a position base per 64 slots) */
+        units += ((uint64_t)plane_off + (uint64_t)NW * 4) / 16;   /* bitmap + one byte per slot (+ a position base per 64 slots) + the wdf >= 2 bitmap */
     }
     DN_TRY(hipMalloc(&idx->d_dense_id, dense_id.size() * 4));
     DN_TRY(hipMalloc(&idx->d_dense_dir, dir.size() * 4));
     DN_TRY(hipMalloc(&idx->d_dense_data, units * 16 + 64));
     DN_TRY(hipMemcpy(idx->d_dense_id, dense_id.data(), dense_id.size() * 4, hipMemcpyHostToDevice));
     DN_TRY(hipMemcpy(idx->d_dense_dir, dir.data(), dir.size() * 4, hipMemcpyHostToDevice));
+    DN_TRY(hipMalloc((void**)&d_wmax, (size_t)n_dense * 4));
+    DN_TRY(hipMemset(d_wmax, 0, (size_t)n_dense * 4));
     hipLaunchKernelGGL(k_dense_fill, dim3(n_stripes, n_dense), dim3(256), 0, 0, idx->view, d_terms, n_stripes, (const uint32_t*)idx->d_dense_dir,
-                       (unsigned char*)idx->d_dense_data, with_pos);
+                       (unsigned char*)idx->d_dense_data, with_pos, d_wmax);
     DN_TRY(hipGetLastError());
     DN_TRY(hipDeviceSynchronize());
+    wmax.resize(n_dense);
+    DN_TRY(hipMemcpy(wmax.data(), d_wmax, (size_t)n_dense * 4, hipMemcpyDeviceToHost));
+    idx->term_wdfmax.assign(idx->term_wdfub.begin(), idx->term_wdfub.end());
+    for (uint32_t d = 0; d < n_dense; ++d)
+        if (wmax[d] && wmax[d] < idx->term_wdfmax[dense_terms[d]]) idx->term_wdfmax[dense_terms[d]] = wmax[d];
     idx->dense_bytes = dense_id.size() * 4 + dir.size() * 4 + units * 16;
     idx->device_bytes += idx->dense_bytes;
     idx->view.dense_id = (const uint32_t*)idx->d_dense_id;
@@ -166,12 +185,14 @@ int xgm_build_dense(xgm_index* idx) {
     idx->view.dense_data = (const unsigned char*)idx->d_dense_data;
     idx->view.n_dense = n_dense;
     idx->view.dense_pos = (uint32_t)with_pos;
+    idx->view.dense_plane = plane_off;
     idx->dense_min_df = (uint64_t)min_avg * n_stripes;
-    hipFree(d_terms); hipFree(d_cnt);
+    hipFree(d_terms); hipFree(d_cnt); hipFree(d_wmax);
     return XGM_OK;
 fail:
     if (d_terms) hipFree(d_terms);
     if (d_cnt) hipFree(d_cnt);
+    if (d_wmax) hipFree(d_wmax);
     if (idx->d_dense_id) { hipFree(idx->d_dense_id); idx->d_dense_id = nullptr; }
     if (idx->d_dense_dir) { hipFree(idx->d_dense_dir); idx->d_dense_dir = nullptr; }
     if (idx->d_dense_data) { hipFree(idx->d_dense_data); idx->d_dense_data = nullptr; }

@@ -45,6 +45,11 @@ typedef struct {
     /* safe upper bound of leaf t's weight over the whole shard (0 for an absent term): drives the
      * MaxScore pruning of xgm_orw_kernel; never part of a result */
     double ub[XGM_MAX_TERMS];
+    /* xgm_orw_kernel: the same bound for a document whose wdf is 1 (the containers' wdf >= 2 bitmap tells which bound applies), and a
+     * first guess of the final k-th weight: weights of (wdf = 1, longest document) summed over the term subsets that — were the terms
+     * independent — at least a few k documents match.  A guess only: the kernel repairs a guess that was too high (xgm_or.hip) */
+    double ub1[XGM_MAX_TERMS];
+    double theta_seed;
     /* XGM_QF_TREE (include/xgm.h, xgm_query): termweight[g] is then the weight of GROUP g */
     uint32_t tree_len, n_groups, tree_root, group_scored;
     uint8_t group_of[XGM_MAX_TERMS];

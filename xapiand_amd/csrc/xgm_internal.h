@@ -39,6 +39,8 @@ struct xgm_index {
     xgm_seg_header hdr{};
     /* host copies used for planning / lookup */
     std::vector<uint32_t> term_df, term_cf, term_wdfub, term_flags;
+    std::vector<uint32_t> term_wdfmax;   /* the terms' true largest wdf where known (terms with probe containers), else term_wdfub; empty = use term_wdfub.
+                                            Pruning bounds only: MSet::max_possible keeps glass's looser bound like the reference */
     std::vector<uint64_t> term_blk, term_word;
     std::vector<uint64_t> str_off;
     std::vector<char> str_bytes;

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                 Words4 pre = {0, 0, 0, 0};
                 {
                     const uint32_t m0 = __builtin_amdgcn_readlane(h_meta, 0);
-                    const uint64_t a0 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(h_addr >> 32), 0) << 32) | __builtin_amdgcn_readlane((uint32_t)h_addr, 0);
+                    const uint64_t a0 = rl64(h_addr, 0u);
                     if (lane * 4u < payload_words(m0)) pre = *reinterpret_cast<const Words4*>(seg.words + a0 + lane * 4u);
                 }
                 for (uint32_t x = 0; x < nthis; ++x) {
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, cons
                     const Words4 cur = pre;
                     if (x + 1u < nthis) {
                         const uint32_t m1 = __builtin_amdgcn_readlane(h_meta, xs + 1u);
-                        const uint64_t a1 = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(h_addr >> 32), xs + 1u) << 32) | __builtin_amdgcn_readlane((uint32_t)h_addr, xs + 1u);
+                        const uint64_t a1 = rl64(h_addr, xs + 1u);
                         if (lane * 4u < payload_words(m1)) pre = *reinterpret_cast<const Words4*>(seg.words + a1 + lane * 4u);
                     }
                     if (lane * 4u < payload_words(meta)) {
@@ -1276,8 +1276,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     if (MAYBE) {
         const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
         const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
-        prog_a = ((uint64_t)__builtin_amdgcn_readfirstlane(ipa32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipa32[0]);
-        prog_b = ((uint64_t)__builtin_amdgcn_readfirstlane(ipb32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipb32[0]);
+        prog_a = ((uint64_t)rfl32(ipa32[1]) << 32) | rfl32(ipa32[0]);
+        prog_b = ((uint64_t)rfl32(ipb32[1]) << 32) | rfl32(ipb32[0]);
         prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
     }
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
     }
     wave_lds_fence();
     auto tbase = [&](uint32_t t) {
-        return ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tbase_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tbase_reg, t);
+        return rl64(tbase_reg, t);
     };
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
     bool theta_valid = false;
@@ -1518,7 +1518,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                             const bool fast = w16 != 0u && nt <= kPosFast;
                             slow = slow || (pass && !fast);
                             if (pass && fast) {
-                                const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
+                                const uint64_t tp = rl64(tpos_reg, t);
                                 const unsigned char* src = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * 2u;
                                 if (nt > 0u) ra[u][0] = *reinterpret_cast<const Pos8*>(src);
                                 if (nt > 8u) ra[u][1] = *reinterpret_cast<const Pos8*>(src + 16);
@@ -1547,7 +1547,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
                 } else if (pass) {
                     PosList pl[XGM_PHRASE_MAX_TERMS];
                     for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
-                        const uint64_t tp = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tpos_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tpos_reg, t);
+                        const uint64_t tp = rl64(tpos_reg, t);
                         const uint32_t w16 = __builtin_amdgcn_readlane(tflag_reg, t) & XGM_TF_POS16;
                         pl[t].p = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * (w16 ? 2u : 4u);
                         pl[t].n = cnt(t);
@@ -1931,7 +1931,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_
             for (uint32_t t = 0; t < 4u; ++t) {
                 raw[t] = andw_u4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
                 if (t < TR) {
-                    const andw_u4* bmp = reinterpret_cast<const andw_u4*>(seg.dense_data + (size_t)__builtin_amdgcn_readlane(hc, t) * 16);
+                    const andw_u4* bmp = reinterpret_cast<const andw_u4*>(seg.dense_data + (size_t)rl32(hc, t) * 16);
                     raw[t] = lane * 4u < NW ? bmp[lane] : andw_u4{0u, 0u, 0u, 0u};
                 }
             }

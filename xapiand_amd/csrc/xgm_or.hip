@@ -25,12 +25,19 @@
  * The pruning threshold is GLOBAL per query: every weighed document is counted in a 256-bucket
  * histogram of weight bit patterns (32 buckets per octave below the query's weight upper bound) shared
  * by all units of the query through global atomics; the highest bucket with >= k documents at or above
- * it is a lower bound of the final k-th weight.  To make that bound tight early, a unit runs in two
- * phases: A weighs only the documents of the term with the largest upper bound (the rarest one —
- * where the top documents are), B weighs the remaining documents of the essential terms and counts
- * the matches.  A and B partition the documents, so none is weighed twice.  Pruning never changes the
- * result: a skipped document's weight is provably below the final k-th weight (strict comparisons;
- * ties are always weighed).
+ * it is a lower bound of the final k-th weight.
+ *
+ * Which documents are weighed: those whose weight BOUND reaches the threshold.  A (document, term) pair
+ * is bounded by the term's weight at wdf = 1 or, when the container's second bitmap says wdf >= 2, at
+ * the term's largest wdf (both with the shortest document's length); the bounds are quantised UP to
+ * 1/64 of the threshold and summed for 32 documents at a time by a bit-sliced adder.  The threshold of
+ * the first pass starts at the planner's GUESS of the final k-th weight (xgm_dev_query::theta_seed)
+ * and follows the histogram upwards; the pass also counts the matches.  If, when a unit has finished
+ * its stripes, fewer than k documents of the query are known at or above the guess, the guess was too
+ * high: the unit goes over its stripes again with the threshold it has, weighing the documents between
+ * that and the guess — those the first pass weighed (recognised per document by the same quantised sum)
+ * are skipped, so none is counted twice.  Pruning never changes the result: a skipped document's weight
+ * is provably below the final k-th weight (strict comparisons; ties are always weighed).
  */
 #include <hip/hip_runtime.h>
 
@@ -53,6 +60,12 @@ constexpr uint32_t kOrwCand = XGM_ORW_CAND;   /* candidates per scoring chunk */
 #ifndef XGM_ORW_MINWG
 #define XGM_ORW_MINWG 2
 #endif
+#ifndef XGM_ORW_GROUP
+#define XGM_ORW_GROUP 5             /* dense terms whose bitmaps (+ wdf >= 2 bitmaps) are in flight together */
+#endif
+#ifndef XGM_ORW_DEBUG
+#define XGM_ORW_DEBUG 0             /* tools/orq.py: first-stripe threshold and quantised bounds in the unit headers (corrupts the match counts) */
+#endif
 #ifndef XGM_ORW_TIMERS
 #define XGM_ORW_TIMERS 0            /* section timers cost ~30 VGPRs: A/B builds only (tools/ab_build.sh) */
 #endif
@@ -67,7 +80,7 @@ __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_
     off += T > 8u ? (size_t)T * 64 * 8 : 0;                    /* val: per-lane leaf / node weights (queries of > 8 terms only: fewer sum in registers) */
     off += (size_t)cap * 4;                                    /* tk_d */
     off += (size_t)kStageWords * 4;                            /* stage */
-    off += (size_t)(W / 32u) * 4 * 4;                          /* bm_all, bm_ess, bm_ne, bm_r */
+    off += (size_t)(W / 32u) * 4 * 3;                          /* bm_all, bm_ess, bm_ne */
     off += (size_t)XGM_OR_HIST * 4;                            /* lh: the wave's pending histogram counts */
     off += (size_t)2 * T * spg * 4;                            /* runs */
     off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
@@ -149,6 +162,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
     /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
     uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
+    uint32_t cn_first = 0, cn_fixw = 0, cn_es = 0;
+    unsigned long long dbg_th0 = 0, dbg_q1 = 0, dbg_q2 = 0;               /* diagnostics (tools/orq.py): weighed in the unit's first stripe / in the second pass; documents of essential block-decoded terms */
     /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
     auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
         const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
@@ -158,8 +173,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     /* the in-place summation program of queries with <= 8 terms, in scalar registers */
     const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
     const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
-    const uint64_t prog_a = ((uint64_t)__builtin_amdgcn_readfirstlane(ipa32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipa32[0]);
-    const uint64_t prog_b = ((uint64_t)__builtin_amdgcn_readfirstlane(ipb32[1]) << 32) | __builtin_amdgcn_readfirstlane(ipb32[0]);
+    const uint64_t prog_a = ((uint64_t)rfl32(ipa32[1]) << 32) | rfl32(ipa32[0]);
+    const uint64_t prog_b = ((uint64_t)rfl32(ipb32[1]) << 32) | rfl32(ipb32[0]);
     const uint32_t prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
 
     /* private LDS slice */
@@ -172,7 +187,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     uint32_t* bm_all = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* bm_ess = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* bm_ne = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
-    uint32_t* bm_r = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* lh = reinterpret_cast<uint32_t*>(base + off); off += (size_t)XGM_OR_HIST * 4;
     uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
@@ -208,27 +222,36 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     const uint64_t sparse_mask = present_mask & ~dense_mask;
     /* MaxScore order: terms by ascending weight upper bound; prefix_reg = sum of the bounds up to and
      * including this term's.  rank_reg = position in that order. */
-    double prefix_reg = 0.0, ub_reg = 0.0;
+    double prefix_reg = 0.0, ub_reg = 0.0, ub1_reg = 0.0;
     uint32_t rank_reg = 0;
     const bool no_sum = (prune_flags & 4) != 0;                    /* A/B: term-level MaxScore only */
     if (lane < T) {
         const double my = q.ub[lane];
         ub_reg = my;
+        /* without a wdf >= 2 bitmap every document of the term is bounded by the term's maximum */
+        ub1_reg = (dense_reg != kNoDense && seg.dense_plane) ? q.ub1[lane] : my;
         for (uint32_t j = 0; j < T; ++j) {
             const double uj = q.ub[j];
             if (uj < my || (uj == my && j <= lane)) { prefix_reg += uj; ++rank_reg; }
         }
         prefix_reg *= 1.000000001;                                 /* covers the rounding of any summation order */
     }
-    /* the term with the largest bound drives phase A; its prefix is the bound of any document's weight */
+    /* the prefix of the term with the largest bound is the bound of any document's weight */
     const uint64_t top_mask = __ballot(present_reg && rank_reg == T);
     const uint32_t r_term = top_mask ? (uint32_t)__builtin_ctzll(top_mask) : 0u;
-    const uint64_t mp_bits = top_mask ? (((uint64_t)__builtin_amdgcn_readlane((uint32_t)((uint64_t)__double_as_longlong(prefix_reg) >> 32), r_term) << 32) |
-                                         __builtin_amdgcn_readlane((uint32_t)(uint64_t)__double_as_longlong(prefix_reg), r_term)) : 0ull;
+    const uint64_t mp_bits = top_mask ? rl64((uint64_t)__double_as_longlong(prefix_reg), r_term) : 0ull;
     const int hbase = (int)(mp_bits >> kHistShift) - (int)(XGM_OR_HIST - 1u);
     const bool prune = (prune_flags & 1) && top_mask != 0ull && hbase > 0 && !empty;
-    const bool two_phase = prune && (prune_flags & 2) && __popcll(present_mask) >= 2;
     uint32_t* hist_g = hist_all + (size_t)wk.qi * XGM_OR_HIST;
+    /* the planner's guess of the final k-th weight, rounded DOWN to a histogram bucket edge (k documents at or above it then lift the
+     * histogram's bound to exactly it); none when it falls below the histogram's range */
+    uint64_t seed_bits = 0;
+    if (prune && (prune_flags & 2) && !no_sum) {
+        const uint64_t sb = (uint64_t)__double_as_longlong(q.theta_seed) >> kHistShift;
+        const uint32_t sb_lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const int sbk = (int)sb_lo - hbase;
+        if (sbk >= 1) seed_bits = (uint64_t)(sbk > (int)XGM_OR_HIST - 1 ? (uint32_t)hbase + XGM_OR_HIST - 1u : sb_lo) << kHistShift;
+    }
 
     /* block ranges of every block-decoded term inside the unit's docid range -> run table */
     for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
@@ -248,7 +271,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     }
     wave_lds_fence();
     auto tbase = [&](uint32_t t) {
-        return ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(tbase_reg >> 32), t) << 32) | __builtin_amdgcn_readlane((uint32_t)tbase_reg, t);
+        return rl64(tbase_reg, t);
     };
     /* the first kOrwRegSparse block-decoded terms get pipelined header registers */
     uint32_t sp_t[kOrwRegSparse];
@@ -299,6 +322,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 
     uint32_t stripe_base = 0;
     uint32_t hc_cur = 0;
+    /* second pass (the guess was too high): the first pass's quantities, to recognise the documents it weighed */
+    bool fix = false;
+    uint64_t essA_mask = 0;
+    uint32_t qA2_reg = 0, qA1_reg = 0, q_neA = 0;
 
     unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};           /* diagnostics: cycles per section */
     unsigned long long tmark = (XGM_ORW_TIMERS && phase_cycles) ? __builtin_readcyclecounter() : 0ull;
@@ -356,6 +383,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
             const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
             uint32_t subqs = 0;
+            uint32_t sumA = 0;                                     /* second pass: the first pass's quantised bound sum of this document */
+            bool essA_hit = false, neA_hit = false;
             double weight;
             if (T <= 8u) {
                 /* leaves and tree in registers: the node program is wave-uniform (SGPRs), so an operand is an
@@ -379,6 +408,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             wt[u] = ev[u] ? x : -0.0;
                             subqs += ev[u] ? 1u : 0u;
                             if (ev[u] && !((dense_mask >> (g * 4u + u)) & 1ull)) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
+                            if (fix && g * 4u + u < T) {
+                                const uint32_t t = g * 4u + u;
+                                if ((dense_mask >> t) & 1ull) sumA += ev[u] ? (ev[u] >= 3u ? __builtin_amdgcn_readlane(qA2_reg, t) : __builtin_amdgcn_readlane(qA1_reg, t)) : 0u;
+                                else if (ev[u]) { if ((essA_mask >> t) & 1ull) essA_hit = true; else neA_hit = true; }
+                            }
                         }
                     }
 #pragma unroll
@@ -406,6 +440,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             const double x = q.termweight[(t0 + u) & (XGM_MAX_TERMS - 1u)] * (wdf / denom);
                             wt[u] = ev[u] ? x : -0.0;
                             subqs += ev[u] ? 1u : 0u;
+                            if (fix && t0 + u < T) {
+                                const uint32_t t = t0 + u;
+                                if ((dense_mask >> t) & 1ull) sumA += ev[u] ? (ev[u] >= 3u ? __builtin_amdgcn_readlane(qA2_reg, t) : __builtin_amdgcn_readlane(qA1_reg, t)) : 0u;
+                                else if (ev[u]) { if ((essA_mask >> t) & 1ull) essA_hit = true; else neA_hit = true; }
+                            }
                         }
                     }
     #pragma unroll
@@ -425,7 +464,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             }
             const uint64_t wb = (uint64_t)__double_as_longlong(weight);
             ORW_PH(10);
-            const bool live = valid && subqs != 0u && wb >= theta_glob;
+            /* weighed by the first pass: its bound sum reached the guess (the same quantised sum, document by document) */
+            const bool in_first = fix && (essA_hit || sumA + (neA_hit ? q_neA : 0u) >= kQ);
+            const bool live = valid && subqs != 0u && wb >= theta_glob && !in_first;
             if (prune && live) {
                 int b = (int)(wb >> kHistShift) - hbase;
                 b = b < 0 ? 0 : (b > (int)XGM_OR_HIST - 1 ? (int)XGM_OR_HIST - 1 : b);
@@ -440,17 +481,74 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         }
     };
 
-    for (uint32_t phase = two_phase ? 0u : 1u; phase < 2u; ++phase) {
-        const bool phase_a = phase == 0u;
-        const bool split = two_phase && !phase_a;                  /* phase B after an A: r_term's documents are done */
-        const uint64_t memb_mask = phase_a ? (1ull << r_term) : present_mask;
+    /* quantised bounds for a threshold th (> 0): which terms are essential (MaxScore over all terms), per lane t the quantised bound of
+     * term t at its largest wdf (q2) and at wdf = 1 (q1), and that of the non-essential block-decoded terms together.
+     * Quantised UP: q >= ub * kQ / th, so sum(q) >= kQ whenever sum(ub) >= th */
+    auto quantise = [&](uint64_t th_bits, uint64_t& ess, uint32_t& q2, uint32_t& q1, uint32_t& qne) {
+        const double th = __longlong_as_double((long long)th_bits);
+        ess = __ballot(present_reg && !(prefix_reg < th));
+        const double r2 = ub_reg * (double)kQ / th, r1 = ub1_reg * (double)kQ / th;
+        q2 = r2 >= (double)kQ ? kQ : (uint32_t)r2 + 1u;
+        q1 = r1 >= (double)kQ ? kQ : (uint32_t)r1 + 1u;
+        double ne_sum = 0.0;
+        for (uint64_t sm = sparse_mask & ~ess; sm; sm &= sm - 1u) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+            ne_sum += rl_f64(ub_reg, t);
+        }
+        const double rn = ne_sum * (double)kQ / th;
+        qne = ne_sum > 0.0 ? (rn >= (double)kQ ? kQ : (uint32_t)rn + 1u) : 0u;
+    };
+    /* the histogram's bound of the final k-th weight: highest bucket with >= k documents at or above it */
+    auto hist_bound = [&](const uint32_t* hc) {
+        const uint32_t s4 = hc[0] + hc[1] + hc[2] + hc[3];
+        const uint32_t P = wave_incl_scan(s4);
+        const uint32_t suf = __builtin_amdgcn_readlane(P, 63) - P + s4;       /* documents in buckets >= 4 * lane */
+        const uint64_t okm = __ballot(suf >= k);
+        if (okm) {
+            const uint32_t Lh = 63u - (uint32_t)__builtin_clzll(okm);
+            const uint32_t cum = __builtin_amdgcn_readlane(suf, Lh) - __builtin_amdgcn_readlane(s4, Lh);
+            uint32_t bsel = 4u * Lh;
+            const uint32_t c3 = __builtin_amdgcn_readlane(hc[3], Lh), c2 = __builtin_amdgcn_readlane(hc[2], Lh), c1 = __builtin_amdgcn_readlane(hc[1], Lh);
+            if (cum + c3 >= k) bsel = 4u * Lh + 3u;
+            else if (cum + c3 + c2 >= k) bsel = 4u * Lh + 2u;
+            else if (cum + c3 + c2 + c1 >= k) bsel = 4u * Lh + 1u;
+            if (bsel > 0u) {
+                const uint64_t tb = (uint64_t)((uint32_t)hbase + bsel) << kHistShift;
+                theta_glob = tb > theta_glob ? tb : theta_glob;
+            }
+        }
+    };
+
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+        if (pass == 1u) {
+            /* was the guess too high?  Only if fewer than k documents of the whole query are known at or above it */
+            if (!seed_bits || empty) break;
+            if (lh_dirty) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    const uint32_t v = lh[lane * 4u + i];
+                    if (v) { atomicAdd(&hist_g[lane * 4u + i], v); lh[lane * 4u + i] = 0; }
+                }
+                lh_dirty = false;
+                wave_lds_fence();
+            }
+            uint32_t hc[4];
+            if (TALLY) { cn_aux += XGM_OR_HIST; }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hist_bound(hc);
+            const uint64_t th_now = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
+            if (th_now >= seed_bits) break;
+            fix = true;
+            quantise(seed_bits, essA_mask, qA2_reg, qA1_reg, q_neA);
+        }
 
         auto next_active = [&](uint32_t from) {
-            if (dense_mask & memb_mask) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere */
+            if (dense_mask) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere */
             uint32_t x = from;
             for (; x < n_local; ++x) {
                 bool any = false;
-                for (uint64_t sm = sparse_mask & memb_mask; sm; sm &= sm - 1u) {
+                for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
                     const uint32_t t = (uint32_t)__builtin_ctzll(sm);
                     any = any || (re[t * SPG + x] != rs[t * SPG + x]);
                 }
@@ -485,7 +583,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             /* ---- 1a. dense terms: union of the containers' bitmaps (4 words per lane) and, once a
              * threshold is known, the bit-sliced sum of the present terms' quantised weight bounds:
              * plane j of S holds bit j of min(sum, 63) for 32 documents, ovf = the sum reached kQ. ---- */
-            uint32_t a[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0}, rb[4] = {0, 0, 0, 0};
+            uint32_t a[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
             uint32_t S[6][4], ovf[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t j = 0; j < 6u; ++j) { S[j][0] = S[j][1] = S[j][2] = S[j][3] = 0; }
@@ -513,94 +611,115 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     ovf[i] |= carry;
                 }
             };
+            /* documents of B get q1v, those also in P (wdf >= 2) get q2v >= q1v: one ripple pass, the addend of plane j chosen by the
+             * (wave-uniform) bits j of the two values */
+            auto add_bound2 = [&](uint32_t q1v, uint32_t q2v, const uint32_t* B, const uint32_t* P) {
+                if (q1v >= kQ || q1v == q2v) { add_bound(q1v, B); return; }
+                uint32_t lo[4];
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) lo[i] = B[i] & ~P[i];
+                if (q2v >= kQ) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= P[i];
+                    add_bound(q1v, lo);
+                    return;
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {
+                    uint32_t carry = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 6u; ++j) {
+                        const uint32_t sj = S[j][i];
+                        const uint32_t b1 = (q1v >> j) & 1u, b2 = (q2v >> j) & 1u;
+                        if (b1 | b2) {
+                            const uint32_t ad = (b1 & b2) ? B[i] : (b1 ? lo[i] : P[i]);
+                            const uint32_t xo = sj ^ ad;
+                            S[j][i] = xo ^ carry;
+                            carry = (sj & ad) | (carry & xo);
+                        } else {
+                            S[j][i] = sj ^ carry;
+                            carry &= sj;
+                        }
+                    }
+                    ovf[i] |= carry;
+                }
+            };
             uint64_t ess_mask = present_mask;                       /* block-decoded terms whose documents are all candidates */
             bool use_sum = false;                                   /* candidates of the dense terms come from the bound sum */
-            uint32_t q_reg = kQ;                                    /* lane t: quantised bound of term t */
+            uint32_t q2_reg = kQ, q1_reg = kQ;                      /* lane t: quantised bounds of term t */
             uint32_t q_ne = 0;                                      /* ... of the non-essential block-decoded terms together */
             bool first_group = true;
-            for (uint64_t dm = dense_mask & memb_mask; dm || first_group;) {
-                uint32_t tt[4], oo[4];
-                uint32_t x[4][4];
+            bool stop = false;
+            for (uint64_t dm = dense_mask; dm || first_group;) {
+                uint32_t tt[XGM_ORW_GROUP], oo[XGM_ORW_GROUP];
+                uint32_t x[XGM_ORW_GROUP][4], pl[XGM_ORW_GROUP][4];
+                /* the wdf >= 2 bitmaps are wanted once there is a threshold; the very first group is requested before this
+                 * stripe's threshold is known: decide by the last one (a threshold never falls) */
+                const bool want_planes = prune && !no_sum && seg.dense_plane != 0u && (fix || seed_bits || theta_valid || theta_glob);
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
+                for (uint32_t u = 0; u < XGM_ORW_GROUP; ++u) {
                     tt[u] = 0; oo[u] = 0;
                     if (dm) { tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u; oo[u] = __builtin_amdgcn_readlane(hc_cur, tt[u]); }
-                    if (TALLY) { if (oo[u]) cn_bmpw += NW; }
+                    if (TALLY) { if (oo[u]) cn_bmpw += want_planes ? 2u * NW : NW; }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
-                        x[u][i] = 0;
+                        x[u][i] = 0; pl[u][i] = 0;
                         const uint32_t w = lane * 4u + i;
-                        if (oo[u] && w < NW) x[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16)[w];
+                        if (oo[u] && w < NW) {
+                            x[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16)[w];
+                            if (want_planes) pl[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16 + seg.dense_plane)[w];
+                        }
                     }
                 }
                 if (first_group) {
                     first_group = false;
                     /* the histogram loads were issued before the bitmaps': consume them while those fly */
                     if (prune) {
-                        const uint32_t s4 = hc[0] + hc[1] + hc[2] + hc[3];
-                        const uint32_t P = wave_incl_scan(s4);
-                        const uint32_t suf = __builtin_amdgcn_readlane(P, 63) - P + s4;       /* documents in buckets >= 4 * lane */
-                        const uint64_t okm = __ballot(suf >= k);
-                        if (okm) {
-                            const uint32_t Lh = 63u - (uint32_t)__builtin_clzll(okm);
-                            const uint32_t cum = __builtin_amdgcn_readlane(suf, Lh) - __builtin_amdgcn_readlane(s4, Lh);
-                            uint32_t bsel = 4u * Lh;
-                            const uint32_t c3 = __builtin_amdgcn_readlane(hc[3], Lh), c2 = __builtin_amdgcn_readlane(hc[2], Lh), c1 = __builtin_amdgcn_readlane(hc[1], Lh);
-                            if (cum + c3 >= k) bsel = 4u * Lh + 3u;
-                            else if (cum + c3 + c2 >= k) bsel = 4u * Lh + 2u;
-                            else if (cum + c3 + c2 + c1 >= k) bsel = 4u * Lh + 1u;
-                            if (bsel > 0u) {
-                                const uint64_t tb = (uint64_t)((uint32_t)hbase + bsel) << kHistShift;
-                                theta_glob = tb > theta_glob ? tb : theta_glob;
-                            }
+                        hist_bound(hc);
+                        uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
+                        if (fix && th_bits >= seed_bits) { stop = true; break; }      /* whatever is left was weighed by the first pass or cannot reach the top k */
+                        if (!fix && seed_bits > th_bits) th_bits = seed_bits;
+                        if (th_bits) {
+                            quantise(th_bits, ess_mask, q2_reg, q1_reg, q_ne);
+                            use_sum = !no_sum;
                         }
-                        if (phase_a) {
-                            ess_mask = 1ull << r_term;
-                        } else {
-                            const uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
-                            if (th_bits) {
-                                const double th = __longlong_as_double((long long)th_bits);
-                                ess_mask = __ballot(present_reg && !(prefix_reg < th));      /* MaxScore over all terms */
-                                use_sum = !no_sum;
-                                /* quantise UP: q >= ub * kQ / th, so sum(q) >= kQ whenever sum(ub) >= th */
-                                const double rq = ub_reg * (double)kQ / th;
-                                q_reg = rq >= (double)kQ ? kQ : (uint32_t)rq + 1u;
-                                double ne_sum = 0.0;
-                                for (uint64_t sm = sparse_mask & ~ess_mask; sm; sm &= sm - 1u) {
-                                    const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-                                    const uint64_t ubits = (uint64_t)__double_as_longlong(ub_reg);
-                                    ne_sum += __longlong_as_double((long long)(((uint64_t)__builtin_amdgcn_readlane((uint32_t)(ubits >> 32), t) << 32) |
-                                                                               __builtin_amdgcn_readlane((uint32_t)ubits, t)));
-                                }
-                                const double rn = ne_sum * (double)kQ / th;
-                                q_ne = ne_sum > 0.0 ? (rn >= (double)kQ ? kQ : (uint32_t)rn + 1u) : 0u;
+                        if (XGM_ORW_DEBUG && TALLY && !fix && sl == 0u) {
+                            dbg_th0 = th_bits;
+                            for (uint32_t t = 0; t < 8u && t < T; ++t) {
+                                dbg_q1 |= (unsigned long long)(__builtin_amdgcn_readlane(q1_reg, t) & 127u) << (8u * t);
+                                dbg_q2 |= (unsigned long long)(__builtin_amdgcn_readlane(q2_reg, t) & 127u) << (8u * t);
                             }
+                            dbg_q2 |= (unsigned long long)(want_planes ? 1u : 0u) << 63;
+                            dbg_q1 |= (unsigned long long)(use_sum ? 1u : 0u) << 63;
                         }
                     }
                 }
 #pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const bool is_r = tt[u] == r_term;
+                for (uint32_t u = 0; u < XGM_ORW_GROUP; ++u) {
 #pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) { a[i] |= x[u][i]; if (is_r) rb[i] |= x[u][i]; }
-                    if (use_sum && oo[u]) add_bound(__builtin_amdgcn_readlane(q_reg, tt[u]), x[u]);
+                    for (uint32_t i = 0; i < 4u; ++i) a[i] |= x[u][i];
+                    if (use_sum && oo[u]) {
+                        const uint32_t qa = __builtin_amdgcn_readlane(q1_reg, tt[u]), qb = __builtin_amdgcn_readlane(q2_reg, tt[u]);
+                        if (want_planes) add_bound2(qa, qb, x[u], pl[u]);
+                        else add_bound(qb, x[u]);                  /* no wdf >= 2 bitmap at hand: every document at the term's maximum */
+                    }
                 }
             }
+            if (stop) break;
             ORW_PH(0);
-            const uint64_t sp_memb = sparse_mask & memb_mask;
             uint32_t es[4] = {0, 0, 0, 0}, ne[4] = {0, 0, 0, 0};   /* unions of the essential / other block-decoded terms */
-            if (sp_memb) {
+            if (sparse_mask) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
                     const uint32_t w = lane * 4u + i;
-                    if (w < NW) { bm_all[w] = a[i]; bm_ess[w] = 0; bm_ne[w] = 0; bm_r[w] = rb[i]; }
+                    if (w < NW) { bm_all[w] = a[i]; bm_ess[w] = 0; bm_ne[w] = 0; }
                 }
                 wave_lds_fence();
                 /* ---- 1b. block-decoded terms: every block of the stripe ---- */
                 uint64_t bmask[kOrwRegSparse];
 #pragma unroll
                 for (uint32_t u = 0; u < kOrwRegSparse; ++u)
-                    bmask[u] = (u < n_sp && ((sp_memb >> sp_t[u]) & 1ull)) ? (cnb[u] >= 64u ? ~0ull : ((1ull << cnb[u]) - 1ull)) : 0ull;
+                    bmask[u] = u < n_sp ? (cnb[u] >= 64u ? ~0ull : ((1ull << cnb[u]) - 1ull)) : 0ull;
                 while (true) {
                     uint64_t any = 0;
 #pragma unroll
@@ -627,10 +746,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         if (have[u])
                             orw_block<TabT, false>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
                                                    stripe_base, bm_all, ((ess_mask >> sp_t[u]) & 1ull) ? bm_ess : bm_ne,
-                                                   sp_t[u] == r_term ? bm_r : nullptr, rankw, c_w, 0u, 0u);
+                                                   nullptr, rankw, c_w, 0u, 0u);
                     }
                 }
-                for (uint64_t sm = slow_sparse_mask & memb_mask; sm; sm &= sm - 1u) {
+                for (uint64_t sm = slow_sparse_mask; sm; sm &= sm - 1u) {
                     const uint32_t t = (uint32_t)__builtin_ctzll(sm);
                     const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
                     for (uint32_t j = 0; j < nb; ++j) {
@@ -639,21 +758,18 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         Words4 pv = Words4{0, 0, 0, 0};
                         if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
                         orw_block<TabT, false>(pv, meta, first, stage, lane, stripe_base, bm_all, ((ess_mask >> t) & 1ull) ? bm_ess : bm_ne,
-                                               t == r_term ? bm_r : nullptr, rankw, c_w, 0u, 0u);
+                                               nullptr, rankw, c_w, 0u, 0u);
                     }
                 }
                 wave_lds_fence();
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
                     const uint32_t w = lane * 4u + i;
-                    if (w < NW) { a[i] = bm_all[w]; es[i] = bm_ess[w]; ne[i] = bm_ne[w]; rb[i] = bm_r[w]; }
+                    if (w < NW) { a[i] = bm_all[w]; es[i] = bm_ess[w]; ne[i] = bm_ne[w]; }
                 }
             }
             /* ---- candidates ---- */
-            if (phase_a) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) e[i] = rb[i];
-            } else if (use_sum) {
+            if (use_sum) {
                 if (q_ne) add_bound(q_ne, ne);
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) e[i] = es[i] | ovf[i];
@@ -674,11 +790,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) e[i] = a[i];
             }
-            if (split) {
-                /* r_term's documents were weighed in phase A */
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) e[i] &= ~rb[i];
-            }
             /* the scatter of the block-decoded terms looks candidates up in bm_ess */
             if (sparse_mask) {
 #pragma unroll
@@ -689,11 +800,16 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             }
             ORW_PH(1);
 
-            /* ---- exact match count (phase B); candidates in docid order ---- */
-            if (!phase_a) matches += (unsigned long long)(__popc(a[0]) + __popc(a[1]) + __popc(a[2]) + __popc(a[3]));
+            /* ---- exact match count (first pass); candidates in docid order ---- */
+            if (!fix) matches += (unsigned long long)(__popc(a[0]) + __popc(a[1]) + __popc(a[2]) + __popc(a[3]));
             const uint32_t cnt = (uint32_t)(__popc(e[0]) + __popc(e[1]) + __popc(e[2]) + __popc(e[3]));
             const uint32_t incl = wave_incl_scan(cnt);
             const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
+            if (TALLY) {
+                if (fix) cn_fixw += n_total; else if (sl == 0u) cn_first += n_total;
+                const uint32_t ce = wave_incl_scan((uint32_t)(__popc(es[0]) + __popc(es[1]) + __popc(es[2]) + __popc(es[3])));
+                if (!fix) cn_es += __builtin_amdgcn_readlane(ce, 63);
+            }
             if (n_total == 0u) {
                 if (sl_next < n_local) issue_headers(sl_next);
                 sl = sl_next;
@@ -859,8 +975,13 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         xgm_group_hdr h;
         h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
-        h.c_pos = 0; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
-        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = h.c_pad[1] = 0;
+        if (XGM_ORW_DEBUG && TALLY) {
+            h.t_start = (unsigned long long)__double_as_longlong(q.theta_seed); h.t_end = mp_bits;
+            h.matches = ((unsigned long long)(uint32_t)hbase << 32) | (uint32_t)(seed_bits >> 32);
+            h.c_pos = ((unsigned long long)(prune ? 1u : 0u) << 62) | ((unsigned long long)(uint32_t)prune_flags << 32) | (uint32_t)(dbg_th0 >> 32);
+        }
+        h.c_pos = ((unsigned long long)(fix ? 1u : 0u) << 63) | cn_es; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
+        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = cn_fixw; h.c_pad[1] = cn_first;
         ghdr_out[wk.slot] = h;
     }
 #undef XGM_SU
@@ -901,6 +1022,8 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
     static const bool no_sum = getenv("XGM_NO_BOUND_SUM") != nullptr;
     static const bool timing = getenv("XGM_PHASE_TIMING") != nullptr;
     if (timing && !g_orw_cycles) { hipMalloc((void**)&g_orw_cycles, 128); hipMemset(g_orw_cycles, 0, 128); }
+    /* bit 0: prune; bit 1: start from the planner's guess of the k-th weight (XGM_NO_PHASE_A keeps its old name: no seeded first pass);
+     * bit 2: term-level MaxScore only, no bound sum (then no guess either) */
     const int flags = no_prune ? 0 : ((no_phase_a ? 1 : 3) | (no_sum ? 4 : 0));
     const size_t smem = xgm_orw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);

@@ -100,7 +100,8 @@ typedef struct {
     uint32_t n_stripes;
     uint32_t dense_pos;             /* the containers end with u32 pos_base[W/64]: position-entry offset (relative to the term) of the
                                        first posting of each 64-slot bucket — the positional filter on the probe path */
-    uint32_t pad_;
+    uint32_t dense_plane;           /* byte offset inside a container of u32 bits2[W/32]: the documents whose wdf is >= 2 — the disjunction's
+                                       weight bound of a (document, term) is then the wdf = 1 bound or the term's maximum (0: no plane) */
 } xgm_seg_dev;
 
 #define XGM_DENSE_MIN_AVG 32u          /* postings per stripe (on average) that make a term dense     */

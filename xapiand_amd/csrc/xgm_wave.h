@@ -22,6 +22,13 @@ __device__ __forceinline__ uint32_t dpp0(uint32_t v) {
 
 /* Inclusive prefix sum over the 64 lanes: 4 row_shr steps inside each 16-lane row, then
  * row_bcast:15 / row_bcast:31 to carry across rows (CDNA DPP). */
+/* __builtin_amdgcn_readlane / readfirstlane return a SIGNED int: OR-ing a low half into a 64-bit value sign-extends it and
+ * wipes the high half whenever bit 31 is set.  Always go through these. */
+__device__ __forceinline__ uint32_t rl32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ __forceinline__ uint32_t rfl32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t rl64(uint64_t v, uint32_t lane) { return ((uint64_t)rl32((uint32_t)(v >> 32), lane) << 32) | (uint64_t)rl32((uint32_t)v, lane); }
+__device__ __forceinline__ double rl_f64(double v, uint32_t lane) { return __longlong_as_double((long long)rl64((uint64_t)__double_as_longlong(v), lane)); }
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     v += dpp0<0x111, 0xf>(v);
     v += dpp0<0x112, 0xf>(v);
