@@ -58,20 +58,6 @@ def close(self):
         print("ORQ with a block-decoded term (rank > 1800):", len(sp), "weighed", sum(r[0] for r in sp), "; without:", len(rows) - len(sp), "weighed", tot_w - sum(r[0] for r in sp))
         for r in rows[:12] + rows[len(rows) // 2 - 4:len(rows) // 2 + 4] + rows[-8:]:
             print("ORQ weighed %8d matches %8d (%.4f) units %3d kcycles %7d ranks %s" % (r[0], r[1], r[0] / max(1, r[1]), r[2], r[3] // 1000, r[4]))
-        if os.environ.get("ORQ_DEBUG"):
-            want = [sorted(int(x) for x in w.split(",")) for w in os.environ["ORQ_DEBUG"].split(";")]
-            for qi in sorted(per):
-                ranks = sorted(int(t[1:]) for t in pool[lo + qi]["terms"])
-                if ranks not in want:
-                    continue
-                print("ORQ DEBUG query", qi, "terms in plan order", pool[lo + qi]["terms"])
-                import struct
-                f64 = lambda b: struct.unpack("<d", struct.pack("<Q", int(b) & 0xFFFFFFFFFFFFFFFF))[0]
-                idxs = np.nonzero(a[:, 0] == qi)[0][:3]
-                for i in idxs:
-                    u = a[i]
-                    print("ORQ DEBUG  unit stripes", int(u[1]), int(u[2]), "weighed", int(u[7]), "theta_seed", f64(u[4]), "mp", f64(u[5]), "hbase", int(u[6]) >> 32, "seed_bits", f64((int(u[6]) & 0xFFFFFFFF) << 32),
-                          "prune", (int(cp[i]) >> 62) & 1, "flags", (int(cp[i]) >> 32) & 0xFF, "th0", f64((int(cp[i]) & 0xFFFFFFFF) << 32))
         # per unit: weighed in the first vs later stripes cannot be separated; print the distribution of weighed per unit
         w = a[:, 7].astype(np.float64); st = (a[:, 2] - a[:, 1]).astype(np.float64)
         print("ORQ per unit: weighed mean %.0f p50 %.0f p95 %.0f max %.0f; stripes mean %.1f; weighed per stripe mean %.1f" % (w.mean(), np.median(w), np.percentile(w, 95), w.max(), st.mean(), (w / np.maximum(1, st)).mean()))

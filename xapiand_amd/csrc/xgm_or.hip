@@ -63,9 +63,6 @@ constexpr uint32_t kOrwCand = XGM_ORW_CAND;   /* candidates per scoring chunk */
 #ifndef XGM_ORW_GROUP
 #define XGM_ORW_GROUP 5             /* dense terms whose bitmaps (+ wdf >= 2 bitmaps) are in flight together */
 #endif
-#ifndef XGM_ORW_DEBUG
-#define XGM_ORW_DEBUG 0             /* tools/orq.py: first-stripe threshold and quantised bounds in the unit headers (corrupts the match counts) */
-#endif
 #ifndef XGM_ORW_TIMERS
 #define XGM_ORW_TIMERS 0            /* section timers cost ~30 VGPRs: A/B builds only (tools/ab_build.sh) */
 #endif
@@ -144,6 +141,13 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
 
 typedef double orw_d8 __attribute__((ext_vector_type(8)));
 
+/* (mask & a) | (~mask & b): v_bfi_b32.  With mask = x ^ y: the majority of (x, y, a) when b = x — the carry of a full adder. */
+__device__ __forceinline__ uint32_t orw_bfi(uint32_t mask, uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+
 template <typename TabT, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
@@ -163,7 +167,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
     uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
     uint32_t cn_first = 0, cn_fixw = 0, cn_es = 0;
-    unsigned long long dbg_th0 = 0, dbg_q1 = 0, dbg_q2 = 0;               /* diagnostics (tools/orq.py): weighed in the unit's first stripe / in the second pass; documents of essential block-decoded terms */
     /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
     auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
         const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
@@ -235,6 +238,16 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             if (uj < my || (uj == my && j <= lane)) { prefix_reg += uj; ++rank_reg; }
         }
         prefix_reg *= 1.000000001;                                 /* covers the rounding of any summation order */
+    }
+    /* the dense terms in ascending order of their bounds, 4 bits each (the bound sum adds them in this order) */
+    uint64_t dense_ord = 0;
+    uint32_t n_dense_ord = 0;
+    for (uint32_t p = 1; p <= T; ++p) {
+        const uint64_t m = __ballot(lane < T && rank_reg == p);
+        if (m) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(m);
+            if ((dense_mask >> t) & 1ull) { dense_ord |= (uint64_t)t << (4u * n_dense_ord); ++n_dense_ord; }
+        }
     }
     /* the prefix of the term with the largest bound is the bound of any document's weight */
     const uint64_t top_mask = __ballot(present_reg && rank_reg == T);
@@ -587,28 +600,46 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             uint32_t S[6][4], ovf[4] = {0, 0, 0, 0};
 #pragma unroll
             for (uint32_t j = 0; j < 6u; ++j) { S[j][0] = S[j][1] = S[j][2] = S[j][3] = 0; }
+            /* S += qv on the documents of B.  Planes outermost: the addend of plane j is chosen once (wave-uniform bit j of qv) for the
+             * lane's four words; planes the running maximum of the sum cannot reach are not touched (max_sum: the largest value any
+             * document's sum can have so far — terms are added in ascending order of their bounds, so the early ones stay low) */
+            uint32_t max_sum = 0;
+            auto planes_for = [&](uint32_t add) {
+                const uint32_t nm = max_sum + add;
+                max_sum = nm < kQ ? nm : kQ;
+                return nm >= kQ ? 6u : 32u - (uint32_t)__builtin_clz(nm | 1u);
+            };
             auto add_bound = [&](uint32_t qv, const uint32_t* B) {
                 if (qv >= kQ) {
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= B[i];
                     return;
                 }
+                const uint32_t np = planes_for(qv);
+                uint32_t carry[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    uint32_t carry = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 6u; ++j) {
-                        const uint32_t sj = S[j][i];
+                for (uint32_t j = 0; j < 6u; ++j) {
+                    if (j < np) {
                         if ((qv >> j) & 1u) {
-                            const uint32_t xo = sj ^ B[i];
-                            S[j][i] = xo ^ carry;
-                            carry = (sj & B[i]) | (carry & xo);
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) {
+                                const uint32_t sj = S[j][i], xo = sj ^ B[i];
+                                S[j][i] = xo ^ carry[i];
+                                carry[i] = orw_bfi(xo, carry[i], sj);  /* majority(sj, B, carry): the carry of a full adder */
+                            }
                         } else {
-                            S[j][i] = sj ^ carry;
-                            carry &= sj;
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) {
+                                const uint32_t sj = S[j][i];
+                                S[j][i] = sj ^ carry[i];
+                                carry[i] &= sj;
+                            }
                         }
                     }
-                    ovf[i] |= carry;
+                }
+                if (np == 6u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= carry[i];
                 }
             };
             /* documents of B get q1v, those also in P (wdf >= 2) get q2v >= q1v: one ripple pass, the addend of plane j chosen by the
@@ -624,24 +655,33 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     add_bound(q1v, lo);
                     return;
                 }
+                const uint32_t np = planes_for(q2v);
+                uint32_t carry[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    uint32_t carry = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 6u; ++j) {
-                        const uint32_t sj = S[j][i];
+                for (uint32_t j = 0; j < 6u; ++j) {
+                    if (j < np) {
                         const uint32_t b1 = (q1v >> j) & 1u, b2 = (q2v >> j) & 1u;
                         if (b1 | b2) {
-                            const uint32_t ad = (b1 & b2) ? B[i] : (b1 ? lo[i] : P[i]);
-                            const uint32_t xo = sj ^ ad;
-                            S[j][i] = xo ^ carry;
-                            carry = (sj & ad) | (carry & xo);
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) {
+                                const uint32_t ad = (b1 & b2) ? B[i] : (b1 ? lo[i] : P[i]);
+                                const uint32_t sj = S[j][i], xo = sj ^ ad;
+                                S[j][i] = xo ^ carry[i];
+                                carry[i] = orw_bfi(xo, carry[i], sj);
+                            }
                         } else {
-                            S[j][i] = sj ^ carry;
-                            carry &= sj;
+#pragma unroll
+                            for (uint32_t i = 0; i < 4u; ++i) {
+                                const uint32_t sj = S[j][i];
+                                S[j][i] = sj ^ carry[i];
+                                carry[i] &= sj;
+                            }
                         }
                     }
-                    ovf[i] |= carry;
+                }
+                if (np == 6u) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= carry[i];
                 }
             };
             uint64_t ess_mask = present_mask;                       /* block-decoded terms whose documents are all candidates */
@@ -650,7 +690,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             uint32_t q_ne = 0;                                      /* ... of the non-essential block-decoded terms together */
             bool first_group = true;
             bool stop = false;
-            for (uint64_t dm = dense_mask; dm || first_group;) {
+            for (uint32_t dp = 0; dp < n_dense_ord || first_group;) {
                 uint32_t tt[XGM_ORW_GROUP], oo[XGM_ORW_GROUP];
                 uint32_t x[XGM_ORW_GROUP][4], pl[XGM_ORW_GROUP][4];
                 /* the wdf >= 2 bitmaps are wanted once there is a threshold; the very first group is requested before this
@@ -659,7 +699,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 #pragma unroll
                 for (uint32_t u = 0; u < XGM_ORW_GROUP; ++u) {
                     tt[u] = 0; oo[u] = 0;
-                    if (dm) { tt[u] = (uint32_t)__builtin_ctzll(dm); dm &= dm - 1u; oo[u] = __builtin_amdgcn_readlane(hc_cur, tt[u]); }
+                    if (dp < n_dense_ord) { tt[u] = (uint32_t)(dense_ord >> (4u * dp)) & 15u; ++dp; oo[u] = rl32(hc_cur, tt[u]); }
                     if (TALLY) { if (oo[u]) cn_bmpw += want_planes ? 2u * NW : NW; }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
@@ -682,15 +722,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         if (th_bits) {
                             quantise(th_bits, ess_mask, q2_reg, q1_reg, q_ne);
                             use_sum = !no_sum;
-                        }
-                        if (XGM_ORW_DEBUG && TALLY && !fix && sl == 0u) {
-                            dbg_th0 = th_bits;
-                            for (uint32_t t = 0; t < 8u && t < T; ++t) {
-                                dbg_q1 |= (unsigned long long)(__builtin_amdgcn_readlane(q1_reg, t) & 127u) << (8u * t);
-                                dbg_q2 |= (unsigned long long)(__builtin_amdgcn_readlane(q2_reg, t) & 127u) << (8u * t);
-                            }
-                            dbg_q2 |= (unsigned long long)(want_planes ? 1u : 0u) << 63;
-                            dbg_q1 |= (unsigned long long)(use_sum ? 1u : 0u) << 63;
                         }
                     }
                 }
@@ -975,11 +1006,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         xgm_group_hdr h;
         h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
-        if (XGM_ORW_DEBUG && TALLY) {
-            h.t_start = (unsigned long long)__double_as_longlong(q.theta_seed); h.t_end = mp_bits;
-            h.matches = ((unsigned long long)(uint32_t)hbase << 32) | (uint32_t)(seed_bits >> 32);
-            h.c_pos = ((unsigned long long)(prune ? 1u : 0u) << 62) | ((unsigned long long)(uint32_t)prune_flags << 32) | (uint32_t)(dbg_th0 >> 32);
-        }
         h.c_pos = ((unsigned long long)(fix ? 1u : 0u) << 63) | cn_es; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
         h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = cn_fixw; h.c_pad[1] = cn_first;
         ghdr_out[wk.slot] = h;
