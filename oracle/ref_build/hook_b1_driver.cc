@@ -52,6 +52,7 @@ int main(int argc, char** argv) {
         auto queries = read_queries(argv[a]);
         std::vector<Xapian::Database> dbs;
         std::vector<xgm_index*> idx;
+        std::vector<std::string> seg_files;
         for (int i = a + 1; i < argc; ++i) {
             dbs.emplace_back(argv[i]);
             char seg[64];
@@ -60,18 +61,21 @@ int main(int argc, char** argv) {
             xgm_index* h = nullptr;
             const uint64_t rev = dbs.back().get_revision();
             if (xgm_index_open(seg, 0, rev, &h) != XGM_OK) { fprintf(stderr, "xgm_index_open: %s\n", xgm_last_error()); return 1; }
-            unlink(seg);
+            seg_files.push_back(seg);                 /* kept: the incremental refresh starts from it */
             idx.push_back(h);
             xgm_hook::register_shard(dbs.back(), h);
         }
         unsigned refreshed = 0;
-        auto export_and_register = [&](size_t i, const char* dir) -> int {
+        /* the shard moved on: refresh its segment INCREMENTALLY — documents below first_changed come from the old segment, only
+         * the rest is read from glass (xgm_segment_refresh_from_glass; byte-identical to a full export, tests/test_glass.py) */
+        auto export_and_register = [&](size_t i, const char* dir, uint32_t first_changed) -> int {
             char seg[64];
-            snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%zu.seg", (int)getpid(), i);
-            if (xgm_segment_build_from_glass(dir, 0, seg) != XGM_OK) { fprintf(stderr, "export %s: %s\n", dir, xgm_last_error()); return 1; }
+            snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%zu_r.seg", (int)getpid(), i);
+            if (xgm_segment_refresh_from_glass(seg_files[i].c_str(), dir, first_changed, 0, seg) != XGM_OK) { fprintf(stderr, "refresh %s: %s\n", dir, xgm_last_error()); return 1; }
             xgm_index* h = nullptr;
             if (xgm_index_open(seg, 0, dbs[i].get_revision(), &h) != XGM_OK) { fprintf(stderr, "xgm_index_open: %s\n", xgm_last_error()); return 1; }
-            unlink(seg);
+            unlink(seg_files[i].c_str());
+            seg_files[i] = seg;
             if (idx[i]) xgm_index_close(idx[i]);
             idx[i] = h;
             xgm_hook::register_shard(dbs[i], h);
@@ -81,7 +85,9 @@ int main(int argc, char** argv) {
             /* The shards move on to a new revision behind the registered segments (one more document each, committed
              * through the reference's WritableDatabase); the re-opened Database handles then carry a revision the
              * registry does not know: every search must be DECLINED (CPU matcher) ... */
+            std::vector<uint32_t> first_changed;
             for (size_t i = 0; i < dbs.size(); ++i) {
+                first_changed.push_back(dbs[i].get_lastdocid() + 1);            /* documents are only appended below */
                 {
                     Xapian::WritableDatabase w(argv[a + 1 + i], Xapian::DB_OPEN);
                     Xapian::Document doc;
@@ -101,7 +107,7 @@ int main(int argc, char** argv) {
                 return 1;
             }
             /* ... until the refreshed segments (keyed by the new revision) are registered */
-            for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i])) return 1; ++refreshed; }
+            for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i], first_changed[i])) return 1; ++refreshed; }
         }
         unsigned bad = 0, bounds_bad = 0;
         const bool percents = dbs.size() == 1;
@@ -133,6 +139,7 @@ int main(int argc, char** argv) {
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed);
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
+        for (const std::string& f : seg_files) unlink(f.c_str());
         return (bad || bounds_bad) ? 1 : 0;
     } catch (const Xapian::Error& e) {
         fprintf(stderr, "Xapian error: %s\n", e.get_description().c_str());

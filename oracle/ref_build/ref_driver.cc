@@ -254,6 +254,46 @@ int cmd_build_range(int argc, char** argv) {
     return 0;
 }
 
+/* append <dbdir> <seed> <g_first> <g_last> <vocab> <len_lo> <len_hi> [<mutate_from>]: open an existing database, add the corpus
+ * documents g_first..g_last (their docids continue after the current last docid) and — with mutate_from — delete every 7th and
+ * replace every 11th document whose docid is >= mutate_from; one commit.  What a shard looks like one revision later
+ * (tests of the incremental segment refresh). */
+int cmd_append(int argc, char** argv) {
+    if (argc < 9) return 2;
+    xgm_corpus_params cp;
+    cp.seed = strtoull(argv[3], nullptr, 0);
+    const uint64_t g0 = strtoull(argv[4], nullptr, 0), g1 = strtoull(argv[5], nullptr, 0);
+    cp.vocab = (uint32_t)strtoul(argv[6], nullptr, 0);
+    cp.len_lo = (uint32_t)strtoul(argv[7], nullptr, 0);
+    cp.len_hi = (uint32_t)strtoul(argv[8], nullptr, 0);
+    const Xapian::docid mutate_from = argc > 9 ? (Xapian::docid)strtoul(argv[9], nullptr, 0) : 0;
+    std::vector<uint64_t> thr(cp.vocab);
+    xgm_zipf_thresholds(cp.vocab, thr.data());
+    Xapian::WritableDatabase db(argv[2], Xapian::DB_OPEN | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
+    char name[16];
+    auto make = [&](uint64_t g) {
+        Xapian::Document doc;
+        const uint32_t len = xgm_doc_len(&cp, g);
+        for (uint32_t pos = 1; pos <= len; ++pos) {
+            snprintf(name, sizeof name, "t%u", xgm_token(&cp, thr.data(), g, pos));
+            doc.add_posting(name, pos);
+        }
+        return doc;
+    };
+    const Xapian::docid last_before = db.get_lastdocid();
+    if (mutate_from) {
+        for (Xapian::docid d = mutate_from; d <= last_before; ++d) {
+            if (d % 7 == 0) db.delete_document(d);
+            else if (d % 11 == 0) db.replace_document(d, make(1000000ull + d));
+        }
+    }
+    for (uint64_t g = g0; g <= g1; ++g) db.add_document(make(g));
+    db.commit();
+    printf("{\"doccount\": %u, \"lastdocid\": %u, \"revision\": %" PRIu64 ", \"last_before\": %u}\n", db.get_doccount(), db.get_lastdocid(),
+           (uint64_t)db.get_revision(), last_before);
+    return 0;
+}
+
 /* info <dbdir> [term ...]: the statistics bounds the reference's weighting schemes see (Database::get_doclength_lower_bound,
  * get_wdf_upper_bound(term) — glass keeps them in its version file and never tightens them on delete / replace). */
 int cmd_info(int argc, char** argv) {
@@ -470,6 +510,7 @@ int main(int argc, char** argv) {
         else if (cmd == "export") rc = cmd_export(argc, argv);
         else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
         else if (cmd == "build_range") rc = cmd_build_range(argc, argv);
+        else if (cmd == "append") rc = cmd_append(argc, argv);
         else if (cmd == "compact") rc = cmd_compact(argc, argv);
         else if (cmd == "info") rc = cmd_info(argc, argv);
         if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());

@@ -99,3 +99,46 @@ def test_statistics_bounds_are_glass_own(built, tmp_path):
         _lib.check(_lib.lib().xgm_lookup_term(h, t.encode(), len(t), None, None, None, C.byref(ub)))
         assert ub.value == ref["wdf_upper_bound"][t], t
     _lib.lib().xgm_index_close(h)
+
+
+@pytest.mark.parametrize("mutate", [False, True])
+def test_incremental_refresh_equals_full_export(built, tmp_path, mutate):
+    """A shard one revision later — documents appended (and, second case, documents at or above a floor deleted / replaced):
+    the segment refreshed from the OLD segment + only the changed part of glass is byte for byte the full export of the new
+    revision; a floor that breaks the contract (a changed document below it) is refused."""
+    db = str(tmp_path / "db")
+    H.xapian_ref("build", db, H.CORPUS_SEED, 9000, 40000, 50, 150)
+    L = _lib.lib()
+    seg1 = str(tmp_path / "rev1.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, seg1.encode()))
+    floor = 6001 if mutate else 9001
+    import json
+    out = json.loads(H.xapian_ref("append", db, H.CORPUS_SEED, 20001, 23000, 40000, 50, 150, *([floor] if mutate else [])))
+    assert out["last_before"] == 9000 and out["lastdocid"] == 12000
+    full, inc = str(tmp_path / "rev2_full.seg"), str(tmp_path / "rev2_inc.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
+    _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), floor, 0, inc.encode()))
+    assert open(full, "rb").read() == open(inc, "rb").read()
+    # floor 1 = nothing taken from the old segment: still the same bytes
+    _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 1, 0, inc.encode()))
+    assert open(full, "rb").read() == open(inc, "rb").read()
+    if mutate:
+        # documents 6006 (deleted) / 6017 (replaced) changed: a floor above them must be refused, not silently produce another index
+        assert L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 9001, 0, inc.encode()) == _lib.XGM_E_INVALID
+    assert L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 9500, 0, inc.encode()) == _lib.XGM_E_INVALID   # beyond the old segment
+
+
+def test_incremental_refresh_keeps_format_corners(built, tmp_path):
+    """The old part holds what the segment cannot give back verbatim — terms whose positions were dropped (postings without
+    positions, boolean terms), zero bytes in terms, long docid gaps: the refreshed segment is still the full export's."""
+    db = str(tmp_path / "misc")
+    H.xapian_ref("build_misc", db)
+    L = _lib.lib()
+    seg1 = str(tmp_path / "rev1.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, seg1.encode()))
+    import json
+    out = json.loads(H.xapian_ref("append", db, H.CORPUS_SEED, 1, 400, 3000, 20, 60))
+    full, inc = str(tmp_path / "rev2_full.seg"), str(tmp_path / "rev2_inc.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
+    _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), out["last_before"] + 1, 0, inc.encode()))
+    assert open(full, "rb").read() == open(inc, "rb").read()

@@ -278,11 +278,12 @@ struct Export {
 
 /* a chunk body: bool is_last, varint(last - first), wdf of the first entry, then (did increase - 1, wdf) pairs */
 template <class F>
-int read_chunk_body(const uint8_t* p, const uint8_t* end, uint64_t first_did, F&& entry) {
+int read_chunk_body(const uint8_t* p, const uint8_t* end, uint64_t first_did, F&& entry, uint64_t min_did = 0) {
     if (p >= end || (uint8_t)(*p - '0') > 1) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: bad header");
     ++p;
     uint64_t span, w;
     if (!get_varint(&p, end, &span) || !get_varint(&p, end, &w)) return xgm_set_error(XGM_E_INVALID, "glass postlist chunk: truncated header");
+    if (first_did + span < min_did) return XGM_OK;                 /* the whole chunk lies below the floor: its header says so, nothing is decoded */
     uint64_t d = first_did;
     entry(d, w);
     while (p < end) {
@@ -295,7 +296,9 @@ int read_chunk_body(const uint8_t* p, const uint8_t* end, uint64_t first_did, F&
     return XGM_OK;
 }
 
-int read_glass(const char* glass_dir, Export* ex) {
+/* min_did > 0: postings and positions of documents below it are skipped (whole chunks by their header, position lists by
+ * their key) — the incremental refresh takes those from the previous segment.  Document lengths are always read in full. */
+int read_glass(const char* glass_dir, Export* ex, uint64_t min_did = 0) {
     const std::string dir(glass_dir);
     int rc = read_version(dir, &ex->ver);
     if (rc) return rc;
@@ -346,10 +349,11 @@ int read_glass(const char* glass_dir, Export* ex) {
             if (!get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &first)) return xgm_set_error(XGM_E_INVALID, "postlist: bad chunk key");
         }
         return read_chunk_body(p, end, first, [&](uint64_t d, uint64_t w) {
+            if (d < min_did) return;
             ex->did.push_back((uint32_t)d);
             ex->wdf.push_back((uint32_t)w);
             ++ex->df.back();
-        });
+        }, min_did);
     });
     if (rc) return rc;
 
@@ -368,6 +372,7 @@ int read_glass(const char* glass_dir, Export* ex) {
             split_term_key(key, &t, &rest);
             uint64_t d;
             if (!rest || !get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &d)) return xgm_set_error(XGM_E_INVALID, "position table: bad key");
+            if (d < min_did) return XGM_OK;
             /* advance the posting cursor to (t, d); postings passed over have no positions */
             while (true) {
                 if (ti >= ex->terms.size()) return xgm_set_error(XGM_E_INVALID, "position table: entry without a posting");
@@ -448,6 +453,141 @@ extern "C" int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stri
     xgm_raw_postings raw;
     fill_raw(ex, &tp, &tl, &raw);
     return xgm_segment_build(&raw, stripe_bits, out_path);
+}
+
+/* ---- incremental refresh ---------------------------------------------------------------------- */
+
+namespace {
+
+inline uint32_t seg_bits(const uint32_t* w, uint64_t idx, uint32_t bw) {
+    if (bw == 0) return 0;
+    const uint64_t bit = idx * bw;
+    const uint64_t v = (uint64_t)w[bit >> 5] | ((uint64_t)w[(bit >> 5) + 1] << 32);
+    return (uint32_t)((v >> (bit & 31)) & (bw == 32 ? 0xFFFFFFFFull : ((1ull << bw) - 1)));
+}
+
+}  // namespace
+
+int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob);
+
+/* Refresh a shard's segment after the shard moved to a newer revision, re-reading from glass only what changed.
+ * Contract (the caller's — Xapiand knows the smallest docid its write-ahead log touched since the old revision, reference
+ * src/database/wal.cc): every document below first_changed_docid is the same in the old segment's revision and in glass now.
+ * Postings and positions of those documents come from the old segment (bit-unpacking at memory speed: no B-tree walk, no varint
+ * or interpolative decoding); glass is read for the rest, whole posting chunks and position lists below the floor being skipped
+ * by their headers / keys.  The merged postings go through the ordinary builder, so the result is byte for byte what a full
+ * xgm_segment_build_from_glass of the new revision writes.  A cheap part of the contract is checked (document lengths below the
+ * floor must agree): XGM_E_INVALID then means "do a full export".  Replaces: the reference reopening the shard on a revision
+ * change (src/database/handler.cc:1282, 1333 — DatabaseModifiedError / reopen). */
+extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, const char* glass_dir, uint32_t first_changed_docid,
+                                              uint32_t stripe_bits, const char* out_path) {
+    if (!old_segment_path || !glass_dir || !out_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    XgmSegmentBlob old;
+    int rc = xgm_read_segment_file(old_segment_path, &old);
+    if (rc) return rc;
+    if ((rc = xgm_validate_blob(old))) return rc;
+    const xgm_seg_header* h = old.header();
+    const uint64_t X = first_changed_docid;
+    if (X > (uint64_t)h->lastdocid + 1) return xgm_set_error(XGM_E_INVALID, "first_changed_docid %u beyond the old segment's last docid %u + 1", first_changed_docid, h->lastdocid);
+    Export ex;
+    if ((rc = read_glass(glass_dir, &ex, X))) return rc;
+    if (ex.ver.revision < h->revision) return xgm_set_error(XGM_E_INVALID, "glass revision %llu is older than the segment's %llu", (unsigned long long)ex.ver.revision, (unsigned long long)h->revision);
+    const uint32_t* odl = old.section<uint32_t>(XGM_S_DOCLEN);
+    for (uint64_t d = 1; d < X; ++d)
+        if (d >= ex.doclen.size() || odl[d] != ex.doclen[d]) return xgm_set_error(XGM_E_INVALID, "document %llu below first_changed_docid differs from the old segment: full export needed", (unsigned long long)d);
+
+    /* old dictionary + block tables */
+    const uint32_t oT = h->n_terms;
+    const uint64_t* so = old.section<uint64_t>(XGM_S_STR_OFF);
+    const char* sb = old.section<char>(XGM_S_STR_BYTES);
+    const uint32_t* oflags = old.section<uint32_t>(XGM_S_TERM_FLAGS);
+    const uint64_t* tb = old.section<uint64_t>(XGM_S_TERM_BLK);
+    const uint64_t* tw = old.section<uint64_t>(XGM_S_TERM_WORD);
+    const uint64_t* tp = old.section<uint64_t>(XGM_S_TERM_POS);
+    const uint32_t* bf = old.section<uint32_t>(XGM_S_BLK_FIRST);
+    const uint32_t* bm = old.section<uint32_t>(XGM_S_BLK_META);
+    const uint32_t* bwd = old.section<uint32_t>(XGM_S_BLK_WORD);
+    const uint32_t* bps = old.section<uint32_t>(XGM_S_BLK_POS);
+    const uint32_t* words = old.section<uint32_t>(XGM_S_WORDS);
+    const uint8_t* opos = old.section<uint8_t>(XGM_S_POSITIONS);
+
+    Export mg;                                   /* merged: old postings below the floor, then glass's */
+    mg.ver = ex.ver;
+    mg.doclen.swap(ex.doclen);
+    mg.has_positions = ex.has_positions;
+    mg.doccount = ex.doccount; mg.total_length = ex.total_length;
+    if (mg.has_positions) mg.pos_off.assign(1, 0);
+    uint64_t np = 0;                             /* cursor into ex's postings */
+    uint32_t oi = 0;
+    size_t ni = 0;
+    auto old_term = [&](uint32_t t) { return std::string(sb + so[t], (size_t)(so[t + 1] - so[t])); };
+    /* appends old term t's postings below the floor; returns how many */
+    auto take_old = [&](uint32_t t) -> uint32_t {
+        uint32_t n = 0;
+        const bool have_pos = h->has_positions && (oflags[t] & XGM_TF_POS_OK);
+        const bool dropped = h->has_positions && !(oflags[t] & XGM_TF_POS_OK);   /* (a shard that had no position table at all: every old posting truly has none) */
+        const bool p16 = (oflags[t] & XGM_TF_POS16) != 0;
+        bool marked = false;                     /* a term whose positions the old segment dropped (some posting had positions != wdf)
+                                                    must come out position-less again: give its first posting a count that cannot match */
+        for (uint64_t b = tb[t]; b < tb[t + 1] && bf[b] < X; ++b) {
+            const uint32_t cnt = XGM_META_COUNT(bm[b]), bwg = XGM_META_BWG(bm[b]), bww = XGM_META_BWW(bm[b]);
+            const uint32_t* gw = words + tw[t] + bwd[b];
+            const uint32_t* ww = gw + ((uint64_t)cnt * bwg + 31) / 32;
+            uint32_t d = bf[b];
+            uint64_t pe = bps[b];                /* position entry of the posting inside the term's array */
+            for (uint32_t j = 0; j < cnt; ++j) {
+                if (j) d += seg_bits(gw, j, bwg) + 1;
+                const uint32_t w = seg_bits(ww, j, bww);
+                if (d >= X) break;
+                mg.did.push_back(d); mg.wdf.push_back(w); ++n;
+                if (mg.has_positions) {
+                    if (have_pos) {
+                        for (uint32_t q = 0; q < w; ++q) {
+                            const uint8_t* e = opos + tp[t] + (pe + q) * (p16 ? 2u : 4u);
+                            mg.pos.push_back(p16 ? (uint32_t)e[0] | ((uint32_t)e[1] << 8) : (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24));
+                        }
+                    } else if (dropped && !marked) {
+                        for (uint32_t q = 0; q <= w; ++q) mg.pos.push_back(1u + q);
+                        marked = true;
+                    }
+                    mg.pos_off.push_back(mg.pos.size());
+                }
+                pe += w;
+            }
+        }
+        return n;
+    };
+    auto take_new = [&](size_t i) -> uint32_t {
+        const uint32_t n = ex.df[i];
+        for (uint32_t k = 0; k < n; ++k) {
+            mg.did.push_back(ex.did[np + k]); mg.wdf.push_back(ex.wdf[np + k]);
+            if (mg.has_positions) {
+                for (uint64_t q = ex.pos_off[np + k]; q < ex.pos_off[np + k + 1]; ++q) mg.pos.push_back(ex.pos[q]);
+                mg.pos_off.push_back(mg.pos.size());
+            }
+        }
+        np += n;
+        return n;
+    };
+    while (oi < oT || ni < ex.terms.size()) {
+        int c;
+        std::string ot;
+        if (oi < oT) ot = old_term(oi);
+        if (oi >= oT) c = 1;
+        else if (ni >= ex.terms.size()) c = -1;
+        else c = ot.compare(ex.terms[ni]);
+        uint32_t n = 0;
+        std::string name;
+        if (c < 0) { name = ot; n = take_old(oi++); }
+        else if (c > 0) { name = ex.terms[ni]; n = take_new(ni++); }
+        else { name = ot; n = take_old(oi++); n += take_new(ni++); }
+        if (n) { mg.terms.push_back(name); mg.df.push_back(n); }
+    }
+    std::vector<const char*> tpv;
+    std::vector<uint32_t> tl;
+    xgm_raw_postings raw;
+    fill_raw(mg, &tpv, &tl, &raw);
+    return xgm_segment_build(&raw, stripe_bits ? stripe_bits : h->stripe_bits, out_path);
 }
 
 extern "C" int xgm_glass_info(const char* glass_dir, uint64_t* revision, uint32_t* doccount, uint32_t* lastdocid, uint64_t* total_length) {
