@@ -33,13 +33,10 @@ def close(self):
     n = L.xgm_debug_last_units2(self._h, buf, pos, cap)
     if n > 0:
         a = np.array(buf[:8 * n], dtype=np.uint64).reshape(n, 8)
-        cp = np.array(pos[:n], dtype=np.uint64)
-        fixed = (cp >> np.uint64(63)).astype(np.int64)
-        n_es = (cp & np.uint64(0xFFFFFFFF)).astype(np.int64)
-        fixw = (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        fixed = ((a[:, 3] >> np.uint64(31)) & np.uint64(1)).astype(np.int64)
+        fixw = (a[:, 3] & np.uint64(0x7FFFFFFF)).astype(np.int64)
         firstw = (a[:, 3] >> np.uint64(32)).astype(np.int64)
-        print("ORQ units", n, "went round again", int(fixed.sum()), "weighed in second passes", int(fixw.sum()), "weighed in the units' first stripe", int(firstw.sum()),
-              "documents of essential block-decoded terms", int(n_es.sum()))
+        print("ORQ units", n, "went round again", int(fixed.sum()), "weighed in second passes", int(fixw.sum()), "weighed in the units' first stripe", int(firstw.sum()))
         pool = H.bench_pool(arg("--op", "AND"), int(arg("--terms", 3)), int(arg("--required", 1)), 10_000_000, 1_000_000, seed=bench.QUERY_SEED)
         nb = (len(pool) - 100) // bench.BATCH
         lo = 100 + (nb - 1) * bench.BATCH                     # the tally loop's last batch is the last launch

@@ -699,15 +699,19 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         }
         total_cost += cost[i];
     }
-    double unit_cost = std::max(1.0, total_cost / (wave_units ? 12288.0 : 3072.0));
+    /* units per launch: ~3 per wave slot of the chip (4 waves per SIMD for the conjunction kernel; the disjunction kernel runs 2 and
+     * pays a longer prologue per unit) */
+    static const double orw_units = getenv("XGM_ORW_UNITS") ? atof(getenv("XGM_ORW_UNITS")) : 8192.0;      /* A/B switch for measurements */
+    const double target_units = bp->orw ? orw_units : 12288.0;
+    double unit_cost = std::max(1.0, total_cost / (wave_units ? target_units : 3072.0));
     if (wave_units) {
         /* the floor of g_min units per query (the LDS table bounds a unit's stripes) eats part of the budget: raise the
          * unit cost until the batch fits ~12288 units again (3 per wave slot of the chip) */
         for (int it = 0; it < 8; ++it) {
             double units = 0;
             for (uint32_t i = 0; i < nq; ++i) units += std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
-            if (units <= 12288.0 * 1.03) break;
-            unit_cost *= std::max(1.02, units / 12288.0);
+            if (units <= target_units * 1.03) break;
+            unit_cost *= std::max(1.02, units / target_units);
         }
     }
     bp->goff.assign(nq + 1, 0);

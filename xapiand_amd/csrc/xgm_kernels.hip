@@ -1158,6 +1158,9 @@ constexpr uint32_t kAndwCandPlain = 512;             /* candidates per chunk = 4
 constexpr uint32_t kAndwCandPhrase = 128;            /* with the position offsets and the K6 staging area: 1 block (3 workgroups per CU at 3 terms) */
 #ifndef XGM_ANDW_WAVES
 #define XGM_ANDW_WAVES 4           /* min waves per SIMD the register allocator must allow */
+#endif
+#ifndef XGM_PHRASE_WAVES
+#define XGM_PHRASE_WAVES 3         /* ... of the positional instantiation (A/B: tools/ab_build.sh) */
 #endif                  /* top-k buffer cap 256 */
 
 __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, size_t tab_elem, uint32_t spg, bool phrase, bool sided) {
@@ -1223,7 +1226,7 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
  * instantiations, so that the plain conjunction pays nothing for them. */
 template <typename TabT, bool PHRASE, int SIDED, bool TALLY>
-__global__ __launch_bounds__(XGM_WG, PHRASE ? 3 : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+__global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                               xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {

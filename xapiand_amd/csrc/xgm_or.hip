@@ -67,6 +67,7 @@ constexpr uint32_t kOrwCand = XGM_ORW_CAND;   /* candidates per scoring chunk */
 #define XGM_ORW_TIMERS 0            /* section timers cost ~30 VGPRs: A/B builds only (tools/ab_build.sh) */
 #endif
 constexpr uint32_t kOrwRegSparse = XGM_ORW_REGSPARSE;   /* block-decoded terms whose headers are software-pipelined */
+static_assert(kOrwRegSparse >= 1u && kOrwRegSparse <= 2u, "the per-term decode of xgm_orw_kernel picks between two header register sets");
 constexpr uint32_t kNoDense = 0xFFFFFFFFu;
 constexpr uint32_t kQ = 64;              /* quantisation of a weight bound relative to the threshold  */
 constexpr uint32_t kHistShift = 47;      /* weight bits >> 47: sign, exponent, 5 mantissa bits         */
@@ -77,7 +78,7 @@ __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_
     off += T > 8u ? (size_t)T * 64 * 8 : 0;                    /* val: per-lane leaf / node weights (queries of > 8 terms only: fewer sum in registers) */
     off += (size_t)cap * 4;                                    /* tk_d */
     off += (size_t)kStageWords * 4;                            /* stage */
-    off += (size_t)(W / 32u) * 4 * 3;                          /* bm_all, bm_ess, bm_ne */
+    off += (size_t)(W / 32u) * 4 * 2;                          /* bm_ess, bm_ne */
     off += (size_t)XGM_OR_HIST * 4;                            /* lh: the wave's pending histogram counts */
     off += (size_t)2 * T * spg * 4;                            /* runs */
     off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
@@ -110,7 +111,7 @@ __device__ void orw_topk_sort(uint64_t* w, uint32_t* d, uint8_t* m, uint32_t cap
 }
 
 /* One posting block: payload (already loaded, 4 words per lane) -> LDS window -> two postings per lane.
- * SCATTER == false: set the docids' bits in bm_a and, when not null, bm_b / bm_c.
+ * SCATTER == false: set the docids' bits in bm_a and, for postings whose wdf is >= 2, in bm_b (bm_c: unused).
  * SCATTER == true : for postings that are candidates of the current chunk (bit set in bm_a, word in
  *                   [wlo, whi)), store wdf+1 at the candidate's ordinal in `row`. */
 template <typename TabT, bool SCATTER>
@@ -130,8 +131,7 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
         const uint32_t s = (h ? r.d1 : r.d0) - stripe_base, wd = s >> 5, bit = s & 31u;
         if (!SCATTER) {
             atomicOr(&bm_a[wd], 1u << bit);
-            if (bm_b) atomicOr(&bm_b[wd], 1u << bit);
-            if (bm_c) atomicOr(&bm_c[wd], 1u << bit);
+            if ((h ? r.w1 : r.w0) >= 2u) atomicOr(&bm_b[wd], 1u << bit);
         } else if (wd >= wlo && wd < whi) {
             const uint32_t bm = bm_a[wd];
             if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)((h ? r.w1 : r.w0) + 1u);
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
     /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
     uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
-    uint32_t cn_first = 0, cn_fixw = 0, cn_es = 0;
+    uint32_t cn_first = 0, cn_fixw = 0;
     /* lanes hold ascending keys: how many distinct (key >> sh) values = memory sectors does one gather round touch? */
     auto tally_sectors = [&](bool valid, uint32_t key, uint32_t sh) {
         const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
@@ -187,7 +187,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     double* val = reinterpret_cast<double*>(base + off); off += tab_terms > 8u ? (size_t)tab_terms * 64 * 8 : 0;
     uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
     uint32_t* stage = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kStageWords * 4;
-    uint32_t* bm_all = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* bm_ess = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* bm_ne = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
     uint32_t* lh = reinterpret_cast<uint32_t*>(base + off); off += (size_t)XGM_OR_HIST * 4;
@@ -232,7 +231,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         const double my = q.ub[lane];
         ub_reg = my;
         /* without a wdf >= 2 bitmap every document of the term is bounded by the term's maximum */
-        ub1_reg = (dense_reg != kNoDense && seg.dense_plane) ? q.ub1[lane] : my;
+        ub1_reg = (dense_reg != kNoDense && !seg.dense_plane) ? my : q.ub1[lane];     /* (block-decoded terms: the decode itself tells wdf = 1 from wdf >= 2) */
         for (uint32_t j = 0; j < T; ++j) {
             const double uj = q.ub[j];
             if (uj < my || (uj == my && j <= lane)) { prefix_reg += uj; ++rank_reg; }
@@ -397,7 +396,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
             uint32_t subqs = 0;
             uint32_t sumA = 0;                                     /* second pass: the first pass's quantised bound sum of this document */
-            bool essA_hit = false, neA_hit = false;
             double weight;
             if (T <= 8u) {
                 /* leaves and tree in registers: the node program is wave-uniform (SGPRs), so an operand is an
@@ -423,8 +421,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             if (ev[u] && !((dense_mask >> (g * 4u + u)) & 1ull)) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
                             if (fix && g * 4u + u < T) {
                                 const uint32_t t = g * 4u + u;
-                                if ((dense_mask >> t) & 1ull) sumA += ev[u] ? (ev[u] >= 3u ? __builtin_amdgcn_readlane(qA2_reg, t) : __builtin_amdgcn_readlane(qA1_reg, t)) : 0u;
-                                else if (ev[u]) { if ((essA_mask >> t) & 1ull) essA_hit = true; else neA_hit = true; }
+                                sumA += ev[u] ? (ev[u] >= 3u ? rl32(qA2_reg, t) : rl32(qA1_reg, t)) : 0u;
                             }
                         }
                     }
@@ -455,8 +452,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             subqs += ev[u] ? 1u : 0u;
                             if (fix && t0 + u < T) {
                                 const uint32_t t = t0 + u;
-                                if ((dense_mask >> t) & 1ull) sumA += ev[u] ? (ev[u] >= 3u ? __builtin_amdgcn_readlane(qA2_reg, t) : __builtin_amdgcn_readlane(qA1_reg, t)) : 0u;
-                                else if (ev[u]) { if ((essA_mask >> t) & 1ull) essA_hit = true; else neA_hit = true; }
+                                sumA += ev[u] ? (ev[u] >= 3u ? rl32(qA2_reg, t) : rl32(qA1_reg, t)) : 0u;
                             }
                         }
                     }
@@ -478,7 +474,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const uint64_t wb = (uint64_t)__double_as_longlong(weight);
             ORW_PH(10);
             /* weighed by the first pass: its bound sum reached the guess (the same quantised sum, document by document) */
-            const bool in_first = fix && (essA_hit || sumA + (neA_hit ? q_neA : 0u) >= kQ);
+            const bool in_first = fix && sumA >= kQ;
             const bool live = valid && subqs != 0u && wb >= theta_glob && !in_first;
             if (prune && live) {
                 int b = (int)(wb >> kHistShift) - hbase;
@@ -587,7 +583,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 
             /* ---- global threshold: highest histogram bucket with >= k documents at or above it ---- */
             uint32_t hc[4] = {0, 0, 0, 0};
-            if (prune) {
+            /* once a threshold is known it moves slowly: the query-wide histogram is read (and, below, fed) every fourth stripe only */
+            const bool have_th = seed_bits || theta_valid || theta_glob;
+            const bool look = prune && (fix || !have_th || (sl & 3u) == 0u);
+            if (look) {
                 if (TALLY) { cn_aux += XGM_OR_HIST; }
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -715,7 +714,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     first_group = false;
                     /* the histogram loads were issued before the bitmaps': consume them while those fly */
                     if (prune) {
-                        hist_bound(hc);
+                        if (look) hist_bound(hc);
                         uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
                         if (fix && th_bits >= seed_bits) { stop = true; break; }      /* whatever is left was weighed by the first pass or cannot reach the top k */
                         if (!fix && seed_bits > th_bits) th_bits = seed_bits;
@@ -738,72 +737,68 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             }
             if (stop) break;
             ORW_PH(0);
-            uint32_t es[4] = {0, 0, 0, 0}, ne[4] = {0, 0, 0, 0};   /* unions of the essential / other block-decoded terms */
+            uint32_t es[4] = {0, 0, 0, 0};                         /* bound sum switched off (A/B): union of the essential block-decoded terms */
             if (sparse_mask) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint32_t w = lane * 4u + i;
-                    if (w < NW) { bm_all[w] = a[i]; bm_ess[w] = 0; bm_ne[w] = 0; }
-                }
-                wave_lds_fence();
-                /* ---- 1b. block-decoded terms: every block of the stripe ---- */
-                uint64_t bmask[kOrwRegSparse];
-#pragma unroll
-                for (uint32_t u = 0; u < kOrwRegSparse; ++u)
-                    bmask[u] = u < n_sp ? (cnb[u] >= 64u ? ~0ull : ((1ull << cnb[u]) - 1ull)) : 0ull;
-                while (true) {
-                    uint64_t any = 0;
-#pragma unroll
-                    for (uint32_t u = 0; u < kOrwRegSparse; ++u) any |= bmask[u];
-                    if (!any) break;
-                    uint32_t jj[kOrwRegSparse];
-                    Words4 pv[kOrwRegSparse];
-                    bool have[kOrwRegSparse];
-#pragma unroll
-                    for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
-                        have[u] = bmask[u] != 0ull;
-                        jj[u] = 0; pv[u] = Words4{0, 0, 0, 0};
-                        if (have[u]) {
-                            jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
-                            bmask[u] &= bmask[u] - 1u;
-                            const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
-                            if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
-                            if (lane * 4u < payload_words(bm))
-                                pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
-                        }
-                    }
-#pragma unroll
-                    for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
-                        if (have[u])
-                            orw_block<TabT, false>(pv[u], __builtin_amdgcn_readlane(cm[u], jj[u]), __builtin_amdgcn_readlane(cf[u], jj[u]), stage, lane,
-                                                   stripe_base, bm_all, ((ess_mask >> sp_t[u]) & 1ull) ? bm_ess : bm_ne,
-                                                   nullptr, rankw, c_w, 0u, 0u);
-                    }
-                }
-                for (uint64_t sm = slow_sparse_mask; sm; sm &= sm - 1u) {
+                /* ---- 1b. block-decoded terms, one at a time: every block of the stripe is decoded into two LDS bitmaps — the term's
+                 * documents, and those whose wdf is >= 2 — which then join the bound sum exactly like a container's pair ---- */
+                for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
                     const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-                    const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
-                    for (uint32_t j = 0; j < nb; ++j) {
-                        const uint32_t meta = seg.blk_meta[rb0 + j], first = seg.blk_first[rb0 + j];
-                        if (TALLY) { cn_hdr += 1u; cn_blkw += XGM_SU(payload_words(meta)) - 2u; }
-                        Words4 pv = Words4{0, 0, 0, 0};
-                        if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
-                        orw_block<TabT, false>(pv, meta, first, stage, lane, stripe_base, bm_all, ((ess_mask >> t) & 1ull) ? bm_ess : bm_ne,
-                                               nullptr, rankw, c_w, 0u, 0u);
-                    }
-                }
-                wave_lds_fence();
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint32_t w = lane * 4u + i;
-                    if (w < NW) { a[i] = bm_all[w]; es[i] = bm_ess[w]; ne[i] = bm_ne[w]; }
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t w = lane * 4u + i;
+                        if (w < NW) { bm_ess[w] = 0; bm_ne[w] = 0; }
+                    }
+                    wave_lds_fence();
+                    const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
+                    /* the pipelined terms' headers are already in registers (lane j = block j of the run) */
+                    int pu = -1;
+#pragma unroll
+                    for (uint32_t u = 0; u < kOrwRegSparse; ++u) if (u < n_sp && sp_t[u] == t) pu = (int)u;
+                    for (uint32_t j0 = 0; j0 < nb; j0 += 2u) {
+                        uint32_t bmeta[2] = {0, 0}, bfirst[2] = {0, 0};
+                        Words4 pv[2] = {Words4{0, 0, 0, 0}, Words4{0, 0, 0, 0}};
+#pragma unroll
+                        for (uint32_t v = 0; v < 2u; ++v) {
+                            const uint32_t j = j0 + v;
+                            if (j < nb) {
+                                uint32_t bword;
+                                if (pu >= 0 && j < 64u) {
+                                    bmeta[v] = rl32(pu == 0 ? cm[0] : cm[kOrwRegSparse - 1u], j);
+                                    bfirst[v] = rl32(pu == 0 ? cf[0] : cf[kOrwRegSparse - 1u], j);
+                                    bword = rl32(pu == 0 ? cw[0] : cw[kOrwRegSparse - 1u], j);
+                                } else {
+                                    bmeta[v] = seg.blk_meta[rb0 + j]; bfirst[v] = seg.blk_first[rb0 + j]; bword = seg.blk_word[rb0 + j];
+                                    if (TALLY) { cn_hdr += 1u; }
+                                }
+                                if (TALLY) { cn_blkw += XGM_SU(payload_words(bmeta[v])) - 2u; }
+                                if (lane * 4u < payload_words(bmeta[v])) pv[v] = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + bword + lane * 4u);
+                            }
+                        }
+#pragma unroll
+                        for (uint32_t v = 0; v < 2u; ++v)
+                            if (j0 + v < nb) orw_block<TabT, false>(pv[v], bmeta[v], bfirst[v], stage, lane, stripe_base, bm_ess, bm_ne, nullptr, rankw, c_w, 0u, 0u);
+                    }
+                    wave_lds_fence();
+                    uint32_t xb[4] = {0, 0, 0, 0}, xp[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const uint32_t w = lane * 4u + i;
+                        if (w < NW) { xb[i] = bm_ess[w]; xp[i] = bm_ne[w]; }
+                    }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) a[i] |= xb[i];
+                    if (use_sum) add_bound2(rl32(q1_reg, t), rl32(q2_reg, t), xb, xp);
+                    else if ((ess_mask >> t) & 1ull) {
+#pragma unroll
+                        for (uint32_t i = 0; i < 4u; ++i) es[i] |= xb[i];
+                    }
+                    wave_lds_fence();
                 }
             }
             /* ---- candidates ---- */
             if (use_sum) {
-                if (q_ne) add_bound(q_ne, ne);
 #pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) e[i] = es[i] | ovf[i];
+                for (uint32_t i = 0; i < 4u; ++i) e[i] = ovf[i];
             } else if (prune && ess_mask != present_mask) {
                 /* the bound sum is switched off (A/B): every document of an essential term */
 #pragma unroll
@@ -838,8 +833,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
             if (TALLY) {
                 if (fix) cn_fixw += n_total; else if (sl == 0u) cn_first += n_total;
-                const uint32_t ce = wave_incl_scan((uint32_t)(__popc(es[0]) + __popc(es[1]) + __popc(es[2]) + __popc(es[3])));
-                if (!fix) cn_es += __builtin_amdgcn_readlane(ce, 63);
             }
             if (n_total == 0u) {
                 if (sl_next < n_local) issue_headers(sl_next);
@@ -864,7 +857,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
                         const uint32_t w = lane * 4u + i;
-                        if (w < NW) rankw[w] = (uint16_t)o;
+                        if (sparse_mask && w < NW) rankw[w] = (uint16_t)o;
                         uint32_t m = e[i];
                         while (m) {
                             const uint32_t bit = (uint32_t)__ffs(m) - 1u;
@@ -974,8 +967,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 wave_lds_fence();
                 ORW_PH(5);
             }
-            /* publish this stripe's histogram counts */
-            if (lh_dirty) {
+            /* publish the histogram counts */
+            if (lh_dirty && (fix || !have_th || (sl & 3u) == 2u || sl_next >= n_local)) {
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) {
                     const uint32_t v = lh[lane * 4u + i];
@@ -1006,8 +999,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         xgm_group_hdr h;
         h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
-        h.c_pos = ((unsigned long long)(fix ? 1u : 0u) << 63) | cn_es; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
-        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = cn_fixw; h.c_pad[1] = cn_first;
+        h.c_pos = 0; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
+        h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = (cn_fixw & 0x7FFFFFFFu) | (fix ? 0x80000000u : 0u); h.c_pad[1] = cn_first;
         ghdr_out[wk.slot] = h;
     }
 #undef XGM_SU
