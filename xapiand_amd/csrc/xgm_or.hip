@@ -81,8 +81,9 @@ __host__ __device__ inline size_t orw_wave_bytes(uint32_t W, uint32_t T, uint32_
     off += (size_t)(W / 32u) * 4 * 2;                          /* bm_ess, bm_ne */
     off += (size_t)XGM_OR_HIST * 4;                            /* lh: the wave's pending histogram counts */
     off += (size_t)2 * T * spg * 4;                            /* runs */
+    off += (size_t)T * spg * 4;                                /* dir_tab: container offsets of the dense terms in the unit's stripes */
     off += (size_t)(W / 32u) * 2;                              /* rankw (u16) */
-    off += (size_t)kOrwCand * 2;                               /* c_slot */
+    off += (size_t)kOrwCand * 4;                               /* c_did */
     off += (size_t)T * kOrwCand * tab_elem;                    /* c_w */
     off += (size_t)cap;                                        /* tk_m (u8) */
     return (off + 15) & ~(size_t)15;
@@ -192,8 +193,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     uint32_t* lh = reinterpret_cast<uint32_t*>(base + off); off += (size_t)XGM_OR_HIST * 4;
     uint32_t* rs = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint32_t* re = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
+    uint32_t* dir_tab = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
     uint16_t* rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
-    uint16_t* c_slot = reinterpret_cast<uint16_t*>(base + off); off += (size_t)kOrwCand * 2;
+    uint32_t* c_did = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kOrwCand * 4;   /* the candidate queue: docids (of several stripes) awaiting their weights */
     TabT* c_w = reinterpret_cast<TabT*>(base + off); off += (size_t)tab_terms * kOrwCand * sizeof(TabT);
     uint8_t* tk_m = reinterpret_cast<uint8_t*>(base + off);
 
@@ -314,6 +316,15 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     uint32_t hm[kOrwRegSparse], hf[kOrwRegSparse], hw[kOrwRegSparse], hn[kOrwRegSparse];
 #pragma unroll
     for (uint32_t u = 0; u < kOrwRegSparse; ++u) { hm[u] = hf[u] = hw[u] = 0; hn[u] = 0xFFFFFFFFu; }
+    /* container offsets of every dense term in the unit's stripes (one pass; later lookups — per stripe for the bitmaps, per queued
+     * candidate for its wdf byte — are LDS reads) */
+    for (uint64_t dm = dense_mask; dm; dm &= dm - 1u) {
+        const uint32_t t = (uint32_t)__builtin_ctzll(dm);
+        const uint32_t dr = rl32(dense_reg, t);
+        if (TALLY) { cn_aux += n_local; }
+        for (uint32_t i = lane; i < n_local; i += 64u) dir_tab[t * SPG + i] = seg.dense_dir[(size_t)dr * seg.n_stripes + (s_begin + i)];
+    }
+    wave_lds_fence();
     uint32_t hc_off = 0;
     auto issue_headers = [&](uint32_t x) {
 #pragma unroll
@@ -327,9 +338,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 }
             }
         }
-        hc_off = 0;
-        if (TALLY) { cn_aux += (uint32_t)__popcll(dense_mask); }
-        if (present_reg && dense_reg != kNoDense) hc_off = seg.dense_dir[(size_t)dense_reg * seg.n_stripes + (s_begin + x)];
+        hc_off = (present_reg && dense_reg != kNoDense) ? dir_tab[lane * SPG + x] : 0u;
     };
 
     uint32_t stripe_base = 0;
@@ -351,8 +360,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     auto prefetch_round = [&](uint32_t i0, uint32_t n_c) {
         const uint32_t o = i0 + lane;
         const bool valid = o < n_c;
-        const uint32_t slot = valid ? (uint32_t)c_slot[o] : 0u;
-        pf_dl = valid ? seg.doclen[stripe_base + slot] : 1u;
+        const uint32_t cd = valid ? c_did[o] : 0u;
+        const uint32_t slot = cd & (W - 1u), csl = valid ? (cd >> SB) - s_begin : 0u;      /* slot in its stripe, stripe of the unit */
+        pf_dl = valid ? seg.doclen[cd] : 1u;
         const uint32_t n_valid = n_c - i0 < 64u ? n_c - i0 : 64u;
         const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
         if (TALLY) { cn_dl += tally_sectors(valid, slot, 4u); cn_dl_raw += n_valid; }
@@ -360,9 +370,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         for (uint32_t t = 0; t < 8u; ++t) {
             pf_pb[t] = 0;
             if (fast && ((dense_mask >> t) & 1ull)) {
-                const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t);
-                if (TALLY) { if (oo) { cn_probe += sec; cn_probe_raw += n_valid; } }
-                if (oo && valid) pf_pb[t] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+                const uint32_t oo = valid ? dir_tab[t * SPG + csl] : 0u;           /* the container of the candidate's own stripe */
+                if (TALLY) { cn_probe += sec; cn_probe_raw += n_valid; }
+                if (oo) pf_pb[t] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
             }
         }
     };
@@ -383,7 +393,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             ORW_PH(8);
             const uint32_t o = i0 + lane;
             const bool valid = o < n_c;
-            const uint32_t did = stripe_base + (valid ? (uint32_t)c_slot[o] : 0u);
+            const uint32_t did = valid ? c_did[o] : 0u;
             const uint32_t dlen = pf_dl;
             uint32_t pb[8];
 #pragma unroll
@@ -488,6 +498,19 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             tkn += (uint32_t)__popcll(tm);
             ORW_PH(11);
         }
+    };
+
+    /* The candidate queue: with a threshold in force a stripe leaves a handful of candidates, far fewer than the 64 lanes of a round
+     * of gathers + BM25.  They wait in c_did / c_w (block-decoded terms: their wdf, scattered while the stripe's blocks are at hand)
+     * and are weighed together, in full rounds, once enough stripes have contributed. */
+    uint32_t qn = 0;
+    auto flush_queue = [&]() {
+        if (qn == 0u) return;
+        wave_lds_fence();
+        prefetch_round(0u, qn);
+        score_candidates(qn);
+        wave_lds_fence();
+        qn = 0;
     };
 
     /* quantised bounds for a threshold th (> 0): which terms are essential (MaxScore over all terms), per lane t the quantised bound of
@@ -851,9 +874,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 const bool in_chunk = lane >= lane_lo && lane < lane_hi;
                 const uint32_t wlo = lane_lo * 4u, whi = lane_hi * 4u;
                 lane_lo = lane_hi;
+                if (qn + n_c > kOrwCand) flush_queue();
+                const uint32_t qb = qn;                                /* the chunk's candidates go behind the queued ones */
                 /* ---- 2a. enumerate the chunk's candidates in docid order ---- */
                 if (in_chunk) {
-                    uint32_t o = incl - cnt - ord_base;
+                    uint32_t o = qb + incl - cnt - ord_base;
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) {
                         const uint32_t w = lane * 4u + i;
@@ -861,7 +886,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         uint32_t m = e[i];
                         while (m) {
                             const uint32_t bit = (uint32_t)__ffs(m) - 1u;
-                            c_slot[o] = (uint16_t)(w * 32u + bit);
+                            c_did[o] = stripe_base + w * 32u + bit;
                             m &= m - 1u;
                             ++o;
                         }
@@ -869,14 +894,13 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 }
                 const unsigned long long coarse = __ballot(in_chunk && cnt != 0u);   /* bit = 128-slot bucket with a candidate */
                 wave_lds_fence();
-                prefetch_round(0u, n_c);                             /* requested now, consumed after the scatter */
                 ORW_PH(2);
 
                 /* ---- 2b. wdf of the dense terms: one byte per candidate and term, two rounds in flight ---- */
                 for (uint32_t c0 = 0; !fast && c0 < n_c; c0 += 128u) {       /* (> 8 terms: through c_w) */
-                    const uint32_t o0 = c0 + lane, o1 = o0 + 64u;
-                    const bool v0 = o0 < n_c, v1 = o1 < n_c;
-                    const uint32_t slot0 = v0 ? c_slot[o0] : 0u, slot1 = v1 ? c_slot[o1] : 0u;
+                    const uint32_t o0 = qb + c0 + lane, o1 = o0 + 64u;
+                    const bool v0 = o0 < qb + n_c, v1 = o1 < qb + n_c;
+                    const uint32_t slot0 = v0 ? c_did[o0] & (W - 1u) : 0u, slot1 = v1 ? c_did[o1] & (W - 1u) : 0u;
                     for (uint64_t dm = dense_mask; dm;) {
                         uint32_t tt[4], wv0[4], wv1[4];
 #pragma unroll
@@ -962,9 +986,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 /* headers of the next active stripe: in flight while this chunk is scored */
                 if (last_chunk && sl_next < n_local) issue_headers(sl_next);
 
-                /* ---- 3. BM25, tree sum, top-k ---- */
-                score_candidates(n_c);
-                wave_lds_fence();
+                /* ---- 3. BM25, tree sum, top-k: once two rounds' worth wait (or a stripe came without a threshold) ---- */
+                qn = qb + n_c;
+                if (qn >= 128u || !use_sum) flush_queue();
                 ORW_PH(5);
             }
             /* publish the histogram counts */
@@ -979,6 +1003,17 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             }
             ORW_PH(6);
             sl = sl_next;
+        }
+        /* the pass is over: weigh what still waits, publish the counts (the units of the query learn from them) */
+        flush_queue();
+        if (lh_dirty) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                const uint32_t v = lh[lane * 4u + i];
+                if (v) { atomicAdd(&hist_g[lane * 4u + i], v); lh[lane * 4u + i] = 0; }
+            }
+            lh_dirty = false;
+            wave_lds_fence();
         }
     }
     ORW_PH(7);
