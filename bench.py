@@ -194,7 +194,7 @@ def main():
         step(batches[b])
         torch.cuda.synchronize()
         h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
-        matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH)
+        matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in timed_plans[b * BATCH:(b + 1) * BATCH])
         tl = (C.c_uint64 * 10)()
         have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel")

@@ -42,7 +42,8 @@ int main(int argc, char** argv) {
     if (rc > 0) { fprintf(stderr, "query shape not handled by the device path: use the CPU matcher\n"); xgm_index_close(idx); return 3; }
     if (rc == 0) rc = xgm_search(idx, &q, hits, &h);
     if (rc) { fprintf(stderr, "search failed: %s\n", xgm_last_error()); xgm_index_close(idx); return 1; }
-    printf("%llu matches, max_possible %.17g\n", (unsigned long long)h.matches_exact, h.max_possible);
+    printf("%llu matches%s, max_possible %.17g\n", (unsigned long long)XGM_MATCHES_COUNT(h.matches_exact),
+           (h.matches_exact & XGM_MATCHES_LOWER_BOUND) ? " (at least)" : "", h.max_possible);
     for (i = q.first; i < h.n_hits; ++i) printf("%2u  docid %-10u weight %.17g\n", i, hits[i].docid, hits[i].weight);
     xgm_index_close(idx);
     return 0;

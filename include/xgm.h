@@ -316,10 +316,17 @@ typedef struct {
     double weight;
 } xgm_hit;                       /* 16 bytes                                                        */
 
+#define XGM_MATCHES_LOWER_BOUND (1ull << 63)
+#define XGM_MATCHES_COUNT(m) ((m) & ~XGM_MATCHES_LOWER_BOUND)
+
 typedef struct {
     uint32_t n_hits;             /* hits written: min(matches, first + maxitems)                   */
     uint32_t max_weight_subqs_matched; /* of the top-weighted doc (protomset.h:174-183)            */
-    uint64_t matches_exact;      /* exact match count (the reference only estimates it)            */
+    uint64_t matches_exact;      /* exact match count (the reference only estimates it); with XGM_MATCHES_LOWER_BOUND
+                                    set: a lower bound — a positional query (PHRASE / NEAR) whose check_at_least lies
+                                    within the page drops candidates that cannot enter the top k BEFORE testing their
+                                    positions (Xapiand's default, check_at_least = 0; ask check_at_least >= doccount
+                                    for the exact count) */
     double max_attained;         /* weight of the best doc, 0 if none                              */
     double max_possible;
 } xgm_result_hdr;                /* 32 bytes                                                        */

@@ -57,7 +57,7 @@ void GpuTopKPostingSource::init(const Xapian::Database&) {
     hits.resize(h.n_hits);
     std::sort(hits.begin(), hits.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
     by_docid_.swap(hits);
-    matches_ = (Xapian::doccount)h.matches_exact;
+    matches_ = (Xapian::doccount)XGM_MATCHES_COUNT(h.matches_exact);
     set_maxweight(h.max_possible);
 }
 

@@ -19,6 +19,21 @@ OPS = {"AND": 1, "OR": 2, "PHRASE": 3, "AND_NOT": 4, "AND_MAYBE": 5, "FILTER": 6
 SIDED = ("AND_NOT", "AND_MAYBE", "FILTER")   # left = AND of the first n_required terms, right = the others
 
 
+MATCHES_LOWER_BOUND = 1 << 63      # include/xgm.h: XGM_MATCHES_LOWER_BOUND
+EXACT_COUNT = 0x7FFFFFFF           # a check_at_least that asks for the exact match count of a positional query
+
+
+def check_matches(got_raw, want, n_hits, what=None):
+    """xgm_result_hdr.matches_exact against the oracle's count: exact — or, flagged (a positional query answered with
+    check_at_least inside the page: candidates that cannot rank are dropped before their positions are tested), a lower
+    bound that still covers the hits returned."""
+    if got_raw & MATCHES_LOWER_BOUND:
+        cnt = got_raw & ~MATCHES_LOWER_BOUND
+        assert n_hits <= cnt <= want, (what, cnt, want, n_hits)
+    else:
+        assert got_raw == want, (what, got_raw, want)
+
+
 class CorpusView(C.Structure):
     _fields_ = [("n_terms", C.c_uint32), ("lastdocid", C.c_uint32), ("doccount", C.c_uint32),
                 ("has_positions", C.c_uint32), ("total_length", C.c_uint64), ("n_postings", C.c_uint64),

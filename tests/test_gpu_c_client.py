@@ -32,4 +32,5 @@ def test_c_client_matches_oracle(built, tmp_path):
         got = [(int(l.split()[2]), float(l.split()[4])) for l in lines[1:]]
         want, hdr = H.oracle_search(c, op, terms, 0, 10, n_required=nreq)
         assert got == [(d, w) for d, w, _ in want], (op, terms)
-        assert int(lines[0].split()[0]) == hdr.matches
+        shown = int(lines[0].split()[0])
+        assert shown == hdr.matches if "(at least)" not in lines[0] else len(got) <= shown <= hdr.matches

@@ -27,7 +27,7 @@ def test_mixed_batch_matches_oracle(built, tmp_path):
     for q, p, (hits, hdr) in zip(qs, plans, got):
         want, oh = H.oracle_search(c, q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0))
         assert [(h.docid, h.weight) for h in hits] == [(d, w) for d, w, _ in want], q
-        assert hdr.matches_exact == oh.matches, q
+        H.check_matches(hdr.matches_exact, oh.matches, len(hits), q)
         (h1, hdr1), = search_batch(db, [p])
         assert [(h.docid, h.weight, h.subqs_matched) for h in h1] == [(h.docid, h.weight, h.subqs_matched) for h in hits], q
     db.close()

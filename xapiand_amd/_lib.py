@@ -15,6 +15,7 @@ XGM_OK, XGM_UNSUPPORTED = 0, 1
 XGM_E_INVALID, XGM_E_IO, XGM_E_NO_DEVICE, XGM_E_DEVICE, XGM_E_REVISION, XGM_E_NOMEM = -1, -2, -3, -4, -5, -6
 XGM_OP_AND, XGM_OP_OR, XGM_OP_PHRASE = 1, 2, 3
 XGM_OP_AND_NOT, XGM_OP_AND_MAYBE, XGM_OP_FILTER, XGM_OP_NEAR = 4, 5, 6, 7
+XGM_MATCHES_LOWER_BOUND = 1 << 63    # xgm_result_hdr.matches_exact: the count is a lower bound (include/xgm.h)
 XGM_DEVICE_NONE = -1          # xgm_index_open: dictionary and statistics only (host memory), no searches
 UINT64_MAX = (1 << 64) - 1
 

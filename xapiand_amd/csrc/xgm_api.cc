@@ -491,6 +491,10 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
     }
     if ((q->op == XGM_OP_PHRASE || q->op == XGM_OP_NEAR) && q->phrase_active) {
         d->flags |= XGM_QF_PHRASE;
+        /* Enquire::get_mset's check_at_least (enquire.cc:419-426): beyond the page it asks for more documents to be LOOKED AT so that
+         * the match count is accurate; within it (Xapiand passes 0) the matcher may stop caring about documents that cannot rank */
+        static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr;         /* A/B switch for measurements */
+        if (!no_pos_prune && q->check_at_least <= q->first + q->maxitems) d->flags |= XGM_QF_POSPRUNE;
         if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR;
         else if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
     }

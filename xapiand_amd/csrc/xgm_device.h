@@ -18,6 +18,8 @@
 #define XGM_QF_EXACT 2u             /* window == n_terms: ExactPhrasePostList semantics            */
 #define XGM_QF_EMPTY 4u             /* provably no match on this shard (absent AND term, ...)      */
 #define XGM_QF_NEAR 8u              /* the positional filter is NearPostList's (any order, span < window) */
+#define XGM_QF_POSPRUNE 32u         /* positional query whose match count may be a lower bound: weigh first, test positions only of
+                                       candidates that can still enter the top k (include/xgm.h, XGM_MATCHES_LOWER_BOUND) */
 #define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */

@@ -1284,6 +1284,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
         prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
     }
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
+    const bool pos_prune = PHRASE && (q.flags & XGM_QF_POSPRUNE);   /* weigh before testing positions: the match count may be a lower bound */
+    bool pos_pruned = false;                                        /* per lane: a candidate was dropped that way */
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
     const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
@@ -1482,7 +1484,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     /* candidates present in every term are matches: BM25 + top-k, 64 per round; also clears c_w */
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
-            if (tkn + 64u > cap) {
+            if (tkn + 64u > cap || (PHRASE && pos_prune && !theta_valid && tkn >= k)) {      /* (positional pruning wants its threshold as soon as k matches are held) */
                 if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
                 tkn = tkn < k ? tkn : k;
                 if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
@@ -1498,6 +1500,38 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 pass = true;
                 for (uint32_t t = 0; t < TR; ++t) pass = pass && c_w[(size_t)t * CAND + o] != 0;
                 for (uint32_t t = TR; t < T; ++t) pass = pass && (!((q.neg_mask >> t) & 1u) || c_w[(size_t)t * CAND + o] == 0);   /* AND_NOT */
+            }
+            /* Positional queries whose match count need not be exact (check_at_least within the page, Xapiand's default): the
+             * document's weight does not depend on its positions, so weigh FIRST — a candidate that cannot enter the unit's top k
+             * (k positional matches are already held) is dropped without looking at its positions.  For phrases of frequent
+             * terms this removes nearly every positional test; the hits are the same, the match count becomes a lower bound. */
+            bool pre_weighed = false;
+            if (PHRASE && phrase && pos_prune && theta_valid) {
+                pre_weighed = true;
+                if (pass) {
+                    did = q_mode ? q_did : stripe_base + c_slot[o];
+                    uint32_t dlen;
+                    if (dl_ready && i0 < 256u) {
+                        dlen = dl[0];
+#pragma unroll
+                        for (uint32_t c = 1; c < 4u; ++c) dlen = (i0 == c * 64u) ? dl[c] : dlen;
+                    } else {
+                        dlen = seg.doclen[did];
+                    }
+                    const double len = (double)dlen;
+                    double normlen = len * q.len_factor;
+                    normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+                    const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                    double weight = 0.0;
+                    for (uint32_t t = 0; t < TR; ++t) {
+                        const double wdf = (double)((uint32_t)c_w[(size_t)t * CAND + o] - 1u);
+                        const double denom = denom_len + wdf;
+                        weight = weight + q.termweight[t] * (wdf / denom);
+                    }
+                    wb = (uint64_t)__double_as_longlong(weight);
+                    if (!cand_before(wb, did, theta_w, theta_d)) { pass = false; pos_pruned = true; }
+                }
+                if (TALLY) { const uint32_t n_ = (uint32_t)__popcll(__ballot(oi < n_c && !(dl_ready && i0 < 256u))); cn_dl += n_; cn_dl_raw += n_; }
             }
             if (PHRASE && phrase && __ballot(pass)) {
                 /* K6: ExactPhrasePostList / PhrasePostList / NearPostList::test_doc for the round's 64 documents.
@@ -1561,7 +1595,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 wave_lds_fence();
             }
             if (oi < n_c) {
-                if (pass) {
+                if (pass && pre_weighed) {
+                    ++matches;
+                    subqs = (uint32_t)__popc(q.score_mask);
+                    take = true;                                   /* it beat the unit's k-th best before its positions were tested */
+                } else if (pass) {
                     ++matches;
                     did = q_mode ? q_did : stripe_base + c_slot[o];
                     uint32_t dlen;
@@ -1612,7 +1650,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 }
                 for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * CAND + o] = 0;
             }
-            if (TALLY) { if (!(dl_ready && i0 < 256u)) { const uint32_t n_ = (uint32_t)__popcll(__ballot(pass)); cn_dl += n_; cn_dl_raw += n_; } }
+            if (TALLY) { if (!pre_weighed && !(dl_ready && i0 < 256u)) { const uint32_t n_ = (uint32_t)__popcll(__ballot(pass)); cn_dl += n_; cn_dl_raw += n_; } }
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; if (MAYBE) tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
@@ -2288,6 +2326,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
     for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
     if (PHRASE && TALLY) { for (int sh = 32; sh > 0; sh >>= 1) cn_pos += (unsigned long long)__shfl_xor((long long)cn_pos, sh); }
+    const bool any_pruned = PHRASE && __ballot(pos_pruned) != 0ull;
     const uint32_t n_out = tkn < k ? tkn : k;
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = lane; i < n_out; i += 64u) {
@@ -2297,7 +2336,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     }
     if (lane == 0) {
         xgm_group_hdr h;
-        h.matches = matches; h.n_cand = n_out; h.pad = TALLY ? q_cands : 0u;
+        h.matches = matches | (PHRASE && any_pruned ? XGM_MATCHES_LOWER_BOUND : 0ull); h.n_cand = n_out; h.pad = TALLY ? q_cands : 0u;
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         h.c_pos = cn_pos; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
         h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = (uint32_t)(ph_a >> 6); h.c_pad[1] = (uint32_t)(ph_b >> 6);
@@ -2329,7 +2368,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     tk.cap = cap;
     unsigned long long& matches = *reinterpret_cast<unsigned long long*>(smem + (size_t)cap * 16);
     uint32_t& fill = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 8);
-    if (tid == 0) { fill = 0; matches = 0; }
+    uint32_t& lower_only = *reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 12);      /* some unit dropped candidates unweighed against positions */
+    if (tid == 0) { fill = 0; matches = 0; lower_only = 0; }
     __syncthreads();
     /* gather: unit u of the query owns the fixed window [u * k_in, (u+1) * k_in) of the sort buffer
      * (k_in = its candidate stride); empty places get the sentinel.  Fully parallel: no prefix sums. */
@@ -2343,7 +2383,10 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 const xgm_cand c = cand[(size_t)(g0 + u) * k_stride_in + j];
                 w = c.wbits; d = c.did; m = c.subqs;
             }
-            if (j == 0) { atomicAdd(&matches, (unsigned long long)h.matches); atomicAdd(&fill, h.n_cand); }
+            if (j == 0) {
+                atomicAdd(&matches, (unsigned long long)(h.matches & ~XGM_MATCHES_LOWER_BOUND)); atomicAdd(&fill, h.n_cand);
+                if (h.matches & XGM_MATCHES_LOWER_BOUND) atomicOr(&lower_only, 1u);
+            }
         }
         tk.w[x] = w; tk.d[x] = d; tk.m[x] = m;
     }
@@ -2408,7 +2451,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 xgm_result_hdr r;
                 r.n_hits = n;
                 r.max_weight_subqs_matched = best_m;
-                r.matches_exact = matches;
+                r.matches_exact = matches | (lower_only ? XGM_MATCHES_LOWER_BOUND : 0ull);
                 r.max_attained = __longlong_as_double((long long)best_w);
                 r.max_possible = max_possible ? max_possible[qi] : 0.0;
                 hdrs[orow] = r;
@@ -2426,7 +2469,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         xgm_result_hdr r;
         r.n_hits = n;
         r.max_weight_subqs_matched = fill ? tk.m[0] : 0u;
-        r.matches_exact = matches;
+        r.matches_exact = matches | (lower_only ? XGM_MATCHES_LOWER_BOUND : 0ull);
         r.max_attained = fill ? __longlong_as_double((long long)tk.w[0]) : 0.0;
         r.max_possible = max_possible ? max_possible[qi] : 0.0;
         hdrs[orow] = r;
@@ -2457,7 +2500,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit*
         const xgm_result_hdr h = all_hdrs[(size_t)sh * nq + qi];
         const xgm_hit* src = all_hits + ((size_t)sh * nq + qi) * k_stride;
         if (tid == 0) {
-            base = fill; fill += h.n_hits; matches += h.matches_exact;
+            base = fill; fill += h.n_hits;
+            matches = ((matches & ~XGM_MATCHES_LOWER_BOUND) + (h.matches_exact & ~XGM_MATCHES_LOWER_BOUND)) | ((matches | h.matches_exact) & XGM_MATCHES_LOWER_BOUND);
             /* MSet::Internal::merge_stats, mset.cc:376-395: max of max_possible / max_attained */
             if (h.max_possible > max_possible) max_possible = h.max_possible;
             if (h.max_attained > max_attained) { max_attained = h.max_attained; max_subqs = h.max_weight_subqs_matched; }

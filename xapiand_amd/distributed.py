@@ -159,6 +159,6 @@ def decode_results(hits, hdrs):
         n = int(d[i, 0:4].view(np.uint32)[0])
         rows = [(int(h[i, j, 0:4].view(np.uint32)[0]), float(h[i, j, 8:16].view(np.float64)[0]), int(h[i, j, 4:8].view(np.uint32)[0]))
                 for j in range(n)]
-        out.append((rows, dict(n_hits=n, max_subqs=int(d[i, 4:8].view(np.uint32)[0]), matches=int(d[i, 8:16].view(np.uint64)[0]),
+        out.append((rows, dict(n_hits=n, max_subqs=int(d[i, 4:8].view(np.uint32)[0]), matches=int(d[i, 8:16].view(np.uint64)[0]) & ((1 << 63) - 1), matches_lower_bound=bool(int(d[i, 8:16].view(np.uint64)[0]) >> 63),
                                max_attained=float(d[i, 16:24].view(np.float64)[0]), max_possible=float(d[i, 24:32].view(np.float64)[0]))))
     return out

@@ -269,7 +269,8 @@ class MSet:
             if rank < first:
                 continue
             self._items.append(MSetItem(h.docid, h.weight, rank, self.convert_to_percent(h.weight), h.subqs_matched))
-        self._matches = hdr.matches_exact
+        self._matches = hdr.matches_exact & ~_lib.XGM_MATCHES_LOWER_BOUND
+        self._matches_is_lower_bound = bool(hdr.matches_exact & _lib.XGM_MATCHES_LOWER_BOUND)
         self._max_possible = hdr.max_possible
         self._max_attained = hdr.max_attained
 
@@ -300,8 +301,12 @@ class MSet:
         return self._first
 
     def get_matches_exact(self):
-        """The exact number of matching documents (the reference only bounds and estimates it)."""
+        """The exact number of matching documents (the reference only bounds and estimates it) — unless
+        matches_is_lower_bound(): a positional query answered with check_at_least inside the page."""
         return self._matches
+
+    def matches_is_lower_bound(self):
+        return self._matches_is_lower_bound
 
     def get_matches_estimated(self):
         return self._bounds[1] if self._bounds else self._matches
@@ -456,7 +461,8 @@ def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None)
         for x in hits:
             g = _lib.Hit((x.docid - 1) * n_shards + s + 1, x.subqs_matched, x.weight)
             allhits.append(g)
-        hdr.matches_exact += h.matches_exact
+        LB = _lib.XGM_MATCHES_LOWER_BOUND
+        hdr.matches_exact = ((hdr.matches_exact & ~LB) + (h.matches_exact & ~LB)) | ((hdr.matches_exact | h.matches_exact) & LB)
         hdr.max_possible = max(hdr.max_possible, h.max_possible)
         if h.max_attained > hdr.max_attained:
             hdr.max_attained = h.max_attained
