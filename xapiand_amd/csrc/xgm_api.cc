@@ -838,9 +838,10 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     }
     idx->last_kernel = bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
-    if (bp.orw) {
+    if (bp.orw || (bp.andw && bp.phrase)) {
         if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
         HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
+        L.hist = s->d_hist;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
     if ((rc = bp.andw ? xgm_launch_andw(L, stream)

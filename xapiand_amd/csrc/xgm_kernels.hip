@@ -1229,7 +1229,7 @@ template <typename TabT, bool PHRASE, int SIDED, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out, uint32_t* __restrict__ hist_all) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t CAND = PHRASE ? kAndwCandPhrase : kAndwCandPlain;     /* candidates per chunk */
     constexpr uint32_t CHUNKB = CAND / XGM_BLOCK;                             /* = blocks of term 0 per chunk */
@@ -1286,6 +1286,42 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
     const bool pos_prune = PHRASE && (q.flags & XGM_QF_POSPRUNE);   /* weigh before testing positions: the match count may be a lower bound */
     bool pos_pruned = false;                                        /* per lane: a candidate was dropped that way */
+    /* ... and the units of a query share what they learn: every positional match that is taken is counted in a 256-bucket
+     * histogram of weight bit patterns (32 buckets per octave below the largest possible weight, global atomics — matches that
+     * pass the pruning are rare); the highest bucket with >= k matches at or above it bounds the final k-th weight from below
+     * although no single unit may hold k matches (phrases whose matches are rare). */
+    uint32_t* hist_g = nullptr;
+    int hbase = 0;
+    uint64_t theta_glob = 0;
+    if (pos_prune && hist_all && !(q.flags & XGM_QF_EMPTY)) {
+        double mp = 0.0;
+        for (uint32_t t = 0; t < q.n_terms; ++t) mp += q.ub[t];
+        mp *= 1.000000001;
+        hbase = (int)rfl32((uint32_t)((uint64_t)__double_as_longlong(mp) >> 47)) - (int)(XGM_OR_HIST - 1u);
+        if (hbase > 0) hist_g = hist_all + (size_t)wk.qi * XGM_OR_HIST;
+    }
+    auto look_at_histogram = [&]() {
+        uint32_t hc[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t s4 = hc[0] + hc[1] + hc[2] + hc[3];
+        const uint32_t P = wave_incl_scan(s4);
+        const uint32_t suf = rl32(P, 63) - P + s4;                   /* matches in buckets >= 4 * lane */
+        const uint64_t okm = __ballot(suf >= q.k);
+        if (okm) {
+            const uint32_t Lh = 63u - (uint32_t)__builtin_clzll(okm);
+            const uint32_t cum = rl32(suf, Lh) - rl32(s4, Lh);
+            const uint32_t c3 = rl32(hc[3], Lh), c2 = rl32(hc[2], Lh), c1 = rl32(hc[1], Lh);
+            uint32_t bsel = 4u * Lh;
+            if (cum + c3 >= q.k) bsel = 4u * Lh + 3u;
+            else if (cum + c3 + c2 >= q.k) bsel = 4u * Lh + 2u;
+            else if (cum + c3 + c2 + c1 >= q.k) bsel = 4u * Lh + 1u;
+            if (bsel > 0u) {
+                const uint64_t tb = (uint64_t)((uint32_t)hbase + bsel) << 47;
+                theta_glob = tb > theta_glob ? tb : theta_glob;
+            }
+        }
+    };
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
     const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
@@ -1483,6 +1519,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     uint32_t q_off = 0;                                            /* ... and their rows start at c_w[..][q_off] */
     /* candidates present in every term are matches: BM25 + top-k, 64 per round; also clears c_w */
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
+        if (PHRASE && hist_g) look_at_histogram();
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
             if (tkn + 64u > cap || (PHRASE && pos_prune && !theta_valid && tkn >= k)) {      /* (positional pruning wants its threshold as soon as k matches are held) */
                 if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
@@ -1506,7 +1543,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
              * (k positional matches are already held) is dropped without looking at its positions.  For phrases of frequent
              * terms this removes nearly every positional test; the hits are the same, the match count becomes a lower bound. */
             bool pre_weighed = false;
-            if (PHRASE && phrase && pos_prune && theta_valid) {
+            if (PHRASE && phrase && pos_prune && (theta_valid || theta_glob)) {
                 pre_weighed = true;
                 if (pass) {
                     did = q_mode ? q_did : stripe_base + c_slot[o];
@@ -1529,7 +1566,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                         weight = weight + q.termweight[t] * (wdf / denom);
                     }
                     wb = (uint64_t)__double_as_longlong(weight);
-                    if (!cand_before(wb, did, theta_w, theta_d)) { pass = false; pos_pruned = true; }
+                    if ((theta_valid && !cand_before(wb, did, theta_w, theta_d)) || wb < theta_glob) { pass = false; pos_pruned = true; }
                 }
                 if (TALLY) { const uint32_t n_ = (uint32_t)__popcll(__ballot(oi < n_c && !(dl_ready && i0 < 256u))); cn_dl += n_; cn_dl_raw += n_; }
             }
@@ -1598,7 +1635,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 if (pass && pre_weighed) {
                     ++matches;
                     subqs = (uint32_t)__popc(q.score_mask);
-                    take = true;                                   /* it beat the unit's k-th best before its positions were tested */
+                    take = true;                                   /* it beat the k-th best known before its positions were tested */
                 } else if (pass) {
                     ++matches;
                     did = q_mode ? q_did : stripe_base + c_slot[o];
@@ -1651,6 +1688,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 for (uint32_t t = 0; t < T; ++t) c_w[(size_t)t * CAND + o] = 0;
             }
             if (TALLY) { if (!pre_weighed && !(dl_ready && i0 < 256u)) { const uint32_t n_ = (uint32_t)__popcll(__ballot(pass)); cn_dl += n_; cn_dl_raw += n_; } }
+            if (PHRASE && hist_g && take) {
+                int b = (int)(wb >> 47) - hbase;
+                b = b < 0 ? 0 : (b > (int)XGM_OR_HIST - 1 ? (int)XGM_OR_HIST - 1 : b);
+                atomicAdd(&hist_g[b], 1u);
+            }
             const uint64_t tm = __ballot(take);
             if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; if (MAYBE) tk_m[p] = (uint8_t)subqs; }
             tkn += (uint32_t)__popcll(tm);
@@ -2664,7 +2706,7 @@ static int launch_andw_inst(const xgm_match_launch& L, size_t smem, hipStream_t 
     auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED, TALLY>;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -18,6 +18,8 @@ struct xgm_match_launch {
     bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
     bool tally = false;               /* wave kernels: also fill the traffic tallies of xgm_group_hdr (measurement)  */
     int sided = 0;                    /* conjunction batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
+    uint32_t* hist = nullptr;         /* device, [nq][XGM_OR_HIST] zeroed: the query-wide weight histogram of xgm_orw_kernel and of the
+                                         positional instantiation of xgm_andw_kernel (units of one query share their k-th weight bound) */
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
     xgm_group_hdr* ghdr;              /* device, [n_work]                                         */
 };
