@@ -1460,36 +1460,48 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
 
     /* wdf of the dense terms [t_lo, T) for the n_c candidates in c_slot: ONE byte load per candidate
      * and term from the container's direct wdf+1 array (0 = the term does not index that docid) */
+    /* with positions: the candidate's whole 64-byte sector of wdf+1 bytes (the memory transaction the one-byte probe costs
+     * anyway) gives its wdf AND, summed over the bucket's earlier slots, where its positions start behind the bucket's base:
+     * entry = pos_base[slot / 64] + Σ wdf of the slots before it in the bucket */
+    auto sector_probe = [&](uint32_t t, uint32_t slot, bool active, uint32_t& wdf1, uint32_t& pos) {
+        const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t & 63u);
+        wdf1 = 0; pos = 0;
+        if (active) {
+            const unsigned char* wbytes = seg.dense_data + (size_t)oo * 16 + (size_t)NW * 4;
+            const uint4* sp = reinterpret_cast<const uint4*>(wbytes + (slot & ~63u));
+            const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
+            pos = reinterpret_cast<const uint32_t*>(wbytes + W)[slot >> 6];
+            const uint32_t wv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            const uint32_t kk = slot & 63u;
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                const uint32_t x = wv[j];
+                const uint32_t nz1 = ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;     /* 1 in every present slot's byte */
+                const int rel = (int)kk - (int)(4u * j);                                             /* bytes of this word before the slot */
+                const uint32_t m = rel >= 4 ? 0xFFFFFFFFu : (rel <= 0 ? 0u : ((1u << (8u * (uint32_t)rel)) - 1u));
+                pos = __builtin_amdgcn_sad_u8((x - nz1) & m, 0u, pos);                               /* += Σ (wdf+1-1) of those bytes */
+                if ((kk >> 2) == j) wdf1 = (x >> (8u * (kk & 3u))) & 0xFFu;
+            }
+        }
+    };
+    /* Once a positional query prunes by weight, nearly every candidate is dropped before its positions matter: the probe then
+     * fetches the wdf byte only, and where the positions start is worked out for the few survivors (score_candidates). */
+    bool lazy_pos = false;
+    uint32_t lazy_tlo = 0;
     auto probe_dense = [&](uint32_t t_lo, uint32_t n_c) {
+        lazy_pos = PHRASE && pos_prune && (theta_valid || theta_glob);
+        lazy_tlo = t_lo;
         for (uint32_t c0 = 0; c0 < n_c; c0 += 64u) {
             const uint32_t o = c0 + lane;
             const bool valid = o < n_c;
             const uint32_t slot = valid ? c_slot[o] : 0u;
             const uint32_t sec = TALLY ? tally_sectors(valid, slot, 6u) : 0u;
-            if (PHRASE) {
-                /* with positions: the candidate's whole 64-byte sector of wdf+1 bytes (the memory transaction the one-byte
-                 * probe costs anyway) gives its wdf AND, summed over the bucket's earlier slots, where its positions start
-                 * behind the bucket's base: entry = pos_base[slot / 64] + Σ wdf of the slots before it in the bucket */
+            if (PHRASE && !lazy_pos) {
                 for (uint32_t t = t_lo; t < T; ++t) {
-                    const uint32_t oo = __builtin_amdgcn_readlane(hc_cur, t & 63u);
                     if (TALLY) { cn_probe += sec; cn_probe_raw += n_c - c0 < 64u ? n_c - c0 : 64u; cn_aux += sec; }
-                    uint32_t wdf1 = 0, pos = 0;
+                    uint32_t wdf1, pos;
+                    sector_probe(t, slot, valid, wdf1, pos);
                     if (valid) {
-                        const unsigned char* wbytes = seg.dense_data + (size_t)oo * 16 + (size_t)NW * 4;
-                        const uint4* sp = reinterpret_cast<const uint4*>(wbytes + (slot & ~63u));
-                        const uint4 q0 = sp[0], q1 = sp[1], q2 = sp[2], q3 = sp[3];
-                        pos = reinterpret_cast<const uint32_t*>(wbytes + W)[slot >> 6];
-                        const uint32_t wv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-                        const uint32_t kk = slot & 63u;
-#pragma unroll
-                        for (uint32_t j = 0; j < 16u; ++j) {
-                            const uint32_t x = wv[j];
-                            const uint32_t nz1 = ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;     /* 1 in every present slot's byte */
-                            const int rel = (int)kk - (int)(4u * j);                                             /* bytes of this word before the slot */
-                            const uint32_t m = rel >= 4 ? 0xFFFFFFFFu : (rel <= 0 ? 0u : ((1u << (8u * (uint32_t)rel)) - 1u));
-                            pos = __builtin_amdgcn_sad_u8((x - nz1) & m, 0u, pos);                               /* += Σ (wdf+1-1) of those bytes */
-                            if ((kk >> 2) == j) wdf1 = (x >> (8u * (kk & 3u))) & 0xFFu;
-                        }
                         c_w[(size_t)t * CAND + o] = (TabT)wdf1;
                         c_pos[(size_t)t * CAND + o] = pos;
                     }
@@ -1569,6 +1581,15 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                     if ((theta_valid && !cand_before(wb, did, theta_w, theta_d)) || wb < theta_glob) { pass = false; pos_pruned = true; }
                 }
                 if (TALLY) { const uint32_t n_ = (uint32_t)__popcll(__ballot(oi < n_c && !(dl_ready && i0 < 256u))); cn_dl += n_; cn_dl_raw += n_; }
+            }
+            if (PHRASE && phrase && lazy_pos && __ballot(pass)) {
+                const uint32_t slot = pass ? (uint32_t)c_slot[o < CAND ? o : 0u] : 0u;
+                for (uint32_t t = lazy_tlo; t < T; ++t) {
+                    uint32_t wdf1, pos;
+                    sector_probe(t, slot, pass, wdf1, pos);
+                    if (pass) c_pos[(size_t)t * CAND + o] = pos;
+                }
+                wave_lds_fence();
             }
             if (PHRASE && phrase && __ballot(pass)) {
                 /* K6: ExactPhrasePostList / PhrasePostList / NearPostList::test_doc for the round's 64 documents.
