@@ -3,8 +3,8 @@
 #   (FETCH_SIZE, WRITE_SIZE, SQ) for the conjunction, disjunction and positional kernels → traffic entries; C3 / C5 / sided lines with parity
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
-timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
-bash tools/calib.sh $tag > gpurun_out/${tag}_calib.out 2>&1; tail -11 gpurun_out/${tag}_calib.out
+# (GPU tests and the headline line: tools/final_a.sh)
+# (counter calibration: tools/calib.sh, kept from the first pass of this round — profiles/r02_fetch_calib.txt)
 : > gpurun_out/${tag}_traffic_entries.jsonl
 for w in "and3 andw" "or5 orw --op OR --terms 5 --topk 100" "phrase andw --op PHRASE --topk 10"; do
   set -- $w; n=$1; rx=$2; shift 2
@@ -24,7 +24,7 @@ json.dump({"entries":ents}, open('profiles/traffic.json','w'), indent=1)      # 
 json.dump({"entries":ents}, open('gpurun_out/${tag}_traffic.json','w'), indent=1)
 for e in ents: print('traffic',e['op'],e['kernel'],round(e['hbm_bytes_per_launch']/1e9,3),'GB/launch')
 PY
-timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err
+cp gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_first.json 2>/dev/null; timeout 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err
 timeout 400 python bench.py --op OR --terms 5 --topk 100 --steps 20 --warmup 2 --ref-docs 0 --cpu-seconds 4 --threads 0 > gpurun_out/${tag}_bench_or5.json 2>gpurun_out/${tag}_or5.err
 timeout 400 python bench.py --op PHRASE --topk 10 --steps 10 --warmup 2 --ref-docs 0 --cpu-seconds 4 --threads 0 > gpurun_out/${tag}_bench_phrase.json 2>gpurun_out/${tag}_phrase.err
 for a in "AND_NOT --terms 4 --required 2" "AND_MAYBE --terms 4 --required 2" "FILTER --terms 3 --required 2" "AND --terms 2"; do
