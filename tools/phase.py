@@ -23,6 +23,11 @@ def close(self):
         names = ["theta+bitmaps+sum", "decode+candset", "enumerate", "dense probes", "block scatter", "score-loop", "hist flush", "setup", "sort", "dlen+leaves", "tree", "hist+insert", "s0:prologue+hist issue", "s0:group loads+hist bound+quantise", "s0:prefetched bitmaps+sum", "-"]
         print("ORW PHASES:", {n: round(100.0 * x / tot, 1) for n, x in zip(names, v)}, "total Gcycles", round(tot / 1e9, 2))
     out = (C.c_ulonglong * 8)()
+    L.xgm_debug_merge_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+    if L.xgm_debug_merge_cycles(out) == 0 and sum(out):
+        v = list(out)
+        print("MERGE PHASES (cycles of thread 0, summed over workgroups and launches):", dict(zip(["headers", "gather", "threshold", "select", "rank+write"], v[:5])))
+    out = (C.c_ulonglong * 8)()
     if L.xgm_debug_phase_cycles(out) == 0:
         v = list(out)
         tot = sum(v[:6]) or 1

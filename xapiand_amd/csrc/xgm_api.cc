@@ -642,7 +642,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     const uint32_t g_min = (n_stripes + spg_max - 1) / spg_max;
     /* few queries in flight (latency mode): a smaller merge (sort of <= 4096) beats more units */
     const uint32_t merge_budget = (nq <= 4u && !bp->orw) ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;   /* (a disjunction's units are long: more of them wins) */
-    const uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
+    static const uint32_t units_cap = getenv("XGM_MAX_UNITS_PER_QUERY") ? (uint32_t)atoi(getenv("XGM_MAX_UNITS_PER_QUERY")) : 0u;   /* A/B switch for measurements */
+    uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
+    if (units_cap) g_max = std::max(g_min, std::min(g_max, units_cap));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
      * active stripe pays a fixed latency chain; each posting block that still has to be decoded (terms
@@ -1597,6 +1599,8 @@ int xgm_phase_cycles_fetch(unsigned long long* out8);
  * the last call; needs XGM_PHASE_TIMING=1 in the environment.  out[0..6] phases, out[7] stripes. */
 extern "C" int xgm_debug_phase_cycles(unsigned long long* out8) { return xgm_phase_cycles_fetch(out8); }
 int xgm_orw_cycles_fetch(unsigned long long* out8);
+int xgm_merge_cycles_fetch(unsigned long long* out8);
+extern "C" int xgm_debug_merge_cycles(unsigned long long* out8) { return xgm_merge_cycles_fetch(out8); }
 extern "C" int xgm_debug_orw_phase_cycles(unsigned long long* out8) { return xgm_orw_cycles_fetch(out8); }
 
 /* Diagnostics (host only — works on an XGM_DEVICE_NONE index): the decomposition a batch would be launched with.

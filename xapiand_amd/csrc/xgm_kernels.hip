@@ -2411,6 +2411,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
 /* ---------------------------------------------------------------- merge kernel --------------- */
 
 constexpr uint32_t kMergeSel = 512;    /* survivors the selection path of the merge ranks by counting */
+#ifndef XGM_MERGE_TIMERS
+#define XGM_MERGE_TIMERS 0
+#endif
+__device__ unsigned long long g_merge_cycles[8];   /* diagnostics (-DXGM_MERGE_TIMERS=1): summed section cycles of thread 0 of every workgroup */
+#define MG_PH(i) do { if (XGM_MERGE_TIMERS && tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_merge_cycles[i], n_ - mg_t); mg_t = n_; } } while (0)
 
 /* One workgroup per query.  Sources: n_src candidate lists of up to k_stride entries
  * (groups of one shard, or shards after the all-gather).  did_mul/did_add remap shard-local
@@ -2424,6 +2429,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     const uint32_t tid = threadIdx.x, qi = blockIdx.x;
     /* a heterogeneous batch runs one launch per kernel class: query qi of this launch is row row_of[qi] of the caller's batch */
     const uint32_t orow = row_of ? row_of[qi] : qi;
+    unsigned long long mg_t = XGM_MERGE_TIMERS ? __builtin_readcyclecounter() : 0ull;
     TopK tk;
     tk.w = reinterpret_cast<uint64_t*>(smem);
     tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
@@ -2435,8 +2441,41 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     if (tid == 0) { fill = 0; matches = 0; lower_only = 0; }
     __syncthreads();
     /* gather: unit u of the query owns the fixed window [u * k_in, (u+1) * k_in) of the sort buffer
-     * (k_in = its candidate stride); empty places get the sentinel.  Fully parallel: no prefix sums. */
+     * (k_in = its candidate stride); empty places get the sentinel.  Fully parallel: no prefix sums.
+     * Two latency-bound steps kept short: the units' headers once (their candidate counts parked in LDS — the selection
+     * arrays are not in use yet), then the candidates four loads at a time (a query cut into 512 units has 5 120 of them:
+     * one dependent load pair per entry used to make the busiest query's merge 60 us long). */
     const uint32_t g0 = goff[qi], n_src = goff[qi + 1] - g0;
+    uint32_t* n_cand_s = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 16 + 64);        /* [n_src] <= cap / k_in entries; the selection arrays start here later */
+    const uint32_t n_src_fit = n_src < 2u * kMergeSel ? n_src : 0u;                          /* (kMergeSel * 16 bytes = room for 4 * kMergeSel counts; be conservative) */
+    for (uint32_t u = tid; u < n_src_fit; u += XGM_WG) {
+        const xgm_group_hdr h = ghdr[g0 + u];
+        n_cand_s[u] = h.n_cand;
+        atomicAdd(&matches, (unsigned long long)(h.matches & ~XGM_MATCHES_LOWER_BOUND)); atomicAdd(&fill, h.n_cand);
+        if (h.matches & XGM_MATCHES_LOWER_BOUND) atomicOr(&lower_only, 1u);
+    }
+    __syncthreads();
+    MG_PH(0);
+    if (n_src_fit) {
+        for (uint32_t x0 = tid; x0 < cap; x0 += 4u * XGM_WG) {
+            xgm_cand c[4];
+            bool have[4];
+#pragma unroll
+            for (uint32_t v = 0; v < 4u; ++v) {
+                const uint32_t x = x0 + v * XGM_WG;
+                const uint32_t u = x / k_stride_in, j = x - u * k_stride_in;
+                have[v] = x < cap && u < n_src && j < n_cand_s[u];
+                if (have[v]) c[v] = cand[(size_t)(g0 + u) * k_stride_in + j];
+            }
+#pragma unroll
+            for (uint32_t v = 0; v < 4u; ++v) {
+                const uint32_t x = x0 + v * XGM_WG;
+                if (x < cap) {
+                    tk.w[x] = have[v] ? c[v].wbits : 0ull; tk.d[x] = have[v] ? c[v].did : 0xFFFFFFFFu; tk.m[x] = have[v] ? c[v].subqs : 0xFFFFFFFFu;
+                }
+            }
+        }
+    } else {
     for (uint32_t x = tid; x < cap; x += XGM_WG) {
         const uint32_t u = x / k_stride_in, j = x - u * k_stride_in;
         uint64_t w = 0; uint32_t d = 0xFFFFFFFFu, m = 0xFFFFFFFFu;
@@ -2453,7 +2492,9 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         }
         tk.w[x] = w; tk.d[x] = d; tk.m[x] = m;
     }
+    }
     __syncthreads();
+    MG_PH(1);
     const uint32_t k = kq[qi];
     const uint32_t n = fill < k ? fill : k;
     /* Selection instead of a full sort: take the best r = ceil(k / units) candidates of every unit (each
@@ -2484,6 +2525,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
             if (rank == k - 1u) { thr_w = hw; thr_d = hd; }        /* empty places tie on the sentinel: same value from all writers */
         }
         __syncthreads();
+        MG_PH(2);
         const uint64_t tw = thr_w;
         const uint32_t td = thr_d;
         for (uint32_t x = tid; x < cap; x += XGM_WG) {
@@ -2495,6 +2537,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
             }
         }
         __syncthreads();
+        MG_PH(3);
         const uint32_t ns = n_sel;
         if (ns <= kMergeSel) {
             for (uint32_t i = tid; i < ns; i += XGM_WG) {
@@ -2510,6 +2553,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 if (rank == 0u) { best_w = w; best_m = sel_m[i]; }
             }
             __syncthreads();
+            MG_PH(4);
             if (tid == 0) {
                 xgm_result_hdr r;
                 r.n_hits = n;
@@ -2746,6 +2790,14 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
     if (L.sided == 2) return L.wide ? launch_andw_variant<uint16_t, false, 2>(L, smem, stream) : launch_andw_variant<uint8_t, false, 2>(L, smem, stream);
     if (L.sided == 1) return L.wide ? launch_andw_variant<uint16_t, false, 1>(L, smem, stream) : launch_andw_variant<uint8_t, false, 1>(L, smem, stream);
     return L.wide ? launch_andw_variant<uint16_t, false, 0>(L, smem, stream) : launch_andw_variant<uint8_t, false, 0>(L, smem, stream);
+}
+
+int xgm_merge_cycles_fetch(unsigned long long* out8) {
+    hipDeviceSynchronize();
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_merge_cycles), 64) != hipSuccess) return -1;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_merge_cycles), z, 64);
+    return 0;
 }
 
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
