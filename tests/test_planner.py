@@ -129,3 +129,27 @@ def test_static_match_bounds_equal_the_references(built, tmp_path):
         _lib.lib().xgm_mset_bounds(C.byref(p), C.byref(hdr), C.byref(lb), C.byref(est), C.byref(ub))
         assert lb.value <= est.value <= ub.value and lb.value <= r["lb"] and ub.value == r["ub"], (q, lb.value, est.value, ub.value, r)
     assert n_full > 100
+
+
+def test_disjunction_threshold_guess_is_conservative(built, tmp_path):
+    """The planner's guess of a disjunction's final k-th weight (xgm_dev_query::theta_seed, xgm_api.cc or_theta_seed) only steers
+    which documents the kernel weighs first — but it earns its keep only if it is (a) rarely above the true k-th weight (then the
+    kernel must go round again) and (b) not far below it.  On the synthetic corpus: never above, and within a factor of two."""
+    import ctypes as C
+    c = H.Corpus(60000, 200000)
+    db = Database(c.build_segment(str(tmp_path / "seed.seg")), device=_lib.XGM_DEVICE_NONE)
+    L = _lib.lib()
+    L.xgm_debug_or_bounds.argtypes = [C.c_void_p, C.POINTER(_lib.Query), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    ratios = []
+    for k in (10, 100):
+        for q in H.gen_term_queries("OR", 20, 5, 8, 4096, seed=77):
+            p = plan(db, Query("OR", q["terms"]), 0, k)
+            seed, ub, ub1 = C.c_double(), (C.c_double * 16)(), (C.c_double * 16)()
+            assert L.xgm_debug_or_bounds(db._h, C.byref(p), C.byref(seed), ub, ub1) == 0
+            want, _ = H.oracle_search(c, "OR", q["terms"], 0, k)
+            for i in range(len(q["terms"])):
+                assert 0.0 < ub1[i] <= ub[i] <= p.terms[i].termweight * 1.00000001      # wdf = 1 bound <= largest-wdf bound <= termweight
+            if len(want) == k and seed.value > 0.0:
+                ratios.append(seed.value / want[k - 1][1])
+    assert len(ratios) >= 30 and max(ratios) <= 1.0 and min(ratios) >= 0.5, (len(ratios), min(ratios), max(ratios))
+    db.close()

@@ -1,2 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-XGM_LIB_PATH=$GRAFT_REPO_ROOT/xapiand_amd/csrc/ab/libxgm_mt.so timeout 300 python tools/phase.py --no-latency --threads 0 2>&1 | grep "MERGE PHASES"
+tag=$1
+timeout 1500 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()"

@@ -9,19 +9,18 @@
  * skipped without being weighed.
  *
  * Here, per stripe of W docids:
- *   1. membership: the union bitmap of ALL terms (exact match count = its popcount) and the union of
- *      the ESSENTIAL terms only.  A term is non-essential when the sum of the weight upper bounds of it
- *      and of every term with a smaller bound is below the k-th best weight known so far (MaxScore —
- *      the set-at-a-time form of the reference's decay): a document matching only non-essential terms
- *      cannot reach the top k, so it is counted but never weighed.  Dense terms contribute their probe
- *      container's bitmap (one 16-byte load per lane), the others are block-decoded (K1) into the LDS
- *      bitmaps.
- *   2. candidates = set bits of the essential union, enumerated in docid order, <= kOrwCand at a
- *      time; per term the candidate's wdf comes from ONE byte of the probe container, or from a
- *      second decode of just those blocks whose docid range holds a candidate.
+ *   1. membership: the union bitmap of ALL terms (exact match count = its popcount).  Dense terms contribute
+ *      their probe container's bitmap (one 16-byte load per lane), the others are block-decoded (K1), one
+ *      term at a time, into an LDS bitmap pair: the term's documents, and those whose wdf is >= 2.
+ *   2. candidates = the documents whose weight BOUND reaches the threshold (below), enumerated in docid
+ *      order and QUEUED in LDS across stripes (a stripe leaves a handful); per term a candidate's wdf
+ *      comes from ONE byte of the probe container of its own stripe, or — block-decoded terms — from a
+ *      second decode of just those blocks whose docid range holds a candidate, scattered into the queue
+ *      while the stripe's blocks are at hand.
  *   3. BM25 (K4, fp64, bm25weight.cc:170-181) per present leaf, tree sum in the reference's
  *      association (absent leaf = -0.0, the identity of IEEE addition), top-k (K5) in the wave's LDS
- *      buffer under msetcmp_by_relevance<true> (msetcmp.cc:55-62).
+ *      buffer under msetcmp_by_relevance<true> (msetcmp.cc:55-62) — in full 64-lane rounds, once enough
+ *      candidates wait.
  * The pruning threshold is GLOBAL per query: every weighed document is counted in a 256-bucket
  * histogram of weight bit patterns (32 buckets per octave below the query's weight upper bound) shared
  * by all units of the query through global atomics; the highest bucket with >= k documents at or above
@@ -346,7 +345,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     /* second pass (the guess was too high): the first pass's quantities, to recognise the documents it weighed */
     bool fix = false;
     uint64_t essA_mask = 0;
-    uint32_t qA2_reg = 0, qA1_reg = 0, q_neA = 0;
+    uint32_t qA2_reg = 0, qA1_reg = 0;
 
     unsigned long long pc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};           /* diagnostics: cycles per section */
     unsigned long long tmark = (XGM_ORW_TIMERS && phase_cycles) ? __builtin_readcyclecounter() : 0ull;
@@ -513,22 +512,15 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         qn = 0;
     };
 
-    /* quantised bounds for a threshold th (> 0): which terms are essential (MaxScore over all terms), per lane t the quantised bound of
-     * term t at its largest wdf (q2) and at wdf = 1 (q1), and that of the non-essential block-decoded terms together.
+    /* quantised bounds for a threshold th (> 0): which terms are essential (MaxScore over all terms: only the A/B variant without the
+     * bound sum uses it) and, per lane t, the quantised bound of term t at its largest wdf (q2) and at wdf = 1 (q1).
      * Quantised UP: q >= ub * kQ / th, so sum(q) >= kQ whenever sum(ub) >= th */
-    auto quantise = [&](uint64_t th_bits, uint64_t& ess, uint32_t& q2, uint32_t& q1, uint32_t& qne) {
+    auto quantise = [&](uint64_t th_bits, uint64_t& ess, uint32_t& q2, uint32_t& q1) {
         const double th = __longlong_as_double((long long)th_bits);
         ess = __ballot(present_reg && !(prefix_reg < th));
         const double r2 = ub_reg * (double)kQ / th, r1 = ub1_reg * (double)kQ / th;
         q2 = r2 >= (double)kQ ? kQ : (uint32_t)r2 + 1u;
         q1 = r1 >= (double)kQ ? kQ : (uint32_t)r1 + 1u;
-        double ne_sum = 0.0;
-        for (uint64_t sm = sparse_mask & ~ess; sm; sm &= sm - 1u) {
-            const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-            ne_sum += rl_f64(ub_reg, t);
-        }
-        const double rn = ne_sum * (double)kQ / th;
-        qne = ne_sum > 0.0 ? (rn >= (double)kQ ? kQ : (uint32_t)rn + 1u) : 0u;
     };
     /* the histogram's bound of the final k-th weight: highest bucket with >= k documents at or above it */
     auto hist_bound = [&](const uint32_t* hc) {
@@ -572,7 +564,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const uint64_t th_now = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
             if (th_now >= seed_bits) break;
             fix = true;
-            quantise(seed_bits, essA_mask, qA2_reg, qA1_reg, q_neA);
+            quantise(seed_bits, essA_mask, qA2_reg, qA1_reg);
         }
 
         auto next_active = [&](uint32_t from) {
@@ -709,7 +701,6 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             uint64_t ess_mask = present_mask;                       /* block-decoded terms whose documents are all candidates */
             bool use_sum = false;                                   /* candidates of the dense terms come from the bound sum */
             uint32_t q2_reg = kQ, q1_reg = kQ;                      /* lane t: quantised bounds of term t */
-            uint32_t q_ne = 0;                                      /* ... of the non-essential block-decoded terms together */
             bool first_group = true;
             bool stop = false;
             for (uint32_t dp = 0; dp < n_dense_ord || first_group;) {
@@ -742,7 +733,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         if (fix && th_bits >= seed_bits) { stop = true; break; }      /* whatever is left was weighed by the first pass or cannot reach the top k */
                         if (!fix && seed_bits > th_bits) th_bits = seed_bits;
                         if (th_bits) {
-                            quantise(th_bits, ess_mask, q2_reg, q1_reg, q_ne);
+                            quantise(th_bits, ess_mask, q2_reg, q1_reg);
                             use_sum = !no_sum;
                         }
                     }
