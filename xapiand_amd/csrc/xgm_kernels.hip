@@ -2514,6 +2514,32 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
         __syncthreads();
         const uint32_t rows = (k + n_src - 1u) / n_src;               /* <= k <= k_stride_in */
         const uint32_t n_h = n_src * rows;
+        if (rows == 1u && n_h > 128u && n_h <= kMergeSel) {
+            /* a query cut into hundreds of units: ranking every head against every other is quadratic (262 k comparisons at 512
+             * units: the busiest query's workgroup then IS the kernel's duration) — sort the heads instead (bitonic, best first,
+             * in the selection arrays, which are free until the threshold is known) and read the k-th off */
+            uint32_t P = 256u;
+            while (P < n_h) P <<= 1;
+            for (uint32_t i = tid; i < P; i += XGM_WG) {
+                sel_w[i] = i < n_h ? tk.w[i * k_stride_in] : 0ull;
+                sel_d[i] = i < n_h ? tk.d[i * k_stride_in] : 0xFFFFFFFFu;
+            }
+            for (uint32_t size = 2; size <= P; size <<= 1) {
+                for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                    __syncthreads();
+                    for (uint32_t i = tid; i < (P >> 1); i += XGM_WG) {
+                        const uint32_t lo = 2u * i - (i & (stride - 1u)), hi = lo + stride;
+                        const bool asc = ((lo & size) == 0);
+                        const uint64_t aw = sel_w[lo], bw = sel_w[hi];
+                        const uint32_t ad = sel_d[lo], bd = sel_d[hi];
+                        const bool swap = asc ? cand_before(bw, bd, aw, ad) : cand_before(aw, ad, bw, bd);
+                        if (swap) { sel_w[lo] = bw; sel_w[hi] = aw; sel_d[lo] = bd; sel_d[hi] = ad; }
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { thr_w = sel_w[k - 1u]; thr_d = sel_d[k - 1u]; }
+        } else {
         for (uint32_t t = tid; t < n_h; t += XGM_WG) {
             const uint32_t xt = (t / rows) * k_stride_in + (t % rows);
             const uint64_t hw = tk.w[xt];
@@ -2523,6 +2549,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
                 for (uint32_t j = 0; j < rows; ++j)
                     rank += cand_before(tk.w[u * k_stride_in + j], tk.d[u * k_stride_in + j], hw, hd) ? 1u : 0u;
             if (rank == k - 1u) { thr_w = hw; thr_d = hd; }        /* empty places tie on the sentinel: same value from all writers */
+        }
         }
         __syncthreads();
         MG_PH(2);
