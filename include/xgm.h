@@ -139,12 +139,14 @@ int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stripe_bits, co
 /* Refresh the segment of a shard that moved to a newer revision, reading from glass only what changed.  Contract: every
  * document with docid < first_changed_docid is the same in the old segment's revision and in glass now (Xapiand knows the
  * smallest docid its write-ahead log touched since a revision: reference src/database/wal.cc; appended documents only →
- * old lastdocid + 1).  Postings and positions below the floor are unpacked from the old segment, the rest is read from
- * glass (posting chunks / position lists below the floor are skipped by their headers / keys), and the merged postings go
- * through the ordinary builder: the output is byte for byte what xgm_segment_build_from_glass writes for the new revision.
- * stripe_bits 0 = the old segment's.  XGM_E_INVALID when the part of the contract that is cheap to check fails (document
- * lengths below the floor differ, floor beyond the old segment): fall back to the full export.  Replaces: the reference
- * reopening a shard whose revision changed (src/database/handler.cc:1282, 1333). */
+ * old lastdocid + 1).  The blocks of the stripes below the floor's are copied verbatim from the old segment, its postings
+ * between that stripe's start and the floor are re-encoded together with what glass holds from the floor on (posting
+ * chunks / position lists below it are skipped by their headers / keys; terms whose positions the old segment had dropped
+ * are read in full): the output is byte for byte what xgm_segment_build_from_glass writes for the new revision.
+ * stripe_bits: 0 or the old segment's.  XGM_E_INVALID when the part of the contract that is cheap to check fails (document
+ * lengths below the floor differ, floor beyond the old segment, another stripe width, the position table appeared or
+ * vanished): fall back to the full export.  Replaces: the reference reopening a shard whose revision changed
+ * (src/database/handler.cc:1282, 1333). */
 int xgm_segment_refresh_from_glass(const char* old_segment_path, const char* glass_dir, uint32_t first_changed_docid,
                                    uint32_t stripe_bits, const char* out_path);
 

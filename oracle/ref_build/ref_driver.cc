@@ -256,7 +256,7 @@ int cmd_build_range(int argc, char** argv) {
 
 /* append <dbdir> <seed> <g_first> <g_last> <vocab> <len_lo> <len_hi> [<mutate_from>]: open an existing database, add the corpus
  * documents g_first..g_last (their docids continue after the current last docid) and — with mutate_from — delete every 7th and
- * replace every 11th document whose docid is >= mutate_from; one commit.  What a shard looks like one revision later
+ * replace every 11th EXISTING document whose docid is >= mutate_from; one commit.  What a shard looks like one revision later
  * (tests of the incremental segment refresh). */
 int cmd_append(int argc, char** argv) {
     if (argc < 9) return 2;
@@ -282,7 +282,10 @@ int cmd_append(int argc, char** argv) {
     };
     const Xapian::docid last_before = db.get_lastdocid();
     if (mutate_from) {
-        for (Xapian::docid d = mutate_from; d <= last_before; ++d) {
+        std::vector<Xapian::docid> present;                 /* the documents that exist at or above the floor */
+        Xapian::PostingIterator it = db.postlist_begin("");
+        for (it.skip_to(mutate_from); it != db.postlist_end(""); ++it) present.push_back(*it);
+        for (Xapian::docid d : present) {
             if (d % 7 == 0) db.delete_document(d);
             else if (d % 11 == 0) db.replace_document(d, make(1000000ull + d));
         }

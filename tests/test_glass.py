@@ -142,3 +142,38 @@ def test_incremental_refresh_keeps_format_corners(built, tmp_path):
     _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
     _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), out["last_before"] + 1, 0, inc.encode()))
     assert open(full, "rb").read() == open(inc, "rb").read()
+
+
+def test_incremental_refresh_copies_whole_stripes(built, tmp_path):
+    """Narrow stripes (2^10 docids): the old segment's blocks of the stripes below the floor's are copied verbatim, the old postings
+    between that stripe's start and the floor are re-encoded together with glass's — deletes and replaces above the floor included."""
+    import json
+    db = str(tmp_path / "db")
+    H.xapian_ref("build", db, H.CORPUS_SEED, 9000, 40000, 50, 150)
+    L = _lib.lib()
+    seg1 = str(tmp_path / "rev1.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 10, seg1.encode()))
+    json.loads(H.xapian_ref("append", db, H.CORPUS_SEED, 20001, 21500, 40000, 50, 150, 5500))
+    full, inc = str(tmp_path / "rev2_full.seg"), str(tmp_path / "rev2_inc.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 10, full.encode()))
+    for floor in (5500, 5121, 5120, 4097, 2):
+        _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), floor, 10, inc.encode()))
+        assert open(full, "rb").read() == open(inc, "rb").read(), floor
+    assert L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 5500, 11, inc.encode()) == _lib.XGM_E_INVALID   # another stripe width
+
+
+def test_incremental_refresh_when_the_reason_positions_were_dropped_is_gone(built, tmp_path):
+    """The old segment keeps no positions for a term that had a posting without them ("mixed": add_term beside add_posting).  When
+    every such document is replaced above the floor, the full export of the new revision stores the term's positions again — the
+    refresh cannot get them out of the old segment and must read that term from glass in full."""
+    import json
+    db = str(tmp_path / "misc")
+    H.xapian_ref("build_misc", db)
+    L = _lib.lib()
+    seg1 = str(tmp_path / "rev1.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, seg1.encode()))
+    json.loads(H.xapian_ref("append", db, H.CORPUS_SEED, 1, 50, 3000, 20, 60, 10))      # from docid 10 on: every 7th deleted, every 11th replaced
+    full, inc = str(tmp_path / "rev2_full.seg"), str(tmp_path / "rev2_inc.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
+    _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 10, 0, inc.encode()))
+    assert open(full, "rb").read() == open(inc, "rb").read()

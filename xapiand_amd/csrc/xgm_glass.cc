@@ -25,6 +25,7 @@
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -298,8 +299,9 @@ int read_chunk_body(const uint8_t* p, const uint8_t* end, uint64_t first_did, F&
 
 /* min_did > 0: postings and positions of documents below it are skipped (whole chunks by their header, position lists by
  * their key) — the incremental refresh takes those from the previous segment.  Document lengths are always read in full. */
-int read_glass(const char* glass_dir, Export* ex, uint64_t min_did = 0) {
+int read_glass(const char* glass_dir, Export* ex, uint64_t min_did_all = 0, const std::set<std::string>* full_terms = nullptr) {
     const std::string dir(glass_dir);
+    uint64_t min_did = min_did_all;                 /* of the term at hand: 0 for the terms wanted in full */
     int rc = read_version(dir, &ex->ver);
     if (rc) return rc;
     if (ex->ver.last_docid > 0xFFFFFFFEull) return xgm_set_error(XGM_E_INVALID, "docids beyond 32 bits");
@@ -344,6 +346,7 @@ int read_glass(const char* glass_dir, Export* ex, uint64_t min_did = 0) {
             ex->df.push_back(0);
             term = t;
             have_term = true;
+            min_did = (full_terms && full_terms->count(t)) ? 0 : min_did_all;
         } else {
             if (!have_term || t != term) return xgm_set_error(XGM_E_INVALID, "postlist: continuation chunk without a first chunk");
             if (!get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &first)) return xgm_set_error(XGM_E_INVALID, "postlist: bad chunk key");
@@ -363,6 +366,8 @@ int read_glass(const char* glass_dir, Export* ex, uint64_t min_did = 0) {
     if (ex->has_positions) {
         /* the table is ordered by (term, docid) like the postings: merge in lockstep */
         ex->pos_off.assign(1, 0);
+        std::string pos_term;                /* (floor) the term of the last entry below it and whether it is wanted in full */
+        bool pos_term_full = false;
         size_t ti = 0;                       /* current term of the posting cursor */
         uint64_t pi = 0, t_end = ex->terms.empty() ? 0 : ex->df[0];             /* posting ordinal, end of term ti */
         std::vector<uint32_t> tmp;
@@ -372,7 +377,11 @@ int read_glass(const char* glass_dir, Export* ex, uint64_t min_did = 0) {
             split_term_key(key, &t, &rest);
             uint64_t d;
             if (!rest || !get_sortable_uint(&rest, (const uint8_t*)key.data() + key.size(), &d)) return xgm_set_error(XGM_E_INVALID, "position table: bad key");
-            if (d < min_did) return XGM_OK;
+            if (d < min_did_all) {
+                if (!full_terms) return XGM_OK;
+                if (t != pos_term) { pos_term = t; pos_term_full = full_terms->count(t) != 0; }
+                if (!pos_term_full) return XGM_OK;
+            }
             /* advance the posting cursor to (t, d); postings passed over have no positions */
             while (true) {
                 if (ti >= ex->terms.size()) return xgm_set_error(XGM_E_INVALID, "position table: entry without a posting");
@@ -489,18 +498,16 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
     const xgm_seg_header* h = old.header();
     const uint64_t X = first_changed_docid;
     if (X > (uint64_t)h->lastdocid + 1) return xgm_set_error(XGM_E_INVALID, "first_changed_docid %u beyond the old segment's last docid %u + 1", first_changed_docid, h->lastdocid);
-    Export ex;
-    if ((rc = read_glass(glass_dir, &ex, X))) return rc;
-    if (ex.ver.revision < h->revision) return xgm_set_error(XGM_E_INVALID, "glass revision %llu is older than the segment's %llu", (unsigned long long)ex.ver.revision, (unsigned long long)h->revision);
-    const uint32_t* odl = old.section<uint32_t>(XGM_S_DOCLEN);
-    for (uint64_t d = 1; d < X; ++d)
-        if (d >= ex.doclen.size() || odl[d] != ex.doclen[d]) return xgm_set_error(XGM_E_INVALID, "document %llu below first_changed_docid differs from the old segment: full export needed", (unsigned long long)d);
+    if (stripe_bits && stripe_bits != h->stripe_bits) return xgm_set_error(XGM_E_INVALID, "stripe width differs from the old segment's: full export needed");
+    const uint32_t SB = h->stripe_bits;
+    const uint64_t Xs = (X >> SB) << SB;         /* stripes below X's are unchanged as a whole: their blocks are copied verbatim */
 
     /* old dictionary + block tables */
     const uint32_t oT = h->n_terms;
     const uint64_t* so = old.section<uint64_t>(XGM_S_STR_OFF);
     const char* sb = old.section<char>(XGM_S_STR_BYTES);
     const uint32_t* oflags = old.section<uint32_t>(XGM_S_TERM_FLAGS);
+    const uint32_t* ocf = old.section<uint32_t>(XGM_S_TERM_CF);
     const uint64_t* tb = old.section<uint64_t>(XGM_S_TERM_BLK);
     const uint64_t* tw = old.section<uint64_t>(XGM_S_TERM_WORD);
     const uint64_t* tp = old.section<uint64_t>(XGM_S_TERM_POS);
@@ -510,65 +517,54 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
     const uint32_t* bps = old.section<uint32_t>(XGM_S_BLK_POS);
     const uint32_t* words = old.section<uint32_t>(XGM_S_WORDS);
     const uint8_t* opos = old.section<uint8_t>(XGM_S_POSITIONS);
-
-    Export mg;                                   /* merged: old postings below the floor, then glass's */
-    mg.ver = ex.ver;
-    mg.doclen.swap(ex.doclen);
-    mg.has_positions = ex.has_positions;
-    mg.doccount = ex.doccount; mg.total_length = ex.total_length;
-    if (mg.has_positions) mg.pos_off.assign(1, 0);
-    uint64_t np = 0;                             /* cursor into ex's postings */
-    uint32_t oi = 0;
-    size_t ni = 0;
     auto old_term = [&](uint32_t t) { return std::string(sb + so[t], (size_t)(so[t + 1] - so[t])); };
-    /* appends old term t's postings below the floor; returns how many */
-    auto take_old = [&](uint32_t t) -> uint32_t {
-        uint32_t n = 0;
-        const bool have_pos = h->has_positions && (oflags[t] & XGM_TF_POS_OK);
-        const bool dropped = h->has_positions && !(oflags[t] & XGM_TF_POS_OK);   /* (a shard that had no position table at all: every old posting truly has none) */
-        const bool p16 = (oflags[t] & XGM_TF_POS16) != 0;
-        bool marked = false;                     /* a term whose positions the old segment dropped (some posting had positions != wdf)
-                                                    must come out position-less again: give its first posting a count that cannot match */
-        for (uint64_t b = tb[t]; b < tb[t + 1] && bf[b] < X; ++b) {
-            const uint32_t cnt = XGM_META_COUNT(bm[b]), bwg = XGM_META_BWG(bm[b]), bww = XGM_META_BWW(bm[b]);
-            const uint32_t* gw = words + tw[t] + bwd[b];
-            const uint32_t* ww = gw + ((uint64_t)cnt * bwg + 31) / 32;
-            uint32_t d = bf[b];
-            uint64_t pe = bps[b];                /* position entry of the posting inside the term's array */
-            for (uint32_t j = 0; j < cnt; ++j) {
-                if (j) d += seg_bits(gw, j, bwg) + 1;
-                const uint32_t w = seg_bits(ww, j, bww);
-                if (d >= X) break;
-                mg.did.push_back(d); mg.wdf.push_back(w); ++n;
-                if (mg.has_positions) {
-                    if (have_pos) {
-                        for (uint32_t q = 0; q < w; ++q) {
-                            const uint8_t* e = opos + tp[t] + (pe + q) * (p16 ? 2u : 4u);
-                            mg.pos.push_back(p16 ? (uint32_t)e[0] | ((uint32_t)e[1] << 8) : (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24));
-                        }
-                    } else if (dropped && !marked) {
-                        for (uint32_t q = 0; q <= w; ++q) mg.pos.push_back(1u + q);
-                        marked = true;
-                    }
-                    mg.pos_off.push_back(mg.pos.size());
-                }
-                pe += w;
-            }
-        }
-        return n;
-    };
-    auto take_new = [&](size_t i) -> uint32_t {
+
+    /* terms whose positions the old segment dropped (some posting had positions != wdf) cannot be reconstructed from it — and the
+     * offending posting may be gone by now: those terms are read from glass in full */
+    std::set<std::string> in_full;
+    if (h->has_positions)
+        for (uint32_t t = 0; t < oT; ++t) if (!(oflags[t] & XGM_TF_POS_OK)) in_full.insert(old_term(t));
+
+    Export ex;
+    if ((rc = read_glass(glass_dir, &ex, X, &in_full))) return rc;
+    if (ex.ver.revision < h->revision) return xgm_set_error(XGM_E_INVALID, "glass revision %llu is older than the segment's %llu", (unsigned long long)ex.ver.revision, (unsigned long long)h->revision);
+    if ((h->has_positions != 0) != ex.has_positions && X > 1) return xgm_set_error(XGM_E_INVALID, "the shard gained or lost its position table: full export needed");
+    const uint32_t* odl = old.section<uint32_t>(XGM_S_DOCLEN);
+    for (uint64_t d = 1; d < X; ++d)
+        if (d >= ex.doclen.size() || odl[d] != ex.doclen[d]) return xgm_set_error(XGM_E_INVALID, "document %llu below first_changed_docid differs from the old segment: full export needed", (unsigned long long)d);
+
+    const bool has_pos = ex.has_positions;
+    xgm_raw_postings raw;
+    std::vector<const char*> tpv;
+    std::vector<uint32_t> tl;
+    {
+        Export stub;                                 /* statistics and document lengths of the new revision (no postings) */
+        stub.ver = ex.ver; stub.has_positions = has_pos;
+        fill_raw(stub, &tpv, &tl, &raw);
+        raw.doclen = ex.doclen.data();
+    }
+    uint32_t wdf_seen = 0, doclen_lb, doclen_ub, wdf_ub_db;
+    for (uint32_t w : ex.wdf) wdf_seen = std::max(wdf_seen, w);
+    xgm_database_bounds(&raw, std::max(wdf_seen, X > 1 ? h->wdf_upper_bound : 0u), &doclen_lb, &doclen_ub, &wdf_ub_db);
+    XgmSegmentWriter w;
+    if ((rc = w.begin(SB, has_pos, wdf_ub_db))) return rc;
+
+    std::vector<uint32_t> t_did, t_wdf, t_pos;     /* the term's postings that are encoded afresh: old ones in [Xs, X), then glass's */
+    std::vector<uint64_t> t_poff;
+    uint64_t np = 0;                               /* cursor into ex's postings */
+    auto take_new = [&](size_t i) {
         const uint32_t n = ex.df[i];
         for (uint32_t k = 0; k < n; ++k) {
-            mg.did.push_back(ex.did[np + k]); mg.wdf.push_back(ex.wdf[np + k]);
-            if (mg.has_positions) {
-                for (uint64_t q = ex.pos_off[np + k]; q < ex.pos_off[np + k + 1]; ++q) mg.pos.push_back(ex.pos[q]);
-                mg.pos_off.push_back(mg.pos.size());
+            t_did.push_back(ex.did[np + k]); t_wdf.push_back(ex.wdf[np + k]);
+            if (has_pos) {
+                for (uint64_t q = ex.pos_off[np + k]; q < ex.pos_off[np + k + 1]; ++q) t_pos.push_back(ex.pos[q]);
+                t_poff.push_back(t_pos.size());
             }
         }
         np += n;
-        return n;
     };
+    uint32_t oi = 0;
+    size_t ni = 0;
     while (oi < oT || ni < ex.terms.size()) {
         int c;
         std::string ot;
@@ -576,18 +572,86 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
         if (oi >= oT) c = 1;
         else if (ni >= ex.terms.size()) c = -1;
         else c = ot.compare(ex.terms[ni]);
-        uint32_t n = 0;
-        std::string name;
-        if (c < 0) { name = ot; n = take_old(oi++); }
-        else if (c > 0) { name = ex.terms[ni]; n = take_new(ni++); }
-        else { name = ot; n = take_old(oi++); n += take_new(ni++); }
-        if (n) { mg.terms.push_back(name); mg.df.push_back(n); }
+        const bool from_old = c <= 0 && X > 1 && !in_full.count(ot);
+        const std::string& name = c <= 0 ? ot : ex.terms[ni];
+        t_did.clear(); t_wdf.clear(); t_pos.clear(); t_poff.assign(1, 0);
+        uint64_t b_copy = 0, cf_copied = 0;
+        uint32_t first_wdf = 0;
+        bool copied16 = true;
+        if (from_old) {
+            const uint32_t t = oi;
+            const bool o16 = (oflags[t] & XGM_TF_POS16) != 0;
+            /* blocks wholly below Xs are copied; the rest of the old list is decoded: what is below X is kept (and re-encoded),
+             * everything decoded is subtracted from the term's collection frequency to get the copied part's */
+            uint64_t lo = tb[t], hi = tb[t + 1];
+            while (lo < hi) { const uint64_t mid = lo + (hi - lo) / 2; if (bf[mid] < Xs) lo = mid + 1; else hi = mid; }
+            b_copy = lo;
+            uint64_t cf_rest = 0;
+            for (uint64_t b = b_copy; b < tb[t + 1]; ++b) {
+                const uint32_t cnt = XGM_META_COUNT(bm[b]), bwg = XGM_META_BWG(bm[b]), bww = XGM_META_BWW(bm[b]);
+                const uint32_t* gw = words + tw[t] + bwd[b];
+                const uint32_t* ww = gw + ((uint64_t)cnt * bwg + 31) / 32;
+                uint32_t d = bf[b];
+                uint64_t pe = bps[b];
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    if (j) d += seg_bits(gw, j, bwg) + 1;
+                    const uint32_t wd = seg_bits(ww, j, bww);
+                    cf_rest += wd;
+                    if (d < X) {
+                        t_did.push_back(d); t_wdf.push_back(wd);
+                        if (has_pos) {
+                            for (uint32_t q = 0; q < wd; ++q) {
+                                const uint8_t* e = opos + tp[t] + (pe + q) * (o16 ? 2u : 4u);
+                                t_pos.push_back(o16 ? (uint32_t)e[0] | ((uint32_t)e[1] << 8) : (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16) | ((uint32_t)e[3] << 24));
+                            }
+                            t_poff.push_back(t_pos.size());
+                        }
+                    }
+                    pe += wd;
+                }
+            }
+            if (b_copy > tb[t]) {
+                if (ocf[t] != 0xFFFFFFFFu) cf_copied = (uint64_t)ocf[t] - cf_rest;
+                else {                                                  /* a saturated collection frequency: count the copied part */
+                    for (uint64_t b = tb[t]; b < b_copy; ++b) {
+                        const uint32_t cnt = XGM_META_COUNT(bm[b]), bwg = XGM_META_BWG(bm[b]), bww = XGM_META_BWW(bm[b]);
+                        const uint32_t* ww = words + tw[t] + bwd[b] + ((uint64_t)cnt * bwg + 31) / 32;
+                        for (uint32_t j = 0; j < cnt; ++j) cf_copied += seg_bits(ww, j, bww);
+                    }
+                }
+                const uint64_t b0 = tb[t];
+                first_wdf = seg_bits(words + tw[t] + bwd[b0] + ((uint64_t)XGM_META_COUNT(bm[b0]) * XGM_META_BWG(bm[b0]) + 31) / 32, 0, XGM_META_BWW(bm[b0]));
+                if (has_pos && !o16) {
+                    /* 4-byte entries: because of a position >= 65536 among the copied postings — or among postings that are gone? */
+                    const uint64_t e_end = b_copy < tb[t + 1] ? bps[b_copy] : cf_copied;
+                    const uint8_t* src = opos + tp[t];
+                    bool small = true;
+                    for (uint64_t e = 0; small && e < e_end; ++e) small = src[4 * e + 2] == 0 && src[4 * e + 3] == 0;
+                    copied16 = small;
+                }
+            }
+        }
+        if (c >= 0) take_new(ni);
+        bool pos_ok = has_pos, pos16 = has_pos && copied16;
+        if (has_pos && !t_did.empty()) {
+            bool ok, p16;
+            xgm_positional_form(t_wdf.data(), (uint32_t)t_did.size(), t_poff.data(), t_pos.data(), &ok, &p16);
+            pos_ok = ok; pos16 = ok && p16 && copied16;
+        }
+        const bool any = (from_old && b_copy > tb[oi]) || !t_did.empty();
+        if (any) {
+            if ((rc = w.begin_term(name.data(), (uint32_t)name.size(), pos_ok, pos16))) return rc;
+            if (from_old && b_copy > tb[oi] && (rc = w.copy_blocks(old, oi, b_copy, cf_copied, first_wdf))) return rc;
+            if (!t_did.empty() && (rc = w.add_postings(t_did.data(), t_wdf.data(), (uint32_t)t_did.size(), has_pos ? t_poff.data() : nullptr, t_pos.data()))) return rc;
+            if ((rc = w.end_term())) return rc;
+        }
+        if (c <= 0) ++oi;
+        if (c >= 0) ++ni;
     }
-    std::vector<const char*> tpv;
-    std::vector<uint32_t> tl;
-    xgm_raw_postings raw;
-    fill_raw(mg, &tpv, &tl, &raw);
-    return xgm_segment_build(&raw, stripe_bits ? stripe_bits : h->stripe_bits, out_path);
+    raw.n_postings = w.n_postings;
+    XgmSegmentBlob blob;
+    if ((rc = w.finish(&raw, doclen_lb, doclen_ub, &blob))) return rc;
+    return xgm_write_blob(blob, out_path);
 }
 
 extern "C" int xgm_glass_info(const char* glass_dir, uint64_t* revision, uint32_t* doccount, uint32_t* lastdocid, uint64_t* total_length) {

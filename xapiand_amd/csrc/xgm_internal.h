@@ -24,6 +24,37 @@ struct XgmSegmentBlob {
 };
 
 int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out);
+
+/* The segment writer behind xgm_build_segment_blob and the incremental refresh (xgm_segment_build.cc). */
+struct XgmSegmentWriter {
+    uint32_t stripe_bits = 0, wdf_ub_db = 0;
+    bool has_pos = false;
+    std::vector<uint32_t> term_df, term_cf, term_wdfub, term_flags;
+    std::vector<uint64_t> term_blk, term_word, term_pos, str_off;
+    std::vector<uint32_t> blk_first, blk_meta, blk_word, blk_pos, words;
+    std::vector<uint8_t> positions;          /* per term: u16 or u32 entries (XGM_TF_POS16) */
+    std::vector<char> str_bytes;
+    uint64_t n_pos_entries = 0, n_postings = 0;
+    /* the term being written */
+    bool t_pos_ok = false, t_pos16 = false, t_have_first = false;
+    uint64_t t_entries = 0, t_df = 0, t_cf = 0;
+    uint32_t t_first_wdf = 0;
+
+    int begin(uint32_t stripe_bits, bool with_positions, uint32_t wdf_ub_of_the_database);
+    /* pos_ok / pos16: the positional form of the WHOLE term (every posting has exactly wdf positions / all below 65536) */
+    int begin_term(const char* name, uint32_t len, bool pos_ok, bool pos16);
+    /* blocks [first block of old term t, b_end) verbatim (headers, payload, positions at this term's entry width): only as the first
+     * thing of a term; cf_of_them = Σ wdf of their postings, first_wdf = wdf of the term's first posting */
+    int copy_blocks(const XgmSegmentBlob& old, uint32_t t, uint64_t b_end, uint64_t cf_of_them, uint32_t first_wdf);
+    /* postings in ascending docid order, after whatever the term holds already; pos_off is indexed like did (df + 1 entries) */
+    int add_postings(const uint32_t* did, const uint32_t* wdf, uint32_t df, const uint64_t* pos_off, const uint32_t* pos);
+    int end_term();
+    int finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out);
+    void put_position(uint32_t v);
+};
+int xgm_write_blob(const XgmSegmentBlob& blob, const char* path);
+void xgm_database_bounds(const xgm_raw_postings* raw, uint32_t wdf_max_seen, uint32_t* doclen_lb, uint32_t* doclen_ub, uint32_t* wdf_ub);
+void xgm_positional_form(const uint32_t* wdf, uint32_t df, const uint64_t* pos_off, const uint32_t* pos, bool* pos_ok, bool* pos16);
 int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vector<const char*>* term_ptrs,
                       std::vector<uint32_t>* term_lens, xgm_raw_postings* raw);
 int xgm_validate_header(const xgm_seg_header* h, uint64_t avail_bytes);

@@ -106,120 +106,152 @@ int xgm_validate_blob(const XgmSegmentBlob& blob) {
     return XGM_OK;
 }
 
-int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out) {
-    if (!raw || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
-    if (stripe_bits == 0) stripe_bits = XGM_DEFAULT_STRIPE_BITS;
-    if (stripe_bits < XGM_MIN_STRIPE_BITS || stripe_bits > XGM_MAX_STRIPE_BITS)
-        return xgm_set_error(XGM_E_INVALID, "stripe_bits %u out of range [%u, %u]", stripe_bits, XGM_MIN_STRIPE_BITS,
-                             XGM_MAX_STRIPE_BITS);
-    const uint32_t T = raw->n_terms;
-    const bool has_pos = raw->has_positions && raw->pos_off && (raw->pos || raw->n_positions == 0);
+/* ---- the segment writer: terms are added in ascending byte order, each as (optionally) a run of blocks copied verbatim from an
+ * older segment followed by postings encoded into new blocks.  xgm_build_segment_blob (everything encoded) and the incremental
+ * refresh (xgm_glass.cc: unchanged stripes copied) go through the same code, so their outputs agree byte for byte. ---- */
 
-    std::vector<uint32_t> term_cf(T), term_wdfub(T), term_flags(T);
-    std::vector<uint64_t> term_blk(T + 1), term_word(T + 1), term_pos(T + 1);
-    std::vector<uint32_t> blk_first, blk_meta, blk_word, blk_pos, words;
-    std::vector<uint8_t> positions;              /* per term: u16 or u32 entries (XGM_TF_POS16) */
-    uint64_t n_pos_entries = 0;
-    std::vector<uint64_t> str_off(T + 1);
-    std::vector<char> str_bytes;
+int XgmSegmentWriter::begin(uint32_t sb, bool with_positions, uint32_t wdf_ub_of_the_database) {
+    if (sb == 0) sb = XGM_DEFAULT_STRIPE_BITS;
+    if (sb < XGM_MIN_STRIPE_BITS || sb > XGM_MAX_STRIPE_BITS)
+        return xgm_set_error(XGM_E_INVALID, "stripe_bits %u out of range [%u, %u]", sb, XGM_MIN_STRIPE_BITS, XGM_MAX_STRIPE_BITS);
+    stripe_bits = sb; has_pos = with_positions; wdf_ub_db = wdf_ub_of_the_database;
+    return XGM_OK;
+}
 
-    /* DB-wide bounds the way glass tracks them (reference glass_version.h:252-270):
-     * doclen lower bound = smallest non-zero length, wdf upper bound = largest wdf. */
-    uint32_t doclen_lb = 0, doclen_ub = 0, wdf_ub_db = 0;
-    for (uint64_t d = 1; d <= raw->lastdocid; ++d) {
-        uint32_t l = raw->doclen[d];
-        if (l && (doclen_lb == 0 || l < doclen_lb)) doclen_lb = l;
-        doclen_ub = std::max(doclen_ub, l);
+int XgmSegmentWriter::begin_term(const char* name, uint32_t len, bool pos_ok, bool pos16) {
+    if (!term_df.empty()) {
+        /* terms must be strictly ascending bytewise */
+        const char* prev = str_bytes.data() + str_off.back();
+        const uint32_t la = (uint32_t)(str_bytes.size() - str_off.back());
+        int c = memcmp(prev, name, std::min(la, len));
+        if (c > 0 || (c == 0 && la >= len)) return xgm_set_error(XGM_E_INVALID, "terms not sorted at index %zu", term_df.size());
     }
-    if (raw->doclen_upper_bound > doclen_ub) doclen_ub = raw->doclen_upper_bound;
-    for (uint64_t i = 0; i < raw->n_postings; ++i) wdf_ub_db = std::max(wdf_ub_db, raw->wdf[i]);
-    /* the backend's own (looser) bounds win when given: they are what the reference's BM25Weight sees */
-    if (raw->doclen_lower_bound && (doclen_lb == 0 || raw->doclen_lower_bound <= doclen_lb)) doclen_lb = raw->doclen_lower_bound;
-    if (raw->wdf_upper_bound >= wdf_ub_db && raw->wdf_upper_bound) wdf_ub_db = raw->wdf_upper_bound;
+    str_off.push_back(str_bytes.size());
+    str_bytes.insert(str_bytes.end(), name, name + len);
+    term_blk.push_back(blk_first.size());
+    term_word.push_back(words.size());
+    t_pos_ok = has_pos && pos_ok; t_pos16 = t_pos_ok && pos16;
+    const size_t pw = t_pos16 ? 2u : 4u;
+    positions.resize((positions.size() + pw - 1) / pw * pw, 0);          /* the term's array is aligned to its entry width */
+    term_pos.push_back(positions.size());
+    t_entries = 0; t_df = 0; t_cf = 0; t_first_wdf = 0; t_have_first = false;
+    return XGM_OK;
+}
 
-    uint64_t p0 = 0;
+void XgmSegmentWriter::put_position(uint32_t v) {
+    positions.push_back((uint8_t)v); positions.push_back((uint8_t)(v >> 8));
+    if (!t_pos16) { positions.push_back((uint8_t)(v >> 16)); positions.push_back((uint8_t)(v >> 24)); }
+    ++t_entries; ++n_pos_entries;
+}
+
+int XgmSegmentWriter::copy_blocks(const XgmSegmentBlob& old, uint32_t t, uint64_t b_end, uint64_t cf_of_them, uint32_t first_wdf) {
+    const xgm_seg_header* h = old.header();
+    if (h->stripe_bits != stripe_bits) return xgm_set_error(XGM_E_INVALID, "copy_blocks: stripe widths differ");
+    const uint64_t* tb = old.section<uint64_t>(XGM_S_TERM_BLK);
+    const uint64_t* tw = old.section<uint64_t>(XGM_S_TERM_WORD);
+    const uint64_t* tp = old.section<uint64_t>(XGM_S_TERM_POS);
+    const uint32_t* oflags = old.section<uint32_t>(XGM_S_TERM_FLAGS);
+    const uint32_t* bf = old.section<uint32_t>(XGM_S_BLK_FIRST);
+    const uint32_t* bm = old.section<uint32_t>(XGM_S_BLK_META);
+    const uint32_t* bwd = old.section<uint32_t>(XGM_S_BLK_WORD);
+    const uint32_t* bps = old.section<uint32_t>(XGM_S_BLK_POS);
+    const uint32_t* ow = old.section<uint32_t>(XGM_S_WORDS);
+    const uint8_t* op = old.section<uint8_t>(XGM_S_POSITIONS);
+    const uint64_t b0 = tb[t];
+    if (b_end <= b0 || t_df) return XGM_OK;                  /* nothing to copy (only ever the first thing added to a term) */
+    /* payload words of the copied blocks: [0, end of the last one) of the old term's payload */
+    const uint64_t last = b_end - 1;
+    const uint32_t lc = XGM_META_COUNT(bm[last]), lg = XGM_META_BWG(bm[last]), lw = XGM_META_BWW(bm[last]);
+    const uint64_t wend = (uint64_t)bwd[last] + ((uint64_t)lc * lg + 31) / 32 + ((uint64_t)lc * lw + 31) / 32;
+    words.insert(words.end(), ow + tw[t], ow + tw[t] + wend);
+    uint64_t n = 0;
+    for (uint64_t b = b0; b < b_end; ++b) {
+        blk_first.push_back(bf[b]); blk_meta.push_back(bm[b]); blk_word.push_back(bwd[b]);
+        blk_pos.push_back(t_pos_ok ? bps[b] : 0u);
+        n += XGM_META_COUNT(bm[b]);
+    }
+    if (t_pos_ok) {
+        /* positions of the copied postings: the old term's entries [0, e_end) — the entry of the block after the last copied one,
+         * or all the term's when every block is copied — at the width this term now has */
+        const bool o16 = (oflags[t] & XGM_TF_POS16) != 0;
+        const uint64_t total = (tp[t + 1] - tp[t]) / (o16 ? 2u : 4u);      /* (alignment padding follows the term, never inside) */
+        uint64_t e_end = b_end < tb[t + 1] ? bps[b_end] : cf_of_them;
+        if (e_end > total) e_end = total;
+        const uint8_t* src = op + tp[t];
+        if (o16 == t_pos16) {
+            positions.insert(positions.end(), src, src + e_end * (o16 ? 2u : 4u));
+            t_entries += e_end; n_pos_entries += e_end;
+        } else {
+            for (uint64_t e = 0; e < e_end; ++e)
+                put_position(o16 ? (uint32_t)src[2 * e] | ((uint32_t)src[2 * e + 1] << 8)
+                                 : (uint32_t)src[4 * e] | ((uint32_t)src[4 * e + 1] << 8) | ((uint32_t)src[4 * e + 2] << 16) | ((uint32_t)src[4 * e + 3] << 24));
+        }
+    }
+    t_df += n; t_cf += cf_of_them;
+    t_first_wdf = first_wdf; t_have_first = true;
+    return XGM_OK;
+}
+
+int XgmSegmentWriter::add_postings(const uint32_t* did, const uint32_t* wdf, uint32_t df, const uint64_t* pos_off, const uint32_t* pos) {
     BitWriter bw(words);
-    for (uint32_t t = 0; t < T; ++t) {
-        if (t > 0) {
-            /* terms must be strictly ascending bytewise */
-            const uint32_t la = raw->term_len[t - 1], lb = raw->term_len[t];
-            int c = memcmp(raw->terms[t - 1], raw->terms[t], std::min(la, lb));
-            if (c > 0 || (c == 0 && la >= lb)) return xgm_set_error(XGM_E_INVALID, "terms not sorted at index %u", t);
+    uint32_t i = 0;
+    if (df && !t_have_first) { t_first_wdf = wdf[0]; t_have_first = true; }
+    for (uint32_t q = 0; q < df; ++q) t_cf += wdf[q];
+    /* cut into blocks: same stripe, <= XGM_BLOCK postings */
+    while (i < df) {
+        uint32_t stripe = did[i] >> stripe_bits;
+        uint32_t n = 1;
+        while (n < XGM_BLOCK && i + n < df && (did[i + n] >> stripe_bits) == stripe) ++n;
+        uint32_t maxgap = 0, maxwdf = 0;
+        for (uint32_t j = 0; j < n; ++j) {
+            if (j) maxgap = std::max(maxgap, did[i + j] - did[i + j - 1] - 1);
+            maxwdf = std::max(maxwdf, wdf[i + j]);
         }
-        str_off[t] = str_bytes.size();
-        str_bytes.insert(str_bytes.end(), raw->terms[t], raw->terms[t] + raw->term_len[t]);
-
-        const uint32_t df = raw->df[t];
-        if (df == 0) return xgm_set_error(XGM_E_INVALID, "term %u has df 0", t);
-        if (p0 + df > raw->n_postings) return xgm_set_error(XGM_E_INVALID, "df overruns postings");
-        term_blk[t] = blk_first.size();
-        term_word[t] = words.size();
-        uint64_t cf = 0;
-        bool pos_ok = has_pos;
-        for (uint32_t i = 0; i < df; ++i) {
-            cf += raw->wdf[p0 + i];
-            if (i && raw->did[p0 + i] <= raw->did[p0 + i - 1]) return xgm_set_error(XGM_E_INVALID, "docids of term %u not ascending", t);
-            if (raw->did[p0 + i] == 0 || raw->did[p0 + i] > raw->lastdocid) return xgm_set_error(XGM_E_INVALID, "docid out of range in term %u", t);
-            if (has_pos && raw->pos_off[p0 + i + 1] - raw->pos_off[p0 + i] != raw->wdf[p0 + i]) pos_ok = false;
+        uint32_t bwg = xgm_bits_needed(maxgap), bww = xgm_bits_needed(maxwdf);
+        uint64_t woff = words.size() - term_word.back();
+        uint64_t poff = t_pos_ok ? t_entries : 0;
+        if (woff > 0xFFFFFFFFull || poff > 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "term %zu too large for 32-bit block offsets", term_df.size());
+        blk_first.push_back(did[i]);
+        blk_meta.push_back(XGM_META(n, bwg, bww));
+        blk_word.push_back((uint32_t)woff);
+        blk_pos.push_back((uint32_t)poff);
+        bw.begin(n, bwg);
+        for (uint32_t j = 1; j < n; ++j) bw.put(j, bwg, did[i + j] - did[i + j - 1] - 1);
+        bw.begin(n, bww);
+        for (uint32_t j = 0; j < n; ++j) bw.put(j, bww, wdf[i + j]);
+        if (t_pos_ok) {
+            for (uint32_t j = 0; j < n; ++j)
+                for (uint64_t q = pos_off[i + j]; q < pos_off[i + j + 1]; ++q) put_position(pos[q]);
         }
-        if (cf > 0xFFFFFFFFull) cf = 0xFFFFFFFFull;
-        term_cf[t] = (uint32_t)cf;
-        /* GlassPostListTable::get_freqs (glass_postlist.cc:175-189) capped as in
-         * GlassDatabase::get_wdf_upper_bound (glass_database.cc:823-830). */
-        uint32_t first_wdf = raw->wdf[p0];
-        uint32_t ub = (cf == 0 || df == 1) ? (uint32_t)cf : std::max((uint32_t)cf - first_wdf, first_wdf);
-        term_wdfub[t] = std::min(ub, wdf_ub_db);
-        bool pos16 = pos_ok;
-        if (pos_ok)
-            for (uint64_t q = raw->pos_off[p0]; pos16 && q < raw->pos_off[p0 + df]; ++q) pos16 = raw->pos[q] < 65536u;
-        term_flags[t] = pos_ok ? (XGM_TF_POS_OK | (pos16 ? XGM_TF_POS16 : 0u)) : 0u;
-        const size_t pw = pos16 ? 2u : 4u;
-        positions.resize((positions.size() + pw - 1) / pw * pw, 0);          /* the term's array is aligned to its entry width */
-        term_pos[t] = positions.size();
-        uint64_t term_entries = 0;
-
-        /* cut into blocks: same stripe, <= XGM_BLOCK postings */
-        uint32_t i = 0;
-        while (i < df) {
-            uint32_t stripe = raw->did[p0 + i] >> stripe_bits;
-            uint32_t n = 1;
-            while (n < XGM_BLOCK && i + n < df && (raw->did[p0 + i + n] >> stripe_bits) == stripe) ++n;
-            uint32_t maxgap = 0, maxwdf = 0;
-            for (uint32_t j = 0; j < n; ++j) {
-                if (j) maxgap = std::max(maxgap, raw->did[p0 + i + j] - raw->did[p0 + i + j - 1] - 1);
-                maxwdf = std::max(maxwdf, raw->wdf[p0 + i + j]);
-            }
-            uint32_t bwg = xgm_bits_needed(maxgap), bww = xgm_bits_needed(maxwdf);
-            uint64_t woff = words.size() - term_word[t];
-            uint64_t poff = term_entries;
-            if (woff > 0xFFFFFFFFull || poff > 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "term %u too large for 32-bit block offsets", t);
-            blk_first.push_back(raw->did[p0 + i]);
-            blk_meta.push_back(XGM_META(n, bwg, bww));
-            blk_word.push_back((uint32_t)woff);
-            blk_pos.push_back((uint32_t)poff);
-            bw.begin(n, bwg);
-            for (uint32_t j = 1; j < n; ++j) bw.put(j, bwg, raw->did[p0 + i + j] - raw->did[p0 + i + j - 1] - 1);
-            bw.begin(n, bww);
-            for (uint32_t j = 0; j < n; ++j) bw.put(j, bww, raw->wdf[p0 + i + j]);
-            if (pos_ok) {
-                for (uint32_t j = 0; j < n; ++j)
-                    for (uint64_t q = raw->pos_off[p0 + i + j]; q < raw->pos_off[p0 + i + j + 1]; ++q) {
-                        const uint32_t v = raw->pos[q];
-                        positions.push_back((uint8_t)v); positions.push_back((uint8_t)(v >> 8));
-                        if (!pos16) { positions.push_back((uint8_t)(v >> 16)); positions.push_back((uint8_t)(v >> 24)); }
-                        ++term_entries; ++n_pos_entries;
-                    }
-            }
-            i += n;
-        }
-        p0 += df;
+        i += n;
     }
-    if (p0 != raw->n_postings) return xgm_set_error(XGM_E_INVALID, "sum of df (%llu) != n_postings (%llu)", (unsigned long long)p0, (unsigned long long)raw->n_postings);
-    term_blk[T] = blk_first.size();
-    term_word[T] = words.size();
-    term_pos[T] = positions.size();
+    t_df += df;
+    return XGM_OK;
+}
+
+int XgmSegmentWriter::end_term() {
+    if (t_df == 0) return xgm_set_error(XGM_E_INVALID, "term %zu has df 0", term_df.size());
+    if (t_df > 0xFFFFFFFFull) return xgm_set_error(XGM_E_INVALID, "term %zu: too many postings", term_df.size());
+    const uint64_t cf = t_cf > 0xFFFFFFFFull ? 0xFFFFFFFFull : t_cf;
+    term_df.push_back((uint32_t)t_df);
+    term_cf.push_back((uint32_t)cf);
+    /* GlassPostListTable::get_freqs (glass_postlist.cc:175-189) capped as in
+     * GlassDatabase::get_wdf_upper_bound (glass_database.cc:823-830). */
+    uint32_t ub = (cf == 0 || t_df == 1) ? (uint32_t)cf : std::max((uint32_t)cf - t_first_wdf, t_first_wdf);
+    term_wdfub.push_back(std::min(ub, wdf_ub_db));
+    term_flags.push_back(t_pos_ok ? (XGM_TF_POS_OK | (t_pos16 ? XGM_TF_POS16 : 0u)) : 0u);
+    n_postings += t_df;
+    return XGM_OK;
+}
+
+int XgmSegmentWriter::finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out) {
+    const uint32_t T = (uint32_t)term_df.size();
+    if (n_postings != raw->n_postings) return xgm_set_error(XGM_E_INVALID, "sum of df (%llu) != n_postings (%llu)", (unsigned long long)n_postings, (unsigned long long)raw->n_postings);
+    term_blk.push_back(blk_first.size());
+    term_word.push_back(words.size());
+    term_pos.push_back(positions.size());
     if (has_pos) positions.resize(positions.size() + XGM_POS_PAD, 0);
-    str_off[T] = str_bytes.size();
+    str_off.push_back(str_bytes.size());
     const uint64_t n_words = words.size();
     words.resize(n_words + XGM_WORD_PAD, 0u);
 
@@ -246,7 +278,7 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
     struct Sec { int id; const void* p; uint64_t bytes; };
     const Sec secs[] = {
         {XGM_S_DOCLEN, raw->doclen, ((uint64_t)raw->lastdocid + 1) * 4},
-        {XGM_S_TERM_DF, raw->df, (uint64_t)T * 4},
+        {XGM_S_TERM_DF, term_df.data(), (uint64_t)T * 4},
         {XGM_S_TERM_CF, term_cf.data(), (uint64_t)T * 4},
         {XGM_S_TERM_WDFUB, term_wdfub.data(), (uint64_t)T * 4},
         {XGM_S_TERM_FLAGS, term_flags.data(), (uint64_t)T * 4},
@@ -274,6 +306,60 @@ int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, Xg
     for (const Sec& s : secs)
         if (s.bytes) memcpy(out->bytes.data() + h.sec_off[s.id], s.p, s.bytes);
     return XGM_OK;
+}
+
+/* DB-wide bounds the way glass tracks them (reference glass_version.h:252-270): doclen lower bound = smallest non-zero length,
+ * wdf upper bound = largest wdf; the backend's own (looser) bounds win when given: they are what the reference's BM25Weight sees */
+void xgm_database_bounds(const xgm_raw_postings* raw, uint32_t wdf_max_seen, uint32_t* doclen_lb_out, uint32_t* doclen_ub_out, uint32_t* wdf_ub_out) {
+    uint32_t doclen_lb = 0, doclen_ub = 0, wdf_ub_db = wdf_max_seen;
+    for (uint64_t d = 1; d <= raw->lastdocid; ++d) {
+        uint32_t l = raw->doclen[d];
+        if (l && (doclen_lb == 0 || l < doclen_lb)) doclen_lb = l;
+        doclen_ub = std::max(doclen_ub, l);
+    }
+    if (raw->doclen_upper_bound > doclen_ub) doclen_ub = raw->doclen_upper_bound;
+    if (raw->doclen_lower_bound && (doclen_lb == 0 || raw->doclen_lower_bound <= doclen_lb)) doclen_lb = raw->doclen_lower_bound;
+    if (raw->wdf_upper_bound >= wdf_ub_db && raw->wdf_upper_bound) wdf_ub_db = raw->wdf_upper_bound;
+    *doclen_lb_out = doclen_lb; *doclen_ub_out = doclen_ub; *wdf_ub_out = wdf_ub_db;
+}
+
+/* which positional form a run of postings allows: every posting has exactly wdf positions (XGM_TF_POS_OK), all of them < 65536 */
+void xgm_positional_form(const uint32_t* wdf, uint32_t df, const uint64_t* pos_off, const uint32_t* pos, bool* pos_ok, bool* pos16) {
+    bool ok = true;
+    for (uint32_t i = 0; ok && i < df; ++i) ok = pos_off[i + 1] - pos_off[i] == wdf[i];
+    bool p16 = ok;
+    if (ok) for (uint64_t q = pos_off[0]; p16 && q < pos_off[df]; ++q) p16 = pos[q] < 65536u;
+    *pos_ok = ok; *pos16 = p16;
+}
+
+int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out) {
+    if (!raw || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
+    const uint32_t T = raw->n_terms;
+    const bool has_pos = raw->has_positions && raw->pos_off && (raw->pos || raw->n_positions == 0);
+    uint32_t wdf_seen = 0, doclen_lb, doclen_ub, wdf_ub_db;
+    for (uint64_t i = 0; i < raw->n_postings; ++i) wdf_seen = std::max(wdf_seen, raw->wdf[i]);
+    xgm_database_bounds(raw, wdf_seen, &doclen_lb, &doclen_ub, &wdf_ub_db);
+    XgmSegmentWriter w;
+    int rc = w.begin(stripe_bits, has_pos, wdf_ub_db);
+    if (rc) return rc;
+    uint64_t p0 = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t df = raw->df[t];
+        if (df == 0) return xgm_set_error(XGM_E_INVALID, "term %u has df 0", t);
+        if (p0 + df > raw->n_postings) return xgm_set_error(XGM_E_INVALID, "df overruns postings");
+        for (uint32_t i = 0; i < df; ++i) {
+            if (i && raw->did[p0 + i] <= raw->did[p0 + i - 1]) return xgm_set_error(XGM_E_INVALID, "docids of term %u not ascending", t);
+            if (raw->did[p0 + i] == 0 || raw->did[p0 + i] > raw->lastdocid) return xgm_set_error(XGM_E_INVALID, "docid out of range in term %u", t);
+        }
+        bool pos_ok = false, pos16 = false;
+        if (has_pos) xgm_positional_form(raw->wdf + p0, df, raw->pos_off + p0, raw->pos, &pos_ok, &pos16);
+        if ((rc = w.begin_term(raw->terms[t], raw->term_len[t], pos_ok, pos16))) return rc;
+        if ((rc = w.add_postings(raw->did + p0, raw->wdf + p0, df, has_pos ? raw->pos_off + p0 : nullptr, raw->pos))) return rc;
+        if ((rc = w.end_term())) return rc;
+        p0 += df;
+    }
+    if (p0 != raw->n_postings) return xgm_set_error(XGM_E_INVALID, "sum of df (%llu) != n_postings (%llu)", (unsigned long long)p0, (unsigned long long)raw->n_postings);
+    return w.finish(raw, doclen_lb, doclen_ub, out);
 }
 
 int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vector<const char*>* term_ptrs,
@@ -329,7 +415,7 @@ int xgm_read_raw_file(const char* path, std::vector<uint8_t>* storage, std::vect
     return XGM_OK;
 }
 
-static int write_blob(const XgmSegmentBlob& blob, const char* path) {
+int xgm_write_blob(const XgmSegmentBlob& blob, const char* path) {
     FILE* f = fopen(path, "wb");
     if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s: %s", path, strerror(errno));
     size_t w = fwrite(blob.bytes.data(), 1, blob.bytes.size(), f);
@@ -342,7 +428,7 @@ extern "C" int xgm_segment_build(const xgm_raw_postings* raw, uint32_t stripe_bi
     XgmSegmentBlob blob;
     int rc = xgm_build_segment_blob(raw, stripe_bits, &blob);
     if (rc) return rc;
-    return write_blob(blob, out_path);
+    return xgm_write_blob(blob, out_path);
 }
 
 extern "C" int xgm_segment_build_from_file(const char* raw_path, uint32_t stripe_bits, const char* out_path) {
