@@ -1,4 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-tag=$1
-timeout 1500 python -m pytest tests -m gpu -q --durations=5 > gpurun_out/${tag}_pytest_gpu.log 2>&1; tail -3 gpurun_out/${tag}_pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke()"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_queries" 2>&1 | tail -15
+XGM_OR_SEED_SCALE=8 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_queries" 2>&1 | tail -3
+XGM_NO_DENSE=1 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "random_queries" 2>&1 | tail -3
