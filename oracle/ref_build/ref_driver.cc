@@ -58,6 +58,10 @@ struct QuerySpec {
     unsigned n_required = 0;      /* AND_NOT / AND_MAYBE / FILTER: the first n_required terms are the left-hand AND */
     unsigned first = 0, maxitems = 10, window = 0;
     std::vector<std::string> terms;
+    /* optional leading tokens of a query line: "SORT=<V|VR|RV>:<slot>:<reverse 0|1>" (Enquire::set_sort_by_value /
+     * _value_then_relevance / _relevance_then_value), "COLLAPSE=<slot>:<max>" (set_collapse_key), "CAL=<n>" (check_at_least) */
+    std::string sort_mode;
+    unsigned sort_slot = 0, sort_reverse = 0, collapse_slot = 0, collapse_max = 0, check_at_least = 0;
 };
 
 std::vector<QuerySpec> read_queries(const char* path) {
@@ -69,6 +73,20 @@ std::vector<QuerySpec> read_queries(const char* path) {
         if (line.empty() || line[0] == '#') continue;
         std::istringstream ss(line);
         QuerySpec q;
+        while (true) {
+            std::streampos at = ss.tellg();
+            std::string tok;
+            if (!(ss >> tok)) break;
+            if (tok.rfind("SORT=", 0) == 0) {
+                char mode[4] = {0};
+                if (sscanf(tok.c_str() + 5, "%3[A-Z]:%u:%u", mode, &q.sort_slot, &q.sort_reverse) != 3) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
+                q.sort_mode = mode;
+            } else if (tok.rfind("COLLAPSE=", 0) == 0) {
+                if (sscanf(tok.c_str() + 9, "%u:%u", &q.collapse_slot, &q.collapse_max) != 2) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
+            } else if (tok.rfind("CAL=", 0) == 0) {
+                q.check_at_least = (unsigned)strtoul(tok.c_str() + 4, nullptr, 10);
+            } else { ss.clear(); ss.seekg(at); break; }
+        }
         ss >> q.op >> q.first >> q.maxitems >> q.window;
         size_t colon = q.op.find(':');
         if (colon != std::string::npos) { q.n_required = (unsigned)strtoul(q.op.c_str() + colon + 1, nullptr, 10); q.op.resize(colon); }
@@ -152,24 +170,38 @@ Xapian::Query make_query(const QuerySpec& q) {
     exit(2);
 }
 
+/* sort / collapse settings of a query on an Enquire (DocMatcher::prepare_mset, reference src/database/handler.cc:1263-1270,
+ * does the same on the shard's and on the merger's) */
+void apply_settings(Xapian::Enquire& enq, const QuerySpec* q) {
+    if (!q) return;
+    if (q->sort_mode == "V") enq.set_sort_by_value(q->sort_slot, q->sort_reverse != 0);
+    else if (q->sort_mode == "VR") enq.set_sort_by_value_then_relevance(q->sort_slot, q->sort_reverse != 0);
+    else if (q->sort_mode == "RV") enq.set_sort_by_relevance_then_value(q->sort_slot, q->sort_reverse != 0);
+    if (q->collapse_max) enq.set_collapse_key(q->collapse_slot, q->collapse_max);
+}
+
 /* One query, Xapiand style.  n_shards == 1 → plain get_mset. */
 Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& query, unsigned first,
-                       unsigned maxitems) {
+                       unsigned maxitems, const QuerySpec* settings = nullptr) {
     size_t n_shards = dbs.size();
+    const unsigned cal = settings ? settings->check_at_least : 0;
     if (n_shards == 1) {
         Xapian::Enquire enq(dbs[0]);
+        apply_settings(enq, settings);
         enq.set_query(query);
-        return enq.get_mset(first, maxitems);
+        return enq.get_mset(first, maxitems, cal);
     }
     bool full_db_has_positions = false;
     for (auto& db : dbs) full_db_has_positions = full_db_has_positions || db.has_positions();
     Xapian::Enquire merger{Xapian::Database{}};
+    apply_settings(merger, settings);
     std::vector<Xapian::Enquire> enqs;
     std::vector<Xapian::MSet> msets(n_shards);
     Xapian::doccount doccount = 0;
     enqs.reserve(n_shards);
     for (size_t s = 0; s < n_shards; ++s) {
         enqs.emplace_back(dbs[s]);
+        apply_settings(enqs[s], settings);
         enqs[s].set_query(query);
         Xapian::MSet prepared = enqs[s].prepare_mset("q", full_db_has_positions, nullptr, nullptr);
         doccount += dbs[s].get_doccount();
@@ -177,7 +209,7 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
     }
     for (size_t s = 0; s < n_shards; ++s) {
         enqs[s].set_prepared_mset(merger.get_prepared_mset());
-        msets[s] = enqs[s].get_mset(0, first + maxitems);
+        msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
         msets[s].unshard_docids(s, n_shards);
     }
     return merger.merge_mset(msets, doccount, first, maxitems);
@@ -194,6 +226,7 @@ int cmd_build(int argc, char** argv) {
     cp.len_hi = (uint32_t)strtoul(argv[7], nullptr, 0);
     unsigned n_shards = argc > 9 ? (unsigned)strtoul(argv[8], nullptr, 0) : 1;
     unsigned shard = argc > 9 ? (unsigned)strtoul(argv[9], nullptr, 0) : 0;
+    const bool with_values = std::string(argv[1]) == "build_values";       /* value slots 0..2 of tools/xgm_corpus.h */
     std::vector<uint64_t> thr(cp.vocab);
     xgm_zipf_thresholds(cp.vocab, thr.data());
     Xapian::WritableDatabase db(dir, Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS |
@@ -207,6 +240,13 @@ int cmd_build(int argc, char** argv) {
         for (uint32_t pos = 1; pos <= len; ++pos) {
             snprintf(name, sizeof name, "t%u", xgm_token(&cp, thr.data(), g, pos));
             doc.add_posting(name, pos);
+        }
+        if (with_values) {
+            char vb[16];
+            for (uint32_t slot = 0; slot < 3; ++slot) {
+                const uint32_t n = xgm_doc_value(&cp, g, slot, vb);
+                if (n) doc.add_value(slot, std::string(vb, n));
+            }
         }
         db.add_document(doc);
         if (++added % 100000 == 0) db.commit();
@@ -386,14 +426,21 @@ int cmd_query(int argc, char** argv) {
     auto dbs = open_dbs(argc, argv, 4);
     for (size_t qi = 0; qi < queries.size(); ++qi) {
         const QuerySpec& q = queries[qi];
-        Xapian::MSet m = run_query(dbs, make_query(q), q.first, q.maxitems);
+        Xapian::MSet m = run_query(dbs, make_query(q), q.first, q.maxitems, &q);
         fprintf(out, "Q %zu %u %u %u %u %a %a\n", qi, m.size(), m.get_matches_lower_bound(),
                 m.get_matches_estimated(), m.get_matches_upper_bound(), m.get_max_possible(),
                 m.get_max_attained());
+        const bool extra = !q.sort_mode.empty() || q.collapse_max;
+        if (extra) fprintf(out, "U %u %u %u\n", m.get_uncollapsed_matches_lower_bound(), m.get_uncollapsed_matches_estimated(), m.get_uncollapsed_matches_upper_bound());
         unsigned rank = q.first;
         for (auto it = m.begin(); it != m.end(); ++it, ++rank) {
             int pct = dbs.size() == 1 ? it.get_percent() : -1;
             fprintf(out, "H %u %u %a %d\n", rank, *it, it.get_weight(), pct);
+            if (extra) {
+                /* the item's sort key and collapse key (hex, "-" = empty) and how many documents were collapsed into it */
+                auto hex = [](const std::string& v) { if (v.empty()) return std::string("-"); std::string h; char b[3]; for (unsigned char c : v) { snprintf(b, 3, "%02x", c); h += b; } return h; };
+                fprintf(out, "X %u %s %s %u\n", rank, hex(it.get_sort_key()).c_str(), hex(it.get_collapse_key()).c_str(), it.get_collapse_count());
+            }
         }
     }
     fclose(out);
@@ -507,7 +554,7 @@ int main(int argc, char** argv) {
     try {
         std::string cmd = argv[1];
         int rc = 2;
-        if (cmd == "build") rc = cmd_build(argc, argv);
+        if (cmd == "build" || cmd == "build_values") rc = cmd_build(argc, argv);
         else if (cmd == "query") rc = cmd_query(argc, argv);
         else if (cmd == "time") rc = cmd_time(argc, argv);
         else if (cmd == "export") rc = cmd_export(argc, argv);

@@ -224,6 +224,7 @@ struct Index {
     std::vector<GlassList> lists;            /* lazily built */
     std::vector<uint8_t> built;
     GlassList doclen_list;                   /* the special doclen posting list */
+    std::vector<std::vector<std::string>> values;    /* [slot][docid]: Document::get_value (empty = none) */
     std::vector<uint32_t> doclen_dense;
     GlassList& list(uint32_t id) {
         if (!built[id]) { lists[id].build(did + term_start[id], wdf + term_start[id], df[id]); built[id] = 1; }
@@ -358,6 +359,10 @@ struct QueryIn {
      * oracle can be pinned to the real reference for PHRASE with k < matches.  0: the intended
      * semantics (true weights), which is what the device path implements.  DESIGN.md §7. */
     uint32_t select_cache_bug;
+    /* widening row (f).3, sort by value (Enquire::set_sort_by_value*, api/enquire.cc; comparison functions matcher/msetcmp.cc:64-107):
+     * 0 = relevance (default), 1 = VAL (value, docid), 2 = VAL_REL (value, weight, docid), 3 = REL_VAL (weight, value, docid);
+     * sort_reverse = the API's `reverse` flag (false: smaller keys first; a document without the value has the empty key) */
+    uint32_t sort_by = 0, sort_slot = 0, sort_reverse = 0;
 };
 
 struct Leaf { uint32_t tf, idx; };
@@ -449,7 +454,8 @@ bool near_window(std::vector<PosCursor>& pl, uint32_t window) {
     }
 }
 
-struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0; };
+struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0;
+                std::vector<std::string> sort_keys; };   /* sorted searches: the items' keys, parallel to hits */
 
 int run_query(Index* ix, const QueryIn& q, Result* out) {
     const uint32_t n = q.n_terms;
@@ -593,9 +599,12 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
         return val[root];
     };
     uint64_t true_matches = 0;      /* every matching document, pruned or not (the reference only estimates this) */
+    std::vector<Hit> every;         /* sorted searches: min_weight stays 0 when the value leads (and weight pruning is exact when the
+                                       weight leads), so the MSet is the best first + maxitems of ALL matches under the chosen order */
     auto score = [&](uint32_t did) {
         ++true_matches;
         double w = weigh(did);
+        if (q.sort_by) { every.push_back(Hit{did, last_subqs, w}); return; }
         if (w < pm.min_weight) { return; }                    /* matcher.cc:496-498 */
         pm.add(Hit{did, last_subqs, w});
     };
@@ -692,6 +701,36 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
             }
             it[0].next();
         }
+    }
+    if (q.sort_by) {
+        if (q.sort_slot >= ix->values.size()) return -1;
+        const std::vector<std::string>& val = ix->values[q.sort_slot];
+        static const std::string none;
+        auto key = [&](uint32_t did) -> const std::string& { return did < val.size() ? val[did] : none; };
+        /* msetcmp_by_value / _by_value_then_relevance / _by_relevance_then_value with FORWARD_DID (docid order ascending):
+         * "a ranks before b"; FORWARD_VALUE = the reverse flag */
+        const bool fwd = q.sort_reverse != 0;
+        auto before = [&](const Hit& a, const Hit& b) {
+            if (q.sort_by == 3) { if (a.weight > b.weight) return true; if (a.weight < b.weight) return false; }
+            const int c = key(a.did).compare(key(b.did));
+            if (c > 0) return fwd;
+            if (c < 0) return !fwd;
+            if (q.sort_by == 2) { if (a.weight > b.weight) return true; if (a.weight < b.weight) return false; }
+            return a.did < b.did;
+        };
+        /* ProtoMSet::update_max_weight sees EVERY matching document (process() and early_reject(), protomset.h:174-183, 249-283):
+         * max_attained and the percentages refer to the best weight of the whole match, not of the page */
+        double mw = 0.0; uint32_t msub = 0;
+        for (const Hit& h : every) if (h.weight > mw) { mw = h.weight; msub = h.subqs; }
+        const size_t keep = std::min<size_t>(k, every.size());
+        std::partial_sort(every.begin(), every.begin() + keep, every.end(), before);
+        every.resize(keep);
+        out->hits = every;
+        for (const Hit& h : every) out->sort_keys.push_back(key(h.did));
+        out->matches = true_matches;
+        out->max_attained = mw;
+        out->max_subqs = msub;
+        return 0;
     }
     pm.finalise();
     out->hits = pm.results;
@@ -1036,6 +1075,38 @@ int xgo_search(void* ixv, uint32_t op, uint32_t n_terms, const char* const* term
     hdr->n_hits = (uint32_t)r.hits.size(); hdr->max_subqs = r.max_subqs; hdr->matches = r.matches;
     hdr->max_attained = r.max_attained; hdr->max_possible = r.max_possible;
     for (size_t i = 0; i < r.hits.size(); ++i) { hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight; }
+    return 0;
+}
+
+/* Value slots 0..2 of the synthetic corpus (tools/xgm_corpus.h) for an index over shard `shard` of `n_shards` (local docid d is
+ * global document (d - 1) * n_shards + shard + 1). */
+void xgo_index_set_synthetic_values(void* ixv, uint64_t seed, uint32_t n_shards, uint32_t shard) {
+    Index* ix = (Index*)ixv;
+    xgm_corpus_params cp{seed, 1u, 1u, 1u};
+    ix->values.assign(3, std::vector<std::string>(ix->lastdocid + 1));
+    char vb[16];
+    for (uint32_t d = 1; d <= ix->lastdocid; ++d) {
+        const uint64_t g = (uint64_t)(d - 1) * n_shards + shard + 1;
+        for (uint32_t slot = 0; slot < 3; ++slot) { const uint32_t n = xgm_doc_value(&cp, g, slot, vb); ix->values[slot][d].assign(vb, n); }
+    }
+}
+
+/* xgo_search with Enquire::set_sort_by_value* in force (sort_by 1 VAL, 2 VAL_REL, 3 REL_VAL).  keys receives the items' sort
+ * keys, key_stride bytes each (NUL-padded; keys of the synthetic corpus are at most 7 bytes). */
+int xgo_search_sorted(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
+                      uint32_t first, uint32_t maxitems, uint32_t sort_by, uint32_t sort_slot, uint32_t sort_reverse,
+                      xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride) {
+    QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, first, maxitems, 0, 0, 0, 0, nullptr, 0};
+    q.sort_by = sort_by; q.sort_slot = sort_slot; q.sort_reverse = sort_reverse;
+    Result r;
+    int rc = run_query((Index*)ixv, q, &r);
+    if (rc) return rc;
+    hdr->n_hits = (uint32_t)r.hits.size(); hdr->max_subqs = r.max_subqs; hdr->matches = r.matches;
+    hdr->max_attained = r.max_attained; hdr->max_possible = r.max_possible;
+    for (size_t i = 0; i < r.hits.size(); ++i) {
+        hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight;
+        if (keys) { memset(keys + i * key_stride, 0, key_stride); memcpy(keys + i * key_stride, r.sort_keys[i].data(), std::min<size_t>(key_stride - 1, r.sort_keys[i].size())); }
+    }
     return 0;
 }
 

@@ -169,6 +169,34 @@ def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=Non
     return [(hits[i].docid, hits[i].weight, hits[i].subqs) for i in range(hdr.n_hits)], hdr
 
 
+SORT_MODES = {"V": 1, "VR": 2, "RV": 3}      # Enquire::set_sort_by_value / _value_then_relevance / _relevance_then_value
+
+
+def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse, n_required=0):
+    """The oracle with a value sort in force (widening row (f).3; corpus value slots: tools/xgm_corpus.h).
+    Returns (list of (docid, weight, subqs, sort_key bytes), hdr)."""
+    ol = olib()
+    ol.xgo_index_set_synthetic_values.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    ol.xgo_search_sorted.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr), C.c_char_p, C.c_uint32]
+    if not getattr(corpus, "_values_set", False):
+        ol.xgo_index_set_synthetic_values(corpus.oracle_index(), corpus.params["seed"], corpus.params["n_shards"], corpus.params["shard"])
+        corpus._values_set = True
+    n = len(terms)
+    opcode = OPS[op] | ((n_required or 1) << 8 if op in SIDED else 0)
+    tb = [t if isinstance(t, bytes) else t.encode() for t in terms]
+    arr = (C.c_char_p * n)(*tb)
+    lens = (C.c_uint32 * n)(*[len(t) for t in tb])
+    cap = max(1, first + maxitems)
+    hits = (OHit * cap)()
+    hdr = OHdr()
+    keys = C.create_string_buffer(cap * 8)
+    rc = ol.xgo_search_sorted(corpus.oracle_index(), opcode, n, arr, lens, 0, first, maxitems, SORT_MODES[mode], slot, 1 if reverse else 0, hits, C.byref(hdr), keys, 8)
+    assert rc == 0
+    raw = keys.raw
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs, raw[8 * i:8 * i + 8].rstrip(b"\0")) for i in range(hdr.n_hits)], hdr
+
+
 def oracle_search_sharded(corpora, op, terms, first, maxitems, window=0):
     """Xapiand's per-shard protocol on the oracle: merged stats, per-shard top first+maxitems, unshard, merge."""
     gs = dict(total_length=sum(c.v.total_length for c in corpora), collection_size=sum(c.v.doccount for c in corpora),
@@ -197,7 +225,14 @@ def write_queries(path, queries):
     with open(path, "w") as f:
         for q in queries:
             op = q["op"] + (":%d" % (q.get("n_required") or 1) if q["op"] in SIDED else "")
-            f.write("%s %d %d %d %s\n" % (op, q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
+            pre = ""
+            if q.get("sort"):
+                pre += "SORT=%s:%d:%d " % (q["sort"][0], q["sort"][1], 1 if q["sort"][2] else 0)
+            if q.get("collapse"):
+                pre += "COLLAPSE=%d:%d " % tuple(q["collapse"])
+            if q.get("check_at_least"):
+                pre += "CAL=%d " % q["check_at_least"]
+            f.write("%s%s %d %d %d %s\n" % (pre, op, q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
 
 
 def parse_ref_output(path):
@@ -211,6 +246,10 @@ def parse_ref_output(path):
                                 max_attained=float.fromhex(p[7]), hits=[]))
             elif p[0] == "H":
                 out[-1]["hits"].append((int(p[2]), float.fromhex(p[3]), int(p[4])))
+            elif p[0] == "X":       # sorted / collapsed searches: sort key, collapse key (hex, "-" = empty), collapse count
+                out[-1].setdefault("extra", []).append((b"" if p[2] == "-" else bytes.fromhex(p[2]), b"" if p[3] == "-" else bytes.fromhex(p[3]), int(p[4])))
+            elif p[0] == "U":
+                out[-1]["uncollapsed"] = (int(p[1]), int(p[2]), int(p[3]))
     return out
 
 

@@ -61,6 +61,28 @@ XGM_HD static inline uint32_t xgm_token(const xgm_corpus_params* p, const uint64
     return xgm_zipf_rank(thresholds, p->vocab, xgm_hash3(p->seed, g, pos));
 }
 
+/* Value slots of global doc g (widening row (f).3: sort by value / collapse), as short byte strings whose bytewise
+ * order is the intended order: slot 0 = a category "cNN" (37 of them; about one document in 29 has none), slot 1 =
+ * a six-digit number (ties are rare), slot 2 = one digit 0..4 (many ties: the second sort criterion decides).
+ * Writes at most 7 bytes + NUL to buf; returns the length (0 = the document has no value in that slot). */
+static inline uint32_t xgm_doc_value(const xgm_corpus_params* p, uint64_t g, uint32_t slot, char* buf) {
+    const uint64_t h = xgm_hash3(p->seed, g, 0xFFFFFFF0ull + slot);
+    uint32_t n = 0;
+    if (slot == 0) {
+        if (h % 29u == 0) { buf[0] = 0; return 0; }
+        const uint32_t c = (uint32_t)((h >> 8) % 37u);
+        buf[n++] = 'c'; buf[n++] = (char)('0' + c / 10u); buf[n++] = (char)('0' + c % 10u);
+    } else if (slot == 1) {
+        uint32_t v = (uint32_t)(h % 1000000u);
+        for (int i = 5; i >= 0; --i) { buf[i] = (char)('0' + v % 10u); v /= 10u; }
+        n = 6;
+    } else {
+        buf[n++] = (char)('0' + (uint32_t)(h % 5u));
+    }
+    buf[n] = 0;
+    return n;
+}
+
 /* Host-only: fill thresholds[0..V-1].  Sequential double summation of 1/r: only IEEE add and
  * divide, so every host computes the same table. */
 static inline void xgm_zipf_thresholds(uint32_t vocab, uint64_t* thresholds) {
