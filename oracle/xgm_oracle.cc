@@ -25,6 +25,9 @@
  *                                                      order matcher/msetcmp.cc:55-62
  *   - multi-shard protocol: merged stats, unshard, merge: api/enquire.cc:385-394, backends/multi.h:69-73,
  *                                                      matcher/matcher.cc:653-743
+ *   - value sorts (widening, not on the device yet):   matcher/msetcmp.cc:64-107 (by value / value then relevance / relevance
+ *       then value, both directions), matcher/matcher.cc:482-536 + protomset.h:249-283 (every matching document reaches
+ *       update_max_weight; with the value leading there is no weight pruning): xgo_search_sorted
  * Plus the deterministic synthetic corpus of tools/xgm_corpus.h and its inversion to raw postings.
  *
  * Build: g++ -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).  C ABI for ctypes.
