@@ -150,6 +150,14 @@ int xgm_segment_build_from_glass(const char* glass_dir, uint32_t stripe_bits, co
 int xgm_segment_refresh_from_glass(const char* old_segment_path, const char* glass_dir, uint32_t first_changed_docid,
                                    uint32_t stripe_bits, const char* out_path);
 
+/* One value slot of a committed glass shard as a column file (widening row (f).3: what a value sort / collapse on the device
+ * will read): "XGMCOL1\0", u32 slot, u32 lastdocid, u32 n_distinct, u32 0, then u32 ord[lastdocid + 1] — 0 when the document
+ * has no value, else 1 + the rank of its value among the slot's distinct values in bytewise order (what Xapian's value sorts
+ * compare, reference src/xapian/matcher/msetcmp.cc:64-107) — then u64 off[n_distinct + 1] and the distinct values, ascending.
+ * Read straight from the value chunks of postlist.glass (backends/glass/glass_values.h:41-47, glass_values.cc:72-95).
+ * Replaces: Document::get_value per candidate in the matcher (matcher/matcher.cc:509-517). */
+int xgm_glass_export_column(const char* glass_dir, uint32_t slot, const char* out_path);
+
 /* The committed revision and statistics of a glass shard, from its version file alone (what
  * Database::get_revision / get_doccount / get_lastdocid / get_total_length would answer): the key under
  * which an exported segment is cached, cheap enough to poll.  Any output pointer may be NULL. */

@@ -337,6 +337,36 @@ int cmd_append(int argc, char** argv) {
     return 0;
 }
 
+/* column <dbdir> <slot> <out>: one value slot as the column file of include/xgm.h (xgm_glass_export_column), through the public
+ * ValueIterator (Database::valuestream_begin): the document's rank among the slot's distinct values, and those values. */
+int cmd_column(int argc, char** argv) {
+    if (argc < 5) return 2;
+    Xapian::Database db(argv[2]);
+    const Xapian::valueno slot = (Xapian::valueno)strtoul(argv[3], nullptr, 0);
+    std::vector<std::string> value((size_t)db.get_lastdocid() + 1);
+    for (Xapian::ValueIterator it = db.valuestream_begin(slot); it != db.valuestream_end(slot); ++it) value[it.get_docid()] = *it;
+    std::vector<std::string> distinct;
+    for (const std::string& v : value) if (!v.empty()) distinct.push_back(v);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    FILE* f = fopen(argv[4], "wb");
+    if (!f) return 2;
+    const uint32_t h32[4] = {(uint32_t)slot, (uint32_t)db.get_lastdocid(), (uint32_t)distinct.size(), 0u};
+    fwrite("XGMCOL1", 1, 8, f); fwrite(h32, 4, 4, f);
+    for (const std::string& v : value) {
+        uint32_t o = 0;
+        if (!v.empty()) o = (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), v) - distinct.begin()) + 1u;
+        fwrite(&o, 4, 1, f);
+    }
+    uint64_t off = 0;
+    for (const std::string& v : distinct) { fwrite(&off, 8, 1, f); off += v.size(); }
+    fwrite(&off, 8, 1, f);
+    for (const std::string& v : distinct) fwrite(v.data(), 1, v.size(), f);
+    fclose(f);
+    printf("{\"distinct\": %zu}\n", distinct.size());
+    return 0;
+}
+
 /* info <dbdir> [term ...]: the statistics bounds the reference's weighting schemes see (Database::get_doclength_lower_bound,
  * get_wdf_upper_bound(term) — glass keeps them in its version file and never tightens them on delete / replace). */
 int cmd_info(int argc, char** argv) {
@@ -561,6 +591,7 @@ int main(int argc, char** argv) {
         else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
         else if (cmd == "build_range") rc = cmd_build_range(argc, argv);
         else if (cmd == "append") rc = cmd_append(argc, argv);
+        else if (cmd == "column") rc = cmd_column(argc, argv);
         else if (cmd == "compact") rc = cmd_compact(argc, argv);
         else if (cmd == "info") rc = cmd_info(argc, argv);
         if (rc == 2) fprintf(stderr, "bad arguments for %s\n", cmd.c_str());

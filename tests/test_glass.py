@@ -177,3 +177,18 @@ def test_incremental_refresh_when_the_reason_positions_were_dropped_is_gone(buil
     _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
     _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 10, 0, inc.encode()))
     assert open(full, "rb").read() == open(inc, "rb").read()
+
+
+def test_native_value_column_matches_the_value_iterator(built, tmp_path):
+    """Value slots (widening row (f).3): the column the device will sort / collapse by — per document the rank of its value
+    among the slot's distinct values — read natively from glass's value chunks equals, byte for byte, the one made through the
+    reference's ValueIterator: several commits (chunks split and re-written), deleted and replaced documents, a sparse slot."""
+    import json
+    db = str(tmp_path / "db")
+    H.xapian_ref("build_values", db, H.CORPUS_SEED, 9000, 20000, 20, 60)
+    H.xapian_ref("append", db, H.CORPUS_SEED, 20001, 20400, 20000, 20, 60, 3000)      # deletes / replaces (the replacements carry no values)
+    for slot in (0, 1, 2, 7):
+        a, b = str(tmp_path / ("ref%d.col" % slot)), str(tmp_path / ("nat%d.col" % slot))
+        json.loads(H.xapian_ref("column", db, slot, a))
+        _lib.check(_lib.lib().xgm_glass_export_column(db.encode(), slot, b.encode()))
+        assert open(a, "rb").read() == open(b, "rb").read(), slot

@@ -100,6 +100,7 @@ _API = [
     ("xgm_segment_build", C.c_int, [_P(RawPostings), C.c_uint32, C.c_char_p]),
     ("xgm_segment_build_from_file", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
     ("xgm_segment_build_from_glass", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
+    ("xgm_glass_export_column", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
     ("xgm_segment_refresh_from_glass", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     ("xgm_glass_export_raw", C.c_int, [C.c_char_p, C.c_char_p]),
     ("xgm_glass_info", C.c_int, [C.c_char_p, _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint64)]),

@@ -22,6 +22,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -652,6 +653,77 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
     XgmSegmentBlob blob;
     if ((rc = w.finish(&raw, doclen_lb, doclen_ub, &blob))) return rc;
     return xgm_write_blob(blob, out_path);
+}
+
+/* ---- value slots (widening row (f).3: the columns a value sort / collapse on the device will read) ---------------------- */
+
+/* One value slot of a committed glass shard as a COLUMN file: per document the rank of its value among the slot's distinct
+ * values in bytewise order — what Xapian's value sorts compare (matcher/msetcmp.cc:64-107) and what set_collapse_key groups
+ * by — plus the distinct values themselves (the host needs the strings for MSet items and for merging shards).
+ *   "XGMCOL1\0", u32 slot, u32 lastdocid, u32 n_distinct, u32 0,
+ *   u32 ord[lastdocid + 1]        0 = the document has no value in the slot (the empty string: sorts first), else 1 + rank
+ *   u64 off[n_distinct + 1], bytes the distinct values, ascending
+ * Value chunks live in the postlist table under "\0\xd8" pack_uint(slot) pack_uint_preserving_sort(first docid); a chunk is
+ * pack_string(value of the first docid) { pack_uint(docid increase - 1) pack_string(value) }* (reference
+ * backends/glass/glass_values.h:41-47, glass_values.cc:72-95).  Replaces: ValueStreamDocument / Document::get_value per
+ * candidate in the matcher (matcher/matcher.cc:509-517). */
+extern "C" int xgm_glass_export_column(const char* glass_dir, uint32_t slot, const char* out_path) {
+    if (!glass_dir || !out_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    const std::string dir(glass_dir);
+    GlassVersion ver;
+    int rc = read_version(dir, &ver);
+    if (rc) return rc;
+    if (ver.last_docid > 0xFFFFFFFEull) return xgm_set_error(XGM_E_INVALID, "docids beyond 32 bits");
+    std::vector<std::string> value((size_t)ver.last_docid + 1);
+    Table post;
+    if ((rc = post.open(dir + "/postlist.glass", ver.root[kTablePostlist]))) return rc;
+    rc = post.walk([&](const std::string& key, const std::string& tag) -> int {
+        if (key.size() < 3 || key[0] != '\0' || (uint8_t)key[1] != 0xD8) return XGM_OK;
+        const uint8_t* kp = (const uint8_t*)key.data() + 2;
+        const uint8_t* kend = (const uint8_t*)key.data() + key.size();
+        uint64_t s, did;
+        if (!get_varint(&kp, kend, &s)) return xgm_set_error(XGM_E_INVALID, "value chunk: bad key");
+        if (s != slot) return XGM_OK;
+        if (!get_sortable_uint(&kp, kend, &did)) return xgm_set_error(XGM_E_INVALID, "value chunk: bad key");
+        const uint8_t* p = (const uint8_t*)tag.data();
+        const uint8_t* end = p + tag.size();
+        bool first = true;
+        while (first || p < end) {
+            uint64_t len;
+            if (!first) {
+                uint64_t inc;
+                if (!get_varint(&p, end, &inc)) return xgm_set_error(XGM_E_INVALID, "value chunk: truncated");
+                did += inc + 1;
+            }
+            first = false;
+            if (!get_varint(&p, end, &len) || len > (uint64_t)(end - p)) return xgm_set_error(XGM_E_INVALID, "value chunk: truncated value");
+            if (did >= value.size()) return xgm_set_error(XGM_E_INVALID, "value chunk: docid beyond the last one");
+            value[did].assign((const char*)p, (size_t)len);
+            p += len;
+        }
+        return XGM_OK;
+    });
+    if (rc) return rc;
+    std::set<std::string> distinct;
+    for (const std::string& v : value) if (!v.empty()) distinct.insert(v);
+    std::vector<const std::string*> sorted;
+    for (const std::string& v : distinct) sorted.push_back(&v);
+    std::vector<uint32_t> ord(value.size(), 0u);
+    for (size_t d = 0; d < value.size(); ++d) {
+        if (value[d].empty()) continue;
+        const auto it = std::lower_bound(sorted.begin(), sorted.end(), value[d], [](const std::string* a, const std::string& b) { return *a < b; });
+        ord[d] = (uint32_t)(it - sorted.begin()) + 1u;
+    }
+    FILE* f = fopen(out_path, "wb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s: %s", out_path, strerror(errno));
+    const uint32_t h32[4] = {slot, (uint32_t)ver.last_docid, (uint32_t)sorted.size(), 0u};
+    bool ok = fwrite("XGMCOL1", 1, 8, f) == 8 && fwrite(h32, 4, 4, f) == 4 && fwrite(ord.data(), 4, ord.size(), f) == ord.size();
+    uint64_t off = 0;
+    for (const std::string* v : sorted) { ok = ok && fwrite(&off, 8, 1, f) == 1; off += v->size(); }
+    ok = ok && fwrite(&off, 8, 1, f) == 1;
+    for (const std::string* v : sorted) ok = ok && fwrite(v->data(), 1, v->size(), f) == v->size();
+    if (fclose(f) != 0 || !ok) return xgm_set_error(XGM_E_IO, "short write on %s", out_path);
+    return XGM_OK;
 }
 
 extern "C" int xgm_glass_info(const char* glass_dir, uint64_t* revision, uint32_t* doccount, uint32_t* lastdocid, uint64_t* total_length) {
