@@ -366,6 +366,11 @@ struct QueryIn {
      * 0 = relevance (default), 1 = VAL (value, docid), 2 = VAL_REL (value, weight, docid), 3 = REL_VAL (weight, value, docid);
      * sort_reverse = the API's `reverse` flag (false: smaller keys first; a document without the value has the empty key) */
     uint32_t sort_by = 0, sort_slot = 0, sort_reverse = 0;
+    /* Enquire::set_collapse_key(slot, collapse_max): of the documents that share a (non-empty) value in the slot only the best
+     * collapse_max — under the order in force — stay in the MSet (matcher/collapser.cc).  INTENDED semantics: every matching
+     * document is considered (what the reference does when check_at_least covers the whole match; with less it stops testing
+     * documents that cannot rank, and its counts depend on its traversal).  collapse_max = 0: off. */
+    uint32_t collapse_slot = 0, collapse_max = 0;
 };
 
 struct Leaf { uint32_t tf, idx; };
@@ -458,7 +463,9 @@ bool near_window(std::vector<PosCursor>& pl, uint32_t window) {
 }
 
 struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0;
-                std::vector<std::string> sort_keys; };   /* sorted searches: the items' keys, parallel to hits */
+                std::vector<std::string> sort_keys;      /* sorted searches: the items' keys, parallel to hits */
+                std::vector<std::string> collapse_keys; std::vector<uint32_t> collapse_counts;   /* collapsed searches, parallel to hits */
+                uint64_t collapsed_lower_bound = 0; };  /* documents without a key + distinct keys... kept entries (Collapser::get_matches_lower_bound) */
 
 int run_query(Index* ix, const QueryIn& q, Result* out) {
     const uint32_t n = q.n_terms;
@@ -607,7 +614,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     auto score = [&](uint32_t did) {
         ++true_matches;
         double w = weigh(did);
-        if (q.sort_by) { every.push_back(Hit{did, last_subqs, w}); return; }
+        if (q.sort_by || q.collapse_max) { every.push_back(Hit{did, last_subqs, w}); return; }
         if (w < pm.min_weight) { return; }                    /* matcher.cc:496-498 */
         pm.add(Hit{did, last_subqs, w});
     };
@@ -705,15 +712,18 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
             it[0].next();
         }
     }
-    if (q.sort_by) {
-        if (q.sort_slot >= ix->values.size()) return -1;
-        const std::vector<std::string>& val = ix->values[q.sort_slot];
+    if (q.sort_by || q.collapse_max) {
+        if (q.sort_by && q.sort_slot >= ix->values.size()) return -1;
+        if (q.collapse_max && q.collapse_slot >= ix->values.size()) return -1;
+        static const std::vector<std::string> no_values;
         static const std::string none;
+        const std::vector<std::string>& val = q.sort_by ? ix->values[q.sort_slot] : no_values;
         auto key = [&](uint32_t did) -> const std::string& { return did < val.size() ? val[did] : none; };
         /* msetcmp_by_value / _by_value_then_relevance / _by_relevance_then_value with FORWARD_DID (docid order ascending):
          * "a ranks before b"; FORWARD_VALUE = the reverse flag */
         const bool fwd = q.sort_reverse != 0;
         auto before = [&](const Hit& a, const Hit& b) {
+            if (q.sort_by == 0) return mcmp(a, b);
             if (q.sort_by == 3) { if (a.weight > b.weight) return true; if (a.weight < b.weight) return false; }
             const int c = key(a.did).compare(key(b.did));
             if (c > 0) return fwd;
@@ -725,9 +735,33 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
          * max_attained and the percentages refer to the best weight of the whole match, not of the page */
         double mw = 0.0; uint32_t msub = 0;
         for (const Hit& h : every) if (h.weight > mw) { mw = h.weight; msub = h.subqs; }
-        const size_t keep = std::min<size_t>(k, every.size());
-        std::partial_sort(every.begin(), every.begin() + keep, every.end(), before);
-        every.resize(keep);
+        if (q.collapse_max) {
+            /* the whole match in rank order; per key the first collapse_max survive, the others are counted against the key */
+            const std::vector<std::string>& cval = ix->values[q.collapse_slot];
+            auto ckey = [&](uint32_t did) -> const std::string& { return did < cval.size() ? cval[did] : none; };
+            std::sort(every.begin(), every.end(), before);
+            std::map<std::string, uint32_t> seen;
+            std::vector<Hit> kept;
+            uint64_t no_key = 0, entries = 0;
+            for (const Hit& h : every) {
+                const std::string& ck = ckey(h.did);
+                if (ck.empty()) { ++no_key; kept.push_back(h); continue; }
+                uint32_t& n = seen[ck];
+                if (n++ < q.collapse_max) { kept.push_back(h); ++entries; }
+            }
+            out->collapsed_lower_bound = no_key + entries;
+            if (kept.size() > k) kept.resize(k);
+            for (const Hit& h : kept) {
+                const std::string& ck = ckey(h.did);
+                out->collapse_keys.push_back(ck);
+                out->collapse_counts.push_back(ck.empty() ? 0u : (seen[ck] > q.collapse_max ? seen[ck] - q.collapse_max : 0u));
+            }
+            every.swap(kept);
+        } else {
+            const size_t keep = std::min<size_t>(k, every.size());
+            std::partial_sort(every.begin(), every.begin() + keep, every.end(), before);
+            every.resize(keep);
+        }
         out->hits = every;
         for (const Hit& h : every) out->sort_keys.push_back(key(h.did));
         out->matches = true_matches;
@@ -1098,9 +1132,11 @@ void xgo_index_set_synthetic_values(void* ixv, uint64_t seed, uint32_t n_shards,
  * keys, key_stride bytes each (NUL-padded; keys of the synthetic corpus are at most 7 bytes). */
 int xgo_search_sorted(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
                       uint32_t first, uint32_t maxitems, uint32_t sort_by, uint32_t sort_slot, uint32_t sort_reverse,
-                      xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride) {
+                      xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride,
+                      uint32_t collapse_slot, uint32_t collapse_max, char* collapse_keys, uint32_t* collapse_counts, uint64_t* collapsed_lower_bound) {
     QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, first, maxitems, 0, 0, 0, 0, nullptr, 0};
     q.sort_by = sort_by; q.sort_slot = sort_slot; q.sort_reverse = sort_reverse;
+    q.collapse_slot = collapse_slot; q.collapse_max = collapse_max;
     Result r;
     int rc = run_query((Index*)ixv, q, &r);
     if (rc) return rc;
@@ -1109,7 +1145,10 @@ int xgo_search_sorted(void* ixv, uint32_t op, uint32_t n_terms, const char* cons
     for (size_t i = 0; i < r.hits.size(); ++i) {
         hits[i].docid = r.hits[i].did; hits[i].subqs = r.hits[i].subqs; hits[i].weight = r.hits[i].weight;
         if (keys) { memset(keys + i * key_stride, 0, key_stride); memcpy(keys + i * key_stride, r.sort_keys[i].data(), std::min<size_t>(key_stride - 1, r.sort_keys[i].size())); }
+        if (collapse_max && collapse_keys) { memset(collapse_keys + i * key_stride, 0, key_stride); memcpy(collapse_keys + i * key_stride, r.collapse_keys[i].data(), std::min<size_t>(key_stride - 1, r.collapse_keys[i].size())); }
+        if (collapse_max && collapse_counts) collapse_counts[i] = r.collapse_counts[i];
     }
+    if (collapsed_lower_bound) *collapsed_lower_bound = r.collapsed_lower_bound;
     return 0;
 }
 

@@ -172,13 +172,15 @@ def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=Non
 SORT_MODES = {"V": 1, "VR": 2, "RV": 3}      # Enquire::set_sort_by_value / _value_then_relevance / _relevance_then_value
 
 
-def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse, n_required=0):
-    """The oracle with a value sort in force (widening row (f).3; corpus value slots: tools/xgm_corpus.h).
-    Returns (list of (docid, weight, subqs, sort_key bytes), hdr)."""
+def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse, n_required=0, collapse=None):
+    """The oracle with a value sort (mode "V" / "VR" / "RV"; None = relevance) and / or a collapse (slot, collapse_max) in force
+    (widening row (f).3; corpus value slots: tools/xgm_corpus.h).  Returns (list of (docid, weight, subqs, sort_key bytes),
+    hdr) — with collapse: (docid, weight, subqs, sort_key, collapse_key, collapse_count) and hdr.collapsed_lower_bound."""
     ol = olib()
     ol.xgo_index_set_synthetic_values.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
     ol.xgo_search_sorted.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
-                                     C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr), C.c_char_p, C.c_uint32]
+                                     C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr), C.c_char_p, C.c_uint32,
+                                     C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
     if not getattr(corpus, "_values_set", False):
         ol.xgo_index_set_synthetic_values(corpus.oracle_index(), corpus.params["seed"], corpus.params["n_shards"], corpus.params["shard"])
         corpus._values_set = True
@@ -190,10 +192,17 @@ def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse
     cap = max(1, first + maxitems)
     hits = (OHit * cap)()
     hdr = OHdr()
-    keys = C.create_string_buffer(cap * 8)
-    rc = ol.xgo_search_sorted(corpus.oracle_index(), opcode, n, arr, lens, 0, first, maxitems, SORT_MODES[mode], slot, 1 if reverse else 0, hits, C.byref(hdr), keys, 8)
+    keys, ckeys = C.create_string_buffer(cap * 8), C.create_string_buffer(cap * 8)
+    ccounts = (C.c_uint32 * cap)()
+    clb = C.c_uint64()
+    cslot, cmax = collapse if collapse else (0, 0)
+    rc = ol.xgo_search_sorted(corpus.oracle_index(), opcode, n, arr, lens, 0, first, maxitems, SORT_MODES[mode] if mode else 0, slot, 1 if reverse else 0,
+                              hits, C.byref(hdr), keys, 8, cslot, cmax, ckeys, ccounts, C.byref(clb))
     assert rc == 0
-    raw = keys.raw
+    raw, craw = keys.raw, ckeys.raw
+    hdr.collapsed_lower_bound = clb.value
+    if collapse:
+        return [(hits[i].docid, hits[i].weight, hits[i].subqs, raw[8 * i:8 * i + 8].rstrip(b"\0"), craw[8 * i:8 * i + 8].rstrip(b"\0"), ccounts[i]) for i in range(hdr.n_hits)], hdr
     return [(hits[i].docid, hits[i].weight, hits[i].subqs, raw[8 * i:8 * i + 8].rstrip(b"\0")) for i in range(hdr.n_hits)], hdr
 
 
