@@ -10,7 +10,7 @@ import pytest
 
 import helpers as H
 from xapiand_amd import Database, Query, _lib
-from xapiand_amd.enquire import merged_stats, plan, search_batch
+from xapiand_amd.enquire import BM25Weight, merged_stats, plan, search_batch
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -152,4 +152,39 @@ def test_disjunction_threshold_guess_is_conservative(built, tmp_path):
             if len(want) == k and seed.value > 0.0:
                 ratios.append(seed.value / want[k - 1][1])
     assert len(ratios) >= 30 and max(ratios) <= 1.0 and min(ratios) >= 0.5, (len(ratios), min(ratios), max(ratios))
+    db.close()
+
+
+def test_disjunction_term_bounds_dominate_every_posting(built, tmp_path):
+    """xgm_orw_kernel may skip a document only because a sum of per-term bounds stays below the running k-th weight, so the bounds
+    the planner hands it (xgm_dev_query::ub — any wdf; ub1 — wdf = 1; xgm_api.cc to_dev_query) must dominate the BM25 weight
+    (bm25weight.cc:170-181) of EVERY posting of the term.  Checked exhaustively over the postings of sampled terms, for the default
+    parameters and for b = 0 / k1 = 0 / a large min_normlen, where the length normalisation degenerates."""
+    import ctypes as C
+    import numpy as np
+    c = H.Corpus(60000, 200000)
+    db = Database(c.build_segment(str(tmp_path / "bounds.seg")), device=_lib.XGM_DEVICE_NONE)
+    L = _lib.lib()
+    L.xgm_debug_or_bounds.argtypes = [C.c_void_p, C.POINTER(_lib.Query), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    doclen = np.ctypeslib.as_array(c.v.doclen, shape=(c.v.lastdocid + 1,)).astype(np.float64)
+    names = c.terms()
+    index_of = {t: i for i, t in enumerate(names)}
+    checked = 0
+    for params in ({}, {"b": 0.0}, {"k1": 0.0}, {"min_normlen": 3.0}, {"k1": 2.0, "b": 0.9}):
+        for q in H.gen_term_queries("OR", 6, 5, 8, 4096, seed=5):
+            p = plan(db, Query("OR", q["terms"]), 0, 10, weight=BM25Weight(**params))
+            seed, ub, ub1 = C.c_double(), (C.c_double * 16)(), (C.c_double * 16)()
+            assert L.xgm_debug_or_bounds(db._h, C.byref(p), C.byref(seed), ub, ub1) == 0
+            for i, t in enumerate(q["terms"]):
+                tb = t if isinstance(t, bytes) else t.encode()
+                did, wdf = c.term_postings(index_of[tb])
+                w = wdf.astype(np.float64)
+                normlen = np.maximum(doclen[did] * p.len_factor, p.min_normlen)
+                weight = p.terms[i].termweight * (w / (p.k1 * (normlen * p.b + (1.0 - p.b)) + w))
+                assert weight.max() <= ub[i], (params, t, weight.max(), ub[i])
+                one = wdf == 1
+                if one.any():
+                    assert weight[one].max() <= ub1[i], (params, t, weight[one].max(), ub1[i])
+                checked += len(did)
+    assert checked > 100000
     db.close()
