@@ -1130,11 +1130,27 @@ void xgo_index_set_synthetic_values(void* ixv, uint64_t seed, uint32_t n_shards,
 
 /* xgo_search with Enquire::set_sort_by_value* in force (sort_by 1 VAL, 2 VAL_REL, 3 REL_VAL).  keys receives the items' sort
  * keys, key_stride bytes each (NUL-padded; keys of the synthetic corpus are at most 7 bytes). */
+int xgo_search_sorted_g(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
+                        uint32_t first, uint32_t maxitems, uint32_t sort_by, uint32_t sort_slot, uint32_t sort_reverse,
+                        xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride,
+                        uint32_t collapse_slot, uint32_t collapse_max, char* collapse_keys, uint32_t* collapse_counts, uint64_t* collapsed_lower_bound,
+                        uint32_t use_global, uint64_t g_total_length, uint32_t g_collection_size, uint32_t g_has_positions, const uint32_t* g_termfreq);
+
 int xgo_search_sorted(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
                       uint32_t first, uint32_t maxitems, uint32_t sort_by, uint32_t sort_slot, uint32_t sort_reverse,
                       xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride,
                       uint32_t collapse_slot, uint32_t collapse_max, char* collapse_keys, uint32_t* collapse_counts, uint64_t* collapsed_lower_bound) {
-    QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, first, maxitems, 0, 0, 0, 0, nullptr, 0};
+    return xgo_search_sorted_g(ixv, op, n_terms, terms, term_len, window, first, maxitems, sort_by, sort_slot, sort_reverse, hits, hdr, keys, key_stride,
+                               collapse_slot, collapse_max, collapse_keys, collapse_counts, collapsed_lower_bound, 0, 0, 0, 0, nullptr);
+}
+
+/* ... on one shard of several, weighted with the merged statistics (Xapiand's per-shard protocol, as xgo_search's use_global) */
+int xgo_search_sorted_g(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
+                        uint32_t first, uint32_t maxitems, uint32_t sort_by, uint32_t sort_slot, uint32_t sort_reverse,
+                        xgo_hit* hits, xgo_result_hdr* hdr, char* keys, uint32_t key_stride,
+                        uint32_t collapse_slot, uint32_t collapse_max, char* collapse_keys, uint32_t* collapse_counts, uint64_t* collapsed_lower_bound,
+                        uint32_t use_global, uint64_t g_total_length, uint32_t g_collection_size, uint32_t g_has_positions, const uint32_t* g_termfreq) {
+    QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, first, maxitems, use_global, g_total_length, g_collection_size, g_has_positions, g_termfreq, 0};
     q.sort_by = sort_by; q.sort_slot = sort_slot; q.sort_reverse = sort_reverse;
     q.collapse_slot = collapse_slot; q.collapse_max = collapse_max;
     Result r;

@@ -172,15 +172,16 @@ def oracle_search(corpus, op, terms, first, maxitems, window=0, global_stats=Non
 SORT_MODES = {"V": 1, "VR": 2, "RV": 3}      # Enquire::set_sort_by_value / _value_then_relevance / _relevance_then_value
 
 
-def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse, n_required=0, collapse=None):
+def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse, n_required=0, collapse=None, global_stats=None):
     """The oracle with a value sort (mode "V" / "VR" / "RV"; None = relevance) and / or a collapse (slot, collapse_max) in force
     (widening row (f).3; corpus value slots: tools/xgm_corpus.h).  Returns (list of (docid, weight, subqs, sort_key bytes),
     hdr) — with collapse: (docid, weight, subqs, sort_key, collapse_key, collapse_count) and hdr.collapsed_lower_bound."""
     ol = olib()
     ol.xgo_index_set_synthetic_values.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
-    ol.xgo_search_sorted.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
-                                     C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr), C.c_char_p, C.c_uint32,
-                                     C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    ol.xgo_search_sorted_g.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(OHit), C.POINTER(OHdr), C.c_char_p, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64),
+                                       C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     if not getattr(corpus, "_values_set", False):
         ol.xgo_index_set_synthetic_values(corpus.oracle_index(), corpus.params["seed"], corpus.params["n_shards"], corpus.params["shard"])
         corpus._values_set = True
@@ -196,8 +197,12 @@ def oracle_search_sorted(corpus, op, terms, first, maxitems, mode, slot, reverse
     ccounts = (C.c_uint32 * cap)()
     clb = C.c_uint64()
     cslot, cmax = collapse if collapse else (0, 0)
-    rc = ol.xgo_search_sorted(corpus.oracle_index(), opcode, n, arr, lens, 0, first, maxitems, SORT_MODES[mode] if mode else 0, slot, 1 if reverse else 0,
-                              hits, C.byref(hdr), keys, 8, cslot, cmax, ckeys, ccounts, C.byref(clb))
+    gs = global_stats
+    tf = (C.c_uint32 * n)(*gs["termfreq"]) if gs else None
+    rc = ol.xgo_search_sorted_g(corpus.oracle_index(), opcode, n, arr, lens, 0, first, maxitems, SORT_MODES[mode] if mode else 0, slot, 1 if reverse else 0,
+                                hits, C.byref(hdr), keys, 8, cslot, cmax, ckeys, ccounts, C.byref(clb),
+                                1 if gs else 0, gs["total_length"] if gs else 0, gs["collection_size"] if gs else 0,
+                                (1 if gs["has_positions"] else 0) if gs else 0, tf)
     assert rc == 0
     raw, craw = keys.raw, ckeys.raw
     hdr.collapsed_lower_bound = clb.value
@@ -217,6 +222,31 @@ def oracle_search_sharded(corpora, op, terms, first, maxitems, window=0):
         hits, _ = oracle_search(c, op, terms, 0, first + maxitems, window, gs)
         allhits += [((d - 1) * n + s + 1, w, m) for d, w, m in hits]
     allhits.sort(key=lambda x: (-x[1], x[0]))
+    return allhits[first:first + maxitems]
+
+
+def oracle_search_sharded_sorted(corpora, op, terms, first, maxitems, mode, slot, reverse):
+    """oracle_search_sharded under a value sort: every shard's first + maxitems best under the comparison, merged under the same
+    comparison over global docids (matcher/msetcmp.cc:64-107).  Returns [(global docid, weight, subqs, sort key)]."""
+    import functools
+    gs = dict(total_length=sum(c.v.total_length for c in corpora), collection_size=sum(c.v.doccount for c in corpora),
+              has_positions=any(c.v.has_positions for c in corpora),
+              termfreq=[sum(c.termfreq(t) for c in corpora) for t in terms])
+    n = len(corpora)
+    allhits = []
+    for s, c in enumerate(corpora):
+        hits, _ = oracle_search_sorted(c, op, terms, 0, first + maxitems, mode, slot, reverse, global_stats=gs)
+        allhits += [((d - 1) * n + s + 1, w, m, k) for d, w, m, k in hits]
+
+    def cmp(a, b):
+        if mode == "RV" and a[1] != b[1]:
+            return -1 if a[1] > b[1] else 1
+        if a[3] != b[3]:
+            return (-1 if a[3] > b[3] else 1) if reverse else (-1 if a[3] < b[3] else 1)
+        if mode == "VR" and a[1] != b[1]:
+            return -1 if a[1] > b[1] else 1
+        return -1 if a[0] < b[0] else (1 if a[0] > b[0] else 0)
+    allhits.sort(key=functools.cmp_to_key(cmp))
     return allhits[first:first + maxitems]
 
 
