@@ -45,6 +45,7 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -62,7 +63,11 @@ struct QuerySpec {
      * _value_then_relevance / _relevance_then_value), "COLLAPSE=<slot>:<max>" (set_collapse_key), "CAL=<n>" (check_at_least) */
     std::string sort_mode;
     unsigned sort_slot = 0, sort_reverse = 0, collapse_slot = 0, collapse_max = 0, check_at_least = 0;
+    /* "SPY=<slot>": a Xapian::ValueCountMatchSpy on the slot (what Xapiand's AggregationMatchSpy is a subclass of) */
+    int spy_slot = -1;
 };
+
+struct SpyResult { unsigned total = 0; std::map<std::string, unsigned> values; };
 
 std::vector<QuerySpec> read_queries(const char* path) {
     std::vector<QuerySpec> out;
@@ -85,6 +90,8 @@ std::vector<QuerySpec> read_queries(const char* path) {
                 if (sscanf(tok.c_str() + 9, "%u:%u", &q.collapse_slot, &q.collapse_max) != 2) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
             } else if (tok.rfind("CAL=", 0) == 0) {
                 q.check_at_least = (unsigned)strtoul(tok.c_str() + 4, nullptr, 10);
+            } else if (tok.rfind("SPY=", 0) == 0) {
+                q.spy_slot = (int)strtoul(tok.c_str() + 4, nullptr, 10);
             } else { ss.clear(); ss.seekg(at); break; }
         }
         ss >> q.op >> q.first >> q.maxitems >> q.window;
@@ -182,14 +189,24 @@ void apply_settings(Xapian::Enquire& enq, const QuerySpec* q) {
 
 /* One query, Xapiand style.  n_shards == 1 → plain get_mset. */
 Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& query, unsigned first,
-                       unsigned maxitems, const QuerySpec* settings = nullptr) {
+                       unsigned maxitems, const QuerySpec* settings = nullptr, SpyResult* spied = nullptr) {
     size_t n_shards = dbs.size();
     const unsigned cal = settings ? settings->check_at_least : 0;
+    const bool spy_on = spied && settings && settings->spy_slot >= 0;
+    auto harvest = [&](Xapian::ValueCountMatchSpy& spy) {        /* per-shard spies add up (Xapiand merges its aggregations the same way) */
+        spied->total += (unsigned)spy.get_total();
+        for (Xapian::TermIterator it = spy.values_begin(); it != spy.values_end(); ++it) spied->values[*it] += it.get_termfreq();
+    };
     if (n_shards == 1) {
         Xapian::Enquire enq(dbs[0]);
         apply_settings(enq, settings);
         enq.set_query(query);
-        return enq.get_mset(first, maxitems, cal);
+        if (!spy_on) return enq.get_mset(first, maxitems, cal);
+        Xapian::ValueCountMatchSpy spy((Xapian::valueno)settings->spy_slot);
+        enq.add_matchspy(&spy);
+        Xapian::MSet m = enq.get_mset(first, maxitems, cal);
+        harvest(spy);
+        return m;
     }
     bool full_db_has_positions = false;
     for (auto& db : dbs) full_db_has_positions = full_db_has_positions || db.has_positions();
@@ -209,7 +226,15 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
     }
     for (size_t s = 0; s < n_shards; ++s) {
         enqs[s].set_prepared_mset(merger.get_prepared_mset());
-        msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
+        if (spy_on) {
+            Xapian::ValueCountMatchSpy spy((Xapian::valueno)settings->spy_slot);
+            enqs[s].add_matchspy(&spy);
+            msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
+            harvest(spy);
+            enqs[s].clear_matchspies();
+        } else {
+            msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
+        }
         msets[s].unshard_docids(s, n_shards);
     }
     return merger.merge_mset(msets, doccount, first, maxitems);
@@ -456,11 +481,16 @@ int cmd_query(int argc, char** argv) {
     auto dbs = open_dbs(argc, argv, 4);
     for (size_t qi = 0; qi < queries.size(); ++qi) {
         const QuerySpec& q = queries[qi];
-        Xapian::MSet m = run_query(dbs, make_query(q), q.first, q.maxitems, &q);
+        SpyResult spied;
+        Xapian::MSet m = run_query(dbs, make_query(q), q.first, q.maxitems, &q, &spied);
         fprintf(out, "Q %zu %u %u %u %u %a %a\n", qi, m.size(), m.get_matches_lower_bound(),
                 m.get_matches_estimated(), m.get_matches_upper_bound(), m.get_max_possible(),
                 m.get_max_attained());
         const bool extra = !q.sort_mode.empty() || q.collapse_max;
+        if (q.spy_slot >= 0) {                    /* S <documents the spy saw> <distinct values>, then V <value hex> <count> in value order */
+            fprintf(out, "S %u %zu\n", spied.total, spied.values.size());
+            for (const auto& kv : spied.values) { fprintf(out, "V "); for (unsigned char c : kv.first) fprintf(out, "%02x", c); fprintf(out, " %u\n", kv.second); }
+        }
         if (extra) fprintf(out, "U %u %u %u\n", m.get_uncollapsed_matches_lower_bound(), m.get_uncollapsed_matches_estimated(), m.get_uncollapsed_matches_upper_bound());
         unsigned rank = q.first;
         for (auto it = m.begin(); it != m.end(); ++it, ++rank) {

@@ -27,7 +27,11 @@
  *                                                      matcher/matcher.cc:653-743
  *   - value sorts (widening, not on the device yet):   matcher/msetcmp.cc:64-107 (by value / value then relevance / relevance
  *       then value, both directions), matcher/matcher.cc:482-536 + protomset.h:249-283 (every matching document reaches
- *       update_max_weight; with the value leading there is no weight pruning): xgo_search_sorted
+ *       update_max_weight; with the value leading there is no weight pruning): xgo_search_sorted (one shard) / _sorted_g (a shard
+ *       of several, merged statistics); collapse (matcher/collapser.cc) with the INTENDED semantics — the snapshot's own is a
+ *       quirk, DESIGN.md 7.3
+ *   - a ValueCountMatchSpy over the whole match:       api/matchspy.cc:307-313, fed by matcher/matcher.cc:519-527 and
+ *       protomset.h:268-275: xgo_search_spy
  * Plus the deterministic synthetic corpus of tools/xgm_corpus.h and its inversion to raw postings.
  *
  * Build: g++ -O2 -ffp-contract=off -shared -fPIC (oracle/Makefile).  C ABI for ctypes.
@@ -366,6 +370,10 @@ struct QueryIn {
      * 0 = relevance (default), 1 = VAL (value, docid), 2 = VAL_REL (value, weight, docid), 3 = REL_VAL (weight, value, docid);
      * sort_reverse = the API's `reverse` flag (false: smaller keys first; a document without the value has the empty key) */
     uint32_t sort_by = 0, sort_slot = 0, sort_reverse = 0;
+    /* a Xapian::ValueCountMatchSpy on slot spy_slot_plus1 - 1 (api/matchspy.cc:307-313) as it counts when the matcher shows it every
+     * matching document: check_at_least >= the matches, or the value leading the sort (ProtoMSet::early_reject still calls the
+     * spies, protomset.h:268-275).  With weight pruning in play what a spy sees is a property of the reference's traversal. */
+    uint32_t spy_slot_plus1 = 0;
     /* Enquire::set_collapse_key(slot, collapse_max): of the documents that share a (non-empty) value in the slot only the best
      * collapse_max — under the order in force — stay in the MSet (matcher/collapser.cc).  INTENDED semantics: every matching
      * document is considered (what the reference does when check_at_least covers the whole match; with less it stops testing
@@ -465,7 +473,8 @@ bool near_window(std::vector<PosCursor>& pl, uint32_t window) {
 struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0;
                 std::vector<std::string> sort_keys;      /* sorted searches: the items' keys, parallel to hits */
                 std::vector<std::string> collapse_keys; std::vector<uint32_t> collapse_counts;   /* collapsed searches, parallel to hits */
-                uint64_t collapsed_lower_bound = 0; };  /* documents without a key + distinct keys... kept entries (Collapser::get_matches_lower_bound) */
+                uint64_t collapsed_lower_bound = 0;
+                uint64_t spy_total = 0; std::map<std::string, uint32_t> spy_values; };  /* documents without a key + distinct keys... kept entries (Collapser::get_matches_lower_bound) */
 
 int run_query(Index* ix, const QueryIn& q, Result* out) {
     const uint32_t n = q.n_terms;
@@ -611,9 +620,12 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     uint64_t true_matches = 0;      /* every matching document, pruned or not (the reference only estimates this) */
     std::vector<Hit> every;         /* sorted searches: min_weight stays 0 when the value leads (and weight pruning is exact when the
                                        weight leads), so the MSet is the best first + maxitems of ALL matches under the chosen order */
+    const std::vector<std::string>* spy_val = nullptr;
+    if (q.spy_slot_plus1) { if (q.spy_slot_plus1 - 1 >= ix->values.size()) return -1; spy_val = &ix->values[q.spy_slot_plus1 - 1]; }
     auto score = [&](uint32_t did) {
         ++true_matches;
         double w = weigh(did);
+        if (spy_val) { ++out->spy_total; if (did < spy_val->size() && !(*spy_val)[did].empty()) ++out->spy_values[(*spy_val)[did]]; }
         if (q.sort_by || q.collapse_max) { every.push_back(Hit{did, last_subqs, w}); return; }
         if (w < pm.min_weight) { return; }                    /* matcher.cc:496-498 */
         pm.add(Hit{did, last_subqs, w});
@@ -1165,6 +1177,26 @@ int xgo_search_sorted_g(void* ixv, uint32_t op, uint32_t n_terms, const char* co
         if (collapse_max && collapse_counts) collapse_counts[i] = r.collapse_counts[i];
     }
     if (collapsed_lower_bound) *collapsed_lower_bound = r.collapsed_lower_bound;
+    return 0;
+}
+
+/* The counts of a ValueCountMatchSpy on `spy_slot` over every document the query matches (QueryIn::spy_slot_plus1): values[] receives the
+ * distinct values in byte order, key_stride bytes each, counts[] how many matching documents carry each; *total = documents seen. */
+int xgo_search_spy(void* ixv, uint32_t op, uint32_t n_terms, const char* const* terms, const uint32_t* term_len, uint32_t window,
+                   uint32_t spy_slot, uint32_t cap, uint32_t key_stride, char* values, uint32_t* counts, uint32_t* n_values, uint64_t* total) {
+    QueryIn q{op & 0xFFu, op >> 8, n_terms, terms, term_len, window, 0, 1, 0, 0, 0, 0, nullptr, 0};
+    q.spy_slot_plus1 = spy_slot + 1;
+    Result r;
+    int rc = run_query((Index*)ixv, q, &r);
+    if (rc) return rc;
+    if (r.spy_values.size() > cap) return -2;
+    uint32_t i = 0;
+    for (const auto& kv : r.spy_values) {
+        memset(values + (size_t)i * key_stride, 0, key_stride);
+        memcpy(values + (size_t)i * key_stride, kv.first.data(), std::min<size_t>(key_stride - 1, kv.first.size()));
+        counts[i++] = kv.second;
+    }
+    *n_values = i; *total = r.spy_total;
     return 0;
 }
 

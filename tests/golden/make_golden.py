@@ -7,7 +7,8 @@ Each fixture records the corpus parameters (tools/xgm_corpus.h), the queries, an
 the reference MSet: (docid, weight as a C99 hex float) per rank plus max_possible / max_attained.
 Config C1 of BASELINE.json: 10k-doc synthetic index, 3-term AND BM25 top-10 through Enquire; the
 other fixtures cover OR-5 top-100, full-result PHRASE, paging (first > 0), the two-sided operators
-(AND_NOT / AND_MAYBE / FILTER) and a 4-shard index run through Xapiand's prepare/merge protocol.
+(AND_NOT / AND_MAYBE / FILTER), a 4-shard index run through Xapiand's prepare/merge protocol, and — groundwork of the
+next widening row — the value sorts (sort keys recorded) and a ValueCountMatchSpy's counts over the whole match.
 """
 import json
 import os
@@ -45,6 +46,10 @@ def run(tmp, dbs, queries, tag, full_ranking_check=False):
         q = {k: (list(v) if isinstance(v, tuple) else v) for k, v in q.items()}
         out.append(dict(query=q, max_possible=r["max_possible"].hex(), max_attained=r["max_attained"].hex(),
                         hits=[[d, w.hex(), pct] for d, w, pct in r["hits"]]))
+        if "extra" in r:                 # sorted searches: the items' sort keys
+            out[-1]["sort_keys"] = [k.hex() for k, _, _ in r["extra"]]
+        if "spy" in r:                   # a ValueCountMatchSpy: documents seen, (value, count) in value order
+            out[-1]["spy_total"], out[-1]["spy"] = r["spy_total"], [[v.hex(), n] for v, n in r["spy"]]
     return out
 
 
@@ -72,6 +77,19 @@ def main():
         for name, qs in fixtures.items():
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(dict(corpus=corpus, n_shards=1, results=run(tmp, [db], qs, name, full_ranking_check=name == "nested_trees")), f, indent=0)
+        # widening row (f).3: value sorts and a ValueCountMatchSpy on the corpus's three value slots (tools/xgm_corpus.h)
+        import random
+        dbv = os.path.join(tmp, "dbv")
+        H.xapian_ref("build_values", dbv, H.CORPUS_SEED, N_DOCS, VOCAB, 50, 150)
+        rng = random.Random(71)
+        base = (H.gen_term_queries("OR", 10, 3, 1, 300, maxitems=10, seed=72) + H.gen_term_queries("AND", 10, 2, 1, 40, maxitems=10, seed=73) +
+                H.gen_sided_queries("AND_MAYBE", 5, 1, 2, 1, 200, maxitems=10, seed=74) + H.gen_term_queries("OR", 5, 2, 1, 2000, first=7, maxitems=9, seed=75))
+        sorted_qs = [dict(q, sort=[rng.choice(["V", "VR", "RV"]), rng.randrange(3), rng.random() < 0.5]) for q in base for _ in range(2)]
+        # (slots 0 and 2, the categories: slot 1 has nearly a distinct value per document — that one is pinned live, tests/test_oracle_vs_reference.py)
+        spy_qs = [dict(q, spy=rng.choice([0, 2]), check_at_least=N_DOCS) for q in base]
+        for name, qs in (("sorted_values", sorted_qs), ("spy_counts", spy_qs)):
+            with open(os.path.join(HERE, name + ".json"), "w") as f:
+                json.dump(dict(corpus=corpus, n_shards=1, results=run(tmp, [dbv], qs, name)), f, indent=0)
         n_shards = 4
         dbs = []
         for s in range(n_shards):

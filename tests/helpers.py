@@ -225,6 +225,29 @@ def oracle_search_sharded(corpora, op, terms, first, maxitems, window=0):
     return allhits[first:first + maxitems]
 
 
+def oracle_spy(corpus, op, terms, slot, window=0, n_required=0):
+    """A ValueCountMatchSpy on `slot` over every document the query matches (corpus value slots: tools/xgm_corpus.h).
+    Returns (documents seen, [(value, count)] in value order)."""
+    ol = olib()
+    ol.xgo_index_set_synthetic_values.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32]
+    ol.xgo_search_spy.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32,
+                                  C.c_uint32, C.c_char_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+    if not getattr(corpus, "_values_set", False):
+        ol.xgo_index_set_synthetic_values(corpus.oracle_index(), corpus.params["seed"], corpus.params["n_shards"], corpus.params["shard"])
+        corpus._values_set = True
+    n = len(terms)
+    opcode = OPS[op] | ((n_required or 1) << 8 if op in SIDED else 0)
+    tb = [t if isinstance(t, bytes) else t.encode() for t in terms]
+    arr = (C.c_char_p * n)(*tb)
+    lens = (C.c_uint32 * n)(*[len(t) for t in tb])
+    cap = 1 << 20
+    values, counts = C.create_string_buffer(cap * 8), (C.c_uint32 * cap)()
+    nv, total = C.c_uint32(), C.c_uint64()
+    assert ol.xgo_search_spy(corpus.oracle_index(), opcode, n, arr, lens, window, slot, cap, 8, values, counts, C.byref(nv), C.byref(total)) == 0
+    raw = values.raw
+    return total.value, [(raw[8 * i:8 * i + 8].rstrip(b"\0"), counts[i]) for i in range(nv.value)]
+
+
 def oracle_search_sharded_sorted(corpora, op, terms, first, maxitems, mode, slot, reverse):
     """oracle_search_sharded under a value sort: every shard's first + maxitems best under the comparison, merged under the same
     comparison over global docids (matcher/msetcmp.cc:64-107).  Returns [(global docid, weight, subqs, sort key)]."""
@@ -271,6 +294,8 @@ def write_queries(path, queries):
                 pre += "COLLAPSE=%d:%d " % tuple(q["collapse"])
             if q.get("check_at_least"):
                 pre += "CAL=%d " % q["check_at_least"]
+            if q.get("spy") is not None:
+                pre += "SPY=%d " % q["spy"]
             f.write("%s%s %d %d %d %s\n" % (pre, op, q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))
 
 
@@ -289,6 +314,10 @@ def parse_ref_output(path):
                 out[-1].setdefault("extra", []).append((b"" if p[2] == "-" else bytes.fromhex(p[2]), b"" if p[3] == "-" else bytes.fromhex(p[3]), int(p[4])))
             elif p[0] == "U":
                 out[-1]["uncollapsed"] = (int(p[1]), int(p[2]), int(p[3]))
+            elif p[0] == "S":       # a ValueCountMatchSpy: documents it saw, then one V line per distinct value
+                out[-1]["spy_total"], out[-1]["spy"] = int(p[1]), []
+            elif p[0] == "V":
+                out[-1]["spy"].append((bytes.fromhex(p[1]), int(p[2])))
     return out
 
 

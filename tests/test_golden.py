@@ -37,6 +37,16 @@ def test_oracle_matches_golden(path):
             rows, hdr, _ = H.oracle_search_tree(shards[0], H.tree_from_json(q["tree"]), q["first"], q["maxitems"])
             got = [(d, w) for d, w, _ in rows[q["first"]:]]
             assert hdr.max_possible == float.fromhex(r["max_possible"])
+        elif q.get("spy") is not None:
+            total, counts = H.oracle_spy(shards[0], q["op"], q["terms"], q["spy"], n_required=q.get("n_required", 0))
+            assert (total, [[v.hex(), n] for v, n in counts]) == (r["spy_total"], r["spy"]), q
+            continue
+        elif q.get("sort"):
+            mode, slot, rev = q["sort"]
+            hits, hdr = H.oracle_search_sorted(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], mode, slot, rev, n_required=q.get("n_required", 0))
+            got = [(d, w) for d, w, _, _ in hits[q["first"]:]]
+            assert [k.hex() for _, _, _, k in hits[q["first"]:]] == r["sort_keys"], q
+            assert hdr.max_attained == float.fromhex(r["max_attained"]), q
         elif fx["n_shards"] == 1:
             hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0))
             got = [(d, w) for d, w, _ in hits[q["first"]:]]
