@@ -430,6 +430,20 @@ int cmd_build_misc(int argc, char** argv) {
         printf("{\"doccount\": 0, \"lastdocid\": 0}\n");
         return 0;
     }
+    if (variant == "longpos") {
+        /* position lists of several KB: glass stores such a tag as several B-tree items ("components"), which straddle leaf blocks */
+        for (unsigned i = 1; i <= 300; ++i) {
+            Xapian::Document doc;
+            for (unsigned k = 0; k < 3000; ++k) doc.add_posting("big", 1 + k * 1000 + (i * 37 + k * k) % 997);
+            if (i % 3 == 0) for (unsigned k = 0; k < 2200; ++k) doc.add_posting("huge", 7 + k * 1500 + (i + k) % 1301);
+            for (unsigned j = 0; j < 12; ++j) doc.add_posting("s" + std::to_string((i * 5 + j * 11) % 90), 4000000 + j);
+            db.add_document(doc);
+            if (i % 100 == 0) db.commit();
+        }
+        db.commit();
+        printf("{\"doccount\": %u, \"lastdocid\": %u}\n", db.get_doccount(), db.get_lastdocid());
+        return 0;
+    }
     if (variant == "nopos") {                                   /* no positional information anywhere */
         for (unsigned i = 1; i <= 500; ++i) {
             Xapian::Document doc;

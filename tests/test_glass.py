@@ -119,6 +119,12 @@ def test_incremental_refresh_equals_full_export(built, tmp_path, mutate):
     _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
     _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), floor, 0, inc.encode()))
     assert open(full, "rb").read() == open(inc, "rb").read()
+    # in place (the old segment file is the output): same bytes again
+    import shutil
+    same = str(tmp_path / "in_place.seg")
+    shutil.copy(seg1, same)
+    _lib.check(L.xgm_segment_refresh_from_glass(same.encode(), db.encode(), floor, 0, same.encode()))
+    assert open(full, "rb").read() == open(same, "rb").read()
     # floor 1 = nothing taken from the old segment: still the same bytes
     _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), 1, 0, inc.encode()))
     assert open(full, "rb").read() == open(inc, "rb").read()
@@ -142,6 +148,30 @@ def test_incremental_refresh_keeps_format_corners(built, tmp_path):
     _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
     _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), out["last_before"] + 1, 0, inc.encode()))
     assert open(full, "rb").read() == open(inc, "rb").read()
+
+
+def test_incremental_refresh_skips_unread_blocks_around_split_items(built, tmp_path):
+    """Under a floor the position table is mostly passed over: leaf blocks between two separators of one term below the floor are not
+    read at all, blocks that begin and end in one term are dropped on their first and last key, other entries on their raw key.  Here
+    the position lists are several KB each, which glass stores as several B-tree items that straddle the leaf blocks — every way of
+    passing over must leave the walk on an item boundary: floors inside the old part (documents re-read from glass), at its end, and
+    with appended documents; always the full export's bytes."""
+    import json
+    db = str(tmp_path / "longpos")
+    H.xapian_ref("build_misc", db, "longpos")
+    L = _lib.lib()
+    seg1 = str(tmp_path / "rev1.seg")
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, seg1.encode()))
+    full, inc = str(tmp_path / "full.seg"), str(tmp_path / "inc.seg")
+    for floor in (2, 150, 151, 299, 300, 301):                # nothing changed yet: any floor must give back the same segment
+        _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), floor, 0, inc.encode()))
+        assert open(seg1, "rb").read() == open(inc, "rb").read(), floor
+    out = json.loads(H.xapian_ref("append", db, H.CORPUS_SEED, 1, 200, 3000, 20, 60))
+    assert out["last_before"] == 300
+    _lib.check(L.xgm_segment_build_from_glass(db.encode(), 0, full.encode()))
+    for floor in (301, 200, 7):
+        _lib.check(L.xgm_segment_refresh_from_glass(seg1.encode(), db.encode(), floor, 0, inc.encode()))
+        assert open(full, "rb").read() == open(inc, "rb").read(), floor
 
 
 def test_incremental_refresh_copies_whole_stripes(built, tmp_path):

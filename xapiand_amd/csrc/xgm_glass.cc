@@ -23,6 +23,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cerrno>
 #include <cstdio>
 #include <cstring>
@@ -148,27 +149,54 @@ class Table {
 
     template <class F>
     int walk(F&& emit) {
+        auto no4 = [](const uint8_t*, uint32_t, const uint8_t*, uint32_t) { return false; };
+        return walk(emit, no4, no4, [](const uint8_t*, uint32_t) { return false; });
+    }
+
+    /* ... passing over what the caller does not want without assembling it — or without touching it:
+     *   skip_child(separator of a leaf block, separator of the next one) → true: the leaf block is not read at all.  Every key k
+     *     of the block satisfies separator <= k < next separator bytewise (separators are prefixes of a block's first key cut
+     *     after the first byte that differs from the block before, glass_table.cc:645-685);
+     *   skip_block(first key, last key of a leaf block) → true drops the block (asked only when it holds complete items);
+     *   skip_item(key) → true drops one item. */
+    template <class F, class SC, class SB, class SI>
+    int walk(F&& emit, SC&& skip_child, SB&& skip_block, SI&& skip_item) {
         if (empty()) return XGM_OK;
-        key_.clear(); tag_.clear(); in_item_ = false;
-        int rc = visit(root_.root, root_.level, emit);
-        if (rc == XGM_OK && in_item_) rc = xgm_set_error(XGM_E_INVALID, "%s: last tag is incomplete", path_.c_str());
+        key_.clear(); tag_.clear(); in_item_ = false; skipping_ = false; after_skip_ = false;
+        int rc = visit(root_.root, root_.level, emit, skip_child, skip_block, skip_item);
+        if (rc == XGM_OK && (in_item_ || skipping_)) rc = xgm_set_error(XGM_E_INVALID, "%s: last tag is incomplete", path_.c_str());
         return rc;
     }
 
   private:
-    template <class F>
-    int visit(uint64_t block, unsigned level, F& emit) {
+    template <class F, class SC, class SB, class SI>
+    int visit(uint64_t block, unsigned level, F& emit, SC& skip_child, SB& skip_block, SI& skip_item) {
         if ((block + 1) * root_.blocksize > size_) return xgm_set_error(XGM_E_INVALID, "%s: block %llu outside the file", path_.c_str(), (unsigned long long)block);
         const uint8_t* b = map_ + block * root_.blocksize;
         if (b[4] != level) return xgm_set_error(XGM_E_INVALID, "%s: block %llu has level %u, expected %u", path_.c_str(), (unsigned long long)block, b[4], level);
         const uint32_t dir_end = be16(b + 9);
         if (dir_end < (uint32_t)kDirStart || dir_end > root_.blocksize) return xgm_set_error(XGM_E_INVALID, "%s: bad directory in block %llu", path_.c_str(), (unsigned long long)block);
+        if (level == 0 && !in_item_ && !skipping_ && !after_skip_ && dir_end >= (uint32_t)kDirStart + 4u) {
+            const uint32_t off_a = be16(b + kDirStart), off_z = be16(b + dir_end - 2);
+            if (off_a + 3 <= root_.blocksize && off_z + 3 <= root_.blocksize) {
+                const uint8_t* a = b + off_a;
+                const uint8_t* z = b + off_z;
+                if ((a[0] & 0x20) && (z[0] & 0x40) && a[2] && off_a + 3u + a[2] <= root_.blocksize && off_z + 3u + z[2] <= root_.blocksize &&
+                    skip_block(a + 3, (uint32_t)a[2], z + 3, (uint32_t)z[2])) return XGM_OK;
+            }
+        }
         for (uint32_t c = kDirStart; c < dir_end; c += 2) {
             const uint32_t off = be16(b + c);
             if (off + 3 > root_.blocksize) return xgm_set_error(XGM_E_INVALID, "%s: bad item offset in block %llu", path_.c_str(), (unsigned long long)block);
             const uint8_t* it = b + off;
             if (level > 0) {
-                int rc = visit(be32(it), level - 1, emit);                       /* BItem::block_given_by */
+                if (level == 1 && !in_item_ && !skipping_ && c + 2 < dir_end) {
+                    /* branch item: block number (4), key length (1), key, component count (2) — glass_table.h:301-331 */
+                    const uint32_t off2 = be16(b + c + 2);
+                    if (off + 5u + it[4] <= root_.blocksize && off2 + 5u <= root_.blocksize && off2 + 5u + b[off2 + 4] <= root_.blocksize &&
+                        skip_child(it + 5, (uint32_t)it[4], b + off2 + 5, (uint32_t)b[off2 + 4])) { after_skip_ = true; continue; }
+                }
+                int rc = visit(be32(it), level - 1, emit, skip_child, skip_block, skip_item);      /* BItem::block_given_by */
                 if (rc) return rc;
                 continue;
             }
@@ -178,8 +206,18 @@ class Table {
             uint32_t cd = 3u + klen + (first ? 0u : 2u);
             if (off + size > root_.blocksize || cd > size) return xgm_set_error(XGM_E_INVALID, "%s: bad item in block %llu", path_.c_str(), (unsigned long long)block);
             if (compressed) return xgm_set_error(XGM_E_INVALID, "%s: compressed tag (not expected in this table)", path_.c_str());
+            if (skipping_) {                          /* further components of an item the caller passed over */
+                if (first) return xgm_set_error(XGM_E_INVALID, "%s: tag components out of sequence", path_.c_str());
+                if (last) skipping_ = false;
+                continue;
+            }
+            if (after_skip_) {                        /* the block before was not read: it may have ended inside an (unwanted) item */
+                after_skip_ = false;
+                if (!first && !in_item_) { skipping_ = !last; continue; }
+            }
             if (first) {
                 if (in_item_) return xgm_set_error(XGM_E_INVALID, "%s: tag components out of sequence", path_.c_str());
+                if (klen && skip_item(it + 3, klen)) { skipping_ = !last; continue; }
                 key_.assign((const char*)it + 3, klen);
                 tag_.clear();
                 in_item_ = true;
@@ -203,7 +241,7 @@ class Table {
     const uint8_t* map_ = nullptr;
     size_t size_ = 0;
     std::string key_, tag_;
-    bool in_item_ = false;
+    bool in_item_ = false, skipping_ = false, after_skip_ = false;
 };
 
 /* unpack_string_preserving_sort on a key prefix: term bytes up to the unescaped \0 (or the end of the key);
@@ -372,6 +410,70 @@ int read_glass(const char* glass_dir, Export* ex, uint64_t min_did_all = 0, cons
         size_t ti = 0;                       /* current term of the posting cursor */
         uint64_t pi = 0, t_end = ex->terms.empty() ? 0 : ex->df[0];             /* posting ordinal, end of term ti */
         std::vector<uint32_t> tmp;
+        /* under a floor most of the table is not wanted: entries are judged on their raw key (no strings built), and a leaf block
+         * that begins and ends in the same term with its last docid below the floor is not looked into at all */
+        auto raw_term_end = [](const uint8_t* k, uint32_t n) -> uint32_t {       /* offset of the terminator of the escaped term, n if none */
+            for (uint32_t i = 0; i < n; ++i) if (k[i] == 0) { if (i + 1 < n && k[i + 1] == 0xFF) { ++i; continue; } return i; }
+            return n;
+        };
+        auto raw_below_floor = [&](const uint8_t* k, uint32_t n, uint32_t* term_len) -> bool {
+            const uint32_t e = raw_term_end(k, n);
+            *term_len = e;
+            if (e >= n) return false;
+            const uint8_t* r = k + e + 1;
+            uint64_t d;
+            return get_sortable_uint(&r, k + n, &d) && d < min_did_all;
+        };
+        auto raw_term_wanted_in_full = [&](const uint8_t* k, uint32_t term_len) -> bool {
+            if (!full_terms || full_terms->empty()) return false;
+            std::string t;
+            for (uint32_t i = 0; i < term_len; ++i) { t.push_back((char)k[i]); if (k[i] == 0) ++i; }
+            return full_terms->count(t) != 0;
+        };
+        /* the floor in the keys' own encoding (pack_uint_preserving_sort, common/pack.h:183-219): a separator's docid may be cut short */
+        uint8_t floor_enc[9];
+        uint32_t floor_len = 0;
+        if (min_did_all) {
+            uint64_t v = min_did_all;
+            if (v < 0x8000) { floor_enc[0] = (uint8_t)(v >> 8); floor_enc[1] = (uint8_t)v; floor_len = 2; }
+            else {
+                uint32_t len = 3;
+                for (uint64_t x = v >> 22; x; x >>= 7) ++len;
+                const unsigned mask = 0xFFu << (10 - len);
+                for (uint32_t i = 1; i < len; ++i) { floor_enc[len - i] = (uint8_t)v; v >>= 8; }
+                floor_enc[0] = (uint8_t)(v | mask);
+                floor_len = len;
+            }
+            const uint8_t* chk = floor_enc;
+            uint64_t back = 0;
+            if (!get_sortable_uint(&chk, floor_enc + floor_len, &back) || back != min_did_all || chk != floor_enc + floor_len) floor_len = 0;   /* (never: then no block is skipped unseen) */
+        }
+        auto skip_child = [&](const uint8_t* a, uint32_t an, const uint8_t* z, uint32_t zn) -> bool {
+            if (!floor_len) return false;
+            const uint32_t ta = raw_term_end(a, an);
+            if (ta >= an || zn < ta + 1 || memcmp(a, z, ta + 1) != 0) return false;       /* both separators: the same whole term */
+            const uint8_t* r = z + ta + 1;
+            const uint32_t rn = zn - ta - 1, m = rn < floor_len ? rn : floor_len;
+            const int c = memcmp(r, floor_enc, m);
+            /* every key of the block sorts below (term, floor): STRICTLY below the next separator is not guaranteed — an item cut
+             * into components across the two blocks gives a separator equal to its key — so that separator itself must sort below */
+            if (!(c < 0 || (c == 0 && rn < floor_len))) return false;
+            return !raw_term_wanted_in_full(a, ta);
+        };
+        auto skip_block = [&](const uint8_t* a, uint32_t an, const uint8_t* z, uint32_t zn) -> bool {
+            if (!min_did_all) return false;
+            uint32_t ta, tz;
+            if (!raw_below_floor(z, zn, &tz)) return false;
+            ta = raw_term_end(a, an);
+            if (ta != tz || ta >= an || memcmp(a, z, ta) != 0) return false;
+            return !raw_term_wanted_in_full(a, ta);
+        };
+        auto skip_item = [&](const uint8_t* k, uint32_t n) -> bool {
+            if (!min_did_all) return false;
+            uint32_t tl;
+            if (!raw_below_floor(k, n, &tl)) return false;
+            return !raw_term_wanted_in_full(k, tl);
+        };
         rc = posn.walk([&](const std::string& key, const std::string& tag) -> int {
             std::string t;
             const uint8_t* rest;
@@ -412,7 +514,7 @@ int read_glass(const char* glass_dir, Export* ex, uint64_t min_did_all = 0, cons
             ++pi;
             ex->pos_off.push_back(ex->pos.size());
             return XGM_OK;
-        });
+        }, skip_child, skip_block, skip_item);
         if (rc) return rc;
         while (ex->pos_off.size() < ex->did.size() + 1) ex->pos_off.push_back(ex->pos.size());
     }
@@ -478,6 +580,7 @@ inline uint32_t seg_bits(const uint32_t* w, uint64_t idx, uint32_t bw) {
 
 }  // namespace
 
+int xgm_map_segment_file(const char* path, XgmSegmentBlob* blob);
 int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob);
 
 /* Refresh a shard's segment after the shard moved to a newer revision, re-reading from glass only what changed.
@@ -492,10 +595,21 @@ int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob);
 extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, const char* glass_dir, uint32_t first_changed_docid,
                                               uint32_t stripe_bits, const char* out_path) {
     if (!old_segment_path || !glass_dir || !out_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    static const bool timing = getenv("XGM_REFRESH_TIMING") != nullptr;      /* diagnostics: where a refresh spends its time */
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "xgm refresh: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     XgmSegmentBlob old;
-    int rc = xgm_read_segment_file(old_segment_path, &old);
+    /* the old segment is mapped, not copied — unless the new one is to replace that very file */
+    struct stat st_old, st_out;
+    const bool in_place = stat(old_segment_path, &st_old) == 0 && stat(out_path, &st_out) == 0 && st_old.st_dev == st_out.st_dev && st_old.st_ino == st_out.st_ino;
+    int rc = in_place ? xgm_read_segment_file(old_segment_path, &old) : xgm_map_segment_file(old_segment_path, &old);
     if (rc) return rc;
-    if ((rc = xgm_validate_blob(old))) return rc;
+    lap("map + validate old segment");
     const xgm_seg_header* h = old.header();
     const uint64_t X = first_changed_docid;
     if (X > (uint64_t)h->lastdocid + 1) return xgm_set_error(XGM_E_INVALID, "first_changed_docid %u beyond the old segment's last docid %u + 1", first_changed_docid, h->lastdocid);
@@ -528,6 +642,7 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
 
     Export ex;
     if ((rc = read_glass(glass_dir, &ex, X, &in_full))) return rc;
+    lap("read glass from the floor");
     if (ex.ver.revision < h->revision) return xgm_set_error(XGM_E_INVALID, "glass revision %llu is older than the segment's %llu", (unsigned long long)ex.ver.revision, (unsigned long long)h->revision);
     if ((h->has_positions != 0) != ex.has_positions && X > 1) return xgm_set_error(XGM_E_INVALID, "the shard gained or lost its position table: full export needed");
     const uint32_t* odl = old.section<uint32_t>(XGM_S_DOCLEN);
@@ -549,6 +664,7 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
     xgm_database_bounds(&raw, std::max(wdf_seen, X > 1 ? h->wdf_upper_bound : 0u), &doclen_lb, &doclen_ub, &wdf_ub_db);
     XgmSegmentWriter w;
     if ((rc = w.begin(SB, has_pos, wdf_ub_db))) return rc;
+    if (X > 1) w.reserve_like(old);
 
     std::vector<uint32_t> t_did, t_wdf, t_pos;     /* the term's postings that are encoded afresh: old ones in [Xs, X), then glass's */
     std::vector<uint64_t> t_poff;
@@ -650,9 +766,10 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
         if (c >= 0) ++ni;
     }
     raw.n_postings = w.n_postings;
-    XgmSegmentBlob blob;
-    if ((rc = w.finish(&raw, doclen_lb, doclen_ub, &blob))) return rc;
-    return xgm_write_blob(blob, out_path);
+    lap("merge terms / copy blocks");
+    rc = w.finish(&raw, doclen_lb, doclen_ub, nullptr, out_path);
+    lap("write");
+    return rc;
 }
 
 /* ---- value slots (widening row (f).3: the columns a value sort / collapse on the device will read) ---------------------- */

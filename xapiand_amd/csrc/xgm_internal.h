@@ -18,9 +18,17 @@ int xgm_set_error(int code, const char* fmt, ...) __attribute__((format(printf, 
 /* A complete segment as one host blob (header + sections). */
 struct XgmSegmentBlob {
     std::vector<uint8_t> bytes;
-    const xgm_seg_header* header() const { return reinterpret_cast<const xgm_seg_header*>(bytes.data()); }
+    const uint8_t* map = nullptr;            /* instead of bytes: a read-only mapping of a segment file (xgm_map_segment_file) */
+    size_t map_size = 0;
+    XgmSegmentBlob() = default;
+    XgmSegmentBlob(const XgmSegmentBlob&) = delete;
+    XgmSegmentBlob& operator=(const XgmSegmentBlob&) = delete;
+    ~XgmSegmentBlob();
+    const uint8_t* data() const { return map ? map : bytes.data(); }
+    size_t size() const { return map ? map_size : bytes.size(); }
+    const xgm_seg_header* header() const { return reinterpret_cast<const xgm_seg_header*>(data()); }
     template <class T>
-    const T* section(int s) const { return reinterpret_cast<const T*>(bytes.data() + header()->sec_off[s]); }
+    const T* section(int s) const { return reinterpret_cast<const T*>(data() + header()->sec_off[s]); }
 };
 
 int xgm_build_segment_blob(const xgm_raw_postings* raw, uint32_t stripe_bits, XgmSegmentBlob* out);
@@ -41,6 +49,7 @@ struct XgmSegmentWriter {
     uint32_t t_first_wdf = 0;
 
     int begin(uint32_t stripe_bits, bool with_positions, uint32_t wdf_ub_of_the_database);
+    void reserve_like(const XgmSegmentBlob& old);      /* the result will be about as large as that segment */
     /* pos_ok / pos16: the positional form of the WHOLE term (every posting has exactly wdf positions / all below 65536) */
     int begin_term(const char* name, uint32_t len, bool pos_ok, bool pos16);
     /* blocks [first block of old term t, b_end) verbatim (headers, payload, positions at this term's entry width): only as the first
@@ -49,7 +58,8 @@ struct XgmSegmentWriter {
     /* postings in ascending docid order, after whatever the term holds already; pos_off is indexed like did (df + 1 entries) */
     int add_postings(const uint32_t* did, const uint32_t* wdf, uint32_t df, const uint64_t* pos_off, const uint32_t* pos);
     int end_term();
-    int finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out);
+    /* out_path != NULL: the segment goes straight to that file (out is not touched) instead of being assembled in memory */
+    int finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out, const char* out_path = nullptr);
     void put_position(uint32_t v);
 };
 int xgm_write_blob(const XgmSegmentBlob& blob, const char* path);

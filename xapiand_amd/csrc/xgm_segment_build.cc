@@ -4,6 +4,11 @@
  * builder (xgm_synth.hip) must produce bit-identical sections for the same postings; the tests
  * check that.
  */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cerrno>
 #include <cstring>
@@ -144,6 +149,18 @@ void XgmSegmentWriter::put_position(uint32_t v) {
     ++t_entries; ++n_pos_entries;
 }
 
+void XgmSegmentWriter::reserve_like(const XgmSegmentBlob& old) {
+    const xgm_seg_header* h = old.header();
+    const auto more = [](uint64_t n) { return (size_t)(n + n / 8 + 4096); };
+    blk_first.reserve(more(h->n_blocks)); blk_meta.reserve(more(h->n_blocks)); blk_word.reserve(more(h->n_blocks)); blk_pos.reserve(more(h->n_blocks));
+    words.reserve(more(h->n_words));
+    positions.reserve(more(h->sec_bytes[XGM_S_POSITIONS]));
+    str_bytes.reserve(more(h->sec_bytes[XGM_S_STR_BYTES]));
+    const size_t T = more(h->n_terms);
+    term_df.reserve(T); term_cf.reserve(T); term_wdfub.reserve(T); term_flags.reserve(T);
+    term_blk.reserve(T); term_word.reserve(T); term_pos.reserve(T); str_off.reserve(T);
+}
+
 int XgmSegmentWriter::copy_blocks(const XgmSegmentBlob& old, uint32_t t, uint64_t b_end, uint64_t cf_of_them, uint32_t first_wdf) {
     const xgm_seg_header* h = old.header();
     if (h->stripe_bits != stripe_bits) return xgm_set_error(XGM_E_INVALID, "copy_blocks: stripe widths differ");
@@ -165,11 +182,12 @@ int XgmSegmentWriter::copy_blocks(const XgmSegmentBlob& old, uint32_t t, uint64_
     const uint64_t wend = (uint64_t)bwd[last] + ((uint64_t)lc * lg + 31) / 32 + ((uint64_t)lc * lw + 31) / 32;
     words.insert(words.end(), ow + tw[t], ow + tw[t] + wend);
     uint64_t n = 0;
-    for (uint64_t b = b0; b < b_end; ++b) {
-        blk_first.push_back(bf[b]); blk_meta.push_back(bm[b]); blk_word.push_back(bwd[b]);
-        blk_pos.push_back(t_pos_ok ? bps[b] : 0u);
-        n += XGM_META_COUNT(bm[b]);
-    }
+    blk_first.insert(blk_first.end(), bf + b0, bf + b_end);
+    blk_meta.insert(blk_meta.end(), bm + b0, bm + b_end);
+    blk_word.insert(blk_word.end(), bwd + b0, bwd + b_end);
+    if (t_pos_ok) blk_pos.insert(blk_pos.end(), bps + b0, bps + b_end);
+    else blk_pos.insert(blk_pos.end(), (size_t)(b_end - b0), 0u);
+    for (uint64_t b = b0; b < b_end; ++b) n += XGM_META_COUNT(bm[b]);
     if (t_pos_ok) {
         /* positions of the copied postings: the old term's entries [0, e_end) — the entry of the block after the last copied one,
          * or all the term's when every block is copied — at the width this term now has */
@@ -244,7 +262,7 @@ int XgmSegmentWriter::end_term() {
     return XGM_OK;
 }
 
-int XgmSegmentWriter::finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out) {
+int XgmSegmentWriter::finish(const xgm_raw_postings* raw, uint32_t doclen_lb, uint32_t doclen_ub, XgmSegmentBlob* out, const char* out_path) {
     const uint32_t T = (uint32_t)term_df.size();
     if (n_postings != raw->n_postings) return xgm_set_error(XGM_E_INVALID, "sum of df (%llu) != n_postings (%llu)", (unsigned long long)n_postings, (unsigned long long)raw->n_postings);
     term_blk.push_back(blk_first.size());
@@ -301,6 +319,21 @@ int XgmSegmentWriter::finish(const xgm_raw_postings* raw, uint32_t doclen_lb, ui
         off = align_up(off + s.bytes);
     }
     h.file_bytes = off;
+    if (out_path) {
+        /* straight to the file, section by section (the same bytes as the assembled blob: zero padding between sections) */
+        FILE* f = fopen(out_path, "wb");
+        if (!f) return xgm_set_error(XGM_E_IO, "cannot create %s: %s", out_path, strerror(errno));
+        static const char zeros[256] = {0};
+        uint64_t at = 0;
+        bool ok = true;
+        auto put = [&](const void* p, uint64_t n) { if (n && fwrite(p, 1, (size_t)n, f) != (size_t)n) ok = false; at += n; };
+        auto pad_to = [&](uint64_t to) { while (ok && at < to) put(zeros, std::min<uint64_t>(sizeof zeros, to - at)); };
+        put(&h, sizeof h);
+        for (const Sec& s : secs) { pad_to(h.sec_off[s.id]); put(s.p, s.bytes); }
+        pad_to(off);
+        if (fclose(f) != 0 || !ok) return xgm_set_error(XGM_E_IO, "short write on %s", out_path);
+        return XGM_OK;
+    }
     out->bytes.assign(off, 0);
     memcpy(out->bytes.data(), &h, sizeof h);
     for (const Sec& s : secs)
@@ -452,6 +485,25 @@ static int read_whole(const char* path, std::vector<uint8_t>* out) {
     fclose(f);
     if (got != (size_t)sz) return xgm_set_error(XGM_E_IO, "short read on %s", path);
     return XGM_OK;
+}
+
+XgmSegmentBlob::~XgmSegmentBlob() { if (map) munmap(const_cast<uint8_t*>(map), map_size); }
+
+/* xgm_read_segment_file without the copy: the file mapped read-only (the refresh reads most of an old segment once, to copy it) */
+int xgm_map_segment_file(const char* path, XgmSegmentBlob* blob) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return xgm_set_error(XGM_E_IO, "cannot stat %s", path); }
+    if ((size_t)st.st_size < sizeof(xgm_seg_header)) { close(fd); return xgm_set_error(XGM_E_INVALID, "%s too small", path); }
+    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (m == MAP_FAILED) return xgm_set_error(XGM_E_IO, "cannot map %s: %s", path, strerror(errno));
+    blob->map = (const uint8_t*)m;
+    blob->map_size = (size_t)st.st_size;
+    int rc = xgm_validate_header(blob->header(), blob->size());
+    if (rc) return rc;
+    return xgm_validate_blob(*blob);
 }
 
 int xgm_read_segment_file(const char* path, XgmSegmentBlob* blob) {
