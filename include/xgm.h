@@ -153,7 +153,7 @@ int xgm_segment_refresh_from_glass(const char* old_segment_path, const char* gla
 /* One value slot of a committed glass shard as a column file (widening row (f).3: what a value sort / collapse on the device
  * will read): "XGMCOL1\0", u32 slot, u32 lastdocid, u32 n_distinct, u32 0, then u32 ord[lastdocid + 1] — 0 when the document
  * has no value, else 1 + the rank of its value among the slot's distinct values in bytewise order (what Xapian's value sorts
- * compare, reference src/xapian/matcher/msetcmp.cc:64-107) — then u64 off[n_distinct + 1] and the distinct values, ascending.
+ * compare, reference src/xapian/matcher/msetcmp.cc:64-101) — then u64 off[n_distinct + 1] and the distinct values, ascending.
  * Read straight from the value chunks of postlist.glass (backends/glass/glass_values.h:41-47, glass_values.cc:72-95).
  * Replaces: Document::get_value per candidate in the matcher (matcher/matcher.cc:509-517). */
 int xgm_glass_export_column(const char* glass_dir, uint32_t slot, const char* out_path);
@@ -353,6 +353,34 @@ void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t*
  * of msetcmp_by_relevance<true> (reference src/xapian/matcher/msetcmp.cc:55-62); the caller drops
  * the first `first`.  Replaces the hot loop of Matcher::get_local_mset + ProtoMSet. */
 int xgm_search(xgm_index*, const xgm_query*, xgm_hit* hits, xgm_result_hdr* hdr);
+
+/* ---- searches under a value sort (widening row (f).3; first version: written in round 2, NOT yet run on a GPU) ----------- */
+
+/* Load the ordinals of a column file (xgm_glass_export_column) into HBM next to the index: 4 bytes per document.  The column's
+ * lastdocid must be the index's (same shard revision).  Attaching a slot again replaces it. */
+int xgm_index_attach_column(xgm_index* idx, const char* column_path);
+
+#define XGM_SORT_VALUE 1u                 /* Enquire::set_sort_by_value                  (msetcmp.cc:64-73)   */
+#define XGM_SORT_VALUE_RELEVANCE 2u       /* Enquire::set_sort_by_value_then_relevance   (msetcmp.cc:75-86)   */
+#define XGM_SORT_RELEVANCE_VALUE 3u       /* Enquire::set_sort_by_relevance_then_value   (msetcmp.cc:88-101)  */
+typedef struct {
+    uint32_t sort_by;                     /* XGM_SORT_*                                                        */
+    uint32_t slot;                        /* value slot of an attached column                                  */
+    uint32_t reverse;                     /* the API's `reverse` flag: larger values first                     */
+    uint32_t reserved;
+} xgm_sort_spec;
+
+/* xgm_search for a planned query with a value sort in force: the first + maxitems best documents under the chosen comparison
+ * (the caller drops the first `first`).  hit_ord[i] (may be NULL) receives the ordinal of hit i's value in the column — 0 = no
+ * value, else 1 + index into the column file's distinct values: the MSet item's sort key.  hdr->max_attained is the best weight
+ * of the WHOLE match, as the reference reports it under a value sort (ProtoMSet::update_max_weight sees every document,
+ * protomset.h:174-183, 249-283), matches_exact the number of matching documents.  Plain operators only: XGM_UNSUPPORTED for
+ * positional (PHRASE / NEAR with the filter active) and nested queries, and when the slot has no column attached.
+ * Replaces: the value-sorted branch of the matcher's main loop (matcher/matcher.cc:482-536) and
+ * ValueStreamDocument::get_value per candidate (matcher/valuestreamdocument.cc). */
+int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
+                      xgm_result_hdr* hdr);
+
 
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
 int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,

@@ -25,7 +25,7 @@
  *                                                      order matcher/msetcmp.cc:55-62
  *   - multi-shard protocol: merged stats, unshard, merge: api/enquire.cc:385-394, backends/multi.h:69-73,
  *                                                      matcher/matcher.cc:653-743
- *   - value sorts (widening, not on the device yet):   matcher/msetcmp.cc:64-107 (by value / value then relevance / relevance
+ *   - value sorts (widening, not on the device yet):   matcher/msetcmp.cc:64-101 (by value / value then relevance / relevance
  *       then value, both directions), matcher/matcher.cc:482-536 + protomset.h:249-283 (every matching document reaches
  *       update_max_weight; with the value leading there is no weight pruning): xgo_search_sorted (one shard) / _sorted_g (a shard
  *       of several, merged statistics); collapse (matcher/collapser.cc) with the INTENDED semantics — the snapshot's own is a
@@ -366,7 +366,7 @@ struct QueryIn {
      * oracle can be pinned to the real reference for PHRASE with k < matches.  0: the intended
      * semantics (true weights), which is what the device path implements.  DESIGN.md §7. */
     uint32_t select_cache_bug;
-    /* widening row (f).3, sort by value (Enquire::set_sort_by_value*, api/enquire.cc; comparison functions matcher/msetcmp.cc:64-107):
+    /* widening row (f).3, sort by value (Enquire::set_sort_by_value*, api/enquire.cc; comparison functions matcher/msetcmp.cc:64-101):
      * 0 = relevance (default), 1 = VAL (value, docid), 2 = VAL_REL (value, weight, docid), 3 = REL_VAL (weight, value, docid);
      * sort_reverse = the API's `reverse` flag (false: smaller keys first; a document without the value has the empty key) */
     uint32_t sort_by = 0, sort_slot = 0, sort_reverse = 0;
@@ -1138,6 +1138,33 @@ void xgo_index_set_synthetic_values(void* ixv, uint64_t seed, uint32_t n_shards,
         const uint64_t g = (uint64_t)(d - 1) * n_shards + shard + 1;
         for (uint32_t slot = 0; slot < 3; ++slot) { const uint32_t n = xgm_doc_value(&cp, g, slot, vb); ix->values[slot][d].assign(vb, n); }
     }
+}
+
+/* One value slot of the index as the column file of include/xgm.h (xgm_glass_export_column writes the same from glass): the
+ * documents' ordinals among the slot's distinct values, then the values.  For device tests that have no glass database. */
+int xgo_write_value_column(void* ixv, uint32_t slot, const char* path) {
+    Index* ix = (Index*)ixv;
+    if (slot >= ix->values.size()) return -1;
+    const std::vector<std::string>& value = ix->values[slot];
+    std::vector<std::string> distinct;
+    for (const std::string& v : value) if (!v.empty()) distinct.push_back(v);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    FILE* f = fopen(path, "wb");
+    if (!f) return -2;
+    const uint32_t h32[4] = {slot, ix->lastdocid, (uint32_t)distinct.size(), 0u};
+    fwrite("XGMCOL1", 1, 8, f); fwrite(h32, 4, 4, f);
+    for (uint32_t d = 0; d <= ix->lastdocid; ++d) {
+        uint32_t o = 0;
+        if (d < value.size() && !value[d].empty()) o = (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), value[d]) - distinct.begin()) + 1u;
+        fwrite(&o, 4, 1, f);
+    }
+    uint64_t off = 0;
+    for (const std::string& v : distinct) { fwrite(&off, 8, 1, f); off += v.size(); }
+    fwrite(&off, 8, 1, f);
+    for (const std::string& v : distinct) fwrite(v.data(), 1, v.size(), f);
+    fclose(f);
+    return 0;
 }
 
 /* xgo_search with Enquire::set_sort_by_value* in force (sort_by 1 VAL, 2 VAL_REL, 3 REL_VAL).  keys receives the items' sort

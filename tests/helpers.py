@@ -250,7 +250,7 @@ def oracle_spy(corpus, op, terms, slot, window=0, n_required=0):
 
 def oracle_search_sharded_sorted(corpora, op, terms, first, maxitems, mode, slot, reverse):
     """oracle_search_sharded under a value sort: every shard's first + maxitems best under the comparison, merged under the same
-    comparison over global docids (matcher/msetcmp.cc:64-107).  Returns [(global docid, weight, subqs, sort key)]."""
+    comparison over global docids (matcher/msetcmp.cc:64-101).  Returns [(global docid, weight, subqs, sort key)]."""
     import functools
     gs = dict(total_length=sum(c.v.total_length for c in corpora), collection_size=sum(c.v.doccount for c in corpora),
               has_positions=any(c.v.has_positions for c in corpora),

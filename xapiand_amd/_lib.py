@@ -83,6 +83,13 @@ class Query(C.Structure):
                 ("est_min", C.c_uint32), ("est_est", C.c_uint32), ("est_max", C.c_uint32), ("reserved2", C.c_uint32)]
 
 
+class SortSpec(C.Structure):
+    _fields_ = [("sort_by", C.c_uint32), ("slot", C.c_uint32), ("reverse", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+XGM_SORT_VALUE, XGM_SORT_VALUE_RELEVANCE, XGM_SORT_RELEVANCE_VALUE = 1, 2, 3
+
+
 class Hit(C.Structure):
     _fields_ = [("docid", C.c_uint32), ("subqs_matched", C.c_uint32), ("weight", C.c_double)]
 
@@ -101,6 +108,8 @@ _API = [
     ("xgm_segment_build_from_file", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
     ("xgm_segment_build_from_glass", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
     ("xgm_glass_export_column", C.c_int, [C.c_char_p, C.c_uint32, C.c_char_p]),
+    ("xgm_index_attach_column", C.c_int, [C.c_void_p, C.c_char_p]),
+    ("xgm_search_sorted", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), _P(Hit), _P(C.c_uint32), _P(ResultHdr)]),
     ("xgm_segment_refresh_from_glass", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     ("xgm_glass_export_raw", C.c_int, [C.c_char_p, C.c_char_p]),
     ("xgm_glass_info", C.c_int, [C.c_char_p, _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint64)]),

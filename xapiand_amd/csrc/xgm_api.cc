@@ -266,6 +266,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->d_dense_id) hipFree(idx->d_dense_id);
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
+    for (auto& c : idx->columns) if (c.second) hipFree(c.second);
     delete idx;
 }
 
@@ -572,13 +573,14 @@ struct BatchPlan {
 };
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
-                      BatchPlan* bp) {
+                      BatchPlan* bp, bool force_general = false) {
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
     bool andnot_ok = true;       /* every query: AND, AND_NOT or AND_MAYBE whose required terms are plan positions [0, n_req) */
     static const bool no_and_kernel = getenv("XGM_NO_AND_KERNEL") != nullptr;      /* A/B switch for measurements */
     if (no_and_kernel) bp->and_only = false;
+    if (force_general) { bp->and_only = false; or_only = false; conj_only = false; andnot_ok = false; }   /* the workgroup kernel's decomposition (xgm_search_sorted) */
     for (uint32_t i = 0; i < nq; ++i) {
         if (qs[i].n_terms == 0 || qs[i].n_terms > XGM_MAX_TERMS) return xgm_set_error(XGM_E_INVALID, "query %u: bad n_terms", i);
         int width = to_dev_query(idx, &qs[i], &dq[i]);
@@ -964,6 +966,128 @@ static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, ui
     } while (0);
     scratch_release(idx, s);
     return rc;
+}
+
+/* ---- searches under a value sort (first version) -------------------------------------------------------------
+ * One query at a time, synchronous, its own device buffers: correctness first.  The unit decomposition is the workgroup
+ * kernel's (plan_batch with the wave kernels switched off); the units' candidates come back to the host, which merges them
+ * under the same comparison the kernel ranks by. */
+
+extern "C" int xgm_index_attach_column(xgm_index* idx, const char* column_path) {
+    if (!idx || !column_path) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    FILE* f = fopen(column_path, "rb");
+    if (!f) return xgm_set_error(XGM_E_IO, "cannot open %s: %s", column_path, strerror(errno));
+    char magic[8];
+    uint32_t h32[4];
+    std::vector<uint32_t> ord;
+    bool ok = fread(magic, 1, 8, f) == 8 && fread(h32, 4, 4, f) == 4 && memcmp(magic, "XGMCOL1", 8) == 0;
+    if (ok && h32[1] != idx->hdr.lastdocid) { fclose(f); return xgm_set_error(XGM_E_INVALID, "%s: column of %u documents, index of %u (another revision?)", column_path, h32[1], idx->hdr.lastdocid); }
+    if (ok) { ord.resize((size_t)h32[1] + 1); ok = fread(ord.data(), 4, ord.size(), f) == ord.size(); }
+    fclose(f);
+    if (!ok) return xgm_set_error(XGM_E_INVALID, "%s is not a column file", column_path);
+    for (uint32_t o : ord) if (o > h32[2]) return xgm_set_error(XGM_E_INVALID, "%s: ordinal beyond the distinct values", column_path);
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, ord.size() * 4));
+    hipError_t e = hipMemcpy(d, ord.data(), ord.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); return xgm_launch_error("column upload", (int)e, hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lk(idx->columns_mu);
+    void*& slot = idx->columns[h32[0]];
+    if (slot) hipFree(slot);
+    slot = d;
+    return XGM_OK;
+}
+
+namespace {
+struct DeviceBuffers {                       /* freed on every way out */
+    std::vector<void*> p;
+    ~DeviceBuffers() { for (void* q : p) if (q) hipFree(q); }
+    int alloc(void** out, size_t bytes) {
+        *out = nullptr;
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e != hipSuccess) return xgm_launch_error("hipMalloc", (int)e, hipGetErrorString(e));
+        p.push_back(*out);
+        return XGM_OK;
+    }
+};
+}  // namespace
+
+extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
+                                 xgm_result_hdr* hdr) {
+    if (!idx || !q || !sort || !hits || !hdr) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
+    if (q->tree_len || q->phrase_active) return XGM_UNSUPPORTED;               /* plain operators only, so far */
+    const uint32_t* d_ord = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(idx->columns_mu);
+        auto it = idx->columns.find(sort->slot);
+        if (it != idx->columns.end()) d_ord = (const uint32_t*)it->second;
+    }
+    if (!d_ord) return XGM_UNSUPPORTED;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    xgm_dev_query dq;
+    uint32_t kq = 0;
+    double mp = 0;
+    BatchPlan bp;
+    if ((rc = plan_batch(idx, q, 1, &dq, &kq, &mp, &bp, true))) return rc;
+    if ((dq.flags & (XGM_QF_PHRASE | XGM_QF_TREE)) || bp.andw || bp.orw || bp.and_only || dq.k == 0) return XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    const uint32_t k = dq.k, n_work = bp.n_work;
+    DeviceBuffers dev;
+    xgm_dev_query* d_q; xgm_work* d_work; xgm_cand_sorted* d_cand; xgm_group_hdr* d_ghdr;
+    if ((rc = dev.alloc((void**)&d_q, sizeof dq)) || (rc = dev.alloc((void**)&d_work, (size_t)n_work * sizeof(xgm_work))) ||
+        (rc = dev.alloc((void**)&d_cand, (size_t)n_work * k * sizeof(xgm_cand_sorted))) || (rc = dev.alloc((void**)&d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr))))
+        return rc;
+    HIP_TRY(hipMemcpy(d_q, &dq, sizeof dq, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_work, bp.work.data(), (size_t)n_work * sizeof(xgm_work), hipMemcpyHostToDevice));
+    xgm_match_launch L;
+    L.seg = idx->view;
+    L.queries = d_q;
+    L.nq = 1; L.n_work = n_work; L.work = d_work; L.stripes_per_group = bp.stripes_per_group;
+    L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
+    L.phrase = false; L.wide = bp.wide; L.sided = 0;
+    L.cand = nullptr; L.ghdr = d_ghdr;
+    if ((rc = xgm_launch_match_sorted(L, d_ord, sort->sort_by, sort->reverse ? 1u : 0u, d_cand, nullptr))) return rc;
+    std::vector<xgm_cand_sorted> cand((size_t)n_work * k);
+    std::vector<xgm_group_hdr> gh(n_work);
+    HIP_TRY(hipMemcpy(gh.data(), d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));     /* (waits for the kernel) */
+    HIP_TRY(hipMemcpy(cand.data(), d_cand, cand.size() * sizeof(xgm_cand_sorted), hipMemcpyDeviceToHost));
+    /* merge the units: their best k each under the comparison the kernel used; the whole match's best weight and count */
+    std::vector<xgm_cand_sorted> all;
+    uint64_t matches = 0, max_w = 0;
+    uint32_t max_d = UINT32_MAX, max_m = 0;
+    for (uint32_t u = 0; u < n_work; ++u) {
+        const xgm_group_hdr& g = gh[u];
+        if (g.n_cand > k) return xgm_set_error(XGM_E_DEVICE, "sorted search: unit %u reports %u candidates for k = %u", u, g.n_cand, k);
+        matches += g.matches;
+        all.insert(all.end(), cand.begin() + (size_t)u * k, cand.begin() + (size_t)u * k + g.n_cand);
+        if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
+    }
+    const bool use_x = sort->sort_by != XGM_SORT_VALUE;
+    std::sort(all.begin(), all.end(), [&](const xgm_cand_sorted& a, const xgm_cand_sorted& b) {
+        if (a.kw != b.kw) return a.kw > b.kw;
+        if (use_x && a.kx != b.kx) return a.kx > b.kx;
+        return a.did < b.did;
+    });
+    const uint32_t n = (uint32_t)std::min<size_t>(k, all.size());
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t wbits = sort->sort_by == XGM_SORT_RELEVANCE_VALUE ? all[i].kw : all[i].kx;
+        const uint32_t okey = (uint32_t)(sort->sort_by == XGM_SORT_RELEVANCE_VALUE ? all[i].kx : all[i].kw);
+        hits[i].docid = all[i].did;
+        hits[i].subqs_matched = all[i].subqs;
+        memcpy(&hits[i].weight, &wbits, 8);
+        if (hit_ord) hit_ord[i] = sort->reverse ? okey : ~okey;
+    }
+    memset(hdr, 0, sizeof *hdr);
+    hdr->n_hits = n;
+    hdr->matches_exact = matches;
+    hdr->max_possible = q->max_possible;
+    if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
+    return XGM_OK;
 }
 
 /* ---- opt-in micro-batching (server mode) -----------------------------------------------------------------------------

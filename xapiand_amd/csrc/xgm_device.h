@@ -65,6 +65,14 @@ typedef struct {
     uint32_t subqs;
 } xgm_cand;
 
+/* ... under a value sort (xgm_match_sorted_kernel): two keys, larger first — (ordinal key, weight bits), or (weight bits, ordinal
+ * key) when the weight leads; the ordinal key is the column's ordinal, complemented for an ascending sort.  24 bytes. */
+typedef struct {
+    uint64_t kw, kx;
+    uint32_t did;
+    uint32_t subqs;
+} xgm_cand_sorted;
+
 /* One unit of work of the match kernels: a query and a contiguous range of docid stripes.  The host
  * cuts every query into units of roughly equal posting-block counts (heavy queries get more units)
  * and sorts the list heaviest-first, so the chip stays full until the end of the launch. */

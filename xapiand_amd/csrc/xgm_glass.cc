@@ -775,7 +775,7 @@ extern "C" int xgm_segment_refresh_from_glass(const char* old_segment_path, cons
 /* ---- value slots (widening row (f).3: the columns a value sort / collapse on the device will read) ---------------------- */
 
 /* One value slot of a committed glass shard as a COLUMN file: per document the rank of its value among the slot's distinct
- * values in bytewise order — what Xapian's value sorts compare (matcher/msetcmp.cc:64-107) and what set_collapse_key groups
+ * values in bytewise order — what Xapian's value sorts compare (matcher/msetcmp.cc:64-101) and what set_collapse_key groups
  * by — plus the distinct values themselves (the host needs the strings for MSet items and for merging shards).
  *   "XGMCOL1\0", u32 slot, u32 lastdocid, u32 n_distinct, u32 0,
  *   u32 ord[lastdocid + 1]        0 = the document has no value in the slot (the empty string: sorts first), else 1 + rank

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <mutex>
 #include <string>
 #include <utility>
@@ -112,6 +113,8 @@ struct xgm_index {
     uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
     XgmBatcher* batcher = nullptr;
     XgmShardCtx* shard_ctx = nullptr;  /* when this index is shards[0] of an xgm_search_sharded list */
+    std::map<uint32_t, void*> columns; /* value slot → device u32 ord[lastdocid + 1] (xgm_index_attach_column) */
+    std::mutex columns_mu;
 };
 
 int xgm_lookup_term_id(const xgm_index* idx, const char* term, size_t len, uint32_t* id);

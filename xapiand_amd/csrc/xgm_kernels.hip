@@ -2685,6 +2685,328 @@ __global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uin
     }
 }
 
+/* ---------------------------------------------------------------- value sorts -- */
+
+/* xgm_match_kernel for a search under Enquire::set_sort_by_value / _value_then_relevance / _relevance_then_value (reference
+ * api/enquire.cc; comparison functions matcher/msetcmp.cc:64-101): the unit's best k documents under
+ *     mode 1 (value):                   value,  docid
+ *     mode 2 (value then relevance):    value,  weight, docid
+ *     mode 3 (relevance then value):    weight, value,  docid
+ * where "value" compares the documents' ordinals in a device column (ord[docid] = 0 for no value, else 1 + the rank of the
+ * document's value among the slot's distinct values: xgm_glass_export_column) — ascending, or descending with `reverse` — weights
+ * descend and docids ascend.  A candidate is ranked by two 64-bit keys, larger first: (kw, kx) = (ordinal key, weight bits), or
+ * (weight bits, ordinal key) in mode 3; mode 1 carries the weight in kx without comparing it.  Every matching document is
+ * weighed: with the value leading there is no weight to prune by, and the reference reports the best weight of the WHOLE match
+ * (ProtoMSet::update_max_weight sees every document, protomset.h:174-183, 249-283) — published per unit in the header (c_pos =
+ * weight bits, c_pad = {docid, weighted leaves} of the first document that attains it).
+ * Plain operators only (AND / OR / AND_NOT / AND_MAYBE / FILTER); positional and nested queries are declined by the host. */
+__device__ __forceinline__ bool sorted_before(uint64_t aw, uint64_t ax, uint32_t ad, uint64_t bw, uint64_t bx, uint32_t bd, bool use_x) {
+    if (aw != bw) return aw > bw;
+    if (use_x && ax != bx) return ax > bx;
+    return ad < bd;
+}
+
+struct SortedExt {                    /* LDS behind the ordinary layout of the match kernel */
+    uint64_t theta_x;
+    unsigned long long max_w;
+    uint32_t max_d, max_m;
+};
+
+/* topk_sort over (w, x, d): unused entries hold (0, 0, UINT32_MAX), which sorts last */
+__device__ void topk_sort_sorted(const TopK& tk, uint64_t* x, uint32_t tid, bool use_x) {
+    for (uint32_t size = 2; size <= tk.cap; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (uint32_t i = tid; i < (tk.cap >> 1); i += XGM_WG) {
+                const uint32_t lo = 2u * i - (i & (stride - 1u)), hi = lo + stride;
+                const bool asc = ((lo & size) == 0);
+                const uint64_t aw = tk.w[lo], bw = tk.w[hi], ax = x[lo], bx = x[hi];
+                const uint32_t ad = tk.d[lo], bd = tk.d[hi];
+                const bool swap = asc ? sorted_before(bw, bx, bd, aw, ax, ad, use_x) : sorted_before(aw, ax, ad, bw, bx, bd, use_x);
+                if (swap) {
+                    tk.w[lo] = bw; tk.w[hi] = aw; x[lo] = bx; x[hi] = ax;
+                    tk.d[lo] = bd; tk.d[hi] = ad;
+                    const uint32_t am = tk.m[lo], bm = tk.m[hi];
+                    tk.m[lo] = bm; tk.m[hi] = am;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename TabT>
+__global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                                   const xgm_work* __restrict__ work, uint32_t stripes_per_group,
+                                                                   uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                                   const uint32_t* __restrict__ ord, uint32_t mode, uint32_t reverse,
+                                                                   xgm_cand_sorted* __restrict__ cand_out,
+                                                                   xgm_group_hdr* __restrict__ ghdr_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const xgm_work wk = work[blockIdx.x];
+    const xgm_dev_query& q = queries[wk.qi];
+    const uint32_t SB = seg.stripe_bits;
+    const uint32_t W = 1u << SB;
+    const uint32_t T = q.n_terms;
+    const bool is_or = q.op == XGM_OP_OR;
+    const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;
+    const uint32_t k = q.k;
+    const uint32_t SPG = stripes_per_group;
+    const bool use_x = mode != 1u;
+
+    KernelSmem sm = carve<TabT>(smem, W, tab_terms, false, cap, SPG);
+    Ctrl& ctl = *sm.ctrl;
+    TabT* tab = reinterpret_cast<TabT*>(sm.tab);
+    uint32_t* my_stage = sm.stage + wave * kStageWords;
+    /* behind the ordinary layout: the second key of the top-k buffer, then the control words */
+    const size_t base_bytes = ((size_t)(reinterpret_cast<unsigned char*>(sm.runs + (size_t)2 * tab_terms * SPG) - smem) + 15) & ~(size_t)15;
+    uint64_t* tkx = reinterpret_cast<uint64_t*>(smem + base_bytes);
+    SortedExt& ext = *reinterpret_cast<SortedExt*>(smem + base_bytes + (size_t)cap * 8);
+
+    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
+    const uint32_t s_begin = wk.s_begin;
+    const uint32_t s_end = wk.s_end;
+
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
+    if (tid == 0) {
+        ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0;
+        ext.theta_x = 0; ext.max_w = 0; ext.max_d = 0xFFFFFFFFu; ext.max_m = 0;
+    }
+    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
+    if (!empty) {
+        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
+            const uint32_t id = q.term_id[t];
+            uint32_t c = 0, e = 0;
+            if (id != 0xFFFFFFFFu) {
+                const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
+                c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
+                e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
+            }
+            if (lane == 0) { ctl.cur[t] = c; ctl.end[t] = e; }
+        }
+    }
+    __syncthreads();
+
+    /* run table: the block range of every (term, stripe of this unit) */
+    uint32_t* rstart = sm.runs;
+    uint32_t* rend = sm.runs + (size_t)tab_terms * SPG;
+    if (!empty) {
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t c = ctl.cur[t], e = ctl.end[t];
+            for (uint32_t i = c + tid; i < e; i += XGM_WG) {
+                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
+                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
+                if (s != sp) rstart[t * SPG + s] = i;
+                if (s != sn) rend[t * SPG + s] = i + 1u;
+            }
+        }
+    }
+    __syncthreads();
+
+    unsigned long long my_matches = 0;
+    uint64_t my_max_w = 0;                         /* best weight among the documents this thread weighed, the first docid with it */
+    uint32_t my_max_d = 0xFFFFFFFFu, my_max_m = 0;
+    const uint32_t n_local = empty ? 0u : s_end - s_begin;
+    for (uint32_t sl = 0; sl < n_local; ++sl) {
+        uint32_t total = 0;
+        bool all = true;
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
+            total += cnt;
+            all = all && (cnt != 0 || !((req_mask >> t) & 1u));
+        }
+        if (is_or ? total == 0 : !all) continue;
+        const uint32_t s = s_begin + sl;
+
+        {
+            uint4* z = reinterpret_cast<uint4*>(sm.tab);
+            const uint32_t n16 = (uint32_t)((size_t)T * W * sizeof(TabT) / 16);
+            for (uint32_t i = tid; i < n16; i += XGM_WG) z[i] = make_uint4(0, 0, 0, 0);
+        }
+        __syncthreads();
+
+        /* K1: every block of the stripe into the per-term tables (wdf + 1 by slot), blocks dealt round-robin to the waves */
+        {
+            const uint32_t wave_items = total > wave ? (total - wave + XGM_WAVES - 1u) / XGM_WAVES : 0u;
+            for (uint32_t base = 0; base < wave_items; base += 64u) {
+                const uint32_t nthis = wave_items - base < 64u ? wave_items - base : 64u;
+                uint32_t h_meta = 0, h_first = 0, h_t = 0;
+                uint64_t h_addr = 0;
+                if (lane < nthis) {
+                    uint32_t item = wave + XGM_WAVES * (base + lane);
+                    uint32_t t = 0;
+                    while (true) {
+                        const uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
+                        if (item < cnt) break;
+                        item -= cnt; ++t;
+                    }
+                    const uint32_t b = rstart[t * SPG + sl] + item;
+                    h_t = t;
+                    h_meta = seg.blk_meta[b];
+                    h_first = seg.blk_first[b];
+                    h_addr = seg.term_word[q.term_id[t]] + seg.blk_word[b];
+                }
+                for (uint32_t x = 0; x < nthis; ++x) {
+                    const uint32_t xs = rfl32(x);
+                    const uint32_t meta = rl32(h_meta, xs);
+                    const uint32_t first = rl32(h_first, xs);
+                    const uint32_t t = rl32(h_t, xs);
+                    const uint64_t a = rl64(h_addr, xs);
+                    if (lane * 4u < payload_words(meta)) {
+                        const Words4 cur = *reinterpret_cast<const Words4*>(seg.words + a + lane * 4u);
+                        my_stage[lane * 4u] = cur.a; my_stage[lane * 4u + 1] = cur.b; my_stage[lane * 4u + 2] = cur.c; my_stage[lane * 4u + 3] = cur.d;
+                    }
+                    wave_lds_fence();
+                    const DecodedPair r = unpack_staged<false>(my_stage, first, meta, lane);
+                    wave_lds_fence();
+                    TabT* row = tab + (size_t)t * W;
+                    if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
+                    if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
+                }
+            }
+        }
+        __syncthreads();
+
+        /* K2 / K3: the slots that match, compacted into the queue */
+        {
+            constexpr uint32_t PER = 16u / sizeof(TabT);
+            for (uint32_t base0 = 0; base0 < W; base0 += XGM_WG * PER) {
+                const uint32_t base = base0 + tid * PER;
+                uint32_t bits = 0;
+                if (base < W) {
+                    uint32_t m[4];
+                    m[0] = m[1] = m[2] = m[3] = is_or ? 0u : 0xFFFFFFFFu;
+                    for (uint32_t t = 0; t < T; ++t) {
+                        const bool req = (req_mask >> t) & 1u, neg = (neg_mask >> t) & 1u;
+                        if (!is_or && !req && !neg) continue;
+                        const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)t * W + base);
+                        const uint32_t xw[4] = {v.x, v.y, v.z, v.w};
+                        for (int c = 0; c < 4; ++c) {
+                            const uint32_t nz = sizeof(TabT) == 1 ? nz_bytes(xw[c]) : nz_halves(xw[c]);
+                            m[c] = is_or ? (m[c] | nz) : neg ? (m[c] & ~nz) : (m[c] & nz);
+                        }
+                    }
+                    if (sizeof(TabT) == 1) {
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t f = m[c] >> 7;
+                            f = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
+                            bits |= f << (4 * c);
+                        }
+                    } else {
+                        for (int c = 0; c < 4; ++c) {
+                            uint32_t f = m[c] >> 15;
+                            f = (f | (f >> 15)) & 0x3u;
+                            bits |= f << (2 * c);
+                        }
+                    }
+                }
+                const uint32_t cnt = (uint32_t)__popc(bits);
+                const uint32_t incl = wave_incl_scan(cnt);
+                const uint32_t wtotal = rl32(incl, 63u);
+                if (wtotal) {
+                    uint32_t wbase = 0;
+                    if (lane == 0) wbase = atomicAdd(&ctl.qn, wtotal);
+                    wbase = rfl32(wbase);
+                    uint32_t o = wbase + incl - cnt;
+                    while (bits) {
+                        const uint32_t bit = (uint32_t)__ffs(bits) - 1u;
+                        bits &= bits - 1u;
+                        sm.queue[o++] = (uint16_t)(base + bit);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        /* K4 / K5: weigh every match, keep the best under the chosen order */
+        const uint32_t qn = ctl.qn;
+        const uint32_t stripe_base = s << SB;
+        for (uint32_t i0 = 0; i0 < qn; i0 += XGM_WG) {
+            const uint32_t fill_now = ctl.tkn;
+            __syncthreads();
+            if (fill_now + XGM_WG > cap) {
+                topk_sort_sorted(sm.tk, tkx, tid, use_x);
+                if (tid == 0) {
+                    const uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
+                    ctl.tkn = keep;
+                    if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ext.theta_x = tkx[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
+                }
+                __syncthreads();
+                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+                __syncthreads();
+            }
+            const uint32_t i = i0 + tid;
+            if (i < qn) {
+                const uint32_t slot = sm.queue[i];
+                const uint32_t did = stripe_base + slot;
+                ++my_matches;
+                /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order (as xgm_match_kernel) */
+                const double len = (double)seg.doclen[did];
+                double normlen = len * q.len_factor;
+                normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+                const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+                double val[2 * XGM_MAX_TERMS];
+                uint32_t subqs = 0;
+                for (uint32_t t = 0; t < T; ++t) {
+                    const uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
+                    double wt = -0.0;
+                    if (e) {
+                        const double wdf = (double)(e - 1u);
+                        wt = q.termweight[t] * (wdf / (denom_len + wdf));
+                        subqs += (q.score_mask >> t) & 1u;
+                    }
+                    val[t] = wt;
+                }
+                for (uint32_t j = 0; j < q.n_nodes; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
+                const double weight = val[q.sum_root];
+                const uint64_t wb = (uint64_t)__double_as_longlong(weight);
+                if (wb > my_max_w || (wb == my_max_w && did < my_max_d)) { my_max_w = wb; my_max_d = did; my_max_m = subqs; }
+                const uint32_t o32 = ord[did];
+                const uint64_t okey = (uint64_t)(reverse ? o32 : ~o32);
+                const uint64_t kw = mode == 3u ? wb : okey, kx = mode == 3u ? okey : wb;
+                const bool take = !ctl.theta_valid || sorted_before(kw, kx, did, ctl.theta_w, ext.theta_x, ctl.theta_d, use_x);
+                if (take) {
+                    const uint32_t o = atomicAdd(&ctl.tkn, 1u);
+                    sm.tk.w[o] = kw; tkx[o] = kx; sm.tk.d[o] = did; sm.tk.m[o] = subqs;
+                }
+            }
+            __syncthreads();
+        }
+
+        if (tid == 0) ctl.qn = 0;
+        __syncthreads();
+    }
+
+    /* epilogue: the unit's best k, its match count and the best weight of everything it matched */
+    __syncthreads();
+    topk_sort_sorted(sm.tk, tkx, tid, use_x);
+    if (my_matches) atomicAdd(&ctl.matches, my_matches);
+    if (my_max_d != 0xFFFFFFFFu) atomicMax(&ext.max_w, (unsigned long long)my_max_w);
+    __syncthreads();
+    if (my_max_d != 0xFFFFFFFFu && my_max_w == ext.max_w) atomicMin(&ext.max_d, my_max_d);
+    __syncthreads();
+    if (my_max_d != 0xFFFFFFFFu && my_max_w == ext.max_w && my_max_d == ext.max_d) ext.max_m = my_max_m;
+    __syncthreads();
+    const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
+    xgm_cand_sorted* out = cand_out + (size_t)wk.slot * k_stride;
+    for (uint32_t i = tid; i < n_out; i += XGM_WG) {
+        xgm_cand_sorted c;
+        c.kw = sm.tk.w[i]; c.kx = tkx[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
+        out[i] = c;
+    }
+    if (tid == 0) {
+        xgm_group_hdr h = {};
+        h.matches = ctl.matches; h.n_cand = n_out;
+        h.c_pos = ext.max_w; h.c_pad[0] = ext.max_d; h.c_pad[1] = ext.max_m;
+        ghdr_out[wk.slot] = h;
+    }
+}
+
 size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
     off += (size_t)cap * 8;
@@ -2738,6 +3060,29 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
     } while (0)
     if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
     else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }
+#undef XGM_LAUNCH
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group) {
+    return match_smem_bytes(1u << stripe_bits, tab_terms, false, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15);
+}
+
+int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, xgm_cand_sorted* cand, hipStream_t stream) {
+    dim3 grid(L.n_work), block(XGM_WG);
+    const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
+    if (smem > 160u * 1024u) return xgm_launch_error("sorted match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+    if (L.phrase || !ord || mode < 1u || mode > 3u) return xgm_launch_error("sorted match kernel", 0, "bad arguments");
+#define XGM_LAUNCH(TT)                                                                                       \
+    do {                                                                                                     \
+        auto kern = xgm_match_sorted_kernel<TT>;                                                             \
+        static std::atomic<size_t> seen{0};                                                                  \
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
+                           L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, cand, L.ghdr);                \
+    } while (0)
+    if (L.wide) XGM_LAUNCH(uint16_t); else XGM_LAUNCH(uint8_t);
 #undef XGM_LAUNCH
     XGM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -222,6 +222,10 @@ class Database:
     def save(self, path):
         _lib.check(_lib.lib().xgm_index_save(self._h, _as_bytes(path)))
 
+    def attach_column(self, column_path):
+        """xgm_index_attach_column: the ordinals of a value slot (a column file of xgm_glass_export_column) into HBM."""
+        _lib.check(_lib.lib().xgm_index_attach_column(self._h, _as_bytes(column_path)))
+
     def set_stream(self, hip_stream):
         _lib.check(_lib.lib().xgm_index_set_stream(self._h, C.c_void_p(hip_stream)))
 
@@ -364,6 +368,32 @@ def plan(db, query, first, maxitems, check_at_least=0, weight=None, global_stats
     _lib.check(_lib.lib().xgm_plan_query(db._h, C.byref(d), gs, C.byref(q)))
     q._keepalive = d
     return q
+
+
+def read_column_values(path):
+    """The distinct values of a column file (xgm_glass_export_column), ascending: ordinal o > 0 of a hit is values[o - 1]."""
+    import struct
+    b = open(path, "rb").read()
+    if b[:8] != b"XGMCOL1\0":
+        raise ValueError("%s is not a column file" % path)
+    slot, lastdocid, n, _ = struct.unpack_from("<4I", b, 8)
+    o = 24 + 4 * (lastdocid + 1)
+    off = struct.unpack_from("<%dQ" % (n + 1), b, o)
+    base = o + 8 * (n + 1)
+    return [b[base + off[i]:base + off[i + 1]] for i in range(n)]
+
+
+def search_sorted(db, planned, sort_by, slot, reverse=False):
+    """xgm_search_sorted: one planned query under Enquire::set_sort_by_value (sort_by 1) / _value_then_relevance (2) /
+    _relevance_then_value (3) on a value slot whose column is attached (Database.attach_column).
+    Returns ([(docid, weight, subqs, ordinal)], hdr)."""
+    k = max(1, planned.first + planned.maxitems)
+    hits = (_lib.Hit * k)()
+    ords = (C.c_uint32 * k)()
+    hdr = _lib.ResultHdr()
+    spec = _lib.SortSpec(sort_by, slot, 1 if reverse else 0, 0)
+    _lib.check(_lib.lib().xgm_search_sorted(db._h, C.byref(planned), C.byref(spec), hits, ords, C.byref(hdr)))
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i]) for i in range(hdr.n_hits)], hdr
 
 
 def search_batch(db, plans):
