@@ -2,8 +2,10 @@
 reference for the three sorts in both directions (tests/test_oracle_vs_reference.py, tests/golden/sorted_values.json).
 
 WRITTEN IN ROUND 2 AFTER THE ROUND'S GPU BUDGET WAS SPENT: xgm_match_sorted_kernel and xgm_search_sorted have been compiled for
-gfx950 but never executed.  The tests therefore run only on request (XGM_RUN_UNVERIFIED=1) until they have passed once on an
-MI355X; the other device paths do not share any code that changed (the existing kernels' ISA is byte-identical)."""
+gfx950 but never executed on one.  They pass under the CPU emulation of the kernels (tests/test_emu.py runs this file against
+tests/emu/libxgm_emu.so), which checks the logic but not the hardware; on a GPU box the tests run only on request
+(XGM_RUN_UNVERIFIED=1) until they have passed once on an MI355X.  The other device paths share no code that changed (the
+existing kernels' device assembly is byte-identical)."""
 import os
 import random
 
@@ -15,6 +17,8 @@ from xapiand_amd.enquire import plan, read_column_values, search_sorted
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("XGM_RUN_UNVERIFIED"), reason="device value sorts: not yet run on a GPU (set XGM_RUN_UNVERIFIED=1)")]
+
+QUICK = bool(os.environ.get("XGM_EMU_QUICK"))          # under emulation a workgroup barrier costs 256 fiber switches: small sizes
 
 MODES = {"V": _lib.XGM_SORT_VALUE, "VR": _lib.XGM_SORT_VALUE_RELEVANCE, "RV": _lib.XGM_SORT_RELEVANCE_VALUE}
 
@@ -30,7 +34,7 @@ def write_column(corpus, slot, path):
 
 @pytest.mark.parametrize("stripe_bits", [0, 10])
 def test_value_sorts_vs_oracle(built, tmp_path, stripe_bits):
-    c = H.Corpus(30000, 60000)
+    c = H.Corpus(*((3000, 8000) if QUICK else (30000, 60000)))
     db = Database(c.build_segment(str(tmp_path / "s.seg"), stripe_bits=stripe_bits))
     values = {}
     for slot in range(3):
@@ -38,12 +42,13 @@ def test_value_sorts_vs_oracle(built, tmp_path, stripe_bits):
         db.attach_column(p)
         values[slot] = read_column_values(p)
     rng = random.Random(3)
-    base = (H.gen_term_queries("OR", 12, 3, 1, 400, maxitems=10, seed=51) + H.gen_term_queries("AND", 12, 2, 1, 60, maxitems=10, seed=52) +
-            H.gen_sided_queries("AND_MAYBE", 6, 1, 2, 1, 200, maxitems=10, seed=53) + H.gen_sided_queries("AND_NOT", 6, 1, 2, 1, 200, maxitems=10, seed=54) +
-            H.gen_term_queries("OR", 6, 5, 1, 3000, first=7, maxitems=93, seed=55) + H.gen_term_queries("AND", 4, 3, 1, 30, maxitems=300, seed=56))
+    n = (lambda full, quick: quick if QUICK else full)
+    base = (H.gen_term_queries("OR", n(12, 3), 3, 1, 400, maxitems=10, seed=51) + H.gen_term_queries("AND", n(12, 3), 2, 1, 60, maxitems=10, seed=52) +
+            H.gen_sided_queries("AND_MAYBE", n(6, 2), 1, 2, 1, 200, maxitems=10, seed=53) + H.gen_sided_queries("AND_NOT", n(6, 2), 1, 2, 1, 200, maxitems=10, seed=54) +
+            H.gen_term_queries("OR", n(6, 1), 5, 1, 3000, first=7, maxitems=93, seed=55) + H.gen_term_queries("AND", n(4, 1), 3, 1, 30, maxitems=300, seed=56))
     n_items = 0
     for q in base:
-        for _ in range(2):
+        for _ in range(n(2, 1)):
             mode, slot, rev = rng.choice(["V", "VR", "RV"]), rng.randrange(3), rng.random() < 0.5
             want, whdr = H.oracle_search_sorted(c, q["op"], q["terms"], q["first"], q["maxitems"], mode, slot, rev, n_required=q.get("n_required", 0))
             p = plan(db, Query(q["op"], q["terms"], n_required=q.get("n_required", 0)), q["first"], q["maxitems"])
@@ -52,7 +57,7 @@ def test_value_sorts_vs_oracle(built, tmp_path, stripe_bits):
             assert [values[slot][o - 1] if o else b"" for _, _, _, o in got] == [k for _, _, _, k in want], (q, mode, slot, rev)
             assert hdr.matches_exact == whdr.matches and hdr.max_attained == whdr.max_attained, (q, mode, slot, rev)
             n_items += len(got)
-    assert n_items > 500
+    assert n_items > (60 if QUICK else 500)
     db.close()
     c.close()
 
