@@ -381,6 +381,15 @@ typedef struct {
 int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                       xgm_result_hdr* hdr);
 
+/* ... with a Xapian::ValueCountMatchSpy (what Xapiand's AggregationMatchSpy derives from, src/aggregations/) on value slot
+ * spy_slot in the same pass: counts[o] = matching documents whose value has ordinal o in that slot's column, counts[0] those
+ * without a value; n_counts = the column's distinct values + 1; hdr->matches_exact is the spy's total.  For sorts the value
+ * leads (XGM_SORT_VALUE, XGM_SORT_VALUE_RELEVANCE): there the matcher shows a spy every matching document whatever
+ * check_at_least is (matcher/protomset.h:268-275), so the counts are the reference's.  Replaces: api/matchspy.cc:307-313
+ * called per document from the matcher's loop (matcher/matcher.cc:519-527). */
+int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
+                          xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
+
 
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
 int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,

@@ -13,7 +13,7 @@ import pytest
 
 import helpers as H
 from xapiand_amd import Database, Query, _lib
-from xapiand_amd.enquire import plan, read_column_values, search_sorted
+from xapiand_amd.enquire import plan, read_column_values, search_sorted, search_sorted_spy
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("XGM_RUN_UNVERIFIED"), reason="device value sorts: not yet run on a GPU (set XGM_RUN_UNVERIFIED=1)")]
@@ -58,6 +58,39 @@ def test_value_sorts_vs_oracle(built, tmp_path, stripe_bits):
             assert hdr.matches_exact == whdr.matches and hdr.max_attained == whdr.max_attained, (q, mode, slot, rev)
             n_items += len(got)
     assert n_items > (60 if QUICK else 500)
+    db.close()
+    c.close()
+
+
+def test_value_count_spy_vs_oracle(built, tmp_path):
+    """A ValueCountMatchSpy in the same pass as a value-led search: counts per distinct value over every matching document and the
+    total, against the oracle's restatement (pinned to Xapian::ValueCountMatchSpy, tests/test_oracle_vs_reference.py); the page of
+    hits is the plain sorted search's."""
+    c = H.Corpus(*((3000, 8000) if QUICK else (30000, 60000)))
+    db = Database(c.build_segment(str(tmp_path / "s.seg")))
+    values = {}
+    for slot in range(3):
+        p = write_column(c, slot, str(tmp_path / ("col%d" % slot)))
+        db.attach_column(p)
+        values[slot] = read_column_values(p)
+    rng = random.Random(8)
+    nq = 3 if QUICK else 10
+    qs = (H.gen_term_queries("OR", nq, 3, 1, 400, maxitems=10, seed=61) + H.gen_term_queries("AND", nq, 2, 1, 60, maxitems=10, seed=62) +
+          H.gen_sided_queries("AND_NOT", nq // 2 + 1, 1, 2, 1, 200, maxitems=10, seed=63))
+    seen = 0
+    for q in qs:
+        mode, slot, rev, spy_slot = rng.choice(["V", "VR"]), rng.randrange(3), rng.random() < 0.5, rng.randrange(3)
+        total, want = H.oracle_spy(c, q["op"], q["terms"], spy_slot, n_required=q.get("n_required", 0))
+        p = plan(db, Query(q["op"], q["terms"], n_required=q.get("n_required", 0)), q["first"], q["maxitems"])
+        plain, _ = search_sorted(db, p, MODES[mode], slot, rev)
+        got, hdr, counts = search_sorted_spy(db, p, MODES[mode], slot, rev, spy_slot, len(values[spy_slot]))
+        assert got == plain, q
+        assert hdr.matches_exact == total == sum(counts), (q, spy_slot)
+        assert [(values[spy_slot][o - 1], n) for o, n in enumerate(counts) if o and n] == want, (q, spy_slot)
+        seen += total
+    assert seen > (300 if QUICK else 20000)
+    with pytest.raises(_lib.XgmError):                            # the counters must be the column's
+        search_sorted_spy(db, p, MODES["V"], 0, False, 2, len(values[2]) + 3)
     db.close()
     c.close()
 

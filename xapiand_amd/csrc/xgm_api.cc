@@ -266,7 +266,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->d_dense_id) hipFree(idx->d_dense_id);
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
-    for (auto& c : idx->columns) if (c.second) hipFree(c.second);
+    for (auto& c : idx->columns) if (c.second.first) hipFree(c.second.first);
     delete idx;
 }
 
@@ -994,9 +994,9 @@ extern "C" int xgm_index_attach_column(xgm_index* idx, const char* column_path) 
     hipError_t e = hipMemcpy(d, ord.data(), ord.size() * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return xgm_launch_error("column upload", (int)e, hipGetErrorString(e)); }
     std::lock_guard<std::mutex> lk(idx->columns_mu);
-    void*& slot = idx->columns[h32[0]];
-    if (slot) hipFree(slot);
-    slot = d;
+    std::pair<void*, uint32_t>& slot = idx->columns[h32[0]];
+    if (slot.first) hipFree(slot.first);
+    slot = std::make_pair(d, h32[2]);
     return XGM_OK;
 }
 
@@ -1014,17 +1014,26 @@ struct DeviceBuffers {                       /* freed on every way out */
 };
 }  // namespace
 
-extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
-                                 xgm_result_hdr* hdr) {
+/* spy_slot >= 0: also count the matching documents by their value in that slot (counts[0 .. n_counts), n_counts = the column's
+ * distinct values + 1) */
+static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord, xgm_result_hdr* hdr,
+                       int spy_slot, uint32_t* counts, uint32_t n_counts) {
     if (!idx || !q || !sort || !hits || !hdr) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
     if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
     if (q->tree_len || q->phrase_active) return XGM_UNSUPPORTED;               /* plain operators only, so far */
     const uint32_t* d_ord = nullptr;
+    const uint32_t* d_spy_ord = nullptr;
     {
         std::lock_guard<std::mutex> lk(idx->columns_mu);
         auto it = idx->columns.find(sort->slot);
-        if (it != idx->columns.end()) d_ord = (const uint32_t*)it->second;
+        if (it != idx->columns.end()) d_ord = (const uint32_t*)it->second.first;
+        if (spy_slot >= 0) {
+            it = idx->columns.find((uint32_t)spy_slot);
+            if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+            if (!counts || n_counts != it->second.second + 1u) return xgm_set_error(XGM_E_INVALID, "spy: %u counters for a column of %u distinct values (+ 1 for no value)", n_counts, it->second.second);
+            d_spy_ord = (const uint32_t*)it->second.first;
+        }
     }
     if (!d_ord) return XGM_UNSUPPORTED;
     int rc = use_device(idx->device);
@@ -1044,6 +1053,11 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
         return rc;
     HIP_TRY(hipMemcpy(d_q, &dq, sizeof dq, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_work, bp.work.data(), (size_t)n_work * sizeof(xgm_work), hipMemcpyHostToDevice));
+    uint32_t* d_counts = nullptr;
+    if (d_spy_ord) {
+        if ((rc = dev.alloc((void**)&d_counts, (size_t)n_counts * 4))) return rc;
+        HIP_TRY(hipMemset(d_counts, 0, (size_t)n_counts * 4));
+    }
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = d_q;
@@ -1051,11 +1065,12 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
     L.phrase = false; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = d_ghdr;
-    if ((rc = xgm_launch_match_sorted(L, d_ord, sort->sort_by, sort->reverse ? 1u : 0u, d_cand, nullptr))) return rc;
+    if ((rc = xgm_launch_match_sorted(L, d_ord, sort->sort_by, sort->reverse ? 1u : 0u, d_spy_ord, d_counts, d_cand, nullptr))) return rc;
     std::vector<xgm_cand_sorted> cand((size_t)n_work * k);
     std::vector<xgm_group_hdr> gh(n_work);
     HIP_TRY(hipMemcpy(gh.data(), d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));     /* (waits for the kernel) */
     HIP_TRY(hipMemcpy(cand.data(), d_cand, cand.size() * sizeof(xgm_cand_sorted), hipMemcpyDeviceToHost));
+    if (d_counts) HIP_TRY(hipMemcpy(counts, d_counts, (size_t)n_counts * 4, hipMemcpyDeviceToHost));
     /* merge the units: their best k each under the comparison the kernel used; the whole match's best weight and count */
     std::vector<xgm_cand_sorted> all;
     uint64_t matches = 0, max_w = 0;
@@ -1088,6 +1103,17 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
     hdr->max_possible = q->max_possible;
     if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
     return XGM_OK;
+}
+
+extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
+                                 xgm_result_hdr* hdr) {
+    return sorted_core(idx, q, sort, hits, hit_ord, hdr, -1, nullptr, 0);
+}
+
+extern "C" int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
+                                     xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts) {
+    if (!sort || sort->sort_by == XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "a spy's counts are defined where the value leads the sort");
+    return sorted_core(idx, q, sort, hits, hit_ord, hdr, (int)spy_slot, counts, n_counts);
 }
 
 /* ---- opt-in micro-batching (server mode) -----------------------------------------------------------------------------

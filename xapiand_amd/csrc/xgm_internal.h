@@ -113,7 +113,7 @@ struct xgm_index {
     uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
     XgmBatcher* batcher = nullptr;
     XgmShardCtx* shard_ctx = nullptr;  /* when this index is shards[0] of an xgm_search_sharded list */
-    std::map<uint32_t, void*> columns; /* value slot → device u32 ord[lastdocid + 1] (xgm_index_attach_column) */
+    std::map<uint32_t, std::pair<void*, uint32_t>> columns;   /* value slot → (device u32 ord[lastdocid + 1], distinct values): xgm_index_attach_column */
     std::mutex columns_mu;
 };
 

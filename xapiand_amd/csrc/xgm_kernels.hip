@@ -2699,6 +2699,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uin
  * weighed: with the value leading there is no weight to prune by, and the reference reports the best weight of the WHOLE match
  * (ProtoMSet::update_max_weight sees every document, protomset.h:174-183, 249-283) — published per unit in the header (c_pos =
  * weight bits, c_pad = {docid, weighted leaves} of the first document that attains it).
+ * spy_counts != NULL: also a Xapian::ValueCountMatchSpy (api/matchspy.cc:307-313) — one count per ordinal of the column spy_ord,
+ * incremented for every matching document (a value-led sort shows the spies every match, protomset.h:268-275).
  * Plain operators only (AND / OR / AND_NOT / AND_MAYBE / FILTER); positional and nested queries are declined by the host. */
 __device__ __forceinline__ bool sorted_before(uint64_t aw, uint64_t ax, uint32_t ad, uint64_t bw, uint64_t bx, uint32_t bd, bool use_x) {
     if (aw != bw) return aw > bw;
@@ -2740,6 +2742,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
                                                                    const xgm_work* __restrict__ work, uint32_t stripes_per_group,
                                                                    uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                                    const uint32_t* __restrict__ ord, uint32_t mode, uint32_t reverse,
+                                                                   const uint32_t* __restrict__ spy_ord, uint32_t* __restrict__ spy_counts,
                                                                    xgm_cand_sorted* __restrict__ cand_out,
                                                                    xgm_group_hdr* __restrict__ ghdr_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2966,6 +2969,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
                 const double weight = val[q.sum_root];
                 const uint64_t wb = (uint64_t)__double_as_longlong(weight);
                 if (wb > my_max_w || (wb == my_max_w && did < my_max_d)) { my_max_w = wb; my_max_d = did; my_max_m = subqs; }
+                if (spy_counts) atomicAdd(&spy_counts[spy_ord[did]], 1u);       /* Xapian::ValueCountMatchSpy: every matching document, by its value */
                 const uint32_t o32 = ord[did];
                 const uint64_t okey = (uint64_t)(reverse ? o32 : ~o32);
                 const uint64_t kw = mode == 3u ? wb : okey, kx = mode == 3u ? okey : wb;
@@ -3069,18 +3073,19 @@ size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uin
     return match_smem_bytes(1u << stripe_bits, tab_terms, false, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15);
 }
 
-int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, xgm_cand_sorted* cand, hipStream_t stream) {
+int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, const uint32_t* spy_ord, uint32_t* spy_counts,
+                            xgm_cand_sorted* cand, hipStream_t stream) {
     dim3 grid(L.n_work), block(XGM_WG);
     const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("sorted match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.phrase || !ord || mode < 1u || mode > 3u) return xgm_launch_error("sorted match kernel", 0, "bad arguments");
+    if (L.phrase || !ord || mode < 1u || mode > 3u || (spy_counts && !spy_ord)) return xgm_launch_error("sorted match kernel", 0, "bad arguments");
 #define XGM_LAUNCH(TT)                                                                                       \
     do {                                                                                                     \
         auto kern = xgm_match_sorted_kernel<TT>;                                                             \
         static std::atomic<size_t> seen{0};                                                                  \
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
-                           L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, cand, L.ghdr);                \
+                           L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cand, L.ghdr); \
     } while (0)
     if (L.wide) XGM_LAUNCH(uint16_t); else XGM_LAUNCH(uint8_t);
 #undef XGM_LAUNCH

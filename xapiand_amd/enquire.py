@@ -396,6 +396,19 @@ def search_sorted(db, planned, sort_by, slot, reverse=False):
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i]) for i in range(hdr.n_hits)], hdr
 
 
+def search_sorted_spy(db, planned, sort_by, slot, reverse, spy_slot, n_distinct):
+    """xgm_search_sorted_spy: search_sorted plus a ValueCountMatchSpy on spy_slot (a column with n_distinct values attached).
+    Returns (hits, hdr, counts) with counts[o] = matching documents whose value has ordinal o (0 = no value)."""
+    k = max(1, planned.first + planned.maxitems)
+    hits = (_lib.Hit * k)()
+    ords = (C.c_uint32 * k)()
+    hdr = _lib.ResultHdr()
+    counts = (C.c_uint32 * (n_distinct + 1))()
+    spec = _lib.SortSpec(sort_by, slot, 1 if reverse else 0, 0)
+    _lib.check(_lib.lib().xgm_search_sorted_spy(db._h, C.byref(planned), C.byref(spec), hits, ords, C.byref(hdr), spy_slot, counts, n_distinct + 1))
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i]) for i in range(hdr.n_hits)], hdr, list(counts)
+
+
 def search_batch(db, plans):
     """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
     nq = len(plans)
