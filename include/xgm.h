@@ -390,6 +390,18 @@ int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* s
 int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                           xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
 
+/* ... with Enquire::set_collapse_key(collapse_slot, collapse_max) in force (sort == NULL: ranked by relevance): of the documents
+ * sharing a value in the collapse slot only the best collapse_max under the ranking stay; documents without a value are never
+ * collapsed.  hit_collapse_ord[i] = ordinal of hit i's collapse key in that slot's column (MSetIterator::get_collapse_key),
+ * hit_collapse_count[i] = matching documents of that key beyond the collapse_max that stay (get_collapse_count);
+ * *collapsed_lower_bound = documents without a key + per key min(matches, collapse_max); hdr->matches_exact counts the
+ * uncollapsed match.  Any output pointer but hits / hdr may be NULL.  These are the INTENDED semantics (the best documents of
+ * a key stay): the reference snapshot's collapser keeps the last-seen ones instead, so a hook that needs
+ * byte-compatibility with it keeps collapsed searches on the CPU.  Replaces: matcher/collapser.cc in ProtoMSet::process. */
+int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, uint32_t collapse_slot, uint32_t collapse_max,
+                         xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord, uint32_t* hit_collapse_count, xgm_result_hdr* hdr,
+                         uint64_t* collapsed_lower_bound);
+
 
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
 int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,

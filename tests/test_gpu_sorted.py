@@ -13,7 +13,7 @@ import pytest
 
 import helpers as H
 from xapiand_amd import Database, Query, _lib
-from xapiand_amd.enquire import plan, read_column_values, search_sorted, search_sorted_spy
+from xapiand_amd.enquire import plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("XGM_RUN_UNVERIFIED"), reason="device value sorts: not yet run on a GPU (set XGM_RUN_UNVERIFIED=1)")]
@@ -91,6 +91,43 @@ def test_value_count_spy_vs_oracle(built, tmp_path):
     assert seen > (300 if QUICK else 20000)
     with pytest.raises(_lib.XgmError):                            # the counters must be the column's
         search_sorted_spy(db, p, MODES["V"], 0, False, 2, len(values[2]) + 3)
+    db.close()
+    c.close()
+
+
+def test_collapse_vs_oracle(built, tmp_path):
+    """Enquire::set_collapse_key by relevance and under the value sorts, collapse_max 1..3, against the oracle's restatement of the
+    INTENDED semantics (the best documents of a key stay; the reference snapshot's collapser is a quirk): docids,
+    weight bits, sort and collapse keys, collapse counts, the collapsed lower bound, the uncollapsed match count."""
+    c = H.Corpus(*((3000, 8000) if QUICK else (30000, 60000)))
+    db = Database(c.build_segment(str(tmp_path / "s.seg"), stripe_bits=10))
+    values = {}
+    for slot in range(3):
+        p = write_column(c, slot, str(tmp_path / ("col%d" % slot)))
+        db.attach_column(p)
+        values[slot] = read_column_values(p)
+    rng = random.Random(12)
+    nq = 3 if QUICK else 10
+    qs = (H.gen_term_queries("OR", nq, 3, 1, 400, maxitems=10, seed=71) + H.gen_term_queries("AND", nq, 2, 1, 60, maxitems=10, seed=72) +
+          H.gen_sided_queries("AND_MAYBE", nq // 2 + 1, 1, 2, 1, 200, maxitems=10, seed=73) + H.gen_term_queries("OR", nq // 2 + 1, 4, 1, 2000, first=5, maxitems=40, seed=74))
+    n_items = n_collapsed = 0
+    for q in qs:
+        for _ in range(1 if QUICK else 2):
+            mode = rng.choice([None, None, "V", "VR", "RV"])
+            slot, rev = rng.randrange(3), rng.random() < 0.5
+            cslot, cmax = rng.choice([0, 2]), rng.randrange(1, 4)
+            want, whdr = H.oracle_search_sorted(c, q["op"], q["terms"], q["first"], q["maxitems"], mode, slot, rev, n_required=q.get("n_required", 0), collapse=(cslot, cmax))
+            p = plan(db, Query(q["op"], q["terms"], n_required=q.get("n_required", 0)), q["first"], q["maxitems"])
+            got, hdr, clb = search_collapsed(db, p, cslot, cmax, MODES[mode] if mode else None, slot, rev)
+            key = lambda o: values[cslot][o - 1] if o else b""
+            assert [(d, w, m) for d, w, m, _, _, _ in got] == [(d, w, m) for d, w, m, _, _, _ in want], (q, mode, slot, rev, cslot, cmax)
+            assert [(key(co), cc) for _, _, _, _, co, cc in got] == [(ck, cc) for _, _, _, _, ck, cc in want], (q, mode, cslot, cmax)
+            if mode:
+                assert [values[slot][o - 1] if o else b"" for _, _, _, o, _, _ in got] == [k for _, _, _, k, _, _ in want], (q, mode, slot, rev)
+            assert hdr.matches_exact == whdr.matches and clb == whdr.collapsed_lower_bound, (q, cslot, cmax)
+            n_items += len(got)
+            n_collapsed += sum(1 for g in got if g[5])
+    assert n_items > (60 if QUICK else 400) and n_collapsed > 10
     db.close()
     c.close()
 

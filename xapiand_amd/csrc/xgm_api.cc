@@ -1015,27 +1015,46 @@ struct DeviceBuffers {                       /* freed on every way out */
 }  // namespace
 
 /* spy_slot >= 0: also count the matching documents by their value in that slot (counts[0 .. n_counts), n_counts = the column's
- * distinct values + 1) */
+ * distinct values + 1).  collapse_slot >= 0: Enquire::set_collapse_key(collapse_slot, cmax) — the kernel collapses inside every
+ * unit, the merge below once more; the per-key match counts (the spy mechanism on the collapse column) give the items' collapse
+ * counts and the collapsed lower bound.  sort == NULL: by relevance. */
 static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord, xgm_result_hdr* hdr,
-                       int spy_slot, uint32_t* counts, uint32_t n_counts) {
-    if (!idx || !q || !sort || !hits || !hdr) return xgm_set_error(XGM_E_INVALID, "null argument");
+                       int spy_slot, uint32_t* counts, uint32_t n_counts,
+                       int collapse_slot = -1, uint32_t cmax = 0, uint32_t* hit_cord = nullptr, uint32_t* hit_ccount = nullptr, uint64_t* collapsed_lb = nullptr) {
+    if (!idx || !q || !hits || !hdr) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
-    if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
+    if (sort && (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE)) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
+    if (!sort && collapse_slot < 0) return xgm_set_error(XGM_E_INVALID, "neither a sort nor a collapse key");
+    if (collapse_slot >= 0 && (cmax == 0 || spy_slot >= 0)) return xgm_set_error(XGM_E_INVALID, "collapse_max 0, or a spy together with a collapse key");
     if (q->tree_len || q->phrase_active) return XGM_UNSUPPORTED;               /* plain operators only, so far */
+    const uint32_t mode = sort ? sort->sort_by : 4u;
+    const bool reverse = sort && sort->reverse;
     const uint32_t* d_ord = nullptr;
     const uint32_t* d_spy_ord = nullptr;
+    const uint32_t* d_cord = nullptr;
+    std::vector<uint32_t> key_counts;
     {
         std::lock_guard<std::mutex> lk(idx->columns_mu);
-        auto it = idx->columns.find(sort->slot);
-        if (it != idx->columns.end()) d_ord = (const uint32_t*)it->second.first;
+        if (sort) {
+            auto it = idx->columns.find(sort->slot);
+            if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+            d_ord = (const uint32_t*)it->second.first;
+        }
         if (spy_slot >= 0) {
-            it = idx->columns.find((uint32_t)spy_slot);
+            auto it = idx->columns.find((uint32_t)spy_slot);
             if (it == idx->columns.end()) return XGM_UNSUPPORTED;
             if (!counts || n_counts != it->second.second + 1u) return xgm_set_error(XGM_E_INVALID, "spy: %u counters for a column of %u distinct values (+ 1 for no value)", n_counts, it->second.second);
             d_spy_ord = (const uint32_t*)it->second.first;
         }
+        if (collapse_slot >= 0) {
+            auto it = idx->columns.find((uint32_t)collapse_slot);
+            if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+            d_cord = (const uint32_t*)it->second.first;
+            d_spy_ord = d_cord;                       /* matches per collapse key */
+            key_counts.assign((size_t)it->second.second + 1u, 0u);
+            counts = key_counts.data(); n_counts = (uint32_t)key_counts.size();
+        }
     }
-    if (!d_ord) return XGM_UNSUPPORTED;
     int rc = use_device(idx->device);
     if (rc) return rc;
     xgm_dev_query dq;
@@ -1043,7 +1062,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     double mp = 0;
     BatchPlan bp;
     if ((rc = plan_batch(idx, q, 1, &dq, &kq, &mp, &bp, true))) return rc;
-    if ((dq.flags & (XGM_QF_PHRASE | XGM_QF_TREE)) || bp.andw || bp.orw || bp.and_only || dq.k == 0) return XGM_UNSUPPORTED;
+    if ((dq.flags & (XGM_QF_PHRASE | XGM_QF_TREE)) || bp.andw || bp.orw || bp.and_only || dq.k == 0 || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
     if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
     const uint32_t k = dq.k, n_work = bp.n_work;
     DeviceBuffers dev;
@@ -1065,7 +1084,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
     L.phrase = false; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = d_ghdr;
-    if ((rc = xgm_launch_match_sorted(L, d_ord, sort->sort_by, sort->reverse ? 1u : 0u, d_spy_ord, d_counts, d_cand, nullptr))) return rc;
+    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, d_cord, cmax, d_cand, nullptr))) return rc;
     std::vector<xgm_cand_sorted> cand((size_t)n_work * k);
     std::vector<xgm_group_hdr> gh(n_work);
     HIP_TRY(hipMemcpy(gh.data(), d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));     /* (waits for the kernel) */
@@ -1082,20 +1101,39 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
         all.insert(all.end(), cand.begin() + (size_t)u * k, cand.begin() + (size_t)u * k + g.n_cand);
         if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
     }
-    const bool use_x = sort->sort_by != XGM_SORT_VALUE;
+    const bool use_x = mode == XGM_SORT_VALUE_RELEVANCE || mode == XGM_SORT_RELEVANCE_VALUE;
     std::sort(all.begin(), all.end(), [&](const xgm_cand_sorted& a, const xgm_cand_sorted& b) {
         if (a.kw != b.kw) return a.kw > b.kw;
         if (use_x && a.kx != b.kx) return a.kx > b.kx;
         return a.did < b.did;
     });
+    if (collapse_slot >= 0) {
+        /* the merged ranking collapsed once more: of every key the first cmax stay */
+        std::vector<uint32_t> kept_of(key_counts.size(), 0u);
+        size_t out = 0;
+        for (const xgm_cand_sorted& c : all) {
+            if (c.cord >= kept_of.size()) return xgm_set_error(XGM_E_DEVICE, "sorted search: collapse ordinal %u beyond the column", c.cord);
+            if (c.cord == 0u || kept_of[c.cord]++ < cmax) all[out++] = c;
+        }
+        all.resize(out);
+        if (collapsed_lb) {
+            /* Collapser::get_matches_lower_bound: documents without a key + per key the entries that stay */
+            uint64_t lb = key_counts[0];
+            for (size_t o = 1; o < key_counts.size(); ++o) lb += std::min<uint32_t>(key_counts[o], cmax);
+            *collapsed_lb = lb;
+        }
+    }
     const uint32_t n = (uint32_t)std::min<size_t>(k, all.size());
+    const bool weight_first = mode >= XGM_SORT_RELEVANCE_VALUE;             /* relevance then value, relevance alone */
     for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t wbits = sort->sort_by == XGM_SORT_RELEVANCE_VALUE ? all[i].kw : all[i].kx;
-        const uint32_t okey = (uint32_t)(sort->sort_by == XGM_SORT_RELEVANCE_VALUE ? all[i].kx : all[i].kw);
+        const uint64_t wbits = weight_first ? all[i].kw : all[i].kx;
+        const uint32_t okey = (uint32_t)(weight_first ? all[i].kx : all[i].kw);
         hits[i].docid = all[i].did;
         hits[i].subqs_matched = all[i].subqs;
         memcpy(&hits[i].weight, &wbits, 8);
-        if (hit_ord) hit_ord[i] = sort->reverse ? okey : ~okey;
+        if (hit_ord) hit_ord[i] = sort ? (reverse ? okey : ~okey) : 0u;
+        if (hit_cord) hit_cord[i] = all[i].cord;
+        if (hit_ccount) hit_ccount[i] = (collapse_slot >= 0 && all[i].cord && key_counts[all[i].cord] > cmax) ? key_counts[all[i].cord] - cmax : 0u;
     }
     memset(hdr, 0, sizeof *hdr);
     hdr->n_hits = n;
@@ -1107,6 +1145,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
 
 extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                                  xgm_result_hdr* hdr) {
+    if (!sort) return xgm_set_error(XGM_E_INVALID, "null argument");
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, -1, nullptr, 0);
 }
 
@@ -1114,6 +1153,12 @@ extern "C" int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const x
                                      xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts) {
     if (!sort || sort->sort_by == XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "a spy's counts are defined where the value leads the sort");
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, (int)spy_slot, counts, n_counts);
+}
+
+extern "C" int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, uint32_t collapse_slot, uint32_t collapse_max,
+                                    xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord, uint32_t* hit_collapse_count, xgm_result_hdr* hdr,
+                                    uint64_t* collapsed_lower_bound) {
+    return sorted_core(idx, q, sort, hits, hit_ord, hdr, -1, nullptr, 0, (int)collapse_slot, collapse_max, hit_collapse_ord, hit_collapse_count, collapsed_lower_bound);
 }
 
 /* ---- opt-in micro-batching (server mode) -----------------------------------------------------------------------------

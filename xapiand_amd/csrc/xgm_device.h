@@ -71,6 +71,8 @@ typedef struct {
     uint64_t kw, kx;
     uint32_t did;
     uint32_t subqs;
+    uint32_t cord;         /* ordinal of the document's collapse key (0: none / not collapsing) */
+    uint32_t pad;
 } xgm_cand_sorted;
 
 /* One unit of work of the match kernels: a query and a contiguous range of docid stripes.  The host

@@ -2699,6 +2699,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uin
  * weighed: with the value leading there is no weight to prune by, and the reference reports the best weight of the WHOLE match
  * (ProtoMSet::update_max_weight sees every document, protomset.h:174-183, 249-283) — published per unit in the header (c_pos =
  * weight bits, c_pad = {docid, weighted leaves} of the first document that attains it).
+ * mode 4: relevance alone (weight, docid) — for a search that only collapses.
+ * cord != NULL: Enquire::set_collapse_key(slot, cmax) by the ordinals of that slot's column (collapse_prune above).
  * spy_counts != NULL: also a Xapian::ValueCountMatchSpy (api/matchspy.cc:307-313) — one count per ordinal of the column spy_ord,
  * incremented for every matching document (a value-led sort shows the spies every match, protomset.h:268-275).
  * Plain operators only (AND / OR / AND_NOT / AND_MAYBE / FILTER); positional and nested queries are declined by the host. */
@@ -2712,10 +2714,11 @@ struct SortedExt {                    /* LDS behind the ordinary layout of the m
     uint64_t theta_x;
     unsigned long long max_w;
     uint32_t max_d, max_m;
+    uint32_t survivors, pad;
 };
 
-/* topk_sort over (w, x, d): unused entries hold (0, 0, UINT32_MAX), which sorts last */
-__device__ void topk_sort_sorted(const TopK& tk, uint64_t* x, uint32_t tid, bool use_x) {
+/* topk_sort over (w, x, d): unused entries hold (0, 0, UINT32_MAX), which sorts last; c (the candidates' collapse ordinals) moves along */
+__device__ void topk_sort_sorted(const TopK& tk, uint64_t* x, uint32_t* c, uint32_t tid, bool use_x) {
     for (uint32_t size = 2; size <= tk.cap; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
@@ -2730,10 +2733,33 @@ __device__ void topk_sort_sorted(const TopK& tk, uint64_t* x, uint32_t tid, bool
                     tk.d[lo] = bd; tk.d[hi] = ad;
                     const uint32_t am = tk.m[lo], bm = tk.m[hi];
                     tk.m[lo] = bm; tk.m[hi] = am;
+                    const uint32_t ac = c[lo], bc = c[hi];
+                    c[lo] = bc; c[hi] = ac;
                 }
             }
         }
     }
+    __syncthreads();
+}
+
+/* Enquire::set_collapse_key on a sorted buffer (best first): an entry with a collapse key (ordinal != 0) behind cmax better entries of
+ * the same key becomes a sentinel; the caller sorts again.  A document evicted here by documents of its own unit is evicted in the
+ * whole match too, and a document inside the global collapsed top k is inside its unit's (per key, the global survivors ahead of it
+ * are at least as many as the unit's) — so the units can collapse independently and the merge collapses once more.  Quadratic in
+ * the buffer (<= a few hundred entries): first version. */
+__device__ void collapse_prune(const TopK& tk, uint64_t* x, uint32_t* c, uint32_t n, uint32_t cmax, uint32_t tid) {
+    bool drop[8];                                   /* the buffer holds at most 8 x XGM_WG entries (the host checks) */
+    uint32_t nd = 0;
+    for (uint32_t i = tid; i < n; i += XGM_WG, ++nd) {
+        const uint32_t key = c[i];
+        uint32_t ahead = 0;
+        if (key) for (uint32_t j = 0; j < i; ++j) ahead += c[j] == key ? 1u : 0u;
+        drop[nd & 7u] = key != 0u && ahead >= cmax;
+    }
+    __syncthreads();
+    nd = 0;
+    for (uint32_t i = tid; i < n; i += XGM_WG, ++nd)
+        if (drop[nd & 7u]) { tk.w[i] = 0; x[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; c[i] = 0; }
     __syncthreads();
 }
 
@@ -2743,6 +2769,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
                                                                    uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                                    const uint32_t* __restrict__ ord, uint32_t mode, uint32_t reverse,
                                                                    const uint32_t* __restrict__ spy_ord, uint32_t* __restrict__ spy_counts,
+                                                                   const uint32_t* __restrict__ cord, uint32_t cmax,
                                                                    xgm_cand_sorted* __restrict__ cand_out,
                                                                    xgm_group_hdr* __restrict__ ghdr_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2758,7 +2785,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
     const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;
     const uint32_t k = q.k;
     const uint32_t SPG = stripes_per_group;
-    const bool use_x = mode != 1u;
+    const bool use_x = mode == 2u || mode == 3u;          /* (1: value alone; 4: relevance alone) */
 
     KernelSmem sm = carve<TabT>(smem, W, tab_terms, false, cap, SPG);
     Ctrl& ctl = *sm.ctrl;
@@ -2768,16 +2795,33 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
     const size_t base_bytes = ((size_t)(reinterpret_cast<unsigned char*>(sm.runs + (size_t)2 * tab_terms * SPG) - smem) + 15) & ~(size_t)15;
     uint64_t* tkx = reinterpret_cast<uint64_t*>(smem + base_bytes);
     SortedExt& ext = *reinterpret_cast<SortedExt*>(smem + base_bytes + (size_t)cap * 8);
+    uint32_t* tkc = reinterpret_cast<uint32_t*>(smem + base_bytes + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15));   /* collapse ordinals */
+    /* sort; with a collapse key: evict what its own key's better documents push out, sort the gaps away; → survivors in front */
+    auto sort_and_collapse = [&]() {
+        topk_sort_sorted(sm.tk, tkx, tkc, tid, use_x);
+        if (!cord) return;
+        const uint32_t n = ctl.tkn < cap ? ctl.tkn : cap;
+        collapse_prune(sm.tk, tkx, tkc, n, cmax, tid);
+        topk_sort_sorted(sm.tk, tkx, tkc, tid, use_x);
+        if (tid == 0) ext.survivors = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = tid; i < n; i += XGM_WG) mine += sm.tk.d[i] != 0xFFFFFFFFu ? 1u : 0u;
+        if (mine) atomicAdd(&ext.survivors, mine);
+        __syncthreads();
+        if (tid == 0) ctl.tkn = ext.survivors;
+        __syncthreads();
+    };
 
     const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
     const uint32_t s_begin = wk.s_begin;
     const uint32_t s_end = wk.s_end;
 
-    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; tkc[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
     for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
     if (tid == 0) {
         ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0;
-        ext.theta_x = 0; ext.max_w = 0; ext.max_d = 0xFFFFFFFFu; ext.max_m = 0;
+        ext.theta_x = 0; ext.max_w = 0; ext.max_d = 0xFFFFFFFFu; ext.max_m = 0; ext.survivors = 0;
     }
     const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
     if (!empty) {
@@ -2933,14 +2977,14 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
             const uint32_t fill_now = ctl.tkn;
             __syncthreads();
             if (fill_now + XGM_WG > cap) {
-                topk_sort_sorted(sm.tk, tkx, tid, use_x);
+                sort_and_collapse();
                 if (tid == 0) {
                     const uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
                     ctl.tkn = keep;
                     if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ext.theta_x = tkx[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
                 }
                 __syncthreads();
-                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
+                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; tkc[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
                 __syncthreads();
             }
             const uint32_t i = i0 + tid;
@@ -2970,13 +3014,13 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
                 const uint64_t wb = (uint64_t)__double_as_longlong(weight);
                 if (wb > my_max_w || (wb == my_max_w && did < my_max_d)) { my_max_w = wb; my_max_d = did; my_max_m = subqs; }
                 if (spy_counts) atomicAdd(&spy_counts[spy_ord[did]], 1u);       /* Xapian::ValueCountMatchSpy: every matching document, by its value */
-                const uint32_t o32 = ord[did];
-                const uint64_t okey = (uint64_t)(reverse ? o32 : ~o32);
-                const uint64_t kw = mode == 3u ? wb : okey, kx = mode == 3u ? okey : wb;
+                const uint32_t o32 = ord ? ord[did] : 0u;                       /* (mode 4, relevance alone: no column) */
+                const uint64_t okey = ord ? (uint64_t)(reverse ? o32 : ~o32) : 0ull;
+                const uint64_t kw = mode >= 3u ? wb : okey, kx = mode >= 3u ? okey : wb;
                 const bool take = !ctl.theta_valid || sorted_before(kw, kx, did, ctl.theta_w, ext.theta_x, ctl.theta_d, use_x);
                 if (take) {
                     const uint32_t o = atomicAdd(&ctl.tkn, 1u);
-                    sm.tk.w[o] = kw; tkx[o] = kx; sm.tk.d[o] = did; sm.tk.m[o] = subqs;
+                    sm.tk.w[o] = kw; tkx[o] = kx; sm.tk.d[o] = did; sm.tk.m[o] = subqs; tkc[o] = cord ? cord[did] : 0u;
                 }
             }
             __syncthreads();
@@ -2988,7 +3032,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
 
     /* epilogue: the unit's best k, its match count and the best weight of everything it matched */
     __syncthreads();
-    topk_sort_sorted(sm.tk, tkx, tid, use_x);
+    sort_and_collapse();
     if (my_matches) atomicAdd(&ctl.matches, my_matches);
     if (my_max_d != 0xFFFFFFFFu) atomicMax(&ext.max_w, (unsigned long long)my_max_w);
     __syncthreads();
@@ -3000,7 +3044,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev se
     xgm_cand_sorted* out = cand_out + (size_t)wk.slot * k_stride;
     for (uint32_t i = tid; i < n_out; i += XGM_WG) {
         xgm_cand_sorted c;
-        c.kw = sm.tk.w[i]; c.kx = tkx[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
+        c.kw = sm.tk.w[i]; c.kx = tkx[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i]; c.cord = tkc[i]; c.pad = 0;
         out[i] = c;
     }
     if (tid == 0) {
@@ -3070,22 +3114,23 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
 }
 
 size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group) {
-    return match_smem_bytes(1u << stripe_bits, tab_terms, false, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15);
+    return match_smem_bytes(1u << stripe_bits, tab_terms, false, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15) + (size_t)cap * 4;
 }
 
 int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, const uint32_t* spy_ord, uint32_t* spy_counts,
-                            xgm_cand_sorted* cand, hipStream_t stream) {
+                            const uint32_t* cord, uint32_t cmax, xgm_cand_sorted* cand, hipStream_t stream) {
     dim3 grid(L.n_work), block(XGM_WG);
     const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("sorted match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.phrase || !ord || mode < 1u || mode > 3u || (spy_counts && !spy_ord)) return xgm_launch_error("sorted match kernel", 0, "bad arguments");
+    if (L.phrase || mode < 1u || mode > 4u || (!ord && mode != 4u) || (spy_counts && !spy_ord) || (cord && cmax == 0u) || L.cap > 8u * XGM_WG)
+        return xgm_launch_error("sorted match kernel", 0, "bad arguments");
 #define XGM_LAUNCH(TT)                                                                                       \
     do {                                                                                                     \
         auto kern = xgm_match_sorted_kernel<TT>;                                                             \
         static std::atomic<size_t> seen{0};                                                                  \
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
-                           L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cand, L.ghdr); \
+                           L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cord, cmax, cand, L.ghdr); \
     } while (0)
     if (L.wide) XGM_LAUNCH(uint16_t); else XGM_LAUNCH(uint8_t);
 #undef XGM_LAUNCH

@@ -30,7 +30,9 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
  * plain operators only, candidates of 24 bytes with two keys, L.cand unused */
 size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, const uint32_t* spy_ord, uint32_t* spy_counts,
-                            xgm_cand_sorted* cand, hipStream_t stream);      /* spy_counts (device, zeroed, one u32 per ordinal of spy_ord) may be NULL */
+                            const uint32_t* cord, uint32_t cmax, xgm_cand_sorted* cand, hipStream_t stream);
+/* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
+ *  column's ordinals or NULL, cmax = collapse_max) */
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
 size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);

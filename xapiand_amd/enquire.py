@@ -409,6 +409,20 @@ def search_sorted_spy(db, planned, sort_by, slot, reverse, spy_slot, n_distinct)
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i]) for i in range(hdr.n_hits)], hdr, list(counts)
 
 
+def search_collapsed(db, planned, collapse_slot, collapse_max, sort_by=None, slot=0, reverse=False):
+    """xgm_search_collapsed: set_collapse_key(collapse_slot, collapse_max), ranked by relevance (sort_by None) or under a value sort.
+    Returns ([(docid, weight, subqs, sort ordinal, collapse ordinal, collapse count)], hdr, collapsed lower bound)."""
+    k = max(1, planned.first + planned.maxitems)
+    hits = (_lib.Hit * k)()
+    ords, cords, ccounts = (C.c_uint32 * k)(), (C.c_uint32 * k)(), (C.c_uint32 * k)()
+    hdr = _lib.ResultHdr()
+    clb = C.c_uint64()
+    spec = _lib.SortSpec(sort_by, slot, 1 if reverse else 0, 0) if sort_by else None
+    _lib.check(_lib.lib().xgm_search_collapsed(db._h, C.byref(planned), C.byref(spec) if spec else None, collapse_slot, collapse_max, hits, ords, cords, ccounts,
+                                               C.byref(hdr), C.byref(clb)))
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i], cords[i], ccounts[i]) for i in range(hdr.n_hits)], hdr, clb.value
+
+
 def search_batch(db, plans):
     """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
     nq = len(plans)
