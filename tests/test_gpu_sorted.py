@@ -12,7 +12,7 @@ import random
 import pytest
 
 import helpers as H
-from xapiand_amd import Database, Query, _lib
+from xapiand_amd import Database, Enquire, Query, ValueCountMatchSpy, _lib
 from xapiand_amd.enquire import plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
 
 pytestmark = [pytest.mark.gpu,
@@ -128,6 +128,48 @@ def test_collapse_vs_oracle(built, tmp_path):
             n_items += len(got)
             n_collapsed += sum(1 for g in got if g[5])
     assert n_items > (60 if QUICK else 400) and n_collapsed > 10
+    db.close()
+    c.close()
+
+
+def test_enquire_mirror_against_the_references_own_msets(built, tmp_path):
+    """Through the Enquire mirror (set_sort_by_value* / add_matchspy, as a test of the reference would read) against the fixtures
+    the compiled reference generated (tests/golden/sorted_values.json, spy_counts.json): docid, weight bits, percentage and sort
+    key at every rank, max_attained; the spy's total and (value, count) list."""
+    import json
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    fx = json.load(open(os.path.join(gdir, "sorted_values.json")))
+    cp = fx["corpus"]
+    c = H.Corpus(cp["n_docs"], cp["vocab"], seed=cp["seed"], len_lo=cp["len_lo"], len_hi=cp["len_hi"])
+    db = Database(c.build_segment(str(tmp_path / "g.seg")))
+    for slot in range(3):
+        db.attach_column(write_column(c, slot, str(tmp_path / ("col%d" % slot))))
+    setters = {"V": Enquire.set_sort_by_value, "VR": Enquire.set_sort_by_value_then_relevance, "RV": Enquire.set_sort_by_relevance_then_value}
+    results = fx["results"][::3] if QUICK else fx["results"]
+    n_items = 0
+    for r in results:
+        q = r["query"]
+        mode, slot, rev = q["sort"]
+        enq = Enquire(db)
+        enq.set_query(Query(q["op"], q["terms"], n_required=q.get("n_required", 0)))
+        setters[mode](enq, slot, rev)
+        mset = enq.get_mset(q["first"], q["maxitems"])
+        assert [(i.docid, i.weight.hex(), i.percent) for i in mset] == [(d, w, pct) for d, w, pct in r["hits"]], q
+        assert [i.sort_key.hex() for i in mset] == r["sort_keys"], q
+        if r["hits"]:
+            assert mset.get_max_attained() == float.fromhex(r["max_attained"]), q
+        n_items += len(r["hits"])
+    assert n_items > (100 if QUICK else 400)
+    fx = json.load(open(os.path.join(gdir, "spy_counts.json")))
+    for r in (fx["results"][::4] if QUICK else fx["results"]):
+        q = r["query"]
+        enq = Enquire(db)
+        enq.set_query(Query(q["op"], q["terms"], n_required=q.get("n_required", 0)))
+        enq.set_sort_by_value(q["spy"], False)                 # the value leads: the spy sees every match whatever check_at_least is
+        spy = ValueCountMatchSpy(q["spy"])
+        enq.add_matchspy(spy)
+        enq.get_mset(q["first"], q["maxitems"])
+        assert spy.get_total() == r["spy_total"] and [[v.hex(), n] for v, n in spy.values()] == r["spy"], q
     db.close()
     c.close()
 

@@ -223,8 +223,21 @@ class Database:
         _lib.check(_lib.lib().xgm_index_save(self._h, _as_bytes(path)))
 
     def attach_column(self, column_path):
-        """xgm_index_attach_column: the ordinals of a value slot (a column file of xgm_glass_export_column) into HBM."""
+        """xgm_index_attach_column: the ordinals of a value slot (a column file of xgm_glass_export_column) into HBM.  The distinct
+        values stay on the host: MSet items get their sort / collapse keys from them."""
+        import struct
         _lib.check(_lib.lib().xgm_index_attach_column(self._h, _as_bytes(column_path)))
+        with open(column_path, "rb") as f:
+            slot = struct.unpack_from("<I", f.read(12), 8)[0]
+        if not hasattr(self, "_column_values"):
+            self._column_values = {}
+        self._column_values[slot] = read_column_values(column_path)
+
+    def column_values(self, slot):
+        vals = getattr(self, "_column_values", {}).get(slot)
+        if vals is None:
+            raise Unsupported("no column attached for value slot %d" % slot)
+        return vals
 
     def set_stream(self, hip_stream):
         _lib.check(_lib.lib().xgm_index_set_stream(self._h, C.c_void_p(hip_stream)))
@@ -241,10 +254,11 @@ class Database:
 
 
 class MSetItem:
-    __slots__ = ("docid", "weight", "rank", "percent", "subqs_matched")
+    __slots__ = ("docid", "weight", "rank", "percent", "subqs_matched", "sort_key", "collapse_key", "collapse_count")
 
     def __init__(self, docid, weight, rank, percent, subqs_matched):
         self.docid, self.weight, self.rank, self.percent, self.subqs_matched = docid, weight, rank, percent, subqs_matched
+        self.sort_key, self.collapse_key, self.collapse_count = b"", b"", 0        # MSetIterator::get_sort_key / get_collapse_key / get_collapse_count
 
     def __repr__(self):
         return "MSetItem(rank=%d, docid=%d, weight=%r, percent=%d)" % (self.rank, self.docid, self.weight, self.percent)
@@ -440,8 +454,31 @@ def search_batch(db, plans):
     return out
 
 
+class ValueCountMatchSpy:
+    """Mirror of Xapian::ValueCountMatchSpy (reference src/xapian/api/matchspy.cc:296-340): how many of the matching documents carry
+    each value of a slot."""
+
+    def __init__(self, slot):
+        self.slot = slot
+        self._total = 0
+        self._values = {}
+
+    def _add(self, total, counts):
+        self._total += total
+        for v, n in counts.items():
+            self._values[v] = self._values.get(v, 0) + n
+
+    def get_total(self):
+        return self._total
+
+    def values(self):
+        """(value, frequency) in value order: ValueCountMatchSpy::values_begin() .. values_end()."""
+        return sorted(self._values.items())
+
+
 class Enquire:
-    """Mirror of Xapian::Enquire for relevance-ordered BM25 searches on one shard."""
+    """Mirror of Xapian::Enquire for BM25 searches on one shard: by relevance, or — first version, DESIGN.md 8 (f).3 — under a value
+    sort, with a collapse key, with a ValueCountMatchSpy."""
 
     def __init__(self, db):
         self._db = db
@@ -459,11 +496,69 @@ class Enquire:
             raise Unsupported("only BM25Weight runs on the device path")
         self._weight = weight
 
+    # Enquire::set_sort_by_* / set_collapse_key / add_matchspy (reference src/xapian/api/enquire.cc): value slots whose columns are
+    # attached to the database (Database.attach_column)
+    def set_sort_by_relevance(self):
+        self._sort = None
+
+    def set_sort_by_value(self, sort_key, reverse):
+        self._sort = (_lib.XGM_SORT_VALUE, sort_key, bool(reverse))
+
+    def set_sort_by_value_then_relevance(self, sort_key, reverse):
+        self._sort = (_lib.XGM_SORT_VALUE_RELEVANCE, sort_key, bool(reverse))
+
+    def set_sort_by_relevance_then_value(self, sort_key, reverse):
+        self._sort = (_lib.XGM_SORT_RELEVANCE_VALUE, sort_key, bool(reverse))
+
+    def set_collapse_key(self, collapse_key, collapse_max=1):
+        self._collapse = (collapse_key, collapse_max) if collapse_max else None
+
+    def add_matchspy(self, spy):
+        if not isinstance(spy, ValueCountMatchSpy):
+            raise Unsupported("only ValueCountMatchSpy runs on the device path")
+        self._spies = getattr(self, "_spies", []) + [spy]
+
+    def clear_matchspies(self):
+        self._spies = []
+
+    def _get_mset_by_value(self, p, sort, collapse, spies):
+        db = self._db
+        if collapse:
+            if spies:
+                raise Unsupported("a collapse key together with a MatchSpy")
+            rows, hdr, _ = search_collapsed(db, p, collapse[0], collapse[1], *(sort if sort else (None, 0, False)))
+        elif spies:
+            if len(spies) > 1 or not sort or sort[0] == _lib.XGM_SORT_RELEVANCE_VALUE:
+                raise Unsupported("one MatchSpy, under a sort the value leads")
+            vals = db.column_values(spies[0].slot)
+            rows, hdr, counts = search_sorted_spy(db, p, sort[0], sort[1], sort[2], spies[0].slot, len(vals))
+            spies[0]._add(hdr.matches_exact, {vals[o - 1]: n for o, n in enumerate(counts) if o and n})
+            rows = [r + (0, 0) for r in rows]
+        else:
+            rows, hdr = search_sorted(db, p, *sort)
+            rows = [r + (0, 0) for r in rows]
+        hits = []
+        for d, w, m, _, _, _ in rows:
+            h = _lib.Hit()
+            h.docid, h.weight, h.subqs_matched = d, w, m
+            hits.append(h)
+        mset = MSet(p.first, hits, hdr, self._query.total_subqs())
+        svals = db.column_values(sort[1]) if sort else None
+        cvals = db.column_values(collapse[0]) if collapse else None
+        for item, (_, _, _, o, co, cc) in zip(mset._items, rows[p.first:]):
+            item.sort_key = svals[o - 1] if (svals and o) else b""
+            item.collapse_key = cvals[co - 1] if (cvals and co) else b""
+            item.collapse_count = cc
+        return mset
+
     def get_mset(self, first, maxitems, check_at_least=0):
         """Enquire::get_mset (reference src/xapian/api/enquire.cc:237, 396-470)."""
         if self._query is None or self._query.empty():
             return MSet(first, [], _lib.ResultHdr(), 0)
         p = plan(self._db, self._query, first, maxitems, check_at_least, self._weight)
+        sort, collapse, spies = getattr(self, "_sort", None), getattr(self, "_collapse", None), getattr(self, "_spies", [])
+        if sort or collapse or spies:
+            return self._get_mset_by_value(p, sort, collapse, spies)
         (hits, hdr), = search_batch(self._db, [p])
         return MSet(p.first, hits, hdr, p.total_subqs if self._query.op == "TREE" else self._query.total_subqs(), plan=p)
 
