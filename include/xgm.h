@@ -374,8 +374,8 @@ typedef struct {
  * (the caller drops the first `first`).  hit_ord[i] (may be NULL) receives the ordinal of hit i's value in the column — 0 = no
  * value, else 1 + index into the column file's distinct values: the MSet item's sort key.  hdr->max_attained is the best weight
  * of the WHOLE match, as the reference reports it under a value sort (ProtoMSet::update_max_weight sees every document,
- * protomset.h:174-183, 249-283), matches_exact the number of matching documents.  Plain operators only: XGM_UNSUPPORTED for
- * positional (PHRASE / NEAR with the filter active) and nested queries, and when the slot has no column attached.
+ * protomset.h:174-183, 249-283), matches_exact the number of matching documents.  Every query shape xgm_search takes;
+ * XGM_UNSUPPORTED when the slot has no column attached.
  * Replaces: the value-sorted branch of the matcher's main loop (matcher/matcher.cc:482-536) and
  * ValueStreamDocument::get_value per candidate (matcher/valuestreamdocument.cc). */
 int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,

@@ -95,6 +95,43 @@ def test_value_count_spy_vs_oracle(built, tmp_path):
     c.close()
 
 
+def test_positional_and_nested_queries_under_a_sort(built, tmp_path):
+    """The sorted kernel is the workgroup kernel's own text compiled a second time: PHRASE (exact) and nested trees rank under a
+    value sort like everything else.  PHRASE against the oracle's sorted search; a tree against its relevance ranking re-ranked
+    under the comparison on the host (the oracle's tree evaluator has no sorted form: its full result is small)."""
+    n_docs, vocab = (3000, 8000) if QUICK else (20000, 40000)
+    c = H.Corpus(n_docs, vocab)
+    db = Database(c.build_segment(str(tmp_path / "s.seg")))
+    values = {}
+    for slot in range(3):
+        p = write_column(c, slot, str(tmp_path / ("col%d" % slot)))
+        db.attach_column(p)
+        values[slot] = read_column_values(p)
+    rng = random.Random(21)
+    n_items = 0
+    for q in H.gen_phrase_queries(4 if QUICK else 16, n_docs, vocab, seed=81, lengths=(2,)):
+        mode, slot, rev = rng.choice(["V", "VR", "RV"]), rng.randrange(3), rng.random() < 0.5
+        want, whdr = H.oracle_search_sorted(c, "PHRASE", q["terms"], 0, 10, mode, slot, rev)
+        got, hdr = search_sorted(db, plan(db, Query("PHRASE", q["terms"]), 0, 10), MODES[mode], slot, rev)
+        assert [(d, w, m) for d, w, m, _ in got] == [(d, w, m) for d, w, m, _ in want], (q, mode, slot, rev)
+        assert hdr.matches_exact == whdr.matches, q
+        n_items += len(got)
+    assert n_items > 0
+    import numpy as np
+    paths = {slot: str(tmp_path / ("col%d" % slot)) for slot in range(3)}
+    for tq in H.gen_tree_queries(3 if QUICK else 12, 1, 200, seed=82):
+        tree = tq["tree"]
+        full, _, _ = H.oracle_search_tree(c, tree, 0, c.v.lastdocid)
+        slot, rev = rng.randrange(3), rng.random() < 0.5
+        ords = np.frombuffer(open(paths[slot], "rb").read(), dtype=np.uint32, count=c.v.lastdocid + 1, offset=24)
+        ranked = sorted(full, key=lambda r: (-int(ords[r[0]]) if rev else int(ords[r[0]]), r[0]))[:10]
+        got, hdr = search_sorted(db, plan(db, Query.tree(tree), 0, 10), MODES["V"], slot, rev)
+        assert [(d, w) for d, w, _, _ in got] == [(d, w) for d, w, _ in ranked], (tq, slot, rev)
+        assert hdr.matches_exact == len(full), tq
+    db.close()
+    c.close()
+
+
 def test_collapse_vs_oracle(built, tmp_path):
     """Enquire::set_collapse_key by relevance and under the value sorts, collapse_max 1..3, against the oracle's restatement of the
     INTENDED semantics (the best documents of a key stay; the reference snapshot's collapser is a quirk): docids,
@@ -182,7 +219,5 @@ def test_sorted_search_declines_what_it_does_not_do(built, tmp_path):
         search_sorted(db, p, _lib.XGM_SORT_VALUE, 0)
     db.attach_column(write_column(c, 0, str(tmp_path / "col0")))
     search_sorted(db, p, _lib.XGM_SORT_VALUE, 0)
-    with pytest.raises(_lib.XgmUnsupported):                       # positional queries: not under a value sort yet
-        search_sorted(db, plan(db, Query("PHRASE", ["t3", "t9"]), 0, 10), _lib.XGM_SORT_VALUE, 0)
     db.close()
     c.close()

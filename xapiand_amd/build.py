@@ -45,7 +45,7 @@ def _up_to_date(target, digest):
 
 def build(force=False, verbose=False):
     """Compile every HIP/C++ source for gfx950 and link libxgm.so.  Returns the library path."""
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h") or f.endswith(".inc")]
     headers += [os.path.join(HERE, "..", "include", "xgm.h"), os.path.join(HERE, "..", "tools", "xgm_corpus.h")]
     objs, digests = [], []
     hipcc = None

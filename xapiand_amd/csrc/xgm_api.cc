@@ -969,8 +969,9 @@ static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, ui
 }
 
 /* ---- searches under a value sort (first version) -------------------------------------------------------------
- * One query at a time, synchronous, its own device buffers: correctness first.  The unit decomposition is the workgroup
- * kernel's (plan_batch with the wave kernels switched off); the units' candidates come back to the host, which merges them
+ * One query at a time, synchronous, its own device buffers: correctness first.  Every query shape the workgroup kernel handles
+ * (plain operators, PHRASE / NEAR, nested trees).  The unit decomposition is that kernel's (plan_batch with the wave kernels
+ * switched off); the units' candidates come back to the host, which merges them
  * under the same comparison the kernel ranks by. */
 
 extern "C" int xgm_index_attach_column(xgm_index* idx, const char* column_path) {
@@ -1026,7 +1027,6 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     if (sort && (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE)) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
     if (!sort && collapse_slot < 0) return xgm_set_error(XGM_E_INVALID, "neither a sort nor a collapse key");
     if (collapse_slot >= 0 && (cmax == 0 || spy_slot >= 0)) return xgm_set_error(XGM_E_INVALID, "collapse_max 0, or a spy together with a collapse key");
-    if (q->tree_len || q->phrase_active) return XGM_UNSUPPORTED;               /* plain operators only, so far */
     const uint32_t mode = sort ? sort->sort_by : 4u;
     const bool reverse = sort && sort->reverse;
     const uint32_t* d_ord = nullptr;
@@ -1062,8 +1062,8 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     double mp = 0;
     BatchPlan bp;
     if ((rc = plan_batch(idx, q, 1, &dq, &kq, &mp, &bp, true))) return rc;
-    if ((dq.flags & (XGM_QF_PHRASE | XGM_QF_TREE)) || bp.andw || bp.orw || bp.and_only || dq.k == 0 || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
-    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    if (bp.andw || bp.orw || bp.and_only || dq.k == 0 || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
     const uint32_t k = dq.k, n_work = bp.n_work;
     DeviceBuffers dev;
     xgm_dev_query* d_q; xgm_work* d_work; xgm_cand_sorted* d_cand; xgm_group_hdr* d_ghdr;
@@ -1082,7 +1082,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     L.queries = d_q;
     L.nq = 1; L.n_work = n_work; L.work = d_work; L.stripes_per_group = bp.stripes_per_group;
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
-    L.phrase = false; L.wide = bp.wide; L.sided = 0;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = d_ghdr;
     if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, d_cord, cmax, d_cand, nullptr))) return rc;
     std::vector<xgm_cand_sorted> cand((size_t)n_work * k);

@@ -336,359 +336,9 @@ struct __attribute__((packed, aligned(2))) Pos8 { uint32_t a, b, c, d; };       
 
 /* ---------------------------------------------------------------- the match kernel ----------- */
 
-template <typename TabT, bool PHRASE>
-__global__ __launch_bounds__(XGM_WG) void xgm_match_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
-                                                            const xgm_work* __restrict__ work, uint32_t stripes_per_group,
-                                                            uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                            xgm_cand* __restrict__ cand_out,
-                                                            xgm_group_hdr* __restrict__ ghdr_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
-    const xgm_work wk = work[blockIdx.x];
-    const uint32_t qi = wk.qi;
-    const xgm_dev_query& q = queries[qi];
-    const uint32_t SB = seg.stripe_bits;
-    const uint32_t W = 1u << SB;
-    const uint32_t T = q.n_terms;
-    const bool is_tree = (q.flags & XGM_QF_TREE) != 0;               /* nested query: candidates = any term, then the node program decides */
-    const bool is_or = (q.op == XGM_OP_OR) || is_tree;
-    const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;      /* non-OR: who must / must not be present */
-    const bool phrase = PHRASE && (q.flags & XGM_QF_PHRASE);
-    const uint32_t k = q.k;
-    const uint32_t SPG = stripes_per_group;
-
-    KernelSmem sm = carve<TabT>(smem, W, tab_terms, PHRASE, cap, SPG);
-    Ctrl& ctl = *sm.ctrl;
-    TabT* tab = reinterpret_cast<TabT*>(sm.tab);
-    uint32_t* my_stage = sm.stage + wave * kStageWords;
-
-    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
-    const uint32_t s_begin = wk.s_begin;
-    const uint32_t s_end = wk.s_end;
-
-    /* ---- init: top-k buffer, the group's block ranges ---- */
-    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
-    for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
-    if (tid == 0) { ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0; }
-    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
-    if (!empty) {
-        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
-            uint32_t id = q.term_id[t];
-            uint32_t c = 0, e = 0;
-            if (id != 0xFFFFFFFFu) {
-                uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
-                c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
-                e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
-            }
-            if (lane == 0) { ctl.cur[t] = c; ctl.end[t] = e; }
-        }
-    }
-    __syncthreads();
-
-    /* ---- run table: for every (term, stripe of this group) the block range [start, end) ----
-     * One coalesced pass over the group's slice of blk_first per term; afterwards stripe selection
-     * (AND: every term present, OR: any) reads LDS only. */
-    uint32_t* rstart = sm.runs;
-    uint32_t* rend = sm.runs + (size_t)tab_terms * SPG;
-    if (!empty) {
-        for (uint32_t t = 0; t < T; ++t) {
-            const uint32_t c = ctl.cur[t], e = ctl.end[t];
-            for (uint32_t i = c + tid; i < e; i += XGM_WG) {
-                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
-                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
-                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
-                if (s != sp) rstart[t * SPG + s] = i;
-                if (s != sn) rend[t * SPG + s] = i + 1u;
-            }
-        }
-    }
-    __syncthreads();
-
-    unsigned long long my_matches = 0;
-    const uint32_t n_local = empty ? 0u : s_end - s_begin;
-    for (uint32_t sl = 0; sl < n_local; ++sl) {
-        /* ---- stripe selection from the run table (uniform, no barrier) ---- */
-        uint32_t total = 0;
-        bool all = true;
-        for (uint32_t t = 0; t < T; ++t) {
-            uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
-            total += cnt;
-            all = all && (cnt != 0 || !((req_mask >> t) & 1u));
-        }
-        if (is_or ? total == 0 : !all) continue;
-        const uint32_t s = s_begin + sl;
-
-        /* ---- zero the tables ---- */
-        {
-            uint4* z = reinterpret_cast<uint4*>(sm.tab);
-            const uint32_t n16 = (uint32_t)((size_t)T * W * sizeof(TabT) / 16);
-            for (uint32_t i = tid; i < n16; i += XGM_WG) z[i] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-
-        /* ---- K1: decode every block of stripe s into the tables ----
-         * Items (blocks) are dealt round-robin to the 4 waves.  A wave first loads the headers of up
-         * to 64 of its blocks with ONE load per field (lane j = j-th block), then walks them with the
-         * payload of the next block already in flight (register double buffer → LDS window). */
-        {
-            const uint32_t wave_items = total > wave ? (total - wave + XGM_WAVES - 1u) / XGM_WAVES : 0u;
-            for (uint32_t base = 0; base < wave_items; base += 64u) {
-                const uint32_t nthis = wave_items - base < 64u ? wave_items - base : 64u;
-                uint32_t h_meta = 0, h_first = 0, h_t = 0, h_pos = 0;
-                uint64_t h_addr = 0;
-                if (lane < nthis) {
-                    uint32_t item = wave + XGM_WAVES * (base + lane);
-                    uint32_t t = 0;
-                    while (true) {
-                        uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
-                        if (item < cnt) break;
-                        item -= cnt; ++t;
-                    }
-                    const uint32_t b = rstart[t * SPG + sl] + item;
-                    h_t = t;
-                    h_meta = seg.blk_meta[b];
-                    h_first = seg.blk_first[b];
-                    h_addr = seg.term_word[q.term_id[t]] + seg.blk_word[b];
-                    if (PHRASE) h_pos = seg.blk_pos[b];
-                }
-                /* prefetch block 0 */
-                Words4 pre = {0, 0, 0, 0};
-                {
-                    const uint32_t m0 = __builtin_amdgcn_readlane(h_meta, 0);
-                    const uint64_t a0 = rl64(h_addr, 0u);
-                    if (lane * 4u < payload_words(m0)) pre = *reinterpret_cast<const Words4*>(seg.words + a0 + lane * 4u);
-                }
-                for (uint32_t x = 0; x < nthis; ++x) {
-                    const uint32_t xs = __builtin_amdgcn_readfirstlane(x);
-                    const uint32_t meta = __builtin_amdgcn_readlane(h_meta, xs);
-                    const uint32_t first = __builtin_amdgcn_readlane(h_first, xs);
-                    const uint32_t t = __builtin_amdgcn_readlane(h_t, xs);
-                    const Words4 cur = pre;
-                    if (x + 1u < nthis) {
-                        const uint32_t m1 = __builtin_amdgcn_readlane(h_meta, xs + 1u);
-                        const uint64_t a1 = rl64(h_addr, xs + 1u);
-                        if (lane * 4u < payload_words(m1)) pre = *reinterpret_cast<const Words4*>(seg.words + a1 + lane * 4u);
-                    }
-                    if (lane * 4u < payload_words(meta)) {
-                        my_stage[lane * 4u] = cur.a; my_stage[lane * 4u + 1] = cur.b; my_stage[lane * 4u + 2] = cur.c; my_stage[lane * 4u + 3] = cur.d;
-                    }
-                    wave_lds_fence();
-                    DecodedPair r = unpack_staged<PHRASE>(my_stage, first, meta, lane);
-                    wave_lds_fence();
-                    TabT* row = tab + (size_t)t * W;
-                    if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
-                    if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
-                    if (PHRASE) {
-                        uint32_t* prow = sm.ptab + (size_t)t * W;
-                        const uint32_t pb = __builtin_amdgcn_readlane(h_pos, xs);
-                        if (r.v0) prow[r.d0 & (W - 1u)] = pb + r.p0;
-                        if (r.v1) prow[r.d1 & (W - 1u)] = pb + r.p1;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        /* ---- K2/K3: find matching slots, compact into the queue ---- */
-        {
-            constexpr uint32_t PER = 16u / sizeof(TabT);        /* slots per 16-byte read */
-            for (uint32_t base0 = 0; base0 < W; base0 += XGM_WG * PER) {     /* uniform trip count */
-                const uint32_t base = base0 + tid * PER;
-                uint32_t bits = 0;
-                if (base < W) {
-                    uint32_t m[4];
-                    m[0] = m[1] = m[2] = m[3] = is_or ? 0u : 0xFFFFFFFFu;
-                    for (uint32_t t = 0; t < T; ++t) {
-                        const bool req = (req_mask >> t) & 1u, neg = (neg_mask >> t) & 1u;
-                        if (!is_or && !req && !neg) continue;               /* optional term: no say in matching */
-                        uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)t * W + base);
-                        uint32_t x[4] = {v.x, v.y, v.z, v.w};
-                        for (int c = 0; c < 4; ++c) {
-                            uint32_t nz = sizeof(TabT) == 1 ? nz_bytes(x[c]) : nz_halves(x[c]);
-                            m[c] = is_or ? (m[c] | nz) : neg ? (m[c] & ~nz) : (m[c] & nz);
-                        }
-                    }
-                    /* one flag bit per slot */
-                    if (sizeof(TabT) == 1) {
-                        for (int c = 0; c < 4; ++c) {
-                            uint32_t f = m[c] >> 7;                      /* bits 0,8,16,24 */
-                            f = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
-                            bits |= f << (4 * c);
-                        }
-                    } else {
-                        for (int c = 0; c < 4; ++c) {
-                            uint32_t f = m[c] >> 15;                     /* bits 0,16 */
-                            f = (f | (f >> 15)) & 0x3u;
-                            bits |= f << (2 * c);
-                        }
-                    }
-                }
-                if (is_tree && bits) {
-                    /* which of the slots that hold any term satisfy the tree: presence of every group, then of every node */
-                    uint32_t keep = 0;
-                    const uint32_t G = q.n_groups;
-                    for (uint32_t bb = bits; bb; bb &= bb - 1u) {
-                        const uint32_t bit = (uint32_t)__ffs(bb) - 1u, slot = base + bit;
-                        uint64_t pm = 0;
-                        for (uint32_t t = 0; t < T; ++t) if (tab[(size_t)t * W + slot]) pm |= 1ull << q.group_of[t];
-                        for (uint32_t j = 0; j < q.tree_len; ++j) {
-                            const uint64_t a = (pm >> q.tnode_a[j]) & 1ull, b = (pm >> q.tnode_b[j]) & 1ull;
-                            const uint32_t op = q.tnode_op[j];
-                            const uint64_t r = op == XGM_N_AND ? (a & b) : op == XGM_N_OR ? (a | b) : op == XGM_N_ANDNOT ? (a & (b ^ 1ull)) : a;
-                            pm |= r << (G + j);
-                        }
-                        if ((pm >> q.tree_root) & 1ull) keep |= 1u << bit;
-                    }
-                    bits = keep;
-                }
-                uint32_t cnt = (uint32_t)__popc(bits);
-                uint32_t incl = wave_incl_scan(cnt);
-                uint32_t wtotal = __builtin_amdgcn_readlane(incl, 63);
-                if (wtotal) {
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&ctl.qn, wtotal);
-                    wbase = __builtin_amdgcn_readfirstlane(wbase);
-                    uint32_t o = wbase + incl - cnt;
-                    while (bits) {
-                        uint32_t bit = (uint32_t)__ffs(bits) - 1u;
-                        bits &= bits - 1u;
-                        sm.queue[o++] = (uint16_t)(base + bit);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-
-        /* ---- K6 + K4 + K5: filter, score and collect the survivors ---- */
-        const uint32_t qn = ctl.qn;
-        const uint32_t stripe_base = s << SB;
-        for (uint32_t i0 = 0; i0 < qn; i0 += XGM_WG) {
-            /* make room: at most XGM_WG candidates are appended per round.  Everyone must see the
-             * same fill, so read it, then barrier before anyone appends. */
-            const uint32_t fill_now = ctl.tkn;
-            __syncthreads();
-            if (fill_now + XGM_WG > cap) {
-                topk_sort(sm.tk, tid);
-                if (tid == 0) {
-                    uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
-                    ctl.tkn = keep;
-                    if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
-                }
-                __syncthreads();
-                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
-                __syncthreads();
-            }
-            const uint32_t i = i0 + tid;
-            if (i < qn) {
-                const uint32_t slot = sm.queue[i];
-                const uint32_t did = stripe_base + slot;
-                bool pass = true;
-                if (phrase) {
-                    PosList pl[XGM_PHRASE_MAX_TERMS];
-                    for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
-                        const uint32_t w16 = seg.term_flags[q.term_id[t]] & XGM_TF_POS16;
-                        pl[t].p = seg.positions + seg.term_pos[q.term_id[t]] + (size_t)sm.ptab[(size_t)t * W + slot] * (w16 ? 2u : 4u);
-                        pl[t].n = (uint32_t)tab[(size_t)t * W + slot] - 1u;
-                        pl[t].w16 = w16;
-                    }
-                    pass = posfilter_slow(pl, q, T);
-                }
-                if (pass) {
-                    ++my_matches;
-                    /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
-                    const double len = (double)seg.doclen[did];
-                    double normlen = len * q.len_factor;
-                    normlen = normlen > q.min_normlen ? normlen : q.min_normlen;   /* std::max(a, b) */
-                    const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
-                    double val[XGM_MAX_TERMS + XGM_MAX_TREE];
-                    uint32_t subqs = 0;
-                    double weight;
-                    if (is_tree) {
-                        /* groups: one BM25 weight over the summed wdf of the members that index the document (a term, or an
-                         * OP_SYNONYM: SynonymPostList::get_weight, synonympostlist.cc:62-95); nodes: (matches, weight, weighted
-                         * leaves) by the rules of include/xgm.h — an absent value weighs -0.0, the identity of IEEE addition */
-                        const uint32_t G = q.n_groups;
-                        uint32_t gsum[XGM_MAX_TERMS];
-                        uint8_t cnt[XGM_MAX_TERMS + XGM_MAX_TREE];
-                        uint64_t pm = 0;
-                        for (uint32_t g = 0; g < G; ++g) gsum[g] = 0;
-                        for (uint32_t t = 0; t < T; ++t) {
-                            const uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
-                            if (e) { pm |= 1ull << q.group_of[t]; gsum[q.group_of[t]] += e - 1u; }
-                        }
-                        for (uint32_t g = 0; g < G; ++g) {
-                            const bool here = (pm >> g) & 1ull;
-                            const double wdf = (double)gsum[g];
-                            val[g] = here ? q.termweight[g] * (wdf / (denom_len + wdf)) : -0.0;
-                            cnt[g] = (uint8_t)(here ? (q.group_scored >> g) & 1u : 0u);
-                        }
-                        for (uint32_t j = 0; j < q.tree_len; ++j) {
-                            const uint32_t a = q.tnode_a[j], b = q.tnode_b[j], op = q.tnode_op[j];
-                            const bool pa = (pm >> a) & 1ull, pb = (pm >> b) & 1ull;
-                            bool pr; double w; uint32_t c;
-                            if (op == XGM_N_AND) { pr = pa && pb; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }
-                            else if (op == XGM_N_OR) { pr = pa || pb; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }
-                            else if (op == XGM_N_ANDNOT) { pr = pa && !pb; w = val[a]; c = cnt[a]; }
-                            else { pr = pa; w = val[a] + val[b]; c = (uint32_t)cnt[a] + cnt[b]; }      /* MAYBE: val[b] is -0.0 where r is absent */
-                            val[G + j] = pr ? w : -0.0;
-                            cnt[G + j] = (uint8_t)(pr ? c : 0u);
-                            if (pr) pm |= 1ull << (G + j);
-                        }
-                        weight = val[q.tree_root];
-                        subqs = cnt[q.tree_root];
-                    } else {
-                    for (uint32_t t = 0; t < T; ++t) {
-                        uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
-                        double wt = -0.0;                       /* absent leaf: x + (-0.0) == x */
-                        if (e) {
-                            double wdf = (double)(e - 1u);
-                            double denom = denom_len + wdf;
-                            wt = q.termweight[t] * (wdf / denom);
-                            subqs += (q.score_mask >> t) & 1u;      /* weighted leaves only (leafpostlist.cc:88-91) */
-                        }
-                        val[t] = wt;
-                    }
-                    for (uint32_t j = 0; j < q.n_nodes; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
-                    weight = val[q.sum_root];
-                    }
-                    uint64_t wb = (uint64_t)__double_as_longlong(weight);
-                    bool take = !ctl.theta_valid || cand_before(wb, did, ctl.theta_w, ctl.theta_d);
-                    if (take) {
-                        uint32_t o = atomicAdd(&ctl.tkn, 1u);
-                        sm.tk.w[o] = wb; sm.tk.d[o] = did; sm.tk.m[o] = subqs;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-
-        if (tid == 0) ctl.qn = 0;
-        __syncthreads();
-    }
-
-    /* ---- group epilogue: sort, publish the best k candidates and the match count ---- */
-    __syncthreads();
-    topk_sort(sm.tk, tid);
-    if (my_matches) atomicAdd(&ctl.matches, my_matches);
-    __syncthreads();
-    const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
-    xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
-    for (uint32_t i = tid; i < n_out; i += XGM_WG) {
-        xgm_cand c;
-        c.wbits = sm.tk.w[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i];
-        out[i] = c;
-    }
-    if (tid == 0) {
-        xgm_group_hdr h = {};
-        h.matches = ctl.matches; h.n_cand = n_out; h.pad = 0;
-        h.t_start = 0; h.t_end = 0;
-        ghdr_out[wk.slot] = h;
-    }
-}
-
+#define XGM_BODY_SORTED 0
+#include "xgm_match_body.inc"
+#undef XGM_BODY_SORTED
 
 /* ---------------------------------------------------------------- the AND kernel ------------- */
 
@@ -2703,7 +2353,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_decode_kernel(xgm_seg_dev seg, uin
  * cord != NULL: Enquire::set_collapse_key(slot, cmax) by the ordinals of that slot's column (collapse_prune above).
  * spy_counts != NULL: also a Xapian::ValueCountMatchSpy (api/matchspy.cc:307-313) — one count per ordinal of the column spy_ord,
  * incremented for every matching document (a value-led sort shows the spies every match, protomset.h:268-275).
- * Plain operators only (AND / OR / AND_NOT / AND_MAYBE / FILTER); positional and nested queries are declined by the host. */
+ * The kernel is xgm_match_kernel's own text compiled a second time (xgm_match_body.inc): every query shape that kernel handles. */
 __device__ __forceinline__ bool sorted_before(uint64_t aw, uint64_t ax, uint32_t ad, uint64_t bw, uint64_t bx, uint32_t bd, bool use_x) {
     if (aw != bw) return aw > bw;
     if (use_x && ax != bx) return ax > bx;
@@ -2763,297 +2413,9 @@ __device__ void collapse_prune(const TopK& tk, uint64_t* x, uint32_t* c, uint32_
     __syncthreads();
 }
 
-template <typename TabT>
-__global__ __launch_bounds__(XGM_WG) void xgm_match_sorted_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
-                                                                   const xgm_work* __restrict__ work, uint32_t stripes_per_group,
-                                                                   uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                                   const uint32_t* __restrict__ ord, uint32_t mode, uint32_t reverse,
-                                                                   const uint32_t* __restrict__ spy_ord, uint32_t* __restrict__ spy_counts,
-                                                                   const uint32_t* __restrict__ cord, uint32_t cmax,
-                                                                   xgm_cand_sorted* __restrict__ cand_out,
-                                                                   xgm_group_hdr* __restrict__ ghdr_out) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u;
-    const uint32_t wave = tid >> 6;
-    const xgm_work wk = work[blockIdx.x];
-    const xgm_dev_query& q = queries[wk.qi];
-    const uint32_t SB = seg.stripe_bits;
-    const uint32_t W = 1u << SB;
-    const uint32_t T = q.n_terms;
-    const bool is_or = q.op == XGM_OP_OR;
-    const uint32_t req_mask = q.req_mask, neg_mask = q.neg_mask;
-    const uint32_t k = q.k;
-    const uint32_t SPG = stripes_per_group;
-    const bool use_x = mode == 2u || mode == 3u;          /* (1: value alone; 4: relevance alone) */
-
-    KernelSmem sm = carve<TabT>(smem, W, tab_terms, false, cap, SPG);
-    Ctrl& ctl = *sm.ctrl;
-    TabT* tab = reinterpret_cast<TabT*>(sm.tab);
-    uint32_t* my_stage = sm.stage + wave * kStageWords;
-    /* behind the ordinary layout: the second key of the top-k buffer, then the control words */
-    const size_t base_bytes = ((size_t)(reinterpret_cast<unsigned char*>(sm.runs + (size_t)2 * tab_terms * SPG) - smem) + 15) & ~(size_t)15;
-    uint64_t* tkx = reinterpret_cast<uint64_t*>(smem + base_bytes);
-    SortedExt& ext = *reinterpret_cast<SortedExt*>(smem + base_bytes + (size_t)cap * 8);
-    uint32_t* tkc = reinterpret_cast<uint32_t*>(smem + base_bytes + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15));   /* collapse ordinals */
-    /* sort; with a collapse key: evict what its own key's better documents push out, sort the gaps away; → survivors in front */
-    auto sort_and_collapse = [&]() {
-        topk_sort_sorted(sm.tk, tkx, tkc, tid, use_x);
-        if (!cord) return;
-        const uint32_t n = ctl.tkn < cap ? ctl.tkn : cap;
-        collapse_prune(sm.tk, tkx, tkc, n, cmax, tid);
-        topk_sort_sorted(sm.tk, tkx, tkc, tid, use_x);
-        if (tid == 0) ext.survivors = 0;
-        __syncthreads();
-        uint32_t mine = 0;
-        for (uint32_t i = tid; i < n; i += XGM_WG) mine += sm.tk.d[i] != 0xFFFFFFFFu ? 1u : 0u;
-        if (mine) atomicAdd(&ext.survivors, mine);
-        __syncthreads();
-        if (tid == 0) ctl.tkn = ext.survivors;
-        __syncthreads();
-    };
-
-    const uint32_t n_stripes = (seg.lastdocid >> SB) + 1u;
-    const uint32_t s_begin = wk.s_begin;
-    const uint32_t s_end = wk.s_end;
-
-    for (uint32_t i = tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; tkc[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
-    for (uint32_t i = tid; i < 2u * tab_terms * SPG; i += XGM_WG) sm.runs[i] = 0;
-    if (tid == 0) {
-        ctl.qn = 0; ctl.tkn = 0; ctl.theta_valid = 0; ctl.theta_w = 0; ctl.theta_d = 0; ctl.matches = 0;
-        ext.theta_x = 0; ext.max_w = 0; ext.max_d = 0xFFFFFFFFu; ext.max_m = 0; ext.survivors = 0;
-    }
-    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
-    if (!empty) {
-        for (uint32_t t = wave; t < T; t += XGM_WAVES) {
-            const uint32_t id = q.term_id[t];
-            uint32_t c = 0, e = 0;
-            if (id != 0xFFFFFFFFu) {
-                const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
-                c = wave_lower_bound(seg.blk_first, b0, b1, s_begin << SB, lane);
-                e = (s_end >= n_stripes) ? b1 : wave_lower_bound(seg.blk_first, c, b1, s_end << SB, lane);
-            }
-            if (lane == 0) { ctl.cur[t] = c; ctl.end[t] = e; }
-        }
-    }
-    __syncthreads();
-
-    /* run table: the block range of every (term, stripe of this unit) */
-    uint32_t* rstart = sm.runs;
-    uint32_t* rend = sm.runs + (size_t)tab_terms * SPG;
-    if (!empty) {
-        for (uint32_t t = 0; t < T; ++t) {
-            const uint32_t c = ctl.cur[t], e = ctl.end[t];
-            for (uint32_t i = c + tid; i < e; i += XGM_WG) {
-                const uint32_t s = (seg.blk_first[i] >> SB) - s_begin;
-                const uint32_t sp = i > c ? (seg.blk_first[i - 1] >> SB) - s_begin : 0xFFFFFFFFu;
-                const uint32_t sn = i + 1 < e ? (seg.blk_first[i + 1] >> SB) - s_begin : 0xFFFFFFFFu;
-                if (s != sp) rstart[t * SPG + s] = i;
-                if (s != sn) rend[t * SPG + s] = i + 1u;
-            }
-        }
-    }
-    __syncthreads();
-
-    unsigned long long my_matches = 0;
-    uint64_t my_max_w = 0;                         /* best weight among the documents this thread weighed, the first docid with it */
-    uint32_t my_max_d = 0xFFFFFFFFu, my_max_m = 0;
-    const uint32_t n_local = empty ? 0u : s_end - s_begin;
-    for (uint32_t sl = 0; sl < n_local; ++sl) {
-        uint32_t total = 0;
-        bool all = true;
-        for (uint32_t t = 0; t < T; ++t) {
-            const uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
-            total += cnt;
-            all = all && (cnt != 0 || !((req_mask >> t) & 1u));
-        }
-        if (is_or ? total == 0 : !all) continue;
-        const uint32_t s = s_begin + sl;
-
-        {
-            uint4* z = reinterpret_cast<uint4*>(sm.tab);
-            const uint32_t n16 = (uint32_t)((size_t)T * W * sizeof(TabT) / 16);
-            for (uint32_t i = tid; i < n16; i += XGM_WG) z[i] = make_uint4(0, 0, 0, 0);
-        }
-        __syncthreads();
-
-        /* K1: every block of the stripe into the per-term tables (wdf + 1 by slot), blocks dealt round-robin to the waves */
-        {
-            const uint32_t wave_items = total > wave ? (total - wave + XGM_WAVES - 1u) / XGM_WAVES : 0u;
-            for (uint32_t base = 0; base < wave_items; base += 64u) {
-                const uint32_t nthis = wave_items - base < 64u ? wave_items - base : 64u;
-                uint32_t h_meta = 0, h_first = 0, h_t = 0;
-                uint64_t h_addr = 0;
-                if (lane < nthis) {
-                    uint32_t item = wave + XGM_WAVES * (base + lane);
-                    uint32_t t = 0;
-                    while (true) {
-                        const uint32_t cnt = rend[t * SPG + sl] - rstart[t * SPG + sl];
-                        if (item < cnt) break;
-                        item -= cnt; ++t;
-                    }
-                    const uint32_t b = rstart[t * SPG + sl] + item;
-                    h_t = t;
-                    h_meta = seg.blk_meta[b];
-                    h_first = seg.blk_first[b];
-                    h_addr = seg.term_word[q.term_id[t]] + seg.blk_word[b];
-                }
-                for (uint32_t x = 0; x < nthis; ++x) {
-                    const uint32_t xs = rfl32(x);
-                    const uint32_t meta = rl32(h_meta, xs);
-                    const uint32_t first = rl32(h_first, xs);
-                    const uint32_t t = rl32(h_t, xs);
-                    const uint64_t a = rl64(h_addr, xs);
-                    if (lane * 4u < payload_words(meta)) {
-                        const Words4 cur = *reinterpret_cast<const Words4*>(seg.words + a + lane * 4u);
-                        my_stage[lane * 4u] = cur.a; my_stage[lane * 4u + 1] = cur.b; my_stage[lane * 4u + 2] = cur.c; my_stage[lane * 4u + 3] = cur.d;
-                    }
-                    wave_lds_fence();
-                    const DecodedPair r = unpack_staged<false>(my_stage, first, meta, lane);
-                    wave_lds_fence();
-                    TabT* row = tab + (size_t)t * W;
-                    if (r.v0) row[r.d0 & (W - 1u)] = (TabT)(r.w0 + 1u);
-                    if (r.v1) row[r.d1 & (W - 1u)] = (TabT)(r.w1 + 1u);
-                }
-            }
-        }
-        __syncthreads();
-
-        /* K2 / K3: the slots that match, compacted into the queue */
-        {
-            constexpr uint32_t PER = 16u / sizeof(TabT);
-            for (uint32_t base0 = 0; base0 < W; base0 += XGM_WG * PER) {
-                const uint32_t base = base0 + tid * PER;
-                uint32_t bits = 0;
-                if (base < W) {
-                    uint32_t m[4];
-                    m[0] = m[1] = m[2] = m[3] = is_or ? 0u : 0xFFFFFFFFu;
-                    for (uint32_t t = 0; t < T; ++t) {
-                        const bool req = (req_mask >> t) & 1u, neg = (neg_mask >> t) & 1u;
-                        if (!is_or && !req && !neg) continue;
-                        const uint4 v = *reinterpret_cast<const uint4*>(tab + (size_t)t * W + base);
-                        const uint32_t xw[4] = {v.x, v.y, v.z, v.w};
-                        for (int c = 0; c < 4; ++c) {
-                            const uint32_t nz = sizeof(TabT) == 1 ? nz_bytes(xw[c]) : nz_halves(xw[c]);
-                            m[c] = is_or ? (m[c] | nz) : neg ? (m[c] & ~nz) : (m[c] & nz);
-                        }
-                    }
-                    if (sizeof(TabT) == 1) {
-                        for (int c = 0; c < 4; ++c) {
-                            uint32_t f = m[c] >> 7;
-                            f = (f | (f >> 7) | (f >> 14) | (f >> 21)) & 0xFu;
-                            bits |= f << (4 * c);
-                        }
-                    } else {
-                        for (int c = 0; c < 4; ++c) {
-                            uint32_t f = m[c] >> 15;
-                            f = (f | (f >> 15)) & 0x3u;
-                            bits |= f << (2 * c);
-                        }
-                    }
-                }
-                const uint32_t cnt = (uint32_t)__popc(bits);
-                const uint32_t incl = wave_incl_scan(cnt);
-                const uint32_t wtotal = rl32(incl, 63u);
-                if (wtotal) {
-                    uint32_t wbase = 0;
-                    if (lane == 0) wbase = atomicAdd(&ctl.qn, wtotal);
-                    wbase = rfl32(wbase);
-                    uint32_t o = wbase + incl - cnt;
-                    while (bits) {
-                        const uint32_t bit = (uint32_t)__ffs(bits) - 1u;
-                        bits &= bits - 1u;
-                        sm.queue[o++] = (uint16_t)(base + bit);
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        /* K4 / K5: weigh every match, keep the best under the chosen order */
-        const uint32_t qn = ctl.qn;
-        const uint32_t stripe_base = s << SB;
-        for (uint32_t i0 = 0; i0 < qn; i0 += XGM_WG) {
-            const uint32_t fill_now = ctl.tkn;
-            __syncthreads();
-            if (fill_now + XGM_WG > cap) {
-                sort_and_collapse();
-                if (tid == 0) {
-                    const uint32_t keep = ctl.tkn < k ? ctl.tkn : k;
-                    ctl.tkn = keep;
-                    if (keep == k) { ctl.theta_valid = 1; ctl.theta_w = sm.tk.w[k - 1]; ext.theta_x = tkx[k - 1]; ctl.theta_d = sm.tk.d[k - 1]; }
-                }
-                __syncthreads();
-                for (uint32_t i = ctl.tkn + tid; i < cap; i += XGM_WG) { sm.tk.w[i] = 0; tkx[i] = 0; tkc[i] = 0; sm.tk.d[i] = 0xFFFFFFFFu; sm.tk.m[i] = 0xFFFFFFFFu; }
-                __syncthreads();
-            }
-            const uint32_t i = i0 + tid;
-            if (i < qn) {
-                const uint32_t slot = sm.queue[i];
-                const uint32_t did = stripe_base + slot;
-                ++my_matches;
-                /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order (as xgm_match_kernel) */
-                const double len = (double)seg.doclen[did];
-                double normlen = len * q.len_factor;
-                normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
-                const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
-                double val[2 * XGM_MAX_TERMS];
-                uint32_t subqs = 0;
-                for (uint32_t t = 0; t < T; ++t) {
-                    const uint32_t e = (uint32_t)tab[(size_t)t * W + slot];
-                    double wt = -0.0;
-                    if (e) {
-                        const double wdf = (double)(e - 1u);
-                        wt = q.termweight[t] * (wdf / (denom_len + wdf));
-                        subqs += (q.score_mask >> t) & 1u;
-                    }
-                    val[t] = wt;
-                }
-                for (uint32_t j = 0; j < q.n_nodes; ++j) val[T + j] = val[q.node_a[j]] + val[q.node_b[j]];
-                const double weight = val[q.sum_root];
-                const uint64_t wb = (uint64_t)__double_as_longlong(weight);
-                if (wb > my_max_w || (wb == my_max_w && did < my_max_d)) { my_max_w = wb; my_max_d = did; my_max_m = subqs; }
-                if (spy_counts) atomicAdd(&spy_counts[spy_ord[did]], 1u);       /* Xapian::ValueCountMatchSpy: every matching document, by its value */
-                const uint32_t o32 = ord ? ord[did] : 0u;                       /* (mode 4, relevance alone: no column) */
-                const uint64_t okey = ord ? (uint64_t)(reverse ? o32 : ~o32) : 0ull;
-                const uint64_t kw = mode >= 3u ? wb : okey, kx = mode >= 3u ? okey : wb;
-                const bool take = !ctl.theta_valid || sorted_before(kw, kx, did, ctl.theta_w, ext.theta_x, ctl.theta_d, use_x);
-                if (take) {
-                    const uint32_t o = atomicAdd(&ctl.tkn, 1u);
-                    sm.tk.w[o] = kw; tkx[o] = kx; sm.tk.d[o] = did; sm.tk.m[o] = subqs; tkc[o] = cord ? cord[did] : 0u;
-                }
-            }
-            __syncthreads();
-        }
-
-        if (tid == 0) ctl.qn = 0;
-        __syncthreads();
-    }
-
-    /* epilogue: the unit's best k, its match count and the best weight of everything it matched */
-    __syncthreads();
-    sort_and_collapse();
-    if (my_matches) atomicAdd(&ctl.matches, my_matches);
-    if (my_max_d != 0xFFFFFFFFu) atomicMax(&ext.max_w, (unsigned long long)my_max_w);
-    __syncthreads();
-    if (my_max_d != 0xFFFFFFFFu && my_max_w == ext.max_w) atomicMin(&ext.max_d, my_max_d);
-    __syncthreads();
-    if (my_max_d != 0xFFFFFFFFu && my_max_w == ext.max_w && my_max_d == ext.max_d) ext.max_m = my_max_m;
-    __syncthreads();
-    const uint32_t n_out = ctl.tkn < k ? ctl.tkn : k;
-    xgm_cand_sorted* out = cand_out + (size_t)wk.slot * k_stride;
-    for (uint32_t i = tid; i < n_out; i += XGM_WG) {
-        xgm_cand_sorted c;
-        c.kw = sm.tk.w[i]; c.kx = tkx[i]; c.did = sm.tk.d[i]; c.subqs = sm.tk.m[i]; c.cord = tkc[i]; c.pad = 0;
-        out[i] = c;
-    }
-    if (tid == 0) {
-        xgm_group_hdr h = {};
-        h.matches = ctl.matches; h.n_cand = n_out;
-        h.c_pos = ext.max_w; h.c_pad[0] = ext.max_d; h.c_pad[1] = ext.max_m;
-        ghdr_out[wk.slot] = h;
-    }
-}
+#define XGM_BODY_SORTED 1
+#include "xgm_match_body.inc"
+#undef XGM_BODY_SORTED
 
 size_t match_smem_bytes(uint32_t W, uint32_t T, bool phrase, uint32_t cap, size_t tab_elem, uint32_t spg) {
     size_t off = 0;
@@ -3113,26 +2475,27 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
     return 0;
 }
 
-size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group) {
-    return match_smem_bytes(1u << stripe_bits, tab_terms, false, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15) + (size_t)cap * 4;
+size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group) {
+    return match_smem_bytes(1u << stripe_bits, tab_terms, phrase, cap, wide ? 2 : 1, stripes_per_group) + (size_t)cap * 8 + ((sizeof(SortedExt) + 15) & ~(size_t)15) + (size_t)cap * 4;
 }
 
 int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, const uint32_t* spy_ord, uint32_t* spy_counts,
                             const uint32_t* cord, uint32_t cmax, xgm_cand_sorted* cand, hipStream_t stream) {
     dim3 grid(L.n_work), block(XGM_WG);
-    const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
+    const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("sorted match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
-    if (L.phrase || mode < 1u || mode > 4u || (!ord && mode != 4u) || (spy_counts && !spy_ord) || (cord && cmax == 0u) || L.cap > 8u * XGM_WG)
+    if (mode < 1u || mode > 4u || (!ord && mode != 4u) || (spy_counts && !spy_ord) || (cord && cmax == 0u) || L.cap > 8u * XGM_WG)
         return xgm_launch_error("sorted match kernel", 0, "bad arguments");
-#define XGM_LAUNCH(TT)                                                                                       \
+#define XGM_LAUNCH(TT, PH)                                                                                   \
     do {                                                                                                     \
-        auto kern = xgm_match_sorted_kernel<TT>;                                                             \
+        auto kern = xgm_match_sorted_kernel<TT, PH>;                                                         \
         static std::atomic<size_t> seen{0};                                                                  \
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
                            L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cord, cmax, cand, L.ghdr); \
     } while (0)
-    if (L.wide) XGM_LAUNCH(uint16_t); else XGM_LAUNCH(uint8_t);
+    if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
+    else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }
 #undef XGM_LAUNCH
     XGM_HIP_CHECK(hipGetLastError());
     return 0;

@@ -27,8 +27,8 @@ struct xgm_match_launch {
 size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);
 /* the same kernel under a value sort (mode 1 value, 2 value then relevance, 3 relevance then value; ord = the device column):
- * plain operators only, candidates of 24 bytes with two keys, L.cand unused */
-size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group);
+ * candidates of 32 bytes with two keys, L.cand unused */
+size_t xgm_match_sorted_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint32_t mode, uint32_t reverse, const uint32_t* spy_ord, uint32_t* spy_counts,
                             const uint32_t* cord, uint32_t cmax, xgm_cand_sorted* cand, hipStream_t stream);
 /* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
