@@ -13,7 +13,7 @@ import pytest
 
 import helpers as H
 from xapiand_amd import Database, Enquire, Query, ValueCountMatchSpy, _lib
-from xapiand_amd.enquire import plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
+from xapiand_amd.enquire import merged_stats, plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
 
 pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not os.environ.get("XGM_RUN_UNVERIFIED"), reason="device value sorts: not yet run on a GPU (set XGM_RUN_UNVERIFIED=1)")]
@@ -130,6 +130,54 @@ def test_positional_and_nested_queries_under_a_sort(built, tmp_path):
         assert hdr.matches_exact == len(full), tq
     db.close()
     c.close()
+
+
+def test_value_sorts_over_three_shards(built, tmp_path):
+    """Xapiand's per-shard protocol under a value sort: every shard searched on the device with the merged statistics (its own
+    column: ordinals are per shard), the shards' pages merged on the host by the value STRINGS under the same comparison — what
+    Enquire::merge_mset does with the MSets a hook hands back.  Against the oracle's sharded sorted search, which is pinned to the
+    reference's multi-shard Enquire (tests/test_oracle_vs_reference.py)."""
+    import functools
+    n_docs, vocab, n_shards = (3000, 8000, 3) if QUICK else (18000, 40000, 3)
+    shards = [H.Corpus(n_docs, vocab, n_shards=n_shards, shard=s) for s in range(n_shards)]
+    dbs, values = [], []
+    for s, c in enumerate(shards):
+        db = Database(c.build_segment(str(tmp_path / ("s%d.seg" % s))))
+        vals = {}
+        for slot in range(3):
+            p = write_column(c, slot, str(tmp_path / ("s%d_col%d" % (s, slot))))
+            db.attach_column(p)
+            vals[slot] = read_column_values(p)
+        dbs.append(db); values.append(vals)
+    rng = random.Random(31)
+    nq = 3 if QUICK else 10
+    n_items = 0
+    for q in H.gen_term_queries("OR", nq, 3, 1, 300, maxitems=10, seed=91) + H.gen_term_queries("AND", nq, 2, 1, 40, maxitems=10, seed=92) + H.gen_term_queries("OR", nq // 2 + 1, 2, 1, 1500, first=5, maxitems=12, seed=93):
+        mode, slot, rev = rng.choice(["V", "VR", "RV"]), rng.randrange(3), rng.random() < 0.5
+        want = H.oracle_search_sharded_sorted(shards, q["op"], q["terms"], q["first"], q["maxitems"], mode, slot, rev)
+        query = Query(q["op"], q["terms"])
+        gs = merged_stats(dbs, query)
+        rows = []
+        for s, db in enumerate(dbs):
+            got, _ = search_sorted(db, plan(db, query, 0, q["first"] + q["maxitems"], global_stats=gs), MODES[mode], slot, rev)
+            rows += [((d - 1) * n_shards + s + 1, w, m, values[s][slot][o - 1] if o else b"") for d, w, m, o in got]
+
+        def cmp(a, b):
+            if mode == "RV" and a[1] != b[1]:
+                return -1 if a[1] > b[1] else 1
+            if a[3] != b[3]:
+                return (-1 if a[3] > b[3] else 1) if rev else (-1 if a[3] < b[3] else 1)
+            if mode == "VR" and a[1] != b[1]:
+                return -1 if a[1] > b[1] else 1
+            return -1 if a[0] < b[0] else (1 if a[0] > b[0] else 0)
+        rows.sort(key=functools.cmp_to_key(cmp))
+        assert rows[q["first"]:q["first"] + q["maxitems"]] == want, (q, mode, slot, rev)
+        n_items += len(want)
+    assert n_items > (40 if QUICK else 200)
+    for db in dbs:
+        db.close()
+    for c in shards:
+        c.close()
 
 
 def test_collapse_vs_oracle(built, tmp_path):
