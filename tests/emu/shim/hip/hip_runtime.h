@@ -157,6 +157,8 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, unsigned char* lds,
     for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
         blockIdx = dim3(bx, by, bz);
         memset(lds, 0xCD, kLdsBytes);
+        const size_t canary_from = (smem_bytes + 15) & ~(size_t)15;          /* LDS the launch did not ask for must stay untouched */
+        for (size_t i = canary_from; i < kLdsBytes; ++i) lds[i] = 0xA5;
         S.blk_arrived = 0;
         S.live = S.n;
         for (unsigned w = 0; w < kMaxWaves; ++w) {
@@ -181,7 +183,11 @@ inline void launch(dim3 grid, dim3 block, size_t smem_bytes, unsigned char* lds,
                 threadIdx = dim3(i, 0, 0);
                 swapcontext(&S.sched, &S.ctx[i]);
             }
-            if (!any) break;
+            if (!any) {
+                for (size_t i = canary_from; i < kLdsBytes; ++i)
+                    if (lds[i] != 0xA5) { fprintf(stderr, "emu: workgroup (%u,%u,%u) wrote LDS byte %zu, beyond the %zu bytes the launch asked for\n", bx, by, bz, i, smem_bytes); abort(); }
+                break;
+            }
             if (S.progress == before) {
                 /* nobody can move: a wave operation reached by only some lanes runs with those (divergence) */
                 bool released = false;
@@ -306,11 +312,42 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255 + 256) & ~(size_t)255); if (!*p) return 2; memset(*p, 0xCD, n); return hipSuccess; }
+/* XGM_EMU_GUARD=1: every device allocation ends 16-byte aligned right before an inaccessible page, so a kernel that reads or
+ * writes past the end of a buffer faults (XGM_EMU_FAULT_TRACE=1 says where) instead of finding host memory there */
+#include <sys/mman.h>
+#include <map>
+namespace emu {
+inline std::map<void*, std::pair<void*, size_t>>& guard_map() { static std::map<void*, std::pair<void*, size_t>> m; return m; }
+inline bool guard_on() { static const bool on = getenv("XGM_EMU_GUARD") != nullptr; return on; }
+}
+inline hipError_t hipMalloc(void** p, size_t n) {
+    if (emu::guard_on()) {
+        const size_t page = 4096, body = (n + 15) & ~(size_t)15, span = (body + page - 1) / page * page;
+        char* base = (char*)mmap(nullptr, span + page, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (base == MAP_FAILED) return 2;
+        mprotect(base + span, page, PROT_NONE);
+        *p = base + span - body;
+        memset(*p, 0xCD, body);
+        emu::guard_map()[*p] = std::make_pair((void*)base, span + page);
+        return hipSuccess;
+    }
+    *p = aligned_alloc(256, (n + 255 + 256) & ~(size_t)255);
+    if (!*p) return 2;
+    memset(*p, 0xCD, n);
+    return hipSuccess;
+}
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc((void**)p, n); }
-inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipFree(void* p) {
+    if (!p) return hipSuccess;
+    if (emu::guard_on()) {
+        auto it = emu::guard_map().find(p);
+        if (it != emu::guard_map().end()) { munmap(it->second.first, it->second.second); emu::guard_map().erase(it); return hipSuccess; }
+    }
+    free(p);
+    return hipSuccess;
+}
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
-inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { return hipFree(p); }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }

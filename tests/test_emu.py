@@ -25,7 +25,9 @@ def emu_lib(built):
 
 def run_device_tests(emu_lib, args, extra_env=None, timeout=900):
     # every query through the workgroup kernels: the wave-autonomous ones use v_readlane under per-lane conditions
-    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_NO_ANDW="1", XGM_NO_ORW="1", XGM_NO_PHRASEW="1", XGM_NO_AND_KERNEL="1")
+    # guard pages behind every device buffer, a canary behind the LDS a launch asked for, a backtrace if a kernel faults
+    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_NO_ANDW="1", XGM_NO_ORW="1", XGM_NO_PHRASEW="1", XGM_NO_AND_KERNEL="1",
+               XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
