@@ -23,11 +23,13 @@ def emu_lib(built):
     return os.path.join(EMU, "libxgm_emu.so")
 
 
-def run_device_tests(emu_lib, args, extra_env=None, timeout=900):
+def run_device_tests(emu_lib, args, extra_env=None, timeout=900, and_kernel=False):
     # every query through the workgroup kernels: the wave-autonomous ones use v_readlane under per-lane conditions
     # guard pages behind every device buffer, a canary behind the LDS a launch asked for, a backtrace if a kernel faults
     env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_NO_ANDW="1", XGM_NO_ORW="1", XGM_NO_PHRASEW="1", XGM_NO_AND_KERNEL="1",
                XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
+    if and_kernel:
+        del env["XGM_NO_AND_KERNEL"]           # conjunctions through xgm_and_kernel (its guarded payload loads carry XGM_EMU hooks)
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=timeout)
@@ -49,6 +51,12 @@ def test_match_kernels_under_emulation(emu_lib):
     merge) and the edge cases, through xgm_match_kernel and the merge kernels."""
     out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_parity.py"), "-k", EMU_SELECT])
     assert "passed" in out and "failed" not in out, out
+
+
+def test_and_workgroup_kernel_under_emulation(emu_lib):
+    """Conjunctions through xgm_and_kernel (candidate-driven decode, two waves' blocks in flight): paging golden and edge cases."""
+    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_parity.py"), "-k", "edge_cases or (golden_single_shard and and_paging)"], and_kernel=True)
+    assert "2 passed" in out, out
 
 
 EMU_SELECT = "golden or edge_cases"
