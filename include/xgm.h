@@ -31,6 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: exactly what this header declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
 
 #define XGM_MAX_TERMS 16      /* leaves per query handled on the device path            */
 #define XGM_MAX_K 1024        /* first + maxitems handled on the device path            */
@@ -514,9 +518,24 @@ int xgm_debug_batching_info(const xgm_index*, uint64_t* out3);
 double xgm_debug_concurrent_searches(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t n,
                                      uint32_t n_threads, uint32_t per_thread, uint32_t k, double* lat_us);
 
+/* Section cycle counters of the -DXGM_PHASE_TIMERS / -DXGM_MERGE_TIMERS / -DXGM_ORW_TIMERS measurement builds (tools/phase.py);
+ * zeros in a product build. */
+int xgm_debug_phase_cycles(unsigned long long* out8);
+int xgm_debug_merge_cycles(unsigned long long* out8);
+int xgm_debug_orw_phase_cycles(unsigned long long* out8);
+/* The work units plan_batch would cut a batch into (tests/test_batch_plan.py), the disjunction's threshold seed and weight bounds
+ * (tests/test_planner.py), and the last batch's per-unit cycle records (tools/units.py). */
+int64_t xgm_debug_plan_batch(const xgm_index*, const xgm_query* qs, uint32_t nq, char* kernel, uint32_t* units, uint64_t cap);
+int xgm_debug_or_bounds(const xgm_index*, const xgm_query* q, double* seed, double* ub, double* ub1);
+int64_t xgm_debug_last_units(xgm_index*, unsigned long long* out, uint64_t cap);
+int64_t xgm_debug_last_units2(xgm_index*, unsigned long long* out, unsigned long long* out_pos, uint64_t cap);
+
 const char* xgm_last_error(void);
 const char* xgm_version(void);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

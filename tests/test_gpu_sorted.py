@@ -1,11 +1,8 @@
 """Searches under a value sort on the device (first version) against the oracle, which is pinned to the compiled
 reference for the three sorts in both directions (tests/test_oracle_vs_reference.py, tests/golden/sorted_values.json).
 
-WRITTEN IN ROUND 2 AFTER THE ROUND'S GPU BUDGET WAS SPENT: xgm_match_sorted_kernel and xgm_search_sorted have been compiled for
-gfx950 but never executed on one.  They pass under the CPU emulation of the kernels (tests/test_emu.py runs this file against
-tests/emu/libxgm_emu.so), which checks the logic but not the hardware; on a GPU box the tests run only on request
-(XGM_RUN_UNVERIFIED=1) until they have passed once on an MI355X.  The other device paths share no code that changed (the
-existing kernels' device assembly is byte-identical)."""
+First run on an MI355X at the start of round 3 (profiles/r03_sorted_first_gpu.log: 8 passed); part of the -m gpu suite since.
+The same file also runs under the CPU emulation of the kernels (tests/test_emu.py against tests/emu/libxgm_emu.so)."""
 import os
 import random
 
@@ -15,8 +12,7 @@ import helpers as H
 from xapiand_amd import Database, Enquire, Query, ValueCountMatchSpy, _lib
 from xapiand_amd.enquire import merged_stats, plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not os.environ.get("XGM_RUN_UNVERIFIED"), reason="device value sorts: not yet run on a GPU (set XGM_RUN_UNVERIFIED=1)")]
+pytestmark = [pytest.mark.gpu]
 
 QUICK = bool(os.environ.get("XGM_EMU_QUICK"))          # under emulation a workgroup barrier costs 256 fiber switches: small sizes
 

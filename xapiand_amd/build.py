@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libxgm.so")
 SOURCES = ["xgm_api.cc", "xgm_plan.cc", "xgm_segment_build.cc", "xgm_glass.cc", "xgm_kernels.hip", "xgm_or.hip", "xgm_synth.hip", "xgm_dense.hip"]
 # -ffp-contract=off: BM25 must round exactly like the reference's separate mul/add/div (no FMA).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-x", "hip"]
 
 
@@ -52,6 +52,7 @@ def build(force=False, verbose=False):
     all_dg = [_digest([os.path.join(CSRC, src)] + headers, " ".join(FLAGS)) for src in SOURCES]
     if not force and _up_to_date(LIB, _digest([], " ".join(all_dg))):
         return LIB                      # the shipped library matches the sources (objects need not be present)
+    jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
@@ -63,9 +64,13 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
-            subprocess.check_call(cmd)
-            with open(o + ".sha", "w") as f:
-                f.write(dg)
+            jobs.append((subprocess.Popen(cmd), cmd, o, dg))       # translation units compile side by side
+    failed = [cmd for proc, cmd, _, _ in jobs if proc.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
+    for _, _, o, dg in jobs:
+        with open(o + ".sha", "w") as f:
+            f.write(dg)
     link_dg = _digest([], " ".join(digests))
     if force or not _up_to_date(LIB, link_dg):
         hipcc = hipcc or _hipcc()

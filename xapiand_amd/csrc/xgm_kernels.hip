@@ -563,21 +563,13 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                 uint32_t ma = 0, mb = 0;
                 if (ja < nblk0) {
                     ma = __builtin_amdgcn_readlane(m0, ja);
-#ifdef XGM_EMU                       /* tests/emu: a wave operation inside a per-lane guard (v_readlane serves inactive lanes too; fibers cannot) */
                     { const uint32_t rl_ = __builtin_amdgcn_readlane(w0, ja);
                       if (lane * 4u < payload_words(ma)) pa = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + rl_ + lane * 4u); }
-#else
-                    if (lane * 4u < payload_words(ma)) pa = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + __builtin_amdgcn_readlane(w0, ja) + lane * 4u);
-#endif
                 }
                 if (jb < nblk0) {
                     mb = __builtin_amdgcn_readlane(m0, jb);
-#ifdef XGM_EMU                       /* tests/emu: a wave operation inside a per-lane guard (v_readlane serves inactive lanes too; fibers cannot) */
                     { const uint32_t rl_ = __builtin_amdgcn_readlane(w0, jb);
                       if (lane * 4u < payload_words(mb)) pb = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + rl_ + lane * 4u); }
-#else
-                    if (lane * 4u < payload_words(mb)) pb = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[0] + __builtin_amdgcn_readlane(w0, jb) + lane * 4u);
-#endif
                 }
                 for (uint32_t pass = 0; pass < 2u; ++pass) {
                     const uint32_t j = pass ? jb : ja;
@@ -680,12 +672,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                             jj[u] = (uint32_t)__builtin_ctzll(mask_a);
                             for (uint32_t x = 0; x < XGM_WAVES && mask_a; ++x) mask_a &= mask_a - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(a_meta, jj[u]);
-#ifdef XGM_EMU                       /* tests/emu: a wave operation inside a per-lane guard (v_readlane serves inactive lanes too; fibers cannot) */
                             { const uint32_t rl_ = __builtin_amdgcn_readlane(a_word, jj[u]);
                               if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[ta] + rl_ + lane * 4u); }
-#else
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[ta] + __builtin_amdgcn_readlane(a_word, jj[u]) + lane * 4u);
-#endif
                             n_a = u + 1u;
                         }
                     }
@@ -696,12 +684,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_and_kernel(xgm_seg_dev seg, const 
                             jj[u] = (uint32_t)__builtin_ctzll(mask_b);
                             for (uint32_t x = 0; x < XGM_WAVES && mask_b; ++x) mask_b &= mask_b - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(b_meta, jj[u]);
-#ifdef XGM_EMU                       /* tests/emu: a wave operation inside a per-lane guard (v_readlane serves inactive lanes too; fibers cannot) */
                             { const uint32_t rl_ = __builtin_amdgcn_readlane(b_word, jj[u]);
                               if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[tb] + rl_ + lane * 4u); }
-#else
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + ctl.tbase[tb] + __builtin_amdgcn_readlane(b_word, jj[u]) + lane * 4u);
-#endif
                             n_b = u - 3u;
                         }
                     }

@@ -143,13 +143,7 @@ typedef double orw_d8 __attribute__((ext_vector_type(8)));
 
 /* (mask & a) | (~mask & b): v_bfi_b32.  With mask = x ^ y: the majority of (x, y, a) when b = x — the carry of a full adder. */
 __device__ __forceinline__ uint32_t orw_bfi(uint32_t mask, uint32_t a, uint32_t b) {
-#ifdef XGM_EMU                       /* tests/emu: the kernels compiled for the host, where there is no such instruction */
     return (mask & a) | (~mask & b);
-#else
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
-    return r;
-#endif
 }
 
 template <typename TabT, bool TALLY>
