@@ -149,6 +149,13 @@ _API = [
     ("xgm_debug_batching_info", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("xgm_debug_host_ns", C.c_int, [_P(C.c_uint64)]),
     ("xgm_debug_concurrent_searches", C.c_double, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_double)]),
+    ("xgm_debug_phase_cycles", C.c_int, [_P(C.c_ulonglong)]),
+    ("xgm_debug_merge_cycles", C.c_int, [_P(C.c_ulonglong)]),
+    ("xgm_debug_orw_phase_cycles", C.c_int, [_P(C.c_ulonglong)]),
+    ("xgm_debug_plan_batch", C.c_int64, [C.c_void_p, _P(Query), C.c_uint32, C.c_char_p, _P(C.c_uint32), C.c_uint64]),
+    ("xgm_debug_or_bounds", C.c_int, [C.c_void_p, _P(Query), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
+    ("xgm_debug_last_units", C.c_int64, [C.c_void_p, _P(C.c_ulonglong), C.c_uint64]),
+    ("xgm_debug_last_units2", C.c_int64, [C.c_void_p, _P(C.c_ulonglong), _P(C.c_ulonglong), C.c_uint64]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]
