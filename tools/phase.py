@@ -11,6 +11,9 @@ buf = io.StringIO()
 orig_close = None
 L = _lib.lib()
 L.xgm_debug_phase_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+_z = (C.c_ulonglong * 8)()
+L.xgm_debug_merge_cycles.argtypes = [C.POINTER(C.c_ulonglong)]
+L.xgm_debug_merge_cycles(_z)        # start a fresh window (the merge timers' minimum needs its reset value)
 # patch Database.close to fetch before closing
 from xapiand_amd import enquire
 oc = enquire.Database.close

@@ -2069,7 +2069,9 @@ constexpr uint32_t kMergeSel = 512;    /* survivors the selection path of the me
 #define XGM_MERGE_TIMERS 0
 #endif
 __device__ unsigned long long g_merge_cycles[8];   /* diagnostics (-DXGM_MERGE_TIMERS=1): summed section cycles of thread 0 of every workgroup */
-#define MG_PH(i) do { if (XGM_MERGE_TIMERS && tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_merge_cycles[i], n_ - mg_t); mg_t = n_; } } while (0)
+__device__ unsigned long long g_merge_max[8];      /* ... and the largest single section of any workgroup of a full batch (the kernel's duration is its slowest workgroup) */
+#define MG_PH(i) do { if (XGM_MERGE_TIMERS && tid == 0) { const unsigned long long n_ = __builtin_readcyclecounter(); atomicAdd(&g_merge_cycles[i], n_ - mg_t); \
+        if (gridDim.x >= 64u) atomicMax(&g_merge_max[i], ((n_ - mg_t) << 20) | ((unsigned long long)(goff[qi + 1] - goff[qi]) << 4) | (i)); mg_t = n_; } } while (0)
 
 /* One workgroup per query.  Sources: n_src candidate lists of up to k_stride entries
  * (groups of one shard, or shards after the all-gather).  did_mul/did_add remap shard-local
@@ -2084,6 +2086,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
     /* a heterogeneous batch runs one launch per kernel class: query qi of this launch is row row_of[qi] of the caller's batch */
     const uint32_t orow = row_of ? row_of[qi] : qi;
     unsigned long long mg_t = XGM_MERGE_TIMERS ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long mg_w0 = XGM_MERGE_TIMERS ? wall_clock64() : 0ull;
+    if (XGM_MERGE_TIMERS && tid == 0 && gridDim.x >= 64u && qi == 0) __hip_atomic_store(&g_merge_max[5], mg_w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     TopK tk;
     tk.w = reinterpret_cast<uint64_t*>(smem);
     tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
@@ -2235,6 +2239,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
             }
             __syncthreads();
             MG_PH(4);
+            if (XGM_MERGE_TIMERS && tid == 0 && gridDim.x >= 64u) { const unsigned long long w1_ = wall_clock64(); atomicMax(&g_merge_max[6], w1_ - __hip_atomic_load(&g_merge_max[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); atomicMax(&g_merge_max[7], w1_ - mg_w0); }
             if (tid == 0) {
                 xgm_result_hdr r;
                 r.n_hits = n;
@@ -2246,6 +2251,20 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
             }
             return;
         }
+    }
+    if (fill == 0) {
+        /* a query without a single candidate (a conjunction that matches nothing): nothing to rank — sorting the sentinels of
+         * the whole buffer made exactly these workgroups the slowest of the launch (round 3: 119 us of a 530 us step) */
+        if (tid == 0) {
+            xgm_result_hdr r;
+            r.n_hits = 0;
+            r.max_weight_subqs_matched = 0u;
+            r.matches_exact = matches | (lower_only ? XGM_MATCHES_LOWER_BOUND : 0ull);
+            r.max_attained = 0.0;
+            r.max_possible = max_possible ? max_possible[qi] : 0.0;
+            hdrs[orow] = r;
+        }
+        return;
     }
     topk_sort(tk, tid);
     for (uint32_t i = tid; i < n; i += XGM_WG) {
@@ -2586,6 +2605,13 @@ int xgm_merge_cycles_fetch(unsigned long long* out8) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_merge_cycles), 64) != hipSuccess) return -1;
     hipMemcpyToSymbol(HIP_SYMBOL(g_merge_cycles), z, 64);
+    if (XGM_MERGE_TIMERS) {
+        unsigned long long mx[8];
+        if (hipMemcpyFromSymbol(mx, HIP_SYMBOL(g_merge_max), 64) == hipSuccess)
+            for (int i = 0; i < 5; ++i) fprintf(stderr, "merge section %d: slowest workgroup %llu cycles (a query of %llu units)\n", i, mx[i] >> 20, (mx[i] >> 4) & 0xFFFFull);
+        fprintf(stderr, "merge: start of workgroup 0 to the last end (longest launch) %llu ticks of 10 ns; longest workgroup %llu ticks\n", mx[6], mx[7]);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_merge_max), z, 64);
+    }
     return 0;
 }
 
