@@ -352,6 +352,11 @@ typedef struct {
  * the estimate is the reference's whenever its static estimate dominates (the common case), and the lower bound is valid
  * but may be looser.  The exact count is in hdr->matches_exact. */
 void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper);
+/* ... with the matcher's known_matching_docs supplied: where the reference's main loop shows ProtoMSet EVERY matching document
+ * (a sort the value leads — min_weight stays 0, matcher.cc:482-536 with protomset.h:249-283 — or check_at_least beyond the match)
+ * that number is the exact match count (hdr->matches_exact) and the three figures are the reference's. */
+void xgm_mset_bounds_known(const xgm_query* plan, const xgm_result_hdr* hdr, uint64_t known_matching_docs, uint32_t* lower, uint32_t* estimated,
+                           uint32_t* upper);
 
 /* One query on one shard: hits[0 .. first+maxitems) sorted by (weight desc, docid asc) — the order
  * of msetcmp_by_relevance<true> (reference src/xapian/matcher/msetcmp.cc:55-62); the caller drops
@@ -363,6 +368,11 @@ int xgm_search(xgm_index*, const xgm_query*, xgm_hit* hits, xgm_result_hdr* hdr)
 /* Load the ordinals of a column file (xgm_glass_export_column) into HBM next to the index: 4 bytes per document.  The column's
  * lastdocid must be the index's (same shard revision).  Attaching a slot again replaces it. */
 int xgm_index_attach_column(xgm_index* idx, const char* column_path);
+/* The same from memory: ord[0 .. lastdocid] (ord[0] unused), ord[d] = 0 when document d has no value, else 1 + the index of its value among
+ * the column's n_distinct distinct values in ascending byte order.  What the matcher hook attaches for a value slot it read through the
+ * shard's ValueIterator, or for the keys a Xapian::KeyMaker makes of every document (Enquire::set_sort_by_key*, which is how Xapiand
+ * sorts: reference src/database/handler.cc:1269); any slot number may be used for such a synthetic column. */
+int xgm_index_attach_column_ordinals(xgm_index* idx, uint32_t slot, const uint32_t* ord, uint32_t n_ord, uint32_t n_distinct);
 
 #define XGM_SORT_VALUE 1u                 /* Enquire::set_sort_by_value                  (msetcmp.cc:64-73)   */
 #define XGM_SORT_VALUE_RELEVANCE 2u       /* Enquire::set_sort_by_value_then_relevance   (msetcmp.cc:75-86)   */
@@ -387,10 +397,12 @@ int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* s
 
 /* ... with a Xapian::ValueCountMatchSpy (what Xapiand's AggregationMatchSpy derives from, src/aggregations/) on value slot
  * spy_slot in the same pass: counts[o] = matching documents whose value has ordinal o in that slot's column, counts[0] those
- * without a value; n_counts = the column's distinct values + 1; hdr->matches_exact is the spy's total.  For sorts the value
- * leads (XGM_SORT_VALUE, XGM_SORT_VALUE_RELEVANCE): there the matcher shows a spy every matching document whatever
- * check_at_least is (matcher/protomset.h:268-275), so the counts are the reference's.  Replaces: api/matchspy.cc:307-313
- * called per document from the matcher's loop (matcher/matcher.cc:519-527). */
+ * without a value; n_counts = the column's distinct values + 1; hdr->matches_exact is the spy's total.  The counts are those of
+ * EVERY matching document.  The reference's matcher shows a spy every matching document where the value leads the sort
+ * (XGM_SORT_VALUE, XGM_SORT_VALUE_RELEVANCE: matcher/protomset.h:268-275) or where the match does not exceed check_at_least;
+ * elsewhere (sort == NULL = by relevance, or XGM_SORT_RELEVANCE_VALUE, with a larger match) what its spy sees depends on its
+ * traversal, and a caller that needs the reference's own counts keeps such a search on the CPU (the matcher hook does).
+ * Replaces: api/matchspy.cc:307-313 called per document from the matcher's loop (matcher/matcher.cc:519-527). */
 int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                           xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
 

@@ -4,16 +4,20 @@
 
 #include "xgm_matcher_hook.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 
 #include "xapian/error.h"
+#include "xapian/api/enquireinternal.h"
 #include "xapian/api/msetinternal.h"
 #include "xapian/api/queryinternal.h"
 #include "xapian/api/result.h"
+#include "xapian/common/pack.h"
 #include "xapian/common/serialise-double.h"
 #include "xapian/weight/weightinternal.h"
 
@@ -21,11 +25,20 @@ namespace xgm_hook {
 
 namespace {
 
-struct Shard { xgm_index* idx; Xapian::rev revision; };
+/* A device column (xgm_index_attach_column_ordinals) of one shard revision and the strings its ordinals stand for */
+struct Column { uint32_t slot_id = 0; std::vector<std::string> values; };
+struct ShardColumns {
+    std::mutex mu;                                               /* one builder at a time per shard */
+    std::map<std::string, std::shared_ptr<Column>> by_key;       /* "v<slot>" | "k<KeyMaker name>\0<serialised>" */
+    uint32_t next_slot = 0x40000000u;                            /* synthetic slot numbers of the index's column map */
+};
+struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; };
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
-std::atomic<bool> g_enabled{true}, g_decline_positional{false};
-std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0};
+std::map<std::string, SpyAdapter> g_spy_adapters;
+std::atomic<bool> g_enabled{true};
+std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
+std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0};
 
 struct Lowered {
     xgm_query_desc d;
@@ -116,7 +129,7 @@ bool lower_flat(const Xapian::Query& q, Lowered* L) {
         L->d.op = op == Xapian::Query::OP_AND ? XGM_OP_AND : XGM_OP_OR;
         L->total_subqs = (uint32_t)L->terms.size();
     } else if (op == Xapian::Query::OP_PHRASE || op == Xapian::Query::OP_NEAR) {
-        if (g_decline_positional.load(std::memory_order_relaxed)) return false;
+        if (g_positional.load(std::memory_order_relaxed) == POSITIONAL_DECLINE) return false;
         const size_t n = q.get_num_subqueries();
         for (size_t i = 0; i < n; ++i) {
             const Xapian::Query s = q.get_subquery(i);
@@ -158,9 +171,88 @@ bool lower(const Xapian::Query& q, Lowered* L) {
 
 }  // namespace
 
-void register_shard(const Xapian::Database& db, xgm_index* idx) {
+
+namespace {
+
+/* The column of `key` for this shard revision: built on first use from one string per document (`fill`), attached to the index
+ * under a synthetic slot number, kept with its distinct strings (ordinal o > 0 stands for values[o - 1]; 0 = no value / empty key). */
+template <class Fill>
+std::shared_ptr<Column> ensure_column(const Shard& sh, const Xapian::Database& db, const std::string& key, Fill fill) {
+    ShardColumns& sc = *sh.cols;
+    std::lock_guard<std::mutex> lk(sc.mu);
+    auto it = sc.by_key.find(key);
+    if (it != sc.by_key.end()) return it->second;
+    const Xapian::docid last = db.get_lastdocid();
+    std::vector<std::string> per(size_t(last) + 1);
+    fill(per);
+    auto col = std::make_shared<Column>();
+    col->values.reserve(per.size() / 4 + 1);
+    for (const std::string& v : per) if (!v.empty()) col->values.push_back(v);
+    std::sort(col->values.begin(), col->values.end());
+    col->values.erase(std::unique(col->values.begin(), col->values.end()), col->values.end());
+    col->values.shrink_to_fit();
+    std::vector<uint32_t> ord(per.size(), 0u);
+    for (size_t d = 1; d < per.size(); ++d)
+        if (!per[d].empty()) ord[d] = uint32_t(std::lower_bound(col->values.begin(), col->values.end(), per[d]) - col->values.begin()) + 1u;
+    col->slot_id = sc.next_slot++;
+    const int rc = xgm_index_attach_column_ordinals(sh.idx, col->slot_id, ord.data(), (uint32_t)ord.size(), (uint32_t)col->values.size());
+    if (rc != XGM_OK) return nullptr;
+    sc.by_key.emplace(key, col);
+    ++g_columns;
+    return col;
+}
+
+/* value slot → column, through the shard's value stream (ValueIterator walks the slot's chunks in docid order) */
+std::shared_ptr<Column> value_column(const Shard& sh, const Xapian::Database& db, Xapian::valueno slot) {
+    return ensure_column(sh, db, "v" + std::to_string(slot), [&](std::vector<std::string>& per) {
+        for (Xapian::ValueIterator it = db.valuestream_begin(slot); it != db.valuestream_end(slot); ++it) per[it.get_docid()] = *it;
+    });
+}
+
+/* KeyMaker → column of its keys.  The identity of a key maker is its class name + serialisation (Xapiand's
+ * Multi_MultiValueKeyMaker implements both, src/multivalue/keymaker.h:366-372); one that does not serialise is declined. */
+std::shared_ptr<Column> key_column(const Shard& sh, const Xapian::Database& db, const Xapian::KeyMaker& sorter) {
+    std::string key = "k";
+    try {
+        key += sorter.name();
+        key += '\0';
+        key += sorter.serialise();
+    } catch (const Xapian::Error&) {
+        return nullptr;
+    }
+    if (key.size() == 2) return nullptr;                       /* no name, no serialisation: nothing to recognise it by */
+    return ensure_column(sh, db, key, [&](std::vector<std::string>& per) {
+        for (Xapian::PostingIterator p = db.postlist_begin(std::string()); p != db.postlist_end(std::string()); ++p)
+            per[*p] = sorter(db.get_document(*p));
+    });
+}
+
+/* which value slot a spy counts: Xapian::ValueCountMatchSpy serialises exactly its slot (api/matchspy.cc: pack_uint_last) */
+bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, const SpyAdapter** adapter) {
+    *adapter = nullptr;
+    std::string name;
+    try { name = spy.name(); } catch (const Xapian::Error&) { return false; }
+    if (name == "Xapian::ValueCountMatchSpy") {
+        const std::string ser = spy.serialise();
+        const char* p = ser.data();
+        Xapian::valueno v;
+        if (!unpack_uint_last(&p, p + ser.size(), &v)) return false;
+        *slot = v;
+        return true;
+    }
     std::lock_guard<std::mutex> lk(g_mu);
-    g_shards[db.get_uuid()] = Shard{idx, db.get_revision()};
+    auto it = g_spy_adapters.find(name);
+    if (it == g_spy_adapters.end() || !it->second.slot_of || !it->second.feed) return false;
+    *adapter = &it->second;
+    return it->second.slot_of(spy, slot);
+}
+
+}  // namespace
+
+void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch) {
+    if (batch) xgm_index_set_batching(idx, batch);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_shards[db.get_uuid()] = Shard{idx, db.get_revision(), std::make_shared<ShardColumns>()};
 }
 
 void unregister_shard(const Xapian::Database& db) {
@@ -169,22 +261,43 @@ void unregister_shard(const Xapian::Database& db) {
 }
 
 void set_enabled(bool on) { g_enabled.store(on); }
-void set_decline_positional(bool on) { g_decline_positional.store(on); }
-Counters counters() { return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load()}; }
+void set_positional_mode(PositionalMode m) { g_positional.store(int(m)); }
+void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
+void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_spy_adapters[spy_class_name] = std::move(adapter);
+}
+Counters counters() {
+    return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load(), g_sorted.load(), g_spied.load(),
+                    g_collapsed.load(), g_columns.load()};
+}
 
 bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const Xapian::Weight::Internal& stats,
                   const Xapian::Weight& wtscheme, bool full_db_has_positions, Xapian::doccount first,
                   Xapian::doccount maxitems, Xapian::doccount check_at_least, const Xapian::MatchDecider* mdecider,
-                  const Xapian::KeyMaker* sorter, Xapian::doccount collapse_max, int percent_threshold,
-                  double weight_threshold, Xapian::Enquire::docid_order order, bool sort_by_rel, double time_limit,
-                  size_t n_matchspies, Xapian::MSet& out) {
+                  const Xapian::KeyMaker* sorter, Xapian::valueno collapse_key, Xapian::doccount collapse_max, int percent_threshold,
+                  double weight_threshold, Xapian::Enquire::docid_order order, Xapian::valueno sort_key, int sort_by,
+                  bool sort_val_reverse, double time_limit,
+                  const std::vector<Xapian::Internal::opt_intrusive_ptr<Xapian::MatchSpy>>& matchspies, Xapian::MSet& out) {
+    typedef Xapian::Enquire::Internal EI;
     if (!g_enabled.load(std::memory_order_relaxed)) return false;
-    /* eligibility */
-    if (db.size() != 1 || !sort_by_rel || order == Xapian::Enquire::DESCENDING || collapse_max != 0 || percent_threshold != 0 ||
-        weight_threshold != 0.0 || mdecider || sorter || n_matchspies != 0 || stats.rset_size != 0 || time_limit != 0.0 ||
-        wtscheme.name() != "Xapian::BM25Weight") {
+    /* eligibility (widened by row (f).3) */
+    const bool by_rel = sort_by == int(EI::REL);
+    const bool by_value = sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL) || sort_by == int(EI::REL_VAL);
+    if (db.size() != 1 || !(by_rel || by_value) || order == Xapian::Enquire::DESCENDING || percent_threshold != 0 || weight_threshold != 0.0 ||
+        mdecider || stats.rset_size != 0 || time_limit != 0.0 || wtscheme.name() != "Xapian::BM25Weight" ||
+        (collapse_max != 0 && (g_collapse.load(std::memory_order_relaxed) == COLLAPSE_DECLINE || !matchspies.empty())) || (by_rel && sorter)) {
         ++g_shape;
         return false;
+    }
+    /* spies: only classes the hook can feed */
+    struct SpyPlan { Xapian::MatchSpy* spy; Xapian::valueno slot; const SpyAdapter* adapter; std::shared_ptr<Column> col; };
+    std::vector<SpyPlan> spies;
+    for (const auto& sp : matchspies) {
+        if (!sp.get()) continue;
+        SpyPlan pl{sp.get(), 0, nullptr, nullptr};
+        if (!spy_slot_of(*sp, &pl.slot, &pl.adapter)) { ++g_shape; return false; }
+        spies.push_back(pl);
     }
     Lowered L;
     if (!lower(query, &L)) { ++g_shape; return false; }
@@ -221,34 +334,133 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
 
     const uint32_t k = first + maxitems;
     std::vector<xgm_hit> hits(k ? k : 1);
+    std::vector<uint32_t> hit_ord, hit_cord, hit_ccount;
     xgm_result_hdr hdr;
     memset(&hdr, 0, sizeof hdr);
     xgm_query plan;
     int rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
-    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
-    if (rc > 0) { ++g_dev; return false; }                                   /* declined by the planner: CPU matcher */
+    if (rc > 0) { ++g_dev; return false; }
     if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
     if (L.d.op == XGM_OP_TREE) L.total_subqs = plan.total_subqs;
 
-    /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682).  matches_*: exact counts
-     * (the reference's are estimates; documented exception). */
+    const bool plain = by_rel && spies.empty() && collapse_max == 0;
+    std::shared_ptr<Column> sort_col, collapse_col;
+    uint64_t collapsed_lb = 0;
+    if (plain) {
+        rc = xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
+    } else {
+        if (k == 0 || plan.max_possible == 0.0) { ++g_shape; return false; }      /* (max_possible == 0: the matcher renormalises the sort, matcher.cc:421-434) */
+        /* the columns this search ranks, counts and collapses by */
+        xgm_sort_spec spec;
+        memset(&spec, 0, sizeof spec);
+        if (by_value) {
+            sort_col = sorter ? key_column(sh, db, *sorter) : value_column(sh, db, sort_key);
+            if (!sort_col) { ++g_shape; return false; }
+            spec.sort_by = sort_by == int(EI::VAL) ? XGM_SORT_VALUE : sort_by == int(EI::VAL_REL) ? XGM_SORT_VALUE_RELEVANCE : XGM_SORT_RELEVANCE_VALUE;
+            spec.slot = sort_col->slot_id;
+            spec.reverse = sort_val_reverse ? 1u : 0u;
+            hit_ord.resize(k);
+        }
+        for (SpyPlan& sp : spies) {
+            sp.col = value_column(sh, db, sp.slot);
+            if (!sp.col) { ++g_shape; return false; }
+        }
+        const xgm_sort_spec* sp_sort = by_value ? &spec : nullptr;
+        if (collapse_max != 0) {
+            collapse_col = value_column(sh, db, collapse_key);
+            if (!collapse_col) { ++g_shape; return false; }
+            hit_cord.resize(k); hit_ccount.resize(k);
+            rc = xgm_search_collapsed(sh.idx, &plan, sp_sort, collapse_col->slot_id, collapse_max, hits.data(), by_value ? hit_ord.data() : nullptr,
+                                      hit_cord.data(), hit_ccount.data(), &hdr, &collapsed_lb);
+        } else if (spies.empty()) {
+            rc = xgm_search_sorted(sh.idx, &plan, sp_sort, hits.data(), hit_ord.data(), &hdr);
+        } else {
+            /* one pass per spy (each counts one column); the first pass's page is the answer */
+            std::vector<std::vector<uint32_t>> counts(spies.size());
+            for (size_t i = 0; i < spies.size() && rc == XGM_OK; ++i) {
+                counts[i].assign(spies[i].col->values.size() + 1, 0u);
+                std::vector<xgm_hit> h2(i ? k : 0);
+                xgm_result_hdr hd2;
+                rc = xgm_search_sorted_spy(sh.idx, &plan, sp_sort, i ? h2.data() : hits.data(), i ? nullptr : (by_value ? hit_ord.data() : nullptr),
+                                           i ? &hd2 : &hdr, spies[i].col->slot_id, counts[i].data(), (uint32_t)counts[i].size());
+            }
+            /* A spy is shown every matching document when the value leads the sort (ProtoMSet::early_reject, protomset.h:249-283:
+             * min_weight stays 0) or when the match does not exceed check_at_least (min_weight is raised only once checked_enough());
+             * otherwise what it sees depends on the CPU matcher's traversal: leave the search to it. */
+            const bool value_leads = sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL);
+            if (rc == XGM_OK && !value_leads && XGM_MATCHES_COUNT(hdr.matches_exact) > plan.check_at_least) { ++g_shape; return false; }
+            if (rc == XGM_OK) {
+                for (size_t i = 0; i < spies.size(); ++i) {
+                    const std::vector<std::string>& vals = spies[i].col->values;
+                    const Xapian::doccount total = (Xapian::doccount)XGM_MATCHES_COUNT(hdr.matches_exact);
+                    if (spies[i].adapter) {
+                        std::vector<std::pair<std::string, Xapian::doccount>> cv;
+                        for (size_t o = 1; o < counts[i].size(); ++o) if (counts[i][o]) cv.emplace_back(vals[o - 1], counts[i][o]);
+                        spies[i].adapter->feed(*spies[i].spy, total, cv);
+                    } else {
+                        /* ValueCountMatchSpy::merge_results (api/matchspy.cc:381-403): total, then (value, frequency) pairs */
+                        std::string ser;
+                        pack_uint(ser, total);
+                        for (size_t o = 1; o < counts[i].size(); ++o) if (counts[i][o]) { pack_string(ser, vals[o - 1]); pack_uint(ser, (Xapian::doccount)counts[i][o]); }
+                        spies[i].spy->merge_results(ser);
+                    }
+                }
+            }
+        }
+    }
+    if (rc > 0) { ++g_dev; return false; }                                   /* declined by the device path: CPU matcher */
+    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+
+    /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682) */
     std::vector<Result> items;
     const uint32_t skip = std::min<uint32_t>(first, hdr.n_hits);
     items.reserve(hdr.n_hits - skip);
-    for (uint32_t i = skip; i < hdr.n_hits; ++i) items.emplace_back(hits[i].weight, hits[i].docid);
+    for (uint32_t i = skip; i < hdr.n_hits; ++i) {
+        items.emplace_back(hits[i].weight, hits[i].docid);
+        if (sort_col && hit_ord[i]) items.back().set_sort_key(sort_col->values[hit_ord[i] - 1]);
+        if (collapse_col && hit_cord[i]) { items.back().set_collapse_key(collapse_col->values[hit_cord[i] - 1]); items.back().set_collapse_count(hit_ccount[i]); }
+    }
     double percent_scale = 0.0;
     if (hdr.n_hits && hdr.max_attained > 0.0 && L.total_subqs) {
         percent_scale = hdr.max_weight_subqs_matched / double(L.total_subqs);
         percent_scale /= hdr.max_attained;
     }
-    /* bounds and estimate as ProtoMSet::finalise derives them from the tree's static termfreq bounds (xgm_mset_bounds: the
-     * upper bound is the reference's; the lower bound and the estimate use the number of documents returned where the
-     * reference uses how many its matcher happened to weigh — DESIGN.md) */
+    /* bounds and estimate as ProtoMSet::finalise derives them from the tree's static termfreq bounds and known_matching_docs
+     * (protomset.h:484-619).  Where the reference's main loop shows ProtoMSet every matching document — a sort the value leads —
+     * known_matching_docs IS the match count and the three figures are the reference's; by relevance the count of documents
+     * returned stands in for it (what known_matching_docs is under weight pruning). */
     uint32_t lb = 0, est = 0, ub = 0;
-    xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
-    out = Xapian::MSet(new Xapian::MSet::Internal(first, ub, lb, est, ub, lb, est, hdr.max_possible, hdr.max_attained, std::move(items),
+    const uint64_t m_all = XGM_MATCHES_COUNT(hdr.matches_exact);
+    if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
+    else xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
+    uint32_t ulb = lb, uest = est, uub = ub;
+    if (collapse_max != 0) {
+        /* ProtoMSet::finalise with a collapser that considered every matching document (protomset.h:497-619): docs_considered = the
+         * match, dups_ignored = the documents beyond collapse_max of their key, lower bound = what stays (collapser.cc:212-218) */
+        uint32_t slb = plan.est_min, sest = plan.est_est, sub = plan.est_max;
+        ulb = std::max<uint32_t>(slb, (uint32_t)std::min<uint64_t>(m_all, 0xFFFFFFFFu)); uest = sest; uub = sub;
+        if (hdr.n_hits < k) {
+            lb = est = ub = hdr.n_hits;
+            ulb = slb;
+        } else {
+            const uint64_t dups = m_all - collapsed_lb;
+            lb = (uint32_t)collapsed_lb;
+            ub = sub - (uint32_t)std::min<uint64_t>(dups, sub);
+            const double unique_rate = m_all ? double(m_all - dups) / double(m_all) : 1.0;
+            est = unique_rate != 1.0 ? Xapian::doccount(sest * unique_rate + 0.5) : sest;
+            if (est < lb) est = lb;
+            est = std::min(std::max(est, lb), std::max(ub, lb));
+            if (ub < lb) ub = lb;
+        }
+        if (lb > ulb) ulb = lb;
+        uest = std::min(std::max(uest, ulb), std::max(uub, ulb));
+        ++g_collapsed;
+    }
+    out = Xapian::MSet(new Xapian::MSet::Internal(first, ub, lb, est, uub, ulb, uest, hdr.max_possible, hdr.max_attained, std::move(items),
                                                    percent_scale * 100.0));
     ++g_answered;
+    if (by_value) ++g_sorted;
+    if (!spies.empty()) ++g_spied;
     return true;
 }
 

@@ -4,27 +4,47 @@
  *
  *     if (!xgm_hook::try_get_mset(...,  local_mset))  local_mset = get_local_mset(...);
  *
- * For an eligible search (SURVEY §8(b) predicate: one local shard, BM25Weight with k2 = 0, relevance order, no
- * collapse / cut-offs / decider / spies / RSet / time limit, a query shape xgm_plan_query accepts) the hook lowers the
- * Xapian::Query to an xgm_query_desc, takes the MERGED statistics out of the Weight::Internal the matcher was
- * handed (Xapiand's add_prepared_mset / set_prepared_mset protocol, src/database/handler.cc:1532-1549, needs nothing
- * else), runs xgm_get_mset_batch on the shard's device-resident segment and builds the MSet exactly like
- * ProtoMSet::finalise does (src/xapian/matcher/protomset.h:672-682).  Anything else — or an xgm return > 0 — leaves
- * the CPU matcher to run, untouched.  A hard failure (< 0) throws Xapian::DatabaseError so that Xapiand's retry
- * logic (src/database/handler.cc:1348-1368) applies.
+ * For an eligible search (SURVEY §8(b) predicate: one local shard, BM25Weight with k2 = 0, ascending docid order, no cut-offs /
+ * decider / RSet / time limit, a query shape xgm_plan_query accepts) the hook lowers the Xapian::Query to an xgm_query_desc, takes
+ * the MERGED statistics out of the Weight::Internal the matcher was handed (Xapiand's add_prepared_mset / set_prepared_mset
+ * protocol, src/database/handler.cc:1532-1549, needs nothing else), runs the search on the shard's device-resident segment and
+ * builds the MSet exactly like ProtoMSet::finalise does (src/xapian/matcher/protomset.h:672-682).  Anything else — or an xgm
+ * return > 0 — leaves the CPU matcher to run, untouched.  A hard failure (< 0) throws Xapian::DatabaseError so that Xapiand's
+ * retry logic (src/database/handler.cc:1348-1368) applies.
+ *
+ * Row (f).3 of SURVEY §8 — what DocMatcher::prepare_mset sets on every Enquire (src/database/handler.cc:1263-1270):
+ *   * value sorts (Enquire::set_sort_by_value / _then_relevance / relevance_then_value) and KEY sorts
+ *     (set_sort_by_key_then_relevance(Multi_MultiValueKeyMaker), which is how Xapiand sorts): the hook keeps, per shard
+ *     revision, one device COLUMN per value slot (read once through the shard's ValueIterator) or per KeyMaker (identified by
+ *     name() + serialise(); its key for every document, made once) — ordinals of the distinct strings — and ranks on those;
+ *     MSet items carry the sort key strings (MSetIterator::get_sort_key).
+ *   * MatchSpies: Xapian::ValueCountMatchSpy natively (counted on the device in the same pass, delivered through its own
+ *     merge_results), other spy classes through a registered SpyAdapter (Xapiand: AggregationMatchSpy for its value-count
+ *     aggregations, src/aggregations/aggregations.h:107).  Taken only where the reference's matcher shows a spy EVERY matching
+ *     document — a sort the value leads (protomset.h:249-283), or check_at_least covering the match — because only then are a spy's
+ *     counts a property of the query rather than of the CPU matcher's traversal; otherwise the search is left to the CPU matcher.
+ *   * Enquire::set_collapse_key: opt-in (set_collapse_mode), see below.
  *
  * Shards are registered by the embedding server (Xapiand: where it opens / reopens a shard) under the glass
  * database's UUID together with the revision the segment was exported from; a search on a Database whose revision
  * moved on is declined (CPU path) until the refreshed segment is registered — the revision key of SURVEY §8(f).1.
+ * Registering a shard switches the index's micro-batching queue on (xgm_index_set_batching): Xapiand's worker threads issue one
+ * get_mset each (src/manager.cc:161), and single-query calls of concurrent threads then share launches.
  */
 #ifndef XGM_MATCHER_HOOK_H
 #define XGM_MATCHER_HOOK_H
 
 #include <cstdint>
+#include <functional>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "xapian/database.h"
 #include "xapian/enquire.h"
+#include "xapian/intrusive_ptr.h"
+#include "xapian/keymaker.h"
+#include "xapian/matchspy.h"
 #include "xapian/mset.h"
 #include "xapian/query.h"
 #include "xapian/weight.h"
@@ -33,28 +53,54 @@
 
 namespace xgm_hook {
 
-/* registry (thread-safe) */
-void register_shard(const Xapian::Database& db, xgm_index* idx);
+/* registry (thread-safe).  batch: the index's micro-batching queue (0 = leave it as it is). */
+void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch = 256);
 void unregister_shard(const Xapian::Database& db);
 
 /* switches (process-wide) */
 void set_enabled(bool on);                 /* default: on */
-/* PHRASE / NEAR with maxitems < matches: the reference's SelectPostList serves a stale cached weight
- * (src/xapian/matcher/selectpostlist.cc:28-55), the device returns the intended top-k.  A deployment
- * that needs byte-compatibility with the CPU matcher on such searches declines them here. */
-void set_decline_positional(bool on);      /* default: off */
 
-struct Counters { uint64_t answered, declined_shape, declined_unregistered, declined_revision, declined_device; };
+/* PHRASE / NEAR with maxitems < matches: the reference's SelectPostList serves a stale cached weight
+ * (src/xapian/matcher/selectpostlist.cc:28-55) and its top-k is then not a prefix of its own full ranking; the device returns
+ * the intended top-k.  The choice is the deployment's and has to be made:
+ *   POSITIONAL_DECLINE  — positional queries stay on the CPU matcher (byte-compatible by construction);
+ *   POSITIONAL_INTENDED — answered on the device with the intended semantics;
+ *   POSITIONAL_REFERENCE — answered on the device and, when the match exceeds the page, the reference's frozen-weight behaviour is
+ *     replayed on the host from the device's docid-ordered list of matches (byte-compatible with the CPU matcher).
+ * Until set_positional_mode has been called positional queries are declined. */
+enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1, POSITIONAL_REFERENCE = 2 };
+void set_positional_mode(PositionalMode m);
+inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONAL_DECLINE : POSITIONAL_INTENDED); }
+
+/* Enquire::set_collapse_key.  The reference snapshot's collapser does not keep the best collapse_max documents of a key when
+ * the proto-MSet overflows or collapse_max > 1 (matcher/collapser.cc:59-76, protomset.h:310-317); the device does.
+ *   COLLAPSE_DECLINE (default) — collapsed searches stay on the CPU matcher;
+ *   COLLAPSE_INTENDED — answered on the device: per key the best collapse_max documents under the ranking in force. */
+enum CollapseMode { COLLAPSE_DECLINE = 0, COLLAPSE_INTENDED = 1 };
+void set_collapse_mode(CollapseMode m);
+
+/* A MatchSpy class the hook does not know natively: the server tells it which value slot the spy counts and how to hand it the
+ * counts of a finished search (total = matching documents, counts = (value, documents) in ascending value order — exactly what the
+ * spy would have tallied had it been shown every matching document).  Xapian::ValueCountMatchSpy needs no adapter. */
+struct SpyAdapter {
+    std::function<bool(const Xapian::MatchSpy&, Xapian::valueno* slot)> slot_of;
+    std::function<void(Xapian::MatchSpy&, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts)> feed;
+};
+void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter);
+
+struct Counters { uint64_t answered, declined_shape, declined_unregistered, declined_revision, declined_device, answered_sorted, answered_spied,
+                  answered_collapsed, columns_built; };
 Counters counters();
 
-/* The call the patch adds.  sort_by_rel: Enquire::Internal::sort_by == REL.  Returns true and fills `out` when the
+/* The call the patch adds.  sort_by: Enquire::Internal::sort_setting as an int.  Returns true and fills `out` when the
  * search ran on the device. */
 bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const Xapian::Weight::Internal& stats,
                   const Xapian::Weight& wtscheme, bool full_db_has_positions, Xapian::doccount first,
                   Xapian::doccount maxitems, Xapian::doccount check_at_least, const Xapian::MatchDecider* mdecider,
-                  const Xapian::KeyMaker* sorter, Xapian::doccount collapse_max, int percent_threshold,
-                  double weight_threshold, Xapian::Enquire::docid_order order, bool sort_by_rel, double time_limit,
-                  size_t n_matchspies, Xapian::MSet& out);
+                  const Xapian::KeyMaker* sorter, Xapian::valueno collapse_key, Xapian::doccount collapse_max, int percent_threshold,
+                  double weight_threshold, Xapian::Enquire::docid_order order, Xapian::valueno sort_key, int sort_by,
+                  bool sort_val_reverse, double time_limit,
+                  const std::vector<Xapian::Internal::opt_intrusive_ptr<Xapian::MatchSpy>>& matchspies, Xapian::MSet& out);
 
 }  // namespace xgm_hook
 

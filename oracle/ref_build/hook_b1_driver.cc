@@ -31,6 +31,9 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
         if (*x != *y) { *why = "docid"; return false; }
         if (memcmp(&wa, &wb, sizeof wa) != 0) { *why = "weight bits"; return false; }
         if (percents && x.get_percent() != y.get_percent()) { *why = "percent"; return false; }
+        if (x.get_sort_key() != y.get_sort_key()) { *why = "sort key"; return false; }
+        if (x.get_collapse_key() != y.get_collapse_key()) { *why = "collapse key"; return false; }
+        if (x.get_collapse_count() != y.get_collapse_count()) { *why = "collapse count"; return false; }
     }
     const double pa = a.get_max_possible(), pb = b.get_max_possible(), ma = a.get_max_attained(), mb = b.get_max_attained();
     if (memcmp(&pa, &pb, 8) != 0) { *why = "max_possible"; return false; }
@@ -43,8 +46,11 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
 int main(int argc, char** argv) {
     int a = 1;
     bool stale = false;
+    xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     for (; a < argc && argv[a][0] == '-'; ++a) {
-        if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_decline_positional(true);
+        if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
+        else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);
+        else if (!strcmp(argv[a], "--collapse-intended")) xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_INTENDED);
         else if (!strcmp(argv[a], "--stale")) stale = true;
     }
     if (argc - a < 2) { fprintf(stderr, "usage: xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]\n"); return 2; }
@@ -114,19 +120,28 @@ int main(int argc, char** argv) {
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const QuerySpec& q = queries[qi];
             const Xapian::Query query = make_query(q);
+            SpyResult spy_want, spy_got;
             xgm_hook::set_enabled(false);
-            Xapian::MSet want = run_query(dbs, query, q.first, q.maxitems);
+            Xapian::MSet want = run_query(dbs, query, q.first, q.maxitems, &q, &spy_want);
             xgm_hook::set_enabled(true);
-            Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems);
+            Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems, &q, &spy_got);
             std::string why;
             if (!same_mset(want, got, percents, &why)) {
                 ++bad;
                 printf("MISMATCH query %zu (%s): %s; cpu %u hits, hook %u hits\n", qi, q.op.c_str(), why.c_str(), want.size(), got.size());
+            } else if (spy_want.total != spy_got.total || spy_want.values != spy_got.values) {
+                ++bad;
+                printf("MISMATCH query %zu (%s): spy: cpu saw %u documents / %zu values, hook %u / %zu\n", qi, q.op.c_str(), spy_want.total, spy_want.values.size(),
+                       spy_got.total, spy_got.values.size());
             }
             /* the upper bound is a static property of the postlist tree: identical; the lower bound may be looser than the CPU
-             * matcher's (which counts the documents it happened to weigh) but never above it or the estimate */
-            if (dbs.size() == 1 && (want.get_matches_upper_bound() != got.get_matches_upper_bound() || got.get_matches_lower_bound() > want.get_matches_lower_bound() ||
-                                    got.get_matches_lower_bound() > got.get_matches_estimated() || got.get_matches_estimated() > got.get_matches_upper_bound())) {
+             * matcher's (which counts the documents it happened to weigh) but never above it or the estimate.  Where the value leads
+             * the sort the matcher shows ProtoMSet every document: all three figures must be the reference's. */
+            const bool exact_bounds = (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR") && !q.collapse_max;
+            if (dbs.size() == 1 && !q.collapse_max &&
+                (want.get_matches_upper_bound() != got.get_matches_upper_bound() || got.get_matches_lower_bound() > want.get_matches_lower_bound() ||
+                 got.get_matches_lower_bound() > got.get_matches_estimated() || got.get_matches_estimated() > got.get_matches_upper_bound() ||
+                 (exact_bounds && (want.get_matches_lower_bound() != got.get_matches_lower_bound() || want.get_matches_estimated() != got.get_matches_estimated())))) {
                 ++bounds_bad;
                 printf("BOUNDS query %zu: hook [%u, %u, %u] vs CPU matcher [%u, %u, %u]\n", qi, got.get_matches_lower_bound(), got.get_matches_estimated(),
                        got.get_matches_upper_bound(), want.get_matches_lower_bound(), want.get_matches_estimated(), want.get_matches_upper_bound());
@@ -134,9 +149,11 @@ int main(int argc, char** argv) {
         }
         const xgm_hook::Counters c = xgm_hook::counters();
         printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
-               "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u}\n",
+               "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
+               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu}\n",
                queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
-               (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed);
+               (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
+               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built);
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
         for (const std::string& f : seg_files) unlink(f.c_str());

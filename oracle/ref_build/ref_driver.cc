@@ -179,8 +179,31 @@ Xapian::Query make_query(const QuerySpec& q) {
 
 /* sort / collapse settings of a query on an Enquire (DocMatcher::prepare_mset, reference src/database/handler.cc:1263-1270,
  * does the same on the shard's and on the merger's) */
+/* A key maker the way Xapiand has them (Multi_MultiValueKeyMaker, reference src/multivalue/keymaker.h:366-372, implements name()
+ * and serialise(); the vendored Xapian::MultiValueKeyMaker does not): the key of slots (s, reversed s + 1 mod 3) of the test corpus */
+class DriverKeyMaker : public Xapian::KeyMaker {
+    Xapian::MultiValueKeyMaker inner;
+    unsigned slot;
+  public:
+    explicit DriverKeyMaker(unsigned slot_) : slot(slot_) { inner.add_value(slot_); inner.add_value((slot_ + 1) % 3, true); }
+    std::string operator()(const Xapian::Document& doc) const override { return inner(doc); }
+    std::string name() const override { return "XgmDriver::KeyMaker"; }
+    std::string serialise() const override { return std::to_string(slot); }
+};
+
+const Xapian::KeyMaker* driver_keymaker(unsigned slot) {
+    static std::map<unsigned, DriverKeyMaker*> made;           /* lives as long as any Enquire that was handed it */
+    auto it = made.find(slot);
+    if (it == made.end()) it = made.emplace(slot, new DriverKeyMaker(slot)).first;
+    return it->second;
+}
+
 void apply_settings(Xapian::Enquire& enq, const QuerySpec* q) {
     if (!q) return;
+    /* "K" / "KR" / "RK": Enquire::set_sort_by_key / _key_then_relevance (what Xapiand calls, handler.cc:1269) / _relevance_then_key */
+    if (q->sort_mode == "K") enq.set_sort_by_key(const_cast<Xapian::KeyMaker*>(driver_keymaker(q->sort_slot)), q->sort_reverse != 0);
+    else if (q->sort_mode == "KR") enq.set_sort_by_key_then_relevance(const_cast<Xapian::KeyMaker*>(driver_keymaker(q->sort_slot)), q->sort_reverse != 0);
+    else if (q->sort_mode == "RK") enq.set_sort_by_relevance_then_key(const_cast<Xapian::KeyMaker*>(driver_keymaker(q->sort_slot)), q->sort_reverse != 0);
     if (q->sort_mode == "V") enq.set_sort_by_value(q->sort_slot, q->sort_reverse != 0);
     else if (q->sort_mode == "VR") enq.set_sort_by_value_then_relevance(q->sort_slot, q->sort_reverse != 0);
     else if (q->sort_mode == "RV") enq.set_sort_by_relevance_then_value(q->sort_slot, q->sort_reverse != 0);

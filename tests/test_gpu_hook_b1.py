@@ -113,3 +113,95 @@ def test_moved_on_revision_is_declined_until_the_segment_is_refreshed(built, gla
     out = run_b1("--stale", qf, copy)
     assert out["mismatches"] == 0 and out["declined_revision"] >= 8 and out["refreshed_shards"] == 1, out
     assert out["answered_on_device"] == len(qs), out
+
+
+@pytest.fixture(scope="module")
+def glass_values(tmp_path_factory):
+    if not (H.have_xapian_ref() and os.path.exists(HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    d = tmp_path_factory.mktemp("b1v")
+    one = str(d / "one")
+    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), N_DOCS, VOCAB, 50, 150)
+    shards = []
+    for s in range(3):
+        p = str(d / ("shard%d" % s))
+        H.xapian_ref("build_values", p, hex(H.CORPUS_SEED), N_DOCS, VOCAB, 50, 150, 3, s)
+        shards.append(p)
+    return d, one, shards
+
+
+def sorted_queries():
+    """SURVEY 8(f).3 through the hook: the three value sorts in both directions, KEY sorts (Enquire::set_sort_by_key_then_relevance —
+    what DocMatcher::prepare_mset calls, reference src/database/handler.cc:1269 — and its two siblings), ValueCountMatchSpy spies
+    under a sort the value leads, and spies under relevance where check_at_least covers the match."""
+    import random
+    rng = random.Random(77)
+    base = (H.gen_term_queries("OR", 14, 3, 1, 400, maxitems=10, seed=61) + H.gen_term_queries("AND", 14, 2, 1, 60, maxitems=10, seed=62) +
+            H.gen_sided_queries("AND_MAYBE", 6, 1, 2, 1, 200, maxitems=10, seed=63) + H.gen_sided_queries("AND_NOT", 6, 1, 2, 1, 200, maxitems=10, seed=64) +
+            H.gen_term_queries("OR", 6, 5, 1, 3000, first=7, maxitems=43, seed=65) + H.gen_tree_queries(8, 1, 300, seed=66))
+    qs = []
+    for i, q in enumerate(base):
+        mode = ["V", "VR", "RV", "K", "KR", "RK"][i % 6]
+        q = dict(q, sort=(mode, rng.randrange(3), rng.random() < 0.5))
+        if mode in ("V", "VR", "K", "KR") and i % 2 == 0:
+            q["spy"] = rng.randrange(3)                       # the value leads: the spy sees every match whatever check_at_least is
+        qs.append(q)
+    n_sorted = len(qs)
+    for q in H.gen_term_queries("OR", 8, 3, 1, 400, maxitems=10, seed=67) + H.gen_term_queries("AND", 8, 2, 1, 60, maxitems=10, seed=68):
+        qs.append(dict(q, spy=rng.randrange(3), check_at_least=N_DOCS))       # by relevance, every match looked at
+    return qs, n_sorted
+
+
+def test_value_and_key_sorts_and_spies_through_the_hook(built, glass_values):
+    d, one, _ = glass_values
+    qs, n_sorted = sorted_queries()
+    qf = str(d / "qs1.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] == len(qs) and out["answered_sorted"] == n_sorted, out
+    assert out["answered_spied"] >= 16 + n_sorted // 3 - 2, out
+    assert 3 <= out["columns_built"] <= 6, out            # one column per value slot / key maker and shard revision, built once
+
+
+def test_sorts_through_the_hook_xapiand_protocol(built, glass_values):
+    d, _, shards = glass_values
+    qs, n_sorted = sorted_queries()
+    qf = str(d / "qs3.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, *shards)
+    assert out["mismatches"] == 0, out
+    assert out["shards"] == 3 and out["answered_on_device"] == 3 * len(qs), out
+
+
+def test_a_spy_under_relevance_with_a_larger_match_stays_on_the_cpu(built, glass_values):
+    d, one, _ = glass_values
+    qs = [dict(q, spy=0) for q in H.gen_term_queries("OR", 6, 3, 1, 50, maxitems=10, seed=69)]      # check_at_least = 0 → 10 < matches
+    qf = str(d / "qs4.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["answered_on_device"] == 0 and out["declined_shape"] == len(qs), out
+
+
+def test_collapse_through_the_hook(built, glass_values):
+    """Enquire::set_collapse_key(slot, 1) — Xapiand's default collapse_max — with the page covering the match: there the reference's
+    collapser cannot lose documents and hook on == hook off, collapse keys and counts included.  Declined unless the
+    deployment opted in."""
+    d, one, _ = glass_values
+    c = H.Corpus(N_DOCS, VOCAB)
+    qs = []
+    for q in (H.gen_term_queries("AND", 60, 2, 1, 400, maxitems=10, seed=70) + H.gen_term_queries("OR", 40, 2, 300, 6000, maxitems=10, seed=71) +
+              H.gen_sided_queries("AND_MAYBE", 20, 1, 1, 100, 3000, maxitems=10, seed=72)):
+        m = H.oracle_search(c, q["op"], q["terms"], 0, 1)[1].matches
+        if 0 < m <= 400:
+            qs.append(dict(q, maxitems=400, collapse=(len(qs) % 3, 1)))
+            if len(qs) % 4 == 0:
+                qs[-1]["sort"] = (("VR", "RV", "V")[len(qs) % 3], (len(qs) + 1) % 3, len(qs) % 8 == 0)       # collapsing under a value sort
+    c.close()
+    assert len(qs) >= 12
+    qf = str(d / "qs5.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["answered_on_device"] == 0, out               # default: declined
+    out = run_b1("--collapse-intended", qf, one)
+    assert out["mismatches"] == 0 and out["answered_collapsed"] == len(qs), out

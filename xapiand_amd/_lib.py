@@ -156,6 +156,8 @@ _API = [
     ("xgm_debug_or_bounds", C.c_int, [C.c_void_p, _P(Query), _P(C.c_double), _P(C.c_double), _P(C.c_double)]),
     ("xgm_debug_last_units", C.c_int64, [C.c_void_p, _P(C.c_ulonglong), C.c_uint64]),
     ("xgm_debug_last_units2", C.c_int64, [C.c_void_p, _P(C.c_ulonglong), _P(C.c_ulonglong), C.c_uint64]),
+    ("xgm_mset_bounds_known", None, [_P(Query), _P(ResultHdr), C.c_uint64, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
+    ("xgm_index_attach_column_ordinals", C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]

@@ -267,6 +267,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
     for (auto& c : idx->columns) if (c.second.first) hipFree(c.second.first);
+    for (void* c : idx->retired_columns) hipFree(c);
     delete idx;
 }
 
@@ -974,6 +975,8 @@ static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, ui
  * switched off); the units' candidates come back to the host, which merges them
  * under the same comparison the kernel ranks by. */
 
+static int attach_ordinals(xgm_index* idx, uint32_t slot, const uint32_t* ord, size_t n_ord, uint32_t n_distinct);
+
 extern "C" int xgm_index_attach_column(xgm_index* idx, const char* column_path) {
     if (!idx || !column_path) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
@@ -988,17 +991,31 @@ extern "C" int xgm_index_attach_column(xgm_index* idx, const char* column_path) 
     fclose(f);
     if (!ok) return xgm_set_error(XGM_E_INVALID, "%s is not a column file", column_path);
     for (uint32_t o : ord) if (o > h32[2]) return xgm_set_error(XGM_E_INVALID, "%s: ordinal beyond the distinct values", column_path);
+    return attach_ordinals(idx, h32[0], ord.data(), ord.size(), h32[2]);
+}
+
+/* A replaced column's device array is not freed while searches that copied its pointer may still be launching with it: it
+ * goes to the index's graveyard, emptied when the index closes. */
+static int attach_ordinals(xgm_index* idx, uint32_t slot, const uint32_t* ord, size_t n_ord, uint32_t n_distinct) {
     int rc = use_device(idx->device);
     if (rc) return rc;
     void* d = nullptr;
-    HIP_TRY(hipMalloc(&d, ord.size() * 4));
-    hipError_t e = hipMemcpy(d, ord.data(), ord.size() * 4, hipMemcpyHostToDevice);
+    HIP_TRY(hipMalloc(&d, n_ord * 4));
+    hipError_t e = hipMemcpy(d, ord, n_ord * 4, hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return xgm_launch_error("column upload", (int)e, hipGetErrorString(e)); }
     std::lock_guard<std::mutex> lk(idx->columns_mu);
-    std::pair<void*, uint32_t>& slot = idx->columns[h32[0]];
-    if (slot.first) hipFree(slot.first);
-    slot = std::make_pair(d, h32[2]);
+    std::pair<void*, uint32_t>& col = idx->columns[slot];
+    if (col.first) idx->retired_columns.push_back(col.first);
+    col = std::make_pair(d, n_distinct);
     return XGM_OK;
+}
+
+extern "C" int xgm_index_attach_column_ordinals(xgm_index* idx, uint32_t slot, const uint32_t* ord, uint32_t n_ord, uint32_t n_distinct) {
+    if (!idx || !ord) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    if (n_ord != idx->hdr.lastdocid + 1u) return xgm_set_error(XGM_E_INVALID, "column of %u entries, index of %u documents (another revision?)", n_ord, idx->hdr.lastdocid);
+    for (uint32_t i = 0; i < n_ord; ++i) if (ord[i] > n_distinct) return xgm_set_error(XGM_E_INVALID, "ordinal beyond the distinct values");
+    return attach_ordinals(idx, slot, ord, n_ord, n_distinct);
 }
 
 namespace {
@@ -1025,7 +1042,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     if (!idx || !q || !hits || !hdr) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
     if (sort && (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE)) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
-    if (!sort && collapse_slot < 0) return xgm_set_error(XGM_E_INVALID, "neither a sort nor a collapse key");
+    if (!sort && collapse_slot < 0 && spy_slot < 0) return xgm_set_error(XGM_E_INVALID, "neither a sort nor a collapse key nor a spy");
     if (collapse_slot >= 0 && (cmax == 0 || spy_slot >= 0)) return xgm_set_error(XGM_E_INVALID, "collapse_max 0, or a spy together with a collapse key");
     const uint32_t mode = sort ? sort->sort_by : 4u;
     const bool reverse = sort && sort->reverse;
@@ -1151,7 +1168,6 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
 
 extern "C" int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                                      xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts) {
-    if (!sort || sort->sort_by == XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "a spy's counts are defined where the value leads the sort");
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, (int)spy_slot, counts, n_counts);
 }
 

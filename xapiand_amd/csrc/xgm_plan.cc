@@ -700,20 +700,40 @@ extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, con
     return XGM_OK;
 }
 
-extern "C" void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper) {
+/* ProtoMSet::finalise (protomset.h:484-619) without collapsing / decider / percent cut-off, given the matcher's known_matching_docs
+ * (`known`; `known_exact`: it is the exact number of matching documents, i.e. the matcher never skipped a document by weight). */
+static void mset_bounds_from(const xgm_query* plan, const xgm_result_hdr* hdr, uint64_t known, bool known_exact, uint32_t* lower, uint32_t* estimated,
+                             uint32_t* upper) {
     uint32_t lb = plan->est_min, est = plan->est_est, ub = plan->est_max;
     const uint32_t want = plan->first + plan->maxitems;
     if (hdr->n_hits < want) {
         /* ProtoMSet not full: we got all there are (protomset.h:497-503) */
         lb = est = ub = hdr->n_hits;
+    } else if (known_exact && known < plan->check_at_least) {
+        /* full, but fewer matching documents than the caller asked to have looked at: the matcher saw every one of them before any
+         * weight pruning could start (min_weight stays 0 until checked_enough(), protomset.h:122-126) — the count is exact
+         * (protomset.h:515-519) */
+        lb = est = ub = (uint32_t)known;
     } else {
-        const uint32_t known = hdr->n_hits;                 /* stand-in for known_matching_docs (see xgm.h) */
-        if (known > lb) lb = known;
-        if (known > est) est = known;
+        const uint32_t k32 = known > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)known;
+        if (k32 > lb) lb = k32;
+        if (k32 > est) est = k32;
         if (est < lb) est = lb;
         if (ub < est) ub = est;
     }
     if (lower) *lower = lb;
     if (estimated) *estimated = est;
     if (upper) *upper = ub;
+}
+
+extern "C" void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper) {
+    const bool exact = !(hdr->matches_exact & XGM_MATCHES_LOWER_BOUND);
+    const uint64_t m = XGM_MATCHES_COUNT(hdr->matches_exact);
+    if (exact && m < plan->check_at_least) { mset_bounds_from(plan, hdr, m, true, lower, estimated, upper); return; }
+    mset_bounds_from(plan, hdr, hdr->n_hits, false, lower, estimated, upper);         /* stand-in for known_matching_docs (see xgm.h) */
+}
+
+extern "C" void xgm_mset_bounds_known(const xgm_query* plan, const xgm_result_hdr* hdr, uint64_t known_matching_docs, uint32_t* lower,
+                                      uint32_t* estimated, uint32_t* upper) {
+    mset_bounds_from(plan, hdr, known_matching_docs, true, lower, estimated, upper);
 }
