@@ -345,6 +345,8 @@ class MSet:
 
 def _desc(query, first, maxitems, check_at_least, weight):
     n = len(query.terms)
+    if n > _lib.XGM_MAX_TERMS:
+        raise Unsupported("too many terms")
     d = _lib.QueryDesc()
     if query.op == Query.LEAF_TERM:
         d.op = _lib.XGM_OP_AND
@@ -360,8 +362,6 @@ def _desc(query, first, maxitems, check_at_least, weight):
             d.wqf[i] = w
     else:
         d.op = Query._OPS[query.op]
-    if n > _lib.XGM_MAX_TERMS:
-        raise Unsupported("too many terms")
     d.n_terms = n
     for i, t in enumerate(query.terms):
         d.terms[i] = t
@@ -542,7 +542,7 @@ class Enquire:
             h = _lib.Hit()
             h.docid, h.weight, h.subqs_matched = d, w, m
             hits.append(h)
-        mset = MSet(p.first, hits, hdr, self._query.total_subqs())
+        mset = MSet(p.first, hits, hdr, p.total_subqs if self._query.op == "TREE" else self._query.total_subqs())
         svals = db.column_values(sort[1]) if sort else None
         cvals = db.column_values(collapse[0]) if collapse else None
         for item, (_, _, _, o, co, cc) in zip(mset._items, rows[p.first:]):
@@ -602,8 +602,10 @@ def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None)
     (host side here; the multi-GPU path does the same merge on device after the RCCL all-gather)."""
     gs = merged_stats(dbs, query)
     per = []
+    tree_subqs = 0
     for db in dbs:
         p = plan(db, query, 0, first + maxitems, check_at_least, weight, gs)
+        tree_subqs = max(tree_subqs, p.total_subqs)          # (the matcher takes the largest answer amongst the shards, matcher.cc:385-388)
         (hits, hdr), = search_batch(db, [p])
         per.append((hits, hdr))
     n_shards = len(dbs)
@@ -622,4 +624,4 @@ def get_mset_sharded(dbs, query, first, maxitems, check_at_least=0, weight=None)
     allhits.sort(key=lambda x: (-x.weight, x.docid))
     allhits = allhits[: first + maxitems]
     hdr.n_hits = len(allhits)
-    return MSet(first, allhits, hdr, query.total_subqs())
+    return MSet(first, allhits, hdr, tree_subqs if query.op == "TREE" else query.total_subqs())
