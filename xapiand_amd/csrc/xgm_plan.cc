@@ -729,7 +729,7 @@ static void mset_bounds_from(const xgm_query* plan, const xgm_result_hdr* hdr, u
 extern "C" void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t* lower, uint32_t* estimated, uint32_t* upper) {
     const bool exact = !(hdr->matches_exact & XGM_MATCHES_LOWER_BOUND);
     const uint64_t m = XGM_MATCHES_COUNT(hdr->matches_exact);
-    if (exact && m < plan->check_at_least) { mset_bounds_from(plan, hdr, m, true, lower, estimated, upper); return; }
+    if (exact && m >= hdr->n_hits && m < plan->check_at_least) { mset_bounds_from(plan, hdr, m, true, lower, estimated, upper); return; }
     mset_bounds_from(plan, hdr, hdr->n_hits, false, lower, estimated, upper);         /* stand-in for known_matching_docs (see xgm.h) */
 }
 
