@@ -81,6 +81,12 @@ extern "C" {
 #define XGM_T_FILTER 5
 #define XGM_T_SYNONYM 6
 #define XGM_T_SCALE 7
+/* OP_WILDCARD expanded by the caller (xgm_expand_prefix) over terms: its OP_SYNONYM form is a synonym group that is never
+ * simplified to its only term (QueryWildcard::postlist wraps even one expansion in a SynonymPostList, api/queryinternal.cc:1441-
+ * 1480; an explicit OP_SYNONYM of one term IS that term, QuerySynonym::done), its OP_OR form an OR tree of its own that an
+ * enclosing OR does not flatten (QueryWildcard has no postlist_sub_or_like: queryinternal.cc:935-941) */
+#define XGM_T_WILDCARD 8
+#define XGM_T_WILDCARD_OR 9
 typedef struct { uint8_t kind, arity; uint16_t term; } xgm_tree_op;
 
 typedef struct xgm_index xgm_index; /* opaque: device-resident segment of ONE shard revision */
@@ -236,6 +242,16 @@ int xgm_lookup_term(const xgm_index*, const char* term, size_t len, uint32_t* te
 /* Bulk per-term statistics for the cross-shard stats merge (Weight::Internal::operator+=,
  * reference src/xapian/weight/weightinternal.cc:55-71): copies termfreq[n_terms] (host). */
 int xgm_index_termfreqs(const xgm_index*, uint32_t* termfreq, uint32_t cap);
+
+/* OP_WILDCARD with a fixed prefix ("prefix*": Xapiand's DSL emits it for `*` values and partial terms, reference
+ * src/query_dsl.cc:305, 634, 668, 724): the shard's terms that start with `prefix`, in the term order the reference's
+ * Context<T>::expand_wildcard walks (db.open_allterms(prefix), src/xapian/api/queryinternal.cc:246-315).  Writes the first
+ * min(cap, *n_total) term ids; *n_total = how many there are.  The caller applies the wildcard's limit (WILDCARD_LIMIT_ERROR /
+ * _FIRST / _MOST_FREQUENT) and lowers the set to an OP_SYNONYM group, which the device weighs as the reference's
+ * SynonymPostList does (QueryWildcard::postlist, queryinternal.cc:1441-1495). */
+int xgm_expand_prefix(const xgm_index*, const char* prefix, size_t len, uint32_t cap, uint32_t* term_ids, uint32_t* n_total);
+/* bytes (borrowed, valid while the index is open), termfreq and collection frequency of a term id */
+int xgm_term_info(const xgm_index*, uint32_t term_id, const char** bytes, size_t* len, uint32_t* termfreq, uint32_t* collfreq);
 
 /* ---- query planning (host) --------------------------------------------------------------------*/
 

@@ -43,8 +43,66 @@ std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0},
 struct Lowered {
     xgm_query_desc d;
     std::vector<std::string> terms;     /* owns the bytes d.terms[] points at */
+    std::vector<bool> lazy;              /* terms[i] came out of a wildcard expansion (LocalSubMatch::open_post_list, lazy_weight) */
     uint32_t total_subqs = 0;            /* weighted leaves: what QueryOptimiser::inc_total_subqs counts */
+    const xgm_index* idx = nullptr;      /* the shard: wildcards expand over ITS dictionary, as qopt->db.open_allterms does */
 };
+
+/* OP_WILDCARD "prefix*" → an OP_SYNONYM (or OP_OR) group over the shard's terms with that prefix, limits applied as
+ * Context<T>::expand_wildcard does (api/queryinternal.cc:246-315).  false = leave the query to the CPU matcher: extended
+ * wildcards, OP_MAX, an expansion the reference would refuse (WILDCARD_LIMIT_ERROR), none or more than the device's leaves,
+ * or a most-frequent cut through a tie of term frequencies (std::nth_element leaves the choice unspecified). */
+bool lower_wildcard(const Xapian::Query& q, Lowered* L) {
+    const auto* w = static_cast<const Xapian::Internal::QueryWildcard*>(q.internal.get());
+    if (!w || !L->idx || w->get_just_flags() != 0) return false;
+    std::string ser;
+    w->serialise(ser);                                  /* 0x0b, max_expansion, flags, combiner, pattern (queryinternal.cc:1507-1514) */
+    const char* p = ser.data() + 1;
+    const char* end = ser.data() + ser.size();
+    Xapian::termcount max_expansion;
+    if (ser.size() < 4 || !unpack_uint(&p, end, &max_expansion) || end - p < 2) return false;
+    const Xapian::Query::op combiner = Xapian::Query::op((unsigned char)p[1]);
+    if (combiner != Xapian::Query::OP_SYNONYM && combiner != Xapian::Query::OP_OR) return false;
+    const std::string pattern = w->get_pattern();
+    uint32_t n_total = 0;
+    std::vector<uint32_t> ids(XGM_MAX_TERMS + 1);
+    if (xgm_expand_prefix(L->idx, pattern.data(), pattern.size(), (uint32_t)ids.size(), ids.data(), &n_total) != XGM_OK || n_total == 0) return false;
+    uint32_t n = n_total;
+    const int max_type = w->get_max_type();
+    if (max_expansion != 0 && n_total > max_expansion) {
+        if (max_type == Xapian::Query::WILDCARD_LIMIT_FIRST) {
+            n = max_expansion;
+        } else if (max_type == Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT) {
+            if (combiner != Xapian::Query::OP_SYNONYM) return false;       /* the OR tree's tie order would follow nth_element's permutation */
+            ids.resize(n_total);
+            if (xgm_expand_prefix(L->idx, pattern.data(), pattern.size(), n_total, ids.data(), &n_total) != XGM_OK) return false;
+            std::vector<std::pair<uint32_t, uint32_t>> by_tf;              /* (termfreq, id) */
+            for (uint32_t i = 0; i < n_total; ++i) { uint32_t tf = 0; xgm_term_info(L->idx, ids[i], nullptr, nullptr, &tf, nullptr); by_tf.emplace_back(tf, ids[i]); }
+            std::sort(by_tf.begin(), by_tf.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
+            if (by_tf[max_expansion - 1].first == by_tf[max_expansion].first) return false;
+            n = max_expansion;
+            for (uint32_t i = 0; i < n; ++i) ids[i] = by_tf[i].second;
+        } else {
+            return false;                                                  /* WILDCARD_LIMIT_ERROR: the CPU matcher throws WildcardError */
+        }
+    }
+    xgm_query_desc& d = L->d;
+    if (n > XGM_MAX_TERMS || L->terms.size() + n > XGM_MAX_TERMS || d.n_tree + n + 1 > XGM_MAX_TREE || n > 255) return false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const char* b = nullptr; size_t bl = 0;
+        if (xgm_term_info(L->idx, ids[i], &b, &bl, nullptr, nullptr) != XGM_OK) return false;
+        d.wqf[L->terms.size()] = 1;
+        d.tree[d.n_tree].kind = XGM_T_TERM; d.tree[d.n_tree].arity = 0; d.tree[d.n_tree].term = (uint16_t)L->terms.size();
+        ++d.n_tree;
+        L->terms.emplace_back(b, bl);
+        L->lazy.resize(L->terms.size(), false);
+        L->lazy.back() = true;
+    }
+    d.tree[d.n_tree].kind = combiner == Xapian::Query::OP_SYNONYM ? XGM_T_WILDCARD : XGM_T_WILDCARD_OR;
+    d.tree[d.n_tree].arity = (uint8_t)n; d.tree[d.n_tree].term = 0;
+    ++d.n_tree;
+    return true;
+}
 
 /* a leaf the device path takes: a term with wqf 1 (MatchAll and scaled leaves are declined) */
 bool leaf_term(const Xapian::Query& q, std::string* term) {
@@ -81,6 +139,7 @@ bool lower_tree_node(const Xapian::Query& q, Lowered* L) {
         L->terms.push_back(t->get_term());
         return true;
     }
+    if (op == Xapian::Query::OP_WILDCARD) return lower_wildcard(q, L);
     uint8_t kind;
     switch (op) {
     case Xapian::Query::OP_AND: kind = XGM_T_AND; break;
@@ -161,6 +220,7 @@ bool lower(const Xapian::Query& q, Lowered* L) {
     if (lower_flat(q, L)) return true;
     memset(&L->d, 0, sizeof L->d);
     L->terms.clear();
+    L->lazy.clear();
     if (!lower_tree_node(q, L)) return false;
     L->d.op = XGM_OP_TREE;
     L->total_subqs = 0;                     /* comes back from the planner (xgm_query.total_subqs) */
@@ -299,8 +359,6 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         if (!spy_slot_of(*sp, &pl.slot, &pl.adapter)) { ++g_shape; return false; }
         spies.push_back(pl);
     }
-    Lowered L;
-    if (!lower(query, &L)) { ++g_shape; return false; }
     Shard sh;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -309,6 +367,9 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         sh = it->second;
     }
     if (sh.revision != db.get_revision()) { ++g_rev; return false; }      /* the segment is of another revision: CPU until refreshed */
+    Lowered L;
+    L.idx = sh.idx;
+    if (!lower(query, &L)) { ++g_shape; return false; }
 
     /* BM25 parameters: the scheme's own serialisation (bm25weight.cc:145-153) */
     {
@@ -328,8 +389,12 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     gs.full_db_has_positions = full_db_has_positions ? 1u : 0u;
     for (size_t i = 0; i < L.terms.size(); ++i) {
         auto it = stats.termfreqs.find(L.terms[i]);
-        if (it == stats.termfreqs.end()) { ++g_shape; return false; }
-        gs.termfreq[i] = it->second.termfreq;
+        if (it != stats.termfreqs.end()) { gs.termfreq[i] = it->second.termfreq; continue; }
+        /* a term out of a wildcard expansion that the query does not name: the matcher registers it with THIS shard's
+         * frequencies when it opens the posting list (LocalSubMatch::open_post_list, lazy_weight: localsubmatch.cc:283-292) */
+        uint32_t tf = 0;
+        if (!(i < L.lazy.size() && L.lazy[i]) || xgm_lookup_term(sh.idx, L.terms[i].data(), L.terms[i].size(), nullptr, &tf, nullptr, nullptr) != XGM_OK) { ++g_shape; return false; }
+        gs.termfreq[i] = tf;
     }
 
     const uint32_t k = first + maxitems;

@@ -164,6 +164,13 @@ Xapian::Query make_query(const QuerySpec& q) {
                 if (st.empty()) { fprintf(stderr, "bad RPN: SCALE needs 1\n"); exit(2); }
                 Xapian::Query r(Xapian::Query::OP_SCALE_WEIGHT, st.back(), strtod(tok.c_str() + 1, nullptr));
                 st.back() = r;
+            } else if (c == '~') {
+                /* "~prefix[,max_expansion,limit F|M|E[,combiner S|O]]": OP_WILDCARD "prefix*" (Xapiand's DSL: query_dsl.cc:305, 634, 724) */
+                char pre[64] = {0}, lim = 'E', comb = 'S';
+                unsigned mx = 0;
+                sscanf(tok.c_str() + 1, "%63[^,],%u,%c,%c", pre, &mx, &lim, &comb);
+                const int flags = lim == 'F' ? Xapian::Query::WILDCARD_LIMIT_FIRST : lim == 'M' ? Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT : Xapian::Query::WILDCARD_LIMIT_ERROR;
+                st.emplace_back(Xapian::Query::OP_WILDCARD, std::string(pre), mx, flags, comb == 'O' ? Xapian::Query::OP_OR : Xapian::Query::OP_SYNONYM);
             } else {
                 const size_t h = tok.find('#');
                 const unsigned wqf = h == std::string::npos ? 1u : (unsigned)strtoul(tok.c_str() + h + 1, nullptr, 10);

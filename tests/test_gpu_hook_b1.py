@@ -205,3 +205,28 @@ def test_collapse_through_the_hook(built, glass_values):
     assert out["mismatches"] == 0 and out["answered_on_device"] == 0, out               # default: declined
     out = run_b1("--collapse-intended", qf, one)
     assert out["mismatches"] == 0 and out["answered_collapsed"] == len(qs), out
+
+
+def wildcard_queries():
+    """OP_WILDCARD "prefix*" (Xapiand's DSL: reference src/query_dsl.cc:305, 634, 668, 724) alone and inside trees, with the three
+    expansion limits; the driver's RPN token is "~prefix,max_expansion,F|M|E[,S|O]"."""
+    qs = []
+    for pre in ("t123", "t77", "t19", "t2500", "t9", "t1999"):
+        for lim in ("8,F", "5,M", "0,E", "12,F,O"):
+            qs.append(dict(op="RPN", terms=["~%s,%s" % (pre, lim)], first=0, maxitems=10, window=0))
+            qs.append(dict(op="RPN", terms=["t5", "~%s,%s" % (pre, lim), "&2"], first=0, maxitems=10, window=0))
+            qs.append(dict(op="RPN", terms=["t40", "~%s,%s" % (pre, lim), "t300", "|3"], first=3, maxitems=12, window=0))
+    qs.append(dict(op="RPN", terms=["~t12,3,E"], first=0, maxitems=10, window=0))           # more than 3 terms: the reference throws WildcardError
+    return qs
+
+
+def test_wildcards_through_the_hook(built, glass):
+    d, one, shards = glass
+    qs = wildcard_queries()
+    qf = str(d / "qw.txt")
+    H.write_queries(qf, qs[:-1])
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] >= len(qs) // 2, out           # the rest: expansions beyond the device's leaves, ties under MOST_FREQUENT
+    out3 = run_b1(qf, *shards)
+    assert out3["mismatches"] == 0 and out3["answered_on_device"] >= len(qs), out3     # (3 shards: >= a third of 3 * n)

@@ -158,6 +158,8 @@ _API = [
     ("xgm_debug_last_units2", C.c_int64, [C.c_void_p, _P(C.c_ulonglong), _P(C.c_ulonglong), C.c_uint64]),
     ("xgm_mset_bounds_known", None, [_P(Query), _P(ResultHdr), C.c_uint64, _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32)]),
     ("xgm_index_attach_column_ordinals", C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32]),
+    ("xgm_expand_prefix", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
+    ("xgm_term_info", C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_char_p), _P(C.c_size_t), _P(C.c_uint32), _P(C.c_uint32)]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]

@@ -399,6 +399,56 @@ extern "C" int xgm_lookup_term(const xgm_index* idx, const char* term, size_t le
     return XGM_OK;
 }
 
+/* ---- OP_WILDCARD: prefix expansion over the host dictionary (reference Context<T>::expand_wildcard, api/queryinternal.cc:246-315,
+ * walks db.open_allterms(prefix) in term order).  Term ids need not follow byte order (the synthetic builder numbers terms by
+ * rank): a byte-ordered permutation of the ids is made on first use. */
+static void build_term_order(xgm_index* idx) {
+    const uint32_t T = idx->hdr.n_terms;
+    const uint64_t* so = idx->str_off.data();
+    const char* sb = idx->str_bytes.data();
+    idx->term_order.resize(T);
+    for (uint32_t i = 0; i < T; ++i) idx->term_order[i] = i;
+    auto less = [&](uint32_t a, uint32_t b) {
+        const size_t la = (size_t)(so[a + 1] - so[a]), lb = (size_t)(so[b + 1] - so[b]);
+        const int c = memcmp(sb + so[a], sb + so[b], std::min(la, lb));
+        return c != 0 ? c < 0 : la < lb;
+    };
+    if (!std::is_sorted(idx->term_order.begin(), idx->term_order.end(), less)) std::sort(idx->term_order.begin(), idx->term_order.end(), less);
+}
+
+extern "C" int xgm_expand_prefix(const xgm_index* cidx, const char* prefix, size_t len, uint32_t cap, uint32_t* term_ids, uint32_t* n_total) {
+    xgm_index* idx = const_cast<xgm_index*>(cidx);
+    if (!idx || (!prefix && len) || !n_total || (cap && !term_ids)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    std::call_once(idx->term_order_once, build_term_order, idx);
+    const uint64_t* so = idx->str_off.data();
+    const char* sb = idx->str_bytes.data();
+    /* first term >= prefix in byte order; the expansion is the run of terms that start with it */
+    auto below = [&](uint32_t t, int) {
+        const size_t lt = (size_t)(so[t + 1] - so[t]);
+        const int c = memcmp(sb + so[t], prefix, std::min(lt, len));
+        return c != 0 ? c < 0 : lt < len;
+    };
+    auto it = std::lower_bound(idx->term_order.begin(), idx->term_order.end(), 0, below);
+    uint32_t n = 0;
+    for (; it != idx->term_order.end(); ++it) {
+        const uint32_t t = *it;
+        if ((size_t)(so[t + 1] - so[t]) < len || memcmp(sb + so[t], prefix, len) != 0) break;
+        if (n < cap) term_ids[n] = t;
+        ++n;
+    }
+    *n_total = n;
+    return XGM_OK;
+}
+
+extern "C" int xgm_term_info(const xgm_index* idx, uint32_t term_id, const char** bytes, size_t* len, uint32_t* termfreq, uint32_t* collfreq) {
+    if (!idx || term_id >= idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "no such term id");
+    if (bytes) *bytes = idx->str_bytes.data() + idx->str_off[term_id];
+    if (len) *len = (size_t)(idx->str_off[term_id + 1] - idx->str_off[term_id]);
+    if (termfreq) *termfreq = idx->term_df[term_id];
+    if (collfreq) *collfreq = idx->term_cf[term_id];
+    return XGM_OK;
+}
+
 extern "C" int xgm_index_termfreqs(const xgm_index* idx, uint32_t* termfreq, uint32_t cap) {
     if (!idx || !termfreq) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (cap < idx->hdr.n_terms) return xgm_set_error(XGM_E_INVALID, "buffer too small");

@@ -360,6 +360,16 @@ struct TreePlanner {
             if (terms.size() == 1) return leaf(terms[0], factor);          /* QuerySynonym::done */
             return synonym(terms, factor);
         }
+        case XGM_T_WILDCARD: {                                             /* QueryWildcard::postlist, OP_SYNONYM combiner: always a SynonymPostList */
+            std::vector<int> terms;
+            for (int k : n.kids) terms.push_back(ast[k].term);
+            return synonym(terms, factor);
+        }
+        case XGM_T_WILDCARD_OR: {                                          /* ... OP_OR combiner: an OrContext of its own */
+            std::vector<int> ctx;
+            for (int k : n.kids) ctx.push_back(leaf(ast[k].term, factor));
+            return rc ? -1 : or_tree(ctx);
+        }
         }
         rc = XGM_UNSUPPORTED;
         return -1;
@@ -400,13 +410,14 @@ int plan_tree(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_st
             nd.term = d->tree[i].term;
         } else {
             const uint32_t ar = nd.kind == XGM_T_SCALE ? 1u : d->tree[i].arity;
-            if (nd.kind > XGM_T_SCALE || ar == 0 || stack.size() < ar) return xgm_set_error(XGM_E_INVALID, "malformed query tree");
+            if (nd.kind > XGM_T_WILDCARD_OR || ar == 0 || stack.size() < ar) return xgm_set_error(XGM_E_INVALID, "malformed query tree");
             if (nd.kind == XGM_T_FILTER && ar != 2) return xgm_set_error(XGM_E_INVALID, "FILTER takes two subqueries");
             if ((nd.kind == XGM_T_AND_NOT || nd.kind == XGM_T_AND_MAYBE) && ar < 2) return xgm_set_error(XGM_E_INVALID, "AND_NOT / AND_MAYBE take a left and a right side");
             nd.kids.assign(stack.end() - ar, stack.end());
             stack.resize(stack.size() - ar);
             if (nd.kind == XGM_T_SCALE) { nd.scale = d->tree_scale[i]; if (!(nd.scale > 0.0)) return XGM_UNSUPPORTED; }   /* a zero scale makes the subtree boolean */
-            if (nd.kind == XGM_T_SYNONYM) for (int k : nd.kids) if (tp.ast[k].kind != XGM_T_TERM) return XGM_UNSUPPORTED;
+            if (nd.kind == XGM_T_SYNONYM || nd.kind == XGM_T_WILDCARD || nd.kind == XGM_T_WILDCARD_OR)
+                for (int k : nd.kids) if (tp.ast[k].kind != XGM_T_TERM) return XGM_UNSUPPORTED;
         }
         tp.ast.push_back(nd);
         stack.push_back((int)tp.ast.size() - 1);
