@@ -373,13 +373,25 @@ void xgm_mset_bounds(const xgm_query* plan, const xgm_result_hdr* hdr, uint32_t*
  * that number is the exact match count (hdr->matches_exact) and the three figures are the reference's. */
 void xgm_mset_bounds_known(const xgm_query* plan, const xgm_result_hdr* hdr, uint64_t known_matching_docs, uint32_t* lower, uint32_t* estimated,
                            uint32_t* upper);
+/* known_matching_docs of the reference's matcher for a search by relevance over operators that visit every matching document (a term,
+ * AND, FILTER, AND_NOT, PHRASE, NEAR), from the weights of ALL matching documents in ascending docid order.  A document counts when
+ * its weight is >= min_weight (matcher.cc:500-505 `if (weight < min_weight) continue`, then ProtoMSet::add counts it); min_weight is 0
+ * until ProtoMSet holds max_size = first + maxitems documents and check_at_least have been counted, and is then the weight of the worst
+ * document kept — set when the heap is made (the (max_size + 1)-th document) and afterwards only by a document that REPLACES the worst
+ * (protomset.h:340-400), so with check_at_least beyond the page it starts at the first replacement after check_at_least documents.
+ * check_at_least as Enquire::get_mset clamps it.  Pinned to the compiled reference's own figures by
+ * tests/test_oracle_vs_reference.py::test_known_matching_docs_is_a_function_of_the_match_in_docid_order. */
+uint64_t xgm_known_matching_docs(const double* weights_in_docid_order, uint64_t n, uint32_t max_size, uint32_t check_at_least);
+/* MSet::get_matches_estimated(): the estimate as the API reports it — rounded to the significant figures the bounds justify
+ * (reference src/xapian/api/roundestimate.h:36-69).  Xapiand's HTTP "total" field is this number (src/server/http_client.cc:2554). */
+uint32_t xgm_round_estimate(uint32_t lower, uint32_t upper, uint32_t estimated);
 
 /* One query on one shard: hits[0 .. first+maxitems) sorted by (weight desc, docid asc) — the order
  * of msetcmp_by_relevance<true> (reference src/xapian/matcher/msetcmp.cc:55-62); the caller drops
  * the first `first`.  Replaces the hot loop of Matcher::get_local_mset + ProtoMSet. */
 int xgm_search(xgm_index*, const xgm_query*, xgm_hit* hits, xgm_result_hdr* hdr);
 
-/* ---- searches under a value sort (widening row (f).3; first version: written in round 2, NOT yet run on a GPU) ----------- */
+/* ---- searches under a value sort, with spies, collapsed (widening row (f).3; on the MI355X since round 3) ------------------ */
 
 /* Load the ordinals of a column file (xgm_glass_export_column) into HBM next to the index: 4 bytes per document.  The column's
  * lastdocid must be the index's (same shard revision).  Attaching a slot again replaces it. */

@@ -36,7 +36,7 @@ struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumn
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
 std::map<std::string, SpyAdapter> g_spy_adapters;
-std::atomic<bool> g_enabled{true};
+std::atomic<bool> g_enabled{true}, g_exact_bounds{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
 std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0};
 
@@ -323,6 +323,7 @@ void unregister_shard(const Xapian::Database& db) {
 void set_enabled(bool on) { g_enabled.store(on); }
 void set_positional_mode(PositionalMode m) { g_positional.store(int(m)); }
 void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
+void set_exact_bounds(bool on) { g_exact_bounds.store(on); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_spy_adapters[spy_class_name] = std::move(adapter);
@@ -496,8 +497,32 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
      * returned stands in for it (what known_matching_docs is under weight pruning). */
     uint32_t lb = 0, est = 0, ub = 0;
     const uint64_t m_all = XGM_MATCHES_COUNT(hdr.matches_exact);
-    if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
-    else xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
+    const bool every_match_visited = L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT;     /* (positional: the frozen weight) */
+    if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
+        xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
+    } else if (plain && g_exact_bounds.load(std::memory_order_relaxed) && every_match_visited && k > 0 && hdr.n_hits == k &&
+               !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least && m_all <= XGM_MAX_K) {
+        /* known_matching_docs is a function of the match in docid order (xgm_known_matching_docs): fetch the whole match — it fits one
+         * device page — and report the reference's own figures */
+        xgm_query_desc d2 = L.d;
+        d2.first = 0; d2.maxitems = (uint32_t)m_all;
+        xgm_query plan2;
+        std::vector<xgm_hit> all(m_all);
+        xgm_result_hdr hdr2;
+        memset(&hdr2, 0, sizeof hdr2);
+        int rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
+        if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, (uint32_t)m_all, all.data(), &hdr2);
+        if (rc2 == XGM_OK && hdr2.n_hits == m_all) {
+            std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+            std::vector<double> w(m_all);
+            for (size_t i = 0; i < all.size(); ++i) w[i] = all[i].weight;
+            xgm_mset_bounds_known(&plan, &hdr, xgm_known_matching_docs(w.data(), w.size(), k, plan.check_at_least), &lb, &est, &ub);
+        } else {
+            xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
+        }
+    } else {
+        xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
+    }
     uint32_t ulb = lb, uest = est, uub = ub;
     if (collapse_max != 0) {
         /* ProtoMSet::finalise with a collapser that considered every matching document (protomset.h:497-619): docs_considered = the

@@ -64,11 +64,11 @@ void set_enabled(bool on);                 /* default: on */
  * (src/xapian/matcher/selectpostlist.cc:28-55) and its top-k is then not a prefix of its own full ranking; the device returns
  * the intended top-k.  The choice is the deployment's and has to be made:
  *   POSITIONAL_DECLINE  — positional queries stay on the CPU matcher (byte-compatible by construction);
- *   POSITIONAL_INTENDED — answered on the device with the intended semantics;
- *   POSITIONAL_REFERENCE — answered on the device and, when the match exceeds the page, the reference's frozen-weight behaviour is
- *     replayed on the host from the device's docid-ordered list of matches (byte-compatible with the CPU matcher).
- * Until set_positional_mode has been called positional queries are declined. */
-enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1, POSITIONAL_REFERENCE = 2 };
+ *   POSITIONAL_INTENDED — answered on the device with the intended semantics.
+ * Until set_positional_mode has been called positional queries are declined.  (Replaying the quirk from the device's results
+ * would need the weight of the first document of the underlying CONJUNCTION after the proto-MSet filled — the value the
+ * reference freezes — which no positional search returns) */
+enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1 };
 void set_positional_mode(PositionalMode m);
 inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONAL_DECLINE : POSITIONAL_INTENDED); }
 
@@ -78,6 +78,17 @@ inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONA
  *   COLLAPSE_INTENDED — answered on the device: per key the best collapse_max documents under the ranking in force. */
 enum CollapseMode { COLLAPSE_DECLINE = 0, COLLAPSE_INTENDED = 1 };
 void set_collapse_mode(CollapseMode m);
+
+/* MSet::get_matches_lower_bound / _estimated by relevance.  The reference derives them from known_matching_docs — how many
+ * documents reached ProtoMSet::add, i.e. passed `weight >= min_weight` in the matcher's loop (matcher.cc:500-505), where
+ * min_weight is the k-th best weight so far once check_at_least documents have been seen.  For the operators that visit every
+ * match whatever min_weight is (a term, AND, FILTER, AND_NOT, PHRASE, NEAR: MultiAndPostList / SelectPostList / AndNotPostList
+ * ignore w_min) that number is a function of the match in docid order (xgm_known_matching_docs); OR and AND_MAYBE skip
+ * documents by weight inside the posting-list tree (orpostlist.cc:35-204), there it is a property of the traversal.
+ * With exact bounds ON the hook, for a full page of those operators whose match is at most XGM_MAX_K documents, fetches the whole
+ * match in a second device search and reports the reference's own figures; otherwise (and when OFF, the default) the number of
+ * documents returned stands in (valid bounds, possibly looser). */
+void set_exact_bounds(bool on);
 
 /* A MatchSpy class the hook does not know natively: the server tells it which value slot the spy counts and how to hand it the
  * counts of a finished search (total = matching documents, counts = (value, documents) in ascending value order — exactly what the

@@ -45,11 +45,11 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
 
 int main(int argc, char** argv) {
     int a = 1;
-    bool stale = false;
+    bool stale = false, exact_bounds_on = false;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
-        else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);
+        else if (!strcmp(argv[a], "--exact-bounds")) { xgm_hook::set_exact_bounds(true); exact_bounds_on = true; }
         else if (!strcmp(argv[a], "--collapse-intended")) xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_INTENDED);
         else if (!strcmp(argv[a], "--stale")) stale = true;
     }
@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
             /* ... until the refreshed segments (keyed by the new revision) are registered */
             for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i], first_changed[i])) return 1; ++refreshed; }
         }
-        unsigned bad = 0, bounds_bad = 0;
+        unsigned bad = 0, bounds_bad = 0, http_total_equal = 0;
         const bool percents = dbs.size() == 1;
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const QuerySpec& q = queries[qi];
@@ -134,10 +134,19 @@ int main(int argc, char** argv) {
                 printf("MISMATCH query %zu (%s): spy: cpu saw %u documents / %zu values, hook %u / %zu\n", qi, q.op.c_str(), spy_want.total, spy_want.values.size(),
                        spy_got.total, spy_got.values.size());
             }
+            /* Xapiand's HTTP response: "total" = mset.get_matches_estimated(), "_percent" = get_percent() of every hit (reference
+             * src/server/http_client.cc:2553-2554, 2598) — the percentages are part of same_mset above */
+            if (want.get_matches_estimated() == got.get_matches_estimated()) ++http_total_equal;
             /* the upper bound is a static property of the postlist tree: identical; the lower bound may be looser than the CPU
              * matcher's (which counts the documents it happened to weigh) but never above it or the estimate.  Where the value leads
              * the sort the matcher shows ProtoMSet every document: all three figures must be the reference's. */
-            const bool exact_bounds = (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR") && !q.collapse_max;
+            /* ... and, with --exact-bounds, by relevance for the operators whose known_matching_docs is a function of the match in docid
+             * order (a term, AND, FILTER, AND_NOT, PHRASE, NEAR) when the match fits one device page; the reference also knows the
+             * exact count whenever its three figures coincide — then the hook must report the same */
+            const bool and_class = q.op == "AND" || q.op == "FILTER" || q.op == "AND_NOT" || q.op == "PHRASE" || q.op == "NEAR";
+            const bool exact_bounds = !q.collapse_max && (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR" ||
+                                                          (exact_bounds_on && and_class && q.sort_mode.empty() && want.get_matches_upper_bound() <= 1024) ||
+                                                          (want.get_matches_lower_bound() == want.get_matches_upper_bound()));
             if (dbs.size() == 1 && !q.collapse_max &&
                 (want.get_matches_upper_bound() != got.get_matches_upper_bound() || got.get_matches_lower_bound() > want.get_matches_lower_bound() ||
                  got.get_matches_lower_bound() > got.get_matches_estimated() || got.get_matches_estimated() > got.get_matches_upper_bound() ||
@@ -150,10 +159,10 @@ int main(int argc, char** argv) {
         const xgm_hook::Counters c = xgm_hook::counters();
         printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
-               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu}\n",
+               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u}\n",
                queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
-               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built);
+               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal);
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
         for (const std::string& f : seg_files) unlink(f.c_str());

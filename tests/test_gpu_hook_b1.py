@@ -160,6 +160,7 @@ def test_value_and_key_sorts_and_spies_through_the_hook(built, glass_values):
     out = run_b1(qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
     assert out["answered_on_device"] == len(qs) and out["answered_sorted"] == n_sorted, out
+    assert out["http_total_equal"] >= n_sorted * 2 // 3, out        # exact wherever the value leads the sort (and often elsewhere)
     assert out["answered_spied"] >= 16 + n_sorted // 3 - 2, out
     assert 3 <= out["columns_built"] <= 6, out            # one column per value slot / key maker and shard revision, built once
 
@@ -230,3 +231,23 @@ def test_wildcards_through_the_hook(built, glass):
     assert out["answered_on_device"] >= len(qs) // 2, out           # the rest: expansions beyond the device's leaves, ties under MOST_FREQUENT
     out3 = run_b1(qf, *shards)
     assert out3["mismatches"] == 0 and out3["answered_on_device"] >= len(qs), out3     # (3 shards: >= a third of 3 * n)
+
+
+def test_exact_match_count_bounds_through_the_hook(built, glass):
+    """SURVEY 8(f).4: with exact bounds on, MSet::get_matches_lower_bound / _estimated / _upper_bound of the hook are the CPU
+    matcher's for the operators whose known_matching_docs is a function of the match (a term, AND, FILTER, AND_NOT) whenever the
+    match fits one device page — not merely valid bounds.  The driver requires equality for those (and wherever the reference's
+    own three figures coincide)."""
+    d, one, _ = glass
+    base = (H.gen_term_queries("AND", 30, 2, 20, 400, maxitems=10, seed=91) + H.gen_term_queries("AND", 12, 3, 1, 60, maxitems=10, seed=92) +
+            H.gen_term_queries("AND", 8, 1, 200, 3000, maxitems=10, seed=93) + H.gen_sided_queries("AND_NOT", 10, 1, 2, 30, 300, seed=94) +
+            H.gen_sided_queries("FILTER", 10, 1, 1, 30, 300, seed=95))
+    qs = []
+    for i, q in enumerate(base):
+        k, first = [(10, 0), (3, 0), (25, 5), (1, 0), (7, 2)][i % 5]
+        qs.append(dict(q, first=first, maxitems=k, check_at_least=[0, 0, 40, 0, 300][i % 5]))
+    qf = str(d / "qeb.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--exact-bounds", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
+    assert out["http_total_equal"] == len(qs), out            # the HTTP "total" field (get_matches_estimated) of every response

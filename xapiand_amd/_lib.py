@@ -160,6 +160,8 @@ _API = [
     ("xgm_index_attach_column_ordinals", C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_uint32), C.c_uint32, C.c_uint32]),
     ("xgm_expand_prefix", C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_uint32, _P(C.c_uint32), _P(C.c_uint32)]),
     ("xgm_term_info", C.c_int, [C.c_void_p, C.c_uint32, _P(C.c_char_p), _P(C.c_size_t), _P(C.c_uint32), _P(C.c_uint32)]),
+    ("xgm_known_matching_docs", C.c_uint64, [_P(C.c_double), C.c_uint64, C.c_uint32, C.c_uint32]),
+    ("xgm_round_estimate", C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     ("xgm_last_error", C.c_char_p, []),
     ("xgm_version", C.c_char_p, []),
 ]

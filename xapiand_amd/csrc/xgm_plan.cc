@@ -748,3 +748,42 @@ extern "C" void xgm_mset_bounds_known(const xgm_query* plan, const xgm_result_hd
                                       uint32_t* estimated, uint32_t* upper) {
     mset_bounds_from(plan, hdr, known_matching_docs, true, lower, estimated, upper);
 }
+
+extern "C" uint64_t xgm_known_matching_docs(const double* w, uint64_t n, uint32_t max_size, uint32_t check_at_least) {
+    if (!w || max_size == 0) return n;                                            /* (nothing is kept: min_weight never moves) */
+    std::vector<double> heap;                                                     /* min-heap of the max_size best weights so far */
+    heap.reserve(max_size);
+    uint64_t known = 0;
+    double min_weight = 0.0;
+    bool heap_built = false;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (w[i] < min_weight) continue;                    /* the matcher's loop drops it before ProtoMSet sees it (matcher.cc:500-505) */
+        ++known;                                            /* ProtoMSet::add */
+        if (heap.size() < max_size) { heap.push_back(w[i]); std::push_heap(heap.begin(), heap.end(), std::greater<double>()); continue; }
+        if (!heap_built) {                                  /* the (max_size + 1)-th document: min_heap is made, min_weight set if checked_enough() */
+            heap_built = true;
+            if (known >= check_at_least) min_weight = heap.front();
+        }
+        if (!(w[i] > heap.front())) continue;               /* not better than the worst kept (equal weight: the larger docid loses): add() returns here */
+        std::pop_heap(heap.begin(), heap.end(), std::greater<double>());
+        heap.back() = w[i];
+        std::push_heap(heap.begin(), heap.end(), std::greater<double>());
+        if (known >= check_at_least) min_weight = heap.front();      /* only a replacement moves min_weight (protomset.h:392-398) */
+    }
+    return known;
+}
+
+/* MSet::get_matches_estimated (api/mset.cc:146-153 → api/roundestimate.h:36-69): the estimate rounded to the significant figures the
+ * bounds justify.  This is the number Xapiand's HTTP API returns as "total" (src/server/http_client.cc:2554, 2684). */
+extern "C" uint32_t xgm_round_estimate(uint32_t m, uint32_t M, uint32_t e) {
+    const uint32_t D = M - m;
+    if (D == 0 || e == 0) return e;
+    uint32_t r = (uint32_t)(pow(10.0, (double)(int)log10((double)D)) + 0.5);       /* exp10(int(log10(D))) */
+    while (r > e) r /= 10;
+    uint32_t R = e / r * r;
+    if (R < m) R += r;
+    else if (R > M) R -= r;
+    else if (R < e && r % 2 == 0 && e - R == r / 2) { if (e - m < M - e) R += r; }  /* round towards the centre of the range */
+    if (R < m || R > M) R = e;
+    return R;
+}
