@@ -188,7 +188,7 @@ def main():
 
     # ---- per-launch byte counts, outside the timed region ------------------------------------------------------
     # algorithmic: Σ_t df_t·8 + S·4 + P·4 + k·16 per query; model: the kernel's own request tallies
-    db.set_profiling(2)                            # the tallying instantiation of the wave kernels
+    db.set_profiling(0 if os.environ.get("XGM_BENCH_NO_TALLY") else 2)   # the tallying instantiation of the wave kernels (tools/units.py switches it off: it wants the product kernel's own timeline)
     alg_bytes, model_sector, model_useful, tallies = [], [], [], []
     for b in range(n_batches):
         step(batches[b])
@@ -197,7 +197,7 @@ def main():
         matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in timed_plans[b * BATCH:(b + 1) * BATCH])
         tl = (C.c_uint64 * 10)()
-        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel")
+        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_dense_kernel")
         bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
         alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
         if have_tally:

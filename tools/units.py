@@ -7,6 +7,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["XGM_DEBUG_UNITS"] = "1"
+os.environ.setdefault("XGM_BENCH_NO_TALLY", "1")
 import numpy as np  # noqa: E402
 
 import bench  # noqa: E402

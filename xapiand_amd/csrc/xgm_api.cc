@@ -696,7 +696,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* few queries in flight (latency mode): a smaller merge (sort of <= 4096) beats more units */
     const uint32_t merge_budget = (nq <= 4u && !bp->orw) ? XGM_MERGE_CAP / 2u : XGM_MERGE_CAP;   /* (a disjunction's units are long: more of them wins) */
     static const uint32_t units_cap = getenv("XGM_MAX_UNITS_PER_QUERY") ? (uint32_t)atoi(getenv("XGM_MAX_UNITS_PER_QUERY")) : 0u;   /* A/B switch for measurements */
-    uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / k_pad)));
+    /* units x k candidates must fit the merge kernel's LDS sort; a unit's window there is k_max entries (not the next power of two) */
+    static const bool units_by_kpad = getenv("XGM_UNITS_BY_KPAD") != nullptr;                      /* A/B switch: the round-2 bound */
+    uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / (units_by_kpad ? k_pad : std::max(1u, bp->k_max)))));
     if (units_cap) g_max = std::max(g_min, std::min(g_max, units_cap));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
@@ -761,7 +763,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* units per launch: ~3 per wave slot of the chip (4 waves per SIMD for the conjunction kernel; the disjunction kernel runs 2 and
      * pays a longer prologue per unit) */
     static const double orw_units = getenv("XGM_ORW_UNITS") ? atof(getenv("XGM_ORW_UNITS")) : 8192.0;      /* A/B switch for measurements */
-    const double target_units = bp->orw ? orw_units : 12288.0;
+    static const double and_units = getenv("XGM_TARGET_UNITS") ? atof(getenv("XGM_TARGET_UNITS")) : 12288.0;      /* A/B switch for measurements */
+    const double target_units = bp->orw ? orw_units : and_units;
     double unit_cost = std::max(1.0, total_cost / (wave_units ? target_units : 3072.0));
     if (wave_units) {
         /* the floor of g_min units per query (the LDS table bounds a unit's stripes) eats part of the budget: raise the
@@ -809,6 +812,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->k_stride_c = bp->k_max;
     return XGM_OK;
 }
+
+static int dense_kind(const xgm_index* idx, const xgm_query& q);
 
 /* Runs one batch of ONE kernel class (or a batch whose mix plan_batch resolves by itself); results land in rows
  * rows[i] (i when rows == NULL) of d_hits / d_hdrs (device).  Asynchronous on `stream`. */
@@ -891,7 +896,12 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
-    idx->last_kernel = bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    /* every query of the batch a conjunction over probe containers only (dense_kind, all of one kind): the kernel written for that */
+    bool dense = bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
+    for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
+    static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
+    if (dense_class_old_kernel) dense = false;
+    idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw || (bp.andw && bp.phrase)) {
         if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
@@ -899,7 +909,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         L.hist = s->d_hist;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = bp.andw ? xgm_launch_andw(L, stream)
+    if ((rc = dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
               : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
               : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream)))
         return rc;
@@ -924,10 +934,34 @@ extern "C" int xgm_debug_host_ns(uint64_t* out4) {      /* (u64[8]) */
 /* Kernel class of a planned query: which match kernel serves it best.  A server's natural batch is heterogeneous
  * (Xapiand's HTTP threads issue whatever the clients send): run_batch cuts it into one launch per class present instead
  * of sending the whole batch to the slowest common denominator. */
-enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_BIGK, XGM_CLS_COUNT };
+enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_BIGK, XGM_CLS_DENSE_AND, XGM_CLS_DENSE_PHRASE,
+       XGM_CLS_COUNT };
 
-static int classify_query(const xgm_query& q) {
+/* xgm_dense_kernel's queries (xgm_dense_and.hip): a conjunction / FILTER — or a positional query that prunes by weight — of 2 to 4
+ * terms that ALL have probe containers (xgm_build_dense's own criterion), a page of at most 64.  1 = plain, 2 = positional, 0 = no. */
+static int dense_kind(const xgm_index* idx, const xgm_query& q) {
+    /* OFF by default (round 3 measurements): as a launch of its own the kernel costs more than it gains — the class split
+     * means two match + merge launches per batch.  XGM_DENSE_KERNEL=1 switches it on (A/B runs, tests/test_gpu_variants.py). */
+    static const bool off = getenv("XGM_DENSE_KERNEL") == nullptr || getenv("XGM_NO_ANDW") != nullptr || getenv("XGM_NO_AND_KERNEL") != nullptr;
+    static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr;
+    static const bool no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr;
+    if (off || idx->view.n_dense == 0 || idx->dense_min_df == 0 || idx->hdr.stripe_bits > 13u) return 0;
+    const uint32_t T = q.n_terms, k = q.first + q.maxitems;
+    if (T < 2u || T > xgm_dense_max_terms() || k == 0u || k > xgm_dense_max_k()) return 0;
+    const bool positional = (q.op == XGM_OP_PHRASE || q.op == XGM_OP_NEAR) && q.phrase_active;
+    if (!(q.op == XGM_OP_AND || q.op == XGM_OP_FILTER || positional)) return 0;
+    if (positional && (no_pos_prune || no_phrase_w || !idx->view.dense_pos || q.check_at_least > k)) return 0;
+    if ((q.op == XGM_OP_PHRASE || q.op == XGM_OP_NEAR) && !positional) return 0;
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t id = q.terms[t].term_id;
+        if (id == UINT32_MAX || (uint64_t)idx->term_df[id] < idx->dense_min_df || idx->term_wdfub[id] > 254u) return 0;
+    }
+    return positional ? 2 : 1;
+}
+
+static int classify_query(const xgm_index* idx, const xgm_query& q) {
     const uint32_t T = q.n_terms;
+    if (const int dk = dense_kind(idx, q)) return dk == 2 ? XGM_CLS_DENSE_PHRASE : XGM_CLS_DENSE_AND;
     /* the wave kernels keep first + maxitems <= 192 candidates per unit: deeper pages go together to the workgroup kernels
      * instead of dragging a whole class there */
     if (q.op != XGM_OP_OR && q.first + q.maxitems > 192u) return XGM_CLS_BIGK;
@@ -952,7 +986,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     static thread_local std::vector<uint8_t> cls;
     cls.resize(nq);
     uint32_t present = 0;
-    for (uint32_t i = 0; i < nq; ++i) { cls[i] = (uint8_t)classify_query(qs[i]); if (count[cls[i]]++ == 0) ++present; }
+    for (uint32_t i = 0; i < nq; ++i) { cls[i] = (uint8_t)classify_query(idx, qs[i]); if (count[cls[i]]++ == 0) ++present; }
     if (present <= 1u || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
     /* one launch per class present, all on `stream`; the first uses the caller's scratch, the others take their own
      * from the pool (each is marked pending behind its launch) */
@@ -1904,7 +1938,7 @@ extern "C" int xgm_debug_batch_launches(const xgm_index* idx, const xgm_query* q
     if (!idx || !qs || !out || cap == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
     out[0] = 0;
     std::vector<std::vector<xgm_query>> by(XGM_CLS_COUNT);
-    for (uint32_t i = 0; i < nq; ++i) by[classify_query(qs[i])].push_back(qs[i]);
+    for (uint32_t i = 0; i < nq; ++i) by[classify_query(idx, qs[i])].push_back(qs[i]);
     int n = 0;
     std::string acc;
     for (auto& v : by) {

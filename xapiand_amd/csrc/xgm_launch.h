@@ -40,6 +40,13 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
  * L.phrase selects the instantiation with the positional filter (every term block-decoded) */
 size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase, bool sided);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
+/* conjunctions (or positional queries that prune by weight) whose every term has probe containers, <= xgm_dense_max_terms() terms,
+ * k <= xgm_dense_max_k(), units of <= xgm_dense_max_stripes() stripes: xgm_dense_and.hip; L.phrase selects the positional instantiation */
+size_t xgm_dense_smem_bytes(bool phrase);
+uint32_t xgm_dense_max_terms();
+uint32_t xgm_dense_max_k();
+uint32_t xgm_dense_max_stripes();
+int xgm_launch_dense(const xgm_match_launch& L, hipStream_t stream);
 /* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
 int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream);

@@ -1,0 +1,115 @@
+/* K6, the positional predicates straight from HBM — one document per lane, serial dependent reads: ExactPhrasePostList / PhrasePostList /
+ * NearPostList::test_doc restated (reference src/xapian/matcher/exactphrasepostlist.cc:75-133, phrasepostlist.cc:60-90,
+ * nearpostlist.cc:60-160).  Shared by the wave kernels' slow path (xgm_kernels.hip) and the dense conjunction kernel
+ * (xgm_dense_and.hip), whose positional survivors are rare. */
+#ifndef XGM_POSFILTER_H
+#define XGM_POSFILTER_H
+
+#include <hip/hip_runtime.h>
+
+#include "xgm_device.h"
+
+namespace {
+
+/* One document's positions of one term, in HBM: 2 or 4 bytes per entry (XGM_TF_POS16). */
+struct PosList {
+    const unsigned char* p; uint32_t n; uint32_t w16;
+    __device__ __forceinline__ uint32_t at(uint32_t i) const {
+        return w16 ? (uint32_t)reinterpret_cast<const uint16_t*>(p)[i] : reinterpret_cast<const uint32_t*>(p)[i];
+    }
+};
+
+/* The three positional predicates straight from HBM, one document per lane with serial dependent reads: the SLOW
+ * path — documents with more than kPosFast positions of a term, 4-byte position lists, and the workgroup kernel.
+ * The wave kernel's fast path (positions staged in LDS by vector loads) is posfilter_lds below. */
+
+/* ExactPhrasePostList::test_doc: is there a base with term i at base + phrase_index[i] for all i? */
+__device__ bool phrase_exact(const PosList* pl, const uint8_t* pidx, uint32_t n_terms) {
+    /* drive from the shortest list */
+    uint32_t drv = 0;
+    for (uint32_t t = 1; t < n_terms; ++t) if (pl[t].n < pl[drv].n) drv = t;
+    uint32_t cursor[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) cursor[t] = 0;
+    for (uint32_t i = 0; i < pl[drv].n; ++i) {
+        uint32_t x = pl[drv].at(i);
+        if (x < pidx[drv]) continue;
+        uint32_t base = x - pidx[drv];
+        bool ok = true;
+        for (uint32_t t = 0; t < n_terms && ok; ++t) {
+            if (t == drv) continue;
+            uint32_t want = base + pidx[t];
+            uint32_t c = cursor[t];
+            while (c < pl[t].n && pl[t].at(c) < want) ++c;
+            cursor[t] = c;
+            ok = (c < pl[t].n) && (pl[t].at(c) == want);
+        }
+        if (ok) return true;
+    }
+    return false;
+}
+
+/* PhrasePostList::test_doc (windowed, ordered), restated with the same forward-only cursors. */
+__device__ bool phrase_window(const PosList* pl_plan, const uint8_t* pidx, uint32_t n_terms, uint32_t window) {
+    /* reorder to phrase order: terms[i] of the reference is the i-th word of the phrase */
+    PosList pl[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < n_terms; ++t) pl[pidx[t]] = pl_plan[t];
+    uint32_t cur[XGM_PHRASE_MAX_TERMS];
+    bool started[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) { cur[t] = 0; started[t] = false; }
+    if (pl[0].n == 0) return false;               /* poslists[0]->next() */
+    uint32_t b;
+    while (true) {
+        uint32_t base = pl[0].at(cur[0]);
+        uint32_t pos = base;
+        uint32_t i = 0;
+        while (true) {
+            if (++i == n_terms) return true;
+            /* skip_to(pos + 1) on a forward-only list: never moves backwards */
+            uint32_t c = cur[i];
+            if (!started[i]) { started[i] = true; c = 0; }
+            while (c < pl[i].n && pl[i].at(c) < pos + 1u) ++c;
+            cur[i] = c;
+            if (c >= pl[i].n) return false;
+            pos = pl[i].at(c);
+            b = pos + (n_terms - i);
+            if (!(b - base <= window)) break;
+        }
+        uint32_t want = b - window;
+        uint32_t c0 = cur[0];
+        while (c0 < pl[0].n && pl[0].at(c0) < want) ++c0;
+        cur[0] = c0;
+        if (c0 >= pl[0].n) return false;
+    }
+}
+
+/* NearPostList::test_doc (reference src/xapian/matcher/nearpostlist.cc:60-160) for DISTINCT terms: one position of
+ * every term inside a span shorter than `window`, in any order — advance the list with the smallest head past
+ * (largest head - window) until the heads fit or a list runs out. */
+__device__ bool near_window(const PosList* pl, uint32_t n_terms, uint32_t window) {
+    uint32_t cur[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) cur[t] = 0;
+    for (uint32_t t = 0; t < n_terms; ++t) if (pl[t].n == 0) return false;
+    while (true) {
+        uint32_t lo = 0, lo_v = pl[0].at(cur[0]), hi_v = lo_v;
+        for (uint32_t t = 1; t < n_terms; ++t) {
+            const uint32_t v = pl[t].at(cur[t]);
+            if (v < lo_v) { lo_v = v; lo = t; }
+            if (v > hi_v) hi_v = v;
+        }
+        if (hi_v - lo_v < window) return true;
+        const uint32_t want = hi_v - window + 1u;
+        uint32_t c = cur[lo];
+        while (c < pl[lo].n && pl[lo].at(c) < want) ++c;
+        if (c >= pl[lo].n) return false;
+        cur[lo] = c;
+    }
+}
+
+__device__ __forceinline__ bool posfilter_slow(const PosList* pl, const xgm_dev_query& q, uint32_t T) {
+    if (q.flags & XGM_QF_NEAR) return near_window(pl, T, q.window);
+    return (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
+}
+
+}  // namespace
+
+#endif
