@@ -623,6 +623,8 @@ struct BatchPlan {
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
 };
 
+static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
+
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
                       BatchPlan* bp, bool force_general = false) {
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
@@ -679,6 +681,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     bp->orw = or_only && (uint64_t)((n_stripes + orw_spg - 1u) / orw_spg) * k_pad <= XGM_MERGE_CAP &&
               xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, orw_spg) <= 160u * 1024u;
     const bool wave_units = bp->andw || bp->orw;
+    /* plain conjunctions over containers only: their units take xgm_dense_unit inside xgm_andw_kernel<uint8_t, false, 0> */
+    if (bp->andw && !bp->phrase && bp->sided == 0 && !bp->wide)
+        for (uint32_t i = 0; i < nq; ++i) if (dense_kind(idx, qs[i], true) == 1) dq[i].flags |= XGM_QF_DENSE;
     bp->cap = wave_units ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
      * plus about one partial block per stripe a term touches).  Every query is cut into units of
@@ -813,7 +818,6 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     return XGM_OK;
 }
 
-static int dense_kind(const xgm_index* idx, const xgm_query& q);
 
 /* Runs one batch of ONE kernel class (or a batch whose mix plan_batch resolves by itself); results land in rows
  * rows[i] (i when rows == NULL) of d_hits / d_hdrs (device).  Asynchronous on `stream`. */
@@ -939,10 +943,13 @@ enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_
 
 /* xgm_dense_kernel's queries (xgm_dense_and.hip): a conjunction / FILTER — or a positional query that prunes by weight — of 2 to 4
  * terms that ALL have probe containers (xgm_build_dense's own criterion), a page of at most 64.  1 = plain, 2 = positional, 0 = no. */
-static int dense_kind(const xgm_index* idx, const xgm_query& q) {
-    /* OFF by default (round 3 measurements): as a launch of its own the kernel costs more than it gains — the class split
+static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused) {
+    /* (fused: the question xgm_andw_kernel's own dense body asks — the same shapes, plain only, decided per query inside one launch)
+     * OFF by default (round 3 measurements): as a launch of its own the kernel costs more than it gains — the class split
      * means two match + merge launches per batch.  XGM_DENSE_KERNEL=1 switches it on (A/B runs, tests/test_gpu_variants.py). */
-    static const bool off = getenv("XGM_DENSE_KERNEL") == nullptr || getenv("XGM_NO_ANDW") != nullptr || getenv("XGM_NO_AND_KERNEL") != nullptr;
+    static const bool off_alone = getenv("XGM_DENSE_KERNEL") == nullptr || getenv("XGM_NO_ANDW") != nullptr || getenv("XGM_NO_AND_KERNEL") != nullptr;
+    static const bool off_fused = getenv("XGM_NO_DENSE_BODY") != nullptr;                           /* A/B switch for measurements */
+    const bool off = fused ? off_fused : off_alone;
     static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr;
     static const bool no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr;
     if (off || idx->view.n_dense == 0 || idx->dense_min_df == 0 || idx->hdr.stripe_bits > 13u) return 0;

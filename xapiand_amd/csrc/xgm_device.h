@@ -20,6 +20,8 @@
 #define XGM_QF_NEAR 8u              /* the positional filter is NearPostList's (any order, span < window) */
 #define XGM_QF_POSPRUNE 32u         /* positional query whose match count may be a lower bound: weigh first, test positions only of
                                        candidates that can still enter the top k (include/xgm.h, XGM_MATCHES_LOWER_BOUND) */
+#define XGM_QF_DENSE 64u            /* a plain conjunction / FILTER of 2..4 terms that ALL have probe containers, k <= 64: its units run
+                                       xgm_dense_unit (xgm_dense_body.inc) inside xgm_andw_kernel */
 #define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */

@@ -778,6 +778,8 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
     wave_lds_fence();
 }
 
+#include "xgm_dense_body.inc"
+
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
  * instantiations, so that the plain conjunction pays nothing for them. */
@@ -796,6 +798,12 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     const xgm_dev_query& q = queries[wk.qi];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k, SPG = spg_max;
+    if (!PHRASE && SIDED == 0 && (rfl32(q.flags) & XGM_QF_DENSE)) {
+        /* every term has containers: the body written for that case alone (same launch, same outputs) */
+        xgm_dense_unit<false, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
+                                     cand_out, ghdr_out, nullptr);
+        return;
+    }
     /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not
      * index it: AndNotPostList) or of an AND_MAYBE (add their weight where they do: AndMaybePostList).  A plain
      * conjunction / FILTER has TR == T. */
