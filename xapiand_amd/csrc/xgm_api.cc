@@ -193,6 +193,7 @@ static void fill_view(xgm_index* idx) {
     v.stripe_bits = idx->hdr.stripe_bits;
     v.lastdocid = idx->hdr.lastdocid;
     v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.dense_plane = 0;
+    v.doclen_narrow = nullptr; v.doclen_narrow_bits = 0; v.doclen_base = 0;
     v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
@@ -264,6 +265,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     }
     if (idx->d_blob) hipFree(idx->d_blob);
     if (idx->d_dense_id) hipFree(idx->d_dense_id);
+    if (idx->d_doclen_narrow) hipFree(idx->d_doclen_narrow);
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
     for (auto& c : idx->columns) if (c.second.first) hipFree(c.second.first);

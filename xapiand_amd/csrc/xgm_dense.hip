@@ -113,9 +113,36 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     if (tid == 0 && wmax_s) atomicMax(&wdf_max[d], wmax_s);            /* the term's true largest wdf: the disjunction's pruning bound */
 }
 
+template <typename T>
+__global__ void k_narrow_doclen(const uint32_t* __restrict__ doclen, uint32_t n, uint32_t base, T* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t v = doclen[i]; out[i] = (T)(v >= base ? v - base : 0u); }      /* (entry 0 and deleted documents hold 0) */
+}
+
 }  // namespace
 
+/* doclen[] as offsets from the shard's shortest document, one or two bytes each (xgm_seg_dev::doclen_narrow) */
+static int build_narrow_doclen(xgm_index* idx) {
+    idx->view.doclen_narrow = nullptr; idx->view.doclen_narrow_bits = 0; idx->view.doclen_base = 0;
+    if (getenv("XGM_NO_NARROW_DOCLEN") || !idx->view.doclen) return XGM_OK;              /* A/B switch for measurements */
+    const uint32_t lb = idx->hdr.doclen_lower_bound, ub = idx->hdr.doclen_upper_bound, n = idx->hdr.lastdocid + 1u;
+    if (ub < lb || ub - lb >= 65536u) return XGM_OK;
+    const uint32_t bits = ub - lb < 256u ? 8u : 16u;
+    void* d = nullptr;
+    if (hipMalloc(&d, (size_t)n * (bits / 8u) + 64) != hipSuccess) return xgm_set_error(XGM_E_NOMEM, "narrow document lengths: out of device memory");
+    if (bits == 8u) hipLaunchKernelGGL(k_narrow_doclen<uint8_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint8_t*)d);
+    else hipLaunchKernelGGL(k_narrow_doclen<uint16_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint16_t*)d);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(d); return xgm_set_error(XGM_E_DEVICE, "narrow document lengths: kernel failed"); }
+    idx->d_doclen_narrow = d;
+    idx->view.doclen_narrow = (const unsigned char*)d;
+    idx->view.doclen_narrow_bits = bits;
+    idx->view.doclen_base = lb;
+    idx->device_bytes += (size_t)n * (bits / 8u);
+    return XGM_OK;
+}
+
 int xgm_build_dense(xgm_index* idx) {
+    if (int rc_ = build_narrow_doclen(idx)) return rc_;
     idx->view.dense_id = nullptr; idx->view.dense_dir = nullptr; idx->view.dense_data = nullptr;
     idx->view.n_dense = 0; idx->view.dense_plane = 0;
     idx->term_wdfmax.clear();

@@ -97,6 +97,7 @@ struct xgm_index {
     void* d_dense_id = nullptr;        /* probe containers (xgm_dense.hip) */
     void* d_dense_dir = nullptr;
     void* d_dense_data = nullptr;
+    void* d_doclen_narrow = nullptr;   /* xgm_seg_dev::doclen_narrow */
     uint64_t dense_bytes = 0;
     uint64_t dense_min_df = UINT64_MAX;   /* termfreq from which a term has probe containers */
     void* stream = nullptr;            /* hipStream_t                                                */

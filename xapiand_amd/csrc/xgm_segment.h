@@ -100,6 +100,11 @@ typedef struct {
     uint32_t n_stripes;
     uint32_t dense_pos;             /* the containers end with u32 pos_base[W/64]: position-entry offset (relative to the term) of the
                                        first posting of each 64-slot bucket — the positional filter on the probe path */
+    /* Document lengths once more, narrow (built in HBM next to the containers): doclen[d] - doclen_base as u8 when the shard's
+     * lengths span < 256, as u16 when < 65 536 (doclen_narrow_bits = 8 / 16; 0: none).  A gather of the lengths of densely matching
+     * documents then touches a quarter / half of the 64-byte sectors the u32 array costs (xgm_dense_unit). */
+    const unsigned char* doclen_narrow;
+    uint32_t doclen_narrow_bits, doclen_base;
     uint32_t dense_plane;           /* byte offset inside a container of u32 bits2[W/32]: the documents whose wdf is >= 2 — the disjunction's
                                        weight bound of a (document, term) is then the wdf = 1 bound or the term's maximum (0: no plane) */
 } xgm_seg_dev;
