@@ -272,6 +272,7 @@ inline uint32_t __builtin_amdgcn_sad_u8(uint32_t a, uint32_t b, uint32_t c) {
 /* (__builtin_readcyclecounter is clang's own: the host's cycle counter; diagnostics only) */
 template <class T> inline T min(T a, T b) { return b < a ? b : a; }
 template <class T> inline T max(T a, T b) { return a < b ? b : a; }
+inline unsigned long long wall_clock64() { return (unsigned long long)__builtin_readcyclecounter(); }      /* (diagnostics only) */
 inline int __popc(uint32_t v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffs(uint32_t v) { return __builtin_ffs((int)v); }
