@@ -91,3 +91,51 @@ def test_phrase_reference_quirk_is_quantified(big_db):
         f.write("C5 sample: %d queries; top-10 (docid, weight) differs from the reference's for %d; same docid SET for %d\n" % (len(queries), differ, same_set))
     ora.close()
     assert differ <= len(queries)
+
+
+@pytest.mark.parametrize("name", ["C2_and3_top10", "C3_or5_top100"])
+def test_sharded_parity_at_config_size(built, name):
+    """C4's per-GPU workload on the hardware the tests get: TWO shards of 10 M documents each (the 20 M-document corpus split the
+    reference's way, global doc g -> shard (g - 1) % 2: src/xapian/backends/multi.h:38-73) resident on the one MI355X, searched through
+    xgm_search_sharded — merged statistics (enquire.cc:385-394), every shard planned with its own leaf order, the top-k exchange and
+    the device merge (matcher.cc:653-781, mset.cc:367-395) — against Xapiand's protocol run on the CPU oracle over the very postings
+    each shard holds in HBM.  128 queries of bench.py's pool for the 20 M-document corpus."""
+    from xapiand_amd.enquire import search_sharded
+    cfg = CONFIGS[name]
+    k, world = cfg["k"], 2
+    n_global = N_DOCS * world
+    queries = H.bench_pool(cfg["op"], cfg["terms"], 1, n_global, VOCAB, maxitems=k)[100:100 + N_CHECK]
+    dbs = [Database.synthetic(H.CORPUS_SEED, n_global, VOCAB, n_shards=world, shard=s, device=0) for s in range(world)]
+    try:
+        assert all(db.info().doccount == N_DOCS for db in dbs)
+        terms = [t for q in queries for t in q["terms"]]
+        oras = [H.DeviceOracle(db, terms) for db in dbs]
+        infos = [db.info() for db in dbs]
+        L = _lib.lib()
+        got = search_sharded(dbs, [Query(q["op"], q["terms"]) for q in queries], 0, k)
+        n_nonempty = 0
+        for q, m in zip(queries, got):
+            tfs = []
+            for t in q["terms"]:
+                tb, tot = t.encode(), 0
+                for db in dbs:
+                    tf = C.c_uint32()
+                    _lib.check(L.xgm_lookup_term(db._h, tb, len(tb), None, C.byref(tf), None, None))
+                    tot += tf.value
+                tfs.append(tot)
+            gs = dict(total_length=sum(i.total_length for i in infos), collection_size=sum(i.doccount for i in infos), has_positions=True, termfreq=tfs)
+            allh, matches = [], 0
+            for s, ora in enumerate(oras):
+                hits, oh = H.oracle_search(ora, q["op"], q["terms"], 0, k, 0, gs)
+                allh += [((d - 1) * world + s + 1, w) for d, w, _ in hits]
+                matches += oh.matches
+            allh.sort(key=lambda x: (-x[1], x[0]))
+            assert [(i.docid, i.weight) for i in m] == allh[:k], (name, q)
+            assert m.get_matches_exact() == matches, (name, "matches", q)
+            n_nonempty += bool(allh)
+        assert n_nonempty >= N_CHECK // 2
+        for ora in oras:
+            ora.close()
+    finally:
+        for db in dbs:
+            db.close()
