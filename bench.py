@@ -241,11 +241,29 @@ def main():
     # which cannot be collected from inside this process; only quoted when measured on this very workload
     traffic, traffic_note = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    sha_path = os.path.join(ROOT, "xapiand_amd", "csrc", "libxgm.so.sha")
+    lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None
+    stale_traffic = False
     if os.path.exists(tpath):
         for tr in json.load(open(tpath)).get("entries", []):
+            if tr.get("lib_sha") != lib_sha:
+                stale_traffic = True          # counters of another build of the library: not this kernel's traffic
+                continue
             if (tr["kernel"] == kernel_name and tr["op"] == args.op and tr["docs_per_gpu"] == args.docs_per_gpu and tr["top_k"] == k and
                     tr["terms"] == (args.terms if args.op != "PHRASE" else 0) and tr["batch"] == BATCH and tr.get("required", 1) == (args.required if sided else 1)):
                 traffic, traffic_note = tr["hbm_bytes_per_launch"], tr["note"]
+
+    # ---- N > 1: every rank's own match kernel against its own GPU's roofline (per-GPU bytes use the shard's own df) ------
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([kernel_ms if kernel_ms and kernel_ms > 0 else 0.0, float(traffic or model_bytes or bytes_per_launch)], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = []
+        for r, v in enumerate(allr):
+            ms, by = float(v[0].item()), float(v[1].item())
+            per_rank.append({"rank": r, "kernel_ms": ms, "bytes_per_launch": by, "achieved": (by / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                             "frac": (by / (ms * 1e-3) / HBM_PEAK) if ms > 0 else None})
 
     result = None
     if rank == 0:
@@ -272,6 +290,7 @@ def main():
                       "build_seconds": build_s},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK, "basis": basis, "traffic": traffic, "traffic_note": traffic_note,
+                         "traffic_lib_sha": lib_sha if traffic else None, "traffic_entries_of_another_build_ignored": stale_traffic,
                          "kernel_ms": kernel_ms,
                          "model_min_bytes": model_bytes, "model_useful_bytes": useful_bytes,
                          "model_frac": (model_bytes / kt / HBM_PEAK) if (model_bytes and kt) else None,
@@ -281,6 +300,12 @@ def main():
                          "algorithmic": {"bytes_per_launch": bytes_per_launch, "achieved": alg_rate / 1e9, "frac": alg_rate / HBM_PEAK,
                                          "note": "SURVEY 8(d): sum df*8 + S*4 + P*4 + k*16 per query; not bytes this design reads"}},
         }
+        if per_rank:
+            ok = [p for p in per_rank if p["achieved"]]
+            result["roofline"]["per_rank"] = per_rank
+            result["roofline"]["aggregate"] = {"achieved": sum(p["achieved"] for p in ok), "peak": HBM_PEAK / 1e9 * world, "unit": "GB/s",
+                                               "frac": (sum(p["frac"] for p in ok) / len(ok)) if ok else None,
+                                               "note": "sum over the ranks of bytes moved per launch / that rank's kernel time; frac = mean of the per-rank fractions"}
         if server:
             result["server_mode"] = server
 

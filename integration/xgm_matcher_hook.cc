@@ -36,7 +36,7 @@ struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumn
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
 std::map<std::string, SpyAdapter> g_spy_adapters;
-std::atomic<bool> g_enabled{true}, g_exact_bounds{false};
+std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
 std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0};
 
@@ -189,6 +189,7 @@ bool lower_flat(const Xapian::Query& q, Lowered* L) {
         L->total_subqs = (uint32_t)L->terms.size();
     } else if (op == Xapian::Query::OP_PHRASE || op == Xapian::Query::OP_NEAR) {
         if (g_positional.load(std::memory_order_relaxed) == POSITIONAL_DECLINE) return false;
+        if (op == Xapian::Query::OP_NEAR && g_near_colocated.load(std::memory_order_relaxed)) return false;
         const size_t n = q.get_num_subqueries();
         for (size_t i = 0; i < n; ++i) {
             const Xapian::Query s = q.get_subquery(i);
@@ -324,6 +325,7 @@ void set_enabled(bool on) { g_enabled.store(on); }
 void set_positional_mode(PositionalMode m) { g_positional.store(int(m)); }
 void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
 void set_exact_bounds(bool on) { g_exact_bounds.store(on); }
+void set_near_colocated_terms(bool may_exist) { g_near_colocated.store(may_exist); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_spy_adapters[spy_class_name] = std::move(adapter);

@@ -72,6 +72,12 @@ enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1 };
 void set_positional_mode(PositionalMode m);
 inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONAL_DECLINE : POSITIONAL_INTENDED); }
 
+/* OP_NEAR on an index that puts DISTINCT terms at the SAME position of a document (prefixed and unprefixed forms of a word, ...): the
+ * reference's NearPostList::test_doc wants one distinct position per term and steps over duplicates (matcher/nearpostlist.cc:108-140);
+ * the device predicate accepts co-located heads.  A deployment whose indexer co-locates terms says so here and OP_NEAR stays on the
+ * CPU matcher (OP_PHRASE is unaffected: its terms sit at increasing positions by definition).  Default: false. */
+void set_near_colocated_terms(bool may_exist);
+
 /* Enquire::set_collapse_key.  The reference snapshot's collapser does not keep the best collapse_max documents of a key when
  * the proto-MSet overflows or collapse_max > 1 (matcher/collapser.cc:59-76, protomset.h:310-317); the device does.
  *   COLLAPSE_DECLINE (default) — collapsed searches stay on the CPU matcher;

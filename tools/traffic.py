@@ -26,7 +26,11 @@ fetch = vals["FETCH_SIZE"] * 1024.0
 write = vals["WRITE_SIZE"] * 1024.0
 total = fetch + streamed / 2.0 + write
 cfg = d["config"]
+import os
+sha_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "xapiand_amd", "csrc", "libxgm.so.sha")
+lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None     # the build these counters were taken from (bench.py refuses another)
 print(json.dumps({
+    "lib_sha": lib_sha,
     "kernel": r["kernel"], "op": cfg["op"], "docs_per_gpu": cfg["docs_per_gpu"], "top_k": cfg["top_k"],
     "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"],
     "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"], "streamed_bytes_model": streamed,
