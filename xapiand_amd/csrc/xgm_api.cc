@@ -258,6 +258,8 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     hipDeviceSynchronize();
     xgm_batcher_destroy(idx);
     if (idx->shard_ctx) { xgm_shard_ctx_destroy(idx->shard_ctx); idx->shard_ctx = nullptr; hipSetDevice(idx->device); }
+    for (XgmShardCtx* rc_ : idx->retired_shard_ctx) xgm_shard_ctx_destroy(rc_);
+    idx->retired_shard_ctx.clear();
     for (XgmScratch* s : idx->scratch_pool) scratch_destroy(s);
     for (auto& pr : idx->prof_events) { hipEventDestroy((hipEvent_t)pr.first); hipEventDestroy((hipEvent_t)pr.second); }
     if (idx->sections_owned) {
@@ -1613,7 +1615,10 @@ static int shard_ctx_get(xgm_index* const* shards, uint32_t n_shards, XgmShardCt
     bool same = c && c->shards.size() == n_shards && std::equal(c->shards.begin(), c->shards.end(), shards);
     for (uint32_t s = 0; same && s < n_shards; ++s) same = c->devs[c->dev_of[s]].device == shards[s]->device;
     if (c && !same) {
-        xgm_shard_ctx_destroy(c);
+        /* another shard list led by the same index: the old context may still be in use by a concurrent xgm_search_sharded (its
+         * mutex is taken only after this function returns), so it is retired, not destroyed — freed when the index closes.  A server's
+         * shard list is stable: this does not grow. */
+        owner->retired_shard_ctx.push_back(c);
         c = owner->shard_ctx = nullptr;
     }
     if (!c) {

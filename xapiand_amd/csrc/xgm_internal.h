@@ -114,6 +114,7 @@ struct xgm_index {
     uint32_t scratch_total = 0;        /* scratches created so far (pooled + in use) */
     XgmBatcher* batcher = nullptr;
     XgmShardCtx* shard_ctx = nullptr;  /* when this index is shards[0] of an xgm_search_sharded list */
+    std::vector<XgmShardCtx*> retired_shard_ctx;   /* contexts of earlier shard lists led by this index: destroyed when it closes */
     std::map<uint32_t, std::pair<void*, uint32_t>> columns;   /* value slot → (device u32 ord[lastdocid + 1], distinct values): xgm_index_attach_column */
     std::vector<uint32_t> term_order;                          /* term ids in byte order of the terms (xgm_expand_prefix), made on first use */
     std::once_flag term_order_once;
