@@ -70,6 +70,8 @@ struct XgmScratch {
     void* d_in = nullptr; size_t cap_in = 0;           /* all per-call inputs, one upload */
     xgm_hit* d_hits = nullptr; size_t cap_hits = 0;
     xgm_result_hdr* d_hdrs = nullptr; size_t cap_hdrs = 0;
+    xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
+    xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
     /* pinned host */
     void* h_up = nullptr; size_t cap_up = 0;
     void* h_down = nullptr; size_t cap_down = 0;
@@ -161,7 +163,7 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
-    hipFree(s->d_hits); hipFree(s->d_hdrs);
+    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
     if (s->h_work) hipHostFree(s->h_work);
@@ -625,6 +627,7 @@ struct BatchPlan {
     bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
     int sided;          /* andw batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
+    uint32_t parts = 1; /* > 1: a query's units are merged in `parts` groups (pseudo-query p * nq + q of goff) and the groups' lists once more */
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
@@ -707,7 +710,13 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     static const uint32_t units_cap = getenv("XGM_MAX_UNITS_PER_QUERY") ? (uint32_t)atoi(getenv("XGM_MAX_UNITS_PER_QUERY")) : 0u;   /* A/B switch for measurements */
     /* units x k candidates must fit the merge kernel's LDS sort; a unit's window there is k_max entries (not the next power of two) */
     static const bool units_by_kpad = getenv("XGM_UNITS_BY_KPAD") != nullptr;                      /* A/B switch: the round-2 bound */
-    uint32_t g_max = std::max(g_min, std::min(n_stripes, std::max(1u, merge_budget / (units_by_kpad ? k_pad : std::max(1u, bp->k_max)))));
+    /* ... per PART: a query whose units exceed one merge's capacity is merged in up to kMaxParts groups and the groups' lists once more
+     * (xgm_merge_parts), so that the heaviest conjunctions — frequent-term phrases whose every document is a candidate — can be cut
+     * down to single stripes: the launch ends with its longest unit (measured: C5's kernel ran at 20 % mean occupancy behind them) */
+    static const uint32_t kMaxParts = getenv("XGM_MAX_PARTS") ? (uint32_t)std::max(1, atoi(getenv("XGM_MAX_PARTS"))) : 4u;      /* A/B switch */
+    const uint32_t units_per_part = std::max(1u, merge_budget / (units_by_kpad ? k_pad : std::max(1u, bp->k_max)));
+    const uint32_t parts_ok = (bp->andw && nq > 4u) ? kMaxParts : 1u;
+    uint32_t g_max = std::max(g_min, std::min(n_stripes, units_per_part * parts_ok));
     if (units_cap) g_max = std::max(g_min, std::min(g_max, units_cap));
     if ((uint64_t)g_min * k_pad > XGM_MERGE_CAP) return XGM_UNSUPPORTED;
     /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
@@ -785,34 +794,45 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             unit_cost *= std::max(1.02, units / target_units);
         }
     }
-    bp->goff.assign(nq + 1, 0);
     bp->work.clear();
     uint32_t spg_used = 1;
     /* units in descending cost order (longest first); the units of a query share one cost, so ordering the QUERIES
      * (stable) orders the units exactly as a stable sort of all of them would */
     std::vector<uint32_t> gqv(nq), spgv(nq), order(nq);
+    uint32_t g_most_q = 0;
     for (uint32_t i = 0; i < nq; ++i) {
         uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
         uint32_t spg = (n_stripes + gq - 1) / gq;
         gq = (n_stripes + spg - 1) / spg;
         spg_used = std::max(spg_used, spg);
         gqv[i] = gq; spgv[i] = spg; order[i] = i;
-        bp->goff[i + 1] = bp->goff[i] + gq;
+        g_most_q = std::max(g_most_q, gq);
     }
+    /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
+    const uint32_t P = (g_most_q + units_per_part - 1) / units_per_part;
+    bp->parts = std::max(1u, P);
+    const uint32_t upp = bp->parts > 1 ? units_per_part : g_most_q + 1u;
+    bp->goff.assign((size_t)nq * bp->parts + 1, 0);
+    for (uint32_t p = 0; p < bp->parts; ++p)
+        for (uint32_t i = 0; i < nq; ++i) {
+            const uint32_t lo = std::min(gqv[i], p * upp), hi = std::min(gqv[i], (p + 1) * upp);
+            bp->goff[(size_t)p * nq + i + 1] = bp->goff[(size_t)p * nq + i] + (bp->parts > 1 ? hi - lo : gqv[i]);
+        }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] / gqv[a] > cost[b] / gqv[b]; });
-    bp->work.reserve(bp->goff[nq]);
+    bp->work.reserve(bp->goff.back());
     for (uint32_t oi = 0; oi < nq; ++oi) {
         const uint32_t i = order[oi], gq = gqv[i], spg = spgv[i];
         for (uint32_t g = 0; g < gq; ++g) {
             xgm_work w;
-            w.qi = i; w.s_begin = g * spg; w.s_end = std::min(n_stripes, (g + 1) * spg); w.slot = bp->goff[i] + g;
+            const uint32_t p = bp->parts > 1 ? g / upp : 0u;
+            w.qi = i; w.s_begin = g * spg; w.s_end = std::min(n_stripes, (g + 1) * spg); w.slot = bp->goff[(size_t)p * nq + i] + (g - p * (bp->parts > 1 ? upp : 0u));
             bp->work.push_back(w);
         }
     }
     bp->n_work = (uint32_t)bp->work.size();
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
-    for (uint32_t i = 0; i < nq; ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
+    for (size_t i = 0; i + 1 < bp->goff.size(); ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
     const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase, bp->sided == 2)
                         : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
@@ -845,20 +865,20 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)bp.n_work * bp.k_stride_c))) return rc;
     if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)bp.n_work))) return rc;
     /* every per-call input goes up in ONE copy: [dev queries | max_possible | work list | k | group offsets] */
+    const uint32_t P = bp.parts, npq = nq * P;              /* pseudo-queries of the units' merge (parts of queries, plan_batch) */
     const size_t o_dq = 0, b_dq = (size_t)nq * sizeof(xgm_dev_query);
-    const size_t o_mp = o_dq + b_dq, b_mp = (size_t)nq * 8;
+    const size_t o_mp = o_dq + b_dq, b_mp = (size_t)npq * 8;
     const size_t o_wk = o_mp + b_mp, b_wk = (size_t)bp.n_work * sizeof(xgm_work);
-    const size_t o_kq = o_wk + b_wk, b_kq = (size_t)nq * 4;
-    const size_t o_go = o_kq + b_kq, b_go = ((size_t)nq + 1) * 4;
+    const size_t o_kq = o_wk + b_wk, b_kq = (size_t)npq * 4;
+    const size_t o_go = o_kq + b_kq, b_go = ((size_t)npq + 1) * 4;
     const size_t o_ro = o_go + b_go, b_ro = rows ? (size_t)nq * 4 : 0;
     const size_t in_bytes = (o_ro + b_ro + 15) & ~(size_t)15;
     if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
     if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
     unsigned char* hin = (unsigned char*)s->h_work;
     memcpy(hin + o_dq, h_dq, b_dq);
-    memcpy(hin + o_mp, h_mp, b_mp);
+    for (uint32_t p = 0; p < P; ++p) { memcpy(hin + o_mp + (size_t)p * nq * 8, h_mp, (size_t)nq * 8); memcpy(hin + o_kq + (size_t)p * nq * 4, h_kq, (size_t)nq * 4); }
     memcpy(hin + o_wk, bp.work.data(), b_wk);
-    memcpy(hin + o_kq, h_kq, b_kq);
     memcpy(hin + o_go, bp.goff.data(), b_go);
     if (rows) memcpy(hin + o_ro, rows, b_ro);
     const uint64_t t_cp = now_ns();
@@ -924,9 +944,23 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     if (pe1) HIP_TRY(hipEventRecord(pe1, stream));
     const uint64_t t_mk = now_ns();
     g_host_ns[6] += t_mk - t_up;
-    if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
-                               d_hdrs, s->d_maxposs, rows ? (const uint32_t*)(din + o_ro) : nullptr, stream)))
-        return rc;
+    const uint32_t* d_rows = rows ? (const uint32_t*)(din + o_ro) : nullptr;
+    if (P == 1u) {
+        if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
+                                   d_hdrs, s->d_maxposs, d_rows, stream)))
+            return rc;
+    } else {
+        /* the units of a heavy query exceed one merge's capacity: its parts are merged like queries of their own (row p * nq + q of a
+         * scratch result), then the parts' lists per query */
+        if ((rc = grow(&s->d_part_hits, &s->cap_part_hits, (size_t)npq * k_stride))) return rc;
+        if ((rc = grow(&s->d_part_hdrs, &s->cap_part_hdrs, (size_t)npq))) return rc;
+        if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, npq, bp.merge_cap, k_stride, s->d_part_hits,
+                                   s->d_part_hdrs, s->d_maxposs, nullptr, stream)))
+            return rc;
+        if ((rc = xgm_launch_merge_parts(s->d_part_hits, s->d_part_hdrs, P, nq, k_stride, s->d_kq, std::max(256u, next_pow2(P * k_stride)), d_hits, d_hdrs,
+                                         d_rows, stream)))
+            return rc;
+    }
     g_host_ns[7] += now_ns() - t_mk;
     g_host_ns[2] += now_ns() - t_st;
     g_host_ns[3] += 1;

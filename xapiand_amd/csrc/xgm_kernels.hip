@@ -2196,9 +2196,12 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
 /* Shard merge after the all-gather: sources are whole result lists (xgm_hit) of each shard. */
 __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit* __restrict__ all_hits, const xgm_result_hdr* __restrict__ all_hdrs,
                                                                    uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* __restrict__ kq,
-                                                                   uint32_t cap, xgm_hit* __restrict__ hits, xgm_result_hdr* __restrict__ hdrs) {
+                                                                   uint32_t cap, xgm_hit* __restrict__ hits, xgm_result_hdr* __restrict__ hdrs,
+                                                                   uint32_t unshard, const uint32_t* __restrict__ row_of) {
+    /* unshard == 0: the sources are the PARTS of one shard's query (same docid space; xgm_launch_merge_parts) */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, qi = blockIdx.x;
+    const uint32_t orow = row_of ? row_of[qi] : qi;
     TopK tk;
     tk.w = reinterpret_cast<uint64_t*>(smem);
     tk.d = reinterpret_cast<uint32_t*>(smem + (size_t)cap * 8);
@@ -2227,7 +2230,7 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit*
         for (uint32_t i = tid; i < h.n_hits; i += XGM_WG) {
             xgm_hit c = src[i];
             tk.w[base + i] = (uint64_t)__double_as_longlong(c.weight);
-            tk.d[base + i] = (c.docid - 1u) * n_shards + sh + 1u;
+            tk.d[base + i] = unshard ? (c.docid - 1u) * n_shards + sh + 1u : c.docid;
             tk.m[base + i] = c.subqs_matched;
         }
         __syncthreads();
@@ -2238,13 +2241,13 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit*
     for (uint32_t i = tid; i < n; i += XGM_WG) {
         xgm_hit hit;
         hit.docid = tk.d[i]; hit.subqs_matched = tk.m[i]; hit.weight = __longlong_as_double((long long)tk.w[i]);
-        hits[(size_t)qi * k_stride + i] = hit;
+        hits[(size_t)orow * k_stride + i] = hit;
     }
     if (tid == 0) {
         xgm_result_hdr r;
         r.n_hits = n; r.max_weight_subqs_matched = max_subqs; r.matches_exact = matches;
         r.max_attained = max_attained; r.max_possible = max_possible;
-        hdrs[qi] = r;
+        hdrs[orow] = r;
     }
 }
 
@@ -2536,13 +2539,23 @@ int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint
     return 0;
 }
 
+int xgm_launch_merge_parts(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_parts, uint32_t nq, uint32_t k_stride,
+                           const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs, const uint32_t* row_of, hipStream_t stream) {
+    const size_t smem = (size_t)cap * 16 + 64;
+    { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_shards_kernel, smem, seen)) return rc_; }
+    hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_parts, nq,
+                       k_stride, kq, cap, hits, hdrs, 0u, row_of);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
                             hipStream_t stream) {
     const size_t smem = (size_t)cap * 16 + 64;
     { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_shards_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_shards, nq,
-                       k_stride, kq, cap, hits, hdrs);
+                       k_stride, kq, cap, hits, hdrs, 1u, (const uint32_t*)nullptr);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -53,6 +53,10 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,
                      xgm_result_hdr* hdrs, const double* max_possible, const uint32_t* row_of, hipStream_t stream);
+/* the parts of a query's units (plan_batch, parts > 1) merged once more: all_hits [n_parts][nq][k_stride], docids as they are; row q of
+ * the result goes to row_of[q] (q when NULL) */
+int xgm_launch_merge_parts(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_parts, uint32_t nq, uint32_t k_stride,
+                           const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs, const uint32_t* row_of, hipStream_t stream);
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
                             hipStream_t stream);
