@@ -428,7 +428,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             if (ev[u] && !((dense_mask >> (g * 4u + u)) & 1ull)) c_w[(size_t)(g * 4u + u) * kOrwCand + o] = 0;
                             if (fix && g * 4u + u < T) {
                                 const uint32_t t = g * 4u + u;
-                                sumA += ev[u] ? (ev[u] >= 3u ? rl32(qA2_reg, t) : rl32(qA1_reg, t)) : 0u;
+                                const uint32_t a2_ = rl32(qA2_reg, t), a1_ = rl32(qA1_reg, t);      /* (read before the per-lane choice: no branches around readlanes) */
+                                sumA += ev[u] ? (ev[u] >= 3u ? a2_ : a1_) : 0u;
                             }
                         }
                     }
@@ -459,7 +460,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             subqs += ev[u] ? 1u : 0u;
                             if (fix && t0 + u < T) {
                                 const uint32_t t = t0 + u;
-                                sumA += ev[u] ? (ev[u] >= 3u ? rl32(qA2_reg, t) : rl32(qA1_reg, t)) : 0u;
+                                const uint32_t a2_ = rl32(qA2_reg, t), a1_ = rl32(qA1_reg, t);      /* (read before the per-lane choice: no branches around readlanes) */
+                                sumA += ev[u] ? (ev[u] >= 3u ? a2_ : a1_) : 0u;
                             }
                         }
                     }
