@@ -109,12 +109,18 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("XGM_BENCH_SHARE_GPU") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # XGM_BENCH_BACKEND=gloo + XGM_BENCH_SHARE_GPU=1: the N > 1 code path on a box with ONE GPU (RCCL refuses two ranks per device) — a
+        # functional check of this script, not a measurement
+        backend = os.environ.get("XGM_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- index: this rank's shard, generated + inverted + block-encoded on the GPU ----------------
     n_docs_global = args.docs_per_gpu * world
@@ -180,7 +186,8 @@ def main():
     kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed steps (HIP events)
     kernel_name = db.last_kernel_name()
     db.set_profiling(0)
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")      # where the small collectives of this script live
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -256,7 +263,7 @@ def main():
     # ---- N > 1: every rank's own match kernel against its own GPU's roofline (per-GPU bytes use the shard's own df) ------
     per_rank = None
     if world > 1:
-        mine = torch.tensor([kernel_ms if kernel_ms and kernel_ms > 0 else 0.0, float(traffic or model_bytes or bytes_per_launch)], dtype=torch.float64, device=dev)
+        mine = torch.tensor([kernel_ms if kernel_ms and kernel_ms > 0 else 0.0, float(traffic or model_bytes or bytes_per_launch)], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = []
