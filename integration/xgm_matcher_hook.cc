@@ -308,6 +308,78 @@ bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, const SpyAd
     return it->second.slot_of(spy, slot);
 }
 
+
+/* ProtoMSet::add for a search by relevance (protomset.h:340-400) with the weight the matcher's loop hands it, and the loop's own
+ * `weight < min_weight` test in front (matcher.cc:500-505): what POSITIONAL_REFERENCE replays on the host. */
+struct RefProtoMSet {
+    struct Item { double w; Xapian::docid did; uint32_t subqs; };
+    size_t max_size; uint64_t check_at_least;
+    std::vector<Item> results;
+    std::vector<uint32_t> heap;                 /* indices into results, worst on top */
+    bool heap_built = false;
+    double min_weight = 0.0, max_weight = 0.0;
+    uint32_t max_weight_subqs = 0;
+    uint64_t known_matching_docs = 0;
+    static bool before(const Item& a, const Item& b) { return a.w > b.w || (a.w == b.w && a.did < b.did); }      /* msetcmp_by_relevance<true> */
+    bool worse_first(uint32_t a, uint32_t b) const { return before(results[a], results[b]); }
+    void add(const Item& it) {
+        ++known_matching_docs;
+        if (it.w > max_weight) { max_weight = it.w; max_weight_subqs = it.subqs; }
+        if (it.w < min_weight) return;
+        if (results.size() < max_size) { results.push_back(it); return; }
+        if (max_size == 0) return;
+        auto cmp = [this](uint32_t a, uint32_t b) { return worse_first(a, b); };
+        if (!heap_built) {
+            heap_built = true;
+            for (uint32_t i = 0; i < results.size(); ++i) heap.push_back(i);
+            std::make_heap(heap.begin(), heap.end(), cmp);
+            if (known_matching_docs >= check_at_least) min_weight = results[heap.front()].w;
+        }
+        const uint32_t worst = heap.front();
+        if (!before(it, results[worst])) return;
+        results[worst] = it;
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        heap.back() = worst;
+        std::push_heap(heap.begin(), heap.end(), cmp);
+        if (known_matching_docs >= check_at_least) min_weight = results[heap.front()].w;
+    }
+};
+
+/* The weight the reference freezes (selectpostlist.cc:28-55): that of the first document after `after` that ALL the query's terms
+ * index, weighed like MultiAndPostList::get_weight does — the plan's leaf order and term weights, BM25Weight::get_sumpart's
+ * operations (bm25weight.cc:170-181).  Found with the shard's own posting lists.  false: there is none. */
+bool frozen_weight(const Xapian::Database& db, const std::vector<std::string>& terms, const xgm_query& plan, Xapian::docid after, double* w_out) {
+    const uint32_t n = plan.n_terms;
+    std::vector<Xapian::PostingIterator> it(n), end(n);
+    for (uint32_t p = 0; p < n; ++p) {
+        const std::string& t = terms[plan.terms[p].phrase_index];
+        it[p] = db.postlist_begin(t); end[p] = db.postlist_end(t);
+        if (it[p] == end[p]) return false;
+    }
+    Xapian::docid did = after + 1;
+    while (true) {
+        bool all = true;
+        for (uint32_t p = 0; p < n; ++p) {
+            it[p].skip_to(did);
+            if (it[p] == end[p]) return false;
+            if (*it[p] != did) { did = *it[p]; all = false; break; }
+        }
+        if (all) break;
+    }
+    const double len = (double)db.get_doclength(did);
+    double normlen = len * plan.len_factor;
+    normlen = normlen > plan.min_normlen ? normlen : plan.min_normlen;
+    const double denom_len = plan.k1 * (normlen * plan.b + (1.0 - plan.b));
+    double weight = 0.0;
+    for (uint32_t p = 0; p < n; ++p) {
+        const double wdf = (double)it[p].get_wdf();
+        const double denom = denom_len + wdf;
+        weight = weight + plan.terms[p].termweight * (wdf / denom);
+    }
+    *w_out = weight;
+    return true;
+}
+
 }  // namespace
 
 void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch) {
@@ -383,6 +455,8 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         L.d.b = unserialise_double(&p, end); L.d.min_normlen = unserialise_double(&p, end);
     }
     L.d.first = first; L.d.maxitems = maxitems; L.d.check_at_least = check_at_least;
+    /* (reference mode needs exact positional semantics first: the pruned search's page is the intended one and only a hint whether the
+     * page fills; the replay below replaces it) */
 
     /* merged statistics, exactly what the CPU matcher would weigh with (weightinternal.h:72-111) */
     xgm_global_stats gs;
@@ -479,6 +553,60 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     if (rc > 0) { ++g_dev; return false; }                                   /* declined by the device path: CPU matcher */
     if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
 
+    /* POSITIONAL_REFERENCE: a full page of a positional query — the reference's own answer, replayed (see the header) */
+    const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
+    bool replayed = false;
+    uint64_t replay_known = 0;
+    if (plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0 && hdr.n_hits == k) {
+        /* how large is the match (every candidate's positions tested: check_at_least beyond the index), then all of it in one page sized to
+         * it — a page of up to 192 stays on the wave kernel */
+        xgm_query_desc d2 = L.d;
+        d2.first = 0; d2.maxitems = k; d2.check_at_least = 0xFFFFFFFFu;
+        xgm_query plan2;
+        std::vector<xgm_hit> all(k);
+        xgm_result_hdr hdr2;
+        memset(&hdr2, 0, sizeof hdr2);
+        int rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
+        if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, k, all.data(), &hdr2);
+        if (rc2 == XGM_OK && !(hdr2.matches_exact & XGM_MATCHES_LOWER_BOUND) && XGM_MATCHES_COUNT(hdr2.matches_exact) > k) {
+            const uint64_t m_exact = XGM_MATCHES_COUNT(hdr2.matches_exact);
+            if (m_exact > XGM_MAX_K) { ++g_dev; return false; }                  /* the match exceeds a device page: CPU matcher */
+            d2.maxitems = (uint32_t)m_exact;
+            all.assign(m_exact, xgm_hit());
+            rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
+            if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, (uint32_t)m_exact, all.data(), &hdr2);
+        }
+        if (rc2 < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+        if (rc2 > 0 || (hdr2.matches_exact & XGM_MATCHES_LOWER_BOUND) || XGM_MATCHES_COUNT(hdr2.matches_exact) != hdr2.n_hits) { ++g_dev; return false; }
+        all.resize(hdr2.n_hits);
+        std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+        RefProtoMSet pm;
+        pm.max_size = k; pm.check_at_least = plan.check_at_least;
+        bool frozen = false, have_w = false, none_left = false;
+        double w_star = 0.0;
+        Xapian::docid trigger = 0;
+        for (const xgm_hit& h : all) {
+            if (!(pm.min_weight > 0.0)) {                                      /* vet(): w_min <= 0 — the document's own weight */
+                pm.add(RefProtoMSet::Item{h.weight, h.docid, h.subqs_matched});
+                if (pm.min_weight > 0.0) { frozen = true; trigger = h.docid; }
+                continue;
+            }
+            if (frozen && !have_w && !none_left) { have_w = frozen_weight(db, L.terms, plan, trigger, &w_star); none_left = !have_w; }
+            if (!have_w) break;                                                 /* (cannot happen: h itself is such a document) */
+            if (w_star < pm.min_weight) break;                                  /* vet() rejects every later document untested */
+            pm.add(RefProtoMSet::Item{w_star, h.docid, h.subqs_matched});
+        }
+        std::sort(pm.results.begin(), pm.results.end(), RefProtoMSet::before);
+        hits.assign(std::max<size_t>(pm.results.size(), 1), xgm_hit());
+        for (size_t i = 0; i < pm.results.size(); ++i) { hits[i].docid = pm.results[i].did; hits[i].weight = pm.results[i].w; hits[i].subqs_matched = pm.results[i].subqs; }
+        hdr.n_hits = (uint32_t)pm.results.size();
+        hdr.max_attained = pm.max_weight;
+        hdr.max_weight_subqs_matched = pm.max_weight_subqs;
+        hdr.matches_exact = hdr2.matches_exact;
+        replayed = true;
+        replay_known = pm.known_matching_docs;
+    }
+
     /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682) */
     std::vector<Result> items;
     const uint32_t skip = std::min<uint32_t>(first, hdr.n_hits);
@@ -500,7 +628,9 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     uint32_t lb = 0, est = 0, ub = 0;
     const uint64_t m_all = XGM_MATCHES_COUNT(hdr.matches_exact);
     const bool every_match_visited = L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT;     /* (positional: the frozen weight) */
-    if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
+    if (replayed) {
+        xgm_mset_bounds_known(&plan, &hdr, replay_known, &lb, &est, &ub);        /* ProtoMSet's own count of the replay */
+    } else if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
         xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
     } else if (plain && g_exact_bounds.load(std::memory_order_relaxed) && every_match_visited && k > 0 && hdr.n_hits == k &&
                !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least && m_all <= XGM_MAX_K) {

@@ -63,12 +63,15 @@ void set_enabled(bool on);                 /* default: on */
 /* PHRASE / NEAR with maxitems < matches: the reference's SelectPostList serves a stale cached weight
  * (src/xapian/matcher/selectpostlist.cc:28-55) and its top-k is then not a prefix of its own full ranking; the device returns
  * the intended top-k.  The choice is the deployment's and has to be made:
- *   POSITIONAL_DECLINE  — positional queries stay on the CPU matcher (byte-compatible by construction);
- *   POSITIONAL_INTENDED — answered on the device with the intended semantics.
- * Until set_positional_mode has been called positional queries are declined.  (Replaying the quirk from the device's results
- * would need the weight of the first document of the underlying CONJUNCTION after the proto-MSet filled — the value the
- * reference freezes — which no positional search returns) */
-enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1 };
+ *   POSITIONAL_DECLINE   — positional queries stay on the CPU matcher (byte-compatible by construction);
+ *   POSITIONAL_INTENDED  — answered on the device with the intended semantics;
+ *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the whole match is fetched (it must fit
+ *     one device page, XGM_MAX_K documents; else the search is left to the CPU matcher) and the reference's loop is replayed on the
+ *     host in docid order — true weights until ProtoMSet's min_weight turns positive, then the FROZEN weight: that of the first
+ *     document of the underlying conjunction after that point (vet() weighs before test_doc(); found with the shard's own posting
+ *     lists, a few skip_to's), served for every later match and compared against min_weight to skip the rest.
+ * Until set_positional_mode has been called positional queries are declined. */
+enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1, POSITIONAL_REFERENCE = 2 };
 void set_positional_mode(PositionalMode m);
 inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONAL_DECLINE : POSITIONAL_INTENDED); }
 

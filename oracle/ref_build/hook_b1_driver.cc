@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
+        else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);
         else if (!strcmp(argv[a], "--exact-bounds")) { xgm_hook::set_exact_bounds(true); exact_bounds_on = true; }
         else if (!strcmp(argv[a], "--collapse-intended")) xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_INTENDED);
         else if (!strcmp(argv[a], "--stale")) stale = true;

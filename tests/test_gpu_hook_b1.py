@@ -251,3 +251,29 @@ def test_exact_match_count_bounds_through_the_hook(built, glass):
     out = run_b1("--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
     assert out["http_total_equal"] == len(qs), out            # the HTTP "total" field (get_matches_estimated) of every response
+
+
+def test_positional_reference_mode_is_byte_compatible(built, glass):
+    """PHRASE / NEAR with maxitems < matches — C5's literal shape — where the reference's SelectPostList serves a frozen weight
+    (selectpostlist.cc:28-55).  POSITIONAL_INTENDED returns the prefix of the reference's own full ranking and so
+    differs from the CPU matcher on part of these queries; POSITIONAL_REFERENCE fetches the match from the device and replays the
+    reference's loop on the host: hook on == hook off, stale weights, percentages and match-count bounds included."""
+    d, one, _ = glass
+    corpus = H.Corpus(N_DOCS, VOCAB)
+    qs = []
+    for q in (H.gen_phrase_queries(160, N_DOCS, VOCAB, seed=101, lengths=(2, 3)) + H.gen_phrase_queries(40, N_DOCS, VOCAB, seed=102, window_extra=3) +
+              H.gen_phrase_queries(40, N_DOCS, VOCAB, seed=103, window_extra=4, op="NEAR")):
+        m = H.oracle_search(corpus, q["op"], q["terms"], 0, 1, window=q.get("window", 0))[1].matches
+        if 12 <= m <= 1000:
+            qs.append(dict(q, first=(0, 0, 3)[len(qs) % 3], maxitems=(10, 5, 7)[len(qs) % 3]))
+    corpus.close()
+    assert len(qs) >= 24, len(qs)
+    qf = str(d / "qpr.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
+    assert out["answered_on_device"] == len(qs), out
+    # the same queries with the intended semantics: the device's answer is NOT the CPU matcher's on some of them (that is the quirk)
+    r = subprocess.run([HOOK_B1, qf, one], capture_output=True, text=True, timeout=900)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert line and json.loads(line[-1])["mismatches"] > 0, r.stdout[-2000:]
