@@ -15,6 +15,7 @@
 #include "xapian/error.h"
 #include "xapian/api/enquireinternal.h"
 #include "xapian/api/msetinternal.h"
+#include "xapian/api/postlist.h"
 #include "xapian/api/queryinternal.h"
 #include "xapian/api/result.h"
 #include "xapian/common/pack.h"
@@ -36,9 +37,9 @@ struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumn
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
 std::map<std::string, SpyAdapter> g_spy_adapters;
-std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false};
+std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false}, g_replay{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
-std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0};
+std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0};
 
 struct Lowered {
     xgm_query_desc d;
@@ -309,6 +310,36 @@ bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, const SpyAd
 }
 
 
+/* What maybe_replay needs from the Matcher::get_mset call that is about to run get_local_mset on this thread */
+struct ReplayCtx { bool armed = false; const Xapian::Weight::Internal* stats = nullptr; const Xapian::Weight* wt = nullptr; bool full_db_has_positions = false; };
+thread_local ReplayCtx tl_replay;
+
+/* ALL matching documents of a search, in docid order, as a PostList for Matcher::get_local_mset's loop (see set_replay) */
+class ReplayPostList : public Xapian::Internal::PostList {
+    std::vector<xgm_hit> hits;
+    size_t pos = size_t(-1);                   /* before the first */
+    Xapian::doccount tf_min, tf_est, tf_max;
+    double max_weight;
+  public:
+    ReplayPostList(std::vector<xgm_hit>&& h, Xapian::doccount mn, Xapian::doccount est, Xapian::doccount mx, double mw)
+        : hits(std::move(h)), tf_min(mn), tf_est(est), tf_max(mx), max_weight(mw) {}
+    Xapian::doccount get_termfreq_min() const override { return tf_min; }
+    Xapian::doccount get_termfreq_max() const override { return tf_max; }
+    Xapian::doccount get_termfreq_est() const override { return tf_est; }
+    Xapian::docid get_docid() const override { return hits[pos].docid; }
+    double get_weight(Xapian::termcount, Xapian::termcount) const override { return hits[pos].weight; }
+    bool at_end() const override { return pos != size_t(-1) && pos >= hits.size(); }
+    double recalc_maxweight() override { return max_weight; }
+    PostList* next(double) override { ++pos; return nullptr; }
+    PostList* skip_to(Xapian::docid did, double) override {
+        if (pos == size_t(-1)) pos = 0;
+        while (pos < hits.size() && hits[pos].docid < did) ++pos;
+        return nullptr;
+    }
+    Xapian::termcount count_matching_subqs() const override { return hits[pos].subqs_matched; }
+    std::string get_description() const override { return "XgmReplay(" + std::to_string(hits.size()) + ")"; }
+};
+
 /* ProtoMSet::add for a search by relevance (protomset.h:340-400) with the weight the matcher's loop hands it, and the loop's own
  * `weight < min_weight` test in front (matcher.cc:500-505): what POSITIONAL_REFERENCE replays on the host. */
 struct RefProtoMSet {
@@ -398,13 +429,14 @@ void set_positional_mode(PositionalMode m) { g_positional.store(int(m)); }
 void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
 void set_exact_bounds(bool on) { g_exact_bounds.store(on); }
 void set_near_colocated_terms(bool may_exist) { g_near_colocated.store(may_exist); }
+void set_replay(bool on) { g_replay.store(on); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_spy_adapters[spy_class_name] = std::move(adapter);
 }
 Counters counters() {
     return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load(), g_sorted.load(), g_spied.load(),
-                    g_collapsed.load(), g_columns.load()};
+                    g_collapsed.load(), g_columns.load(), g_replayed.load()};
 }
 
 bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const Xapian::Weight::Internal& stats,
@@ -415,7 +447,20 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
                   bool sort_val_reverse, double time_limit,
                   const std::vector<Xapian::Internal::opt_intrusive_ptr<Xapian::MatchSpy>>& matchspies, Xapian::MSet& out) {
     typedef Xapian::Enquire::Internal EI;
+    tl_replay.armed = false;
     if (!g_enabled.load(std::memory_order_relaxed)) return false;
+    /* searches whose exact semantics live in the reference's own collation (set_replay): left to get_local_mset, which will ask
+     * maybe_replay for the device's match list */
+    {
+        const bool basic = db.size() == 1 && !mdecider && time_limit == 0.0 && stats.rset_size == 0 && order != Xapian::Enquire::DESCENDING &&
+                           wtscheme.name() == "Xapian::BM25Weight";
+        const bool by_collapse = collapse_max != 0 && g_collapse.load(std::memory_order_relaxed) == COLLAPSE_REFERENCE;
+        const bool by_cutoff = (percent_threshold != 0 || weight_threshold != 0.0) && g_replay.load(std::memory_order_relaxed);
+        if (basic && (by_collapse || by_cutoff)) {
+            tl_replay = ReplayCtx{true, &stats, &wtscheme, full_db_has_positions};
+            return false;
+        }
+    }
     /* eligibility (widened by row (f).3) */
     const bool by_rel = sort_by == int(EI::REL);
     const bool by_value = sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL) || sort_by == int(EI::REL_VAL);
@@ -530,7 +575,11 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
              * min_weight stays 0) or when the match does not exceed check_at_least (min_weight is raised only once checked_enough());
              * otherwise what it sees depends on the CPU matcher's traversal: leave the search to it. */
             const bool value_leads = sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL);
-            if (rc == XGM_OK && !value_leads && XGM_MATCHES_COUNT(hdr.matches_exact) > plan.check_at_least) { ++g_shape; return false; }
+            if (rc == XGM_OK && !value_leads && XGM_MATCHES_COUNT(hdr.matches_exact) > plan.check_at_least) {
+                if (g_replay.load(std::memory_order_relaxed) && sort_by == int(EI::REL)) tl_replay = ReplayCtx{true, &stats, &wtscheme, full_db_has_positions};
+                else ++g_shape;
+                return false;
+            }
             if (rc == XGM_OK) {
                 for (size_t i = 0; i < spies.size(); ++i) {
                     const std::vector<std::string>& vals = spies[i].col->values;
@@ -555,6 +604,17 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
 
     /* POSITIONAL_REFERENCE: a full page of a positional query — the reference's own answer, replayed (see the header) */
     const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
+    /* exact match-count bounds for the shapes whose known_matching_docs depends on more than the match in docid order being visited in
+     * full (OR, AND_MAYBE, trees: the tree prunes — but only documents the loop would drop anyway): a full page over a match that fits
+     * one device page is replayed through the reference's own loop, which counts for itself */
+    if (plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0 && hdr.n_hits == k && !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) &&
+        !(L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT)) {
+        const uint64_t m_ = XGM_MATCHES_COUNT(hdr.matches_exact);
+        if (m_ > k && m_ >= plan.check_at_least && m_ <= XGM_MAX_K) {
+            tl_replay = ReplayCtx{true, &stats, &wtscheme, full_db_has_positions};
+            return false;
+        }
+    }
     bool replayed = false;
     uint64_t replay_known = 0;
     if (plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0 && hdr.n_hits == k) {
@@ -684,6 +744,68 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     if (by_value) ++g_sorted;
     if (!spies.empty()) ++g_spied;
     return true;
+}
+
+Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapian::Query& query, Xapian::Internal::PostList* pl) {
+    const ReplayCtx ctx = tl_replay;
+    tl_replay.armed = false;
+    if (!ctx.armed || !pl) return pl;
+    Shard sh;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(db.get_uuid());
+        if (it == g_shards.end()) { ++g_unreg; return pl; }
+        sh = it->second;
+    }
+    if (sh.revision != db.get_revision()) { ++g_rev; return pl; }
+    Lowered L;
+    L.idx = sh.idx;
+    if (!lower(query, &L)) { ++g_shape; return pl; }
+    const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
+    if (positional && g_positional.load(std::memory_order_relaxed) != POSITIONAL_INTENDED) { ++g_shape; return pl; }   /* the frozen weight lives in the tree */
+    {
+        const std::string ser = ctx.wt->serialise();
+        const char* p = ser.data();
+        const char* end = p + ser.size();
+        L.d.k1 = unserialise_double(&p, end); L.d.k2 = unserialise_double(&p, end); L.d.k3 = unserialise_double(&p, end);
+        L.d.b = unserialise_double(&p, end); L.d.min_normlen = unserialise_double(&p, end);
+    }
+    xgm_global_stats gs;
+    memset(&gs, 0, sizeof gs);
+    gs.total_length = ctx.stats->total_length;
+    gs.collection_size = ctx.stats->collection_size;
+    gs.full_db_has_positions = ctx.full_db_has_positions ? 1u : 0u;
+    for (size_t i = 0; i < L.terms.size(); ++i) {
+        auto it = ctx.stats->termfreqs.find(L.terms[i]);
+        if (it != ctx.stats->termfreqs.end()) { gs.termfreq[i] = it->second.termfreq; continue; }
+        uint32_t tf = 0;
+        if (!(i < L.lazy.size() && L.lazy[i]) || xgm_lookup_term(sh.idx, L.terms[i].data(), L.terms[i].size(), nullptr, &tf, nullptr, nullptr) != XGM_OK) { ++g_shape; return pl; }
+        gs.termfreq[i] = tf;
+    }
+    /* how large is the match (positional: every candidate's positions tested), then all of it */
+    L.d.first = 0; L.d.maxitems = 1; L.d.check_at_least = 0xFFFFFFFFu;
+    xgm_query plan;
+    xgm_hit one;
+    xgm_result_hdr hdr;
+    memset(&hdr, 0, sizeof hdr);
+    int rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
+    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, 1, &one, &hdr);
+    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    const uint64_t m = XGM_MATCHES_COUNT(hdr.matches_exact);
+    if (rc > 0 || (hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) || m == 0 || m > XGM_MAX_K) { ++g_dev; return pl; }      /* nothing to gain / beyond a device page */
+    std::vector<xgm_hit> all(m);
+    L.d.maxitems = (uint32_t)m;
+    rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
+    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, (uint32_t)m, all.data(), &hdr);
+    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    if (rc > 0 || hdr.n_hits != m) { ++g_dev; return pl; }
+    std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+    /* the static figures of the tree this list stands in for */
+    Xapian::Internal::PostList* r = new ReplayPostList(std::move(all), pl->get_termfreq_min(), pl->get_termfreq_est(), pl->get_termfreq_max(), pl->recalc_maxweight());
+    delete pl;
+    ++g_replayed;
+    ++g_answered;
+    return r;
 }
 
 }  // namespace xgm_hook

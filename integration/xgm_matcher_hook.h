@@ -51,6 +51,8 @@
 
 #include "xgm.h"
 
+namespace Xapian { namespace Internal { class PostList; } }
+
 namespace xgm_hook {
 
 /* registry (thread-safe).  batch: the index's micro-batching queue (0 = leave it as it is). */
@@ -85,8 +87,22 @@ void set_near_colocated_terms(bool may_exist);
  * the proto-MSet overflows or collapse_max > 1 (matcher/collapser.cc:59-76, protomset.h:310-317); the device does.
  *   COLLAPSE_DECLINE (default) — collapsed searches stay on the CPU matcher;
  *   COLLAPSE_INTENDED — answered on the device: per key the best collapse_max documents under the ranking in force. */
-enum CollapseMode { COLLAPSE_DECLINE = 0, COLLAPSE_INTENDED = 1 };
+enum CollapseMode { COLLAPSE_DECLINE = 0, COLLAPSE_INTENDED = 1, COLLAPSE_REFERENCE = 2 };
 void set_collapse_mode(CollapseMode m);
+
+/* REPLAY — the reference's own collation over the device's match.  Dynamic pruning in the posting-list tree only ever skips documents
+ * whose weight is below ProtoMSet's min_weight, and the matcher's loop drops exactly those too (`if (weight < min_weight) continue`,
+ * matcher.cc:500-505): the documents that reach ProtoMSet — and with them the collapser, the spies, the cut-offs, known_matching_docs —
+ * are the same whether the loop walks the tree or the plain list of ALL matching documents in docid order with their weights.  So for
+ * a search the device path cannot answer with the reference's exact semantics (COLLAPSE_REFERENCE: the snapshot's collapser, bugs and
+ * all; with set_replay(true) also percentage / weight cut-offs and spies by relevance whose match exceeds check_at_least) the hook
+ * fetches the whole match from the device — it has to fit one device page, XGM_MAX_K documents; else the search stays on the CPU —
+ * and hands Matcher::get_local_mset a PostList that replays it (the second hunk of matcher_hook.patch): ProtoMSet, Collapser,
+ * SpyMaster, the sorter run natively on it.  Static figures (termfreq bounds, max weight) are taken from the tree it replaces.
+ * Not for positional queries unless POSITIONAL_INTENDED (the frozen weight lives in the tree), nor with a MatchDecider (its
+ * counters see the tree's traversal). */
+void set_replay(bool on);                  /* default: off */
+Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapian::Query& query, Xapian::Internal::PostList* pl);
 
 /* MSet::get_matches_lower_bound / _estimated by relevance.  The reference derives them from known_matching_docs — how many
  * documents reached ProtoMSet::add, i.e. passed `weight >= min_weight` in the matcher's loop (matcher.cc:500-505), where
@@ -109,7 +125,7 @@ struct SpyAdapter {
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter);
 
 struct Counters { uint64_t answered, declined_shape, declined_unregistered, declined_revision, declined_device, answered_sorted, answered_spied,
-                  answered_collapsed, columns_built; };
+                  answered_collapsed, columns_built, replayed; };
 Counters counters();
 
 /* The call the patch adds.  sort_by: Enquire::Internal::sort_setting as an int.  Returns true and fills `out` when the

@@ -45,13 +45,15 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
 
 int main(int argc, char** argv) {
     int a = 1;
-    bool stale = false, exact_bounds_on = false;
+    bool stale = false, exact_bounds_on = false, replay_on = false;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
         else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);
         else if (!strcmp(argv[a], "--exact-bounds")) { xgm_hook::set_exact_bounds(true); exact_bounds_on = true; }
         else if (!strcmp(argv[a], "--collapse-intended")) xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_INTENDED);
+        else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
+        else if (!strcmp(argv[a], "--replay")) { xgm_hook::set_replay(true); replay_on = true; }
         else if (!strcmp(argv[a], "--stale")) stale = true;
     }
     if (argc - a < 2) { fprintf(stderr, "usage: xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]\n"); return 2; }
@@ -147,8 +149,20 @@ int main(int argc, char** argv) {
             const bool and_class = q.op == "AND" || q.op == "FILTER" || q.op == "AND_NOT" || q.op == "PHRASE" || q.op == "NEAR";
             const bool exact_bounds = !q.collapse_max && (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR" ||
                                                           (exact_bounds_on && and_class && q.sort_mode.empty() && want.get_matches_upper_bound() <= 1024) ||
+                                                          (exact_bounds_on && q.op != "PHRASE" && q.op != "NEAR" && q.sort_mode.empty() && want.get_matches_upper_bound() <= 1024) ||
                                                           (want.get_matches_lower_bound() == want.get_matches_upper_bound()));
-            if (dbs.size() == 1 && !q.collapse_max &&
+            if (dbs.size() == 1 && replay_on && (q.collapse_max || q.cut_percent || q.cut_weight != 0.0 || q.spy_slot >= 0)) {
+                /* replayed through the reference's own collation: every figure is the CPU matcher's */
+                if (want.get_matches_lower_bound() != got.get_matches_lower_bound() || want.get_matches_estimated() != got.get_matches_estimated() ||
+                    want.get_matches_upper_bound() != got.get_matches_upper_bound() ||
+                    want.get_uncollapsed_matches_lower_bound() != got.get_uncollapsed_matches_lower_bound() ||
+                    want.get_uncollapsed_matches_estimated() != got.get_uncollapsed_matches_estimated() ||
+                    want.get_uncollapsed_matches_upper_bound() != got.get_uncollapsed_matches_upper_bound()) {
+                    ++bounds_bad;
+                    printf("BOUNDS (replay) query %zu: hook [%u, %u, %u] vs CPU matcher [%u, %u, %u]\n", qi, got.get_matches_lower_bound(), got.get_matches_estimated(),
+                           got.get_matches_upper_bound(), want.get_matches_lower_bound(), want.get_matches_estimated(), want.get_matches_upper_bound());
+                }
+            } else if (dbs.size() == 1 && !q.collapse_max &&
                 (want.get_matches_upper_bound() != got.get_matches_upper_bound() || got.get_matches_lower_bound() > want.get_matches_lower_bound() ||
                  got.get_matches_lower_bound() > got.get_matches_estimated() || got.get_matches_estimated() > got.get_matches_upper_bound() ||
                  (exact_bounds && (want.get_matches_lower_bound() != got.get_matches_lower_bound() || want.get_matches_estimated() != got.get_matches_estimated())))) {
@@ -160,10 +174,10 @@ int main(int argc, char** argv) {
         const xgm_hook::Counters c = xgm_hook::counters();
         printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
-               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u}\n",
+               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu}\n",
                queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
-               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal);
+               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed);
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
         for (const std::string& f : seg_files) unlink(f.c_str());

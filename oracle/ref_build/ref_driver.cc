@@ -65,6 +65,8 @@ struct QuerySpec {
     unsigned sort_slot = 0, sort_reverse = 0, collapse_slot = 0, collapse_max = 0, check_at_least = 0;
     /* "SPY=<slot>": a Xapian::ValueCountMatchSpy on the slot (what Xapiand's AggregationMatchSpy is a subclass of) */
     int spy_slot = -1;
+    /* "CUT=<percent>:<weight>": Enquire::set_cutoff (DocMatcher::prepare_mset sets it on every Enquire, handler.cc:1265) */
+    int cut_percent = 0; double cut_weight = 0.0;
 };
 
 struct SpyResult { unsigned total = 0; std::map<std::string, unsigned> values; };
@@ -90,6 +92,8 @@ std::vector<QuerySpec> read_queries(const char* path) {
                 if (sscanf(tok.c_str() + 9, "%u:%u", &q.collapse_slot, &q.collapse_max) != 2) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
             } else if (tok.rfind("CAL=", 0) == 0) {
                 q.check_at_least = (unsigned)strtoul(tok.c_str() + 4, nullptr, 10);
+            } else if (tok.rfind("CUT=", 0) == 0) {
+                if (sscanf(tok.c_str() + 4, "%d:%lf", &q.cut_percent, &q.cut_weight) != 2) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
             } else if (tok.rfind("SPY=", 0) == 0) {
                 q.spy_slot = (int)strtoul(tok.c_str() + 4, nullptr, 10);
             } else { ss.clear(); ss.seekg(at); break; }
@@ -215,6 +219,7 @@ void apply_settings(Xapian::Enquire& enq, const QuerySpec* q) {
     else if (q->sort_mode == "VR") enq.set_sort_by_value_then_relevance(q->sort_slot, q->sort_reverse != 0);
     else if (q->sort_mode == "RV") enq.set_sort_by_relevance_then_value(q->sort_slot, q->sort_reverse != 0);
     if (q->collapse_max) enq.set_collapse_key(q->collapse_slot, q->collapse_max);
+    if (q->cut_percent || q->cut_weight != 0.0) enq.set_cutoff(q->cut_percent, q->cut_weight);
 }
 
 /* One query, Xapiand style.  n_shards == 1 → plain get_mset. */

@@ -242,6 +242,10 @@ def test_exact_match_count_bounds_through_the_hook(built, glass):
     base = (H.gen_term_queries("AND", 30, 2, 20, 400, maxitems=10, seed=91) + H.gen_term_queries("AND", 12, 3, 1, 60, maxitems=10, seed=92) +
             H.gen_term_queries("AND", 8, 1, 200, 3000, maxitems=10, seed=93) + H.gen_sided_queries("AND_NOT", 10, 1, 2, 30, 300, seed=94) +
             H.gen_sided_queries("FILTER", 10, 1, 1, 30, 300, seed=95))
+    # ... and the shapes whose tree prunes by weight (OR, AND_MAYBE, nested trees): replayed through the reference's own loop when the
+    # match fits a device page; rare terms keep their static upper bound within 1 024, where the driver requires equality
+    base += (H.gen_term_queries("OR", 24, 3, 1500, 12000, maxitems=10, seed=96) + H.gen_sided_queries("AND_MAYBE", 12, 1, 2, 800, 8000, seed=97) +
+             H.gen_tree_queries(16, 1500, 12000, seed=98))
     qs = []
     for i, q in enumerate(base):
         k, first = [(10, 0), (3, 0), (25, 5), (1, 0), (7, 2)][i % 5]
@@ -251,6 +255,7 @@ def test_exact_match_count_bounds_through_the_hook(built, glass):
     out = run_b1("--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
     assert out["http_total_equal"] == len(qs), out            # the HTTP "total" field (get_matches_estimated) of every response
+    assert out["replayed"] >= 10, out                          # OR / AND_MAYBE / tree pages inside a match
 
 
 def test_positional_reference_mode_is_byte_compatible(built, glass):
@@ -277,3 +282,38 @@ def test_positional_reference_mode_is_byte_compatible(built, glass):
     r = subprocess.run([HOOK_B1, qf, one], capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert line and json.loads(line[-1])["mismatches"] > 0, r.stdout[-2000:]
+
+
+def test_replay_reference_collation_over_the_device_match(built, glass_values):
+    """set_replay / COLLAPSE_REFERENCE: searches whose exact semantics live in the reference's own collation — set_collapse_key with any
+    collapse_max and a page INSIDE the match (where the snapshot's collapser loses documents: the device's intended semantics differs),
+    percentage and weight cut-offs, ValueCountMatchSpy by relevance with a match beyond check_at_least — run Matcher::get_local_mset's
+    own loop (ProtoMSet, Collapser, SpyMaster) over the list of ALL matching documents the device hands back.  Hook on == hook off:
+    docids, weight bits, percentages, collapse keys and counts, spy counts, every match-count figure (uncollapsed ones too)."""
+    d, one, _ = glass_values
+    c = H.Corpus(N_DOCS, VOCAB)
+    qs = []
+    cand = (H.gen_term_queries("AND", 80, 2, 1, 400, maxitems=10, seed=111) + H.gen_term_queries("OR", 60, 2, 300, 6000, maxitems=10, seed=112) +
+            H.gen_sided_queries("AND_MAYBE", 30, 1, 1, 100, 3000, maxitems=10, seed=113) + H.gen_tree_queries(30, 200, 4000, seed=114))
+    for q in cand:
+        if q["op"] == "RPN":
+            continue
+        m = H.oracle_search(c, q["op"], q["terms"], 0, 1, n_required=q.get("n_required", 0))[1].matches
+        if 30 <= m <= 1000:
+            i = len(qs)
+            kind = i % 4
+            if kind == 0:
+                qs.append(dict(q, first=0, maxitems=10, collapse=(i % 3, 1 + (i // 4) % 3)))                  # collapse_max 1..3, page inside the match
+            elif kind == 1:
+                qs.append(dict(q, first=2, maxitems=8, collapse=((i + 1) % 3, 1), sort=(("VR", "RV")[i % 2], i % 3, False)))
+            elif kind == 2:
+                qs.append(dict(q, first=0, maxitems=10, cutoff=((40, 0.0), (0, 1.5), (70, 0.5))[(i // 4) % 3]))
+            else:
+                qs.append(dict(q, first=0, maxitems=10, spy=i % 3))                                           # by relevance, check_at_least 0 < match
+    c.close()
+    assert len(qs) >= 40, len(qs)
+    qf = str(d / "qrp.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--collapse-reference", "--replay", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["replayed"] == len(qs) and out["http_total_equal"] == len(qs), out

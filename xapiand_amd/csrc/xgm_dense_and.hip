@@ -1,27 +1,14 @@
-/* xgm_dense_kernel — the conjunction whose every term has probe containers, as a kernel of its own (gfx950, wave64).
+/* xgm_dense_kernel — xgm_dense_unit (xgm_dense_body.inc: the conjunction whose every term has probe containers) as a kernel of its
+ * own, plain and positional.  AN EXPERIMENT KEPT FOR A/B RUNS, OFF BY DEFAULT (XGM_DENSE_KERNEL=1 switches it on; run_batch then cuts
+ * such queries into a class of their own).  The product runs the same body INSIDE xgm_andw_kernel, one launch for the whole batch.
  *
- * Why it exists (round 3): xgm_andw_kernel serves every conjunction shape from one body — block-decoded rarest terms, sided
- * operators, the positional filter with its LDS staging — and needs 128 VGPRs (+ spills) for the plain AND-3 the headline is
- * measured on, 168 for the positional instantiation: 4 and 3 waves per SIMD.  The path that dominates both C2 and C5 is much
- * simpler: every term is dense, so the candidates of a stripe ARE the bits of the AND of the terms' bitmaps, and a candidate
- * costs one wdf byte per term and its document length.  Measured on the MI355X, occupancy beats everything else on this
- * latency-bound path (4 waves with spills 0.40 ms, 3 waves without 0.43 ms, 2 waves 4.0 vs 3.2 ms for the phrase class), so this
- * kernel is written for 8 waves per SIMD: <= 64 VGPRs, ~3 KB of LDS per wave, T <= 4 terms unrolled, k <= 64.
- *
- * One wave per work unit (a query, <= 32 stripes), no workgroup barrier:
- *   producer  per stripe: one 16-byte load per lane and term of the containers' bitmaps (next stripe's in flight), AND; the set
- *             bits go to a ring of docids in LDS, two per lane and pass (wave prefix sum of the counts) — the order in which
- *             candidates are weighed does not matter to a top-k under a total order;
- *   consumer  64 candidates per round, every lane busy: T one-byte probes + the document length, BM25 in fp64 with the
- *             reference's operation order (BM25Weight::get_sumpart, bm25weight.cc:170-181; MultiAndPostList::get_weight,
- *             multiandpostlist.cc:150-160), threshold test against the unit's k-th best, survivors into the wave's top-k buffer
- *             (bitonic selection when it fills: ProtoMSet::add, protomset.h:340-400, order of msetcmp.cc:55-62);
- *   PHRASE / NEAR with positional pruning (XGM_QF_POSPRUNE: Xapiand's check_at_least = 0): a candidate is weighed first and its
- *             positions are tested only if it can still enter the top k (unit's k-th best and the query-wide histogram of the
- *             matches taken so far) — survivors are rare, so they take the serial predicates straight from HBM
- *             (xgm_posfilter.h: ExactPhrasePostList / PhrasePostList / NearPostList::test_doc).
- * Replaces, for these shapes, the queue path of xgm_andw_kernel; same inputs (work units of plan_batch), same outputs
- * (xgm_cand / xgm_group_hdr for xgm_merge_kernel).  Compile with -ffp-contract=off.
+ * What it showed on the MI355X (round 3): at 6 waves per SIMD without spills C2's all-container class takes 266 us
+ * against ~303 us through xgm_andw_kernel's queue path — but a batch then needs two match + two merge launches and loses more than
+ * that; the positional instantiation (survivors' positions tested 64 at a time by the serial predicates of xgm_posfilter.h) halves
+ * the instructions of xgm_andw_kernel<..., true, ...> and is still slower (2.96 vs 2.59 ms on its class): that path is bound by the
+ * latency chain of a wave's round, not by issue slots.  Same inputs (work units of plan_batch), same outputs (xgm_cand /
+ * xgm_group_hdr for xgm_merge_kernel); parity-green at 10 M documents (tests/test_gpu_variants.py runs the suite with it on).
+ * Compile with -ffp-contract=off.
  */
 #include <hip/hip_runtime.h>
 
