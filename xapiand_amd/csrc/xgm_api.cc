@@ -70,6 +70,8 @@ struct XgmScratch {
     void* d_in = nullptr; size_t cap_in = 0;           /* all per-call inputs, one upload */
     xgm_hit* d_hits = nullptr; size_t cap_hits = 0;
     xgm_result_hdr* d_hdrs = nullptr; size_t cap_hdrs = 0;
+    unsigned char* d_sorted = nullptr; size_t cap_sorted = 0;   /* xgm_search_sorted*: query, work list, headers, counters, candidates */
+    void* h_sorted = nullptr; size_t cap_hsorted = 0;
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
     /* pinned host */
@@ -163,7 +165,8 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
-    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs);
+    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_sorted);
+    if (s->h_sorted) hipHostFree(s->h_sorted);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
     if (s->h_work) hipHostFree(s->h_work);
@@ -1211,18 +1214,31 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     if (bp.andw || bp.orw || bp.and_only || dq.k == 0 || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
     if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
     const uint32_t k = dq.k, n_work = bp.n_work;
-    DeviceBuffers dev;
-    xgm_dev_query* d_q; xgm_work* d_work; xgm_cand_sorted* d_cand; xgm_group_hdr* d_ghdr;
-    if ((rc = dev.alloc((void**)&d_q, sizeof dq)) || (rc = dev.alloc((void**)&d_work, (size_t)n_work * sizeof(xgm_work))) ||
-        (rc = dev.alloc((void**)&d_cand, (size_t)n_work * k * sizeof(xgm_cand_sorted))) || (rc = dev.alloc((void**)&d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr))))
-        return rc;
-    HIP_TRY(hipMemcpy(d_q, &dq, sizeof dq, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_work, bp.work.data(), (size_t)n_work * sizeof(xgm_work), hipMemcpyHostToDevice));
-    uint32_t* d_counts = nullptr;
-    if (d_spy_ord) {
-        if ((rc = dev.alloc((void**)&d_counts, (size_t)n_counts * 4))) return rc;
-        HIP_TRY(hipMemset(d_counts, 0, (size_t)n_counts * 4));
-    }
+    /* per-call device and pinned buffers + a stream from the index's scratch pool (re-used across calls: no allocation, no null stream —
+     * searches of concurrent threads do not serialise): [query | work list] go up in one copy, [headers | counters | candidates] come down in one */
+    XgmScratch* sc;
+    if ((rc = scratch_acquire(idx, &sc))) return rc;
+    struct Release { xgm_index* i; XgmScratch* s; ~Release() { scratch_release(i, s); } } release_{idx, sc};
+    hipStream_t stream = sc->stream;
+    const size_t o_q = 0, b_q = (sizeof dq + 15) & ~(size_t)15;
+    const size_t o_wk = o_q + b_q, b_wk = ((size_t)n_work * sizeof(xgm_work) + 15) & ~(size_t)15;
+    const size_t up_bytes = o_wk + b_wk;
+    const size_t o_gh = up_bytes, b_gh = (size_t)n_work * sizeof(xgm_group_hdr);
+    const size_t o_ct = o_gh + b_gh, b_ct = d_spy_ord ? (((size_t)n_counts * 4 + 15) & ~(size_t)15) : 0;
+    const size_t o_cd = o_ct + b_ct, b_cd = (size_t)n_work * k * sizeof(xgm_cand_sorted);
+    const size_t total = o_cd + b_cd;
+    if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
+    if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total))) return rc;
+    unsigned char* hb = (unsigned char*)sc->h_sorted;
+    memcpy(hb + o_q, &dq, sizeof dq);
+    memcpy(hb + o_wk, bp.work.data(), (size_t)n_work * sizeof(xgm_work));
+    HIP_TRY(hipMemcpyAsync(sc->d_sorted, hb, up_bytes, hipMemcpyHostToDevice, stream));
+    xgm_dev_query* d_q = (xgm_dev_query*)(sc->d_sorted + o_q);
+    xgm_work* d_work = (xgm_work*)(sc->d_sorted + o_wk);
+    xgm_group_hdr* d_ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
+    uint32_t* d_counts = d_spy_ord ? (uint32_t*)(sc->d_sorted + o_ct) : nullptr;
+    xgm_cand_sorted* d_cand = (xgm_cand_sorted*)(sc->d_sorted + o_cd);
+    if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)n_counts * 4, stream));
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = d_q;
@@ -1230,12 +1246,12 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = d_ghdr;
-    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, d_cord, cmax, d_cand, nullptr))) return rc;
-    std::vector<xgm_cand_sorted> cand((size_t)n_work * k);
-    std::vector<xgm_group_hdr> gh(n_work);
-    HIP_TRY(hipMemcpy(gh.data(), d_ghdr, (size_t)n_work * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));     /* (waits for the kernel) */
-    HIP_TRY(hipMemcpy(cand.data(), d_cand, cand.size() * sizeof(xgm_cand_sorted), hipMemcpyDeviceToHost));
-    if (d_counts) HIP_TRY(hipMemcpy(counts, d_counts, (size_t)n_counts * 4, hipMemcpyDeviceToHost));
+    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, d_cord, cmax, d_cand, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(hb + o_gh, sc->d_sorted + o_gh, total - o_gh, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const xgm_group_hdr* gh = (const xgm_group_hdr*)(hb + o_gh);
+    const xgm_cand_sorted* cand = (const xgm_cand_sorted*)(hb + o_cd);
+    if (d_counts) memcpy(counts, hb + o_ct, (size_t)n_counts * 4);
     /* merge the units: their best k each under the comparison the kernel used; the whole match's best weight and count */
     std::vector<xgm_cand_sorted> all;
     uint64_t matches = 0, max_w = 0;
@@ -1244,7 +1260,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
         const xgm_group_hdr& g = gh[u];
         if (g.n_cand > k) return xgm_set_error(XGM_E_DEVICE, "sorted search: unit %u reports %u candidates for k = %u", u, g.n_cand, k);
         matches += g.matches;
-        all.insert(all.end(), cand.begin() + (size_t)u * k, cand.begin() + (size_t)u * k + g.n_cand);
+        all.insert(all.end(), cand + (size_t)u * k, cand + (size_t)u * k + g.n_cand);
         if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
     }
     const bool use_x = mode == XGM_SORT_VALUE_RELEVANCE || mode == XGM_SORT_RELEVANCE_VALUE;
