@@ -790,14 +790,14 @@ Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapia
     memset(&hdr, 0, sizeof hdr);
     int rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
     if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, 1, &one, &hdr);
-    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    if (rc < 0) { ++g_dev; return pl; }                  /* a device failure here costs nothing: the tree is still there, the CPU matcher runs */
     const uint64_t m = XGM_MATCHES_COUNT(hdr.matches_exact);
     if (rc > 0 || (hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) || m == 0 || m > XGM_MAX_K) { ++g_dev; return pl; }      /* nothing to gain / beyond a device page */
     std::vector<xgm_hit> all(m);
     L.d.maxitems = (uint32_t)m;
     rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
     if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, (uint32_t)m, all.data(), &hdr);
-    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    if (rc < 0) { ++g_dev; return pl; }                  /* a device failure here costs nothing: the tree is still there, the CPU matcher runs */
     if (rc > 0 || hdr.n_hits != m) { ++g_dev; return pl; }
     std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
     /* the static figures of the tree this list stands in for */
