@@ -49,34 +49,51 @@ struct Lowered {
     const xgm_index* idx = nullptr;      /* the shard: wildcards expand over ITS dictionary, as qopt->db.open_allterms does */
 };
 
-/* OP_WILDCARD "prefix*" → an OP_SYNONYM (or OP_OR) group over the shard's terms with that prefix, limits applied as
- * Context<T>::expand_wildcard does (api/queryinternal.cc:246-315).  false = leave the query to the CPU matcher: extended
- * wildcards, OP_MAX, an expansion the reference would refuse (WILDCARD_LIMIT_ERROR), none or more than the device's leaves,
- * or a most-frequent cut through a tie of term frequencies (std::nth_element leaves the choice unspecified). */
-bool lower_wildcard(const Xapian::Query& q, Lowered* L) {
-    const auto* w = static_cast<const Xapian::Internal::QueryWildcard*>(q.internal.get());
-    if (!w || !L->idx || w->get_just_flags() != 0) return false;
-    std::string ser;
-    w->serialise(ser);                                  /* 0x0b, max_expansion, flags, combiner, pattern (queryinternal.cc:1507-1514) */
-    const char* p = ser.data() + 1;
-    const char* end = ser.data() + ser.size();
-    Xapian::termcount max_expansion;
-    if (ser.size() < 4 || !unpack_uint(&p, end, &max_expansion) || end - p < 2) return false;
-    const Xapian::Query::op combiner = Xapian::Query::op((unsigned char)p[1]);
-    if (combiner != Xapian::Query::OP_SYNONYM && combiner != Xapian::Query::OP_OR) return false;
-    const std::string pattern = w->get_pattern();
+/* OP_WILDCARD / OP_EDIT_DISTANCE → an OP_SYNONYM (or OP_OR) group over the shard's terms the expansion selects, as
+ * Context<T>::expand_wildcard / expand_edit_distance do (api/queryinternal.cc:246-315, 319-383): the terms under the pattern's
+ * fixed prefix in term order (with an empty prefix, none that starts with A-Z), each put to the reference's OWN test —
+ * QueryWildcard::test_prefix_known for '?' / '*' patterns, QueryEditDistance::test — then the limit.  `test` null: every term
+ * under the prefix is taken (the 1.4-style "prefix*").  false = leave the query to the CPU matcher: OP_MAX, an expansion the
+ * reference would refuse (WILDCARD_LIMIT_ERROR), none or more than the device's leaves, or a most-frequent cut through a tie of
+ * term frequencies (std::nth_element leaves the choice unspecified). */
+template <class Test>
+bool lower_expansion(Lowered* L, const std::string& pfx, Xapian::termcount max_expansion, int max_type, Xapian::Query::op combiner, const Test* test) {
+    if (!L->idx || (combiner != Xapian::Query::OP_SYNONYM && combiner != Xapian::Query::OP_OR)) return false;
     uint32_t n_total = 0;
     std::vector<uint32_t> ids(XGM_MAX_TERMS + 1);
-    if (xgm_expand_prefix(L->idx, pattern.data(), pattern.size(), (uint32_t)ids.size(), ids.data(), &n_total) != XGM_OK || n_total == 0) return false;
+    if (xgm_expand_prefix(L->idx, pfx.data(), pfx.size(), (uint32_t)ids.size(), ids.data(), &n_total) != XGM_OK || n_total == 0) return false;
+    const bool filtered = test != nullptr || pfx.empty();
+    if (!filtered && (max_expansion == 0 || n_total <= max_expansion || max_type == Xapian::Query::WILDCARD_LIMIT_ERROR) && n_total > XGM_MAX_TERMS) return false;
+    if (filtered || (max_expansion != 0 && n_total > max_expansion && max_type == Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT)) {
+        if (n_total > ids.size()) {
+            ids.resize(n_total);
+            if (xgm_expand_prefix(L->idx, pfx.data(), pfx.size(), n_total, ids.data(), &n_total) != XGM_OK) return false;
+        }
+    }
+    ids.resize(std::min<size_t>(ids.size(), n_total));
+    if (filtered) {
+        size_t kept = 0;
+        std::string cand;
+        for (size_t i = 0; i < ids.size(); ++i) {
+            const char* b = nullptr; size_t bl = 0;
+            if (xgm_term_info(L->idx, ids[i], &b, &bl, nullptr, nullptr) != XGM_OK || bl == 0) return false;
+            if (pfx.empty() && b[0] >= 'A' && b[0] <= 'Z') continue;            /* skip_ucase: prefixed terms */
+            if (test) { cand.assign(b, bl); if (!(*test)(cand)) continue; }
+            ids[kept++] = ids[i];
+            /* no limit will cut it down and it no longer fits: stop walking the dictionary */
+            if (kept > XGM_MAX_TERMS && (max_expansion == 0 || max_expansion > XGM_MAX_TERMS)) return false;
+            if (max_type == Xapian::Query::WILDCARD_LIMIT_FIRST && max_expansion != 0 && kept > max_expansion) break;   /* the rest is cut anyway */
+        }
+        ids.resize(kept);
+        n_total = (uint32_t)kept;
+        if (n_total == 0) return false;
+    }
     uint32_t n = n_total;
-    const int max_type = w->get_max_type();
     if (max_expansion != 0 && n_total > max_expansion) {
         if (max_type == Xapian::Query::WILDCARD_LIMIT_FIRST) {
             n = max_expansion;
         } else if (max_type == Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT) {
             if (combiner != Xapian::Query::OP_SYNONYM) return false;       /* the OR tree's tie order would follow nth_element's permutation */
-            ids.resize(n_total);
-            if (xgm_expand_prefix(L->idx, pattern.data(), pattern.size(), n_total, ids.data(), &n_total) != XGM_OK) return false;
             std::vector<std::pair<uint32_t, uint32_t>> by_tf;              /* (termfreq, id) */
             for (uint32_t i = 0; i < n_total; ++i) { uint32_t tf = 0; xgm_term_info(L->idx, ids[i], nullptr, nullptr, &tf, nullptr); by_tf.emplace_back(tf, ids[i]); }
             std::sort(by_tf.begin(), by_tf.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first > b.first; });
@@ -103,6 +120,36 @@ bool lower_wildcard(const Xapian::Query& q, Lowered* L) {
     d.tree[d.n_tree].arity = (uint8_t)n; d.tree[d.n_tree].term = 0;
     ++d.n_tree;
     return true;
+}
+
+/* (max_expansion, combiner) of a QueryWildcard / QueryEditDistance: both keep them private and serialise them alike —
+ * tag, pack_uint(max_expansion), flags byte, combiner byte, ... (api/queryinternal.cc:1507-1514, 1617-1626) */
+bool expansion_header(const Xapian::Query::Internal* qi, Xapian::termcount* max_expansion, Xapian::Query::op* combiner) {
+    std::string ser;
+    qi->serialise(ser);
+    const char* p = ser.data() + 1;
+    const char* end = ser.data() + ser.size();
+    if (ser.size() < 4 || !unpack_uint(&p, end, max_expansion) || end - p < 2) return false;
+    *combiner = Xapian::Query::op((unsigned char)p[1]);
+    return true;
+}
+
+bool lower_wildcard(const Xapian::Query& q, Lowered* L) {
+    const auto* w = static_cast<const Xapian::Internal::QueryWildcard*>(q.internal.get());
+    Xapian::termcount max_expansion;
+    Xapian::Query::op combiner;
+    if (!w || !expansion_header(w, &max_expansion, &combiner)) return false;
+    struct Test { const Xapian::Internal::QueryWildcard* w; bool operator()(const std::string& c) const { return w->test_prefix_known(c); } } test{w};
+    return lower_expansion(L, w->get_fixed_prefix(), max_expansion, w->get_max_type(), combiner, w->get_just_flags() != 0 ? &test : (const Test*)nullptr);
+}
+
+bool lower_edit_distance(const Xapian::Query& q, Lowered* L) {
+    const auto* e = static_cast<const Xapian::Internal::QueryEditDistance*>(q.internal.get());
+    Xapian::termcount max_expansion;
+    Xapian::Query::op combiner;
+    if (!e || !expansion_header(e, &max_expansion, &combiner)) return false;
+    struct Test { const Xapian::Internal::QueryEditDistance* e; bool operator()(const std::string& c) const { return e->test(c) != 0; } } test{e};
+    return lower_expansion(L, std::string(e->get_pattern(), 0, e->get_fixed_prefix_len()), max_expansion, e->get_max_type(), combiner, &test);
 }
 
 /* a leaf the device path takes: a term with wqf 1 (MatchAll and scaled leaves are declined) */
@@ -141,6 +188,7 @@ bool lower_tree_node(const Xapian::Query& q, Lowered* L) {
         return true;
     }
     if (op == Xapian::Query::OP_WILDCARD) return lower_wildcard(q, L);
+    if (op == Xapian::Query::OP_EDIT_DISTANCE) return lower_edit_distance(q, L);
     uint8_t kind;
     switch (op) {
     case Xapian::Query::OP_AND: kind = XGM_T_AND; break;

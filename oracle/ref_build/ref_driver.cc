@@ -169,12 +169,22 @@ Xapian::Query make_query(const QuerySpec& q) {
                 Xapian::Query r(Xapian::Query::OP_SCALE_WEIGHT, st.back(), strtod(tok.c_str() + 1, nullptr));
                 st.back() = r;
             } else if (c == '~') {
-                /* "~prefix[,max_expansion,limit F|M|E[,combiner S|O]]": OP_WILDCARD "prefix*" (Xapiand's DSL: query_dsl.cc:305, 634, 724) */
-                char pre[64] = {0}, lim = 'E', comb = 'S';
+                /* "~pattern[,max_expansion,limit F|M|E[,combiner S|O[,P]]]": OP_WILDCARD "pattern*" (Xapiand's DSL: query_dsl.cc:305, 634, 724);
+                 * with P the pattern's '?' and '*' are wildcards (WILDCARD_PATTERN_SINGLE | _MULTI, query_dsl.cc:736-740) */
+                char pre[64] = {0}, lim = 'E', comb = 'S', pat = 0;
                 unsigned mx = 0;
-                sscanf(tok.c_str() + 1, "%63[^,],%u,%c,%c", pre, &mx, &lim, &comb);
-                const int flags = lim == 'F' ? Xapian::Query::WILDCARD_LIMIT_FIRST : lim == 'M' ? Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT : Xapian::Query::WILDCARD_LIMIT_ERROR;
+                sscanf(tok.c_str() + 1, "%63[^,],%u,%c,%c,%c", pre, &mx, &lim, &comb, &pat);
+                int flags = lim == 'F' ? Xapian::Query::WILDCARD_LIMIT_FIRST : lim == 'M' ? Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT : Xapian::Query::WILDCARD_LIMIT_ERROR;
+                if (pat == 'P') flags |= Xapian::Query::WILDCARD_PATTERN_SINGLE | Xapian::Query::WILDCARD_PATTERN_MULTI;
                 st.emplace_back(Xapian::Query::OP_WILDCARD, std::string(pre), mx, flags, comb == 'O' ? Xapian::Query::OP_OR : Xapian::Query::OP_SYNONYM);
+            } else if (c == '^') {
+                /* "^target,max_expansion,limit F|M|E,combiner S|O,edit_distance,fixed_prefix_len": OP_EDIT_DISTANCE (Xapiand's "term~" /
+                 * "term~N": query_dsl.cc:747-759) */
+                char pre[64] = {0}, lim = 'E', comb = 'S';
+                unsigned mx = 0, dist = 2, fixed = 0;
+                sscanf(tok.c_str() + 1, "%63[^,],%u,%c,%c,%u,%u", pre, &mx, &lim, &comb, &dist, &fixed);
+                const int flags = lim == 'F' ? Xapian::Query::WILDCARD_LIMIT_FIRST : lim == 'M' ? Xapian::Query::WILDCARD_LIMIT_MOST_FREQUENT : Xapian::Query::WILDCARD_LIMIT_ERROR;
+                st.emplace_back(Xapian::Query::OP_EDIT_DISTANCE, std::string(pre), mx, flags, comb == 'O' ? Xapian::Query::OP_OR : Xapian::Query::OP_SYNONYM, dist, (size_t)fixed);
             } else {
                 const size_t h = tok.find('#');
                 const unsigned wqf = h == std::string::npos ? 1u : (unsigned)strtoul(tok.c_str() + h + 1, nullptr, 10);

@@ -233,6 +233,37 @@ def test_wildcards_through_the_hook(built, glass):
     assert out3["mismatches"] == 0 and out3["answered_on_device"] >= len(qs), out3     # (3 shards: >= a third of 3 * n)
 
 
+def expansion_queries():
+    """The other two expansions Xapiand's DSL emits for keyword / text fields (reference src/query_dsl.cc:719-760): extended
+    wildcards ('?' / '*' inside the pattern: WILDCARD_PATTERN_SINGLE | _MULTI) and OP_EDIT_DISTANCE ("term~", "term~N"); and the
+    "partial" shape OR(OP_WILDCARD(prefix, 50, MOST_FREQUENT), prefix).  Driver tokens: "~pattern,max,F|M|E,S|O,P" and
+    "^target,max,F|M|E,S|O,distance,fixed_prefix_len"."""
+    toks = ["~t1?3,0,E,S,P", "~t19?5,0,E,S,P", "~t19*5,8,F,S,P", "~t1?5*,6,F,S,P", "~?123,0,E,S,P", "~*999,12,F,S,P", "~*1999,0,E,S,P",
+            "~t?99,0,E,O,P", "~t1*77,5,M,S,P", "~t12?4,30,E,S,P",
+            "^t1234,0,E,S,1,5", "^t1234,10,F,S,1,1", "^t19876,6,M,S,1,1", "^t777,0,E,S,1,3", "^t2500,0,E,O,1,4", "^t150,12,F,S,2,3",
+            "^t15000,0,E,S,2,5", "^t42,9,F,S,1,0"]
+    qs = []
+    for t in toks:
+        qs.append(dict(op="RPN", terms=[t], first=0, maxitems=10, window=0))
+        qs.append(dict(op="RPN", terms=["t7", t, "&2"], first=0, maxitems=10, window=0))
+        qs.append(dict(op="RPN", terms=["t60", t, "t450", "|3"], first=2, maxitems=12, window=0))
+    for pre in ("t1999", "t1234", "t777", "t19"):
+        qs.append(dict(op="RPN", terms=["~%s,50,M" % pre, pre, "|2"], first=0, maxitems=10, window=0))     # Xapiand's "prefix**"
+    return qs
+
+
+def test_pattern_wildcards_and_edit_distance_through_the_hook(built, glass):
+    d, one, shards = glass
+    qs = expansion_queries()
+    qf = str(d / "qx.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] >= len(qs) // 2, out           # the rest: expansions beyond the device's leaves, refused limits, ties
+    out3 = run_b1(qf, *shards)
+    assert out3["mismatches"] == 0 and out3["answered_on_device"] >= len(qs), out3
+
+
 def test_exact_match_count_bounds_through_the_hook(built, glass):
     """SURVEY 8(f).4: with exact bounds on, MSet::get_matches_lower_bound / _estimated / _upper_bound of the hook are the CPU
     matcher's for the operators whose known_matching_docs is a function of the match (a term, AND, FILTER, AND_NOT) whenever the
