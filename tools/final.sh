@@ -31,6 +31,9 @@ for a in "AND_NOT --terms 4 --required 2" "AND_MAYBE --terms 4 --required 2" "FI
   n=$(echo $a | tr -d '-' | tr ' ' '_' | tr A-Z a-z)
   timeout 300 python bench.py --op $a --steps 20 --warmup 2 --ref-docs 0 --cpu-seconds 3 --threads 0 > gpurun_out/${tag}_bench_$n.json 2>gpurun_out/${tag}_$n.err
 done
+# the N > 1 code path (C4's protocol: shards on ranks, all-gather, merge) on this box's one GPU: two ranks share it, gloo carries the
+# exchange — a functional line (the ranks contend for one GPU), not a scaling figure; the driver measures N = 2, 4, 8 on its node
+XGM_BENCH_BACKEND=gloo XGM_BENCH_SHARE_GPU=1 timeout 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline --no-latency --threads 0 > gpurun_out/${tag}_n2_shared_gpu.json 2> gpurun_out/${tag}_n2_shared_gpu.err; tail -c 400 gpurun_out/${tag}_n2_shared_gpu.json
 python - <<PY
 import json,glob
 for f in sorted(glob.glob('gpurun_out/${tag}_bench*.json')):
