@@ -222,7 +222,7 @@ namespace { alignas(64) thread_local unsigned char smem[emu::kLdsBytes]; inline 
 /* ---- work-item functions ---- */
 inline void __syncthreads() { emu::block_barrier(); }
 #define EMU_SITE __builtin_return_address(0)
-#define EMU_WAVE_OP __attribute__((noinline))
+#define EMU_WAVE_OP __attribute__((noinline, convergent, noduplicate))
 EMU_WAVE_OP inline int __builtin_amdgcn_readlane(int v, int lane) { return emu::exchange(EMU_SITE, (uint32_t)v, [&](const uint64_t* s) { return (int)(uint32_t)s[lane & 63]; }); }
 EMU_WAVE_OP inline int __builtin_amdgcn_readfirstlane(int v) { return emu::exchange(EMU_SITE, (uint32_t)v, [&](const uint64_t* s) { const uint64_t act = emu::active_lanes(); return (int)(uint32_t)s[act ? __builtin_ctzll(act) : 0]; }); }
 EMU_WAVE_OP inline unsigned long long __ballot(int pred) {

@@ -1176,8 +1176,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                             const uint32_t nt = pass ? cnt(t) : 0u;
                             const bool fast = w16 != 0u && nt <= kPosFast;
                             slow = slow || (pass && !fast);
+                            const uint64_t tp = rl64(tpos_reg, t);                /* (read by every lane, not under the per-lane test) */
                             if (pass && fast) {
-                                const uint64_t tp = rl64(tpos_reg, t);
                                 const unsigned char* src = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * 2u;
                                 if (nt > 0u) ra[u][0] = *reinterpret_cast<const Pos8*>(src);
                                 if (nt > 8u) ra[u][1] = *reinterpret_cast<const Pos8*>(src + 16);
@@ -1203,16 +1203,21 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                     pass = (q.flags & XGM_QF_NEAR) ? lds_near_window(L, cnt, T, q.window)
                          : (q.flags & XGM_QF_EXACT) ? lds_phrase_exact(L, cnt, q.phrase_index, T)
                                                     : lds_phrase_window(L, cnt, q.phrase_index, T, q.window);
-                } else if (pass) {
+                }
+                if (__ballot(pass && slow)) {
+                    /* (the loop over the terms is wave-uniform, only the stores and the test are per lane: a lane whose document
+                     * takes the serial path reads the terms' registers together with the lanes that do not) */
                     PosList pl[XGM_PHRASE_MAX_TERMS];
                     for (uint32_t t = 0; t < T && t < XGM_PHRASE_MAX_TERMS; ++t) {
                         const uint64_t tp = rl64(tpos_reg, t);
                         const uint32_t w16 = __builtin_amdgcn_readlane(tflag_reg, t) & XGM_TF_POS16;
-                        pl[t].p = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * (w16 ? 2u : 4u);
-                        pl[t].n = cnt(t);
-                        pl[t].w16 = w16;
+                        if (pass && slow) {
+                            pl[t].p = seg.positions + tp + (size_t)c_pos[(size_t)t * CAND + o] * (w16 ? 2u : 4u);
+                            pl[t].n = cnt(t);
+                            pl[t].w16 = w16;
+                        }
                     }
-                    pass = posfilter_slow(pl, q, T);
+                    if (pass && slow) pass = posfilter_slow(pl, q, T);
                 }
                 wave_lds_fence();
             }
@@ -1322,7 +1327,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                             mask &= mask - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(x_meta, jj[u]);
                             if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbx + __builtin_amdgcn_readlane(x_word, jj[u]) + lane * 4u);
+                            const uint32_t bwd = __builtin_amdgcn_readlane(x_word, jj[u]);      /* read by every lane, not under the per-lane test */
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbx + bwd + lane * 4u);
                             nn = u + 1u;
                         }
                     }
@@ -1767,7 +1773,9 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                 if (j < nblk0) {
                     const uint32_t mj = __builtin_amdgcn_readlane(m0, j);
                     if (TALLY) { cn_blkw += payload_words(mj) - 2u; }
-                    if (lane * 4u < payload_words(mj)) p0[j] = *reinterpret_cast<const Words4*>(seg.words + tbase(0) + __builtin_amdgcn_readlane(w0, j) + lane * 4u);
+                    const uint32_t wj = __builtin_amdgcn_readlane(w0, j);                       /* read by every lane, not under the per-lane test */
+                    const uint64_t tb0j = tbase(0);
+                    if (lane * 4u < payload_words(mj)) p0[j] = *reinterpret_cast<const Words4*>(seg.words + tb0j + wj + lane * 4u);
                 }
             }
             unsigned long long coarse = 0;
@@ -1876,7 +1884,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                             mask_a &= mask_a - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(a_meta, jj[u]);
                             if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tba + __builtin_amdgcn_readlane(a_word, jj[u]) + lane * 4u);
+                            const uint32_t bwd = __builtin_amdgcn_readlane(a_word, jj[u]);      /* read by every lane, not under the per-lane test */
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tba + bwd + lane * 4u);
                             n_a = u + 1u;
                         }
                     }
@@ -1888,7 +1897,8 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                             mask_b &= mask_b - 1u;
                             const uint32_t bm = __builtin_amdgcn_readlane(b_meta, jj[u]);
                             if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
-                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbb + __builtin_amdgcn_readlane(b_word, jj[u]) + lane * 4u);
+                            const uint32_t bwd = __builtin_amdgcn_readlane(b_word, jj[u]);
+                            if (lane * 4u < payload_words(bm)) pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbb + bwd + lane * 4u);
                             n_b = u - 3u;
                         }
                     }

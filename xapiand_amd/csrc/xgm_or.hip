@@ -785,7 +785,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                     if (TALLY) { cn_hdr += 1u; }
                                 }
                                 if (TALLY) { cn_blkw += XGM_SU(payload_words(bmeta[v])) - 2u; }
-                                if (lane * 4u < payload_words(bmeta[v])) pv[v] = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + bword + lane * 4u);
+                                const uint64_t tbt = tbase(t);                                      /* read by every lane, not under the per-lane test */
+                                if (lane * 4u < payload_words(bmeta[v])) pv[v] = *reinterpret_cast<const Words4*>(seg.words + tbt + bword + lane * 4u);
                             }
                         }
 #pragma unroll
@@ -944,9 +945,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                 jj[u] = (uint32_t)__builtin_ctzll(bmask[u]);
                                 bmask[u] &= bmask[u] - 1u;
                                 const uint32_t bm = __builtin_amdgcn_readlane(cm[u], jj[u]);
+                                const uint32_t bwd = __builtin_amdgcn_readlane(cw[u], jj[u]);      /* (read by every lane: not under the per-lane test below) */
+                                const uint64_t tbu = tbase(sp_t[u]);
                                 if (TALLY) { cn_blkw += payload_words(bm) - 2u; }
                                 if (lane * 4u < payload_words(bm))
-                                    pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbase(sp_t[u]) + __builtin_amdgcn_readlane(cw[u], jj[u]) + lane * 4u);
+                                    pv[u] = *reinterpret_cast<const Words4*>(seg.words + tbu + bwd + lane * 4u);
                             }
                         }
 #pragma unroll
@@ -966,7 +969,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             if (!bucket_need(first, nfirst)) continue;
                             if (TALLY) { cn_blkw += XGM_SU(payload_words(meta)) - 2u; }
                             Words4 pv = Words4{0, 0, 0, 0};
-                            if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbase(t) + seg.blk_word[rb0 + j] + lane * 4u);
+                            const uint64_t tbt = tbase(t);
+                            if (lane * 4u < payload_words(meta)) pv = *reinterpret_cast<const Words4*>(seg.words + tbt + seg.blk_word[rb0 + j] + lane * 4u);
                             orw_block<TabT, true>(pv, meta, first, stage, lane, stripe_base, bm_ess, nullptr, nullptr, rankw, c_w + (size_t)t * kOrwCand, wlo, whi);
                         }
                     }
