@@ -22,6 +22,8 @@ PHRASE_SELECT = "phrase or other_stripe_widths or edge_cases"
                                            # round 3: the conjunction body for all-container queries off (the queue path serves them), its
                                            # narrow document lengths off, and the same body as a kernel of its own (plain and positional)
                                            ("XGM_NO_DENSE_BODY", SELECT), ("XGM_NO_NARROW_DOCLEN", SELECT), ("XGM_DENSE_KERNEL", SELECT + " or phrase"),
+                                           # the conjunction kernel finishing its queries itself (the last unit merges) off: the merge launches
+                                           ("XGM_NO_FUSED_MERGE", SELECT + " or phrase or sided"),
                                            # the disjunction's guess of the k-th weight far too high: every unit must go round again
                                            # below it (second pass) and still skip what the first pass weighed; and a little too high
                                            ("XGM_OR_SEED_SCALE=8", SELECT), ("XGM_OR_SEED_SCALE=1.3", SELECT)])

@@ -74,6 +74,7 @@ struct XgmScratch {
     void* h_sorted = nullptr; size_t cap_hsorted = 0;
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
+    uint32_t* d_arrive = nullptr; size_t cap_arrive = 0;        /* per-query arrival counters of a launch that finishes its queries itself (zero between launches) */
     /* pinned host */
     void* h_up = nullptr; size_t cap_up = 0;
     void* h_down = nullptr; size_t cap_down = 0;
@@ -165,7 +166,7 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
-    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_sorted);
+    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_arrive); hipFree(s->d_sorted);
     if (s->h_sorted) hipHostFree(s->h_sorted);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
@@ -630,6 +631,7 @@ struct BatchPlan {
     bool andw;          /* ... and k is small: the wave-autonomous variant (one wave per unit) */
     int sided;          /* andw batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
+    bool fused = false; /* the conjunction kernel finishes its queries itself (xgm_unit_finish.h): no merge launch, no parts */
     uint32_t parts = 1; /* > 1: a query's units are merged in `parts` groups (pseudo-query p * nq + q of goff) and the groups' lists once more */
 };
 
@@ -812,7 +814,11 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         g_most_q = std::max(g_most_q, gq);
     }
     /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
-    const uint32_t P = (g_most_q + units_per_part - 1) / units_per_part;
+    /* xgm_andw_kernel merges a query's lists in its last unit, whatever their number (XGM_NO_FUSED_MERGE: A/B switch, the variant tests) */
+    static const bool no_fused = getenv("XGM_NO_FUSED_MERGE") != nullptr;
+    static const bool dense_alone = getenv("XGM_DENSE_KERNEL") != nullptr;                         /* (the stand-alone experiment kernel keeps the merge launch) */
+    bp->fused = bp->andw && !no_fused && !dense_alone;
+    const uint32_t P = bp->fused ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
     bp->parts = std::max(1u, P);
     const uint32_t upp = bp->parts > 1 ? units_per_part : g_most_q + 1u;
     bp->goff.assign((size_t)nq * bp->parts + 1, 0);
@@ -875,7 +881,8 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     const size_t o_kq = o_wk + b_wk, b_kq = (size_t)npq * 4;
     const size_t o_go = o_kq + b_kq, b_go = ((size_t)npq + 1) * 4;
     const size_t o_ro = o_go + b_go, b_ro = rows ? (size_t)nq * 4 : 0;
-    const size_t in_bytes = (o_ro + b_ro + 15) & ~(size_t)15;
+    const size_t o_fu = (o_ro + b_ro + 15) & ~(size_t)15, b_fu = sizeof(xgm_fuse);      /* (filled below, once the scratch buffers are known) */
+    const size_t in_bytes = (o_fu + b_fu + 15) & ~(size_t)15;
     if ((rc = grow_pinned(&s->h_work, &s->cap_hwork, in_bytes))) return rc;
     if ((rc = grow(reinterpret_cast<unsigned char**>(&s->d_in), &s->cap_in, in_bytes))) return rc;
     unsigned char* hin = (unsigned char*)s->h_work;
@@ -884,6 +891,27 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     memcpy(hin + o_wk, bp.work.data(), b_wk);
     memcpy(hin + o_go, bp.goff.data(), b_go);
     if (rows) memcpy(hin + o_ro, rows, b_ro);
+    /* every query of the batch a conjunction over probe containers only (dense_kind, all of one kind): the kernel written for that */
+    bool dense = bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
+    for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
+    static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
+    if (dense_class_old_kernel) dense = false;
+    const bool fused = bp.fused && !dense;
+    {
+        unsigned char* din_ = (unsigned char*)s->d_in;
+        xgm_fuse fu;
+        memset(&fu, 0, sizeof fu);
+        if (fused) {
+            if (s->cap_arrive < nq) {
+                if ((rc = grow(&s->d_arrive, &s->cap_arrive, (size_t)std::max<uint32_t>(nq, 1024u)))) return rc;
+                HIP_TRY(hipMemsetAsync(s->d_arrive, 0, s->cap_arrive * sizeof(uint32_t), stream));      /* once: every launch leaves the counters at zero */
+            }
+            fu.arrive = s->d_arrive; fu.goff = (const uint32_t*)(din_ + o_go); fu.max_possible = (const double*)(din_ + o_mp);
+            fu.row_of = rows ? (const uint32_t*)(din_ + o_ro) : nullptr;
+            fu.hits = d_hits; fu.hdrs = d_hdrs; fu.k_stride_out = k_stride;
+        }
+        memcpy(hin + o_fu, &fu, sizeof fu);
+    }
     const uint64_t t_cp = now_ns();
     g_host_ns[4] += t_cp - t_st;
     if (stream != s->stream) {
@@ -927,11 +955,6 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
-    /* every query of the batch a conjunction over probe containers only (dense_kind, all of one kind): the kernel written for that */
-    bool dense = bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
-    for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
-    static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
-    if (dense_class_old_kernel) dense = false;
     idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw || (bp.andw && bp.phrase)) {
@@ -939,6 +962,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
         L.hist = s->d_hist;
     }
+    if (fused) L.fuse = (const xgm_fuse*)(din + o_fu);
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
     if ((rc = dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
               : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
@@ -948,7 +972,9 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     const uint64_t t_mk = now_ns();
     g_host_ns[6] += t_mk - t_up;
     const uint32_t* d_rows = rows ? (const uint32_t*)(din + o_ro) : nullptr;
-    if (P == 1u) {
+    if (fused) {
+        /* (the kernel wrote d_hits / d_hdrs) */
+    } else if (P == 1u) {
         if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
                                    d_hdrs, s->d_maxposs, d_rows, stream)))
             return rc;

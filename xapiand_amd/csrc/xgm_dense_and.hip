@@ -19,6 +19,7 @@
 #include "xgm_launch.h"
 #include "xgm_wave.h"
 #include "xgm_posfilter.h"
+#include "xgm_unit_finish.h"
 
 namespace {
 
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_DENSE_PHRASE_WAVES : XGM_DENSE
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
-    xgm_dense_unit<PHRASE, TALLY>(seg, queries, work[unit], smem + (size_t)wave * dense_wave_bytes(PHRASE), lane, k_stride, cand_out, ghdr_out, hist_all);
+    xgm_dense_unit<PHRASE, TALLY>(seg, queries, work[unit], smem + (size_t)wave * dense_wave_bytes(PHRASE), lane, k_stride, cand_out, ghdr_out, hist_all, nullptr);
 }
 
 }  // namespace

@@ -108,4 +108,16 @@ typedef struct {
     uint32_t c_pad[2];
 } xgm_group_hdr;
 
+/* xgm_andw_kernel finishing its queries itself (xgm_unit_finish.h): the LAST unit of a query to arrive merges the units' lists into
+ * the final hits — no merge launch.  arrive == NULL: the units only write their lists (xgm_merge_kernel follows). */
+typedef struct {
+    uint32_t* arrive;              /* [nq] zero between launches: units of the query that have written their list */
+    const uint32_t* goff;          /* [nq + 1] unit slots of query qi: [goff[qi], goff[qi + 1]) */
+    const double* max_possible;    /* [nq] or NULL */
+    const uint32_t* row_of;        /* [nq] row of the caller's batch, or NULL (= qi) */
+    xgm_hit* hits;                 /* [rows][k_stride_out] */
+    xgm_result_hdr* hdrs;          /* [rows] */
+    uint32_t k_stride_out, pad;
+} xgm_fuse;
+
 #endif

@@ -778,6 +778,7 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
     wave_lds_fence();
 }
 
+#include "xgm_unit_finish.h"
 #include "xgm_dense_body.inc"
 
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
@@ -787,7 +788,8 @@ template <typename TabT, bool PHRASE, int SIDED, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES) void xgm_andw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                               uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out, uint32_t* __restrict__ hist_all) {
+                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out, uint32_t* __restrict__ hist_all,
+                                                              const xgm_fuse* __restrict__ fuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t CAND = PHRASE ? kAndwCandPhrase : kAndwCandPlain;     /* candidates per chunk */
     constexpr uint32_t CHUNKB = CAND / XGM_BLOCK;                             /* = blocks of term 0 per chunk */
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     if (!PHRASE && SIDED == 0 && (rfl32(q.flags) & XGM_QF_DENSE)) {
         /* every term has containers: the body written for that case alone (same launch, same outputs) */
         xgm_dense_unit<false, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
-                                     cand_out, ghdr_out, nullptr);
+                                     cand_out, ghdr_out, nullptr, fuse);
         return;
     }
     /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not
@@ -1966,10 +1968,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     const bool any_pruned = PHRASE && __ballot(pos_pruned) != 0ull;
     const uint32_t n_out = tkn < k ? tkn : k;
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
+    const bool through = fuse != nullptr;                          /* the launch finishes its queries itself (xgm_unit_finish.h) */
     for (uint32_t i = lane; i < n_out; i += 64u) {
         xgm_cand c;
         c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = MAYBE ? (uint32_t)tk_m[i] : (uint32_t)__popc(q.score_mask);   /* plain: the weighted leaves all match */
-        out[i] = c;
+        xgm_store_cand(through, &out[i], c);
     }
     if (lane == 0) {
         xgm_group_hdr h;
@@ -1977,8 +1980,10 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         h.c_pos = cn_pos; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
         h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = (uint32_t)(ph_a >> 6); h.c_pad[1] = (uint32_t)(ph_b >> 6);
-        ghdr_out[wk.slot] = h;
+        xgm_store_hdr(through, &ghdr_out[wk.slot], h);
     }
+    if (through) xgm_unit_arrive<MAYBE>(*fuse, wk.qi, k, (uint32_t)__popc(q.score_mask), tk_w, tk_d, tk_m, cap, cand_out, ghdr_out, k_stride, lane,
+                           [&]() { if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane); });
 #undef XGM_SU
 }
 
@@ -2502,7 +2507,7 @@ static int launch_andw_inst(const xgm_match_launch& L, size_t smem, hipStream_t 
     auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED, TALLY>;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist);
+    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -22,6 +22,7 @@ struct xgm_match_launch {
                                          positional instantiation of xgm_andw_kernel (units of one query share their k-th weight bound) */
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
     xgm_group_hdr* ghdr;              /* device, [n_work]                                         */
+    const xgm_fuse* fuse = nullptr;   /* xgm_andw_kernel only: device copy of the parameters with which the kernel writes the final hits itself (no merge launch) */
 };
 
 size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
