@@ -104,3 +104,75 @@ def test_matcher_hook_under_emulation(emu_lib, tmp_path):
     out = json.loads(line[-1])
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
     assert out["answered_on_device"] >= len(qs) * 2 // 3, out
+
+
+def _run_hook_emulated(T, alias, *args):
+    import json
+    env = dict(os.environ, LD_LIBRARY_PATH=str(alias) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([T.HOOK_B1] + [str(a) for a in args], capture_output=True, text=True, timeout=1500, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-3000:] + r.stderr[-2000:]
+    return json.loads(line[-1])
+
+
+def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
+    """The hook's other modes without a GPU, on a small glass index with value slots: value and KEY sorts with ValueCountMatchSpy
+    spies (device columns built from the value stream / the KeyMaker); REPLAY + COLLAPSE_REFERENCE (collapse with any collapse_max and
+    pages inside the match, cut-offs, spies by relevance: the reference's own collation over the device's match list);
+    POSITIONAL_REFERENCE (PHRASE / NEAR pages inside the match: the reference's stale-weight ranking reproduced).  Hook on == hook
+    off in every case — sort keys, collapse keys and counts, spy counts, percentages, every match-count figure."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import test_gpu_hook_b1 as T
+    if not (H.have_xapian_ref() and os.path.exists(T.HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    alias = tmp_path / "lib"
+    alias.mkdir()
+    os.symlink(emu_lib, str(alias / "libxgm.so"))
+    n_docs = 6000
+    one = str(tmp_path / "one")
+    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), n_docs, T.VOCAB, 50, 150)
+    # value / key sorts and spies
+    qs, n_sorted = T.sorted_queries()
+    qs = qs[:n_sorted:2] + qs[n_sorted::4]
+    qf = str(tmp_path / "qs.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
+    assert out["answered_sorted"] >= n_sorted // 2 and out["answered_spied"] >= 6 and out["columns_built"] >= 3, out
+    # replay: collapse / cut-offs / spies by relevance with pages inside the match
+    c = H.Corpus(n_docs, T.VOCAB)
+    qs = []
+    for q in (H.gen_term_queries("AND", 60, 2, 1, 150, maxitems=10, seed=111) + H.gen_term_queries("OR", 40, 2, 100, 2000, maxitems=10, seed=112) +
+              H.gen_sided_queries("AND_MAYBE", 20, 1, 1, 50, 1000, maxitems=10, seed=113)):
+        m = H.oracle_search(c, q["op"], q["terms"], 0, 1, n_required=q.get("n_required", 0))[1].matches
+        if 30 <= m <= 1000 and len(qs) < 24:
+            i = len(qs)
+            kind = i % 4
+            if kind == 0:
+                qs.append(dict(q, first=0, maxitems=10, collapse=(i % 3, 1 + (i // 4) % 3)))
+            elif kind == 1:
+                qs.append(dict(q, first=2, maxitems=8, collapse=((i + 1) % 3, 1), sort=(("VR", "RV")[i % 2], i % 3, False)))
+            elif kind == 2:
+                qs.append(dict(q, first=0, maxitems=10, cutoff=((40, 0.0), (0, 1.5), (70, 0.5))[(i // 4) % 3]))
+            else:
+                qs.append(dict(q, first=0, maxitems=10, spy=i % 3))
+    assert len(qs) >= 16, len(qs)
+    qf = str(tmp_path / "qr.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, "--collapse-reference", "--replay", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["replayed"] == len(qs) and out["http_total_equal"] == len(qs), out
+    # PHRASE / NEAR pages inside the match: the reference's frozen weights
+    qs = []
+    for q in (H.gen_phrase_queries(120, n_docs, T.VOCAB, seed=101, lengths=(2, 3)) + H.gen_phrase_queries(40, n_docs, T.VOCAB, seed=103, window_extra=4, op="NEAR")):
+        m = H.oracle_search(c, q["op"], q["terms"], 0, 1, window=q.get("window", 0))[1].matches
+        if 12 <= m <= 1000 and len(qs) < 16:
+            qs.append(dict(q, first=(0, 0, 3)[len(qs) % 3], maxitems=(10, 5, 7)[len(qs) % 3]))
+    c.close()
+    assert len(qs) >= 8, len(qs)
+    qf = str(tmp_path / "qp.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
+    assert out["answered_on_device"] == len(qs), out
