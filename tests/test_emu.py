@@ -104,6 +104,17 @@ def test_matcher_hook_under_emulation(emu_lib, tmp_path):
     out = json.loads(line[-1])
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
     assert out["answered_on_device"] >= len(qs) * 2 // 3, out
+    # ... and through Xapiand's per-shard protocol (prepare_mset / add_prepared_mset / get_mset / merge_mset) over three shards
+    shards = []
+    for sh in range(3):
+        p = str(tmp_path / ("shard%d" % sh))
+        H.xapian_ref("build", p, hex(H.CORPUS_SEED), 6000, T.VOCAB, 50, 150, 3, sh)
+        shards.append(p)
+    r = subprocess.run([T.HOOK_B1, qf] + shards, capture_output=True, text=True, timeout=1500, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and line, r.stdout[-3000:] + r.stderr[-2000:]
+    out3 = json.loads(line[-1])
+    assert out3["mismatches"] == 0 and out3["shards"] == 3 and out3["answered_on_device"] >= len(qs) * 2, out3
 
 
 def _run_hook_emulated(T, alias, *args):
