@@ -188,3 +188,33 @@ def test_disjunction_term_bounds_dominate_every_posting(built, tmp_path):
                 checked += len(did)
     assert checked > 100000
     db.close()
+
+
+def test_prefix_expansion_walks_the_dictionary_in_term_order(host_env):
+    """xgm_expand_prefix / xgm_term_info (what the matcher hook expands OP_WILDCARD / OP_EDIT_DISTANCE with): the terms under a prefix
+    in byte order — the order Database::allterms_begin(prefix) walks, Context<T>::expand_wildcard's input (reference
+    src/xapian/api/queryinternal.cc:246-315) — with their strings and shard-local term frequencies; the count is exact whatever the
+    caller's capacity is."""
+    import ctypes as C
+    c1, db1, _, _ = host_env
+    L = _lib.lib()
+    terms = c1.terms()
+    df = c1.df_array()
+    tf_of = {t: int(df[i]) for i, t in enumerate(terms)}
+    for prefix in (b"t12", b"t9", b"t1999", b"t", b"t77777", b"", b"zz", b"t0"):
+        want = sorted(t for t in terms if t.startswith(prefix))
+        n_total = C.c_uint32()
+        small = (C.c_uint32 * 5)()
+        assert L.xgm_expand_prefix(db1._h, prefix, len(prefix), 5, small, C.byref(n_total)) == 0
+        assert n_total.value == len(want), (prefix, n_total.value, len(want))
+        ids = (C.c_uint32 * max(1, len(want)))()
+        assert L.xgm_expand_prefix(db1._h, prefix, len(prefix), len(want), ids, C.byref(n_total)) == 0 and n_total.value == len(want)
+        got = []
+        for i in range(min(len(want), 4000)):
+            b, bl, tf = C.c_char_p(), C.c_size_t(), C.c_uint32()
+            assert L.xgm_term_info(db1._h, ids[i], C.byref(b), C.byref(bl), C.byref(tf), None) == 0
+            t = C.string_at(b, bl.value)
+            got.append(t)
+            assert tf.value == tf_of[t], (t, tf.value, tf_of[t])
+        assert got == want[:len(got)], (prefix, got[:5], want[:5])
+        assert list(small[:min(5, len(want))]) == list(ids[:min(5, len(want))])
