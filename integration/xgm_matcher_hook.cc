@@ -36,7 +36,7 @@ struct ShardColumns {
 struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; };
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
-std::map<std::string, SpyAdapter> g_spy_adapters;
+std::map<std::string, std::shared_ptr<const SpyAdapter>> g_spy_adapters;      /* (shared: a search keeps its adapter although the name is registered again meanwhile) */
 std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false}, g_replay{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
 std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0};
@@ -338,8 +338,8 @@ std::shared_ptr<Column> key_column(const Shard& sh, const Xapian::Database& db, 
 }
 
 /* which value slot a spy counts: Xapian::ValueCountMatchSpy serialises exactly its slot (api/matchspy.cc: pack_uint_last) */
-bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, const SpyAdapter** adapter) {
-    *adapter = nullptr;
+bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, std::shared_ptr<const SpyAdapter>* adapter) {
+    adapter->reset();
     std::string name;
     try { name = spy.name(); } catch (const Xapian::Error&) { return false; }
     if (name == "Xapian::ValueCountMatchSpy") {
@@ -352,9 +352,9 @@ bool spy_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot, const SpyAd
     }
     std::lock_guard<std::mutex> lk(g_mu);
     auto it = g_spy_adapters.find(name);
-    if (it == g_spy_adapters.end() || !it->second.slot_of || !it->second.feed) return false;
-    *adapter = &it->second;
-    return it->second.slot_of(spy, slot);
+    if (it == g_spy_adapters.end() || !it->second || !it->second->slot_of || !it->second->feed) return false;
+    *adapter = it->second;
+    return (*adapter)->slot_of(spy, slot);
 }
 
 
@@ -480,7 +480,7 @@ void set_near_colocated_terms(bool may_exist) { g_near_colocated.store(may_exist
 void set_replay(bool on) { g_replay.store(on); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
-    g_spy_adapters[spy_class_name] = std::move(adapter);
+    g_spy_adapters[spy_class_name] = std::make_shared<const SpyAdapter>(std::move(adapter));
 }
 Counters counters() {
     return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load(), g_sorted.load(), g_spied.load(),
@@ -519,7 +519,7 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         return false;
     }
     /* spies: only classes the hook can feed */
-    struct SpyPlan { Xapian::MatchSpy* spy; Xapian::valueno slot; const SpyAdapter* adapter; std::shared_ptr<Column> col; };
+    struct SpyPlan { Xapian::MatchSpy* spy; Xapian::valueno slot; std::shared_ptr<const SpyAdapter> adapter; std::shared_ptr<Column> col; };
     std::vector<SpyPlan> spies;
     for (const auto& sp : matchspies) {
         if (!sp.get()) continue;
