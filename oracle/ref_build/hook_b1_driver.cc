@@ -47,6 +47,21 @@ int main(int argc, char** argv) {
     int a = 1;
     bool stale = false, exact_bounds_on = false, replay_on = false;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
+    {   /* the driver's own spy class reaches the device through an adapter (how Xapiand binds AggregationMatchSpy) */
+        xgm_hook::SpyAdapter ad;
+        ad.slot_of = [](const Xapian::MatchSpy& s, Xapian::valueno* slot) {
+            const DriverCountSpy* d = dynamic_cast<const DriverCountSpy*>(&s);
+            if (!d) return false;
+            *slot = d->slot;
+            return true;
+        };
+        ad.feed = [](Xapian::MatchSpy& s, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts) {
+            DriverCountSpy& d = static_cast<DriverCountSpy&>(s);
+            d.total += total;
+            for (const auto& kv : counts) d.values[kv.first] += kv.second;
+        };
+        xgm_hook::register_spy_adapter("DriverCountSpy", ad);
+    }
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
         else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);

@@ -65,11 +65,29 @@ struct QuerySpec {
     unsigned sort_slot = 0, sort_reverse = 0, collapse_slot = 0, collapse_max = 0, check_at_least = 0;
     /* "SPY=<slot>": a Xapian::ValueCountMatchSpy on the slot (what Xapiand's AggregationMatchSpy is a subclass of) */
     int spy_slot = -1;
+    /* "SPYC=<slot>": the same counts through a MatchSpy subclass of the driver's own (DriverCountSpy) — a class the hook only knows
+     * through a registered xgm_hook::SpyAdapter, the way Xapiand's AggregationMatchSpy would be bound */
+    bool spy_custom = false;
     /* "CUT=<percent>:<weight>": Enquire::set_cutoff (DocMatcher::prepare_mset sets it on every Enquire, handler.cc:1265) */
     int cut_percent = 0; double cut_weight = 0.0;
 };
 
 struct SpyResult { unsigned total = 0; std::map<std::string, unsigned> values; };
+
+/* A MatchSpy class of the application's own, counting a slot's values the way Xapian::ValueCountMatchSpy does (api/matchspy.cc) */
+class DriverCountSpy : public Xapian::MatchSpy {
+  public:
+    Xapian::valueno slot;
+    unsigned total = 0;
+    std::map<std::string, unsigned> values;
+    explicit DriverCountSpy(Xapian::valueno slot_) : slot(slot_) {}
+    void operator()(const Xapian::Document& doc, double) override {
+        ++total;
+        const std::string v = doc.get_value(slot);
+        if (!v.empty()) ++values[v];
+    }
+    std::string name() const override { return "DriverCountSpy"; }
+};
 
 std::vector<QuerySpec> read_queries(const char* path) {
     std::vector<QuerySpec> out;
@@ -96,6 +114,9 @@ std::vector<QuerySpec> read_queries(const char* path) {
                 if (sscanf(tok.c_str() + 4, "%d:%lf", &q.cut_percent, &q.cut_weight) != 2) { fprintf(stderr, "bad %s\n", tok.c_str()); exit(2); }
             } else if (tok.rfind("SPY=", 0) == 0) {
                 q.spy_slot = (int)strtoul(tok.c_str() + 4, nullptr, 10);
+            } else if (tok.rfind("SPYC=", 0) == 0) {
+                q.spy_slot = (int)strtoul(tok.c_str() + 5, nullptr, 10);
+                q.spy_custom = true;
             } else { ss.clear(); ss.seekg(at); break; }
         }
         ss >> q.op >> q.first >> q.maxitems >> q.window;
@@ -247,6 +268,14 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
         apply_settings(enq, settings);
         enq.set_query(query);
         if (!spy_on) return enq.get_mset(first, maxitems, cal);
+        if (settings->spy_custom) {
+            DriverCountSpy cspy((Xapian::valueno)settings->spy_slot);
+            enq.add_matchspy(&cspy);
+            Xapian::MSet m = enq.get_mset(first, maxitems, cal);
+            spied->total += cspy.total;
+            for (auto& kv : cspy.values) spied->values[kv.first] += kv.second;
+            return m;
+        }
         Xapian::ValueCountMatchSpy spy((Xapian::valueno)settings->spy_slot);
         enq.add_matchspy(&spy);
         Xapian::MSet m = enq.get_mset(first, maxitems, cal);
@@ -271,7 +300,14 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
     }
     for (size_t s = 0; s < n_shards; ++s) {
         enqs[s].set_prepared_mset(merger.get_prepared_mset());
-        if (spy_on) {
+        if (spy_on && settings->spy_custom) {
+            DriverCountSpy cspy((Xapian::valueno)settings->spy_slot);
+            enqs[s].add_matchspy(&cspy);
+            msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
+            spied->total += cspy.total;
+            for (auto& kv : cspy.values) spied->values[kv.first] += kv.second;
+            enqs[s].clear_matchspies();
+        } else if (spy_on) {
             Xapian::ValueCountMatchSpy spy((Xapian::valueno)settings->spy_slot);
             enqs[s].add_matchspy(&spy);
             msets[s] = enqs[s].get_mset(0, first + maxitems, cal);

@@ -146,6 +146,14 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
     # value / key sorts and spies
     qs, n_sorted = T.sorted_queries()
     qs = qs[:n_sorted:2] + qs[n_sorted::4]
+    # ... some of the spies as a MatchSpy class of the application's own, bound through xgm_hook::register_spy_adapter (the way
+    # Xapiand's AggregationMatchSpy would be): the driver's DriverCountSpy
+    n_custom = 0
+    for q in qs:
+        if q.get("spy") is not None and n_custom % 2 == 0:
+            q["spy_custom"] = True
+        n_custom += q.get("spy") is not None
+    assert sum(1 for q in qs if q.get("spy_custom")) >= 3
     qf = str(tmp_path / "qs.txt")
     H.write_queries(qf, qs)
     out = _run_hook_emulated(T, alias, qf, one)
