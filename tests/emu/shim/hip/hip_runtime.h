@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 
 #define XGM_EMU 1
 #define __global__
@@ -69,6 +70,7 @@ struct State {
     bool in_kernel = false;
 };
 inline State S;
+inline std::mutex launch_mu;        /* one launch at a time: host threads that search concurrently take turns on the one emulated device */
 
 inline void yield() { swapcontext(&S.ctx[S.cur], &S.sched); }
 
@@ -146,6 +148,7 @@ inline void install_fault_handler() {
 
 template <class F>
 inline void launch(dim3 grid, dim3 block, size_t smem_bytes, unsigned char* lds, F&& body) {
+    std::lock_guard<std::mutex> launch_lk(launch_mu);
     if (getenv("XGM_EMU_FAULT_TRACE")) install_fault_handler();
     if (S.in_kernel) { fprintf(stderr, "emu: nested launch\n"); abort(); }
     if (block.x * block.y * block.z > kMaxThreads || block.y != 1 || block.z != 1 || smem_bytes > kLdsBytes) { fprintf(stderr, "emu: unsupported launch shape\n"); abort(); }
