@@ -448,6 +448,19 @@ int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xgm_sort_spec
                          xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord, uint32_t* hit_collapse_count, xgm_result_hdr* hdr,
                          uint64_t* collapsed_lower_bound);
 
+/* EVERY matching document of a planned query — no page, no pruning — in ASCENDING DOCID order, each with its weight and the number
+ * of weighted leaves matching it: the sequence the reference's matcher loop is shown by its posting-list tree (Matcher::get_local_mset,
+ * matcher/matcher.cc:482-536) before ProtoMSet, the collapser, the spies or a cut-off look at it.  The plan's first / maxitems /
+ * check_at_least are ignored (positional queries test every candidate's positions).  hits[0 .. *n_matches) are written when
+ * *n_matches <= cap; otherwise nothing is written and *n_matches tells the room needed (plan->est_max — the tree's own
+ * get_termfreq_max — always suffices).  hdr: matches_exact = *n_matches, max_attained / max_weight_subqs_matched of the whole match,
+ * n_hits = hits written.  Every query shape xgm_search takes (positional queries of up to 3 terms); one query per call.
+ * What it is for: answers that must be BYTE-COMPATIBLE with the reference where the reference's answer depends on its traversal —
+ * known_matching_docs behind MSet::get_matches_lower_bound / _estimated (protomset.h:497-619; xgm_known_matching_docs), the frozen
+ * weight of PHRASE / NEAR (selectpostlist.cc:28-55), the snapshot's collapser, cut-offs and spies by relevance — for matches of ANY
+ * size (rounds 1-3 could fetch at most XGM_MAX_K of them).  The matcher hook replays the reference's own loop over this list. */
+int xgm_search_all(xgm_index*, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr);
+
 
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
 int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,

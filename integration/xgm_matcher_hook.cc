@@ -364,28 +364,30 @@ thread_local ReplayCtx tl_replay;
 
 /* ALL matching documents of a search, in docid order, as a PostList for Matcher::get_local_mset's loop (see set_replay) */
 class ReplayPostList : public Xapian::Internal::PostList {
-    std::vector<xgm_hit> hits;
+    std::unique_ptr<xgm_hit[]> hits;           /* ascending docid (xgm_search_all) */
+    size_t n_hits;
     size_t pos = size_t(-1);                   /* before the first */
     Xapian::doccount tf_min, tf_est, tf_max;
     double max_weight;
   public:
-    ReplayPostList(std::vector<xgm_hit>&& h, Xapian::doccount mn, Xapian::doccount est, Xapian::doccount mx, double mw)
-        : hits(std::move(h)), tf_min(mn), tf_est(est), tf_max(mx), max_weight(mw) {}
+    ReplayPostList(std::unique_ptr<xgm_hit[]>&& h, size_t n, Xapian::doccount mn, Xapian::doccount est, Xapian::doccount mx, double mw)
+        : hits(std::move(h)), n_hits(n), tf_min(mn), tf_est(est), tf_max(mx), max_weight(mw) {}
     Xapian::doccount get_termfreq_min() const override { return tf_min; }
     Xapian::doccount get_termfreq_max() const override { return tf_max; }
     Xapian::doccount get_termfreq_est() const override { return tf_est; }
     Xapian::docid get_docid() const override { return hits[pos].docid; }
     double get_weight(Xapian::termcount, Xapian::termcount) const override { return hits[pos].weight; }
-    bool at_end() const override { return pos != size_t(-1) && pos >= hits.size(); }
+    bool at_end() const override { return pos != size_t(-1) && pos >= n_hits; }
     double recalc_maxweight() override { return max_weight; }
     PostList* next(double) override { ++pos; return nullptr; }
     PostList* skip_to(Xapian::docid did, double) override {
         if (pos == size_t(-1)) pos = 0;
-        while (pos < hits.size() && hits[pos].docid < did) ++pos;
+        if (pos < n_hits && hits[pos].docid < did)
+            pos = size_t(std::lower_bound(hits.get() + pos, hits.get() + n_hits, did, [](const xgm_hit& h, Xapian::docid d) { return h.docid < d; }) - hits.get());
         return nullptr;
     }
     Xapian::termcount count_matching_subqs() const override { return hits[pos].subqs_matched; }
-    std::string get_description() const override { return "XgmReplay(" + std::to_string(hits.size()) + ")"; }
+    std::string get_description() const override { return "XgmReplay(" + std::to_string(n_hits) + ")"; }
 };
 
 /* ProtoMSet::add for a search by relevance (protomset.h:340-400) with the weight the matcher's loop hands it, and the loop's own
@@ -457,6 +459,21 @@ bool frozen_weight(const Xapian::Database& db, const std::vector<std::string>& t
     }
     *w_out = weight;
     return true;
+}
+
+/* EVERY matching document of a planned query in ascending docid order with its weight (xgm_search_all): what the byte-compatible
+ * modes replay — of any size since round 4 (rounds 1-3: at most XGM_MAX_K documents, fetched as one page and sorted here).  The
+ * buffer is sized by the tree's own upper bound (plan.est_max = PostList::get_termfreq_max of the tree the reference builds), left
+ * uninitialised: only the matches are ever touched.  Returns the library's code. */
+int fetch_all(xgm_index* idx, const xgm_query& plan, Xapian::doccount doccount, std::unique_ptr<xgm_hit[]>* out, uint64_t* n, xgm_result_hdr* hdr) {
+    const uint64_t cap = std::max<uint64_t>(1, plan.est_max ? std::min<uint64_t>(plan.est_max, doccount) : doccount);
+    out->reset(new xgm_hit[cap]);
+    int rc = xgm_search_all(idx, &plan, out->get(), cap, n, hdr);
+    if (rc == XGM_OK && *n > cap) {                           /* (cannot happen with a bound from the plan; be exact anyway) */
+        out->reset(new xgm_hit[*n]);
+        rc = xgm_search_all(idx, &plan, out->get(), *n, n, hdr);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -658,7 +675,7 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     if (plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0 && hdr.n_hits == k && !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) &&
         !(L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT)) {
         const uint64_t m_ = XGM_MATCHES_COUNT(hdr.matches_exact);
-        if (m_ > k && m_ >= plan.check_at_least && m_ <= XGM_MAX_K) {
+        if (m_ > k && m_ >= plan.check_at_least) {
             tl_replay = ReplayCtx{true, &stats, &wtscheme, full_db_has_positions};
             return false;
         }
@@ -666,34 +683,21 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     bool replayed = false;
     uint64_t replay_known = 0;
     if (plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0 && hdr.n_hits == k) {
-        /* how large is the match (every candidate's positions tested: check_at_least beyond the index), then all of it in one page sized to
-         * it — a page of up to 192 stays on the wave kernel */
-        xgm_query_desc d2 = L.d;
-        d2.first = 0; d2.maxitems = k; d2.check_at_least = 0xFFFFFFFFu;
-        xgm_query plan2;
-        std::vector<xgm_hit> all(k);
+        /* the whole match in docid order, every candidate's positions tested (xgm_search_all: a match of any size) */
+        std::unique_ptr<xgm_hit[]> all;
+        uint64_t n_all = 0;
         xgm_result_hdr hdr2;
         memset(&hdr2, 0, sizeof hdr2);
-        int rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
-        if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, k, all.data(), &hdr2);
-        if (rc2 == XGM_OK && !(hdr2.matches_exact & XGM_MATCHES_LOWER_BOUND) && XGM_MATCHES_COUNT(hdr2.matches_exact) > k) {
-            const uint64_t m_exact = XGM_MATCHES_COUNT(hdr2.matches_exact);
-            if (m_exact > XGM_MAX_K) { ++g_dev; return false; }                  /* the match exceeds a device page: CPU matcher */
-            d2.maxitems = (uint32_t)m_exact;
-            all.assign(m_exact, xgm_hit());
-            rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
-            if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, (uint32_t)m_exact, all.data(), &hdr2);
-        }
+        const int rc2 = fetch_all(sh.idx, plan, db.get_doccount(), &all, &n_all, &hdr2);
         if (rc2 < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
-        if (rc2 > 0 || (hdr2.matches_exact & XGM_MATCHES_LOWER_BOUND) || XGM_MATCHES_COUNT(hdr2.matches_exact) != hdr2.n_hits) { ++g_dev; return false; }
-        all.resize(hdr2.n_hits);
-        std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+        if (rc2 > 0) { ++g_dev; return false; }                                /* e.g. a phrase of more than 3 terms: CPU matcher */
         RefProtoMSet pm;
         pm.max_size = k; pm.check_at_least = plan.check_at_least;
         bool frozen = false, have_w = false, none_left = false;
         double w_star = 0.0;
         Xapian::docid trigger = 0;
-        for (const xgm_hit& h : all) {
+        for (uint64_t ai = 0; ai < n_all; ++ai) {
+            const xgm_hit& h = all[ai];
             if (!(pm.min_weight > 0.0)) {                                      /* vet(): w_min <= 0 — the document's own weight */
                 pm.add(RefProtoMSet::Item{h.weight, h.docid, h.subqs_matched});
                 if (pm.min_weight > 0.0) { frozen = true; trigger = h.docid; }
@@ -741,21 +745,17 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     } else if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
         xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
     } else if (plain && g_exact_bounds.load(std::memory_order_relaxed) && every_match_visited && k > 0 && hdr.n_hits == k &&
-               !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least && m_all <= XGM_MAX_K) {
-        /* known_matching_docs is a function of the match in docid order (xgm_known_matching_docs): fetch the whole match — it fits one
-         * device page — and report the reference's own figures */
-        xgm_query_desc d2 = L.d;
-        d2.first = 0; d2.maxitems = (uint32_t)m_all;
-        xgm_query plan2;
-        std::vector<xgm_hit> all(m_all);
+               !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least) {
+        /* known_matching_docs is a function of the match in docid order (xgm_known_matching_docs): fetch the whole match — of any
+         * size — and report the reference's own figures */
+        std::unique_ptr<xgm_hit[]> all;
+        uint64_t n_all = 0;
         xgm_result_hdr hdr2;
         memset(&hdr2, 0, sizeof hdr2);
-        int rc2 = xgm_plan_query(sh.idx, &d2, &gs, &plan2);
-        if (rc2 == XGM_OK) rc2 = xgm_search_batch(sh.idx, &plan2, 1, (uint32_t)m_all, all.data(), &hdr2);
-        if (rc2 == XGM_OK && hdr2.n_hits == m_all) {
-            std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
-            std::vector<double> w(m_all);
-            for (size_t i = 0; i < all.size(); ++i) w[i] = all[i].weight;
+        const int rc2 = fetch_all(sh.idx, plan, db.get_doccount(), &all, &n_all, &hdr2);
+        if (rc2 == XGM_OK && n_all == m_all) {
+            std::vector<double> w(n_all);
+            for (size_t i = 0; i < n_all; ++i) w[i] = all[i].weight;
             xgm_mset_bounds_known(&plan, &hdr, xgm_known_matching_docs(w.data(), w.size(), k, plan.check_at_least), &lb, &est, &ub);
         } else {
             xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
@@ -830,26 +830,18 @@ Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapia
         if (!(i < L.lazy.size() && L.lazy[i]) || xgm_lookup_term(sh.idx, L.terms[i].data(), L.terms[i].size(), nullptr, &tf, nullptr, nullptr) != XGM_OK) { ++g_shape; return pl; }
         gs.termfreq[i] = tf;
     }
-    /* how large is the match (positional: every candidate's positions tested), then all of it */
+    /* the whole match in docid order (positional: every candidate's positions tested) */
     L.d.first = 0; L.d.maxitems = 1; L.d.check_at_least = 0xFFFFFFFFu;
     xgm_query plan;
-    xgm_hit one;
     xgm_result_hdr hdr;
     memset(&hdr, 0, sizeof hdr);
     int rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
-    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, 1, &one, &hdr);
-    if (rc < 0) { ++g_dev; return pl; }                  /* a device failure here costs nothing: the tree is still there, the CPU matcher runs */
-    const uint64_t m = XGM_MATCHES_COUNT(hdr.matches_exact);
-    if (rc > 0 || (hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) || m == 0 || m > XGM_MAX_K) { ++g_dev; return pl; }      /* nothing to gain / beyond a device page */
-    std::vector<xgm_hit> all(m);
-    L.d.maxitems = (uint32_t)m;
-    rc = xgm_plan_query(sh.idx, &L.d, &gs, &plan);
-    if (rc == XGM_OK) rc = xgm_search_batch(sh.idx, &plan, 1, (uint32_t)m, all.data(), &hdr);
-    if (rc < 0) { ++g_dev; return pl; }                  /* a device failure here costs nothing: the tree is still there, the CPU matcher runs */
-    if (rc > 0 || hdr.n_hits != m) { ++g_dev; return pl; }
-    std::sort(all.begin(), all.end(), [](const xgm_hit& a, const xgm_hit& b) { return a.docid < b.docid; });
+    std::unique_ptr<xgm_hit[]> all;
+    uint64_t m = 0;
+    if (rc == XGM_OK) rc = fetch_all(sh.idx, plan, db.get_doccount(), &all, &m, &hdr);
+    if (rc != XGM_OK || m == 0) { ++g_dev; return pl; }  /* declined, nothing to gain, or a device failure — which costs nothing here: the tree is still there, the CPU matcher runs */
     /* the static figures of the tree this list stands in for */
-    Xapian::Internal::PostList* r = new ReplayPostList(std::move(all), pl->get_termfreq_min(), pl->get_termfreq_est(), pl->get_termfreq_max(), pl->recalc_maxweight());
+    Xapian::Internal::PostList* r = new ReplayPostList(std::move(all), (size_t)m, pl->get_termfreq_min(), pl->get_termfreq_est(), pl->get_termfreq_max(), pl->recalc_maxweight());
     delete pl;
     ++g_replayed;
     ++g_answered;

@@ -45,7 +45,7 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
 
 int main(int argc, char** argv) {
     int a = 1;
-    bool stale = false, exact_bounds_on = false, replay_on = false;
+    bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     {   /* the driver's own spy class reaches the device through an adapter (how Xapiand binds AggregationMatchSpy) */
         xgm_hook::SpyAdapter ad;
@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     }
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
-        else if (!strcmp(argv[a], "--positional-reference")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE);
+        else if (!strcmp(argv[a], "--positional-reference")) { xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE); positional_reference_on = true; }
         else if (!strcmp(argv[a], "--exact-bounds")) { xgm_hook::set_exact_bounds(true); exact_bounds_on = true; }
         else if (!strcmp(argv[a], "--collapse-intended")) xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_INTENDED);
         else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
@@ -158,13 +158,15 @@ int main(int argc, char** argv) {
             /* the upper bound is a static property of the postlist tree: identical; the lower bound may be looser than the CPU
              * matcher's (which counts the documents it happened to weigh) but never above it or the estimate.  Where the value leads
              * the sort the matcher shows ProtoMSet every document: all three figures must be the reference's. */
-            /* ... and, with --exact-bounds, by relevance for the operators whose known_matching_docs is a function of the match in docid
-             * order (a term, AND, FILTER, AND_NOT, PHRASE, NEAR) when the match fits one device page; the reference also knows the
-             * exact count whenever its three figures coincide — then the hook must report the same */
-            const bool and_class = q.op == "AND" || q.op == "FILTER" || q.op == "AND_NOT" || q.op == "PHRASE" || q.op == "NEAR";
+            /* ... and, with --exact-bounds, by relevance for EVERY operator and a match of ANY size (round 4: the device hands back the
+             * whole match in docid order, xgm_search_all; rounds 1-3 required it only when the match fit one device page): a term, AND,
+             * FILTER, AND_NOT through xgm_known_matching_docs, OR / AND_MAYBE / trees through the replay of the reference's own loop;
+             * positional queries in --positional-reference mode (the frozen-weight replay counts like ProtoMSet does); the reference
+             * also knows the exact count whenever its three figures coincide — then the hook must report the same */
+            const bool positional = q.op == "PHRASE" || q.op == "NEAR";
             const bool exact_bounds = !q.collapse_max && (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR" ||
-                                                          (exact_bounds_on && and_class && q.sort_mode.empty() && want.get_matches_upper_bound() <= 1024) ||
-                                                          (exact_bounds_on && q.op != "PHRASE" && q.op != "NEAR" && q.sort_mode.empty() && want.get_matches_upper_bound() <= 1024) ||
+                                                          (exact_bounds_on && !positional && q.sort_mode.empty()) ||
+                                                          (positional_reference_on && positional && q.sort_mode.empty()) ||
                                                           (want.get_matches_lower_bound() == want.get_matches_upper_bound()));
             if (dbs.size() == 1 && replay_on && (q.collapse_max || q.cut_percent || q.cut_weight != 0.0 || q.spy_slot >= 0)) {
                 /* replayed through the reference's own collation: every figure is the CPU matcher's */

@@ -266,6 +266,7 @@ EMU_WAVE_OP inline int __builtin_amdgcn_update_dpp(int old, int v, int ctrl, int
 inline uint32_t __builtin_amdgcn_mbcnt_lo(uint32_t mask, uint32_t base) { const unsigned l = emu::lane_of(); const uint32_t m = l >= 32 ? mask : (mask & ((1u << l) - 1u)); return base + (uint32_t)__builtin_popcount(m); }
 inline uint32_t __builtin_amdgcn_mbcnt_hi(uint32_t mask, uint32_t base) { const unsigned l = emu::lane_of(); const uint32_t m = l <= 32 ? 0u : (mask & ((1u << (l - 32)) - 1u)); return base + (uint32_t)__builtin_popcount(m); }
 inline void __builtin_amdgcn_fence(int, const char*) {}
+inline void __builtin_amdgcn_s_waitcnt(int) {}
 EMU_WAVE_OP inline void __builtin_amdgcn_wave_barrier() { emu::wave_barrier_at(EMU_SITE); }
 inline uint32_t __builtin_amdgcn_alignbit(uint32_t hi, uint32_t lo, uint32_t shift) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (shift & 31u)); }
 inline uint32_t __builtin_amdgcn_sad_u8(uint32_t a, uint32_t b, uint32_t c) {

@@ -195,3 +195,40 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
     out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
     assert out["answered_on_device"] == len(qs), out
+
+
+def test_search_all_under_emulation(emu_lib):
+    """xgm_search_all (every match in docid order; round 4) against the oracle's full ranking: all operator classes, trees, matches
+    beyond one device page."""
+    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_all.py")])
+    assert "3 passed" in out, out
+
+
+def test_byte_compatible_modes_beyond_one_device_page_under_emulation(emu_lib, tmp_path):
+    """The hook's exact bounds / replay / positional-reference modes on matches LARGER than XGM_MAX_K (round 4, xgm_search_all):
+    hook on == hook off incl. the HTTP total, without a GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import test_gpu_hook_b1 as T
+    if not (H.have_xapian_ref() and os.path.exists(T.HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    alias = tmp_path / "lib"
+    alias.mkdir()
+    os.symlink(emu_lib, str(alias / "libxgm.so"))
+    n_docs = 6000
+    one = str(tmp_path / "one")
+    H.xapian_ref("build", one, hex(H.CORPUS_SEED), n_docs, T.VOCAB, 50, 150)
+    c = H.Corpus(n_docs, T.VOCAB)
+    plain, positional = T.big_match_queries(c, n_docs, T.VOCAB, 1100, 3)
+    c.close()
+    assert len(plain) >= 10 and len(positional) >= 4, (len(plain), len(positional))
+    qf = str(tmp_path / "qbig.txt")
+    H.write_queries(qf, plain)
+    out = _run_hook_emulated(T, alias, "--exact-bounds", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(plain), out
+    assert out["http_total_equal"] == len(plain) and out["replayed"] >= 3, out
+    qf = str(tmp_path / "qbigpos.txt")
+    H.write_queries(qf, positional)
+    out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(positional), out
+    assert out["answered_on_device"] == len(positional), out

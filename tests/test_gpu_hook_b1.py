@@ -348,3 +348,52 @@ def test_replay_reference_collation_over_the_device_match(built, glass_values):
     out = run_b1("--collapse-reference", "--replay", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
     assert out["replayed"] == len(qs) and out["http_total_equal"] == len(qs), out
+
+
+def big_match_queries(corpus, n_docs, vocab, min_match, per_kind):
+    """Queries whose match is LARGER than one device page (XGM_MAX_K = 1 024 documents): what rounds 1-3 left to a stand-in or to
+    the CPU matcher.  Returns (plain relevance queries, positional queries), every match counted by the oracle."""
+    plain, positional = [], []
+    cand = (H.gen_term_queries("AND", 60, 2, 1, 12, maxitems=10, seed=131) + H.gen_term_queries("AND", 30, 1, 1, 30, maxitems=10, seed=132) +
+            H.gen_term_queries("OR", 60, 3, 1, 400, maxitems=10, seed=133) + H.gen_term_queries("OR", 30, 5, 1, 3000, maxitems=100, seed=134) +
+            H.gen_sided_queries("AND_MAYBE", 40, 1, 2, 1, 40, maxitems=10, seed=135) + H.gen_sided_queries("AND_NOT", 40, 1, 2, 1, 30, other_lo=20, other_hi=400, maxitems=10, seed=136) +
+            H.gen_sided_queries("FILTER", 40, 1, 1, 1, 12, maxitems=10, seed=137))
+    count = {}
+    for q in cand:
+        m = H.oracle_search(corpus, q["op"], q["terms"], 0, 1, n_required=q.get("n_required", 0))[1].matches
+        if m > min_match and count.get(q["op"], 0) < per_kind:
+            i = len(plain)
+            k, first = [(10, 0), (3, 0), (25, 5), (100, 0), (7, 2)][i % 5]
+            plain.append(dict(q, first=first, maxitems=k, check_at_least=[0, 0, 40, 0, 2000][i % 5]))
+            count[q["op"]] = count.get(q["op"], 0) + 1
+    # phrases of the most frequent terms: thousands of matches
+    import itertools
+    for a, b in itertools.permutations(range(1, 8), 2):
+        for op, window in (("PHRASE", 0), ("PHRASE", 4), ("NEAR", 5)):
+            q = dict(op=op, terms=["t%d" % a, "t%d" % b], first=0, maxitems=10, window=window)
+            m = H.oracle_search(corpus, op, q["terms"], 0, 1, window=window)[1].matches
+            if m > min_match and len(positional) < per_kind * 2:
+                positional.append(dict(q, first=(0, 0, 3)[len(positional) % 3], maxitems=(10, 5, 7)[len(positional) % 3]))
+    return plain, positional
+
+
+def test_byte_compatible_modes_beyond_one_device_page(built, glass):
+    """every mechanism that makes the device byte-compatible with the reference — exact match-count figures (the HTTP
+    `total`), the REPLAY of the reference's own loop, POSITIONAL_REFERENCE — stopped at matches of 1 024 documents.  With
+    xgm_search_all the device hands back EVERY match in docid order: hook on == hook off (docids, weight bits, percentages, all three
+    match-count figures, HTTP total) on queries matching 1 100 to 25 000 of the 30 000 documents, all answered on the device."""
+    d, one, _ = glass
+    corpus = H.Corpus(N_DOCS, VOCAB)
+    plain, positional = big_match_queries(corpus, N_DOCS, VOCAB, 1100, 8)
+    corpus.close()
+    assert len(plain) >= 30 and len(positional) >= 10, (len(plain), len(positional))
+    qf = str(d / "qbig.txt")
+    H.write_queries(qf, plain)
+    out = run_b1("--exact-bounds", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(plain), out
+    assert out["http_total_equal"] == len(plain) and out["replayed"] >= 10, out
+    qf = str(d / "qbigpos.txt")
+    H.write_queries(qf, positional)
+    out = run_b1("--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(positional), out
+    assert out["answered_on_device"] == len(positional), out

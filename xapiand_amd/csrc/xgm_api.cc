@@ -74,6 +74,7 @@ struct XgmScratch {
     void* h_sorted = nullptr; size_t cap_hsorted = 0;
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
+    unsigned char* d_all = nullptr; size_t cap_all = 0;         /* xgm_search_all: counter, unordered + ordered match lists, the sort's temporary storage */
     uint32_t* d_arrive = nullptr; size_t cap_arrive = 0;        /* per-query arrival counters of a launch that finishes its queries itself (zero between launches) */
     /* pinned host */
     void* h_up = nullptr; size_t cap_up = 0;
@@ -166,7 +167,7 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
-    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_arrive); hipFree(s->d_sorted);
+    hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_arrive); hipFree(s->d_sorted); hipFree(s->d_all);
     if (s->h_sorted) hipHostFree(s->h_sorted);
     if (s->h_up) hipHostFree(s->h_up);
     if (s->h_down) hipHostFree(s->h_down);
@@ -1346,6 +1347,100 @@ extern "C" int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xg
                                     xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord, uint32_t* hit_collapse_count, xgm_result_hdr* hdr,
                                     uint64_t* collapsed_lower_bound) {
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, -1, nullptr, 0, (int)collapse_slot, collapse_max, hit_collapse_ord, hit_collapse_count, collapsed_lower_bound);
+}
+
+/* ---- every match of a query, in docid order (include/xgm.h: xgm_search_all) -------------------------------------------------
+ * The workgroup kernel (every query shape; it decodes the posting blocks of each stripe: K1 at full size) weighs every matching
+ * document anyway when it runs under a sort; here it also appends each to one list (a wave-aggregated atomic per round), which a
+ * device radix sort on the docid then orders (xgm_all.hip).  One query per call, synchronous. */
+extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr) {
+    if (!idx || !q || !n_matches || !hdr || (cap && !hits)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    *n_matches = 0;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    xgm_query q1 = *q;
+    q1.first = 0; q1.maxitems = 1; q1.check_at_least = 0xFFFFFFFFu;          /* the kernel's own top-k is not used: keep it smallest; positions of every candidate tested */
+    xgm_dev_query dq;
+    uint32_t kq = 0;
+    double mp = 0;
+    BatchPlan bp;
+    if ((rc = plan_batch(idx, &q1, 1, &dq, &kq, &mp, &bp, true))) return rc;
+    if (bp.andw || bp.orw || bp.and_only || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    dq.flags &= ~XGM_QF_POSPRUNE;
+    /* no more documents can match than the tree's own upper bound (the reference's get_termfreq_max, which the planner restates) —
+     * nor than the shard holds, nor than the caller has room for */
+    uint64_t cap_dev = std::min<uint64_t>(cap, idx->hdr.doccount);
+    if (q->est_max) cap_dev = std::min<uint64_t>(cap_dev, q->est_max);
+    const uint32_t n_work = bp.n_work;
+    XgmScratch* sc;
+    if ((rc = scratch_acquire(idx, &sc))) return rc;
+    struct Release { xgm_index* i; XgmScratch* s; ~Release() { scratch_release(i, s); } } release_{idx, sc};
+    hipStream_t stream = sc->stream;
+    /* the sorted kernel's own buffers: [query | work list] up, [unit headers | unit candidates (k = 1)] */
+    const size_t o_q = 0, b_q = (sizeof dq + 15) & ~(size_t)15;
+    const size_t o_wk = o_q + b_q, b_wk = ((size_t)n_work * sizeof(xgm_work) + 15) & ~(size_t)15;
+    const size_t up_bytes = o_wk + b_wk;
+    const size_t o_gh = up_bytes, b_gh = (size_t)n_work * sizeof(xgm_group_hdr);
+    const size_t o_cd = o_gh + b_gh, b_cd = (size_t)n_work * sizeof(xgm_cand_sorted);
+    const size_t total = o_cd + b_cd;
+    if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
+    if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total + 16))) return rc;
+    /* the list: [counter 16 B | keys | keys' | weights | weights' | hits | sort temporary] */
+    const size_t tmp_bytes = xgm_all_sort_temp_bytes((size_t)cap_dev);
+    if (tmp_bytes == 0) return xgm_set_error(XGM_E_DEVICE, "radix sort: no temporary storage size");
+    const size_t a_cnt = 0, a_k0 = 16, a_k1 = a_k0 + cap_dev * 8, a_v0 = a_k1 + cap_dev * 8, a_v1 = a_v0 + cap_dev * 8, a_hit = a_v1 + cap_dev * 8;
+    const size_t a_tmp = (a_hit + cap_dev * sizeof(xgm_hit) + 255) & ~(size_t)255, a_total = a_tmp + tmp_bytes;
+    if ((rc = grow(&sc->d_all, &sc->cap_all, a_total))) return rc;
+    unsigned char* hb = (unsigned char*)sc->h_sorted;
+    memcpy(hb + o_q, &dq, sizeof dq);
+    memcpy(hb + o_wk, bp.work.data(), (size_t)n_work * sizeof(xgm_work));
+    HIP_TRY(hipMemcpyAsync(sc->d_sorted, hb, up_bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(sc->d_all + a_cnt, 0, 16, stream));
+    xgm_match_launch L;
+    L.seg = idx->view;
+    L.queries = (xgm_dev_query*)(sc->d_sorted + o_q);
+    L.nq = 1; L.n_work = n_work; L.work = (xgm_work*)(sc->d_sorted + o_wk); L.stripes_per_group = bp.stripes_per_group;
+    L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = 1;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
+    L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
+    unsigned long long* d_cnt = (unsigned long long*)(sc->d_all + a_cnt);
+    unsigned long long* k0 = (unsigned long long*)(sc->d_all + a_k0), *k1 = (unsigned long long*)(sc->d_all + a_k1);
+    unsigned long long* v0 = (unsigned long long*)(sc->d_all + a_v0), *v1 = (unsigned long long*)(sc->d_all + a_v1);
+    idx->last_kernel = "xgm_match_sorted_kernel";
+    if ((rc = xgm_launch_match_sorted(L, nullptr, 4u, 0u, nullptr, nullptr, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream, k0, v0, d_cnt, cap_dev))) return rc;
+    unsigned long long* h_cnt = (unsigned long long*)(hb + total);
+    HIP_TRY(hipMemcpyAsync(hb + o_gh, sc->d_sorted + o_gh, b_gh, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const uint64_t n = *h_cnt;
+    /* the whole match's count and best weight from the unit headers (the same fields xgm_search_sorted reports) */
+    const xgm_group_hdr* gh = (const xgm_group_hdr*)(hb + o_gh);
+    uint64_t matches = 0, max_w = 0;
+    uint32_t max_d = UINT32_MAX, max_m = 0;
+    for (uint32_t u = 0; u < n_work; ++u) {
+        const xgm_group_hdr& g = gh[u];
+        matches += g.matches;
+        if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
+    }
+    if (matches != n) return xgm_set_error(XGM_E_DEVICE, "xgm_search_all: %llu documents listed, %llu counted", (unsigned long long)n, (unsigned long long)matches);
+    memset(hdr, 0, sizeof *hdr);
+    hdr->matches_exact = n;
+    hdr->max_possible = q->max_possible;
+    if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
+    *n_matches = n;
+    if (n > cap_dev) {
+        if (n > cap) return XGM_OK;                                /* the caller's buffer is too small: nothing written, *n_matches says how many there are */
+        return xgm_set_error(XGM_E_DEVICE, "xgm_search_all: %llu matches exceed the plan's upper bound %u", (unsigned long long)n, q->est_max);
+    }
+    if (n == 0) return XGM_OK;
+    xgm_hit* d_out = (xgm_hit*)(sc->d_all + a_hit);
+    if ((rc = xgm_all_sort_pack(sc->d_all + a_tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, d_out, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(hits, d_out, (size_t)n * sizeof(xgm_hit), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    hdr->n_hits = (uint32_t)n;
+    return XGM_OK;
 }
 
 /* ---- opt-in micro-batching (server mode) -----------------------------------------------------------------------------

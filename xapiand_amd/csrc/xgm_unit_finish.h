@@ -6,9 +6,13 @@
  *
  * Visibility between units without flushing the L2: a release fence at agent scope costs an L2 write-back per unit on this part
  * (measured: the conjunction kernel 0.35 -> 1.43 ms with one per unit), so the lists and headers are written THROUGH
- * (agent-scope atomic stores, 8 bytes each), the wave waits for their acknowledgement (workgroup-scope release = s_waitcnt), then
- * lane 0 bumps the counter (agent-scope atomic); the last unit reads the others' lists with agent-scope atomic loads.  Measured cost
- * of the write-through stores + the arrival: none (0.351-0.368 vs 0.351-0.364 ms).
+ * (agent-scope atomic stores, 8 bytes each, `global_store ... sc1`), the wave waits for their acknowledgement with an EXPLICIT
+ * `s_waitcnt vmcnt(0)` (a workgroup-scope release fence alone emits no vmcnt wait on gfx950 outside tgsplit mode — ADVICE r3: the
+ * counter and the lists live in different L2 channels, the counter could become visible first), then lane 0 bumps the counter
+ * (agent-scope atomic); the last unit reads the others' lists with agent-scope atomic loads (`sc1`), which the compiler may not hoist
+ * above the counter read (acquire fence at workgroup scope = a compiler barrier, no cache invalidate).  tools/isa_contract.py checks
+ * the ISA of every instantiation for exactly this sequence, so a compiler upgrade cannot silently drop it.  Measured cost of the
+ * write-through stores + the arrival: none (0.351-0.368 vs 0.351-0.364 ms).
  */
 #ifndef XGM_UNIT_FINISH_H
 #define XGM_UNIT_FINISH_H
@@ -45,11 +49,13 @@ __device__ __forceinline__ void xgm_unit_arrive(const xgm_fuse& F, uint32_t qi, 
                                                 uint8_t* tk_m, uint32_t tk_cap, const xgm_cand* cand_all, const xgm_group_hdr* ghdr_all,
                                                 uint32_t k_stride, uint32_t lane, SortFn sort) {
     qi = rfl32(qi);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         /* the write-through stores of this wave have been acknowledged */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         /* compiler: nothing of the unit's list moves below this point */
+    xgm_wait_vmem();                                               /* hardware: every write-through store of this wave has been acknowledged */
     __builtin_amdgcn_wave_barrier();
     uint32_t old = 0;
     if (lane == 0) old = __hip_atomic_fetch_add(&F.arrive[qi], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     old = rfl32(old);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");         /* compiler: no list load moves above the counter read */
     const uint32_t g0 = F.goff[qi], U = F.goff[qi + 1] - g0;
     if (old + 1u != U) return;
     /* ---- the query's last unit: every list is in memory ---- */

@@ -52,6 +52,10 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
+/* s_waitcnt vmcnt(0) (gfx9 encoding: vmcnt = simm16[15:14|3:0], expcnt [6:4] and lgkmcnt [11:8] left at their maxima): every
+ * vector-memory operation this wave has issued — write-through stores included — has been acknowledged by its coherence point. */
+__device__ __forceinline__ void xgm_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 /* First index in [lo, hi) with arr[i] >= key (hi if none); 64-ary search, result wave-uniform. */
 __device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ arr, uint32_t lo, uint32_t hi, uint32_t key,
                                      uint32_t lane) {

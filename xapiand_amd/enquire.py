@@ -437,6 +437,20 @@ def search_collapsed(db, planned, collapse_slot, collapse_max, sort_by=None, slo
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i], cords[i], ccounts[i]) for i in range(hdr.n_hits)], hdr, clb.value
 
 
+def search_all(db, planned, cap=None):
+    """xgm_search_all: EVERY matching document of one planned query in ascending docid order — the sequence the reference's matcher
+    loop is shown (matcher.cc:482-536).  Returns ([(docid, weight, subqs)], hdr); cap defaults to the plan's own upper bound."""
+    if cap is None:
+        cap = max(1, planned.est_max or db.get_doccount())
+    hits = (_lib.Hit * max(1, cap))()
+    hdr = _lib.ResultHdr()
+    n = C.c_uint64()
+    _lib.check(_lib.lib().xgm_search_all(db._h, C.byref(planned), hits, cap, C.byref(n), C.byref(hdr)))
+    if n.value > cap:
+        return None, hdr                      # (the room needed is hdr.matches_exact)
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(n.value)], hdr
+
+
 def search_batch(db, plans):
     """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
     nq = len(plans)
