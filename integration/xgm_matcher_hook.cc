@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -39,6 +40,7 @@ std::map<std::string, Shard> g_shards;
 std::map<std::string, std::shared_ptr<const SpyAdapter>> g_spy_adapters;      /* (shared: a search keeps its adapter although the name is registered again meanwhile) */
 std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false}, g_replay{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
+std::atomic<uint32_t> g_column_limit{50u * 1000u * 1000u};     /* documents per shard up to which a column is built on the search thread */
 std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0};
 
 struct Lowered {
@@ -284,38 +286,47 @@ bool lower(const Xapian::Query& q, Lowered* L) {
 
 namespace {
 
-/* The column of `key` for this shard revision: built on first use from one string per document (`fill`), attached to the index
- * under a synthetic slot number, kept with its distinct strings (ordinal o > 0 stands for values[o - 1]; 0 = no value / empty key). */
-template <class Fill>
-std::shared_ptr<Column> ensure_column(const Shard& sh, const Xapian::Database& db, const std::string& key, Fill fill) {
+/* The column of `key` for this shard revision: built on first use, attached to the index under a synthetic slot number, kept with its
+ * distinct strings (ordinal o > 0 stands for values[o - 1]; 0 = no value / empty key).  `walk(emit)` calls emit(docid, string) for every
+ * document that has one, and is run TWICE — first to collect the distinct strings, then to assign ordinals — so that nothing is held
+ * per document but its 4-byte ordinal (one std::string per document of a large shard was gigabytes of host memory).  The
+ * build holds the shard's column mutex: other sorted / spied / collapsed searches of that shard wait for it once per (revision, key);
+ * shards beyond set_column_build_limit() documents are declined instead, and a build that failed is remembered (a negative entry) so
+ * that later searches decline at once instead of rebuilding. */
+template <class Walk>
+std::shared_ptr<Column> ensure_column(const Shard& sh, const Xapian::Database& db, const std::string& key, Walk walk) {
     ShardColumns& sc = *sh.cols;
     std::lock_guard<std::mutex> lk(sc.mu);
     auto it = sc.by_key.find(key);
-    if (it != sc.by_key.end()) return it->second;
+    if (it != sc.by_key.end()) return it->second;                /* (nullptr: a remembered failure) */
     const Xapian::docid last = db.get_lastdocid();
-    std::vector<std::string> per(size_t(last) + 1);
-    fill(per);
+    if (last > g_column_limit.load(std::memory_order_relaxed)) return nullptr;      /* not cached: the limit may be raised */
     auto col = std::make_shared<Column>();
-    col->values.reserve(per.size() / 4 + 1);
-    for (const std::string& v : per) if (!v.empty()) col->values.push_back(v);
-    std::sort(col->values.begin(), col->values.end());
-    col->values.erase(std::unique(col->values.begin(), col->values.end()), col->values.end());
-    col->values.shrink_to_fit();
-    std::vector<uint32_t> ord(per.size(), 0u);
-    for (size_t d = 1; d < per.size(); ++d)
-        if (!per[d].empty()) ord[d] = uint32_t(std::lower_bound(col->values.begin(), col->values.end(), per[d]) - col->values.begin()) + 1u;
-    col->slot_id = sc.next_slot++;
-    const int rc = xgm_index_attach_column_ordinals(sh.idx, col->slot_id, ord.data(), (uint32_t)ord.size(), (uint32_t)col->values.size());
-    if (rc != XGM_OK) return nullptr;
+    try {
+        walk([&](Xapian::docid, const std::string& v) { if (!v.empty()) col->values.push_back(v); });
+        std::sort(col->values.begin(), col->values.end());
+        col->values.erase(std::unique(col->values.begin(), col->values.end()), col->values.end());
+        col->values.shrink_to_fit();
+        std::vector<uint32_t> ord(size_t(last) + 1, 0u);
+        walk([&](Xapian::docid did, const std::string& v) {
+            if (!v.empty() && did <= last) ord[did] = uint32_t(std::lower_bound(col->values.begin(), col->values.end(), v) - col->values.begin()) + 1u;
+        });
+        col->slot_id = sc.next_slot++;
+        if (xgm_index_attach_column_ordinals(sh.idx, col->slot_id, ord.data(), (uint32_t)ord.size(), (uint32_t)col->values.size()) != XGM_OK) col.reset();
+    } catch (const Xapian::Error&) {
+        col.reset();
+    } catch (const std::bad_alloc&) {
+        col.reset();
+    }
     sc.by_key.emplace(key, col);
-    ++g_columns;
+    if (col) ++g_columns;
     return col;
 }
 
 /* value slot → column, through the shard's value stream (ValueIterator walks the slot's chunks in docid order) */
 std::shared_ptr<Column> value_column(const Shard& sh, const Xapian::Database& db, Xapian::valueno slot) {
-    return ensure_column(sh, db, "v" + std::to_string(slot), [&](std::vector<std::string>& per) {
-        for (Xapian::ValueIterator it = db.valuestream_begin(slot); it != db.valuestream_end(slot); ++it) per[it.get_docid()] = *it;
+    return ensure_column(sh, db, "v" + std::to_string(slot), [&](const std::function<void(Xapian::docid, const std::string&)>& emit) {
+        for (Xapian::ValueIterator it = db.valuestream_begin(slot); it != db.valuestream_end(slot); ++it) emit(it.get_docid(), *it);
     });
 }
 
@@ -331,9 +342,8 @@ std::shared_ptr<Column> key_column(const Shard& sh, const Xapian::Database& db, 
         return nullptr;
     }
     if (key.size() == 2) return nullptr;                       /* no name, no serialisation: nothing to recognise it by */
-    return ensure_column(sh, db, key, [&](std::vector<std::string>& per) {
-        for (Xapian::PostingIterator p = db.postlist_begin(std::string()); p != db.postlist_end(std::string()); ++p)
-            per[*p] = sorter(db.get_document(*p));
+    return ensure_column(sh, db, key, [&](const std::function<void(Xapian::docid, const std::string&)>& emit) {
+        for (Xapian::PostingIterator p = db.postlist_begin(std::string()); p != db.postlist_end(std::string()); ++p) emit(*p, sorter(db.get_document(*p)));
     });
 }
 
@@ -495,6 +505,7 @@ void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
 void set_exact_bounds(bool on) { g_exact_bounds.store(on); }
 void set_near_colocated_terms(bool may_exist) { g_near_colocated.store(may_exist); }
 void set_replay(bool on) { g_replay.store(on); }
+void set_column_build_limit(uint32_t max_documents) { g_column_limit.store(max_documents); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_spy_adapters[spy_class_name] = std::make_shared<const SpyAdapter>(std::move(adapter));

@@ -67,9 +67,9 @@ void set_enabled(bool on);                 /* default: on */
  * the intended top-k.  The choice is the deployment's and has to be made:
  *   POSITIONAL_DECLINE   — positional queries stay on the CPU matcher (byte-compatible by construction);
  *   POSITIONAL_INTENDED  — answered on the device with the intended semantics;
- *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the whole match is fetched (it must fit
- *     one device page, XGM_MAX_K documents; else the search is left to the CPU matcher) and the reference's loop is replayed on the
- *     host in docid order — true weights until ProtoMSet's min_weight turns positive, then the FROZEN weight: that of the first
+ *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the whole match is fetched in docid order
+ *     (xgm_search_all: any size; phrases of more than 3 terms are left to the CPU matcher) and the reference's loop is replayed on the
+ *     host — true weights until ProtoMSet's min_weight turns positive, then the FROZEN weight: that of the first
  *     document of the underlying conjunction after that point (vet() weighs before test_doc(); found with the shard's own posting
  *     lists, a few skip_to's), served for every later match and compared against min_weight to skip the rest.
  * Until set_positional_mode has been called positional queries are declined. */
@@ -96,12 +96,18 @@ void set_collapse_mode(CollapseMode m);
  * are the same whether the loop walks the tree or the plain list of ALL matching documents in docid order with their weights.  So for
  * a search the device path cannot answer with the reference's exact semantics (COLLAPSE_REFERENCE: the snapshot's collapser, bugs and
  * all; with set_replay(true) also percentage / weight cut-offs and spies by relevance whose match exceeds check_at_least) the hook
- * fetches the whole match from the device — it has to fit one device page, XGM_MAX_K documents; else the search stays on the CPU —
- * and hands Matcher::get_local_mset a PostList that replays it (the second hunk of matcher_hook.patch): ProtoMSet, Collapser,
+ * fetches the whole match from the device in docid order (xgm_search_all: a match of ANY size since round 4; rounds 1-3 stopped at
+ * one device page of XGM_MAX_K documents) and hands Matcher::get_local_mset a PostList that replays it (the second hunk of matcher_hook.patch): ProtoMSet, Collapser,
  * SpyMaster, the sorter run natively on it.  Static figures (termfreq bounds, max weight) are taken from the tree it replaces.
  * Not for positional queries unless POSITIONAL_INTENDED (the frozen weight lives in the tree), nor with a MatchDecider (its
  * counters see the tree's traversal). */
 void set_replay(bool on);                  /* default: off */
+/* Columns (value slots, KeyMaker keys) are built on the first sorted / spied / collapsed search of a shard revision, on that search's
+ * thread, under the shard's column mutex (two passes over the value stream; 4 bytes per document + the distinct strings).  Shards
+ * with more documents than this are declined (CPU matcher) instead of stalling their searches behind the scan; a server that wants
+ * them on the device builds the columns when it registers the shard (run one sorted search then) and raises the limit.  A build that
+ * fails is remembered: later searches decline at once.  Default: 50 000 000. */
+void set_column_build_limit(uint32_t max_documents);
 Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapian::Query& query, Xapian::Internal::PostList* pl);
 
 /* MSet::get_matches_lower_bound / _estimated by relevance.  The reference derives them from known_matching_docs — how many
@@ -110,9 +116,10 @@ Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapia
  * match whatever min_weight is (a term, AND, FILTER, AND_NOT, PHRASE, NEAR: MultiAndPostList / SelectPostList / AndNotPostList
  * ignore w_min) that number is a function of the match in docid order (xgm_known_matching_docs); OR and AND_MAYBE skip
  * documents by weight inside the posting-list tree (orpostlist.cc:35-204), there it is a property of the traversal.
- * With exact bounds ON the hook, for a full page of those operators whose match is at most XGM_MAX_K documents, fetches the whole
- * match in a second device search and reports the reference's own figures; otherwise (and when OFF, the default) the number of
- * documents returned stands in (valid bounds, possibly looser). */
+ * With exact bounds ON the hook, for a full page, fetches the whole match — of any size — in docid order with a second device search
+ * (xgm_search_all) and reports the reference's own figures: through xgm_known_matching_docs for those operators, through the replay
+ * of the reference's loop (set_replay's mechanism) for OR / AND_MAYBE / trees; when OFF (the default) the number of documents returned
+ * stands in (valid bounds, possibly looser). */
 void set_exact_bounds(bool on);
 
 /* A MatchSpy class the hook does not know natively: the server tells it which value slot the spy counts and how to hand it the

@@ -719,7 +719,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* ... per PART: a query whose units exceed one merge's capacity is merged in up to kMaxParts groups and the groups' lists once more
      * (xgm_merge_parts), so that the heaviest conjunctions — frequent-term phrases whose every document is a candidate — can be cut
      * down to single stripes: the launch ends with its longest unit (measured: C5's kernel ran at 20 % mean occupancy behind them) */
-    static const uint32_t kMaxParts = getenv("XGM_MAX_PARTS") ? (uint32_t)std::max(1, atoi(getenv("XGM_MAX_PARTS"))) : 4u;      /* A/B switch */
+    static const uint32_t kMaxParts = getenv("XGM_MAX_PARTS") ? (uint32_t)std::min(8, std::max(1, atoi(getenv("XGM_MAX_PARTS")))) : 4u;      /* A/B switch (<= 8: the parts' merge sorts parts x k in LDS) */
     const uint32_t units_per_part = std::max(1u, merge_budget / (units_by_kpad ? k_pad : std::max(1u, bp->k_max)));
     const uint32_t parts_ok = (bp->andw && nq > 4u) ? kMaxParts : 1u;
     uint32_t g_max = std::max(g_min, std::min(n_stripes, units_per_part * parts_ok));
@@ -903,9 +903,16 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         xgm_fuse fu;
         memset(&fu, 0, sizeof fu);
         if (fused) {
-            if (s->cap_arrive < nq) {
-                if ((rc = grow(&s->d_arrive, &s->cap_arrive, (size_t)std::max<uint32_t>(nq, 1024u)))) return rc;
-                HIP_TRY(hipMemsetAsync(s->d_arrive, 0, s->cap_arrive * sizeof(uint32_t), stream));      /* once: every launch leaves the counters at zero */
+            if ((rc = grow(&s->d_arrive, &s->cap_arrive, (size_t)std::max<uint32_t>(nq, 1024u)))) return rc;
+            /* every launch leaves its counters at zero — unless it failed or was aborted: 4 bytes per query are cheaper
+             * than trusting that, and the memset orders behind the previous launch on the same stream */
+            HIP_TRY(hipMemsetAsync(s->d_arrive, 0, (size_t)nq * sizeof(uint32_t), stream));
+            /* stress-test switch (tests/test_gpu_stress.py): wipe the units' lists and headers of the previous batch, so that a unit
+             * read before it landed shows as missing hits instead of passing for plausible stale ones */
+            static const bool poison = getenv("XGM_DEBUG_POISON_SCRATCH") != nullptr;
+            if (poison) {
+                HIP_TRY(hipMemsetAsync(s->d_cand, 0, (size_t)bp.n_work * bp.k_stride_c * sizeof(xgm_cand), stream));
+                HIP_TRY(hipMemsetAsync(s->d_ghdr, 0, (size_t)bp.n_work * sizeof(xgm_group_hdr), stream));
             }
             fu.arrive = s->d_arrive; fu.goff = (const uint32_t*)(din_ + o_go); fu.max_possible = (const double*)(din_ + o_mp);
             fu.row_of = rows ? (const uint32_t*)(din_ + o_ro) : nullptr;

@@ -113,10 +113,16 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
     if (tid == 0 && wmax_s) atomicMax(&wdf_max[d], wmax_s);            /* the term's true largest wdf: the disjunction's pruning bound */
 }
 
+/* *misfit is raised when a length does not fit T above the base (a header whose bounds do not cover its own lengths): the narrow
+ * array is then not used — a truncated length would change BM25 weights silently */
 template <typename T>
-__global__ void k_narrow_doclen(const uint32_t* __restrict__ doclen, uint32_t n, uint32_t base, T* __restrict__ out) {
+__global__ void k_narrow_doclen(const uint32_t* __restrict__ doclen, uint32_t n, uint32_t base, T* __restrict__ out, uint32_t* __restrict__ misfit) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t v = doclen[i]; out[i] = (T)(v >= base ? v - base : 0u); }      /* (entry 0 and deleted documents hold 0) */
+    if (i < n) {
+        const uint32_t v = doclen[i], off = v >= base ? v - base : 0u;                         /* (entry 0 and deleted documents hold 0) */
+        if ((v != 0u && v < base) || off > (uint32_t)(T)~(T)0) atomicOr(misfit, 1u);
+        out[i] = (T)off;
+    }
 }
 
 }  // namespace
@@ -128,11 +134,20 @@ static int build_narrow_doclen(xgm_index* idx) {
     const uint32_t lb = idx->hdr.doclen_lower_bound, ub = idx->hdr.doclen_upper_bound, n = idx->hdr.lastdocid + 1u;
     if (ub < lb || ub - lb >= 65536u) return XGM_OK;
     const uint32_t bits = ub - lb < 256u ? 8u : 16u;
+    if (idx->d_doclen_narrow) {                              /* a second xgm_build_dense on the same index: the old array goes first */
+        hipFree(idx->d_doclen_narrow);
+        idx->d_doclen_narrow = nullptr;
+    }
     void* d = nullptr;
-    if (hipMalloc(&d, (size_t)n * (bits / 8u) + 64) != hipSuccess) return xgm_set_error(XGM_E_NOMEM, "narrow document lengths: out of device memory");
-    if (bits == 8u) hipLaunchKernelGGL(k_narrow_doclen<uint8_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint8_t*)d);
-    else hipLaunchKernelGGL(k_narrow_doclen<uint16_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint16_t*)d);
-    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { hipFree(d); return xgm_set_error(XGM_E_DEVICE, "narrow document lengths: kernel failed"); }
+    const size_t arr = ((size_t)n * (bits / 8u) + 64 + 15) & ~(size_t)15;
+    if (hipMalloc(&d, arr + 16) != hipSuccess) return xgm_set_error(XGM_E_NOMEM, "narrow document lengths: out of device memory");
+    uint32_t* d_misfit = reinterpret_cast<uint32_t*>((unsigned char*)d + arr);
+    uint32_t misfit = 0;
+    if (hipMemset(d_misfit, 0, 16) != hipSuccess) { hipFree(d); return xgm_set_error(XGM_E_DEVICE, "narrow document lengths: memset failed"); }
+    if (bits == 8u) hipLaunchKernelGGL(k_narrow_doclen<uint8_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint8_t*)d, d_misfit);
+    else hipLaunchKernelGGL(k_narrow_doclen<uint16_t>, dim3((n + 255u) / 256u), dim3(256), 0, 0, idx->view.doclen, n, lb, (uint16_t*)d, d_misfit);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(&misfit, d_misfit, 4, hipMemcpyDeviceToHost) != hipSuccess) { hipFree(d); return xgm_set_error(XGM_E_DEVICE, "narrow document lengths: kernel failed"); }
+    if (misfit) { hipFree(d); return XGM_OK; }               /* the header's bounds do not hold: every kernel reads the u32 lengths */
     idx->d_doclen_narrow = d;
     idx->view.doclen_narrow = (const unsigned char*)d;
     idx->view.doclen_narrow_bits = bits;
