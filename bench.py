@@ -8,10 +8,13 @@ itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --ma
 the driver uses directly), so both invocations work.
 
 Workload (N = 1, BASELINE.json configs[1], "C2"): 10 M-doc / 1 M-term Zipf synthetic index resident in HBM,
-3-term conjunctive BM25 queries, top-10.  One "step" = one pass of the hot path over one batch of 256 queries
-AS THE MATCHER HOOK RECEIVES THEM (terms, operator, first/maxitems, BM25 parameters, merged statistics):
-xgm_get_mset_batch_device = dictionary lookups + BM25Weight::init + leaf ordering (xgm_plan_query) → decode →
-intersect → BM25 → top-k → merge.  N > 1 is configs[3] scaled ("C4"): the corpus has 10 M × N documents sharded
+3-term conjunctive BM25 queries, top-10.  One "step" = one pass of the hot path over --batches-per-step (16) batches of
+256 queries each (4 096 queries; 20 steps ≈ 130 ms of GPU work) AS THE MATCHER HOOK RECEIVES THEM (terms, operator,
+first/maxitems, BM25 parameters, merged statistics): xgm_get_mset_batch_begin = dictionary lookups + BM25Weight::init +
+leaf ordering (xgm_plan_query) → decode → intersect → BM25 → top-k → merge → the hits and headers of EVERY batch copied
+to pinned HOST memory (xgm_batch_end hands them out); up to three batches are in flight, so planning, match and
+download overlap (round 4: rounds 1-3 left the results in HBM).  The default run also times C3 (5-term OR, top-100) and
+C5 (2-3-term PHRASE, top-10) the same way (`other_configs`), each checked against the oracle on 128 queries.  N > 1 is configs[3] scaled ("C4"): the corpus has 10 M × N documents sharded
 N ways exactly like the reference (global doc g → shard (g-1) % N, src/xapian/backends/multi.h:38-73), every rank
 searches its shard with the MERGED collection statistics, then one RCCL all-gather of the per-shard top-k records
 + a device-side merge (xgm_merge_shards_device).  Weak scaling: per-GPU work is fixed.
@@ -52,8 +55,13 @@ BATCH = 256
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batches-per-step", type=int, default=16, help="batches of 256 queries one step submits")
+    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (xgm_get_mset_batch_begin ... xgm_batch_end)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 sub-legs of the default (C2) line")
+    ap.add_argument("--no-hook-parity", action="store_true", help="skip the hook-on == hook-off leg on the reference's own glass index")
+    ap.add_argument("--hook-pos-docs", type=int, default=2_000_000, help="documents of the glass index WITH positions the C5 hook-parity leg builds (0: skip)")
     ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--op", default="AND")
@@ -64,8 +72,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--ref-docs", type=int, default=-1, help="documents of the reference glass index built on this box (0: skip the reference leg; "
-                    "default: 1/5 of the configuration's documents — indexing 10 M documents through the reference's WritableDatabase takes "
-                    "~3.5 min even on 128 cores; `--ref-docs 10000000` reproduces profiles/r02_reference_full.json)")
+                    "default: the configuration's own size for the headline workload — indexing 10 M documents through the reference's "
+                    "WritableDatabase takes ~3.5 min on the 256-core host —, 1/5 of it for the other operators)")
     ap.add_argument("--no-latency", action="store_true", help="skip the one-query-in-flight leg (profiling runs)")
     ap.add_argument("--threads", type=int, default=64, help="server leg: T host threads, each with one xgm_get_mset_batch(nq=1) in flight (0: skip)")
     return ap.parse_args()
@@ -94,17 +102,306 @@ def workload_name(args, world, n_docs_global, k):
     return "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (cfg, args.docs_per_gpu // 1000000, args.vocab // 1000000, shape, k)
 
 
+class Leg:
+    """One workload on the resident index: its query pool as the hook would receive it, cut into batches."""
+
+    def __init__(self, searcher, op, terms, required, k, n_docs_global, vocab, n_batches):
+        import helpers as H
+        from xapiand_amd import Query, _lib
+        self.op, self.terms, self.required, self.k = op, terms, required, k
+        self.sided = op in ("AND_NOT", "AND_MAYBE", "FILTER")
+        self.pool = H.bench_pool(op, terms, required, n_docs_global, vocab, n=100 + n_batches * BATCH, seed=QUERY_SEED, maxitems=k)
+        qobjs = [Query(q["op"], q["terms"], n_required=required if self.sided else 0) for q in self.pool]
+        self.descs, self.gstats = searcher.describe(qobjs, 0, k)       # what the hook is handed per get_mset
+        self.plans = searcher.prepare(qobjs, 0, k)                     # bookkeeping only (algorithmic bytes, parity leg)
+        self._keep = searcher._keep                                   # (the descriptions' term bytes)
+        n = len(self.pool)
+
+        def batch_of(lo):
+            d = (_lib.QueryDesc * BATCH)(*[self.descs[(lo + i) % n] for i in range(BATCH)])
+            g = (_lib.GlobalStats * BATCH)(*[self.gstats[(lo + i) % n] for i in range(BATCH)])
+            return d, g
+        self.batches = [batch_of(100 + b * BATCH) for b in range(n_batches)]
+        self.warm = batch_of(0)
+        self.timed_plans = self.plans[100:]
+        self.timed_pool = self.pool[100:]
+
+
+def run_steps(db, searcher, leg, steps, bps, depth, world, keep_last=False):
+    """`steps` steps of `bps` batches each.  N = 1: through xgm_get_mset_batch_begin / xgm_batch_end with up to `depth` batches in flight,
+    every batch's hits and headers delivered to pinned host memory and touched there.  N > 1: the sharded protocol per batch
+    (ShardedSearcher.run_descs: search, RCCL all-gather, device merge) and an asynchronous copy of the merged result to pinned host
+    memory, double-buffered.  Returns (host seconds spent inside the calls, rows delivered, bytes of the last batch on the host)."""
+    import collections
+    import torch
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    k, nb = leg.k, len(leg.batches)
+    host_s, delivered, last = 0.0, 0, None
+    if world == 1:
+        inflight = collections.deque()
+        hp, dp = C.POINTER(_lib.Hit)(), C.POINTER(_lib.ResultHdr)()
+
+        def finish(f, keep):
+            _lib.check(L.xgm_batch_end(f, C.byref(hp), C.byref(dp)))
+            n = dp[0].n_hits + dp[BATCH - 1].n_hits                   # the rows are host memory: read them
+            snap = None
+            if keep:
+                snap = (C.string_at(hp, BATCH * k * 16), C.string_at(dp, BATCH * 32))
+            L.xgm_batch_release(f)
+            return n, snap
+        for s in range(steps):
+            for j in range(bps):
+                d, g = leg.batches[(s * bps + j) % nb]
+                h0 = time.perf_counter()
+                f = C.c_void_p()
+                _lib.check(L.xgm_get_mset_batch_begin(db._h, d, g, BATCH, k, C.byref(f)))
+                host_s += time.perf_counter() - h0
+                inflight.append(f)
+                if len(inflight) >= depth:
+                    delivered += finish(inflight.popleft(), False)[0]
+        while inflight:
+            n, snap = finish(inflight.popleft(), keep_last and len(inflight) == 0)
+            delivered += n
+            last = snap or last
+        return host_s, delivered, last
+    # sharded: results of batch i on the host while batch i + 1 runs
+    slots = getattr(searcher, "_host_slots", None)
+    if slots is None:
+        slots = searcher._host_slots = [dict(hits=torch.empty((BATCH, k, 2), dtype=torch.float64).pin_memory(), hdrs=torch.empty((BATCH, 4), dtype=torch.float64).pin_memory(),
+                                             ev=torch.cuda.Event()) for _ in range(2)]
+    pending = [False, False]
+    i = 0
+    for s in range(steps):
+        for j in range(bps):
+            d, g = leg.batches[(s * bps + j) % nb]
+            sl = slots[i & 1]
+            if pending[i & 1]:
+                sl["ev"].synchronize()
+                delivered += int(sl["hdrs"][0, 0].item() != -1.0)
+            h0 = time.perf_counter()
+            oh, od = searcher.run_descs(d, g, BATCH, k)
+            sl["hits"].copy_(oh, non_blocking=True)
+            sl["hdrs"].copy_(od, non_blocking=True)
+            sl["ev"].record()
+            host_s += time.perf_counter() - h0
+            pending[i & 1] = True
+            i += 1
+    for b in range(2):
+        if pending[b]:
+            slots[b]["ev"].synchronize()
+    return host_s, delivered, None
+
+
+def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
+    """Timed region + per-launch byte counts of one workload.  Returns a dict (rank 0 uses it; every rank takes part in the collectives)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    k, bps, depth = leg.k, args.batches_per_step, max(1, args.in_flight)
+    bind_one_stream = os.environ.get("XGM_BENCH_ONE_STREAM") is not None
+    if world == 1:
+        db.set_stream(torch.cuda.current_stream(dev).cuda_stream if bind_one_stream else 0)
+    run_steps(db, searcher, leg, warmup, bps, depth, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    db.set_profiling(1)
+    L.xgm_debug_host_ns((C.c_uint64 * 8)())           # reset the host-side section timers
+    t0 = time.perf_counter()
+    host_s, delivered, last = run_steps(db, searcher, leg, steps, bps, depth, world, keep_last=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    hn = (C.c_uint64 * 8)()
+    L.xgm_debug_host_ns(hn)
+    n_launch = max(1, int(hn[3]))
+    n_batches_run = steps * bps
+    host_sections = {"plan_queries": round(hn[0] / 1e3 / n_batches_run, 1), "plan_batch": round(hn[1] / 1e3 / n_launch, 1),
+                     "stage_enqueue_launch": round(hn[2] / 1e3 / n_launch, 1), "staging_memcpy": round(hn[4] / 1e3 / n_launch, 1),
+                     "upload_enqueue": round(hn[5] / 1e3 / n_launch, 1), "match_launch": round(hn[6] / 1e3 / n_launch, 1),
+                     "merge_launch": round(hn[7] / 1e3 / n_launch, 1), "launches_per_batch": round(n_launch / n_batches_run, 2), "unit": "us per batch"}
+    kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed launches (HIP events on the launch streams)
+    kernel_name = db.last_kernel_name()
+    db.set_profiling(0)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")      # where the small collectives of this script live
+    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    # the last delivered batch against a synchronous search of the same batch: the rows on the host are the answer
+    verified = None
+    if world == 1 and last is not None:
+        d, g = leg.batches[(steps * bps - 1) % len(leg.batches)]
+        hits = (_lib.Hit * (BATCH * k))()
+        hdrs = (_lib.ResultHdr * BATCH)()
+        _lib.check(L.xgm_get_mset_batch(db._h, d, g, BATCH, k, hits, hdrs))
+        verified = bytes(memoryview(hdrs)) == last[1]
+        hb = bytes(memoryview(hits))
+        for q in range(BATCH):
+            n = hdrs[q].n_hits
+            verified = verified and hb[q * k * 16:(q * k + n) * 16] == last[0][q * k * 16:(q * k + n) * 16]
+    # ---- kernel duration WITHOUT a neighbour: one batch in flight (the timed region overlaps consecutive batches on the chip) ----
+    kernel_ms_solo = None
+    if world == 1 and depth > 1:
+        db.set_profiling(1)
+        run_steps(db, searcher, leg, max(1, min(4, steps)), bps, 1, world)
+        torch.cuda.synchronize()
+        kernel_ms_solo = db.last_kernel_ms()
+        db.set_profiling(0)
+
+    # ---- per-launch byte counts, outside the timed region ------------------------------------------------------
+    # algorithmic (SURVEY.md §8(d)): Σ_t df_t·8 + S·4 + P·4 + k·16 per query; model: the kernel's own request tallies
+    db.set_profiling(0 if os.environ.get("XGM_BENCH_NO_TALLY") else 2)   # the tallying instantiation of the wave kernels
+    if world == 1:
+        db.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    alg_bytes, model_sector, model_useful, tallies = [], [], [], []
+    for b in range(min(len(leg.batches), 4)):
+        searcher.run_descs(leg.batches[b][0], leg.batches[b][1], BATCH, k)
+        torch.cuda.synchronize()
+        h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
+        matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
+        post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in leg.timed_plans[b * BATCH:(b + 1) * BATCH])
+        tl = (C.c_uint64 * 10)()
+        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_dense_kernel")
+        bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
+        alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
+        if have_tally:
+            stream_b = 4 * bmpw + 4 * blkw + 12 * hdrs_ + 4 * aux + 16 * cands + 4 * npos
+            model_sector.append(stream_b + SECTOR * (probes + dls))
+            model_useful.append(stream_b + probes_raw + 4 * dls_raw)
+            tallies.append(dict(bitmap_words=bmpw, probe_sectors=probes, probes=probes_raw, payload_words=blkw, block_headers=hdrs_,
+                                doclen_sectors=dls, doclen_gathers=dls_raw, aux_words=aux, candidates_out=cands, positions=npos))
+    db.set_profiling(0)
+    bytes_per_launch = float(np.mean(alg_bytes))
+    model_bytes = float(np.mean(model_sector)) if model_sector else None
+    useful_bytes = float(np.mean(model_useful)) if model_useful else None
+
+    # ---- HBM traffic of the dominant kernel: from the committed PMC passes (tools/final.sh → profiles/traffic.json),
+    # which cannot be collected from inside this process; only quoted when measured on this very workload AND this very build
+    traffic, traffic_note = None, None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    sha_path = os.path.join(ROOT, "xapiand_amd", "csrc", "libxgm.so.sha")
+    lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None
+    stale_traffic = False
+    if os.path.exists(tpath):
+        for tr in json.load(open(tpath)).get("entries", []):
+            if tr.get("lib_sha") != lib_sha:
+                stale_traffic = True          # counters of another build of the library: not this kernel's traffic
+                continue
+            if (tr["kernel"] == kernel_name and tr["op"] == leg.op and tr["docs_per_gpu"] == args.docs_per_gpu and tr["top_k"] == k and
+                    tr["terms"] == (leg.terms if leg.op != "PHRASE" else 0) and tr["batch"] == BATCH and tr.get("required", 1) == (leg.required if leg.sided else 1)):
+                traffic, traffic_note = tr["hbm_bytes_per_launch"], tr["note"]
+
+    # ---- N > 1: every rank's own match kernel against its own GPU's roofline, with ITS OWN bytes (the shard's own tallies) ------
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([kernel_ms if kernel_ms and kernel_ms > 0 else 0.0, float(model_bytes or bytes_per_launch)], dtype=torch.float64, device=cdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = []
+        for r, v in enumerate(allr):
+            ms, by = float(v[0].item()), float(v[1].item())
+            per_rank.append({"rank": r, "kernel_ms": ms, "bytes_per_launch": by, "basis": "model (this rank's own request tallies)",
+                             "achieved": (by / (ms * 1e-3) / 1e9) if ms > 0 else None, "frac": (by / (ms * 1e-3) / HBM_PEAK) if ms > 0 else None})
+
+    n_queries = steps * bps * BATCH
+    kt = kernel_ms * 1e-3 if kernel_ms and kernel_ms > 0 else None
+    basis = "pmc" if traffic else ("model" if model_bytes else "algorithmic")
+    moved = traffic if traffic else (model_bytes if model_bytes else bytes_per_launch)
+    achieved = moved / kt if kt else 0.0
+    alg_rate = bytes_per_launch / kt if kt else 0.0
+    kts = kernel_ms_solo * 1e-3 if kernel_ms_solo and kernel_ms_solo > 0 else None
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "basis": basis, "traffic": traffic, "traffic_note": traffic_note,
+                "traffic_lib_sha": lib_sha if traffic else None, "traffic_entries_of_another_build_ignored": stale_traffic,
+                "kernel_ms": kernel_ms,
+                "kernel_ms_note": "mean HIP-event duration of the match kernel over the timed region, where up to %d batches are in flight on "
+                                  "streams of their own: consecutive launches overlap on the chip, so this is the duration of a launch that SHARES "
+                                  "the GPU; kernel_ms_one_in_flight is the same kernel alone" % depth if world == 1 else None,
+                "kernel_ms_one_in_flight": kernel_ms_solo,
+                "frac_one_in_flight": (moved / kts / HBM_PEAK) if kts else None,
+                "whole_timed_region": {"bytes": moved * n_batches_run, "seconds": elapsed, "achieved": moved * n_batches_run / elapsed / 1e9,
+                                       "frac": moved * n_batches_run / elapsed / HBM_PEAK,
+                                       "note": "every byte the match launches moved / wall time of the timed region (planning, uploads, downloads, gaps included)"},
+                "model_min_bytes": model_bytes, "model_useful_bytes": useful_bytes,
+                "model_frac": (model_bytes / kt / HBM_PEAK) if (model_bytes and kt) else None,
+                "model_note": "requests tallied by the kernel itself (xgm_last_batch_traffic): streamed words at 4 B + %d B per DISTINCT "
+                              "memory sector a round of one-byte container probes / doclen gathers touches" % SECTOR,
+                "model_counts": tallies[0] if tallies else None,
+                "algorithmic": {"bytes_per_launch": bytes_per_launch, "achieved": alg_rate / 1e9, "frac": alg_rate / HBM_PEAK,
+                                "note": "SURVEY 8(d): sum df*8 + S*4 + P*4 + k*16 per query; not bytes this design reads"}}
+    if per_rank:
+        ok = [p for p in per_rank if p["achieved"]]
+        roofline["per_rank"] = per_rank
+        roofline["aggregate"] = {"achieved": sum(p["achieved"] for p in ok), "peak": HBM_PEAK / 1e9 * world, "unit": "GB/s",
+                                 "frac": (sum(p["frac"] for p in ok) / len(ok)) if ok else None,
+                                 "note": "sum over the ranks of bytes moved per launch / that rank's kernel time; frac = mean of the per-rank fractions"}
+    return {"value": n_queries / elapsed, "unit": "queries/s", "ms_per_step": elapsed / steps * 1e3, "ms_per_batch": elapsed / n_batches_run * 1e3,
+            "queries_per_step": bps * BATCH, "steps": steps, "elapsed_s": elapsed,
+            "host_ms_per_batch": round(1e3 * host_s / n_batches_run, 4), "host_us_per_batch": host_sections,
+            "hits_delivered_to_host": True, "rows_read_on_host": delivered, "last_batch_on_host_equals_synchronous_search": verified,
+            "roofline": roofline}
+
+
+def parity_vs_port(db, leg, n=128):
+    """The GPU's answers to the first n queries of the timed pool against the oracle port run on the very postings the device holds
+    (copied back from HBM): docids, weight bit patterns, match counts.  Returns (queries checked, DeviceOracle) — outside any timing."""
+    import helpers as H
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    sample = leg.timed_pool[:n]
+    ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]], positions=leg.op == "PHRASE")
+    ora.warm()
+    want = H.oracle_search_batch(ora, sample, 0, leg.k)
+    db.set_stream(0)
+    k = leg.k
+    qs = (_lib.Query * n)(*leg.timed_plans[:n])
+    hits = (_lib.Hit * (n * k))()
+    hdrs = (_lib.ResultHdr * n)()
+    _lib.check(L.xgm_search_batch(db._h, qs, n, k, hits, hdrs))
+    for qi, (rows, oh) in enumerate(want):
+        got = [(hits[qi * k + j].docid, hits[qi * k + j].weight) for j in range(hdrs[qi].n_hits)]
+        assert got == [(d, w) for d, w, _ in rows], "GPU/CPU parity failure on %s bench query %d" % (leg.op, qi)
+        H.check_matches(hdrs[qi].matches_exact, oh.matches, len(got), (leg.op, qi))
+    return len(want), ora
+
+
+def latency_leg(db, leg, n_timed):
+    """One query in flight: host-timed around plan + search incl. H2D / D2H (1 000 queries, the first 20 warm up)."""
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    k = leg.k
+    one_hits = (_lib.Hit * k)()
+    one_hdr = _lib.ResultHdr()
+    db.set_stream(0)
+    lat = []
+    for i in range(min(1000, n_timed)):
+        d1 = (_lib.QueryDesc * 1)(leg.descs[100 + i])
+        g1 = (_lib.GlobalStats * 1)(leg.gstats[100 + i])
+        a = time.perf_counter()
+        _lib.check(L.xgm_get_mset_batch(db._h, d1, g1, 1, k, one_hits, C.byref(one_hdr)))
+        if i >= 20:
+            lat.append(time.perf_counter() - a)
+    lat.sort()
+    return lat
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_spawn(args)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
 
     import helpers as H        # query pool shared with tests/test_gpu_configs.py (PHRASE: the corpus restated in Python)
-    from xapiand_amd import Database, Query, _lib
+    from xapiand_amd import Database, _lib
     from xapiand_amd.distributed import ShardedSearcher
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,195 +427,93 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     info = db.info()
-    # One explicit (non-null) HIP stream for searches and collectives: the xgm_*_device calls are then asynchronous,
-    # so the host plans batch i+1 while the GPU runs batch i (ShardedSearcher binds the index to torch's current stream).
+    # N > 1 / the tally passes: one explicit (non-null) HIP stream for searches and collectives (ShardedSearcher binds the index to
+    # torch's current stream per call).  N = 1 timed region: every batch in flight runs on a stream of its own (no stream bound).
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 
-    # ---- queries + merged statistics (Enquire::add_prepared_mset: Σ over shards): one all-reduce ----
-    pool = H.bench_pool(args.op, args.terms, args.required, n_docs_global, args.vocab, seed=QUERY_SEED)
     k = args.topk
     searcher = ShardedSearcher(db, rank, world, dev)
-    sided = args.op in ("AND_NOT", "AND_MAYBE", "FILTER")
-    qobjs = [Query(q["op"], q["terms"], n_required=args.required if sided else 0) for q in pool]
-    descs, gstats = searcher.describe(qobjs, 0, k)                 # what the hook is handed per get_mset
-    plans = searcher.prepare(qobjs, 0, k)                          # bookkeeping only (algorithmic bytes, parity leg)
     L = _lib.lib()
-    n_timed = len(pool) - 100
-    n_batches = n_timed // BATCH
-
-    def batch_of(lo):
-        d = (_lib.QueryDesc * BATCH)(*[descs[(lo + i) % len(pool)] for i in range(BATCH)])
-        g = (_lib.GlobalStats * BATCH)(*[gstats[(lo + i) % len(pool)] for i in range(BATCH)])
-        return d, g
-    batches = [batch_of(100 + b * BATCH) for b in range(n_batches)]
-    warm = batch_of(0)
-    timed_plans = plans[100:]
-
-    def step(b):
-        # plan + search (+ RCCL all-gather of top-k + xgm_merge_shards_device when sharded)
-        return searcher.run_descs(b[0], b[1], BATCH, k)
-
-    for _ in range(args.warmup):
-        step(warm)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    db.set_profiling(1)
-    L.xgm_debug_host_ns((C.c_uint64 * 8)())           # reset the host-side section timers
-    t0 = time.perf_counter()
-    host_s = 0.0                                   # time the host spends inside the (asynchronous) calls: plan + enqueue
-    for s in range(args.steps):
-        h0 = time.perf_counter()
-        step(batches[s % n_batches])
-        host_s += time.perf_counter() - h0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    hn = (C.c_uint64 * 8)()
-    L.xgm_debug_host_ns(hn)
-    n_launch = max(1, int(hn[3]))
-    host_sections = {"plan_queries": round(hn[0] / 1e3 / args.steps, 1), "plan_batch": round(hn[1] / 1e3 / n_launch, 1),
-                     "stage_enqueue_launch": round(hn[2] / 1e3 / n_launch, 1), "staging_memcpy": round(hn[4] / 1e3 / n_launch, 1), "upload_enqueue": round(hn[5] / 1e3 / n_launch, 1), "match_launch": round(hn[6] / 1e3 / n_launch, 1), "merge_launch": round(hn[7] / 1e3 / n_launch, 1), "launches_per_step": round(n_launch / args.steps, 2)}
-    kernel_ms = db.last_kernel_ms()            # mean match-kernel duration over the timed steps (HIP events)
-    kernel_name = db.last_kernel_name()
-    db.set_profiling(0)
-    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")      # where the small collectives of this script live
-    t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    qps = args.steps * BATCH / elapsed             # queries answered over the WHOLE (sharded) index per second
-
-    # ---- per-launch byte counts, outside the timed region ------------------------------------------------------
-    # algorithmic: Σ_t df_t·8 + S·4 + P·4 + k·16 per query; model: the kernel's own request tallies
-    db.set_profiling(0 if os.environ.get("XGM_BENCH_NO_TALLY") else 2)   # the tallying instantiation of the wave kernels (tools/units.py switches it off: it wants the product kernel's own timeline)
-    alg_bytes, model_sector, model_useful, tallies = [], [], [], []
-    for b in range(n_batches):
-        step(batches[b])
-        torch.cuda.synchronize()
-        h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
-        matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
-        post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in timed_plans[b * BATCH:(b + 1) * BATCH])
-        tl = (C.c_uint64 * 10)()
-        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_dense_kernel")
-        bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
-        alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
-        if have_tally:
-            stream_b = 4 * bmpw + 4 * blkw + 12 * hdrs_ + 4 * aux + 16 * cands + 4 * npos
-            model_sector.append(stream_b + SECTOR * (probes + dls))
-            model_useful.append(stream_b + probes_raw + 4 * dls_raw)
-            tallies.append(dict(bitmap_words=bmpw, probe_sectors=probes, probes=probes_raw, payload_words=blkw, block_headers=hdrs_,
-                                doclen_sectors=dls, doclen_gathers=dls_raw, aux_words=aux, candidates_out=cands, positions=npos))
-    db.set_profiling(0)
-    used = [s % n_batches for s in range(args.steps)]
-    bytes_per_launch = float(np.mean([alg_bytes[i] for i in used]))
-    kt = kernel_ms * 1e-3 if kernel_ms and kernel_ms > 0 else None
-    alg_rate = bytes_per_launch / kt if kt else 0.0
-    model_bytes = float(np.mean([model_sector[i] for i in used])) if model_sector else None
-    useful_bytes = float(np.mean([model_useful[i] for i in used])) if model_useful else None
+    n_pool_batches = max(4, args.batches_per_step)
+    leg = Leg(searcher, args.op, args.terms, args.required, k, n_docs_global, args.vocab, n_pool_batches)
+    m = measure(db, searcher, leg, args, world, rank, dev, args.steps, args.warmup)
+    n_timed = len(leg.timed_pool)
 
     # ---- planning cost (inside every timed step): host microseconds per query ------------------------------------
-    plan_us = L.xgm_debug_plan_us(db._h, batches[0][0], batches[0][1], BATCH, 20)
+    plan_us = L.xgm_debug_plan_us(db._h, leg.batches[0][0], leg.batches[0][1], BATCH, 20)
 
     # ---- latency mode: one query in flight, host-timed around plan + search incl. H2D/D2H ---------------------
     lat = []
     if (rank == 0 or world > 1) and not args.no_latency:
-        one_hits = (_lib.Hit * k)()
-        one_hdr = _lib.ResultHdr()
-        db.set_stream(0)
-        for i in range(min(1000, n_timed)):                 # 1 000 queries (the first 20 warm up)
-            d1 = (_lib.QueryDesc * 1)(descs[100 + i])
-            g1 = (_lib.GlobalStats * 1)(gstats[100 + i])
-            a = time.perf_counter()
-            _lib.check(L.xgm_get_mset_batch(db._h, d1, g1, 1, k, one_hits, C.byref(one_hdr)))
-            if i >= 20:
-                lat.append(time.perf_counter() - a)
-    lat.sort()
+        lat = latency_leg(db, leg, n_timed)
 
     # ---- server mode: T host threads, each with ONE query in flight (Xapiand's http_client_pool shape) ----------
     server = None
     if rank == 0 and world == 1 and args.threads > 0:
-        server = server_leg(db, descs, gstats, k, args.threads, n_timed)
-
-    # ---- HBM traffic of the dominant kernel: from the committed PMC passes (tools/final.sh → profiles/traffic.json),
-    # which cannot be collected from inside this process; only quoted when measured on this very workload
-    traffic, traffic_note = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    sha_path = os.path.join(ROOT, "xapiand_amd", "csrc", "libxgm.so.sha")
-    lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None
-    stale_traffic = False
-    if os.path.exists(tpath):
-        for tr in json.load(open(tpath)).get("entries", []):
-            if tr.get("lib_sha") != lib_sha:
-                stale_traffic = True          # counters of another build of the library: not this kernel's traffic
-                continue
-            if (tr["kernel"] == kernel_name and tr["op"] == args.op and tr["docs_per_gpu"] == args.docs_per_gpu and tr["top_k"] == k and
-                    tr["terms"] == (args.terms if args.op != "PHRASE" else 0) and tr["batch"] == BATCH and tr.get("required", 1) == (args.required if sided else 1)):
-                traffic, traffic_note = tr["hbm_bytes_per_launch"], tr["note"]
-
-    # ---- N > 1: every rank's own match kernel against its own GPU's roofline (per-GPU bytes use the shard's own df) ------
-    per_rank = None
-    if world > 1:
-        mine = torch.tensor([kernel_ms if kernel_ms and kernel_ms > 0 else 0.0, float(traffic or model_bytes or bytes_per_launch)], dtype=torch.float64, device=cdev)
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = []
-        for r, v in enumerate(allr):
-            ms, by = float(v[0].item()), float(v[1].item())
-            per_rank.append({"rank": r, "kernel_ms": ms, "bytes_per_launch": by, "achieved": (by / (ms * 1e-3) / 1e9) if ms > 0 else None,
-                             "frac": (by / (ms * 1e-3) / HBM_PEAK) if ms > 0 else None})
+        server = server_leg(db, leg.descs, leg.gstats, k, args.threads, n_timed)
 
     result = None
+    headline = world == 1 and args.op == "AND" and args.terms == 3 and k == 10
     if rank == 0:
-        basis = "pmc" if traffic else ("model" if model_bytes else "algorithmic")
-        moved = traffic if traffic else (model_bytes if model_bytes else bytes_per_launch)
-        achieved = moved / kt if kt else 0.0
         result = {
             "metric": "queries/sec + p50 latency, %dM-doc synthetic index, %s, top-%d" % (
                 args.docs_per_gpu // 1000000, {"AND": "%d-term AND" % args.terms, "OR": "%d-term OR" % args.terms,
                                                "PHRASE": "2-3-term PHRASE"}.get(args.op, "%d-term %s" % (args.terms, args.op)), k),
-            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": m["value"], "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32 postings + f64 BM25", "data": "synthetic",
             "config": {"workload": workload_name(args, world, n_docs_global, k),
                        "docs_per_gpu": args.docs_per_gpu, "docs_total": n_docs_global, "vocab": args.vocab, "op": args.op,
-                       "terms_per_query": args.terms, "top_k": k, "batch": BATCH, "parallelism": "shard%d" % world,
+                       "terms_per_query": args.terms, "top_k": k, "batch": BATCH, "batches_per_step": args.batches_per_step,
+                       "queries_per_step": args.batches_per_step * BATCH, "batches_in_flight": args.in_flight if world == 1 else 2,
+                       "parallelism": "shard%d" % world,
                        "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED),
-                       "step": "xgm_get_mset_batch_device: plan (lookups, BM25 init, leaf order) + match + merge, 256 queries"},
-            "host_ms_per_step": round(1e3 * host_s / args.steps, 4), "host_us_per_step": host_sections, "p50_latency_us": lat[len(lat) // 2] * 1e6 if lat else None,
+                       "step": ("%d x xgm_get_mset_batch_begin (plan: lookups, BM25 init, leaf order + match + merge, 256 queries) ... xgm_batch_end: the hits and "
+                                "headers of every batch delivered to pinned HOST memory, %d batches in flight" % (args.batches_per_step, args.in_flight)) if world == 1 else
+                               ("%d x (xgm_get_mset_batch_device + all-gather of the shards' top-k + xgm_merge_shards_device, 256 queries) with the merged hits "
+                                "copied to pinned HOST memory, double-buffered" % args.batches_per_step)},
+            "ms_per_batch": m["ms_per_batch"], "host_ms_per_batch": m["host_ms_per_batch"], "host_us_per_batch": m["host_us_per_batch"],
+            "hits_delivered_to_host": m["hits_delivered_to_host"], "last_batch_on_host_equals_synchronous_search": m["last_batch_on_host_equals_synchronous_search"],
+            "p50_latency_us": lat[len(lat) // 2] * 1e6 if lat else None,
             "p99_latency_us": lat[int(len(lat) * 0.99)] * 1e6 if lat else None,
             "plan_us_per_query": plan_us,
             "index": {"postings": info.n_postings, "blocks": info.n_blocks, "payload_bytes": info.payload_bytes,
                       "device_bytes": info.device_bytes, "bytes_per_posting": info.device_bytes / max(1, info.n_postings),
                       "build_seconds": build_s},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK, "basis": basis, "traffic": traffic, "traffic_note": traffic_note,
-                         "traffic_lib_sha": lib_sha if traffic else None, "traffic_entries_of_another_build_ignored": stale_traffic,
-                         "kernel_ms": kernel_ms,
-                         "model_min_bytes": model_bytes, "model_useful_bytes": useful_bytes,
-                         "model_frac": (model_bytes / kt / HBM_PEAK) if (model_bytes and kt) else None,
-                         "model_note": "requests tallied by the kernel itself (xgm_last_batch_traffic): streamed words at 4 B + %d B per DISTINCT "
-                                       "memory sector a round of one-byte container probes / doclen gathers touches" % SECTOR,
-                         "model_counts": tallies[0] if tallies else None,
-                         "algorithmic": {"bytes_per_launch": bytes_per_launch, "achieved": alg_rate / 1e9, "frac": alg_rate / HBM_PEAK,
-                                         "note": "SURVEY 8(d): sum df*8 + S*4 + P*4 + k*16 per query; not bytes this design reads"}},
+            "roofline": m["roofline"],
         }
-        if per_rank:
-            ok = [p for p in per_rank if p["achieved"]]
-            result["roofline"]["per_rank"] = per_rank
-            result["roofline"]["aggregate"] = {"achieved": sum(p["achieved"] for p in ok), "peak": HBM_PEAK / 1e9 * world, "unit": "GB/s",
-                                               "frac": (sum(p["frac"] for p in ok) / len(ok)) if ok else None,
-                                               "note": "sum over the ranks of bytes moved per launch / that rank's kernel time; frac = mean of the per-rank fractions"}
         if server:
             result["server_mode"] = server
 
+    # ---- the other single-GPU configurations of BASELINE.json in the same run: C3 (5-term OR, top-100), C5 (2-3-term PHRASE, top-10) ----
+    if rank == 0 and headline and not args.no_other_configs:
+        others = {}
+        for name, op, terms, kk, st in (("C3", "OR", 5, 100, max(2, args.steps // 4)), ("C5", "PHRASE", 3, 10, max(2, args.steps // 4))):
+            try:
+                lg = Leg(searcher, op, terms, 1, kk, n_docs_global, args.vocab, n_pool_batches)
+                mm = measure(db, searcher, lg, args, world, rank, dev, st, 1)
+                ll = latency_leg(db, lg, min(220, len(lg.timed_pool))) if not args.no_latency else []
+                checked, ora = parity_vs_port(db, lg, 128)
+                port = None
+                if not args.no_cpu_baseline:
+                    port = time_port(ora, lg.timed_pool[:32], op, kk, min(4.0, args.cpu_seconds), 0)
+                ora.close()
+                others[name] = {"workload": "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (
+                                    name, args.docs_per_gpu // 1000000, args.vocab // 1000000, "5-term disjunctive" if op == "OR" else "2-3-term phrase (positions)", kk),
+                                "value": mm["value"], "unit": "queries/s", "ms_per_step": mm["ms_per_step"], "steps": st, "queries_per_step": mm["queries_per_step"],
+                                "ms_per_batch": mm["ms_per_batch"], "hits_delivered_to_host": True,
+                                "last_batch_on_host_equals_synchronous_search": mm["last_batch_on_host_equals_synchronous_search"],
+                                "p50_latency_us": ll[len(ll) // 2] * 1e6 if ll else None, "p99_latency_us": ll[int(len(ll) * 0.99)] * 1e6 if ll else None,
+                                "roofline": mm["roofline"], "parity_checked_queries": checked,
+                                "cpu_baseline": dict(port, kind="port", sample="first 32 queries of the timed pool, oracle port on the postings copied back from HBM") if port else None}
+            except Exception as e:                # a sub-leg must not take the headline line down with it: say what happened
+                others[name] = {"error": repr(e)}
+        result["other_configs"] = others
+
     # ---- CPU baseline: the real reference + the oracle port, on this box's host cores -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(db, pool[100:], args, k, timed_plans)
+        result["cpu_baseline"] = cpu_baseline(db, leg.timed_pool, args, k, leg.timed_plans, result)
     if rank == 0:
         print(json.dumps(result), flush=True)
     db.close()
@@ -392,7 +587,66 @@ def port_all_cores(ora, sample, op, k, seconds, n_required=0):
     return {"value": done.value / wall.value, "unit": "queries/s", "cores": n_threads, "seconds": wall.value}
 
 
-def reference_leg(args, sample, k, n_required, full, ora_full):
+HOOK_B1 = os.path.join(ROOT, "oracle", "_ref", "xapian_hook_b1")
+
+
+def run_hook_b1(flags, qfile, dbdir, timeout=1500):
+    r = subprocess.run([HOOK_B1] + flags + [qfile, dbdir], capture_output=True, text=True, timeout=timeout)
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not line:
+        return {"error": (r.stdout[-600:] + r.stderr[-600:]) or "no output", "returncode": r.returncode}
+    out = json.loads(line[-1])
+    out["returncode"] = r.returncode
+    bad = [l for l in r.stdout.splitlines() if l.startswith(("MISMATCH", "BOUNDS"))]
+    if bad:
+        out["first_differences"] = bad[:5]
+    return out
+
+
+def hook_parity_leg(args, tmp, dbdir, ref_docs, pools, pos_docs):
+    """The boundary at (reference-index) size, through the REAL reference (VERDICT r3 #1b): oracle/_ref/xapian_hook_b1 — the vendored
+    Xapian with integration/matcher_hook.patch applied and integration/xgm_matcher_hook.cc linked in — exports the glass index this
+    run just built with the native reader (xgm_segment_build_from_glass, timed), loads it onto the GPU, registers it with the hook and
+    answers the first 128 queries of the C2 and C3 pools with the hook OFF (CPU matcher) and ON (device) — exact match-count figures on
+    (byte-compatible mode: xgm_search_all + xgm_known_matching_docs / the replay of the reference's loop) — and, on a second glass
+    index WITH positions, the first 128 C5 queries in POSITIONAL_REFERENCE mode.  Identical MSets required: docids, weight bits,
+    percentages, matches_lower / estimated / upper, HTTP total."""
+    import helpers as H
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_index
+    if not os.path.exists(HOOK_B1):
+        return {"skipped": "oracle/_ref/xapian_hook_b1 is not built"}
+    out = {"docs": ref_docs, "shapes": {}}
+    total = dict(queries=0, mismatches=0, bounds_violations=0, http_total_equal=0, answered_on_device=0)
+    for name in ("C2", "C3"):
+        qf = os.path.join(tmp, "hook_%s.txt" % name)
+        H.write_queries(qf, [dict(q, first=0) for q in pools[name][:128]])
+        r = run_hook_b1(["--exact-bounds"], qf, dbdir)
+        out["shapes"][name] = r
+        if "export_seconds" in r and "exporter" not in out:
+            out["exporter"] = {"docs": r["docs"], "seconds": r["export_seconds"], "segment_bytes": r["segment_bytes"], "open_seconds": r["open_seconds"],
+                               "what": "xgm_segment_build_from_glass: the glass B-trees read natively (postlist.glass), block-encoded, written"}
+    if pos_docs > 0:
+        posdir = os.path.join(tmp, "glass_pos")
+        binfo = ref_index.build(posdir, pos_docs, nopos=False, vocab=args.vocab)
+        qf = os.path.join(tmp, "hook_C5.txt")
+        # (the PHRASE pool is drawn from documents of the full corpus; on the smaller index some phrases match less — or nothing: still a query)
+        H.write_queries(qf, [dict(q, first=0) for q in pools["C5"][:128]])
+        r = run_hook_b1(["--positional-reference"], qf, posdir)
+        r["index_build"] = binfo
+        out["shapes"]["C5 (POSITIONAL_REFERENCE)"] = r
+        out["docs_with_positions"] = pos_docs
+    for r in out["shapes"].values():
+        for key in total:
+            if key in r:
+                total[key] += r[key]
+        if "error" in r:
+            total["errors"] = total.get("errors", 0) + 1
+    out.update(total)
+    return out
+
+
+def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None):
     """The real reference on this box: build a glass index of the first --ref-docs documents of the corpus with
     the reference's own WritableDatabase (parallel slices + Database::compact, tools/ref_index.py), time
     Enquire::get_mset on 1 thread and on every core (one Database handle per thread) with
@@ -403,7 +657,8 @@ def reference_leg(args, sample, k, n_required, full, ora_full):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import ref_index
     from xapiand_amd import Database
-    ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu // 5)
+    headline = args.op == "AND" and args.terms == 3 and k == 10
+    ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu if headline else args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu // 5)
     if not H.have_xapian_ref() or ref_docs <= 0:
         return None
     # the index lives in memory-backed storage when there is one: indexing through WritableDatabase is write-heavy
@@ -440,15 +695,21 @@ def reference_leg(args, sample, k, n_required, full, ora_full):
         if small is not None:
             ora.close()
             small.close()
-        return {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
-                "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3},
-                "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
-                "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
+        out = {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
+               "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3},
+               "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
+               "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
+        if hook_pools is not None:
+            try:
+                out["_hook_parity"] = hook_parity_leg(args, tmp, dbdir, ref_docs, hook_pools, args.hook_pos_docs)
+            except Exception as e:
+                out["_hook_parity"] = {"error": repr(e)}
+        return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def cpu_baseline(db, pool_q, args, k, timed_plans):
+def cpu_baseline(db, pool_q, args, k, timed_plans, result=None):
     """`value` is the REAL reference when oracle/_ref/xapian_ref is present (kind "reference": Enquire::get_mset of the
     vendored Xapian on a --ref-docs glass index built on this box), else the port (kind "port").  Always also: the
     port at the configuration's full size on the postings copied back from HBM, 1 thread and all cores, with the GPU
@@ -477,7 +738,15 @@ def cpu_baseline(db, pool_q, args, k, timed_plans):
                   "ProtoMSet algorithm restated) on the same %d-doc postings copied back from HBM, %.1f s of CPU work" % (len(sample), full["docs"], full["seconds"]))
     ref = None
     try:
-        ref = reference_leg(args, sample, k, n_required, full, ora)
+        hook_pools = None
+        if result is not None and not args.no_hook_parity and args.op == "AND" and args.terms == 3 and k == 10:
+            n_docs = db.info().doccount
+            hook_pools = {"C2": [dict(q, maxitems=10) for q in pool_q[:128]],
+                          "C3": H.bench_pool("OR", 5, 1, n_docs, args.vocab, n=228, seed=QUERY_SEED, maxitems=100)[100:],
+                          "C5": H.bench_pool("PHRASE", 3, 1, n_docs, args.vocab, n=228, seed=QUERY_SEED, maxitems=10)[100:]}
+        ref = reference_leg(args, sample, k, n_required, full, ora, hook_pools)
+        if ref and "_hook_parity" in ref:
+            result["hook_parity"] = ref.pop("_hook_parity")
     except Exception as e:       # the reference leg is best effort (disk space, missing binary): say why it is absent
         ref = None
         sample_txt += "; reference leg failed: %r" % (e,)
@@ -489,7 +758,7 @@ def cpu_baseline(db, pool_q, args, k, timed_plans):
             out["reference_full_size_estimate"] = {"value": full["value"] / ref["port_over_reference"], "unit": "queries/s", "cores": 1,
                                                    "note": "port at %d docs / port_over_reference" % full["docs"]}
             rpath = os.path.join(ROOT, "profiles", "r02_reference_full.json")
-            if args.op == "AND" and args.terms == 3 and k == 10 and full["docs"] == 10_000_000 and os.path.exists(rpath):
+            if args.op == "AND" and args.terms == 3 and k == 10 and full["docs"] == 10_000_000 and os.path.exists(rpath):    # (only when --ref-docs made this run's index smaller)
                 # the same leg run ONCE at the full size on this box type (too long for every default run)
                 r = json.load(open(rpath))
                 out["reference_full_size_measured"] = {"value": r["one_thread"]["value"], "unit": "queries/s", "cores": 1, "all_cores": r["all_cores"],

@@ -230,7 +230,9 @@ int xgm_index_set_stream(xgm_index*, void* hip_stream);
  * src/database/handler.cc:1338).  With max_batch > 0, single-query calls (xgm_search, xgm_search_batch / xgm_get_mset_batch
  * with nq == 1) from any number of threads are queued and a dispatcher thread owned by the index launches whatever has
  * accumulated — up to max_batch queries, of any mix of shapes — as one batch, then returns each caller its own hits and
- * return code.  No timer: while one batch runs the next one fills.  max_batch == 0 switches it off (the default).  Like
+ * return code.  No timer: while one batch runs the next one fills — and is launched as soon as the dispatcher has cut it (up to three
+ * batches in flight, each on its own stream; a completer thread hands the rows back and wakes exactly the callers of the finished
+ * batch).  max_batch == 0 switches it off (the default).  Like
  * xgm_index_open / xgm_index_close the call is externally serialised with searches on the index (the matcher hook makes it once, when
  * a shard is registered). */
 int xgm_index_set_batching(xgm_index*, uint32_t max_batch);
@@ -481,6 +483,22 @@ int xgm_get_mset_batch(xgm_index*, const xgm_query_desc* descs, const xgm_global
                        uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
 int xgm_get_mset_batch_device(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq,
                               uint32_t k_stride, void* d_hits, void* d_hdrs);
+
+/* A batch in flight: *_begin plans the work units, uploads, launches the kernels and the copy of the results into pinned host memory
+ * the library owns, and returns at once; xgm_batch_end waits for THAT batch and hands out its results — hits [nq][k_stride] (the
+ * valid prefix of row q is hdrs[q].n_hits) and hdrs [nq], valid until xgm_batch_release, which returns the batch's buffers to the
+ * index.  xgm_batch_poll: 1 when the batch has finished, 0 when not.  Several batches may be in flight per index (each on a stream
+ * of its own unless xgm_index_set_stream bound one): the host plans batch i + 1 while the GPU runs batch i, and consecutive batches
+ * overlap on the chip.  This is how a server keeps the device busy AND gets every hit on the host: the dispatcher of
+ * xgm_index_set_batching is built on it, bench.py times it.  Begin a batch only while fewer than 8 are unreleased on the index.
+ * Replaces: Enquire::get_mset blocking its HTTP worker thread for the whole match (reference src/database/handler.cc:1338). */
+typedef struct xgm_inflight xgm_inflight;
+int xgm_search_batch_begin(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out);
+int xgm_get_mset_batch_begin(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t k_stride,
+                             xgm_inflight** out);
+int xgm_batch_end(xgm_inflight*, const xgm_hit** hits, const xgm_result_hdr** hdrs);
+int xgm_batch_poll(xgm_inflight*);
+void xgm_batch_release(xgm_inflight*);
 
 /* Merge per-shard results after the all-gather.  d_all_hits is [n_shards][nq][k_stride], d_all_hdrs
  * [n_shards][nq] (device); output [nq][k_stride] / [nq] (device) with GLOBAL docids

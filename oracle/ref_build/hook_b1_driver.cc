@@ -16,6 +16,9 @@
 #include "ref_driver.cc"
 
 #include <unistd.h>
+#include <sys/stat.h>
+
+#include <chrono>
 
 #include "../../integration/xgm_matcher_hook.h"
 
@@ -77,14 +80,22 @@ int main(int argc, char** argv) {
         std::vector<Xapian::Database> dbs;
         std::vector<xgm_index*> idx;
         std::vector<std::string> seg_files;
+        double export_s = 0.0, open_s = 0.0;
+        unsigned long long segment_bytes = 0;
+        auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (int i = a + 1; i < argc; ++i) {
             dbs.emplace_back(argv[i]);
             char seg[64];
             snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%d.seg", (int)getpid(), i);
+            const double t_e0 = now_s();
             if (xgm_segment_build_from_glass(argv[i], 0, seg) != XGM_OK) { fprintf(stderr, "export %s: %s\n", argv[i], xgm_last_error()); return 1; }
+            const double t_e1 = now_s();
+            export_s += t_e1 - t_e0;
+            { struct stat st; if (stat(seg, &st) == 0) segment_bytes += (unsigned long long)st.st_size; }
             xgm_index* h = nullptr;
             const uint64_t rev = dbs.back().get_revision();
             if (xgm_index_open(seg, 0, rev, &h) != XGM_OK) { fprintf(stderr, "xgm_index_open: %s\n", xgm_last_error()); return 1; }
+            open_s += now_s() - t_e1;
             seg_files.push_back(seg);                 /* kept: the incremental refresh starts from it */
             idx.push_back(h);
             xgm_hook::register_shard(dbs.back(), h);
@@ -134,15 +145,19 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i], first_changed[i])) return 1; ++refreshed; }
         }
         unsigned bad = 0, bounds_bad = 0, http_total_equal = 0;
+        double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const QuerySpec& q = queries[qi];
             const Xapian::Query query = make_query(q);
             SpyResult spy_want, spy_got;
             xgm_hook::set_enabled(false);
+            const double t_q0 = now_s();
             Xapian::MSet want = run_query(dbs, query, q.first, q.maxitems, &q, &spy_want);
+            const double t_q1 = now_s();
             xgm_hook::set_enabled(true);
             Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems, &q, &spy_got);
+            cpu_s += t_q1 - t_q0; hook_s += now_s() - t_q1;
             std::string why;
             if (!same_mset(want, got, percents, &why)) {
                 ++bad;
@@ -191,10 +206,12 @@ int main(int argc, char** argv) {
         const xgm_hook::Counters c = xgm_hook::counters();
         printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
-               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu}\n",
+               "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu, "
+               "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f}\n",
                queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
-               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed);
+               (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed,
+               (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s);
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
         for (const std::string& f : seg_files) unlink(f.c_str());

@@ -30,6 +30,7 @@ def worker():
 
     import torch
 
+    sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import helpers as H
     from xapiand_amd import Database, Query, _lib

@@ -1107,7 +1107,23 @@ extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq
     return search_batch_now(idx, qs, nq, k_stride, hits, hdrs);
 }
 
-static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
+/* ---- a batch in flight ---------------------------------------------------------------------------------------------------
+ * begin: plan the work units, upload, launch the match (+ merge) kernels and the copy of the results into PINNED host memory the
+ * library owns — all asynchronous on the batch's own stream (or the index's, xgm_index_set_stream) — and return at once; end: wait
+ * for that batch alone.  A server (the dispatcher of xgm_index_set_batching, bench.py's timed loop) keeps two or three batches in
+ * flight: the host plans batch i + 1 while the GPU runs batch i, consecutive batches on different streams overlap on the chip (the
+ * tail of one — the last queries' merges — under the head of the next), and every batch's hits reach the HOST.  The scratch (device
+ * + pinned buffers, stream) belongs to the batch until xgm_batch_release. */
+struct xgm_inflight {
+    xgm_index* idx = nullptr;
+    XgmScratch* s = nullptr;
+    uint32_t nq = 0, k_stride = 0;
+    bool ended = false;
+    int rc_end = XGM_OK;
+};
+
+static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out) {
+    *out = nullptr;
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
@@ -1121,17 +1137,94 @@ static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, ui
         const size_t down = n_hit * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
         if ((rc = grow_pinned(&s->h_down, &s->cap_down, down))) break;
         if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, d_hdrs))) break;
-        xgm_hit* h_hits = (xgm_hit*)s->h_down;
-        xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + n_hit);
-        hipError_t e = hipMemcpyAsync(h_hits, s->d_hits, down, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        /* an index bound to ONE stream (xgm_index_set_stream) runs its batches' kernels back to back there; the download of batch i then
+         * goes on the scratch's own stream behind an event, so that it does not sit between the match kernels of batches i and i + 1
+         * (XGM_COPY_ON_BATCH_STREAM=1: A/B switch, the copy in stream order) */
+        static const bool copy_in_order = getenv("XGM_COPY_ON_BATCH_STREAM") != nullptr;
+        hipError_t e = hipSuccess;
+        if (stream != s->stream && !copy_in_order) {
+            e = hipEventRecord(s->ev1, stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev1, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(s->h_down, s->d_hits, down, hipMemcpyDeviceToHost, s->stream);
+            if (e == hipSuccess) e = hipEventRecord(s->ev_done, s->stream);
+        } else {
+            e = hipMemcpyAsync(s->h_down, s->d_hits, down, hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipEventRecord(s->ev_done, stream);
+        }
         if (e != hipSuccess) { rc = xgm_launch_error("result copy", (int)e, hipGetErrorString(e)); break; }
+    } while (0);
+    if (rc) {
+        hipStreamSynchronize(stream);              /* whatever was enqueued no longer uses the scratch */
+        hipStreamSynchronize(s->stream);
+        scratch_release(idx, s);
+        return rc;
+    }
+    xgm_inflight* f = new xgm_inflight();
+    f->idx = idx; f->s = s; f->nq = nq; f->k_stride = k_stride;
+    *out = f;
+    return XGM_OK;
+}
+
+extern "C" int xgm_search_batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out) {
+    if (!idx || !qs || !out || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    return batch_begin(idx, qs, nq, k_stride, out);
+}
+
+extern "C" int xgm_get_mset_batch_begin(xgm_index* idx, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t k_stride,
+                                        xgm_inflight** out) {
+    if (!idx || !descs || !out || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    static thread_local std::vector<xgm_query> plans;
+    plans.resize(nq);
+    const uint64_t t0 = now_ns();
+    for (uint32_t i = 0; i < nq; ++i) {
+        int rc = xgm_plan_query(idx, &descs[i], gs ? &gs[i] : nullptr, &plans[i]);
+        if (rc) return rc;
+    }
+    g_host_ns[0] += now_ns() - t0;
+    return batch_begin(idx, plans.data(), nq, k_stride, out);
+}
+
+extern "C" int xgm_batch_end(xgm_inflight* f, const xgm_hit** hits, const xgm_result_hdr** hdrs) {
+    if (!f) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (!f->ended) {
+        f->ended = true;
+        hipError_t e = hipEventSynchronize(f->s->ev_done);
+        if (e != hipSuccess) f->rc_end = xgm_launch_error("batch completion", (int)e, hipGetErrorString(e));
+    }
+    if (hits) *hits = (const xgm_hit*)f->s->h_down;
+    if (hdrs) *hdrs = (const xgm_result_hdr*)((const xgm_hit*)f->s->h_down + (size_t)f->nq * f->k_stride);
+    return f->rc_end;
+}
+
+extern "C" int xgm_batch_poll(xgm_inflight* f) {
+    if (!f) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (f->ended) return 1;
+    return hipEventQuery(f->s->ev_done) == hipSuccess ? 1 : 0;
+}
+
+extern "C" void xgm_batch_release(xgm_inflight* f) {
+    if (!f) return;
+    if (!f->ended) hipEventSynchronize(f->s->ev_done);
+    scratch_release(f->idx, f->s);
+    delete f;
+}
+
+static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
+    xgm_inflight* f = nullptr;
+    int rc = batch_begin(idx, qs, nq, k_stride, &f);
+    if (rc) return rc;
+    const xgm_hit* h_hits = nullptr;
+    const xgm_result_hdr* h_hdrs = nullptr;
+    rc = xgm_batch_end(f, &h_hits, &h_hdrs);
+    if (rc == XGM_OK) {
         memcpy(hdrs, h_hdrs, (size_t)nq * sizeof(xgm_result_hdr));
         /* only the valid prefix of each row is defined on the device */
         for (uint32_t i = 0; i < nq; ++i)
             memcpy(hits + (size_t)i * k_stride, h_hits + (size_t)i * k_stride, (size_t)h_hdrs[i].n_hits * sizeof(xgm_hit));
-    } while (0);
-    scratch_release(idx, s);
+    }
+    xgm_batch_release(f);
     return rc;
 }
 
@@ -1358,8 +1451,8 @@ extern "C" int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xg
 
 /* ---- every match of a query, in docid order (include/xgm.h: xgm_search_all) -------------------------------------------------
  * The workgroup kernel (every query shape; it decodes the posting blocks of each stripe: K1 at full size) weighs every matching
- * document anyway when it runs under a sort; here it also appends each to one list (a wave-aggregated atomic per round), which a
- * device radix sort on the docid then orders (xgm_all.hip).  One query per call, synchronous. */
+ * document anyway when it runs under a sort; here it also appends each to one list (a wave-aggregated atomic per round), which
+ * xgm_all.hip then puts in docid order by RANK (a bitmap of the matches, prefix counts, one scatter).  One query per call, synchronous. */
 extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr) {
     if (!idx || !q || !n_matches || !hdr || (cap && !hits)) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
@@ -1394,10 +1487,9 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     const size_t total = o_cd + b_cd;
     if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
     if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total + 16))) return rc;
-    /* the list: [counter 16 B | keys | keys' | weights | weights' | hits | sort temporary] */
-    const size_t tmp_bytes = xgm_all_sort_temp_bytes((size_t)cap_dev);
-    if (tmp_bytes == 0) return xgm_set_error(XGM_E_DEVICE, "radix sort: no temporary storage size");
-    const size_t a_cnt = 0, a_k0 = 16, a_k1 = a_k0 + cap_dev * 8, a_v0 = a_k1 + cap_dev * 8, a_v1 = a_v0 + cap_dev * 8, a_hit = a_v1 + cap_dev * 8;
+    /* the list: [counter 16 B | keys | weights | hits | the ordering's bitmap and prefix counts] */
+    const size_t tmp_bytes = xgm_all_order_bytes(idx->hdr.lastdocid);
+    const size_t a_cnt = 0, a_k0 = 16, a_v0 = a_k0 + cap_dev * 8, a_hit = a_v0 + cap_dev * 8;
     const size_t a_tmp = (a_hit + cap_dev * sizeof(xgm_hit) + 255) & ~(size_t)255, a_total = a_tmp + tmp_bytes;
     if ((rc = grow(&sc->d_all, &sc->cap_all, a_total))) return rc;
     unsigned char* hb = (unsigned char*)sc->h_sorted;
@@ -1413,8 +1505,8 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
     unsigned long long* d_cnt = (unsigned long long*)(sc->d_all + a_cnt);
-    unsigned long long* k0 = (unsigned long long*)(sc->d_all + a_k0), *k1 = (unsigned long long*)(sc->d_all + a_k1);
-    unsigned long long* v0 = (unsigned long long*)(sc->d_all + a_v0), *v1 = (unsigned long long*)(sc->d_all + a_v1);
+    unsigned long long* k0 = (unsigned long long*)(sc->d_all + a_k0);
+    unsigned long long* v0 = (unsigned long long*)(sc->d_all + a_v0);
     idx->last_kernel = "xgm_match_sorted_kernel";
     if ((rc = xgm_launch_match_sorted(L, nullptr, 4u, 0u, nullptr, nullptr, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream, k0, v0, d_cnt, cap_dev))) return rc;
     unsigned long long* h_cnt = (unsigned long long*)(hb + total);
@@ -1443,7 +1535,7 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     }
     if (n == 0) return XGM_OK;
     xgm_hit* d_out = (xgm_hit*)(sc->d_all + a_hit);
-    if ((rc = xgm_all_sort_pack(sc->d_all + a_tmp, tmp_bytes, k0, k1, v0, v1, (size_t)n, d_out, stream))) return rc;
+    if ((rc = xgm_all_order_pack(sc->d_all + a_tmp, idx->hdr.lastdocid, k0, v0, (size_t)n, d_out, stream))) return rc;
     HIP_TRY(hipMemcpyAsync(hits, d_out, (size_t)n * sizeof(xgm_hit), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     hdr->n_hits = (uint32_t)n;
@@ -1459,28 +1551,46 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
 struct XgmBatchReq {
     const xgm_query* q; uint32_t k_stride; xgm_hit* hits; xgm_result_hdr* hdr;
     int rc = 0; bool done = false; char err[192];
+    std::condition_variable cv;                 /* this request's own: a finished batch wakes exactly its callers */
+};
+
+struct XgmFlight {                              /* a launched batch and the requests it answers */
+    xgm_inflight* f = nullptr;
+    std::vector<XgmBatchReq*> reqs;
+    uint32_t ks = 1;
 };
 
 struct XgmBatcher {
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work, cv_flight, cv_room;
     std::deque<XgmBatchReq*> queue;
-    std::thread th;
+    std::deque<XgmFlight*> flights;             /* launched, not yet handed back: at most max_flights */
+    std::thread th, th_done;
     bool stop = false;
     uint32_t max_batch = 256;
+    uint32_t max_flights = 3;
     uint64_t batches = 0, requests = 0;
 };
 
+static void batcher_finish(XgmBatcher* b, XgmBatchReq* r, int rc, const char* err) {
+    std::lock_guard<std::mutex> lk(b->mu);
+    r->rc = rc;
+    if (rc < 0 && err) snprintf(r->err, sizeof r->err, "%s", err);
+    r->done = true;
+    r->cv.notify_one();
+}
+
+/* the dispatcher: whatever has accumulated becomes one batch, launched asynchronously; while it runs the next one fills — and is
+ * launched too (up to max_flights batches in flight, each on its own stream) instead of waiting for the first to finish */
 static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
     std::vector<XgmBatchReq*> take;
     std::vector<xgm_query> qs;
-    std::vector<xgm_hit> hits;
-    std::vector<xgm_result_hdr> hdrs;
     while (true) {
         {
             std::unique_lock<std::mutex> lk(b->mu);
             b->cv_work.wait(lk, [&] { return b->stop || !b->queue.empty(); });
-            if (b->stop && b->queue.empty()) return;
+            if (b->stop && b->queue.empty()) break;
+            b->cv_room.wait(lk, [&] { return b->flights.size() < b->max_flights; });
             take.clear();
             while (!b->queue.empty() && take.size() < b->max_batch) { take.push_back(b->queue.front()); b->queue.pop_front(); }
         }
@@ -1488,31 +1598,65 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
         uint32_t ks = 1;
         qs.resize(n);
         for (uint32_t i = 0; i < n; ++i) { qs[i] = *take[i]->q; ks = std::max(ks, take[i]->k_stride); }
-        hits.resize((size_t)n * ks);
-        hdrs.resize(n);
-        int rc = search_batch_now(idx, qs.data(), n, ks, hits.data(), hdrs.data());
-        if (rc != XGM_OK && n > 1) {
+        XgmFlight* fl = new XgmFlight();
+        fl->reqs = take; fl->ks = ks;
+        int rc = batch_begin(idx, qs.data(), n, ks, &fl->f);
+        if (rc != XGM_OK) {
             /* one query of the batch was declined or failed: answer each on its own so that only that caller sees it */
+            delete fl;
             for (uint32_t i = 0; i < n; ++i) {
-                take[i]->rc = search_batch_now(idx, take[i]->q, 1, take[i]->k_stride, take[i]->hits, take[i]->hdr);
-                if (take[i]->rc < 0) snprintf(take[i]->err, sizeof take[i]->err, "%s", xgm_last_error());
+                const int r1 = n > 1 ? search_batch_now(idx, take[i]->q, 1, take[i]->k_stride, take[i]->hits, take[i]->hdr) : rc;
+                batcher_finish(b, take[i], r1, xgm_last_error());
             }
-        } else {
-            for (uint32_t i = 0; i < n; ++i) {
-                take[i]->rc = rc;
-                if (rc < 0) snprintf(take[i]->err, sizeof take[i]->err, "%s", xgm_last_error());
-                if (rc == XGM_OK) {
-                    *take[i]->hdr = hdrs[i];
-                    memcpy(take[i]->hits, hits.data() + (size_t)i * ks, (size_t)hdrs[i].n_hits * sizeof(xgm_hit));
-                }
-            }
+            std::lock_guard<std::mutex> lk(b->mu);
+            ++b->batches; b->requests += n;
+            continue;
         }
         {
             std::lock_guard<std::mutex> lk(b->mu);
-            for (XgmBatchReq* r : take) r->done = true;
+            b->flights.push_back(fl);
             ++b->batches; b->requests += n;
         }
-        b->cv_done.notify_all();
+        b->cv_flight.notify_one();
+    }
+    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
+    b->cv_flight.notify_all();
+}
+
+/* the completer: waits for the oldest batch in flight, hands every caller its rows, wakes it */
+static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
+    (void)idx;
+    while (true) {
+        XgmFlight* fl = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            b->cv_flight.wait(lk, [&] { return !b->flights.empty() || (b->stop && b->queue.empty()); });
+            if (b->flights.empty()) return;
+            fl = b->flights.front();
+        }
+        const xgm_hit* hh = nullptr;
+        const xgm_result_hdr* hd = nullptr;
+        const int rc = xgm_batch_end(fl->f, &hh, &hd);
+        const std::string err = rc < 0 ? xgm_last_error() : "";
+        const uint32_t n = (uint32_t)fl->reqs.size();
+        if (rc == XGM_OK)
+            for (uint32_t i = 0; i < n; ++i) {
+                *fl->reqs[i]->hdr = hd[i];
+                memcpy(fl->reqs[i]->hits, hh + (size_t)i * fl->ks, (size_t)hd[i].n_hits * sizeof(xgm_hit));
+            }
+        xgm_batch_release(fl->f);
+        {
+            std::lock_guard<std::mutex> lk(b->mu);
+            b->flights.pop_front();
+            for (XgmBatchReq* r : fl->reqs) {
+                r->rc = rc;
+                if (rc < 0) snprintf(r->err, sizeof r->err, "%s", err.c_str());
+                r->done = true;
+                r->cv.notify_one();
+            }
+        }
+        b->cv_room.notify_one();
+        delete fl;
     }
 }
 
@@ -1523,8 +1667,8 @@ static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride,
     {
         std::unique_lock<std::mutex> lk(b->mu);
         b->queue.push_back(&r);
-        b->cv_work.notify_one();
-        b->cv_done.wait(lk, [&] { return r.done; });
+        if (b->queue.size() == 1) b->cv_work.notify_one();
+        r.cv.wait(lk, [&] { return r.done; });
     }
     if (r.rc < 0) return xgm_set_error(r.rc, "%s", r.err);
     return r.rc;
@@ -1535,7 +1679,10 @@ void xgm_batcher_destroy(xgm_index* idx) {
     if (!b) return;
     { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
     b->cv_work.notify_all();
+    b->cv_room.notify_all();
     if (b->th.joinable()) b->th.join();
+    b->cv_flight.notify_all();
+    if (b->th_done.joinable()) b->th_done.join();
     idx->batcher = nullptr;
     delete b;
 }
@@ -1547,8 +1694,11 @@ extern "C" int xgm_index_set_batching(xgm_index* idx, uint32_t max_batch) {
     if (max_batch == 0) return XGM_OK;
     XgmBatcher* b = new XgmBatcher();
     b->max_batch = std::min<uint32_t>(max_batch, 1024u);
+    static const uint32_t flights_env = getenv("XGM_BATCHER_FLIGHTS") ? (uint32_t)std::max(1, atoi(getenv("XGM_BATCHER_FLIGHTS"))) : 3u;   /* A/B switch (1 = rounds 1-3) */
+    b->max_flights = std::min(flights_env, 6u);
     idx->batcher = b;
     b->th = std::thread(batcher_loop, idx, b);
+    b->th_done = std::thread(batcher_done_loop, idx, b);
     return XGM_OK;
 }
 

@@ -36,10 +36,10 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
                             unsigned long long all_cap = 0);
 /* all_keys != NULL (xgm_search_all): every matching document is also appended, in no particular order, to all_keys / all_vals
  * (docid << 32 | weighted leaves matched, weight bits) at the position the zeroed counter *all_count hands out; entries beyond all_cap
- * are counted, not written.  xgm_all_sort_pack (xgm_all.hip) restores docid order. */
-size_t xgm_all_sort_temp_bytes(size_t n);
-int xgm_all_sort_pack(void* tmp, size_t tmp_bytes, unsigned long long* keys, unsigned long long* keys_alt, unsigned long long* vals,
-                      unsigned long long* vals_alt, size_t n, xgm_hit* out, hipStream_t stream);
+ * are counted, not written.  xgm_all_order_pack (xgm_all.hip) restores docid order: tmp = xgm_all_order_bytes(lastdocid) device bytes. */
+size_t xgm_all_order_bytes(uint32_t lastdocid);
+int xgm_all_order_pack(void* tmp, uint32_t lastdocid, const unsigned long long* keys, const unsigned long long* vals, size_t n, xgm_hit* out,
+                       hipStream_t stream);
 /* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
  *  column's ordinals or NULL, cmax = collapse_max) */
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
