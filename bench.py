@@ -201,7 +201,9 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
     from xapiand_amd import _lib
     L = _lib.lib()
     k, bps, depth = leg.k, args.batches_per_step, max(1, args.in_flight)
-    bind_one_stream = os.environ.get("XGM_BENCH_ONE_STREAM") is not None
+    # the batches' kernels run back to back on ONE stream, uploads and downloads on the in-flight batches' own streams (measured, round 4:
+    # 603 k queries/s; with every batch on a stream of its own the kernels overlap and slow each other down: 539 k — XGM_BENCH_MULTI_STREAM=1)
+    bind_one_stream = os.environ.get("XGM_BENCH_MULTI_STREAM") is None
     if world == 1:
         db.set_stream(torch.cuda.current_stream(dev).cuda_stream if bind_one_stream else 0)
     run_steps(db, searcher, leg, warmup, bps, depth, world)
@@ -321,9 +323,9 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
                 "frac": achieved / HBM_PEAK, "basis": basis, "traffic": traffic, "traffic_note": traffic_note,
                 "traffic_lib_sha": lib_sha if traffic else None, "traffic_entries_of_another_build_ignored": stale_traffic,
                 "kernel_ms": kernel_ms,
-                "kernel_ms_note": "mean HIP-event duration of the match kernel over the timed region, where up to %d batches are in flight on "
-                                  "streams of their own: consecutive launches overlap on the chip, so this is the duration of a launch that SHARES "
-                                  "the GPU; kernel_ms_one_in_flight is the same kernel alone" % depth if world == 1 else None,
+                "kernel_ms_note": "mean HIP-event duration of the match kernel over the timed region (up to %d batches in flight; their match kernels run "
+                                  "back to back on one stream, uploads and downloads on streams of their own); kernel_ms_one_in_flight: the same with "
+                                  "one batch in flight" % depth if world == 1 else None,
                 "kernel_ms_one_in_flight": kernel_ms_solo,
                 "frac_one_in_flight": (moved / kts / HBM_PEAK) if kts else None,
                 "whole_timed_region": {"bytes": moved * n_batches_run, "seconds": elapsed, "achieved": moved * n_batches_run / elapsed / 1e9,
@@ -427,8 +429,8 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     info = db.info()
-    # N > 1 / the tally passes: one explicit (non-null) HIP stream for searches and collectives (ShardedSearcher binds the index to
-    # torch's current stream per call).  N = 1 timed region: every batch in flight runs on a stream of its own (no stream bound).
+    # one explicit (non-null) HIP stream for searches and collectives (ShardedSearcher binds the index to torch's current stream per call;
+    # the N = 1 timed region binds it once: the match kernels of the batches in flight run back to back there)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
 

@@ -75,6 +75,7 @@ struct XgmScratch {
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
     unsigned char* d_all = nullptr; size_t cap_all = 0;         /* xgm_search_all: counter, unordered + ordered match lists, the sort's temporary storage */
+    bool arrive_dirty = false;                                  /* a fused launch on this scratch was not enqueued completely: zero the counters before the next */
     uint32_t* d_arrive = nullptr; size_t cap_arrive = 0;        /* per-query arrival counters of a launch that finishes its queries itself (zero between launches) */
     /* pinned host */
     void* h_up = nullptr; size_t cap_up = 0;
@@ -695,8 +696,14 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
               xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, orw_spg) <= 160u * 1024u;
     const bool wave_units = bp->andw || bp->orw;
     /* plain conjunctions over containers only: their units take xgm_dense_unit inside xgm_andw_kernel<uint8_t, false, 0> */
-    if (bp->andw && !bp->phrase && bp->sided == 0 && !bp->wide)
-        for (uint32_t i = 0; i < nq; ++i) if (dense_kind(idx, qs[i], true) == 1) dq[i].flags |= XGM_QF_DENSE;
+    /* ... and positional queries over containers only that prune by weight: xgm_dense_unit<PHRASE> inside the positional instantiation
+     * (XGM_NO_DENSE_PHRASE_BODY: A/B switch, the variant tests) */
+    static const bool no_dense_phrase = getenv("XGM_NO_DENSE_PHRASE_BODY") != nullptr;
+    if (bp->andw && bp->sided == 0 && !bp->wide)
+        for (uint32_t i = 0; i < nq; ++i) {
+            const int dk = dense_kind(idx, qs[i], true);
+            if ((dk == 1 && !bp->phrase) || (dk == 2 && bp->phrase && !no_dense_phrase && (dq[i].flags & XGM_QF_POSPRUNE))) dq[i].flags |= XGM_QF_DENSE;
+        }
     bp->cap = wave_units ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
      * plus about one partial block per stripe a term touches).  Every query is cut into units of
@@ -817,8 +824,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
     /* xgm_andw_kernel merges a query's lists in its last unit, whatever their number (XGM_NO_FUSED_MERGE: A/B switch, the variant tests) */
     static const bool no_fused = getenv("XGM_NO_FUSED_MERGE") != nullptr;
-    static const bool dense_alone = getenv("XGM_DENSE_KERNEL") != nullptr;                         /* (the stand-alone experiment kernel keeps the merge launch) */
-    bp->fused = bp->andw && !no_fused && !dense_alone;
+    bp->fused = bp->andw && !no_fused;                                                             /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
     const uint32_t P = bp->fused ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
     bp->parts = std::max(1u, P);
     const uint32_t upp = bp->parts > 1 ? units_per_part : g_most_q + 1u;
@@ -897,16 +903,19 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
     static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
     if (dense_class_old_kernel) dense = false;
-    const bool fused = bp.fused && !dense;
+    const bool fused = bp.fused;
     {
         unsigned char* din_ = (unsigned char*)s->d_in;
         xgm_fuse fu;
         memset(&fu, 0, sizeof fu);
         if (fused) {
+            /* every launch leaves its counters at zero — unless it failed part-way: the scratch is then marked and zeroed
+             * here before its next use.  (Zeroing before EVERY launch was measured: a fill command between two match kernels adds ~8 us
+             * of stream time per batch, gpurun_out/r04b_*.)  A kernel that FAULTS poisons the HIP context: every later call fails. */
+            const size_t cap_before = s->cap_arrive;
             if ((rc = grow(&s->d_arrive, &s->cap_arrive, (size_t)std::max<uint32_t>(nq, 1024u)))) return rc;
-            /* every launch leaves its counters at zero — unless it failed or was aborted: 4 bytes per query are cheaper
-             * than trusting that, and the memset orders behind the previous launch on the same stream */
-            HIP_TRY(hipMemsetAsync(s->d_arrive, 0, (size_t)nq * sizeof(uint32_t), stream));
+            if (s->cap_arrive != cap_before || s->arrive_dirty) HIP_TRY(hipMemsetAsync(s->d_arrive, 0, s->cap_arrive * sizeof(uint32_t), stream));
+            s->arrive_dirty = true;                          /* until this call has enqueued everything (cleared at its end) */
             /* stress-test switch (tests/test_gpu_stress.py): wipe the units' lists and headers of the previous batch, so that a unit
              * read before it landed shows as missing hits instead of passing for plausible stale ones */
             static const bool poison = getenv("XGM_DEBUG_POISON_SCRATCH") != nullptr;
@@ -1001,6 +1010,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     g_host_ns[7] += now_ns() - t_mk;
     g_host_ns[2] += now_ns() - t_st;
     g_host_ns[3] += 1;
+    s->arrive_dirty = false;
     return XGM_OK;
 }
 
@@ -1122,13 +1132,13 @@ struct xgm_inflight {
     int rc_end = XGM_OK;
 };
 
-static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out) {
+static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out, hipStream_t on = nullptr) {
     *out = nullptr;
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
     if ((rc = scratch_acquire(idx, &s))) return rc;
-    hipStream_t stream = pick_stream(idx, s);
+    hipStream_t stream = on ? on : pick_stream(idx, s);
     do {
         /* hits and headers share one device buffer → one download */
         const size_t n_hit = (size_t)nq * k_stride;
@@ -1566,6 +1576,8 @@ struct XgmBatcher {
     std::deque<XgmBatchReq*> queue;
     std::deque<XgmFlight*> flights;             /* launched, not yet handed back: at most max_flights */
     std::thread th, th_done;
+    hipStream_t stream = nullptr;               /* the flights' match kernels run back to back on ONE stream (kernels of concurrent streams slow each other
+                                                   down: measured 0.53 vs 0.38 ms per 256-query launch); uploads and downloads ride the scratches' own streams */
     bool stop = false;
     uint32_t max_batch = 256;
     uint32_t max_flights = 3;
@@ -1600,7 +1612,7 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
         for (uint32_t i = 0; i < n; ++i) { qs[i] = *take[i]->q; ks = std::max(ks, take[i]->k_stride); }
         XgmFlight* fl = new XgmFlight();
         fl->reqs = take; fl->ks = ks;
-        int rc = batch_begin(idx, qs.data(), n, ks, &fl->f);
+        int rc = batch_begin(idx, qs.data(), n, ks, &fl->f, b->stream);
         if (rc != XGM_OK) {
             /* one query of the batch was declined or failed: answer each on its own so that only that caller sees it */
             delete fl;
@@ -1683,6 +1695,7 @@ void xgm_batcher_destroy(xgm_index* idx) {
     if (b->th.joinable()) b->th.join();
     b->cv_flight.notify_all();
     if (b->th_done.joinable()) b->th_done.join();
+    if (b->stream) { hipStreamSynchronize(b->stream); hipStreamDestroy(b->stream); }
     idx->batcher = nullptr;
     delete b;
 }
@@ -1696,6 +1709,12 @@ extern "C" int xgm_index_set_batching(xgm_index* idx, uint32_t max_batch) {
     b->max_batch = std::min<uint32_t>(max_batch, 1024u);
     static const uint32_t flights_env = getenv("XGM_BATCHER_FLIGHTS") ? (uint32_t)std::max(1, atoi(getenv("XGM_BATCHER_FLIGHTS"))) : 3u;   /* A/B switch (1 = rounds 1-3) */
     b->max_flights = std::min(flights_env, 6u);
+    {
+        int rc = use_device(idx->device);
+        if (rc) { delete b; return rc; }
+        hipError_t e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete b; return xgm_launch_error("hipStreamCreate", (int)e, hipGetErrorString(e)); }
+    }
     idx->batcher = b;
     b->th = std::thread(batcher_loop, idx, b);
     b->th_done = std::thread(batcher_done_loop, idx, b);

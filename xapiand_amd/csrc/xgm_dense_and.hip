@@ -36,12 +36,12 @@ template <bool PHRASE, bool TALLY>
 __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_DENSE_PHRASE_WAVES : XGM_DENSE_WAVES) void xgm_dense_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                               const xgm_work* __restrict__ work, uint32_t n_work, uint32_t k_stride,
                                                               xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out,
-                                                              uint32_t* __restrict__ hist_all) {
+                                                              uint32_t* __restrict__ hist_all, const xgm_fuse* __restrict__ fuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
-    xgm_dense_unit<PHRASE, TALLY>(seg, queries, work[unit], smem + (size_t)wave * dense_wave_bytes(PHRASE), lane, k_stride, cand_out, ghdr_out, hist_all, nullptr);
+    xgm_dense_unit<PHRASE, TALLY>(seg, queries, work[unit], smem + (size_t)wave * dense_wave_bytes(PHRASE), lane, k_stride, cand_out, ghdr_out, hist_all, fuse);
 }
 
 }  // namespace
@@ -57,7 +57,7 @@ template <bool PHRASE, bool TALLY>
 static int launch_dense_inst(const xgm_match_launch& L, hipStream_t stream) {
     const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
     hipLaunchKernelGGL((xgm_dense_kernel<PHRASE, TALLY>), grid, block, xgm_dense_smem_bytes(PHRASE), stream, L.seg, L.queries, L.work, L.n_work, L.k_stride,
-                       L.cand, L.ghdr, L.hist);
+                       L.cand, L.ghdr, L.hist, L.fuse);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("xgm_dense_kernel", (int)e, hipGetErrorString(e));
     return 0;

@@ -800,10 +800,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     const xgm_dev_query& q = queries[wk.qi];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k, SPG = spg_max;
-    if (!PHRASE && SIDED == 0 && (rfl32(q.flags) & XGM_QF_DENSE)) {
-        /* every term has containers: the body written for that case alone (same launch, same outputs) */
-        xgm_dense_unit<false, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
-                                     cand_out, ghdr_out, nullptr, fuse);
+    if (SIDED == 0 && (rfl32(q.flags) & XGM_QF_DENSE)) {
+        /* every term has containers: the body written for that case alone (same launch, same outputs) — plain conjunctions and,
+         * since round 4, positional queries that prune by weight (C5's frequent-term phrases) */
+        xgm_dense_unit<PHRASE, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
+                                      cand_out, ghdr_out, PHRASE ? hist_all : nullptr, fuse);
         return;
     }
     /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not
