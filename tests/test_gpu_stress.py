@@ -83,7 +83,8 @@ def worker():
                 hd = hdrs[i]
                 # a positional query that prunes by weight reports a LOWER BOUND of its match count (include/xgm.h): how many candidates
                 # had their positions tested depends on when the query-wide threshold rose — timing, not semantics; the hits do not
-                m = hd.matches_exact if not (hd.matches_exact >> 63) else (1 << 63)
+                # ... and whether anything was dropped at all (the flag itself) is timing too: positional queries are compared by their hits
+                m = hd.matches_exact if pool[ids[i]]["op"] not in ("PHRASE", "NEAR") else 0
                 h.update(struct.pack("<IIQdd", hd.n_hits, hd.max_weight_subqs_matched, m, hd.max_attained, hd.max_possible))
                 n = hd.n_hits
                 h.update(bytes(memoryview(hits)[i * ks:i * ks + n]))

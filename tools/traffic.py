@@ -14,10 +14,13 @@ import sys
 
 pmc, bench, kern = sys.argv[1:4]
 vals = {}
+names = set()
 for l in open(pmc):
-    m = re.match(r"PMC (.{40}) (\S+)\s+mean (\S+) over (\d+)", l)
+    m = re.match(r"PMC ([^\t]+)\t(\S+)\s+mean (\S+) over (\d+)", l)          # (PMC-TALLY lines: the tallying instantiation, not the product's)
     if m and kern in m.group(1):
+        names.add(m.group(1))
         vals[m.group(2)] = float(m.group(3))
+assert len(names) == 1, "the kernel substring %r matches %d kernels in %s: %s" % (kern, len(names), pmc, sorted(names))
 d = json.load(open(bench))
 r = d["roofline"]
 c = r["model_counts"]
@@ -31,7 +34,7 @@ sha_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None     # the build these counters were taken from (bench.py refuses another)
 print(json.dumps({
     "lib_sha": lib_sha,
-    "kernel": r["kernel"], "op": cfg["op"], "docs_per_gpu": cfg["docs_per_gpu"], "top_k": cfg["top_k"],
+    "kernel": r["kernel"], "kernel_instantiation": sorted(names)[0], "op": cfg["op"], "docs_per_gpu": cfg["docs_per_gpu"], "top_k": cfg["top_k"],
     "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"],
     "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"], "streamed_bytes_model": streamed,
     "hbm_bytes_per_launch": total,
