@@ -232,3 +232,11 @@ def test_byte_compatible_modes_beyond_one_device_page_under_emulation(emu_lib, t
     out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(positional), out
     assert out["answered_on_device"] == len(positional), out
+
+
+def test_flat_led_conjunctions_under_emulation(emu_lib):
+    """xgm_flat_unit and the flat posting arrays (round 4) against the oracle, every path through the tallies, without a GPU."""
+    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_flat.py")],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "2 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])

@@ -202,6 +202,7 @@ static void fill_view(xgm_index* idx) {
     v.lastdocid = idx->hdr.lastdocid;
     v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.dense_plane = 0;
     v.doclen_narrow = nullptr; v.doclen_narrow_bits = 0; v.doclen_base = 0;
+    v.flat_off = nullptr; v.flat_did = nullptr; v.flat_wdf = nullptr;
     v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
@@ -276,6 +277,9 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->d_blob) hipFree(idx->d_blob);
     if (idx->d_dense_id) hipFree(idx->d_dense_id);
     if (idx->d_doclen_narrow) hipFree(idx->d_doclen_narrow);
+    if (idx->d_flat_off) hipFree(idx->d_flat_off);
+    if (idx->d_flat_did) hipFree(idx->d_flat_did);
+    if (idx->d_flat_wdf) hipFree(idx->d_flat_wdf);
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
     for (auto& c : idx->columns) if (c.second.first) hipFree(c.second.first);
@@ -638,6 +642,7 @@ struct BatchPlan {
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
+static bool flat_kind(const xgm_index* idx, const xgm_query& q);
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
                       BatchPlan* bp, bool force_general = false) {
@@ -703,6 +708,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         for (uint32_t i = 0; i < nq; ++i) {
             const int dk = dense_kind(idx, qs[i], true);
             if ((dk == 1 && !bp->phrase) || (dk == 2 && bp->phrase && !no_dense_phrase && (dq[i].flags & XGM_QF_POSPRUNE))) dq[i].flags |= XGM_QF_DENSE;
+            /* ... or led by a long-tail term with a flat posting array: xgm_flat_unit */
+            else if (!bp->phrase && !(dq[i].flags & XGM_QF_EMPTY) && flat_kind(idx, qs[i])) dq[i].flags |= XGM_QF_FLAT;
         }
     bp->cap = wave_units ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
@@ -775,6 +782,16 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         } else if (bp->andw && !bp->phrase) {
             cost[i] = stripes * 28.0 + 0.9 * sparse_blocks + per_cand * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
         }
+        if (dq[i].flags & XGM_QF_FLAT) {
+            /* xgm_flat_unit: rounds of 64 postings of the lead term, whatever stripes they fall in (~3 k cycles a round: two dependent gathers;
+             * a binary search per other term that has no containers) + the unit's prologue */
+            double flat_others = 0;
+            for (uint32_t t = 1; t < qs[i].n_terms; ++t) {
+                const uint32_t id = qs[i].terms[t].term_id;
+                if (id != UINT32_MAX && !(idx->view.n_dense && (uint64_t)idx->term_df[id] >= idx->dense_min_df)) flat_others += 1.0;
+            }
+            cost[i] = 2.0 + (double)idx->term_df[qs[i].terms[0].term_id] / 64.0 * (3.0 + 2.0 * flat_others);
+        }
         if (bp->orw) {
             /* every stripe: the terms' bitmaps / block decodes (twice where candidates remain) and a
              * share of the union that survives the MaxScore pruning */
@@ -795,7 +812,12 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
      * pays a longer prologue per unit) */
     static const double orw_units = getenv("XGM_ORW_UNITS") ? atof(getenv("XGM_ORW_UNITS")) : 8192.0;      /* A/B switch for measurements */
     static const double and_units = getenv("XGM_TARGET_UNITS") ? atof(getenv("XGM_TARGET_UNITS")) : 12288.0;      /* A/B switch for measurements */
-    const double target_units = bp->orw ? orw_units : and_units;
+    /* a SMALL batch (a server's natural batches are a few dozen queries, xgm_index_set_batching) keeps the units-per-query ratio of a
+     * full one instead of the full unit count: a 24-query batch cut into 12 288 units spends more on its work list (196 KB built, staged,
+     * uploaded) and on scheduling 3 072 tiny workgroups than on matching.  XGM_UNITS_PER_QUERY: A/B switch (0 = rounds 1-3). */
+    static const double units_per_query = getenv("XGM_UNITS_PER_QUERY") ? atof(getenv("XGM_UNITS_PER_QUERY")) : 48.0;
+    const double scaled_units = (units_per_query > 0.0 && nq > 4u) ? std::min(and_units, std::max(3072.0, units_per_query * (double)nq)) : and_units;
+    const double target_units = bp->orw ? orw_units : scaled_units;
     double unit_cost = std::max(1.0, total_cost / (wave_units ? target_units : 3072.0));
     if (wave_units) {
         /* the floor of g_min units per query (the LDS table bounds a unit's stripes) eats part of the budget: raise the
@@ -813,8 +835,15 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
      * (stable) orders the units exactly as a stable sort of all of them would */
     std::vector<uint32_t> gqv(nq), spgv(nq), order(nq);
     uint32_t g_most_q = 0;
+    /* positional queries: what a unit costs depends on how soon it holds k matches (until then every candidate's positions are tested),
+     * which the cost model cannot know — a 3-term phrase of frequent terms with few matches ran 2 ms in ONE 30-stripe unit while the
+     * rest of the launch took 0.6 ms (tools/qcost.py, round 4).  A unit of such a query is bounded to XGM_PHRASE_UNIT_STRIPES stripes
+     * when its stripes hold many candidates (the launch ends with its longest unit; more, shorter units cost little). */
+    static const uint32_t phrase_unit_stripes = getenv("XGM_PHRASE_UNIT_STRIPES") ? (uint32_t)atoi(getenv("XGM_PHRASE_UNIT_STRIPES")) : 8u;
     for (uint32_t i = 0; i < nq; ++i) {
         uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
+        if (bp->phrase && bp->andw && phrase_unit_stripes && (dq[i].flags & XGM_QF_DENSE) && nq > 4u)
+            gq = std::max(gq, std::min(g_max, (n_stripes + phrase_unit_stripes - 1u) / phrase_unit_stripes));
         uint32_t spg = (n_stripes + gq - 1) / gq;
         gq = (n_stripes + spg - 1) / spg;
         spg_used = std::max(spg_used, spg);
@@ -1049,6 +1078,25 @@ static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused) {
         if (id == UINT32_MAX || (uint64_t)idx->term_df[id] < idx->dense_min_df || idx->term_wdfub[id] > 254u) return 0;
     }
     return positional ? 2 : 1;
+}
+
+/* xgm_flat_unit's queries (xgm_flat_body.inc): a plain conjunction / FILTER of 2..4 terms, a page of at most 64, whose FIRST plan term — the
+ * rarest: MultiAndPostList order — has no probe containers but a flat posting array, every other term containers or a flat array.  The
+ * criteria are xgm_build_dense's own (xgm_dense.hip: build_containers / build_flat). */
+static bool flat_kind(const xgm_index* idx, const xgm_query& q) {
+    static const bool off = getenv("XGM_NO_FLAT") != nullptr || getenv("XGM_NO_DENSE") != nullptr || getenv("XGM_NO_ANDW") != nullptr ||
+                            getenv("XGM_NO_AND_KERNEL") != nullptr;
+    if (off || !idx->view.flat_off || idx->hdr.stripe_bits > 13u) return false;
+    const uint32_t T = q.n_terms, k = q.first + q.maxitems;
+    if (T < 2u || T > xgm_dense_max_terms() || k == 0u || k > xgm_dense_max_k()) return false;
+    if (!(q.op == XGM_OP_AND || q.op == XGM_OP_FILTER)) return false;
+    for (uint32_t t = 0; t < T; ++t) {
+        const uint32_t id = q.terms[t].term_id;
+        if (id == UINT32_MAX || idx->term_wdfub[id] > 254u || idx->term_df[id] == 0u) return false;
+        const bool dense = idx->view.n_dense && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
+        if (t == 0u && dense) return false;
+    }
+    return true;
 }
 
 static int classify_query(const xgm_index* idx, const xgm_query& q) {

@@ -115,6 +115,36 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
 
 /* *misfit is raised when a length does not fit T above the base (a header whose bounds do not cover its own lengths): the narrow
  * array is then not used — a truncated length would change BM25 weights silently */
+/* flat posting arrays: one wave per term without containers; lane j decodes block j of the term's next 64 blocks on its own (a block of
+ * the long tail holds a dozen postings), a wave prefix sum of the blocks' counts gives every block its place */
+__global__ __launch_bounds__(256) void k_flat_fill(xgm_seg_dev seg, const uint32_t* __restrict__ flat_terms, uint32_t n_flat, const uint64_t* __restrict__ flat_off,
+                                                   uint32_t* __restrict__ out_did, unsigned char* __restrict__ out_wdf) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (w >= n_flat) return;                                       /* (whole waves leave: no barrier below) */
+    const uint32_t t = flat_terms[w];
+    const uint64_t b0 = seg.term_blk[t], b1 = seg.term_blk[t + 1], tw = seg.term_word[t];
+    uint64_t place = flat_off[t];
+    for (uint64_t c = b0; c < b1; c += 64u) {
+        const uint64_t b = c + lane;
+        const uint32_t meta = b < b1 ? seg.blk_meta[b] : 0u;
+        const uint32_t n = b < b1 ? XGM_META_COUNT(meta) : 0u;
+        const uint32_t incl = dn_scan(n);
+        if (n) {
+            const uint32_t bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta), ngw = (n * bwg + 31u) >> 5;
+            const uint32_t* words = seg.words + tw + seg.blk_word[b];
+            uint32_t did = seg.blk_first[b];
+            const uint64_t o = place + incl - n;
+            for (uint32_t i = 0; i < n; ++i) {
+                if (i) did += dn_extract(words, i, bwg) + 1u;
+                out_did[o + i] = did;
+                out_wdf[o + i] = (unsigned char)dn_extract(words + ngw, i, bww);
+            }
+        }
+        place += (uint64_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+}
+
 template <typename T>
 __global__ void k_narrow_doclen(const uint32_t* __restrict__ doclen, uint32_t n, uint32_t base, T* __restrict__ out, uint32_t* __restrict__ misfit) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,8 +186,61 @@ static int build_narrow_doclen(xgm_index* idx) {
     return XGM_OK;
 }
 
+/* Flat posting arrays of the terms without containers (xgm_seg_dev::flat_*): decoded once, here, from the blocks already in HBM. */
+static int build_flat(xgm_index* idx) {
+    idx->view.flat_off = nullptr; idx->view.flat_did = nullptr; idx->view.flat_wdf = nullptr;
+    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf}) if (*p) { hipFree(*p); *p = nullptr; }
+    idx->flat_bytes = 0; idx->flat_postings = 0;
+    /* XGM_NO_DENSE = no acceleration structures at all (the variant tests run the block decode K1 that way); XGM_NO_FLAT: this one off */
+    if (getenv("XGM_NO_DENSE") || getenv("XGM_NO_FLAT")) return XGM_OK;
+    const uint32_t T = idx->hdr.n_terms;
+    std::vector<uint64_t> off((size_t)T + 1, 0);
+    std::vector<uint32_t> terms;
+    uint64_t n = 0;
+    for (uint32_t t = 0; t < T; ++t) {
+        off[t] = n;
+        const bool dense = idx->view.n_dense && (uint64_t)idx->term_df[t] >= idx->dense_min_df && idx->term_wdfub[t] <= 254u;
+        if (!dense && idx->term_df[t] && idx->term_wdfub[t] <= 254u) { n += idx->term_df[t]; terms.push_back(t); }
+    }
+    off[T] = n;
+    if (n == 0) return XGM_OK;
+    int rc = XGM_OK;
+    uint32_t* d_terms = nullptr;
+    DN_TRY(hipMalloc(&idx->d_flat_off, off.size() * 8));
+    DN_TRY(hipMalloc(&idx->d_flat_did, n * 4 + 256));
+    DN_TRY(hipMalloc(&idx->d_flat_wdf, n + 256));
+    DN_TRY(hipMalloc((void**)&d_terms, terms.size() * 4));
+    DN_TRY(hipMemcpy(idx->d_flat_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
+    DN_TRY(hipMemcpy(d_terms, terms.data(), terms.size() * 4, hipMemcpyHostToDevice));
+    DN_TRY(hipMemset((unsigned char*)idx->d_flat_did + n * 4, 0xFF, 256));         /* (a round reads up to 63 entries past a slice's end: sentinels, never used) */
+    DN_TRY(hipMemset((unsigned char*)idx->d_flat_wdf + n, 0, 256));
+    hipLaunchKernelGGL(k_flat_fill, dim3((unsigned)((terms.size() + 3u) / 4u)), dim3(256), 0, 0, idx->view, d_terms, (uint32_t)terms.size(),
+                       (const uint64_t*)idx->d_flat_off, (uint32_t*)idx->d_flat_did, (unsigned char*)idx->d_flat_wdf);
+    DN_TRY(hipGetLastError());
+    DN_TRY(hipDeviceSynchronize());
+    hipFree(d_terms);
+    idx->view.flat_off = (const uint64_t*)idx->d_flat_off;
+    idx->view.flat_did = (const uint32_t*)idx->d_flat_did;
+    idx->view.flat_wdf = (const unsigned char*)idx->d_flat_wdf;
+    idx->flat_postings = n;
+    idx->flat_bytes = off.size() * 8 + n * 5 + 512;
+    idx->device_bytes += idx->flat_bytes;
+    return XGM_OK;
+fail:
+    if (d_terms) hipFree(d_terms);
+    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf}) if (*p) { hipFree(*p); *p = nullptr; }
+    return rc;
+}
+
+static int build_containers(xgm_index* idx);
+
 int xgm_build_dense(xgm_index* idx) {
     if (int rc_ = build_narrow_doclen(idx)) return rc_;
+    if (int rc_ = build_containers(idx)) return rc_;
+    return build_flat(idx);
+}
+
+static int build_containers(xgm_index* idx) {
     idx->view.dense_id = nullptr; idx->view.dense_dir = nullptr; idx->view.dense_data = nullptr;
     idx->view.n_dense = 0; idx->view.dense_plane = 0;
     idx->term_wdfmax.clear();

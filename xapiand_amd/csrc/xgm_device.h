@@ -22,6 +22,8 @@
                                        candidates that can still enter the top k (include/xgm.h, XGM_MATCHES_LOWER_BOUND) */
 #define XGM_QF_DENSE 64u            /* a plain conjunction / FILTER of 2..4 terms that ALL have probe containers, k <= 64: its units run
                                        xgm_dense_unit (xgm_dense_body.inc) inside xgm_andw_kernel */
+#define XGM_QF_FLAT 128u            /* a plain conjunction / FILTER of 2..4 terms, k <= 64, led by a term WITHOUT containers that has a flat posting array
+                                       (every other term: containers or a flat array): its units run xgm_flat_unit (xgm_flat_body.inc) inside xgm_andw_kernel */
 #define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */

@@ -98,6 +98,10 @@ struct xgm_index {
     void* d_dense_dir = nullptr;
     void* d_dense_data = nullptr;
     void* d_doclen_narrow = nullptr;   /* xgm_seg_dev::doclen_narrow */
+    void* d_flat_off = nullptr;        /* flat posting arrays of the terms without containers (xgm_seg_dev::flat_*) */
+    void* d_flat_did = nullptr;
+    void* d_flat_wdf = nullptr;
+    uint64_t flat_bytes = 0, flat_postings = 0;
     uint64_t dense_bytes = 0;
     uint64_t dense_min_df = UINT64_MAX;   /* termfreq from which a term has probe containers */
     void* stream = nullptr;            /* hipStream_t                                                */

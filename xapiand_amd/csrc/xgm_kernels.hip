@@ -124,117 +124,7 @@ __device__ __forceinline__ uint32_t nz_halves(uint32_t x) {
 
 /* ---------------------------------------------------------------- K6: positional filter ------ */
 
-/* ---- K6 fast path: positions staged in the wave's LDS ------------------------------------------------------------
- * lp[(t * kPosFast + j) * 64 + lane] = j-th position (u16) of plan term t in the lane's document; cnt(t) = how many.
- * The same three predicates as above, on LDS data with per-lane cursors packed 5 bits per term into one 64-bit
- * register; every loop over terms is unrolled (T is wave-uniform), so nothing is indexed dynamically in registers.
- * Bank conflicts: lanes l and l' collide only if (j * 32 + l / 2) = (j' * 32 + l' / 2) mod 64 with (j, l/2) != (j', l'/2),
- * which needs l/2 and l'/2 to differ by 32: never. */
-constexpr uint32_t kPosFast = 16;          /* positions per (document, term) the fast path holds: 32 bytes = 2 vector loads */
-
-struct LdsPos {
-    const uint16_t* lp; uint32_t lane;
-    __device__ __forceinline__ uint32_t at(uint32_t t, uint32_t j) const { return lp[(t * kPosFast + j) * 64u + lane]; }
-};
-__device__ __forceinline__ uint32_t cur_get(uint64_t c, uint32_t t) { return (uint32_t)(c >> (5u * t)) & 31u; }
-__device__ __forceinline__ uint64_t cur_set(uint64_t c, uint32_t t, uint32_t v) { return (c & ~(31ull << (5u * t))) | ((uint64_t)v << (5u * t)); }
-
-template <typename CntF>
-__device__ bool lds_phrase_exact(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T) {
-    /* driven from plan term 0 (the rarest term of the collection); the predicate does not depend on the driver */
-    const uint32_t n0 = cnt(0u), p0 = pidx[0];
-    uint64_t cur = 0;
-    for (uint32_t i = 0; i < n0; ++i) {
-        const uint32_t x = L.at(0u, i);
-        if (x < p0) continue;
-        const uint32_t base = x - p0;
-        bool ok = true;
-#pragma unroll
-        for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
-            if (t < T && ok) {
-                const uint32_t want = base + pidx[t], nt = cnt(t);
-                uint32_t c = cur_get(cur, t);
-                while (c < nt && L.at(t, c) < want) ++c;
-                cur = cur_set(cur, t, c);
-                ok = c < nt && L.at(t, c) == want;
-            }
-        }
-        if (ok) return true;
-    }
-    return false;
-}
-
-template <typename CntF>
-__device__ bool lds_phrase_window(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T, uint32_t window) {
-    /* inv[i] = plan term that is the i-th word of the phrase (wave-uniform) */
-    uint32_t inv[XGM_PHRASE_MAX_TERMS];
-#pragma unroll
-    for (uint32_t i = 0; i < XGM_PHRASE_MAX_TERMS; ++i) inv[i] = 0;
-#pragma unroll
-    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t)
-        if (t < T) {
-#pragma unroll
-            for (uint32_t i = 0; i < XGM_PHRASE_MAX_TERMS; ++i) if (pidx[t] == i) inv[i] = t;
-        }
-    const uint32_t n0 = cnt(inv[0]);
-    if (n0 == 0) return false;
-    uint64_t cur = 0;                              /* cursor of phrase word i at bits 5i; all lists start at their first entry */
-    while (true) {
-        const uint32_t base = L.at(inv[0], cur_get(cur, 0u));
-        uint32_t pos = base, b = 0;
-        bool fits = true, out = false;
-#pragma unroll
-        for (uint32_t i = 1; i < XGM_PHRASE_MAX_TERMS; ++i) {
-            if (i < T && fits && !out) {
-                const uint32_t ni = cnt(inv[i]);
-                uint32_t c = cur_get(cur, i);
-                while (c < ni && L.at(inv[i], c) < pos + 1u) ++c;
-                cur = cur_set(cur, i, c);
-                if (c >= ni) { out = true; }
-                else {
-                    pos = L.at(inv[i], c);
-                    b = pos + (T - i);
-                    fits = b - base <= window;
-                }
-            }
-        }
-        if (out) return false;
-        if (fits) return true;
-        const uint32_t want = b - window;
-        uint32_t c0 = cur_get(cur, 0u);
-        while (c0 < n0 && L.at(inv[0], c0) < want) ++c0;
-        if (c0 >= n0) return false;
-        cur = cur_set(cur, 0u, c0);
-    }
-}
-
-template <typename CntF>
-__device__ bool lds_near_window(const LdsPos& L, CntF cnt, uint32_t T, uint32_t window) {
-    uint64_t cur = 0;
-    bool empty = false;
-#pragma unroll
-    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) if (t < T && cnt(t) == 0u) empty = true;
-    if (empty) return false;
-    while (true) {
-        uint32_t lo = 0, lo_v = L.at(0u, cur_get(cur, 0u)), hi_v = lo_v;
-#pragma unroll
-        for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
-            if (t < T) {
-                const uint32_t v = L.at(t, cur_get(cur, t));
-                if (v < lo_v) { lo_v = v; lo = t; }
-                if (v > hi_v) hi_v = v;
-            }
-        }
-        if (hi_v - lo_v < window) return true;
-        const uint32_t want = hi_v - window + 1u, nl = cnt(lo);
-        uint32_t c = cur_get(cur, lo);
-        while (c < nl && L.at(lo, c) < want) ++c;
-        if (c >= nl) return false;
-        cur = cur_set(cur, lo, c);
-    }
-}
-
-struct __attribute__((packed, aligned(2))) Pos8 { uint32_t a, b, c, d; };        /* 8 u16 positions, 2-byte aligned in HBM */
+/* (K6 fast path — positions staged in the wave's LDS, the predicates on LDS data — lives in xgm_posfilter.h: shared with the dense body) */
 
 /* ---------------------------------------------------------------- the match kernel ----------- */
 
@@ -780,6 +670,7 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
 
 #include "xgm_unit_finish.h"
 #include "xgm_dense_body.inc"
+#include "xgm_flat_body.inc"
 
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
@@ -805,6 +696,12 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
          * since round 4, positional queries that prune by weight (C5's frequent-term phrases) */
         xgm_dense_unit<PHRASE, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
                                       cand_out, ghdr_out, PHRASE ? hist_all : nullptr, fuse);
+        return;
+    }
+    if (!PHRASE && SIDED == 0 && (rfl32(q.flags) & XGM_QF_FLAT)) {
+        /* led by a long-tail term: its flat posting array is streamed 64 postings per round (same launch, same outputs) */
+        xgm_flat_unit<TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
+                             cand_out, ghdr_out, fuse);
         return;
     }
     /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not

@@ -107,6 +107,15 @@ typedef struct {
     uint32_t doclen_narrow_bits, doclen_base;
     uint32_t dense_plane;           /* byte offset inside a container of u32 bits2[W/32]: the documents whose wdf is >= 2 — the disjunction's
                                        weight bound of a (document, term) is then the wdf = 1 bound or the term's maximum (0: no plane) */
+    /* Flat posting arrays (round 4; built in HBM next to the containers, never stored): every term WITHOUT containers (the long tail:
+     * under XGM_DENSE_MIN_AVG postings per stripe) whose wdf fits a byte also exists decoded — docids ascending, one wdf byte each,
+     * 5 bytes per posting (1.9 GB for the 375 M such postings of the 10 M-document corpus).  Stripe alignment leaves such a term ~1 block
+     * of a dozen postings per stripe it touches, and a conjunction led by it paid a header + payload round trip per stripe for a handful
+     * of candidates (41 % of C2's wave cycles, tools/qcost.py); from the flat array a unit streams the term's postings of its docid range
+     * 64 per round, whatever stripes they fall in (xgm_flat_unit).  flat_off[t] .. flat_off[t + 1]: the term's slice (empty: no array). */
+    const uint64_t* flat_off;       /* [n_terms + 1] or NULL */
+    const uint32_t* flat_did;
+    const unsigned char* flat_wdf;
 } xgm_seg_dev;
 
 #define XGM_DENSE_MIN_AVG 32u          /* postings per stripe (on average) that make a term dense     */
