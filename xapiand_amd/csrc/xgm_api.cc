@@ -75,6 +75,7 @@ struct XgmScratch {
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
     unsigned char* d_all = nullptr; size_t cap_all = 0;         /* xgm_search_all: counter, unordered + ordered match lists, the sort's temporary storage */
+    bool inorder = false;                                       /* this batch's upload and download go on the batch's stream (the dispatcher's small batches: fewer HIP calls) */
     bool arrive_dirty = false;                                  /* a fused launch on this scratch was not enqueued completely: zero the counters before the next */
     uint32_t* d_arrive = nullptr; size_t cap_arrive = 0;        /* per-query arrival counters of a launch that finishes its queries itself (zero between launches) */
     /* pinned host */
@@ -124,6 +125,7 @@ static int scratch_acquire(xgm_index* idx, XgmScratch** out) {
             XgmScratch* c = pool[i];
             if (!c->pending || hipEventQuery(c->ev_done) == hipSuccess) {
                 c->pending = false;
+                c->inorder = false;
                 pool.erase(pool.begin() + (ptrdiff_t)i);
                 *out = c;
                 break;
@@ -142,6 +144,7 @@ static int scratch_acquire(xgm_index* idx, XgmScratch** out) {
     if (wait_for) {
         hipEventSynchronize(wait_for->ev_done);
         wait_for->pending = false;
+        wait_for->inorder = false;
         *out = wait_for;
         return XGM_OK;
     }
@@ -816,7 +819,8 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
      * full one instead of the full unit count: a 24-query batch cut into 12 288 units spends more on its work list (196 KB built, staged,
      * uploaded) and on scheduling 3 072 tiny workgroups than on matching.  XGM_UNITS_PER_QUERY: A/B switch (0 = rounds 1-3). */
     static const double units_per_query = getenv("XGM_UNITS_PER_QUERY") ? atof(getenv("XGM_UNITS_PER_QUERY")) : 48.0;
-    const double scaled_units = (units_per_query > 0.0 && nq > 4u) ? std::min(and_units, std::max(3072.0, units_per_query * (double)nq)) : and_units;
+    static const double units_floor = getenv("XGM_UNITS_FLOOR") ? atof(getenv("XGM_UNITS_FLOOR")) : 3072.0;                     /* A/B switch */
+    const double scaled_units = (units_per_query > 0.0 && nq > 4u) ? std::min(and_units, std::max(units_floor, units_per_query * (double)nq)) : and_units;
     const double target_units = bp->orw ? orw_units : scaled_units;
     double unit_cost = std::max(1.0, total_cost / (wave_units ? target_units : 3072.0));
     if (wave_units) {
@@ -837,9 +841,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     uint32_t g_most_q = 0;
     /* positional queries: what a unit costs depends on how soon it holds k matches (until then every candidate's positions are tested),
      * which the cost model cannot know — a 3-term phrase of frequent terms with few matches ran 2 ms in ONE 30-stripe unit while the
-     * rest of the launch took 0.6 ms (tools/qcost.py, round 4).  A unit of such a query is bounded to XGM_PHRASE_UNIT_STRIPES stripes
-     * when its stripes hold many candidates (the launch ends with its longest unit; more, shorter units cost little). */
-    static const uint32_t phrase_unit_stripes = getenv("XGM_PHRASE_UNIT_STRIPES") ? (uint32_t)atoi(getenv("XGM_PHRASE_UNIT_STRIPES")) : 8u;
+     * rest of the launch took 0.6 ms (tools/qcost.py, round 4, BEFORE the dense body tested survivors from LDS-staged positions).  A/B switch:
+     * XGM_PHRASE_UNIT_STRIPES = n bounds a unit of such a query to n stripes (0 = off, the default). */
+    static const uint32_t phrase_unit_stripes = getenv("XGM_PHRASE_UNIT_STRIPES") ? (uint32_t)atoi(getenv("XGM_PHRASE_UNIT_STRIPES")) : 0u;   /* (measured with the LDS-staged positional test in place: C5 113.3 k queries/s unbounded, 109.5 k at 8 stripes, 100.9 k at 4: off) */
     for (uint32_t i = 0; i < nq; ++i) {
         uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
         if (bp->phrase && bp->andw && phrase_unit_stripes && (dq[i].flags & XGM_QF_DENSE) && nq > 4u)
@@ -960,7 +964,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     }
     const uint64_t t_cp = now_ns();
     g_host_ns[4] += t_cp - t_st;
-    if (stream != s->stream) {
+    if (stream != s->stream && !s->inorder) {
         /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
          * kernels of the previous batch still running on the caller's stream */
         HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, s->stream));
@@ -1180,13 +1184,14 @@ struct xgm_inflight {
     int rc_end = XGM_OK;
 };
 
-static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out, hipStream_t on = nullptr) {
+static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out, hipStream_t on = nullptr, bool inorder = false) {
     *out = nullptr;
     int rc = use_device(idx->device);
     if (rc) return rc;
     XgmScratch* s;
     if ((rc = scratch_acquire(idx, &s))) return rc;
     hipStream_t stream = on ? on : pick_stream(idx, s);
+    s->inorder = inorder;
     do {
         /* hits and headers share one device buffer → one download */
         const size_t n_hit = (size_t)nq * k_stride;
@@ -1200,7 +1205,7 @@ static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_
          * (XGM_COPY_ON_BATCH_STREAM=1: A/B switch, the copy in stream order) */
         static const bool copy_in_order = getenv("XGM_COPY_ON_BATCH_STREAM") != nullptr;
         hipError_t e = hipSuccess;
-        if (stream != s->stream && !copy_in_order) {
+        if (stream != s->stream && !copy_in_order && !s->inorder) {
             e = hipEventRecord(s->ev1, stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev1, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(s->h_down, s->d_hits, down, hipMemcpyDeviceToHost, s->stream);
@@ -1660,7 +1665,10 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
         for (uint32_t i = 0; i < n; ++i) { qs[i] = *take[i]->q; ks = std::max(ks, take[i]->k_stride); }
         XgmFlight* fl = new XgmFlight();
         fl->reqs = take; fl->ks = ks;
-        int rc = batch_begin(idx, qs.data(), n, ks, &fl->f, b->stream);
+        /* the dispatcher's batches are small (a few dozen queries: the GPU is not the bottleneck, the calls per batch are): upload, match and
+         * download in stream order — four HIP calls fewer than with the copies on streams of their own (XGM_BATCHER_COPY_STREAMS=1: A/B) */
+        static const bool copy_streams = getenv("XGM_BATCHER_COPY_STREAMS") != nullptr;
+        int rc = batch_begin(idx, qs.data(), n, ks, &fl->f, b->stream, !copy_streams);
         if (rc != XGM_OK) {
             /* one query of the batch was declined or failed: answer each on its own so that only that caller sees it */
             delete fl;
