@@ -230,9 +230,9 @@ int xgm_index_set_stream(xgm_index*, void* hip_stream);
  * src/database/handler.cc:1338).  With max_batch > 0, single-query calls (xgm_search, xgm_search_batch / xgm_get_mset_batch
  * with nq == 1) from any number of threads are queued and a dispatcher thread owned by the index launches whatever has
  * accumulated — up to max_batch queries, of any mix of shapes — as one batch, then returns each caller its own hits and
- * return code.  No timer: while one batch runs the next one fills — and is launched as soon as the dispatcher has cut it (up to three
- * batches in flight, each on its own stream; a completer thread hands the rows back and wakes exactly the callers of the finished
- * batch).  max_batch == 0 switches it off (the default).  Like
+ * return code.  No timer: while one batch runs the next one fills — and is launched as soon as the dispatcher has cut it (two
+ * batches in flight, their kernels back to back on one stream; a completer thread hands the rows back and wakes exactly the callers of
+ * the finished batch; a small batch keeps the units-per-query ratio of a full one).  max_batch == 0 switches it off (the default).  Like
  * xgm_index_open / xgm_index_close the call is externally serialised with searches on the index (the matcher hook makes it once, when
  * a shard is registered). */
 int xgm_index_set_batching(xgm_index*, uint32_t max_batch);

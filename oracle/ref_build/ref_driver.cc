@@ -52,6 +52,9 @@
 
 #include "xgm_corpus.h"
 
+/* Xapiand's own key maker (oracle/ref_build/xapiand_classes.cc; linked into xapian_hook_b1 only: weak here) */
+const Xapian::KeyMaker* xapiand_keymaker(unsigned variant, bool reverse) __attribute__((weak));
+
 namespace {
 
 struct QuerySpec {
@@ -242,6 +245,12 @@ const Xapian::KeyMaker* driver_keymaker(unsigned slot) {
 
 void apply_settings(Xapian::Enquire& enq, const QuerySpec* q) {
     if (!q) return;
+    /* "XR": Multi_MultiValueKeyMaker through Enquire::set_sort_by_key_then_relevance(sorter, false) — exactly Xapiand's call
+     * (src/database/handler.cc:1269); the direction lives inside the key */
+    if (q->sort_mode == "XR") {
+        if (!xapiand_keymaker) { fprintf(stderr, "SORT=XR needs the build with Xapiand's classes (xapian_hook_b1)\n"); exit(2); }
+        enq.set_sort_by_key_then_relevance(const_cast<Xapian::KeyMaker*>(xapiand_keymaker(q->sort_slot, q->sort_reverse != 0)), false);
+    }
     /* "K" / "KR" / "RK": Enquire::set_sort_by_key / _key_then_relevance (what Xapiand calls, handler.cc:1269) / _relevance_then_key */
     if (q->sort_mode == "K") enq.set_sort_by_key(const_cast<Xapian::KeyMaker*>(driver_keymaker(q->sort_slot)), q->sort_reverse != 0);
     else if (q->sort_mode == "KR") enq.set_sort_by_key_then_relevance(const_cast<Xapian::KeyMaker*>(driver_keymaker(q->sort_slot)), q->sort_reverse != 0);
@@ -349,9 +358,21 @@ int cmd_build(int argc, char** argv) {
         }
         if (with_values) {
             char vb[16];
+            std::vector<std::string> have;
             for (uint32_t slot = 0; slot < 3; ++slot) {
                 const uint32_t n = xgm_doc_value(&cp, g, slot, vb);
-                if (n) doc.add_value(slot, std::string(vb, n));
+                if (n) { doc.add_value(slot, std::string(vb, n)); have.emplace_back(vb, n); }
+            }
+            /* slot 3: the document's values once more the way XAPIAND stores a multi-valued field — a StringList, ascending: one value as it
+             * is, several as '\0' + (length, bytes)... (reference src/serialise_list.h:318-327; serialise_length of < 255 is one byte,
+             * src/length.cc:40-46) — what Multi_MultiValueKeyMaker's SerialiseKey reads (src/multivalue/keymaker.cc:66-92) */
+            std::sort(have.begin(), have.end());
+            have.erase(std::unique(have.begin(), have.end()), have.end());
+            if (have.size() == 1) doc.add_value(3, have[0]);
+            else if (have.size() > 1) {
+                std::string sl(1, '\0');
+                for (const std::string& v : have) { sl += (char)(unsigned char)v.size(); sl += v; }
+                doc.add_value(3, sl);
             }
         }
         db.add_document(doc);

@@ -240,3 +240,24 @@ def test_flat_led_conjunctions_under_emulation(emu_lib):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_flat.py")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "2 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+
+
+def test_xapiand_own_keymaker_under_emulation(emu_lib, tmp_path):
+    """Xapiand's own Multi_MultiValueKeyMaker (compiled from the reference's sources into the hook driver) in front of the hook, without a GPU:
+    hook on == hook off incl. the class's key strings."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import test_gpu_hook_b1 as T
+    if not (H.have_xapian_ref() and os.path.exists(T.HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    alias = tmp_path / "lib"
+    alias.mkdir()
+    os.symlink(emu_lib, str(alias / "libxgm.so"))
+    one = str(tmp_path / "one")
+    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), 6000, T.VOCAB, 50, 150)
+    qs = T.xapiand_keymaker_queries()[::2]
+    qf = str(tmp_path / "qx.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
+    assert out["answered_sorted"] == len(qs) and out["http_total_equal"] == len(qs), out

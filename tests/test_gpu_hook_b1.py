@@ -165,6 +165,34 @@ def test_value_and_key_sorts_and_spies_through_the_hook(built, glass_values):
     assert 3 <= out["columns_built"] <= 6, out            # one column per value slot / key maker and shard revision, built once
 
 
+def xapiand_keymaker_queries():
+    """Sorted by Xapiand's OWN key maker: Multi_MultiValueKeyMaker (reference src/multivalue/keymaker.h:366; compiled from the reference's
+    sources into the driver, oracle/ref_build/xapiand_classes.cc) through Enquire::set_sort_by_key_then_relevance(sorter, false) — the
+    call DocMatcher makes (src/database/handler.cc:1269): one SerialiseKey over the multi-valued slot 3 (smallest / largest value of the
+    document's StringList), alone or followed by a second field in the other direction; forward and reverse."""
+    base = (H.gen_term_queries("OR", 12, 3, 1, 400, maxitems=10, seed=161) + H.gen_term_queries("AND", 12, 2, 1, 60, maxitems=10, seed=162) +
+            H.gen_sided_queries("AND_MAYBE", 4, 1, 2, 1, 200, maxitems=10, seed=163) + H.gen_term_queries("OR", 4, 5, 1, 3000, first=7, maxitems=43, seed=165) +
+            H.gen_tree_queries(6, 1, 300, seed=166))
+    return [dict(q, sort=("XR", i % 4, i % 3 == 0)) for i, q in enumerate(base)]
+
+
+def test_xapiand_own_keymaker_through_the_hook(built, glass_values):
+    """the hook in front of the reference's REAL sort class, not a stand-in written for the test: hook on == hook off —
+    docids, weight bits, percentages, sort keys (the class's own key strings), match-count figures — every search answered on the device,
+    the column built once per (key maker serialisation, shard revision) from the keys the class itself makes."""
+    d, one, shards = glass_values
+    qs = xapiand_keymaker_queries()
+    qf = str(d / "qx1.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] == len(qs) and out["answered_sorted"] == len(qs), out
+    assert out["http_total_equal"] == len(qs), out                 # the key leads the sort: every figure is the CPU matcher's
+    assert 2 <= out["columns_built"] <= 8, out                     # (variant, direction) pairs: distinct serialisations of the class
+    out3 = run_b1(qf, *shards)
+    assert out3["mismatches"] == 0 and out3["answered_on_device"] == 3 * len(qs), out3
+
+
 def test_sorts_through_the_hook_xapiand_protocol(built, glass_values):
     d, _, shards = glass_values
     qs, n_sorted = sorted_queries()
