@@ -24,7 +24,8 @@ json.dump({"entries":ents}, open('profiles/traffic.json','w'), indent=1)      # 
 json.dump({"entries":ents}, open('gpurun_out/${tag}_traffic.json','w'), indent=1)
 for e in ents: print('traffic',e['op'],e['kernel'],round(e['hbm_bytes_per_launch']/1e9,3),'GB/launch')
 PY
-cp gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_first.json 2>/dev/null; timeout 1700 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err
+# (XGM_FINAL_NO_BENCH=1: the headline line is taken afterwards by tools/final_a.sh, with profiles/traffic.json = gpurun_out/${tag}_traffic.json in place)
+if [ -z "$XGM_FINAL_NO_BENCH" ]; then cp gpurun_out/${tag}_bench.json gpurun_out/${tag}_bench_first.json 2>/dev/null; timeout 1700 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; tail -c 300 gpurun_out/${tag}_bench.err; fi
 # (C3 / C5: sub-legs of the default line since round 4 — other_configs — with parity and PMC-stamped rooflines)
 # the merge launch instead of the last-unit merge, for the record (same build, same box)
 XGM_NO_FUSED_MERGE=1 timeout 300 python bench.py --no-cpu-baseline --no-other-configs --threads 0 > gpurun_out/${tag}_bench_merge_launch.json 2>/dev/null
@@ -44,6 +45,8 @@ for f in sorted(glob.glob('gpurun_out/${tag}_bench*.json')):
         d=json.load(open(f)); r=d['roofline']; c=d.get('cpu_baseline',{})
         print(f.split('/')[-1],round(d['value']),r['kernel'],'kernel_ms',round(r['kernel_ms'],3),'p50',d['p50_latency_us'],'frac',round(r['frac'],3),r['basis'],'model',r['model_frac'] and round(r['model_frac'],3),'alg',round(r['algorithmic']['frac'],3),'parity',c.get('parity_checked_queries'),'cpu',c.get('kind'),c.get('value'))
     except Exception as e: print(f,'failed',e)
-d=json.load(open('gpurun_out/${tag}_bench.json')); print(json.dumps(d.get('server_mode'))); print(json.dumps({k:v for k,v in d['cpu_baseline'].items() if k!='sample'})[:1500])
+try:
+    d=json.load(open('gpurun_out/${tag}_bench.json')); print(json.dumps(d.get('server_mode'))); print(json.dumps({k:v for k,v in d['cpu_baseline'].items() if k!='sample'})[:1500])
+except Exception as e: print('no headline line in this call', e)
 PY
 find gpurun_out/${tag}_prof_* -name "*kernel_stats.csv" | head
