@@ -997,7 +997,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     auto score_candidates = [&](uint32_t n_c, bool dl_ready) {
         if (PHRASE && hist_g) look_at_histogram();
         for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
-            if (tkn + 64u > cap || (PHRASE && pos_prune && !theta_valid && tkn >= k)) {      /* (positional pruning wants its threshold as soon as k matches are held) */
+            if (__builtin_expect(tkn + 64u > cap || (PHRASE && pos_prune && !theta_valid && tkn >= k), 0)) {      /* (positional pruning wants its threshold as soon as k matches are held; rare: spills stay out of the loops) */
                 if (MAYBE) wave_topk_sort_m(tk_w, tk_d, tk_m, cap, lane); else wave_topk_sort(tk_w, tk_d, cap, lane);
                 tkn = tkn < k ? tkn : k;
                 if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
@@ -1104,7 +1104,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                          : (q.flags & XGM_QF_EXACT) ? lds_phrase_exact(L, cnt, q.phrase_index, T)
                                                     : lds_phrase_window(L, cnt, q.phrase_index, T, q.window);
                 }
-                if (__ballot(pass && slow)) {
+                if (__builtin_expect(__ballot(pass && slow) != 0ull, 0)) {
                     /* (the loop over the terms is wave-uniform, only the stores and the test are per lane: a lane whose document
                      * takes the serial path reads the terms' registers together with the lanes that do not) */
                     PosList pl[XGM_PHRASE_MAX_TERMS];
