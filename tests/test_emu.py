@@ -239,7 +239,7 @@ def test_flat_led_conjunctions_under_emulation(emu_lib):
     env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_flat.py")],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "2 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "3 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
 
 
 def test_xapiand_own_keymaker_under_emulation(emu_lib, tmp_path):

@@ -57,3 +57,42 @@ def test_flat_led_conjunctions_vs_oracle(built, tmp_path, stripe_bits):
         assert [(h.docid, h.weight) for h in h1] == [(h.docid, h.weight) for h in hits] and hdr1.matches_exact == hdr.matches_exact, q
     db.close()
     c.close()
+
+
+def test_flat_led_positional_queries_vs_oracle(built, tmp_path):
+    """PHRASE / windowed PHRASE / NEAR led by a long-tail term (xgm_flat_unit<PHRASE>): the lead term's flat postings streamed, the other terms
+    from containers or their own flat slices, candidates weighed first, survivors' positions (flat_pos of the flat terms, bucket bases of the
+    container terms) tested from LDS — hits bit-equal to the oracle, match counts exact or a flagged lower bound; the same with
+    check_at_least asking for the exact count (then the queue path answers: every candidate's positions are tested)."""
+    n_docs, vocab = (6000, 12000) if QUICK else (120000, 100000)
+    c = H.Corpus(n_docs, vocab)
+    db = Database(c.build_segment(str(tmp_path / "p.seg")))
+    L = _lib.lib()
+    n = (lambda full, quick: quick if QUICK else full)
+    qs = (H.gen_phrase_queries(n(160, 24), n_docs, vocab, seed=31, lengths=(2, 3)) + H.gen_phrase_queries(n(48, 8), n_docs, vocab, seed=32, window_extra=3) +
+          H.gen_phrase_queries(n(48, 8), n_docs, vocab, seed=33, window_extra=4, op="NEAR") + H.gen_phrase_queries(n(24, 6), n_docs, vocab, seed=34, lengths=(4,)))
+    for i, q in enumerate(qs):
+        q["first"], q["maxitems"] = [(0, 10), (0, 10), (2, 5), (0, 64), (0, 1)][i % 5]
+    plans = [plan(db, Query(q["op"], q["terms"], window=q.get("window", 0)), q["first"], q["maxitems"]) for q in qs]
+    db.set_profiling(2)
+    got = search_batch(db, plans)
+    tl = (C.c_uint64 * 10)()
+    assert L.xgm_last_batch_traffic(db._h, tl, 10) == 0
+    db.set_profiling(0)
+    n_hits = 0
+    for q, (hits, hdr) in zip(qs, got):
+        want, oh = H.oracle_search(c, q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0))
+        assert [(h.docid, h.weight, h.subqs_matched) for h in hits] == want, q
+        H.check_matches(hdr.matches_exact, oh.matches, len(hits), q)
+        n_hits += len(want)
+    assert n_hits > (40 if QUICK else 600), n_hits
+    if not any(os.environ.get(v) for v in ("XGM_NO_FLAT", "XGM_NO_DENSE", "XGM_NO_FLAT_PHRASE", "XGM_NO_DENSE_PHRASE_BODY", "XGM_NO_POS_PRUNE", "XGM_NO_PHRASEW")):
+        assert tl[2] == 0 and tl[3] == 0, list(tl)            # every query took one of the two bodies: no block decoded
+    # exact counts asked for: the same hits, the exact number of positional matches
+    for q in qs[::5]:
+        p = plan(db, Query(q["op"], q["terms"], window=q.get("window", 0)), q["first"], q["maxitems"], check_at_least=H.EXACT_COUNT)
+        (hits, hdr), = search_batch(db, [p])
+        want, oh = H.oracle_search(c, q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0))
+        assert [(h.docid, h.weight) for h in hits] == [(d, w) for d, w, _ in want] and hdr.matches_exact == oh.matches, q
+    db.close()
+    c.close()

@@ -26,7 +26,7 @@ PHRASE_SELECT = "phrase or other_stripe_widths or edge_cases"
                                            ("XGM_NO_FUSED_MERGE", SELECT + " or phrase or sided"),
                                            # round 4: conjunctions led by a long-tail term through the queue path again (no flat arrays); positional
                                            # all-container queries through xgm_andw_kernel's own positional path again
-                                           ("XGM_NO_FLAT", SELECT), ("XGM_NO_DENSE_PHRASE_BODY", PHRASE_SELECT),
+                                           ("XGM_NO_FLAT", SELECT + " or phrase"), ("XGM_NO_DENSE_PHRASE_BODY", PHRASE_SELECT), ("XGM_NO_FLAT_PHRASE", PHRASE_SELECT),
                                            # the disjunction's guess of the k-th weight far too high: every unit must go round again
                                            # below it (second pass) and still skip what the first pass weighed; and a little too high
                                            ("XGM_OR_SEED_SCALE=8", SELECT), ("XGM_OR_SEED_SCALE=1.3", SELECT)])

@@ -205,7 +205,7 @@ static void fill_view(xgm_index* idx) {
     v.lastdocid = idx->hdr.lastdocid;
     v.dense_id = nullptr; v.dense_dir = nullptr; v.dense_data = nullptr; v.n_dense = 0; v.dense_pos = 0; v.dense_plane = 0;
     v.doclen_narrow = nullptr; v.doclen_narrow_bits = 0; v.doclen_base = 0;
-    v.flat_off = nullptr; v.flat_did = nullptr; v.flat_wdf = nullptr;
+    v.flat_off = nullptr; v.flat_did = nullptr; v.flat_wdf = nullptr; v.flat_pos = nullptr;
     v.n_stripes = (idx->hdr.lastdocid >> idx->hdr.stripe_bits) + 1u;
 }
 
@@ -283,6 +283,7 @@ extern "C" void xgm_index_close(xgm_index* idx) {
     if (idx->d_flat_off) hipFree(idx->d_flat_off);
     if (idx->d_flat_did) hipFree(idx->d_flat_did);
     if (idx->d_flat_wdf) hipFree(idx->d_flat_wdf);
+    if (idx->d_flat_pos) hipFree(idx->d_flat_pos);
     if (idx->d_dense_dir) hipFree(idx->d_dense_dir);
     if (idx->d_dense_data) hipFree(idx->d_dense_data);
     for (auto& c : idx->columns) if (c.second.first) hipFree(c.second.first);
@@ -711,9 +712,20 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         for (uint32_t i = 0; i < nq; ++i) {
             const int dk = dense_kind(idx, qs[i], true);
             if ((dk == 1 && !bp->phrase) || (dk == 2 && bp->phrase && !no_dense_phrase && (dq[i].flags & XGM_QF_POSPRUNE))) dq[i].flags |= XGM_QF_DENSE;
-            /* ... or led by a long-tail term with a flat posting array: xgm_flat_unit */
-            else if (!bp->phrase && !(dq[i].flags & XGM_QF_EMPTY) && flat_kind(idx, qs[i])) dq[i].flags |= XGM_QF_FLAT;
+            /* ... or led by a long-tail term with a flat posting array: xgm_flat_unit (positional queries: those that prune by weight) */
+            else if (!(dq[i].flags & XGM_QF_EMPTY) && flat_kind(idx, qs[i]) && (!bp->phrase || (dq[i].flags & XGM_QF_POSPRUNE)) &&
+                     ((qs[i].op == XGM_OP_PHRASE || qs[i].op == XGM_OP_NEAR) ? bp->phrase : !bp->phrase))
+                dq[i].flags |= XGM_QF_FLAT;
         }
+    /* the bodies live in the first bytes of xgm_andw_kernel's per-wave LDS slice: flagged only where they fit (they do for any batch the
+     * wave kernel takes: its positional slice holds its own staging area of tab_terms x 2 KiB) */
+    if (bp->andw && bp->sided == 0 && !bp->wide) {
+        const size_t slice = xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, 32u, bp->phrase, false) / XGM_WAVES;
+        for (uint32_t i = 0; i < nq; ++i) {
+            if ((dq[i].flags & XGM_QF_FLAT) && xgm_body_wave_bytes(true, bp->phrase, dq[i].n_terms) > slice) dq[i].flags &= ~XGM_QF_FLAT;
+            if ((dq[i].flags & XGM_QF_DENSE) && xgm_body_wave_bytes(false, bp->phrase, dq[i].n_terms) > slice) dq[i].flags &= ~XGM_QF_DENSE;
+        }
+    }
     bp->cap = wave_units ? std::max(128u, next_pow2(bp->k_max + 64u)) : std::max(512u, next_pow2(bp->k_max + XGM_WG));
     /* Work decomposition.  Cost model of a query: the posting blocks its terms own (df/128 full blocks
      * plus about one partial block per stripe a term touches).  Every query is cut into units of
@@ -1093,12 +1105,18 @@ static bool flat_kind(const xgm_index* idx, const xgm_query& q) {
     if (off || !idx->view.flat_off || idx->hdr.stripe_bits > 13u) return false;
     const uint32_t T = q.n_terms, k = q.first + q.maxitems;
     if (T < 2u || T > xgm_dense_max_terms() || k == 0u || k > xgm_dense_max_k()) return false;
-    if (!(q.op == XGM_OP_AND || q.op == XGM_OP_FILTER)) return false;
+    const bool positional = (q.op == XGM_OP_PHRASE || q.op == XGM_OP_NEAR) && q.phrase_active;
+    if (!(q.op == XGM_OP_AND || q.op == XGM_OP_FILTER || positional)) return false;
+    /* positional: the flat arrays carry position offsets, the containers position bases; only queries that prune by weight (XGM_QF_POSPRUNE) */
+    static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr, no_phrase_w = getenv("XGM_NO_PHRASEW") != nullptr,
+                      no_flat_phrase = getenv("XGM_NO_FLAT_PHRASE") != nullptr;
+    if (positional && (no_pos_prune || no_phrase_w || no_flat_phrase || !idx->view.flat_pos || q.check_at_least > k)) return false;
     for (uint32_t t = 0; t < T; ++t) {
         const uint32_t id = q.terms[t].term_id;
         if (id == UINT32_MAX || idx->term_wdfub[id] > 254u || idx->term_df[id] == 0u) return false;
         const bool dense = idx->view.n_dense && (uint64_t)idx->term_df[id] >= idx->dense_min_df;
         if (t == 0u && dense) return false;
+        if (positional && dense && !idx->view.dense_pos) return false;
     }
     return true;
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_dense_fill(xgm_seg_dev seg, const uint3
 /* flat posting arrays: one wave per term without containers; lane j decodes block j of the term's next 64 blocks on its own (a block of
  * the long tail holds a dozen postings), a wave prefix sum of the blocks' counts gives every block its place */
 __global__ __launch_bounds__(256) void k_flat_fill(xgm_seg_dev seg, const uint32_t* __restrict__ flat_terms, uint32_t n_flat, const uint64_t* __restrict__ flat_off,
-                                                   uint32_t* __restrict__ out_did, unsigned char* __restrict__ out_wdf) {
+                                                   uint32_t* __restrict__ out_did, unsigned char* __restrict__ out_wdf, uint32_t* __restrict__ out_pos) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= n_flat) return;                                       /* (whole waves leave: no barrier below) */
@@ -134,11 +134,14 @@ __global__ __launch_bounds__(256) void k_flat_fill(xgm_seg_dev seg, const uint32
             const uint32_t bwg = XGM_META_BWG(meta), bww = XGM_META_BWW(meta), ngw = (n * bwg + 31u) >> 5;
             const uint32_t* words = seg.words + tw + seg.blk_word[b];
             uint32_t did = seg.blk_first[b];
+            uint32_t pos = out_pos ? seg.blk_pos[b] : 0u;              /* a posting's positions start at entry blk_pos + the wdf of the block's earlier postings */
             const uint64_t o = place + incl - n;
             for (uint32_t i = 0; i < n; ++i) {
                 if (i) did += dn_extract(words, i, bwg) + 1u;
+                const uint32_t wdf = dn_extract(words + ngw, i, bww);
                 out_did[o + i] = did;
-                out_wdf[o + i] = (unsigned char)dn_extract(words + ngw, i, bww);
+                out_wdf[o + i] = (unsigned char)wdf;
+                if (out_pos) { out_pos[o + i] = pos; pos += wdf; }
             }
         }
         place += (uint64_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -188,8 +191,8 @@ static int build_narrow_doclen(xgm_index* idx) {
 
 /* Flat posting arrays of the terms without containers (xgm_seg_dev::flat_*): decoded once, here, from the blocks already in HBM. */
 static int build_flat(xgm_index* idx) {
-    idx->view.flat_off = nullptr; idx->view.flat_did = nullptr; idx->view.flat_wdf = nullptr;
-    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf}) if (*p) { hipFree(*p); *p = nullptr; }
+    idx->view.flat_off = nullptr; idx->view.flat_did = nullptr; idx->view.flat_wdf = nullptr; idx->view.flat_pos = nullptr;
+    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf, &idx->d_flat_pos}) if (*p) { hipFree(*p); *p = nullptr; }
     idx->flat_bytes = 0; idx->flat_postings = 0;
     /* XGM_NO_DENSE = no acceleration structures at all (the variant tests run the block decode K1 that way); XGM_NO_FLAT: this one off */
     if (getenv("XGM_NO_DENSE") || getenv("XGM_NO_FLAT")) return XGM_OK;
@@ -209,26 +212,28 @@ static int build_flat(xgm_index* idx) {
     DN_TRY(hipMalloc(&idx->d_flat_off, off.size() * 8));
     DN_TRY(hipMalloc(&idx->d_flat_did, n * 4 + 256));
     DN_TRY(hipMalloc(&idx->d_flat_wdf, n + 256));
+    if (idx->hdr.has_positions && !getenv("XGM_NO_FLAT_PHRASE")) DN_TRY(hipMalloc(&idx->d_flat_pos, n * 4 + 256));      /* (A/B switch: positional queries never take the flat body) */
     DN_TRY(hipMalloc((void**)&d_terms, terms.size() * 4));
     DN_TRY(hipMemcpy(idx->d_flat_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     DN_TRY(hipMemcpy(d_terms, terms.data(), terms.size() * 4, hipMemcpyHostToDevice));
     DN_TRY(hipMemset((unsigned char*)idx->d_flat_did + n * 4, 0xFF, 256));         /* (a round reads up to 63 entries past a slice's end: sentinels, never used) */
     DN_TRY(hipMemset((unsigned char*)idx->d_flat_wdf + n, 0, 256));
     hipLaunchKernelGGL(k_flat_fill, dim3((unsigned)((terms.size() + 3u) / 4u)), dim3(256), 0, 0, idx->view, d_terms, (uint32_t)terms.size(),
-                       (const uint64_t*)idx->d_flat_off, (uint32_t*)idx->d_flat_did, (unsigned char*)idx->d_flat_wdf);
+                       (const uint64_t*)idx->d_flat_off, (uint32_t*)idx->d_flat_did, (unsigned char*)idx->d_flat_wdf, (uint32_t*)idx->d_flat_pos);
     DN_TRY(hipGetLastError());
     DN_TRY(hipDeviceSynchronize());
     hipFree(d_terms);
     idx->view.flat_off = (const uint64_t*)idx->d_flat_off;
     idx->view.flat_did = (const uint32_t*)idx->d_flat_did;
     idx->view.flat_wdf = (const unsigned char*)idx->d_flat_wdf;
+    idx->view.flat_pos = (const uint32_t*)idx->d_flat_pos;
     idx->flat_postings = n;
-    idx->flat_bytes = off.size() * 8 + n * 5 + 512;
+    idx->flat_bytes = off.size() * 8 + n * (idx->d_flat_pos ? 9 : 5) + 768;
     idx->device_bytes += idx->flat_bytes;
     return XGM_OK;
 fail:
     if (d_terms) hipFree(d_terms);
-    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf}) if (*p) { hipFree(*p); *p = nullptr; }
+    for (void** p : {&idx->d_flat_off, &idx->d_flat_did, &idx->d_flat_wdf, &idx->d_flat_pos}) if (*p) { hipFree(*p); *p = nullptr; }
     return rc;
 }
 

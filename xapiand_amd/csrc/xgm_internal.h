@@ -101,6 +101,7 @@ struct xgm_index {
     void* d_flat_off = nullptr;        /* flat posting arrays of the terms without containers (xgm_seg_dev::flat_*) */
     void* d_flat_did = nullptr;
     void* d_flat_wdf = nullptr;
+    void* d_flat_pos = nullptr;
     uint64_t flat_bytes = 0, flat_postings = 0;
     uint64_t dense_bytes = 0;
     uint64_t dense_min_df = UINT64_MAX;   /* termfreq from which a term has probe containers */

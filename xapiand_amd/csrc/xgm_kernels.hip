@@ -623,6 +623,11 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
     off += phrase ? (size_t)T * kAndwCand * 4 : 0;             /* c_pos: position-list offset per candidate and term */
     off += phrase ? (size_t)T * kPosFast * 64 * 2 : 0;         /* lpos: the round's positions, u16 [T][kPosFast][64 lanes] */
     off += sided ? (size_t)cap : 0;                            /* tk_m: weighted subqueries matched, per top-k entry */
+    /* the bodies for all-container / long-tail-led queries (xgm_dense_unit, xgm_flat_unit) run out of the first bytes of the same slice:
+     * top-k 1.5 KiB + offsets 0.5 KiB + the dense body's ring 1 KiB (positional: + survivor queue <= 4 KiB + T x 2 KiB of staged positions) —
+     * static_asserts below */
+    const size_t body = phrase ? 6144 + (size_t)T * 2048 : 3072;
+    if (off < body) off = body;
     return (off + 15) & ~(size_t)15;
 }
 
@@ -671,6 +676,10 @@ __device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t 
 #include "xgm_unit_finish.h"
 #include "xgm_dense_body.inc"
 #include "xgm_flat_body.inc"
+static_assert(dense_wave_bytes(false) <= 3072 && flat_wave_bytes(false, 0) <= 3072, "andw_wave_bytes reserves 3 KiB for the plain bodies");
+static_assert(dense_wave_bytes(true, 4) <= 6144 + 4 * 2048 && flat_wave_bytes(true, 4) <= 6144 + 4 * 2048 &&
+              dense_wave_bytes(true, 2) <= 6144 + 2 * 2048 && flat_wave_bytes(true, 2) <= 6144 + 2 * 2048,
+              "andw_wave_bytes reserves 6 KiB + T x 2 KiB for the positional bodies");
 
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
@@ -698,10 +707,11 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                                       cand_out, ghdr_out, PHRASE ? hist_all : nullptr, fuse);
         return;
     }
-    if (!PHRASE && SIDED == 0 && (rfl32(q.flags) & XGM_QF_FLAT)) {
-        /* led by a long-tail term: its flat posting array is streamed 64 postings per round (same launch, same outputs) */
-        xgm_flat_unit<TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
-                             cand_out, ghdr_out, fuse);
+    if (SIDED == 0 && (rfl32(q.flags) & XGM_QF_FLAT)) {
+        /* led by a long-tail term: its flat posting array is streamed 64 postings per round (same launch, same outputs) — plain conjunctions
+         * and positional queries that prune by weight */
+        xgm_flat_unit<PHRASE, TALLY>(seg, queries, wk, smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, sizeof(TabT), SPG, PHRASE, SIDED == 2), lane, k_stride,
+                                     cand_out, ghdr_out, PHRASE ? hist_all : nullptr, fuse);
         return;
     }
     /* plan positions [0, TR) must index a document; [TR, T) are the right-hand side of an AND_NOT (must not
@@ -2352,6 +2362,9 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }
+
+/* what xgm_dense_unit / xgm_flat_unit use of a wave's LDS slice (plan_batch checks it against xgm_andw_smem_bytes / XGM_WAVES before flagging a query) */
+size_t xgm_body_wave_bytes(bool flat, bool phrase, uint32_t terms) { return flat ? flat_wave_bytes(phrase, terms) : dense_wave_bytes(phrase, terms); }
 
 size_t xgm_and_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t stripes_per_group) {
     return and_smem_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, stripes_per_group);

@@ -49,6 +49,7 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
  * L.phrase selects the instantiation with the positional filter (every term block-decoded) */
 size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase, bool sided);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
+size_t xgm_body_wave_bytes(bool flat, bool phrase, uint32_t terms);      /* LDS a unit of xgm_flat_unit (flat) / xgm_dense_unit uses of the wave's slice */
 /* conjunctions (or positional queries that prune by weight) whose every term has probe containers, <= xgm_dense_max_terms() terms,
  * k <= xgm_dense_max_k(), units of <= xgm_dense_max_stripes() stripes: xgm_dense_and.hip; L.phrase selects the positional instantiation */
 size_t xgm_dense_smem_bytes(bool phrase);

@@ -116,6 +116,7 @@ typedef struct {
     const uint64_t* flat_off;       /* [n_terms + 1] or NULL */
     const uint32_t* flat_did;
     const unsigned char* flat_wdf;
+    const uint32_t* flat_pos;       /* indexes with positions: position-entry offset (relative to the term's list) of every flat posting's first position, or NULL */
 } xgm_seg_dev;
 
 #define XGM_DENSE_MIN_AVG 32u          /* postings per stripe (on average) that make a term dense     */
