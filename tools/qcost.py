@@ -19,8 +19,9 @@ from xapiand_amd import _lib, enquire  # noqa: E402
 user = sys.argv[1:]
 sys.argv = ["bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-other-configs", "--no-latency", "--threads", "0"] + user
 L = _lib.lib()
-L.xgm_debug_last_units.restype = C.c_int64
-L.xgm_debug_last_units.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint64]
+L.xgm_debug_last_units2.restype = C.c_int64
+L.xgm_debug_last_units2.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong), C.c_uint64]
+CLOCKS = os.environ.get("XGM_QCOST_CLOCKS") is not None       # the library is a -DXGM_DENSE_CLOCKS build: cycles per phase of the dense body in the headers
 oc = enquire.Database.close
 
 
@@ -31,7 +32,8 @@ def arg(name, default):
 def close(self):
     cap = 40000
     buf = (C.c_ulonglong * (8 * cap))()
-    n = L.xgm_debug_last_units(self._h, buf, cap)
+    pos = (C.c_ulonglong * cap)()
+    n = L.xgm_debug_last_units2(self._h, buf, pos, cap)
     if n > 0:
         a = np.array(buf[:8 * n], dtype=np.uint64).reshape(n, 8)
         dur = (a[:, 5] - a[:, 4]).astype(np.float64)
@@ -41,7 +43,11 @@ def close(self):
         units_q = np.bincount(qi, minlength=nq)
         longest = np.zeros(nq)
         np.maximum.at(longest, qi, dur)
-        matches_q = np.bincount(qi, weights=a[:, 6].astype(np.float64), minlength=nq)
+        matches_q = np.bincount(qi, weights=(a[:, 6] & np.uint64((1 << 62) - 1)).astype(np.float64), minlength=nq)
+        tested_q = np.bincount(qi, weights=a[:, 7].astype(np.float64), minlength=nq)       # positional kernels: candidates whose positions were tested
+        cpos = np.array(pos[:n], dtype=np.uint64)
+        ph = {"produce": (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64), "issue": (a[:, 3] >> np.uint64(32)).astype(np.float64),
+              "weigh": (cpos & np.uint64(0xFFFFFFFF)).astype(np.float64), "survivors": (cpos >> np.uint64(32)).astype(np.float64)}
         op = arg("--op", "AND")
         bps = 16
         pool = H.bench_pool(op, int(arg("--terms", 3)), int(arg("--required", 1)), 10_000_000, 1_000_000, n=100 + bps * bench.BATCH, seed=bench.QUERY_SEED,
@@ -58,8 +64,12 @@ def close(self):
             terms = qs[q]["terms"] if q < len(qs) else []
             ranks = [int(t[1:]) for t in terms]
             dfs = [int(self.get_termfreq(t)) for t in terms]
-            print("QCOST #%2d q%3d share %.3f cum %.3f units %4d longest unit %8.0f matches %9d ranks %s all-dense %s" % (
-                rank, q, per_q[q] / total, cum / total, units_q[q], longest[q], matches_q[q], ranks, all(d >= dense_min for d in dfs)))
+            print("QCOST #%2d q%3d share %.3f cum %.3f units %4d longest unit %8.0f mean %8.0f matches %9d tested %8d ranks %s dfs %s all-dense %s" % (
+                rank, q, per_q[q] / total, cum / total, units_q[q], longest[q], per_q[q] / max(1, units_q[q]), matches_q[q], tested_q[q], ranks, dfs,
+                all(d >= dense_min for d in dfs)))
+            if CLOCKS:
+                sel = qi == q
+                print("QCOST      phases of its units' cycles: " + "  ".join("%s %.3f" % (k, v[sel].sum() / max(1.0, per_q[q])) for k, v in ph.items()))
         dense_q = np.array([all(int(self.get_termfreq(t)) >= dense_min for t in qs[q]["terms"]) if q < len(qs) else False for q in range(nq)])
         print("QCOST all-dense queries: %d of %d, their share of the cycles %.3f" % (int(dense_q.sum()), nq, per_q[dense_q].sum() / total))
         print("QCOST cycles per unit: mean %.0f p50 %.0f p99 %.0f max %.0f" % (dur.mean(), np.median(dur), np.percentile(dur, 99), dur.max()))

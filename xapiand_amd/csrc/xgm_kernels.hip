@@ -632,7 +632,10 @@ __host__ __device__ inline size_t andw_wave_bytes(uint32_t W, uint32_t T, uint32
 }
 
 /* the same with a byte of payload per entry (weighted subqueries matched) */
-__device__ void wave_topk_sort_m(uint64_t* w, uint32_t* d, uint8_t* m, uint32_t cap, uint32_t lane) {
+__device__ void wave_topk_sort_m(uint64_t* w_, uint32_t* d_, uint8_t* m_, uint32_t cap, uint32_t lane) {
+    XGM_AS_LDS uint64_t* w = (XGM_AS_LDS uint64_t*)w_;
+    XGM_AS_LDS uint32_t* d = (XGM_AS_LDS uint32_t*)d_;
+    XGM_AS_LDS uint8_t* m = (XGM_AS_LDS uint8_t*)m_;
     for (uint32_t size = 2; size <= cap; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             wave_lds_fence();
@@ -656,7 +659,9 @@ __device__ void wave_topk_sort_m(uint64_t* w, uint32_t* d, uint8_t* m, uint32_t 
 typedef double andw_d8 __attribute__((ext_vector_type(8)));
 
 /* bitonic sort of cap (power of two, >= 128) candidates by one wave; best first */
-__device__ void wave_topk_sort(uint64_t* w, uint32_t* d, uint32_t cap, uint32_t lane) {
+__device__ void wave_topk_sort(uint64_t* w_, uint32_t* d_, uint32_t cap, uint32_t lane) {
+    XGM_AS_LDS uint64_t* w = (XGM_AS_LDS uint64_t*)w_;                               /* (the wave's top-k buffer lives in its LDS slice) */
+    XGM_AS_LDS uint32_t* d = (XGM_AS_LDS uint32_t*)d_;
     for (uint32_t size = 2; size <= cap; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             wave_lds_fence();

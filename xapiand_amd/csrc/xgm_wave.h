@@ -56,9 +56,20 @@ __device__ __forceinline__ void wave_lds_fence() {
  * vector-memory operation this wave has issued — write-through stores included — has been acknowledged by its coherence point. */
 __device__ __forceinline__ void xgm_wait_vmem() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+/* Address spaces for the few helpers that stay out of line: a plain pointer parameter is GENERIC there, and the compiler reads LDS through flat
+ * loads (slow path into the LDS, counted as memory AND LDS operations).  The host build of the emulation has one address space. */
+#if defined(XGM_EMU)
+#define XGM_AS_LDS
+#define XGM_AS_GLOBAL
+#else
+#define XGM_AS_LDS __attribute__((address_space(3)))
+#define XGM_AS_GLOBAL __attribute__((address_space(1)))
+#endif
+
 /* First index in [lo, hi) with arr[i] >= key (hi if none); 64-ary search, result wave-uniform. */
-__device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ arr, uint32_t lo, uint32_t hi, uint32_t key,
+__device__ uint32_t wave_lower_bound(const uint32_t* __restrict__ arr_, uint32_t lo, uint32_t hi, uint32_t key,
                                      uint32_t lane) {
+    const XGM_AS_GLOBAL uint32_t* arr = (const XGM_AS_GLOBAL uint32_t*)arr_;          /* (every caller searches an array of the segment in HBM) */
     while (hi - lo > 64u) {
         uint32_t step = (hi - lo + 63u) / 64u;
         uint32_t p = lo + lane * step;
