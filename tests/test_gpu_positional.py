@@ -54,12 +54,13 @@ def test_phrase_near_window_and_long_phrases(built, tmp_path):
 
 
 def test_slow_path_many_positions_and_wide_positions(built, tmp_path):
-    """wdf > 16 (more than the fast path stages per document and term) and positions >= 65 536 (4-byte lists)."""
+    """wdf > 16 (more than the fast path stages per document and term), wdf > 64 (more than its wide second pass does) and positions >= 65 536
+    (4-byte lists)."""
     rng = random.Random(3)
     post = {"a": [], "b": [], "c": [], "w": [], "x": []}
     doclen = {}
     for d in range(1, 4001):
-        na, nb = rng.choice([1, 3, 9, 17, 20, 40]), rng.choice([1, 2, 8, 16, 18, 33])
+        na, nb = rng.choice([1, 3, 9, 17, 20, 40, 64, 70, 130]), rng.choice([1, 2, 8, 16, 18, 33, 65])      # <= 16: staged 64 documents at a time; <= 64: 16 at a time; more: one at a time
         pa = sorted(rng.sample(range(1, 400), na))
         pb = sorted(set(min(399, p + rng.choice([1, 1, 2, 5])) for p in rng.sample(pa, min(len(pa), nb))) | set(rng.sample(range(1, 400), max(0, nb - na))))
         pc = sorted(rng.sample(range(1, 400), rng.choice([1, 2, 5])))

@@ -44,7 +44,8 @@ def close(self):
         longest = np.zeros(nq)
         np.maximum.at(longest, qi, dur)
         matches_q = np.bincount(qi, weights=(a[:, 6] & np.uint64((1 << 62) - 1)).astype(np.float64), minlength=nq)
-        tested_q = np.bincount(qi, weights=a[:, 7].astype(np.float64), minlength=nq)       # positional kernels: candidates whose positions were tested
+        tested_q = np.bincount(qi, weights=(a[:, 7] & np.uint64(0xFFFFF)).astype(np.float64), minlength=nq)
+        calls_q = np.bincount(qi, weights=(a[:, 7] >> np.uint64(20)).astype(np.float64), minlength=nq)     # -DXGM_DENSE_CLOCKS=2 builds: survivors() calls       # positional kernels: candidates whose positions were tested
         cpos = np.array(pos[:n], dtype=np.uint64)
         ph = {"produce": (a[:, 3] & np.uint64(0xFFFFFFFF)).astype(np.float64), "issue": (a[:, 3] >> np.uint64(32)).astype(np.float64),
               "weigh": (cpos & np.uint64(0xFFFFFFFF)).astype(np.float64), "survivors": (cpos >> np.uint64(32)).astype(np.float64)}
@@ -69,7 +70,7 @@ def close(self):
                 all(d >= dense_min for d in dfs)))
             if CLOCKS:
                 sel = qi == q
-                print("QCOST      phases of its units' cycles: " + "  ".join("%s %.3f" % (k, v[sel].sum() / max(1.0, per_q[q])) for k, v in ph.items()))
+                print("QCOST      phases of its units' cycles: " + "  ".join("%s %.3f" % (k, v[sel].sum() / max(1.0, per_q[q])) for k, v in ph.items()) + "  survivors() calls %d" % calls_q[q])
         dense_q = np.array([all(int(self.get_termfreq(t)) >= dense_min for t in qs[q]["terms"]) if q < len(qs) else False for q in range(nq)])
         print("QCOST all-dense queries: %d of %d, their share of the cycles %.3f" % (int(dense_q.sum()), nq, per_q[dense_q].sum() / total))
         print("QCOST cycles per unit: mean %.0f p50 %.0f p99 %.0f max %.0f" % (dur.mean(), np.median(dur), np.percentile(dur, 99), dur.max()))

@@ -111,6 +111,23 @@ __device__ __forceinline__ bool posfilter_slow(const PosList* pl, const xgm_dev_
     return (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
 }
 
+/* The serial predicates on position lists the WAVE has copied into its LDS first (list t at stage + t * stride, n_t entries of 2 or 4 bytes):
+ * the slow path of xgm_dense_unit / xgm_flat_unit for a document with more than kPosFast positions of a term.  Straight from HBM (above) every
+ * position costs a dependent read of ~1-2 us — a two-term phrase over lists of 20 and 8 positions took ~50 us, one lane busy, and the frequent
+ * terms of C5 put such a document into every other batch of 64 survivors (tools/qcost.py phase clocks, round 4); the copy is one 16-byte load
+ * per lane and list, the reads behind it cost an LDS access each.  Out of line: its registers and private cursor arrays are its own. */
+__device__ __attribute__((noinline)) bool posfilter_staged(const unsigned char* stage, uint32_t stride, const xgm_dev_query& q, uint32_t T, uint32_t n0, uint32_t n1,
+                                                           uint32_t n2, uint32_t n3, uint32_t w16_mask) {
+    const uint32_t ns[4] = {n0, n1, n2, n3};
+    PosList pl[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < T && t < 4u; ++t) {
+        pl[t].p = stage + (size_t)t * stride;
+        pl[t].n = ns[t];
+        pl[t].w16 = (w16_mask >> t) & 1u;
+    }
+    return posfilter_slow(pl, q, T);
+}
+
 /* ---- K6 fast path: positions staged in the wave's LDS ------------------------------------------------------------
  * lp[(t * kPosFast + j) * 64 + lane] = j-th position (u16) of plan term t in the lane's document; cnt(t) = how many.
  * The same three predicates as above, on LDS data with per-lane cursors packed 5 bits per term into one 64-bit
@@ -123,11 +140,24 @@ struct LdsPos {
     const uint16_t* lp; uint32_t lane;
     __device__ __forceinline__ uint32_t at(uint32_t t, uint32_t j) const { return lp[(t * kPosFast + j) * 64u + lane]; }
 };
-__device__ __forceinline__ uint32_t cur_get(uint64_t c, uint32_t t) { return (uint32_t)(c >> (5u * t)) & 31u; }
-__device__ __forceinline__ uint64_t cur_set(uint64_t c, uint32_t t, uint32_t v) { return (c & ~(31ull << (5u * t))) | ((uint64_t)v << (5u * t)); }
+/* The WIDE layout of the same area: 16 documents at a time with up to kPosWide = 64 positions of a term each — document s (0..15) owns
+ * lanes' columns 4 s .. 4 s + 3 of every row, its j-th position of term t sits in row j & 15, column 4 s + (j >> 4).  For the documents the
+ * first pass had to leave out (17..64 positions of a term: among the candidates that pass the WEIGHT test of a frequent-term phrase — high wdf
+ * is what makes them heavy — every third one), before the serial path takes what is left (posfilter_staged). */
+constexpr uint32_t kPosWide = 64;
+struct LdsPosWide {
+    const uint16_t* lp; uint32_t col;              /* col = 4 x the document's slot */
+    __device__ __forceinline__ uint32_t at(uint32_t t, uint32_t j) const { return lp[(t * kPosFast + (j & 15u)) * 64u + col + (j >> 4)]; }
+};
+/* per-lane cursors, BITS per term in one 64-bit register (5: counts <= 16 ... 31; 7: counts <= 64; XGM_PHRASE_MAX_TERMS x 7 <= 64) */
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t cur_get(uint64_t c, uint32_t t) { return (uint32_t)(c >> (BITS * t)) & ((1u << BITS) - 1u); }
+template <uint32_t BITS>
+__device__ __forceinline__ uint64_t cur_set(uint64_t c, uint32_t t, uint32_t v) { return (c & ~((uint64_t)((1u << BITS) - 1u) << (BITS * t))) | ((uint64_t)v << (BITS * t)); }
+static_assert(XGM_PHRASE_MAX_TERMS * 7u <= 64u, "the wide pass packs 7-bit cursors of every term into 64 bits");
 
-template <typename CntF>
-__device__ bool lds_phrase_exact(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T) {
+template <uint32_t BITS = 5u, typename LP, typename CntF>
+__device__ bool lds_phrase_exact(const LP& L, CntF cnt, const uint8_t* pidx, uint32_t T) {
     /* driven from plan term 0 (the rarest term of the collection); the predicate does not depend on the driver */
     const uint32_t n0 = cnt(0u), p0 = pidx[0];
     uint64_t cur = 0;
@@ -140,9 +170,9 @@ __device__ bool lds_phrase_exact(const LdsPos& L, CntF cnt, const uint8_t* pidx,
         for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
             if (t < T && ok) {
                 const uint32_t want = base + pidx[t], nt = cnt(t);
-                uint32_t c = cur_get(cur, t);
+                uint32_t c = cur_get<BITS>(cur, t);
                 while (c < nt && L.at(t, c) < want) ++c;
-                cur = cur_set(cur, t, c);
+                cur = cur_set<BITS>(cur, t, c);
                 ok = c < nt && L.at(t, c) == want;
             }
         }
@@ -151,8 +181,8 @@ __device__ bool lds_phrase_exact(const LdsPos& L, CntF cnt, const uint8_t* pidx,
     return false;
 }
 
-template <typename CntF>
-__device__ bool lds_phrase_window(const LdsPos& L, CntF cnt, const uint8_t* pidx, uint32_t T, uint32_t window) {
+template <uint32_t BITS = 5u, typename LP, typename CntF>
+__device__ bool lds_phrase_window(const LP& L, CntF cnt, const uint8_t* pidx, uint32_t T, uint32_t window) {
     /* inv[i] = plan term that is the i-th word of the phrase (wave-uniform) */
     uint32_t inv[XGM_PHRASE_MAX_TERMS];
 #pragma unroll
@@ -167,16 +197,16 @@ __device__ bool lds_phrase_window(const LdsPos& L, CntF cnt, const uint8_t* pidx
     if (n0 == 0) return false;
     uint64_t cur = 0;                              /* cursor of phrase word i at bits 5i; all lists start at their first entry */
     while (true) {
-        const uint32_t base = L.at(inv[0], cur_get(cur, 0u));
+        const uint32_t base = L.at(inv[0], cur_get<BITS>(cur, 0u));
         uint32_t pos = base, b = 0;
         bool fits = true, out = false;
 #pragma unroll
         for (uint32_t i = 1; i < XGM_PHRASE_MAX_TERMS; ++i) {
             if (i < T && fits && !out) {
                 const uint32_t ni = cnt(inv[i]);
-                uint32_t c = cur_get(cur, i);
+                uint32_t c = cur_get<BITS>(cur, i);
                 while (c < ni && L.at(inv[i], c) < pos + 1u) ++c;
-                cur = cur_set(cur, i, c);
+                cur = cur_set<BITS>(cur, i, c);
                 if (c >= ni) { out = true; }
                 else {
                     pos = L.at(inv[i], c);
@@ -188,36 +218,36 @@ __device__ bool lds_phrase_window(const LdsPos& L, CntF cnt, const uint8_t* pidx
         if (out) return false;
         if (fits) return true;
         const uint32_t want = b - window;
-        uint32_t c0 = cur_get(cur, 0u);
+        uint32_t c0 = cur_get<BITS>(cur, 0u);
         while (c0 < n0 && L.at(inv[0], c0) < want) ++c0;
         if (c0 >= n0) return false;
-        cur = cur_set(cur, 0u, c0);
+        cur = cur_set<BITS>(cur, 0u, c0);
     }
 }
 
-template <typename CntF>
-__device__ bool lds_near_window(const LdsPos& L, CntF cnt, uint32_t T, uint32_t window) {
+template <uint32_t BITS = 5u, typename LP, typename CntF>
+__device__ bool lds_near_window(const LP& L, CntF cnt, uint32_t T, uint32_t window) {
     uint64_t cur = 0;
     bool empty = false;
 #pragma unroll
     for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) if (t < T && cnt(t) == 0u) empty = true;
     if (empty) return false;
     while (true) {
-        uint32_t lo = 0, lo_v = L.at(0u, cur_get(cur, 0u)), hi_v = lo_v;
+        uint32_t lo = 0, lo_v = L.at(0u, cur_get<BITS>(cur, 0u)), hi_v = lo_v;
 #pragma unroll
         for (uint32_t t = 1; t < XGM_PHRASE_MAX_TERMS; ++t) {
             if (t < T) {
-                const uint32_t v = L.at(t, cur_get(cur, t));
+                const uint32_t v = L.at(t, cur_get<BITS>(cur, t));
                 if (v < lo_v) { lo_v = v; lo = t; }
                 if (v > hi_v) hi_v = v;
             }
         }
         if (hi_v - lo_v < window) return true;
         const uint32_t want = hi_v - window + 1u, nl = cnt(lo);
-        uint32_t c = cur_get(cur, lo);
+        uint32_t c = cur_get<BITS>(cur, lo);
         while (c < nl && L.at(lo, c) < want) ++c;
         if (c >= nl) return false;
-        cur = cur_set(cur, lo, c);
+        cur = cur_set<BITS>(cur, lo, c);
     }
 }
 
