@@ -49,7 +49,7 @@ HBM_PEAK = 8.0e12          # B/s, /opt/skills/guides/MI355X_MICROARCH.md
 SECTOR = 64                # bytes one random gather costs at the memory side (tools/fetch_calib.hip, profiles/)
 CORPUS_SEED = 0x5EED0001
 QUERY_SEED = 0x5EED0002
-BATCH = 256
+BATCH = int(os.environ.get("XGM_BENCH_BATCH", "256"))          # (diagnostics only: the metric is quoted on batches of 256)
 
 
 def parse_args():

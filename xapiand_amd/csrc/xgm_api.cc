@@ -784,7 +784,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         const double cand_per_stripe = all_dense ? Wd * dens : (stripes > 0 ? min_df / stripes : 0.0);
         /* a candidate of a positional query costs a 64-byte sector per term, its positions and the predicate on top of the probe */
         static const double phrase_cand = getenv("XGM_PHRASE_CAND_COST") ? atof(getenv("XGM_PHRASE_CAND_COST")) : 0.25;
-        const double per_cand = bp->phrase ? phrase_cand : 0.03;
+        /* ... and with three or more terms the matches are rarer, the query-wide threshold comes later and more of the candidates are tested
+         * (C5's `t70 t11 t5`: 38 matches, 120 k tests: its 41 units ran as long as the whole launch) */
+        static const double phrase_t3 = getenv("XGM_PHRASE_T3_COST") ? atof(getenv("XGM_PHRASE_T3_COST")) : 2.0;      /* A/B switch; measured C5 231 / 253 / 248 k queries/s at 1 / 2 / 4 */
+        const double per_cand = bp->phrase ? phrase_cand * (qs[i].n_terms >= 3 ? phrase_t3 : 1.0) : 0.03;
         cost[i] = stripes * (bp->andw ? 15.0 : 8.0) + 0.9 * sparse_blocks + per_cand * cand_per_stripe * qs[i].n_terms * stripes + 1.0;
         if (bp->andw && !bp->phrase && min_df > 0 && sparse_req <= 1 && !sparse_rhs && qs[i].n_terms <= 8) {
             /* the conjunction kernel's queue path (measured per unit on MI355X, tools/units.py, in ~1k cycles of a wave
@@ -1653,6 +1656,9 @@ struct XgmBatcher {
     uint32_t max_batch = 256;
     uint32_t max_flights = 2;
     uint64_t batches = 0, requests = 0;
+    uint32_t inflight_reqs = 0;                 /* requests of the launched flights */
+    double peak_outstanding = 0.0;              /* queued + in flight, a slowly decaying maximum: how many callers there are */
+    uint32_t linger_us = 0;
 };
 
 static void batcher_finish(XgmBatcher* b, XgmBatchReq* r, int rc, const char* err) {
@@ -1674,6 +1680,19 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
             b->cv_work.wait(lk, [&] { return b->stop || !b->queue.empty(); });
             if (b->stop && b->queue.empty()) break;
             b->cv_room.wait(lk, [&] { return b->flights.size() < b->max_flights; });
+            /* While a flight is on the GPU the next one may as well wait for the callers that are about to come back: the flights run back to
+             * back on one stream and a launch costs ~50 us + ~1.2 us per query, so 64 callers in two flights of 32 get through faster than in
+             * three groups of 21 (two in flight, one queued — what taking whatever has accumulated settles into; measured 189 k queries/s).
+             * Linger until everyone who is not in a flight has queued up, a flight has come back (the GPU is about to idle), or linger_us. */
+            const double outstanding = (double)(b->queue.size() + b->inflight_reqs);
+            b->peak_outstanding = std::max(outstanding, b->peak_outstanding * 0.98);
+            if (b->linger_us && !b->flights.empty() && !b->stop) {
+                const size_t flights0 = b->flights.size();
+                const double want = std::min<double>(b->max_batch, b->peak_outstanding - (double)b->inflight_reqs);
+                if ((double)b->queue.size() < want)
+                    b->cv_work.wait_for(lk, std::chrono::microseconds(b->linger_us),
+                                        [&] { return b->stop || (double)b->queue.size() >= want || b->flights.size() < flights0; });
+            }
             take.clear();
             while (!b->queue.empty() && take.size() < b->max_batch) { take.push_back(b->queue.front()); b->queue.pop_front(); }
         }
@@ -1701,6 +1720,7 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
         {
             std::lock_guard<std::mutex> lk(b->mu);
             b->flights.push_back(fl);
+            b->inflight_reqs += n;
             ++b->batches; b->requests += n;
         }
         b->cv_flight.notify_one();
@@ -1734,6 +1754,7 @@ static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
         {
             std::lock_guard<std::mutex> lk(b->mu);
             b->flights.pop_front();
+            b->inflight_reqs -= n;
             for (XgmBatchReq* r : fl->reqs) {
                 r->rc = rc;
                 if (rc < 0) snprintf(r->err, sizeof r->err, "%s", err.c_str());
@@ -1742,6 +1763,7 @@ static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
             }
         }
         b->cv_room.notify_one();
+        b->cv_work.notify_one();                   /* (a lingering dispatcher: the GPU is about to idle) */
         delete fl;
     }
 }
@@ -1783,6 +1805,8 @@ extern "C" int xgm_index_set_batching(xgm_index* idx, uint32_t max_batch) {
     b->max_batch = std::min<uint32_t>(max_batch, 1024u);
     static const uint32_t flights_env = getenv("XGM_BATCHER_FLIGHTS") ? (uint32_t)std::max(1, atoi(getenv("XGM_BATCHER_FLIGHTS"))) : 2u;   /* A/B switch (1 = rounds 1-3; measured at 64 threads: 1 → 110 k, 2 → 195 k, 3 → 162 k queries/s) */
     b->max_flights = std::min(flights_env, 6u);
+    static const int linger_env = getenv("XGM_BATCHER_LINGER_US") ? atoi(getenv("XGM_BATCHER_LINGER_US")) : 0;        /* A/B switch, off: measured at 64 threads 193 k queries/s (mean batch 21) without, 179 k (28) at 40 us, 162 k at 80 us — the flights are not bound by the GPU's share */
+    b->linger_us = (uint32_t)std::max(0, linger_env);
     {
         int rc = use_device(idx->device);
         if (rc) { delete b; return rc; }
