@@ -529,6 +529,13 @@ int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, const xgm_qu
  * shards[0] is this index. */
 int xgm_debug_sharded_info(const xgm_index* shards0, uint64_t* out4);
 
+/* OP_NEAR on a shard whose indexer may put DISTINCT TERMS AT ONE POSITION (Xapiand's schema can index several terms per token position):
+ * NearPostList::test_doc then wants the terms at pairwise distinct positions inside the window and settles coinciding heads by its
+ * duplicate-position step (reference src/xapian/matcher/nearpostlist.cc:106-140).  may_exist != 0: every later OP_NEAR on this index runs
+ * the reference's procedure in full (the serial predicate near_colocated of xgm_posfilter.h; the answers are the reference's either way,
+ * the fast predicate is simply not valid when heads can coincide).  Default 0: one term per position, the wave-parallel predicate. */
+int xgm_index_set_near_colocated(xgm_index*, int may_exist);
+
 /* Kernel timing with HIP events on the launch stream.  xgm_index_set_profiling(idx, 1) makes every
  * later xgm_search* call record an event pair around the dominant kernel (xgm_match_kernel) without
  * synchronising; xgm_last_kernel_ms waits for the recorded launches, returns their MEAN duration in

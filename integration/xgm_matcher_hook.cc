@@ -240,7 +240,12 @@ bool lower_flat(const Xapian::Query& q, Lowered* L) {
         L->total_subqs = (uint32_t)L->terms.size();
     } else if (op == Xapian::Query::OP_PHRASE || op == Xapian::Query::OP_NEAR) {
         if (g_positional.load(std::memory_order_relaxed) == POSITIONAL_DECLINE) return false;
-        if (op == Xapian::Query::OP_NEAR && g_near_colocated.load(std::memory_order_relaxed)) return false;
+        /* NEAR where terms may share a position: the device runs NearPostList's procedure per document from QUERY order; the reference's
+         * `terms` vector keeps the order its previous test_doc left (nearpostlist.cc:80 sorts the member in place), which decides
+         * which of two coinciding heads moves — its answer depends on the documents tested before.  Answered on the device
+         * as INTENDED; the byte-compatible mode keeps such queries on the CPU matcher. */
+        if (op == Xapian::Query::OP_NEAR && g_near_colocated.load(std::memory_order_relaxed) &&
+            g_positional.load(std::memory_order_relaxed) != POSITIONAL_INTENDED) return false;
         const size_t n = q.get_num_subqueries();
         for (size_t i = 0; i < n; ++i) {
             const Xapian::Query s = q.get_subquery(i);
@@ -490,6 +495,7 @@ int fetch_all(xgm_index* idx, const xgm_query& plan, Xapian::doccount doccount, 
 
 void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch) {
     if (batch) xgm_index_set_batching(idx, batch);
+    if (g_near_colocated.load(std::memory_order_relaxed)) xgm_index_set_near_colocated(idx, 1);
     std::lock_guard<std::mutex> lk(g_mu);
     g_shards[db.get_uuid()] = Shard{idx, db.get_revision(), std::make_shared<ShardColumns>()};
 }
@@ -503,7 +509,13 @@ void set_enabled(bool on) { g_enabled.store(on); }
 void set_positional_mode(PositionalMode m) { g_positional.store(int(m)); }
 void set_collapse_mode(CollapseMode m) { g_collapse.store(int(m)); }
 void set_exact_bounds(bool on) { g_exact_bounds.store(on); }
-void set_near_colocated_terms(bool may_exist) { g_near_colocated.store(may_exist); }
+void set_near_colocated_terms(bool may_exist) {
+    /* the shards run NearPostList's procedure in full from here on (xgm_index_set_near_colocated); POSITIONAL_INTENDED answers such
+     * queries on the device, POSITIONAL_REFERENCE keeps them on the CPU matcher (lower_query) */
+    g_near_colocated.store(may_exist);
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_shards) xgm_index_set_near_colocated(kv.second.idx, may_exist ? 1 : 0);
+}
 void set_replay(bool on) { g_replay.store(on); }
 void set_column_build_limit(uint32_t max_documents) { g_column_limit.store(max_documents); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {

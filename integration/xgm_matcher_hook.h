@@ -78,9 +78,14 @@ void set_positional_mode(PositionalMode m);
 inline void set_decline_positional(bool on) { set_positional_mode(on ? POSITIONAL_DECLINE : POSITIONAL_INTENDED); }
 
 /* OP_NEAR on an index that puts DISTINCT terms at the SAME position of a document (prefixed and unprefixed forms of a word, ...): the
- * reference's NearPostList::test_doc wants one distinct position per term and steps over duplicates (matcher/nearpostlist.cc:108-140);
- * the device predicate accepts co-located heads.  A deployment whose indexer co-locates terms says so here and OP_NEAR stays on the
- * CPU matcher (OP_PHRASE is unaffected: its terms sit at increasing positions by definition).  Default: false. */
+ * reference's NearPostList::test_doc wants one distinct position per term and steps over duplicates (matcher/nearpostlist.cc:106-140);
+ * the device's wave-parallel predicate assumes heads never coincide.  A deployment whose indexer co-locates terms says so here and every
+ * registered shard (now and later) runs the reference's procedure in full for OP_NEAR (xgm_index_set_near_colocated, round 4), each
+ * document from QUERY order.  The reference itself carries the order of its term vector from one tested document to the next (it sorts
+ * the member in place), so with coinciding heads its answer depends on what was tested before — NEAR(a b) and NEAR(b a) differ, a top-k
+ * search can differ from the full one (the oracle reproduces it and is pinned on it).  Hence: POSITIONAL_INTENDED answers
+ * such queries on the device (the stateless reading), POSITIONAL_REFERENCE — the byte-compatible mode — keeps them on the CPU matcher
+ * (rounds 2-3: always).  OP_PHRASE is unaffected: its terms sit at increasing positions by definition.  Default: false. */
 void set_near_colocated_terms(bool may_exist);
 
 /* Enquire::set_collapse_key.  The reference snapshot's collapser does not keep the best collapse_max documents of a key when

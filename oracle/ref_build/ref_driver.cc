@@ -523,6 +523,32 @@ int cmd_compact(int argc, char** argv) {
  * (tests/test_glass.py): several commits, deleted and replaced documents (docid gaps), docids beyond
  * 0x8000 / 0x200000 (longer sort-preserving chunk keys), terms with embedded zero bytes, postings without
  * positions, boolean terms (wdf 0), long posting lists (several chunks). */
+/* build_postings <dbdir> <file>: documents spelled out posting by posting — one line per document, docids 1, 2, ... in file order,
+ * "term:pos term:pos ..." (add_posting each: several terms may share a position, what a schema that indexes a word's prefixed and
+ * unprefixed forms does).  For NEAR over co-located terms (nearpostlist.cc:106-140; tests/helpers.py coloc_postings). */
+int cmd_build_postings(int argc, char** argv) {
+    if (argc < 4) return 2;
+    Xapian::WritableDatabase db(argv[2], Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
+    std::ifstream in(argv[3]);
+    std::string line;
+    unsigned n = 0;
+    while (std::getline(in, line)) {
+        Xapian::Document doc;
+        std::istringstream ss(line);
+        std::string tok;
+        while (ss >> tok) {
+            const size_t c = tok.rfind(':');
+            if (c == std::string::npos) return 2;
+            doc.add_posting(tok.substr(0, c), (Xapian::termpos)std::stoul(tok.substr(c + 1)));
+        }
+        db.add_document(doc);
+        if (++n % 1000 == 0) db.commit();
+    }
+    db.commit();
+    printf("{\"doccount\": %u, \"lastdocid\": %u}\n", db.get_doccount(), db.get_lastdocid());
+    return 0;
+}
+
 int cmd_build_misc(int argc, char** argv) {
     if (argc < 3) return 2;
     Xapian::WritableDatabase db(argv[2], Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
@@ -735,6 +761,7 @@ int main(int argc, char** argv) {
         else if (cmd == "time") rc = cmd_time(argc, argv);
         else if (cmd == "export") rc = cmd_export(argc, argv);
         else if (cmd == "build_misc") rc = cmd_build_misc(argc, argv);
+        else if (cmd == "build_postings") rc = cmd_build_postings(argc, argv);
         else if (cmd == "build_range") rc = cmd_build_range(argc, argv);
         else if (cmd == "append") rc = cmd_append(argc, argv);
         else if (cmd == "column") rc = cmd_column(argc, argv);

@@ -454,20 +454,99 @@ bool window_phrase(std::vector<PosCursor>& pl, uint32_t window) {
     return false;
 }
 
-/* NearPostList::test_doc (matcher/nearpostlist.cc:60-160) for DISTINCT terms: one position of every term inside a
- * span shorter than `window`, in any order.  The reference keeps the lists' heads in a heap and advances the
- * smallest one past (largest - window); with distinct terms no two heads can coincide, so its duplicate-position
- * handling never engages and the test is exactly "max(head) - min(head) < window for some alignment". */
-bool near_window(std::vector<PosCursor>& pl, uint32_t window) {
+/* NearPostList::test_doc (matcher/nearpostlist.cc:70-150), the whole of it: one occurrence of every term inside a span shorter than
+ * `window` AT PAIRWISE DISTINCT POSITIONS, found the reference's way.  The lists are started lazily in ascending wdf order (TermCmp,
+ * nearpostlist.cc:52-58; std::sort of <= 16 elements is an insertion sort: ties keep query order); their heads sit in a binary heap
+ * with the smallest position on top — common/heap.h, i.e. libc++'s sift-up / sift-down, whose behaviour on equal keys decides which of
+ * two coinciding heads is moved; while the span from the top to `last` (the largest head) is too wide the top skips to last - window + 1;
+ * once every list is inside the window the heads are walked in ascending position (lines 106-140): a head on the previous head's
+ * position is advanced — past the window: back to the outer loop with it as the new maximum (the heap is rebuilt), otherwise it sinks
+ * to its place and the walk goes on; all heads distinct: a match.  With one term per position no two heads ever coincide and this is
+ * "max(head) - min(head) < window for some alignment" — the predicate the device's wave-parallel path evaluates; a shard whose indexer
+ * puts several terms at one position needs every step (xgm_index_set_near_colocated; xgm_posfilter.h near_colocated). */
+/* `history`: NearPostList sorts its `terms` MEMBER in place (nearpostlist.cc:80), so between documents the vector keeps the order the
+ * previous test left: equal wdf then fall in the order of the LAST TESTED documents' wdf, not in query order — and with coinciding heads
+ * the order decides which list is advanced, i.e. whether a match is found (reference quirk, DESIGN.md §7.4: NEAR(ca cb) and NEAR(cb ca)
+ * match different documents, and a top-k search, which tests fewer documents, can disagree with the full search of the same query).
+ * history != nullptr reproduces that (the vector lives across the calls of one query, in the matcher's document order); nullptr is the
+ * stateless reading the device implements: every document starts from query order. */
+bool near_window(std::vector<PosCursor>& pl, const std::vector<uint32_t>& wdfs, uint32_t window, std::vector<unsigned>* history = nullptr) {
     const size_t n = pl.size();
-    for (size_t i = 0; i < n; ++i) if (!pl[i].next()) return false;
+    std::vector<unsigned> fresh;
+    if (!history) { fresh.resize(n); for (size_t i = 0; i < n; ++i) fresh[i] = (unsigned)i; history = &fresh; }
+    std::stable_sort(history->begin(), history->end(), [&](unsigned a, unsigned b) { return wdfs[a] < wdfs[b]; });
+    const std::vector<unsigned>& ord = *history;
+    std::vector<unsigned> h(n);
+    auto pos = [&](unsigned id) { return pl[id].get(); };
+    auto above = [&](unsigned a, unsigned b) { return pos(a) > pos(b); };          /* Cmp: a min-heap on the heads */
+    auto sift_down = [&](size_t len, size_t start) {
+        size_t child = start;
+        if (len < 2 || (len - 2) / 2 < child) return;
+        child = 2 * child + 1;
+        if (child + 1 < len && above(h[child], h[child + 1])) ++child;
+        if (above(h[child], h[start])) return;
+        const unsigned top = h[start];
+        do {
+            h[start] = h[child];
+            start = child;
+            if ((len - 2) / 2 < child) break;
+            child = 2 * child + 1;
+            if (child + 1 < len && above(h[child], h[child + 1])) ++child;
+        } while (!above(h[child], top));
+        h[start] = top;
+    };
+    auto push = [&](size_t len) {
+        if (len < 2) return;
+        size_t p = (len - 2) / 2, last = len - 1;
+        if (!above(h[p], h[last])) return;
+        const unsigned t = h[last];
+        do {
+            h[last] = h[p];
+            last = p;
+            if (p == 0) break;
+            p = (p - 1) / 2;
+        } while (above(h[p], t));
+        h[last] = t;
+    };
+    auto pop = [&](size_t len) { if (len > 1) { std::swap(h[0], h[len - 1]); sift_down(len - 1, 0); } };
+    h[0] = ord[0];
+    if (!pl[h[0]].next()) return false;
+    uint32_t last = pos(h[0]);
+    size_t end = 1;
     while (true) {
-        size_t lo = 0;
-        uint32_t hi = pl[0].get();
-        for (size_t i = 1; i < n; ++i) { if (pl[i].get() < pl[lo].get()) lo = i; if (pl[i].get() > hi) hi = pl[i].get(); }
-        if (hi - pl[lo].get() < window) return true;
-        if (!pl[lo].skip_to(hi - window + 1)) return false;
+        if (last - pos(h[0]) < window) {
+            if (end != n) {
+                const unsigned id = ord[end];
+                if (last < window) { if (!pl[id].next()) return false; }
+                else if (!pl[id].skip_to(last - window + 1)) return false;
+                if (pos(id) > last) last = pos(id);
+                h[end++] = id;
+                push(end);
+                continue;
+            }
+            uint32_t p = pos(h[0]);
+            pop(end);
+            size_t i = end - 1;
+            while (true) {
+                if (pos(h[0]) == p) {
+                    if (!pl[h[0]].next()) return false;
+                    const uint32_t np = pos(h[0]);
+                    if (np - pos(h[end - 1]) >= window) { last = np; break; }
+                    sift_down(i, 0);
+                    continue;
+                }
+                p = pos(h[0]);
+                pop(i);
+                if (--i == 0) return true;
+            }
+            if (end > 1) for (size_t s = (end - 2) / 2 + 1; s-- > 0;) sift_down(end, s);
+            continue;
+        }
+        if (!pl[h[0]].skip_to(last - window + 1)) break;
+        last = std::max(last, pos(h[0]));
+        sift_down(end, 0);
     }
+    return false;
 }
 
 struct Result { std::vector<Hit> hits; uint64_t matches = 0; double max_possible = 0, max_attained = 0; uint32_t max_subqs = 0;
@@ -592,6 +671,8 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
     dl.init(&ix->doclen_list);
     ProtoMSet pm(k);
     double select_cached = -HUGE_VAL;
+    std::vector<unsigned> near_history(n);          /* NearPostList::terms as the previous test_doc left it (reference mode only) */
+    for (uint32_t i = 0; i < n; ++i) near_history[i] = i;
     std::vector<double> val(2 * n);
     std::vector<char> present(n);
 
@@ -709,7 +790,7 @@ int run_query(Index* ix, const QueryIn& q, Result* out) {
                     pl[i] = PosCursor{ix->pos + ix->pos_off[ord], (uint32_t)(ix->pos_off[ord + 1] - ix->pos_off[ord]), 0, false};
                     wdfs[i] = it[p].wdf;
                 }
-                ok = q.op == 7 ? near_window(pl, window) : (window == n) ? exact_phrase(pl, wdfs) : window_phrase(pl, window);
+                ok = q.op == 7 ? near_window(pl, wdfs, window, q.select_cache_bug ? &near_history : nullptr) : (window == n) ? exact_phrase(pl, wdfs) : window_phrase(pl, window);
             }
             if (ok) {
                 if (cached_weight >= 0) {

@@ -90,6 +90,15 @@ def main():
         for name, qs in (("sorted_values", sorted_qs), ("spy_counts", spy_qs)):
             with open(os.path.join(HERE, name + ".json"), "w") as f:
                 json.dump(dict(corpus=corpus, n_shards=1, results=run(tmp, [dbv], qs, name)), f, indent=0)
+        # NEAR over co-located terms (nearpostlist.cc:106-140): hand-made documents with several terms per position (helpers.coloc_postings),
+        # built posting by posting; the reference's answers INCLUDE its history dependence: the oracle's reference mode
+        # must reproduce them query by query, top-10 pages too
+        post, doclen = H.coloc_postings()
+        pf, dbc = os.path.join(tmp, "coloc.txt"), os.path.join(tmp, "dbc")
+        H.write_postings_file(pf, post, doclen)
+        H.xapian_ref("build_postings", dbc, pf)
+        with open(os.path.join(HERE, "near_colocated.json"), "w") as f:
+            json.dump(dict(coloc=dict(seed=0xC010C, n_docs=600), n_shards=1, results=run(tmp, [dbc], H.coloc_near_queries(), "coloc")), f, indent=0)
         n_shards = 4
         dbs = []
         for s in range(n_shards):

@@ -499,6 +499,59 @@ class ManualCorpus(Corpus):
         return list(self._term_bytes)
 
 
+def coloc_postings(seed=0xC010C, n_docs=600):
+    """Documents whose indexer puts SEVERAL TERMS AT ONE POSITION (a word's prefixed and unprefixed forms, synonyms): what engages the
+    duplicate-position step of NearPostList::test_doc (nearpostlist.cc:106-140).  Returns (postings {term: [(did, wdf, [pos...])]}, doclen
+    {did: length}) for ManualCorpus; write_postings_file() spells the same documents out for `xapian_ref build_postings`.  Five query terms
+    ca..ce — ca / cb mostly TOGETHER on a position, cc often with one of them, cd / ce on positions of their own — among fillers."""
+    import random
+    rng = random.Random(seed)
+    post, doclen = {}, {}
+    for d in range(1, n_docs + 1):
+        at = {}                                      # position -> set of terms
+        n_pos = rng.randrange(12, 40)
+        for p in range(1, n_pos + 1):
+            r = rng.random()
+            here = set()
+            if r < 0.10: here |= {"ca", "cb"}
+            elif r < 0.16: here.add("ca")
+            elif r < 0.22: here.add("cb")
+            if rng.random() < 0.12: here.add("cc")
+            if rng.random() < 0.07: here.add(rng.choice(["cd", "ce"]))
+            if rng.random() < 0.03: here |= {"cd", "ce"}
+            if not here or rng.random() < 0.5: here.add("f%d" % rng.randrange(30))
+            at[p] = here
+        by = {}
+        for p in sorted(at):
+            for t in at[p]:
+                by.setdefault(t, []).append(p)
+        for t, pp in by.items():
+            post.setdefault(t, []).append((d, len(pp), pp))
+        doclen[d] = sum(len(pp) for pp in by.values())
+    return post, doclen
+
+
+def write_postings_file(path, post, doclen):
+    docs = {}
+    for t, pl in post.items():
+        for d, _, pp in pl:
+            docs.setdefault(d, []).extend("%s:%d" % (t, p) for p in pp)
+    with open(path, "w") as f:
+        for d in range(1, max(doclen) + 1):
+            f.write(" ".join(sorted(docs.get(d, []))) + "\n")
+
+
+def coloc_near_queries():
+    qs = []
+    for terms in (["ca", "cb"], ["cb", "ca"], ["ca", "cc"], ["ca", "cb", "cc"], ["cc", "cb", "ca"], ["cd", "ce"], ["ca", "cd", "ce"], ["ca", "cb", "cc", "cd"],
+                  ["ce", "cc", "cb", "ca", "cd"], ["f1", "ca"], ["cb", "f2", "cc"]):
+        for win in (len(terms), len(terms) + 1, len(terms) + 3, 12):
+            if win in (len(terms), len(terms) + 3) and len(terms) <= 3:
+                qs.append(dict(op="NEAR", terms=terms, first=0, maxitems=2000, window=win))      # the whole match
+            qs.append(dict(op="NEAR", terms=terms, first=0, maxitems=10, window=win))
+    return qs
+
+
 # ---- oracle over postings copied back from a device-resident index (config-scale parity, bench cpu_baseline) ----
 
 class DeviceOracle:

@@ -14,6 +14,11 @@ _cache = {}
 
 
 def shards_for(fx):
+    if "coloc" in fx:                      # hand-made documents with several terms per position (NEAR's duplicate-position step)
+        key = ("coloc", fx["coloc"]["seed"], fx["coloc"]["n_docs"])
+        if key not in _cache:
+            _cache[key] = [H.ManualCorpus(*H.coloc_postings(fx["coloc"]["seed"], fx["coloc"]["n_docs"]))]
+        return _cache[key]
     c = fx["corpus"]
     key = (c["seed"], c["n_docs"], c["vocab"], fx["n_shards"])
     if key not in _cache:
@@ -48,7 +53,9 @@ def test_oracle_matches_golden(path):
             assert [k.hex() for _, _, _, k in hits[q["first"]:]] == r["sort_keys"], q
             assert hdr.max_attained == float.fromhex(r["max_attained"]), q
         elif fx["n_shards"] == 1:
-            hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0))
+            # (co-located NEAR: the reference's answers carry its history dependence and its stale weights — the oracle's reference mode)
+            hits, hdr = H.oracle_search(shards[0], q["op"], q["terms"], q["first"], q["maxitems"], q.get("window", 0), n_required=q.get("n_required", 0),
+                                        reference_select_bug="coloc" in fx)
             got = [(d, w) for d, w, _ in hits[q["first"]:]]
             assert hdr.max_possible == float.fromhex(r["max_possible"])
         else:

@@ -79,3 +79,21 @@ def test_slow_path_many_positions_and_wide_positions(built, tmp_path):
             qs.append(dict(op=op, terms=terms, first=0, maxitems=10, window=win))
     assert check(db, c, qs) > 50
     db.close()
+
+
+def test_near_over_colocated_terms(built, tmp_path):
+    """Documents with several terms per position (helpers.coloc_postings): with xgm_index_set_near_colocated the device runs NearPostList's
+    procedure IN FULL (duplicate-position step, nearpostlist.cc:106-140; xgm_posfilter.h near_colocated) — every kernel class that can carry
+    a NEAR (the bodies for all-container / long-tail-led queries, the queue path, the workgroup kernel via the variant switches) against the
+    oracle's stateless reading, the whole match and top-10 pages; without the flag the wave-parallel predicate accepts coinciding heads,
+    which is what it must NOT be used for (the answers differ: checked, so that the test would notice a flag that does nothing)."""
+    post, doclen = H.coloc_postings()
+    c = H.ManualCorpus(post, doclen)
+    db = Database(c.build_segment(str(tmp_path / "c.seg")))
+    qs = H.coloc_near_queries()
+    plain = [search_batch(db, [plan(db, Query(q["op"], q["terms"], window=q["window"]), 0, q["maxitems"], H.EXACT_COUNT)])[0] for q in qs[:6]]
+    db.set_near_colocated(True)
+    assert check(db, c, qs) > 1000
+    flagged = [search_batch(db, [plan(db, Query(q["op"], q["terms"], window=q["window"]), 0, q["maxitems"], H.EXACT_COUNT)])[0] for q in qs[:6]]
+    assert any(a[1].matches_exact != b[1].matches_exact for a, b in zip(plain, flagged))
+    db.close()

@@ -142,6 +142,7 @@ _API = [
     ("xgm_debug_sharded_info", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("xgm_merge_shards_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
     ("xgm_index_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("xgm_index_set_near_colocated", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_last_kernel_ms", C.c_double, [C.c_void_p]),
     ("xgm_last_kernel_name", C.c_char_p, [C.c_void_p]),
     ("xgm_last_batch_traffic", C.c_int, [C.c_void_p, _P(C.c_uint64), C.c_uint32]),

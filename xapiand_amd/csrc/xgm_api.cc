@@ -335,6 +335,13 @@ extern "C" int xgm_index_set_stream(xgm_index* idx, void* hip_stream) {
     return XGM_OK;
 }
 
+/* reference src/xapian/matcher/nearpostlist.cc:106-140: the duplicate-position step of NearPostList::test_doc */
+extern "C" int xgm_index_set_near_colocated(xgm_index* idx, int may_exist) {
+    if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
+    idx->near_colocated.store(may_exist != 0);
+    return XGM_OK;
+}
+
 extern "C" int xgm_index_set_profiling(xgm_index* idx, int on) {
     if (!idx) return xgm_set_error(XGM_E_INVALID, "null argument");
     std::lock_guard<std::mutex> lk(idx->scratch_mu);
@@ -567,7 +574,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
          * the match count is accurate; within it (Xapiand passes 0) the matcher may stop caring about documents that cannot rank */
         static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr;         /* A/B switch for measurements */
         if (!no_pos_prune && q->check_at_least <= q->first + q->maxitems) d->flags |= XGM_QF_POSPRUNE;
-        if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR;
+        if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR | (idx->near_colocated.load(std::memory_order_relaxed) ? XGM_QF_NEAR_COLOC : 0u);
         else if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
     }
     if (q->op == XGM_OP_TREE) {

@@ -18,6 +18,8 @@
 #define XGM_QF_EXACT 2u             /* window == n_terms: ExactPhrasePostList semantics            */
 #define XGM_QF_EMPTY 4u             /* provably no match on this shard (absent AND term, ...)      */
 #define XGM_QF_NEAR 8u              /* the positional filter is NearPostList's (any order, span < window) */
+#define XGM_QF_NEAR_COLOC 256u      /* ... on a shard whose indexer may put DISTINCT TERMS AT ONE POSITION (xgm_index_set_near_colocated): NearPostList's
+                                       duplicate-position step decides then (nearpostlist.cc:106-140) — the serial restatement near_colocated() */
 #define XGM_QF_POSPRUNE 32u         /* positional query whose match count may be a lower bound: weigh first, test positions only of
                                        candidates that can still enter the top k (include/xgm.h, XGM_MATCHES_LOWER_BOUND) */
 #define XGM_QF_DENSE 64u            /* a plain conjunction / FILTER of 2..4 terms that ALL have probe containers, k <= 64: its units run

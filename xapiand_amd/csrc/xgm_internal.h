@@ -2,6 +2,7 @@
 #ifndef XGM_INTERNAL_H
 #define XGM_INTERNAL_H
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -108,6 +109,7 @@ struct xgm_index {
     void* stream = nullptr;            /* hipStream_t                                                */
     bool own_stream = false;
     bool profiling = false;
+    std::atomic<bool> near_colocated{false};   /* distinct terms may share a position in this shard: NEAR by the reference's full procedure (xgm_index_set_near_colocated) */
     bool tally = false;                /* launch the wave kernels' tallying instantiation (xgm_index_set_profiling bit 1) */
     const char* last_kernel = "";      /* diagnostics: which match kernel the last batch used */
     void* last_ghdr = nullptr;         /* device: per-unit summaries of the last batch (xgm_last_batch_traffic) */

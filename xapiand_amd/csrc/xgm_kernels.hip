@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
                  * the wave parks them in LDS; then each lane runs the predicate on LDS data.  Documents with more
                  * positions of a term, or a term with 4-byte positions, take the serial path straight from HBM. */
                 auto cnt = [&](uint32_t t) { return (uint32_t)c_w[(size_t)t * CAND + (o < CAND ? o : 0u)] - 1u; };
-                bool slow = false;
+                bool slow = (q.flags & XGM_QF_NEAR_COLOC) != 0u;      /* (NEAR where terms may share a position: the reference's own steps, serially) */
                 if (TALLY) { if (pass) { for (uint32_t t = 0; t < T; ++t) cn_pos += cnt(t); } }
                 for (uint32_t t0 = 0; t0 < T; t0 += 2u) {
                     Pos8 ra[2][2];

@@ -106,7 +106,115 @@ __device__ bool near_window(const PosList* pl, uint32_t n_terms, uint32_t window
     }
 }
 
+/* NearPostList::test_doc IN FULL (nearpostlist.cc:70-150), for shards where distinct terms may share a position: the reference then wants
+ * one occurrence of every term inside a span shorter than `window` AT PAIRWISE DISTINCT POSITIONS, and finds it greedily — the lists' heads in
+ * a binary heap (smallest position on top; the heap of common/heap.h: libc++'s sift-up / sift-down, whose tie behaviour decides WHICH of two
+ * equal heads moves), lists started lazily in ascending wdf order (TermCmp, nearpostlist.cc:52-58; equal wdf: query order — the sort of <= 8
+ * elements is an insertion sort), the smallest head skipped forward while the span is too wide, and once every list is inside the window the
+ * heads are walked in ascending position: one that sits on the previous head's position is advanced — out of the window: back to the outer
+ * loop with the new maximum; otherwise it sinks to its place and the walk goes on.  Restated step by step so that the answer is the
+ * reference's in every corner, not merely the predicate it approximates.  qpos[t] = plan term t's place in the query. */
+__device__ bool near_colocated(const PosList* pl, const uint8_t* qpos, uint32_t n, uint32_t window) {
+    uint32_t cur[XGM_PHRASE_MAX_TERMS];            /* cursor of every list; 0xFFFFFFFF = not started */
+    uint32_t ord[XGM_PHRASE_MAX_TERMS], h[XGM_PHRASE_MAX_TERMS];
+    for (uint32_t t = 0; t < XGM_PHRASE_MAX_TERMS; ++t) { cur[t] = 0xFFFFFFFFu; ord[t] = t; h[t] = 0; }
+    /* terms by ascending wdf (= positions of the document's posting), ties in query order */
+    for (uint32_t i = 1; i < n; ++i) {
+        const uint32_t v = ord[i];
+        uint32_t j = i;
+        while (j > 0 && (pl[v].n < pl[ord[j - 1]].n || (pl[v].n == pl[ord[j - 1]].n && qpos[v] < qpos[ord[j - 1]]))) { ord[j] = ord[j - 1]; --j; }
+        ord[j] = v;
+    }
+    auto pos = [&](uint32_t id) { return pl[id].at(cur[id]); };
+    auto next = [&](uint32_t id) { cur[id] = cur[id] == 0xFFFFFFFFu ? 0u : cur[id] + 1u; return cur[id] < pl[id].n; };
+    auto skip_to = [&](uint32_t id, uint32_t want) {           /* first position >= want, never backwards */
+        uint32_t c = cur[id] == 0xFFFFFFFFu ? 0u : cur[id];
+        while (c < pl[id].n && pl[id].at(c) < want) ++c;
+        cur[id] = c;
+        return c < pl[id].n;
+    };
+    auto above = [&](uint32_t a, uint32_t b) { return pos(a) > pos(b); };      /* Cmp: a min-heap on the heads' positions */
+    auto sift_down = [&](uint32_t len, uint32_t start) {
+        uint32_t child = start;
+        if (len < 2u || (len - 2u) / 2u < child) return;
+        child = 2u * child + 1u;
+        if (child + 1u < len && above(h[child], h[child + 1u])) ++child;
+        if (above(h[child], h[start])) return;
+        const uint32_t top = h[start];
+        const uint32_t top_pos = pos(top);
+        do {
+            h[start] = h[child];
+            start = child;
+            if ((len - 2u) / 2u < child) break;
+            child = 2u * child + 1u;
+            if (child + 1u < len && above(h[child], h[child + 1u])) ++child;
+        } while (!(pos(h[child]) > top_pos));
+        h[start] = top;
+    };
+    auto push = [&](uint32_t len) {                              /* h[len - 1] is new */
+        if (len < 2u) return;
+        uint32_t p = (len - 2u) / 2u, last = len - 1u;
+        if (!above(h[p], h[last])) return;
+        const uint32_t t = h[last];
+        const uint32_t t_pos = pos(t);
+        do {
+            h[last] = h[p];
+            last = p;
+            if (p == 0u) break;
+            p = (p - 1u) / 2u;
+        } while (pos(h[p]) > t_pos);
+        h[last] = t;
+    };
+    auto pop = [&](uint32_t len) {                               /* the top goes to h[len - 1] */
+        if (len < 2u) return;
+        const uint32_t t = h[0]; h[0] = h[len - 1u]; h[len - 1u] = t;
+        sift_down(len - 1u, 0u);
+    };
+    h[0] = ord[0];
+    if (!next(h[0])) return false;
+    uint32_t last = pos(h[0]), end = 1u;
+    while (true) {
+        if (last - pos(h[0]) < window) {
+            if (end != n) {
+                const uint32_t id = ord[end];
+                if (last < window) { if (!next(id)) return false; }
+                else if (!skip_to(id, last - window + 1u)) return false;
+                const uint32_t p = pos(id);
+                if (p > last) last = p;
+                h[end++] = id;
+                push(end);
+                continue;
+            }
+            /* every list inside the window: advance the ones that share a position with the head before them */
+            uint32_t p = pos(h[0]);
+            pop(end);
+            uint32_t i = end - 1u;
+            bool refit = false;
+            while (true) {
+                if (pos(h[0]) == p) {
+                    if (!next(h[0])) return false;
+                    const uint32_t np = pos(h[0]);
+                    if (np - pos(h[end - 1u]) >= window) { last = np; refit = true; break; }
+                    sift_down(i, 0u);                              /* Heap::replace */
+                    continue;
+                }
+                p = pos(h[0]);
+                pop(i);
+                if (--i == 0u) return true;
+            }
+            (void)refit;
+            if (end > 1u) for (int s = (int)((end - 2u) / 2u); s >= 0; --s) sift_down(end, (uint32_t)s);      /* Heap::make */
+            continue;
+        }
+        if (!skip_to(h[0], last - window + 1u)) break;
+        { const uint32_t p = pos(h[0]); if (p > last) last = p; }
+        sift_down(end, 0u);                                        /* Heap::replace */
+    }
+    return false;
+}
+
 __device__ __forceinline__ bool posfilter_slow(const PosList* pl, const xgm_dev_query& q, uint32_t T) {
+    if (q.flags & XGM_QF_NEAR_COLOC) return near_colocated(pl, q.phrase_index, T, q.window);
     if (q.flags & XGM_QF_NEAR) return near_window(pl, T, q.window);
     return (q.flags & XGM_QF_EXACT) ? phrase_exact(pl, q.phrase_index, T) : phrase_window(pl, q.phrase_index, T, q.window);
 }

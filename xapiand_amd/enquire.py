@@ -242,6 +242,10 @@ class Database:
     def set_stream(self, hip_stream):
         _lib.check(_lib.lib().xgm_index_set_stream(self._h, C.c_void_p(hip_stream)))
 
+    def set_near_colocated(self, may_exist=True):
+        """Distinct terms may share a position in this shard: OP_NEAR by NearPostList's full procedure (nearpostlist.cc:106-140)."""
+        _lib.check(_lib.lib().xgm_index_set_near_colocated(self._h, 1 if may_exist else 0))
+
     def set_profiling(self, on):
         """on: bit 0 = time the match kernel with HIP events, bit 1 = launch the tallying instantiation (xgm.h)."""
         _lib.check(_lib.lib().xgm_index_set_profiling(self._h, int(on)))
