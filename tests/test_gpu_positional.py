@@ -72,6 +72,9 @@ def test_slow_path_many_positions_and_wide_positions(built, tmp_path):
         doclen[d] = 70000
     c = H.ManualCorpus(post, doclen)
     db = Database(c.build_segment(str(tmp_path / "s.seg")))
+    # b's positions are drawn next to a's and can fall ON one of them: several terms per position — NEAR by NearPostList's full procedure
+    # (xgm_index_set_near_colocated; the oracle always runs it).  With > 16 positions per list that is the serial path from the LDS copy.
+    db.set_near_colocated(True)
     qs = []
     for terms in (["a", "b"], ["b", "a"], ["a", "b", "c"], ["w", "x"], ["a", "w"], ["x", "w", "a"]):
         for op, win in (("PHRASE", 0), ("PHRASE", len(terms) + 3), ("NEAR", len(terms) + 2), ("NEAR", 40)):
