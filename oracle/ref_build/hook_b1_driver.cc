@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
         else if (!strcmp(argv[a], "--replay")) { xgm_hook::set_replay(true); replay_on = true; }
         else if (!strcmp(argv[a], "--stale")) stale = true;
+        else if (!strcmp(argv[a], "--near-colocated")) xgm_hook::set_near_colocated_terms(true);     /* the indexer may put several terms at one position (nearpostlist.cc:106-140) */
     }
     if (argc - a < 2) { fprintf(stderr, "usage: xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]\n"); return 2; }
     try {
