@@ -29,53 +29,84 @@ def emu_lib(built):
     return os.path.join(EMU, "libxgm_emu.so")
 
 
-def run_device_tests(emu_lib, args, extra_env=None, timeout=900, and_kernel=False):
-    # every query through the workgroup kernels: the wave-autonomous ones use v_readlane under per-lane conditions
-    # guard pages behind every device buffer, a canary behind the LDS a launch asked for, a backtrace if a kernel faults
-    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_NO_ANDW="1", XGM_NO_ORW="1", XGM_NO_PHRASEW="1", XGM_NO_AND_KERNEL="1",
-               XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
-    if and_kernel:
-        del env["XGM_NO_AND_KERNEL"]           # conjunctions through xgm_and_kernel (its guarded payload loads carry XGM_EMU hooks)
-    env.update(extra_env or {})
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
-                       capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
-    return r.stdout
+EMU_SELECT = "golden or edge_cases"
+# every query through the workgroup kernels: the wave-autonomous ones use v_readlane under per-lane conditions
+WORKGROUP = dict(XGM_NO_ANDW="1", XGM_NO_ORW="1", XGM_NO_PHRASEW="1", XGM_NO_AND_KERNEL="1")
+PARITY, SORTED = os.path.join("tests", "test_gpu_parity.py"), os.path.join("tests", "test_gpu_sorted.py")
+# The emulated runs of the device tests: (pytest arguments, extra environment).  Each is a process of its own (the library reads its
+# switches once) that keeps ONE core busy for minutes — they are all started when this module's first test begins and run side by
+# side, beside the tests that drive the matcher hook; a test then waits for its own (the CPU tier's wall time was the SUM of these runs: 24 of its 28 minutes).
+DEVICE_RUNS = {
+    "value_sorts": ([SORTED], dict(WORKGROUP, XGM_RUN_UNVERIFIED="1")),
+    "match_kernels": ([PARITY, "-k", EMU_SELECT], WORKGROUP),
+    # conjunctions through xgm_and_kernel (its guarded payload loads carry XGM_EMU hooks)
+    "and_workgroup_kernel": ([PARITY, "-k", "edge_cases or (golden_single_shard and and_paging)"], {k: v for k, v in WORKGROUP.items() if k != "XGM_NO_AND_KERNEL"}),
+    "wave_kernels": ([PARITY, "-k", EMU_SELECT], {}),
+    "search_all": ([os.path.join("tests", "test_gpu_all.py")], WORKGROUP),
+    "flat": ([os.path.join("tests", "test_gpu_flat.py")], {}),
+    "positional": ([os.path.join("tests", "test_gpu_positional.py"), "-k", "slow_path or colocated"], {}),
+}
 
 
-def test_value_sorts_under_emulation(emu_lib):
+@pytest.fixture(scope="module", autouse=True)
+def device_runs(emu_lib, tmp_path_factory):
+    d = tmp_path_factory.mktemp("emu_runs")
+    procs = {}
+
+    def start_all():
+        for name, (args, extra) in DEVICE_RUNS.items():
+            # guard pages behind every device buffer, a canary behind the LDS a launch asked for, a backtrace if a kernel faults
+            env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
+            env.update(extra)
+            out = open(str(d / (name + ".out")), "w")
+            procs[name] = (subprocess.Popen([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                                            stdout=out, stderr=subprocess.STDOUT), out)
+
+    start_all()                                        # (autouse: when the module's first test begins; the waiting tests run last, conftest.py)
+
+    def result(name, timeout=3000):
+        p, out = procs[name]
+        rc = p.wait(timeout=timeout)
+        out.close()
+        text = open(str(d / (name + ".out"))).read()
+        assert rc == 0, text[-4000:]
+        return text
+
+    yield result
+    for p, out in procs.values():
+        if p.poll() is None:
+            p.kill()                                   # (the exact processes this fixture started)
+        out.close()
+
+
+def test_value_sorts_under_emulation(device_runs):
     """xgm_match_sorted_kernel + xgm_search_sorted (written without a GPU at hand) against the pinned oracle: the three sorts,
     both directions, AND / OR / AND_NOT / AND_MAYBE, deep pages, two stripe widths; the ValueCountMatchSpy of the same pass; set_collapse_key by relevance and under the sorts; and, through the Enquire mirror,
     the MSets the compiled reference itself recorded (golden fixtures: docid, weight bits, percentage, sort key at every rank)."""
-    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_sorted.py")], {"XGM_RUN_UNVERIFIED": "1"})
+    out = device_runs("value_sorts")
     assert "8 passed" in out, out
 
 
-def test_match_kernels_under_emulation(emu_lib):
+def test_match_kernels_under_emulation(device_runs):
     """The emulator's own credentials: device tests that are green on the MI355X are green on it too — the golden fixtures from
     the reference (AND-3, OR-5 top-100, paging, the two-sided operators, nested trees, PHRASE, four shards with the device shard
     merge) and the edge cases, through xgm_match_kernel and the merge kernels."""
-    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_parity.py"), "-k", EMU_SELECT])
+    out = device_runs("match_kernels")
     assert "passed" in out and "failed" not in out, out
 
 
-def test_and_workgroup_kernel_under_emulation(emu_lib):
+def test_and_workgroup_kernel_under_emulation(device_runs):
     """Conjunctions through xgm_and_kernel (candidate-driven decode, two waves' blocks in flight): paging golden and edge cases."""
-    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_parity.py"), "-k", "edge_cases or (golden_single_shard and and_paging)"], and_kernel=True)
+    out = device_runs("and_workgroup_kernel")
     assert "2 passed" in out, out
 
 
-EMU_SELECT = "golden or edge_cases"
-
-
-def test_wave_kernels_under_emulation(emu_lib):
+def test_wave_kernels_under_emulation(device_runs):
     """The default kernels — xgm_andw_kernel (queue path, xgm_dense_unit, positional filter K6), xgm_orw_kernel, the merge — on the
     golden fixtures of the reference (AND-3 top-10, OR-5 top-100, paging, the two-sided operators, nested trees, PHRASE, four
     shards) and the edge cases, guard pages behind every buffer."""
-    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_parity.py"),
-                        "-k", EMU_SELECT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "8 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    out = device_runs("wave_kernels")
+    assert "8 passed" in out, out
 
 
 def test_matcher_hook_under_emulation(emu_lib, tmp_path):
@@ -197,10 +228,10 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
     assert out["answered_on_device"] == len(qs), out
 
 
-def test_search_all_under_emulation(emu_lib):
+def test_search_all_under_emulation(device_runs):
     """xgm_search_all (every match in docid order; round 4) against the oracle's full ranking: all operator classes, trees, matches
     beyond one device page."""
-    out = run_device_tests(emu_lib, [os.path.join("tests", "test_gpu_all.py")])
+    out = device_runs("search_all")
     assert "3 passed" in out, out
 
 
@@ -234,22 +265,18 @@ def test_byte_compatible_modes_beyond_one_device_page_under_emulation(emu_lib, t
     assert out["answered_on_device"] == len(positional), out
 
 
-def test_flat_led_conjunctions_under_emulation(emu_lib):
+def test_flat_led_conjunctions_under_emulation(device_runs):
     """xgm_flat_unit and the flat posting arrays (round 4) against the oracle, every path through the tallies, without a GPU."""
-    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_flat.py")],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
-    assert r.returncode == 0 and "3 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    out = device_runs("flat")
+    assert "3 passed" in out, out
 
 
-def test_positional_slow_paths_under_emulation(emu_lib):
+def test_positional_slow_paths_under_emulation(device_runs):
     """The positional bodies' three ways to test a survivor — positions staged 64 documents at a time (<= 16 per term), 16 at a time (<= 64),
     one at a time from a copy in LDS (more, or 4-byte lists) — on hand-made documents, against the oracle, without a GPU."""
-    env = dict(os.environ, XGM_LIB_PATH=emu_lib, XGM_EMU_QUICK="1", XGM_EMU_GUARD="1", XGM_EMU_FAULT_TRACE="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", os.path.join("tests", "test_gpu_positional.py"),
-                        "-k", "slow_path or colocated"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     # (colocated: NEAR where several terms share a position — NearPostList's duplicate-position step restated on the device, round 4)
-    assert r.returncode == 0 and "2 passed" in r.stdout, "%s\n%s" % (r.stdout[-3000:], r.stderr[-2000:])
+    out = device_runs("positional")
+    assert "2 passed" in out, out
 
 
 def test_near_colocated_switch_through_the_hook_under_emulation(emu_lib, tmp_path):
