@@ -61,7 +61,8 @@ def parse_args():
     ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (xgm_get_mset_batch_begin ... xgm_batch_end)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 sub-legs of the default (C2) line")
     ap.add_argument("--no-hook-parity", action="store_true", help="skip the hook-on == hook-off leg on the reference's own glass index")
-    ap.add_argument("--hook-pos-docs", type=int, default=2_000_000, help="documents of the glass index WITH positions the C5 hook-parity leg builds (0: skip)")
+    ap.add_argument("--ref-no-positions", action="store_true", help="build the reference index of the headline run WITHOUT positions (faster; C5's reference baseline and hook-parity leg are then skipped)")
+    ap.add_argument("--ref-seconds", type=float, default=12.0, help="time box of the reference's all-core leg")
     ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--op", default="AND")
@@ -97,7 +98,9 @@ def workload_name(args, world, n_docs_global, k):
     shape = {"AND": "%d-term conjunctive" % args.terms, "OR": "%d-term disjunctive" % args.terms, "PHRASE": "2-3-term phrase (positions)"}.get(
         args.op, "%s (%d-term AND, %d on the right)" % (args.op, args.required, args.terms - args.required))
     if world > 1:
-        return "C4 (weak-scaled): %dM-doc index sharded %d ways, %s BM25 top-%d, RCCL top-k all-gather" % (n_docs_global // 1000000, world, shape, k)
+        import torch.distributed as dist
+        exchange = "RCCL top-k all-gather" if dist.is_initialized() and dist.get_backend() == "nccl" else "gloo top-k all-gather staged through host memory (functional run: not RCCL)"
+        return "C4 (weak-scaled): %dM-doc index sharded %d ways, %s BM25 top-%d, %s" % (n_docs_global // 1000000, world, shape, k, exchange)
     cfg = {"AND": "C2", "OR": "C3", "PHRASE": "C5"}.get(args.op, "next (SURVEY 8f.2)")
     return "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (cfg, args.docs_per_gpu // 1000000, args.vocab // 1000000, shape, k)
 
@@ -152,16 +155,21 @@ def run_steps(db, searcher, leg, steps, bps, depth, world, keep_last=False):
             return n, snap
         for s in range(steps):
             for j in range(bps):
-                d, g = leg.batches[(s * bps + j) % nb]
+                bi = (s * bps + j) % nb
+                d, g = leg.batches[bi]
                 h0 = time.perf_counter()
                 f = C.c_void_p()
                 _lib.check(L.xgm_get_mset_batch_begin(db._h, d, g, BATCH, k, C.byref(f)))
                 host_s += time.perf_counter() - h0
-                inflight.append(f)
+                inflight.append((f, bi))
                 if len(inflight) >= depth:
-                    delivered += finish(inflight.popleft(), False)[0]
+                    f0, b0 = inflight.popleft()
+                    n, snap = finish(f0, keep_last and b0 == 0 and s == steps - 1)      # (batch 0 of the LAST step: the oracle answers its first 128 queries)
+                    delivered += n
+                    last = snap or last
         while inflight:
-            n, snap = finish(inflight.popleft(), keep_last and len(inflight) == 0)
+            f0, b0 = inflight.popleft()
+            n, snap = finish(f0, keep_last and b0 == 0)
             delivered += n
             last = snap or last
         return host_s, delivered, last
@@ -239,7 +247,7 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
     # the last delivered batch against a synchronous search of the same batch: the rows on the host are the answer
     verified = None
     if world == 1 and last is not None:
-        d, g = leg.batches[(steps * bps - 1) % len(leg.batches)]
+        d, g = leg.batches[0]                                     # (the snapshot is batch 0 of the last timed step)
         hits = (_lib.Hit * (BATCH * k))()
         hdrs = (_lib.ResultHdr * BATCH)()
         _lib.check(L.xgm_get_mset_batch(db._h, d, g, BATCH, k, hits, hdrs))
@@ -354,12 +362,25 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
             "queries_per_step": bps * BATCH, "steps": steps, "elapsed_s": elapsed,
             "host_ms_per_batch": round(1e3 * host_s / n_batches_run, 4), "host_us_per_batch": host_sections,
             "hits_delivered_to_host": True, "rows_read_on_host": delivered, "last_batch_on_host_equals_synchronous_search": verified,
-            "roofline": roofline}
+            "_snapshot": last, "roofline": roofline}
 
 
-def parity_vs_port(db, leg, n=128):
+def snapshot_rows(snap, k, n):
+    """Rows 0..n of a delivered batch (the bytes xgm_batch_end handed out inside the timed region) → [(hits, (n_hits, subqs, matches, max_attained))]."""
+    import struct
+    out = []
+    for q in range(n):
+        nh, ms, mx, ma, _mp = struct.unpack_from("<IIQdd", snap[1], q * 32)
+        hits = [struct.unpack_from("<IId", snap[0], (q * k + j) * 16) for j in range(nh)]
+        out.append(([(d, w) for d, _, w in hits], (nh, ms, mx, ma)))
+    return out
+
+
+def parity_vs_port(db, leg, n=128, snapshot=None):
     """The GPU's answers to the first n queries of the timed pool against the oracle port run on the very postings the device holds
-    (copied back from HBM): docids, weight bit patterns, match counts.  Returns (queries checked, DeviceOracle) — outside any timing."""
+    (copied back from HBM): docids, weight bit patterns, match counts — through xgm_search_batch AND, when `snapshot` is given, the very
+    rows the TIMED entry point (xgm_get_mset_batch_begin ... xgm_batch_end) delivered to the host for batch 0 of the last timed step.
+    Returns (queries checked, DeviceOracle, rows of the timed batch checked) — outside any timing."""
     import helpers as H
     from xapiand_amd import _lib
     L = _lib.lib()
@@ -377,7 +398,87 @@ def parity_vs_port(db, leg, n=128):
         got = [(hits[qi * k + j].docid, hits[qi * k + j].weight) for j in range(hdrs[qi].n_hits)]
         assert got == [(d, w) for d, w, _ in rows], "GPU/CPU parity failure on %s bench query %d" % (leg.op, qi)
         H.check_matches(hdrs[qi].matches_exact, oh["matches"], len(got), (leg.op, qi))
-    return len(want), ora
+    timed_rows = 0
+    if snapshot is not None:
+        for qi, ((rows, oh), (got, hd)) in enumerate(zip(want, snapshot_rows(snapshot, k, min(n, BATCH)))):
+            assert got == [(d, w) for d, w, _ in rows], "timed batch / oracle parity failure on %s bench query %d" % (leg.op, qi)
+            H.check_matches(hd[2], oh["matches"], len(got), (leg.op, qi, "timed batch"))
+            timed_rows += 1
+    return len(want), ora, timed_rows
+
+
+def byte_compatible_leg(db, leg, ora, n=256, n_check=128):
+    """The REFERENCE-IDENTICAL modes of C5 / C3 through the C ABI, one query in flight (what the matcher hook does per get_mset in its
+    byte-compatible modes): the ordinary search for the page; then, when the page is full, xgm_search_replay — ProtoMSet's collation
+    replayed on the device over the whole match in docid order (the match never leaves HBM):
+      PHRASE  XGM_REPLAY_FROZEN_WEIGHT: the page, weights and known_matching_docs of the reference incl. SelectPostList's frozen weight
+              (selectpostlist.cc:28-55) — checked here against the oracle's reference mode (pinned to the compiled reference);
+      OR      XGM_REPLAY_COUNT: known_matching_docs behind the HTTP total (protomset.h:340-400) — checked against the host restatement
+              (xgm_known_matching_docs, pinned to the compiled reference) over xgm_search_all's list on a few queries.
+    Returns a dict with queries/s in that mode."""
+    import helpers as H
+    from xapiand_amd import _lib
+    L = _lib.lib()
+    k = leg.k
+    positional = leg.op == "PHRASE"
+    mode = 1 if positional else 0
+    hits = (_lib.Hit * k)()
+    page = (_lib.Hit * k)()
+    hdr, hdr2 = _lib.ResultHdr(), _lib.ResultHdr()
+    known = C.c_uint64()
+    db.set_stream(0)
+    n = min(n, len(leg.timed_plans))
+    lat, answers, replayed = [], [], 0
+    t0 = time.perf_counter()
+    for i in range(n):
+        a = time.perf_counter()
+        p = leg.timed_plans[i]
+        _lib.check(L.xgm_search(db._h, C.byref(p), hits, C.byref(hdr)))
+        rows, kn = None, None
+        if hdr.n_hits == k and (hdr.matches_exact & ((1 << 63) - 1)) > k or (positional and hdr.n_hits == k):
+            _lib.check(L.xgm_search_replay(db._h, C.byref(p), mode, page, C.byref(hdr2), C.byref(known)))
+            replayed += 1
+            kn = known.value
+            if positional:
+                rows = [(page[j].docid, page[j].weight) for j in range(hdr2.n_hits)]
+        if rows is None:
+            rows = [(hits[j].docid, hits[j].weight) for j in range(hdr.n_hits)]
+        lat.append(time.perf_counter() - a)
+        answers.append((rows, kn))
+    wall = time.perf_counter() - t0
+    lat.sort()
+    out = {"value": n / wall, "unit": "queries/s", "queries": n, "in_flight": 1, "p50_us": lat[len(lat) // 2] * 1e6, "p99_us": lat[int(len(lat) * 0.99)] * 1e6,
+           "replayed_on_device": replayed,
+           "what": ("xgm_search + xgm_search_replay(XGM_REPLAY_FROZEN_WEIGHT) per query: the reference's own top-%d incl. its frozen weight" % k) if positional else
+                   ("xgm_search + xgm_search_replay(XGM_REPLAY_COUNT) per query: the page + the reference's known_matching_docs (exact HTTP total)")}
+    if positional:
+        sample = leg.timed_pool[:min(n_check, n)]
+        want = H.oracle_search_batch(ora, sample, 0, k, reference_select_bug=True)
+        differs_from_intended = 0
+        intended = H.oracle_search_batch(ora, sample, 0, k)
+        for qi, ((rows, _), (irows, _)) in enumerate(zip(want, intended)):
+            assert answers[qi][0] == [(d, w) for d, w, _ in rows], "reference-mode parity failure on C5 bench query %d" % qi
+            differs_from_intended += [(d, w) for d, w, _ in rows] != [(d, w) for d, w, _ in irows]
+        out["parity_checked_queries"] = len(want)
+        out["parity_against"] = "oracle/xgm_oracle.cc in reference mode (SelectPostList's stale cached weight restated; pinned to the compiled reference)"
+        out["answers_that_differ_from_the_intended_top_k"] = differs_from_intended
+    else:
+        L.xgm_known_matching_docs.restype = C.c_uint64
+        L.xgm_known_matching_docs.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.c_uint32]
+        checked = 0
+        for qi in range(min(6, n)):
+            if answers[qi][1] is None:
+                continue
+            p = leg.timed_plans[qi]
+            cap = max(1, p.est_max)
+            allh = (_lib.Hit * cap)()
+            nm = C.c_uint64()
+            _lib.check(L.xgm_search_all(db._h, C.byref(p), allh, cap, C.byref(nm), C.byref(hdr2)))
+            w = (C.c_double * nm.value)(*[allh[j].weight for j in range(nm.value)])
+            assert L.xgm_known_matching_docs(w, nm.value, k, p.check_at_least) == answers[qi][1], "known_matching_docs differs on C3 bench query %d" % qi
+            checked += 1
+        out["known_matching_docs_checked_queries"] = checked
+    return out
 
 
 def latency_leg(db, leg, n_timed):
@@ -477,6 +578,9 @@ def main():
                        "queries_per_step": args.batches_per_step * BATCH, "batches_in_flight": args.in_flight if world == 1 else 2,
                        "parallelism": "shard%d" % world,
                        "corpus_seed": hex(CORPUS_SEED), "query_seed": hex(QUERY_SEED),
+                       "corpus": "BASELINE.md §3's distribution (Zipf s = 1 over the vocabulary, document lengths uniform in [50, 150], positions 1..L, contiguous docids) drawn from a "
+                                 "COUNTER HASH of (seed, document, position) instead of std::mt19937_64 — a deviation from §3's letter, chosen so that the GPU builder, the CPU oracle and "
+                                 "the reference's indexer generate any document independently (tools/xgm_corpus.h); every side of every comparison uses the same generator",
                        "step": ("%d x xgm_get_mset_batch_begin (plan: lookups, BM25 init, leaf order + match + merge, 256 queries) ... xgm_batch_end: the hits and "
                                 "headers of every batch delivered to pinned HOST memory, %d batches in flight" % (args.batches_per_step, args.in_flight)) if world == 1 else
                                ("%d x (xgm_get_mset_batch_device + all-gather of the shards' top-k + xgm_merge_shards_device, 256 queries) with the merged hits "
@@ -502,10 +606,14 @@ def main():
                 lg = Leg(searcher, op, terms, 1, kk, n_docs_global, args.vocab, n_pool_batches)
                 mm = measure(db, searcher, lg, args, world, rank, dev, st, 1)
                 ll = latency_leg(db, lg, min(220, len(lg.timed_pool))) if not args.no_latency else []
-                checked, ora = parity_vs_port(db, lg, 128)
+                checked, ora, timed_rows = parity_vs_port(db, lg, 128, mm.pop("_snapshot", None))
                 port = None
                 if not args.no_cpu_baseline:
                     port = time_port(ora, lg.timed_pool[:32], op, kk, min(4.0, args.cpu_seconds), 0)
+                try:
+                    compat = byte_compatible_leg(db, lg, ora)
+                except Exception as e:
+                    compat = {"error": repr(e)}
                 ora.close()
                 others[name] = {"workload": "%s: %dM-doc / %dM-term Zipf index, %s BM25 top-%d, 1 MI355X" % (
                                     name, args.docs_per_gpu // 1000000, args.vocab // 1000000, "5-term disjunctive" if op == "OR" else "2-3-term phrase (positions)", kk),
@@ -513,7 +621,11 @@ def main():
                                 "ms_per_batch": mm["ms_per_batch"], "hits_delivered_to_host": True,
                                 "last_batch_on_host_equals_synchronous_search": mm["last_batch_on_host_equals_synchronous_search"],
                                 "p50_latency_us": ll[len(ll) // 2] * 1e6 if ll else None, "p99_latency_us": ll[int(len(ll) * 0.99)] * 1e6 if ll else None,
-                                "roofline": mm["roofline"], "parity_checked_queries": checked,
+                                "roofline": mm["roofline"], "parity_checked_queries": checked, "timed_batch_rows_checked_against_oracle": timed_rows,
+                                ("reference_identical_mode" if op == "PHRASE" else "exact_bounds_mode"): compat,
+                                "headline_mode": ("intended semantics (the top-k of the reference's own full ranking, positional pruning); the reference itself answers part of these "
+                                                  "queries differently (SelectPostList's frozen weight, DESIGN.md 7.1): `reference_identical_mode` is its answer, measured beside it") if op == "PHRASE" else
+                                                 "the reference's own top-k (bit-identical); `exact_bounds_mode` adds its known_matching_docs (the exact HTTP total)",
                                 "cpu_baseline": dict(port, kind="port", sample="first 32 queries of the timed pool, oracle port on the postings copied back from HBM") if port else None}
             except Exception as e:                # a sub-leg must not take the headline line down with it: say what happened
                 others[name] = {"error": repr(e)}
@@ -521,7 +633,7 @@ def main():
 
     # ---- CPU baseline: the real reference + the oracle port, on this box's host cores -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(db, leg.timed_pool, args, k, leg.timed_plans, result)
+        result["cpu_baseline"] = cpu_baseline(db, leg.timed_pool, args, k, leg.timed_plans, result, m.get("_snapshot"))
     if rank == 0:
         print(json.dumps(result), flush=True)
     db.close()
@@ -599,51 +711,50 @@ HOOK_B1 = os.path.join(ROOT, "oracle", "_ref", "xapian_hook_b1")
 
 
 def run_hook_b1(flags, qfile, dbdir, timeout=1500):
-    r = subprocess.run([HOOK_B1] + flags + [qfile, dbdir], capture_output=True, text=True, timeout=timeout)
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    if not line:
-        return {"error": (r.stdout[-600:] + r.stderr[-600:]) or "no output", "returncode": r.returncode}
-    out = json.loads(line[-1])
-    out["returncode"] = r.returncode
+    r = subprocess.run([HOOK_B1] + flags + ([qfile] if qfile else []) + [dbdir], capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if not lines:
+        return [{"error": (r.stdout[-600:] + r.stderr[-600:]) or "no output", "returncode": r.returncode}]
+    outs = [json.loads(l) for l in lines]
     bad = [l for l in r.stdout.splitlines() if l.startswith(("MISMATCH", "BOUNDS"))]
+    for o in outs:
+        o["returncode"] = r.returncode
     if bad:
-        out["first_differences"] = bad[:5]
-    return out
+        outs[-1]["first_differences"] = bad[:5]
+    return outs
 
 
-def hook_parity_leg(args, tmp, dbdir, ref_docs, pools, pos_docs):
-    """The boundary at (reference-index) size, through the REAL reference (VERDICT r3 #1b): oracle/_ref/xapian_hook_b1 — the vendored
+def hook_parity_leg(args, tmp, dbdir, ref_docs, pools, has_positions):
+    """The boundary at (reference-index) size, through the REAL reference (VERDICT r3 #1b, r4 #1a): oracle/_ref/xapian_hook_b1 — the vendored
     Xapian with integration/matcher_hook.patch applied and integration/xgm_matcher_hook.cc linked in — exports the glass index this
-    run just built with the native reader (xgm_segment_build_from_glass, timed), loads it onto the GPU, registers it with the hook and
-    answers the first 128 queries of the C2 and C3 pools with the hook OFF (CPU matcher) and ON (device) — exact match-count figures on
-    (byte-compatible mode: xgm_search_all + xgm_known_matching_docs / the replay of the reference's loop) — and, on a second glass
-    index WITH positions, the first 128 C5 queries in POSITIONAL_REFERENCE mode.  Identical MSets required: docids, weight bits,
-    percentages, matches_lower / estimated / upper, HTTP total."""
+    run just built with the native reader (xgm_segment_build_from_glass, timed; ONE export and load for all legs), registers it with the
+    hook and answers the first 128 queries of the C2 and C3 pools with the hook OFF (CPU matcher) and ON (device) — exact match-count
+    figures on (byte-compatible mode: the device counts as ProtoMSet would, xgm_search_replay) — and, the index having positions, the
+    first 128 C5 queries in POSITIONAL_REFERENCE mode (the frozen-weight replay on the device) AT THE SAME SIZE.  Identical MSets
+    required: docids, weight bits, percentages, matches_lower / estimated / upper, HTTP total."""
     import helpers as H
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import ref_index
     if not os.path.exists(HOOK_B1):
         return {"skipped": "oracle/_ref/xapian_hook_b1 is not built"}
     out = {"docs": ref_docs, "shapes": {}}
     total = dict(queries=0, mismatches=0, bounds_violations=0, http_total_equal=0, answered_on_device=0)
-    for name in ("C2", "C3"):
+    flags = []
+    for name, mode in (("C2", "exact-bounds"), ("C3", "exact-bounds"), ("C5", "positional-reference")):
+        if name == "C5" and not has_positions:
+            continue
         qf = os.path.join(tmp, "hook_%s.txt" % name)
         H.write_queries(qf, [dict(q, first=0) for q in pools[name][:128]])
-        r = run_hook_b1(["--exact-bounds"], qf, dbdir)
-        out["shapes"][name] = r
+        flags += ["--leg", "%s:%s:%s" % (name, mode, qf)]
+    for r in run_hook_b1(flags + ["-"], None, dbdir):
+        name = r.pop("leg", "error")
+        out["shapes"]["C5 (POSITIONAL_REFERENCE)" if name == "C5" else name] = r
+        if r.get("queries") and r.get("hook_seconds"):
+            r["hook_queries_per_second"] = r["queries"] / r["hook_seconds"]
+            r["cpu_matcher_queries_per_second"] = r["queries"] / r["cpu_matcher_seconds"]
         if "export_seconds" in r and "exporter" not in out:
-            out["exporter"] = {"docs": r["docs"], "seconds": r["export_seconds"], "segment_bytes": r["segment_bytes"], "open_seconds": r["open_seconds"],
-                               "what": "xgm_segment_build_from_glass: the glass B-trees read natively (postlist.glass), block-encoded, written"}
-    if pos_docs > 0:
-        posdir = os.path.join(tmp, "glass_pos")
-        binfo = ref_index.build(posdir, pos_docs, nopos=False, vocab=args.vocab)
-        qf = os.path.join(tmp, "hook_C5.txt")
-        # (the PHRASE pool is drawn from documents of the full corpus; on the smaller index some phrases match less — or nothing: still a query)
-        H.write_queries(qf, [dict(q, first=0) for q in pools["C5"][:128]])
-        r = run_hook_b1(["--positional-reference"], qf, posdir)
-        r["index_build"] = binfo
-        out["shapes"]["C5 (POSITIONAL_REFERENCE)"] = r
-        out["docs_with_positions"] = pos_docs
+            out["exporter"] = {"docs": r["docs"], "seconds": r["export_seconds"], "segment_bytes": r["segment_bytes"], "open_seconds": r["open_seconds"], "positions": has_positions,
+                               "what": "xgm_segment_build_from_glass: the glass B-trees read natively (postlist.glass, position.glass), block-encoded, written; once for all legs"}
+    if has_positions:
+        out["docs_with_positions"] = ref_docs
     for r in out["shapes"].values():
         for key in total:
             if key in r:
@@ -654,7 +765,23 @@ def hook_parity_leg(args, tmp, dbdir, ref_docs, pools, pos_docs):
     return out
 
 
-def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None):
+def time_reference(H, qfile, threads, repeat, seconds, dbdir):
+    """`xapian_ref time` (oracle/ref_build/ref_driver.cc cmd_time: one shared atomic work counter, handles opened and warmed before the start
+    barrier) → its JSON."""
+    return json.loads(H.xapian_ref("time", qfile, threads, repeat, "--seconds", seconds, dbdir))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
+def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, pool_all=None):
     """The real reference on this box: build a glass index of the first --ref-docs documents of the corpus with
     the reference's own WritableDatabase (parallel slices + Database::compact, tools/ref_index.py), time
     Enquire::get_mset on 1 thread and on every core (one Database handle per thread) with
@@ -669,18 +796,43 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None):
     ref_docs = args.ref_docs if args.ref_docs >= 0 else (args.docs_per_gpu if headline else args.docs_per_gpu // 10 if args.op == "PHRASE" else args.docs_per_gpu // 5)
     if not H.have_xapian_ref() or ref_docs <= 0:
         return None
+    # the headline run builds ONE index of the configuration's own size WITH positions: it serves C2, C3 (the position table is never
+    # opened by AND / OR) and C5, the reference's timings of all three and the hook-parity legs (round 4: two indexes, C5's at 2 M documents)
+    with_positions = args.op == "PHRASE" or (hook_pools is not None and not args.ref_no_positions)
     # the index lives in memory-backed storage when there is one: indexing through WritableDatabase is write-heavy
     tmp = tempfile.mkdtemp(prefix="xgm_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
     try:
         dbdir = os.path.join(tmp, "glass")
-        binfo = ref_index.build(dbdir, ref_docs, nopos=args.op != "PHRASE", vocab=args.vocab)
+        binfo = ref_index.build(dbdir, ref_docs, nopos=not with_positions, vocab=args.vocab)
         qfile = os.path.join(tmp, "q.txt")
         H.write_queries(qfile, [dict(q, first=0, maxitems=k) for q in sample])
         cores = max(1, os.cpu_count() or 1)
-        one = json.loads(H.xapian_ref("time", qfile, 1, 2, dbdir))
-        # enough repeats that every thread answers a few dozen queries
-        rep = max(2, (cores * 24 + len(sample) - 1) // len(sample))
-        many = json.loads(H.xapian_ref("time", qfile, cores, rep, dbdir))
+        one = time_reference(H, qfile, 1, 2, 60, dbdir)
+        # all cores: the whole timed pool (>= 8 queries per thread wherever the pool allows), handed out by one atomic counter, time-boxed
+        pool_file = os.path.join(tmp, "q_pool.txt")
+        H.write_queries(pool_file, [dict(q, first=0, maxitems=k) for q in (pool_all or sample)])
+        many = time_reference(H, pool_file, cores, 64, args.ref_seconds, dbdir)
+        others = {}
+        if hook_pools is not None:
+            # the reference itself on C3 and C5: 1 thread on the first 48 queries, all cores on the pool, same index
+            for name, kk in (("C3", 100), ("C5", 10)):
+                if name == "C5" and not with_positions:
+                    continue
+                try:
+                    qf1, qfp = os.path.join(tmp, "q1_%s.txt" % name), os.path.join(tmp, "qp_%s.txt" % name)
+                    H.write_queries(qf1, [dict(q, first=0, maxitems=kk) for q in hook_pools[name][:48]])
+                    H.write_queries(qfp, [dict(q, first=0, maxitems=kk) for q in hook_pools[name]])
+                    o1 = time_reference(H, qf1, 1, 1, 30, dbdir)
+                    om = time_reference(H, qfp, cores, 64, max(4.0, args.ref_seconds / 2), dbdir)
+                    others[name] = {"kind": "reference", "value": o1["qps"], "unit": "queries/s", "cores": 1, "p50_ms": o1["p50_us"] / 1e3, "queries": o1["queries"],
+                                    "all_cores": {"value": om["qps"], "unit": "queries/s", "cores": cores, "p50_ms": om["p50_us"] / 1e3, "queries": om["queries"],
+                                                  "pool": om["pool"], "seconds": om["wall_s"]},
+                                    "docs": ref_docs,
+                                    "sample": "Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time) on the glass index of the headline leg (%d documents%s): "
+                                              "1 thread over the first 48 queries of the timed pool, all cores over %d queries of it for %.0f s" % (
+                                                  ref_docs, ", positions" if with_positions else "", om["pool"], om["wall_s"])}
+                except Exception as e:
+                    others[name] = {"error": repr(e)}
         # the port on the same postings: the same corpus generated on the GPU at the reference index's size
         small = None
         if ref_docs == full["docs"]:
@@ -704,12 +856,15 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None):
             ora.close()
             small.close()
         out = {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
-               "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3},
+               "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3, "queries": many["queries"], "pool": many["pool"],
+                             "seconds": many["wall_s"], "efficiency_vs_cores_x_one_thread": many["qps"] / (cores * one["qps"]),
+                             "scheduling": many.get("scheduling")},
+               "cpu_model": cpu_model(), "_others": others,
                "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
                "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
         if hook_pools is not None:
             try:
-                out["_hook_parity"] = hook_parity_leg(args, tmp, dbdir, ref_docs, hook_pools, args.hook_pos_docs)
+                out["_hook_parity"] = hook_parity_leg(args, tmp, dbdir, ref_docs, hook_pools, with_positions)
             except Exception as e:
                 out["_hook_parity"] = {"error": repr(e)}
         return out
@@ -717,7 +872,7 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def cpu_baseline(db, pool_q, args, k, timed_plans, result=None):
+def cpu_baseline(db, pool_q, args, k, timed_plans, result=None, snapshot=None):
     """`value` is the REAL reference when oracle/_ref/xapian_ref is present (kind "reference": Enquire::get_mset of the
     vendored Xapian on a --ref-docs glass index built on this box), else the port (kind "port").  Always also: the
     port at the configuration's full size on the postings copied back from HBM, 1 thread and all cores, with the GPU
@@ -732,12 +887,18 @@ def cpu_baseline(db, pool_q, args, k, timed_plans, result=None):
     one_hits = (_lib.Hit * k)()
     one_hdr = _lib.ResultHdr()
     checked = [0]
+    timed_rows = [0]
+    snap_rows = snapshot_rows(snapshot, k, min(len(sample), BATCH)) if snapshot is not None else None
 
     def checker(qi, hits):          # parity of the GPU answer on every sampled query, outside the timing
         _lib.check(L.xgm_search(db._h, C.byref(timed_plans[qi]), one_hits, C.byref(one_hdr)))
         got = [(one_hits[j].docid, one_hits[j].weight) for j in range(one_hdr.n_hits)]
         assert got == [(d, w) for d, w, _ in hits], "GPU/CPU parity failure on bench query %d" % qi
         checked[0] += 1
+        # ... and of the very rows the TIMED entry point delivered to the host (batch 0 of the last timed step)
+        if snap_rows is not None and qi < len(snap_rows):
+            assert snap_rows[qi][0] == [(d, w) for d, w, _ in hits], "timed batch / oracle parity failure on bench query %d" % qi
+            timed_rows[0] += 1
     db.set_stream(0)
     full = time_port(ora, sample, args.op, k, args.cpu_seconds, n_required, checker)
     full["all_cores"] = port_all_cores(ora, sample, args.op, k, min(5.0, args.cpu_seconds), n_required)
@@ -750,11 +911,20 @@ def cpu_baseline(db, pool_q, args, k, timed_plans, result=None):
         if result is not None and not args.no_hook_parity and args.op == "AND" and args.terms == 3 and k == 10:
             n_docs = db.info().doccount
             hook_pools = {"C2": [dict(q, maxitems=10) for q in pool_q[:128]],
-                          "C3": H.bench_pool("OR", 5, 1, n_docs, args.vocab, n=228, seed=QUERY_SEED, maxitems=100)[100:],
-                          "C5": H.bench_pool("PHRASE", 3, 1, n_docs, args.vocab, n=228, seed=QUERY_SEED, maxitems=10)[100:]}
-        ref = reference_leg(args, sample, k, n_required, full, ora, hook_pools)
+                          "C3": H.bench_pool("OR", 5, 1, n_docs, args.vocab, n=100 + 2048, seed=QUERY_SEED, maxitems=100)[100:],
+                          "C5": H.bench_pool("PHRASE", 3, 1, n_docs, args.vocab, n=100 + 2048, seed=QUERY_SEED, maxitems=10)[100:]}
+        ref = reference_leg(args, sample, k, n_required, full, ora, hook_pools, pool_q)
         if ref and "_hook_parity" in ref:
             result["hook_parity"] = ref.pop("_hook_parity")
+        if ref:
+            # the reference's own timings of C3 / C5 become those sub-legs' cpu_baseline (the port's stays beside it)
+            for name, rb in (ref.pop("_others", None) or {}).items():
+                oc = (result or {}).get("other_configs", {}).get(name)
+                if oc is not None and "error" not in rb:
+                    rb["port_same_queries"] = oc.get("cpu_baseline")
+                    oc["cpu_baseline"] = rb
+                elif oc is not None:
+                    oc["cpu_baseline_reference_error"] = rb["error"]
     except Exception as e:       # the reference leg is best effort (disk space, missing binary): say why it is absent
         ref = None
         sample_txt += "; reference leg failed: %r" % (e,)
@@ -775,9 +945,10 @@ def cpu_baseline(db, pool_q, args, k, timed_plans, result=None):
                          "corpus built on this box (%.0f s on %d cores + %.0f s compact), same queries; " % (ref["docs"], ref["index_build"]["build_s"],
                                                                                                        ref["index_build"]["procs"], ref["index_build"]["compact_s"])) + sample_txt
         out["parity_checked_queries"] = checked[0]
+        out["timed_batch_rows_checked_against_oracle"] = timed_rows[0]
         return out
     out = dict(full)
-    out.update(kind="port", sample=sample_txt, parity_checked_queries=checked[0])
+    out.update(kind="port", sample=sample_txt, parity_checked_queries=checked[0], timed_batch_rows_checked_against_oracle=timed_rows[0])
     return out
 
 

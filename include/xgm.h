@@ -456,12 +456,33 @@ int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xgm_sort_spec
  * check_at_least are ignored (positional queries test every candidate's positions).  hits[0 .. *n_matches) are written when
  * *n_matches <= cap; otherwise nothing is written and *n_matches tells the room needed (plan->est_max — the tree's own
  * get_termfreq_max — always suffices).  hdr: matches_exact = *n_matches, max_attained / max_weight_subqs_matched of the whole match,
- * n_hits = hits written.  Every query shape xgm_search takes (positional queries of up to 3 terms); one query per call.
+ * n_hits = hits written.  Every query shape xgm_search takes (positional queries of up to 8 terms: beyond 3 the kernel takes every stripe
+ * in several passes over narrower LDS tables); one query per call.
  * What it is for: answers that must be BYTE-COMPATIBLE with the reference where the reference's answer depends on its traversal —
  * known_matching_docs behind MSet::get_matches_lower_bound / _estimated (protomset.h:497-619; xgm_known_matching_docs), the frozen
  * weight of PHRASE / NEAR (selectpostlist.cc:28-55), the snapshot's collapser, cut-offs and spies by relevance — for matches of ANY
  * size (rounds 1-3 could fetch at most XGM_MAX_K of them).  The matcher hook replays the reference's own loop over this list. */
 int xgm_search_all(xgm_index*, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr);
+
+/* The reference's own COLLATION of a search by relevance, replayed on the device over that list — without the list ever leaving HBM.
+ * Matcher::get_local_mset's loop (matcher/matcher.cc:482-536) drops a document whose weight is below ProtoMSet's min_weight and shows
+ * the others to ProtoMSet::add (matcher/protomset.h:340-400), which counts them (known_matching_docs), keeps the best
+ * first + maxitems and raises min_weight when the heap is made and at every replacement — if check_at_least documents have been
+ * counted by then.  That sequence decides MSet::get_matches_lower_bound / _estimated (Xapiand's HTTP "total",
+ * src/server/http_client.cc:2554) and, for OP_PHRASE / OP_NEAR, the page itself: once min_weight is positive SelectPostList::vet
+ * (matcher/selectpostlist.cc:28-55) weighs the next document of the underlying conjunction, caches that weight and serves it for
+ * every later match.  One workgroup walks the docid-ordered match exactly so (xgm_replay.hip): only the page and the figures
+ * cross PCIe.  q->first + q->maxitems and q->check_at_least (as Enquire::get_mset clamps it) are ProtoMSet's max_size and
+ * check_at_least.
+ *   XGM_REPLAY_COUNT          any shape xgm_search_all takes: hits[0 .. hdr->n_hits) = the page as ProtoMSet keeps it (the best
+ *                             first + maxitems — what xgm_search returns), *known_matching_docs = ProtoMSet's count
+ *                             (= xgm_known_matching_docs over the weights of xgm_search_all's list)
+ *   XGM_REPLAY_FROZEN_WEIGHT  OP_PHRASE / OP_NEAR (<= 8 terms): the page, weights and count of the REFERENCE, frozen weight included
+ * hdr: matches_exact = the exact match count, max_attained / max_weight_subqs_matched = ProtoMSet's max_weight and the leaves of the
+ * document that set it (under XGM_REPLAY_FROZEN_WEIGHT this can be the frozen weight), n_hits = hits written. */
+#define XGM_REPLAY_COUNT 0u
+#define XGM_REPLAY_FROZEN_WEIGHT 1u
+int xgm_search_replay(xgm_index*, const xgm_query* q, uint32_t mode, xgm_hit* hits, xgm_result_hdr* hdr, uint64_t* known_matching_docs);
 
 
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */

@@ -40,6 +40,7 @@ std::map<std::string, Shard> g_shards;
 std::map<std::string, std::shared_ptr<const SpyAdapter>> g_spy_adapters;      /* (shared: a search keeps its adapter although the name is registered again meanwhile) */
 std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false}, g_replay{false};
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
+std::atomic<uint64_t> g_replay_limit{4u * 1000u * 1000u};       /* matches up to which a replay downloads the match (set_replay_limit) */
 std::atomic<uint32_t> g_column_limit{50u * 1000u * 1000u};     /* documents per shard up to which a column is built on the search thread */
 std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0};
 
@@ -405,89 +406,22 @@ class ReplayPostList : public Xapian::Internal::PostList {
     std::string get_description() const override { return "XgmReplay(" + std::to_string(n_hits) + ")"; }
 };
 
-/* ProtoMSet::add for a search by relevance (protomset.h:340-400) with the weight the matcher's loop hands it, and the loop's own
- * `weight < min_weight` test in front (matcher.cc:500-505): what POSITIONAL_REFERENCE replays on the host. */
-struct RefProtoMSet {
-    struct Item { double w; Xapian::docid did; uint32_t subqs; };
-    size_t max_size; uint64_t check_at_least;
-    std::vector<Item> results;
-    std::vector<uint32_t> heap;                 /* indices into results, worst on top */
-    bool heap_built = false;
-    double min_weight = 0.0, max_weight = 0.0;
-    uint32_t max_weight_subqs = 0;
-    uint64_t known_matching_docs = 0;
-    static bool before(const Item& a, const Item& b) { return a.w > b.w || (a.w == b.w && a.did < b.did); }      /* msetcmp_by_relevance<true> */
-    bool worse_first(uint32_t a, uint32_t b) const { return before(results[a], results[b]); }
-    void add(const Item& it) {
-        ++known_matching_docs;
-        if (it.w > max_weight) { max_weight = it.w; max_weight_subqs = it.subqs; }
-        if (it.w < min_weight) return;
-        if (results.size() < max_size) { results.push_back(it); return; }
-        if (max_size == 0) return;
-        auto cmp = [this](uint32_t a, uint32_t b) { return worse_first(a, b); };
-        if (!heap_built) {
-            heap_built = true;
-            for (uint32_t i = 0; i < results.size(); ++i) heap.push_back(i);
-            std::make_heap(heap.begin(), heap.end(), cmp);
-            if (known_matching_docs >= check_at_least) min_weight = results[heap.front()].w;
-        }
-        const uint32_t worst = heap.front();
-        if (!before(it, results[worst])) return;
-        results[worst] = it;
-        std::pop_heap(heap.begin(), heap.end(), cmp);
-        heap.back() = worst;
-        std::push_heap(heap.begin(), heap.end(), cmp);
-        if (known_matching_docs >= check_at_least) min_weight = results[heap.front()].w;
-    }
-};
-
-/* The weight the reference freezes (selectpostlist.cc:28-55): that of the first document after `after` that ALL the query's terms
- * index, weighed like MultiAndPostList::get_weight does — the plan's leaf order and term weights, BM25Weight::get_sumpart's
- * operations (bm25weight.cc:170-181).  Found with the shard's own posting lists.  false: there is none. */
-bool frozen_weight(const Xapian::Database& db, const std::vector<std::string>& terms, const xgm_query& plan, Xapian::docid after, double* w_out) {
-    const uint32_t n = plan.n_terms;
-    std::vector<Xapian::PostingIterator> it(n), end(n);
-    for (uint32_t p = 0; p < n; ++p) {
-        const std::string& t = terms[plan.terms[p].phrase_index];
-        it[p] = db.postlist_begin(t); end[p] = db.postlist_end(t);
-        if (it[p] == end[p]) return false;
-    }
-    Xapian::docid did = after + 1;
-    while (true) {
-        bool all = true;
-        for (uint32_t p = 0; p < n; ++p) {
-            it[p].skip_to(did);
-            if (it[p] == end[p]) return false;
-            if (*it[p] != did) { did = *it[p]; all = false; break; }
-        }
-        if (all) break;
-    }
-    const double len = (double)db.get_doclength(did);
-    double normlen = len * plan.len_factor;
-    normlen = normlen > plan.min_normlen ? normlen : plan.min_normlen;
-    const double denom_len = plan.k1 * (normlen * plan.b + (1.0 - plan.b));
-    double weight = 0.0;
-    for (uint32_t p = 0; p < n; ++p) {
-        const double wdf = (double)it[p].get_wdf();
-        const double denom = denom_len + wdf;
-        weight = weight + plan.terms[p].termweight * (wdf / denom);
-    }
-    *w_out = weight;
-    return true;
-}
-
 /* EVERY matching document of a planned query in ascending docid order with its weight (xgm_search_all): what the byte-compatible
  * modes replay — of any size since round 4 (rounds 1-3: at most XGM_MAX_K documents, fetched as one page and sorted here).  The
  * buffer is sized by the tree's own upper bound (plan.est_max = PostList::get_termfreq_max of the tree the reference builds), left
  * uninitialised: only the matches are ever touched.  Returns the library's code. */
 int fetch_all(xgm_index* idx, const xgm_query& plan, Xapian::doccount doccount, std::unique_ptr<xgm_hit[]>* out, uint64_t* n, xgm_result_hdr* hdr) {
-    const uint64_t cap = std::max<uint64_t>(1, plan.est_max ? std::min<uint64_t>(plan.est_max, doccount) : doccount);
+    /* sized by the match itself, not by the plan's upper bound (a frequent-term OR on 10 M documents would allocate 240 MB per call
+     * for a few thousand matches): a first call with no room only counts; beyond the configured ceiling the search is left to the
+     * CPU matcher (XGM_UNSUPPORTED) — set_replay_limit */
+    (void)doccount;
+    int rc = xgm_search_all(idx, &plan, nullptr, 0, n, hdr);
+    if (rc != XGM_OK || *n == 0) return rc;
+    if (*n > g_replay_limit.load(std::memory_order_relaxed)) return XGM_UNSUPPORTED;
+    const uint64_t cap = *n;
     out->reset(new xgm_hit[cap]);
-    int rc = xgm_search_all(idx, &plan, out->get(), cap, n, hdr);
-    if (rc == XGM_OK && *n > cap) {                           /* (cannot happen with a bound from the plan; be exact anyway) */
-        out->reset(new xgm_hit[*n]);
-        rc = xgm_search_all(idx, &plan, out->get(), *n, n, hdr);
-    }
+    rc = xgm_search_all(idx, &plan, out->get(), cap, n, hdr);
+    if (rc == XGM_OK && *n > cap) rc = XGM_UNSUPPORTED;        /* (the shard changed between the two calls: cannot happen under the shard lock) */
     return rc;
 }
 
@@ -517,6 +451,7 @@ void set_near_colocated_terms(bool may_exist) {
     for (auto& kv : g_shards) xgm_index_set_near_colocated(kv.second.idx, may_exist ? 1 : 0);
 }
 void set_replay(bool on) { g_replay.store(on); }
+void set_replay_limit(uint64_t max_matches) { g_replay_limit.store(max_matches); }
 void set_column_build_limit(uint32_t max_documents) { g_column_limit.store(max_documents); }
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter) {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -690,56 +625,23 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     if (rc > 0) { ++g_dev; return false; }                                   /* declined by the device path: CPU matcher */
     if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
 
-    /* POSITIONAL_REFERENCE: a full page of a positional query — the reference's own answer, replayed (see the header) */
+    /* POSITIONAL_REFERENCE: a full page of a positional query — the reference's own answer, replayed ON THE DEVICE (round 5; rounds
+     * 3-4 downloaded the whole match and looped on the host): xgm_search_replay tests every candidate's positions, walks the match in
+     * docid order as ProtoMSet would and freezes the weight as SelectPostList does (selectpostlist.cc:28-55) — phrases of up to 8 terms */
     const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
-    /* exact match-count bounds for the shapes whose known_matching_docs depends on more than the match in docid order being visited in
-     * full (OR, AND_MAYBE, trees: the tree prunes — but only documents the loop would drop anyway): a full page over a match that fits
-     * one device page is replayed through the reference's own loop, which counts for itself */
-    if (plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0 && hdr.n_hits == k && !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) &&
-        !(L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT)) {
-        const uint64_t m_ = XGM_MATCHES_COUNT(hdr.matches_exact);
-        if (m_ > k && m_ >= plan.check_at_least) {
-            tl_replay = ReplayCtx{true, &stats, &wtscheme, full_db_has_positions};
-            return false;
-        }
-    }
     bool replayed = false;
     uint64_t replay_known = 0;
     if (plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0 && hdr.n_hits == k) {
-        /* the whole match in docid order, every candidate's positions tested (xgm_search_all: a match of any size) */
-        std::unique_ptr<xgm_hit[]> all;
-        uint64_t n_all = 0;
         xgm_result_hdr hdr2;
         memset(&hdr2, 0, sizeof hdr2);
-        const int rc2 = fetch_all(sh.idx, plan, db.get_doccount(), &all, &n_all, &hdr2);
-        if (rc2 < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
-        if (rc2 > 0) { ++g_dev; return false; }                                /* e.g. a phrase of more than 3 terms: CPU matcher */
-        RefProtoMSet pm;
-        pm.max_size = k; pm.check_at_least = plan.check_at_least;
-        bool frozen = false, have_w = false, none_left = false;
-        double w_star = 0.0;
-        Xapian::docid trigger = 0;
-        for (uint64_t ai = 0; ai < n_all; ++ai) {
-            const xgm_hit& h = all[ai];
-            if (!(pm.min_weight > 0.0)) {                                      /* vet(): w_min <= 0 — the document's own weight */
-                pm.add(RefProtoMSet::Item{h.weight, h.docid, h.subqs_matched});
-                if (pm.min_weight > 0.0) { frozen = true; trigger = h.docid; }
-                continue;
-            }
-            if (frozen && !have_w && !none_left) { have_w = frozen_weight(db, L.terms, plan, trigger, &w_star); none_left = !have_w; }
-            if (!have_w) break;                                                 /* (cannot happen: h itself is such a document) */
-            if (w_star < pm.min_weight) break;                                  /* vet() rejects every later document untested */
-            pm.add(RefProtoMSet::Item{w_star, h.docid, h.subqs_matched});
-        }
-        std::sort(pm.results.begin(), pm.results.end(), RefProtoMSet::before);
-        hits.assign(std::max<size_t>(pm.results.size(), 1), xgm_hit());
-        for (size_t i = 0; i < pm.results.size(); ++i) { hits[i].docid = pm.results[i].did; hits[i].weight = pm.results[i].w; hits[i].subqs_matched = pm.results[i].subqs; }
-        hdr.n_hits = (uint32_t)pm.results.size();
-        hdr.max_attained = pm.max_weight;
-        hdr.max_weight_subqs_matched = pm.max_weight_subqs;
+        const int rc2 = xgm_search_replay(sh.idx, &plan, XGM_REPLAY_FROZEN_WEIGHT, hits.data(), &hdr2, &replay_known);
+        if (rc2 != XGM_OK) { ++g_dev; return false; }                          /* declined or failed: the CPU matcher answers (nothing was lost) */
+        hdr.n_hits = hdr2.n_hits;
+        hdr.max_attained = hdr2.max_attained;
+        hdr.max_weight_subqs_matched = hdr2.max_weight_subqs_matched;
         hdr.matches_exact = hdr2.matches_exact;
         replayed = true;
-        replay_known = pm.known_matching_docs;
+        ++g_replayed;
     }
 
     /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682) */
@@ -762,24 +664,25 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
      * returned stands in for it (what known_matching_docs is under weight pruning). */
     uint32_t lb = 0, est = 0, ub = 0;
     const uint64_t m_all = XGM_MATCHES_COUNT(hdr.matches_exact);
-    const bool every_match_visited = L.d.op == XGM_OP_AND || L.d.op == XGM_OP_FILTER || L.d.op == XGM_OP_AND_NOT;     /* (positional: the frozen weight) */
     if (replayed) {
         xgm_mset_bounds_known(&plan, &hdr, replay_known, &lb, &est, &ub);        /* ProtoMSet's own count of the replay */
     } else if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
         xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
-    } else if (plain && g_exact_bounds.load(std::memory_order_relaxed) && every_match_visited && k > 0 && hdr.n_hits == k &&
+    } else if (plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0 && hdr.n_hits == k &&
                !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least) {
-        /* known_matching_docs is a function of the match in docid order (xgm_known_matching_docs): fetch the whole match — of any
-         * size — and report the reference's own figures */
-        std::unique_ptr<xgm_hit[]> all;
-        uint64_t n_all = 0;
+        /* known_matching_docs is a function of the match in docid order with its weights — for the operators that visit every match (a
+         * term, AND, FILTER, AND_NOT) and for those whose tree prunes by weight (OR, AND_MAYBE, nested trees: it only ever skips documents
+         * the matcher's loop would drop anyway, matcher.cc:500-505) alike.  The device counts as ProtoMSet would, over the whole match, which
+         * never leaves HBM (xgm_search_replay; rounds 3-4: a download of 16 B per match + the reference's own loop over a ReplayPostList —
+         * slower than the CPU matcher on frequent-term disjunctions).  The page stays the search's own: ProtoMSet keeps the same documents. */
+        std::vector<xgm_hit> page(k);
         xgm_result_hdr hdr2;
         memset(&hdr2, 0, sizeof hdr2);
-        const int rc2 = fetch_all(sh.idx, plan, db.get_doccount(), &all, &n_all, &hdr2);
-        if (rc2 == XGM_OK && n_all == m_all) {
-            std::vector<double> w(n_all);
-            for (size_t i = 0; i < n_all; ++i) w[i] = all[i].weight;
-            xgm_mset_bounds_known(&plan, &hdr, xgm_known_matching_docs(w.data(), w.size(), k, plan.check_at_least), &lb, &est, &ub);
+        uint64_t known = 0;
+        const int rc2 = xgm_search_replay(sh.idx, &plan, XGM_REPLAY_COUNT, page.data(), &hdr2, &known);
+        if (rc2 == XGM_OK && hdr2.matches_exact == m_all) {
+            xgm_mset_bounds_known(&plan, &hdr, known, &lb, &est, &ub);
+            ++g_replayed;
         } else {
             xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
         }

@@ -67,11 +67,11 @@ void set_enabled(bool on);                 /* default: on */
  * the intended top-k.  The choice is the deployment's and has to be made:
  *   POSITIONAL_DECLINE   — positional queries stay on the CPU matcher (byte-compatible by construction);
  *   POSITIONAL_INTENDED  — answered on the device with the intended semantics;
- *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the whole match is fetched in docid order
- *     (xgm_search_all: any size; phrases of more than 3 terms are left to the CPU matcher) and the reference's loop is replayed on the
- *     host — true weights until ProtoMSet's min_weight turns positive, then the FROZEN weight: that of the first
- *     document of the underlying conjunction after that point (vet() weighs before test_doc(); found with the shard's own posting
- *     lists, a few skip_to's), served for every later match and compared against min_weight to skip the rest.
+ *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the reference's loop is replayed ON THE
+ *     DEVICE over the whole match in docid order (xgm_search_replay, XGM_REPLAY_FROZEN_WEIGHT: a match of any size, phrases of up to 8
+ *     terms; rounds 3-4 downloaded the match and looped on the host, <= 3 terms) — true weights until ProtoMSet's min_weight turns
+ *     positive, then the FROZEN weight: that of the first document of the underlying conjunction after that point (vet() weighs before
+ *     test_doc()), served for every later match and compared against min_weight to skip the rest.  Only the page crosses PCIe.
  * Until set_positional_mode has been called positional queries are declined. */
 enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1, POSITIONAL_REFERENCE = 2 };
 void set_positional_mode(PositionalMode m);
@@ -107,6 +107,9 @@ void set_collapse_mode(CollapseMode m);
  * Not for positional queries unless POSITIONAL_INTENDED (the frozen weight lives in the tree), nor with a MatchDecider (its
  * counters see the tree's traversal). */
 void set_replay(bool on);                  /* default: off */
+/* ... for matches of up to this many documents (16 bytes each on the host; the replay's first device search only counts): a larger
+ * match leaves the search to the CPU matcher.  Default: 4 000 000. */
+void set_replay_limit(uint64_t max_matches);
 /* Columns (value slots, KeyMaker keys) are built on the first sorted / spied / collapsed search of a shard revision, on that search's
  * thread, under the shard's column mutex (two passes over the value stream; 4 bytes per document + the distinct strings).  Shards
  * with more documents than this are declined (CPU matcher) instead of stalling their searches behind the scan; a server that wants
@@ -120,11 +123,12 @@ Xapian::Internal::PostList* maybe_replay(const Xapian::Database& db, const Xapia
  * min_weight is the k-th best weight so far once check_at_least documents have been seen.  For the operators that visit every
  * match whatever min_weight is (a term, AND, FILTER, AND_NOT, PHRASE, NEAR: MultiAndPostList / SelectPostList / AndNotPostList
  * ignore w_min) that number is a function of the match in docid order (xgm_known_matching_docs); OR and AND_MAYBE skip
- * documents by weight inside the posting-list tree (orpostlist.cc:35-204), there it is a property of the traversal.
- * With exact bounds ON the hook, for a full page, fetches the whole match — of any size — in docid order with a second device search
- * (xgm_search_all) and reports the reference's own figures: through xgm_known_matching_docs for those operators, through the replay
- * of the reference's loop (set_replay's mechanism) for OR / AND_MAYBE / trees; when OFF (the default) the number of documents returned
- * stands in (valid bounds, possibly looser). */
+ * documents by weight inside the posting-list tree (orpostlist.cc:35-204)
+ * — but only documents the matcher's loop would drop anyway, so there too the number is that function of the whole match.
+ * With exact bounds ON the hook, for a full page, lets the device count as ProtoMSet would over the whole match in docid order
+ * (a second device search, xgm_search_replay with XGM_REPLAY_COUNT: the match never leaves HBM, one number comes back) and reports
+ * the reference's own figures for every shape (rounds 3-4: a download of the match + the host function / the reference's loop over a
+ * ReplayPostList); when OFF (the default) the number of documents returned stands in (valid bounds, possibly looser). */
 void set_exact_bounds(bool on);
 
 /* A MatchSpy class the hook does not know natively: the server tells it which value slot the spy counts and how to hand it the

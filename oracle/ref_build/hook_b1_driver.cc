@@ -8,6 +8,9 @@
  * device path (documented exception); they are checked against the CPU matcher's bounds: lower <= exact <= upper.
  *
  *   xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]
+ *   xapian_hook_b1 --leg <name>:<mode>:<queries.txt> [--leg ...] - <dbdir> [...]      several query files against ONE export + load of the
+ *       shards (bench.py's hook_parity at 10 M documents: the export is the expensive part); mode = plain | exact-bounds |
+ *       positional-reference | positional-intended; one JSON line per leg ("leg": name), the exit code covers all of them
  * Each shard's segment is exported from its glass directory by the native reader (xgm_segment_build_from_glass) and
  * loaded onto device 0.  --stale registers every shard under a wrong revision: every search must then be declined
  * (CPU path) and still answer identically.  Test infrastructure (tests/test_gpu_hook_b1.py); query file format as
@@ -49,6 +52,8 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
 int main(int argc, char** argv) {
     int a = 1;
     bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false;
+    struct Leg { std::string name, mode, file; };
+    std::vector<Leg> legs;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
     {   /* the driver's own spy class reaches the device through an adapter (how Xapiand binds AggregationMatchSpy) */
         xgm_hook::SpyAdapter ad;
@@ -73,11 +78,19 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
         else if (!strcmp(argv[a], "--replay")) { xgm_hook::set_replay(true); replay_on = true; }
         else if (!strcmp(argv[a], "--stale")) stale = true;
+        else if (!strcmp(argv[a], "--leg") && a + 1 < argc) {
+            const std::string spec = argv[++a];
+            const size_t c1 = spec.find(':'), c2 = c1 == std::string::npos ? c1 : spec.find(':', c1 + 1);
+            if (c2 == std::string::npos) { fprintf(stderr, "--leg wants <name>:<mode>:<queries.txt>\n"); return 2; }
+            legs.push_back(Leg{spec.substr(0, c1), spec.substr(c1 + 1, c2 - c1 - 1), spec.substr(c2 + 1)});
+        }
+        else if (!strcmp(argv[a], "-")) { ++a; break; }
         else if (!strcmp(argv[a], "--near-colocated")) xgm_hook::set_near_colocated_terms(true);     /* the indexer may put several terms at one position (nearpostlist.cc:106-140) */
     }
+    if (!legs.empty()) --a;                                  /* (no query file argument: the shard directories follow) */
     if (argc - a < 2) { fprintf(stderr, "usage: xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]\n"); return 2; }
     try {
-        auto queries = read_queries(argv[a]);
+        auto queries = legs.empty() ? read_queries(argv[a]) : std::vector<QuerySpec>();
         std::vector<Xapian::Database> dbs;
         std::vector<xgm_index*> idx;
         std::vector<std::string> seg_files;
@@ -145,6 +158,17 @@ int main(int argc, char** argv) {
             /* ... until the refreshed segments (keyed by the new revision) are registered */
             for (size_t i = 0; i < dbs.size(); ++i) { if (export_and_register(i, argv[a + 1 + i], first_changed[i])) return 1; ++refreshed; }
         }
+        unsigned bad_total = 0;
+        if (legs.empty()) legs.push_back(Leg{"", "", ""});
+        for (const Leg& leg : legs) {
+        if (!leg.file.empty()) {
+            queries = read_queries(leg.file.c_str());
+            exact_bounds_on = leg.mode == "exact-bounds";
+            positional_reference_on = leg.mode == "positional-reference";
+            xgm_hook::set_exact_bounds(exact_bounds_on);
+            xgm_hook::set_positional_mode(positional_reference_on ? xgm_hook::POSITIONAL_REFERENCE : xgm_hook::POSITIONAL_INTENDED);
+        }
+        const xgm_hook::Counters c0 = xgm_hook::counters();
         unsigned bad = 0, bounds_bad = 0, http_total_equal = 0;
         double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;
@@ -204,19 +228,27 @@ int main(int argc, char** argv) {
                        got.get_matches_upper_bound(), want.get_matches_lower_bound(), want.get_matches_estimated(), want.get_matches_upper_bound());
             }
         }
-        const xgm_hook::Counters c = xgm_hook::counters();
-        printf("{\"queries\": %zu, \"shards\": %zu, \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
+        xgm_hook::Counters c = xgm_hook::counters();
+        c.answered -= c0.answered; c.declined_shape -= c0.declined_shape; c.declined_unregistered -= c0.declined_unregistered; c.declined_revision -= c0.declined_revision;
+        c.declined_device -= c0.declined_device; c.answered_sorted -= c0.answered_sorted; c.answered_spied -= c0.answered_spied; c.answered_collapsed -= c0.answered_collapsed;
+        c.replayed -= c0.replayed;
+        if (!leg.name.empty()) printf("{\"leg\": \"%s\", \"mode\": \"%s\", ", leg.name.c_str(), leg.mode.c_str());
+        printf("%s\"queries\": %zu, \"shards\": %zu,", leg.name.empty() ? "{" : "", queries.size(), dbs.size());
+        printf(" \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
                "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu, "
                "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f}\n",
-               queries.size(), dbs.size(), bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
+               bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
                (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed,
                (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s);
+        fflush(stdout);
+        bad_total += bad + bounds_bad;
+        }   /* legs */
         for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) xgm_index_close(h);
         for (const std::string& f : seg_files) unlink(f.c_str());
-        return (bad || bounds_bad) ? 1 : 0;
+        return bad_total ? 1 : 0;
     } catch (const Xapian::Error& e) {
         fprintf(stderr, "Xapian error: %s\n", e.get_description().c_str());
         return 1;

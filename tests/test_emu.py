@@ -230,9 +230,10 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
 
 def test_search_all_under_emulation(device_runs):
     """xgm_search_all (every match in docid order; round 4) against the oracle's full ranking: all operator classes, trees, matches
-    beyond one device page."""
+    beyond one device page — and xgm_search_replay (round 5): ProtoMSet's collation replayed by xgm_replay_kernel over that list (the page,
+    known_matching_docs for every operator class and check_at_least; the frozen weight of PHRASE / NEAR of 2-6 terms, two stripe widths)."""
     out = device_runs("search_all")
-    assert "3 passed" in out, out
+    assert "6 passed" in out, out
 
 
 def test_byte_compatible_modes_beyond_one_device_page_under_emulation(emu_lib, tmp_path):

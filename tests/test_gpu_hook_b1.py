@@ -343,6 +343,32 @@ def test_positional_reference_mode_is_byte_compatible(built, glass):
     assert line and json.loads(line[-1])["mismatches"] > 0, r.stdout[-2000:]
 
 
+def test_positional_reference_mode_takes_long_phrases(built, tmp_path):
+    """Round 5: the frozen-weight replay runs on the device (xgm_search_replay) and takes PHRASE / NEAR of up to 8 terms (rounds 3-4: a
+    host loop, <= 3 terms, longer phrases left to the CPU matcher).  A small vocabulary gives 4-6-term phrases matches beyond their page:
+    hook on == hook off — stale weights, percentages, the three match-count figures — all answered on the device."""
+    if not (H.have_xapian_ref() and os.path.exists(HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    n_docs, vocab = 12000, 120
+    one = str(tmp_path / "small_vocab")
+    H.xapian_ref("build", one, hex(H.CORPUS_SEED), n_docs, vocab, 50, 150)
+    corpus = H.Corpus(n_docs, vocab)
+    qs = []
+    for q in (H.gen_phrase_queries(200, n_docs, vocab, seed=111, lengths=(4, 5, 6)) + H.gen_phrase_queries(60, n_docs, vocab, seed=112, lengths=(4, 5), window_extra=3) +
+              H.gen_phrase_queries(60, n_docs, vocab, seed=113, lengths=(4, 5), window_extra=4, op="NEAR")):
+        m = H.oracle_search(corpus, q["op"], q["terms"], 0, 1, window=q.get("window", 0))[1].matches
+        first, k = [(0, 3), (0, 5), (1, 3)][len(qs) % 3]
+        if m > first + k + 2:
+            qs.append(dict(q, first=first, maxitems=k))
+    corpus.close()
+    assert len(qs) >= 20 and sum(len(q["terms"]) >= 5 for q in qs) >= 4, (len(qs), [len(q["terms"]) for q in qs])
+    qf = str(tmp_path / "qlong.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
+    assert out["answered_on_device"] == len(qs) and out["replayed"] == len(qs), out
+
+
 def test_replay_reference_collation_over_the_device_match(built, glass_values):
     """set_replay / COLLAPSE_REFERENCE: searches whose exact semantics live in the reference's own collation — set_collapse_key with any
     collapse_max and a page INSIDE the match (where the snapshot's collapser loses documents: the device's intended semantics differs),

@@ -650,6 +650,7 @@ struct BatchPlan {
     bool orw;           /* every query is a plain disjunction → xgm_orw_kernel (one wave per unit) */
     bool fused = false; /* the conjunction kernel finishes its queries itself (xgm_unit_finish.h): no merge launch, no parts */
     uint32_t parts = 1; /* > 1: a query's units are merged in `parts` groups (pseudo-query p * nq + q of goff) and the groups' lists once more */
+    uint32_t sub_bits = 0; /* workgroup kernels: every stripe in 2^sub_bits passes over narrower tables (positional queries of > 3 terms) */
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
@@ -742,7 +743,16 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     uint32_t spg_max = bp->andw ? 32u : bp->orw ? orw_spg : std::max(1u, (16u * 1024u) / (8u * bp->tab_terms));
     if (!wave_units) {
         /* the run table shares the 160 KiB with the tables (PHRASE position tables are large) */
-        const size_t base = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, 0);
+        /* (the sorted instantiation — force_general — keeps a second key, a collapse ordinal and its control words per top-k entry) */
+        const size_t extra = force_general ? (size_t)bp->cap * 12 + 128 : 0;
+        size_t base = xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, 0) + extra;
+        /* a positional query of more than XGM_PHRASE_MAX_TERMS_WG terms: 4-byte position starts for every slot of a stripe and term do not
+         * fit; the kernel then takes a stripe in 2^sub_bits passes over tables of W >> sub_bits slots (xgm_match_body.inc), leaving room
+         * for a run table of at least 16 stripes */
+        while (bp->phrase && base + 8u * bp->tab_terms * 16u + 64u > 160u * 1024u && bp->sub_bits < 3u && idx->hdr.stripe_bits - bp->sub_bits > 8u) {
+            ++bp->sub_bits;
+            base = xgm_match_smem_bytes(idx->hdr.stripe_bits - bp->sub_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, 0) + extra;
+        }
         if (base + 8u * bp->tab_terms + 64u > 160u * 1024u) return XGM_UNSUPPORTED;
         spg_max = std::min<uint32_t>(spg_max, (uint32_t)((160u * 1024u - 64u - base) / (8u * bp->tab_terms)));
     }
@@ -906,7 +916,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     for (size_t i = 0; i + 1 < bp->goff.size(); ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
     const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase, bp->sided == 2)
                         : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
-                                 : xgm_match_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
+                                 : xgm_match_smem_bytes(idx->hdr.stripe_bits - bp->sub_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
     bp->merge_cap = std::max(512u, next_pow2(g_most * bp->k_max));     /* fixed window of k_max per unit */
     bp->k_stride_c = bp->k_max;
@@ -1007,7 +1017,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = s->d_queries;
-    L.nq = nq; L.n_work = bp.n_work; L.work = s->d_work; L.stripes_per_group = bp.stripes_per_group;
+    L.nq = nq; L.n_work = bp.n_work; L.work = s->d_work; L.stripes_per_group = bp.stripes_per_group; L.sub_bits = bp.sub_bits;
     static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
@@ -1430,7 +1440,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     BatchPlan bp;
     if ((rc = plan_batch(idx, q, 1, &dq, &kq, &mp, &bp, true))) return rc;
     if (bp.andw || bp.orw || bp.and_only || dq.k == 0 || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
-    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits - bp.sub_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
     const uint32_t k = dq.k, n_work = bp.n_work;
     /* per-call device and pinned buffers + a stream from the index's scratch pool (re-used across calls: no allocation, no null stream —
      * searches of concurrent threads do not serialise): [query | work list] go up in one copy, [headers | counters | candidates] come down in one */
@@ -1460,7 +1470,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = d_q;
-    L.nq = 1; L.n_work = n_work; L.work = d_work; L.stripes_per_group = bp.stripes_per_group;
+    L.nq = 1; L.n_work = n_work; L.work = d_work; L.stripes_per_group = bp.stripes_per_group; L.sub_bits = bp.sub_bits;
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = k;
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = d_ghdr;
@@ -1544,12 +1554,14 @@ extern "C" int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xg
  * The workgroup kernel (every query shape; it decodes the posting blocks of each stripe: K1 at full size) weighs every matching
  * document anyway when it runs under a sort; here it also appends each to one list (a wave-aggregated atomic per round), which
  * xgm_all.hip then puts in docid order by RANK (a bitmap of the matches, prefix counts, one scatter).  One query per call, synchronous. */
-extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr) {
-    if (!idx || !q || !n_matches || !hdr || (cap && !hits)) return xgm_set_error(XGM_E_INVALID, "null argument");
-    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
-    *n_matches = 0;
-    int rc = use_device(idx->device);
-    if (rc) return rc;
+/* The device half both entry points share: the whole match of `q` in ascending docid order, left in HBM (sc->d_all).  list_conj: a
+ * positional query's list also carries the documents of the underlying conjunction that fail the positional test, flagged
+ * XGM_ALL_NOT_A_MATCH (what the frozen-weight replay needs).  *n_list = entries of the list, *n_matches = matching documents among them,
+ * hdr = the whole match's figures.  *d_list = NULL when the list does not fit cap_dev entries (nothing packed). */
+static int search_all_device(xgm_index* idx, const xgm_query* q, XgmScratch* sc, bool list_conj, uint64_t cap_dev, xgm_hit** d_list, uint64_t* n_list,
+                             uint64_t* n_matches, xgm_result_hdr* hdr, size_t extra_bytes, unsigned char** d_extra) {
+    *d_list = nullptr; *n_list = 0; *n_matches = 0;
+    int rc;
     xgm_query q1 = *q;
     q1.first = 0; q1.maxitems = 1; q1.check_at_least = 0xFFFFFFFFu;          /* the kernel's own top-k is not used: keep it smallest; positions of every candidate tested */
     xgm_dev_query dq;
@@ -1558,16 +1570,10 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     BatchPlan bp;
     if ((rc = plan_batch(idx, &q1, 1, &dq, &kq, &mp, &bp, true))) return rc;
     if (bp.andw || bp.orw || bp.and_only || bp.cap > 8u * XGM_WG) return XGM_UNSUPPORTED;
-    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits - bp.sub_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
     dq.flags &= ~XGM_QF_POSPRUNE;
-    /* no more documents can match than the tree's own upper bound (the reference's get_termfreq_max, which the planner restates) —
-     * nor than the shard holds, nor than the caller has room for */
-    uint64_t cap_dev = std::min<uint64_t>(cap, idx->hdr.doccount);
-    if (q->est_max) cap_dev = std::min<uint64_t>(cap_dev, q->est_max);
+    if (list_conj && (dq.flags & XGM_QF_PHRASE)) dq.flags |= XGM_QF_LIST_CONJ;
     const uint32_t n_work = bp.n_work;
-    XgmScratch* sc;
-    if ((rc = scratch_acquire(idx, &sc))) return rc;
-    struct Release { xgm_index* i; XgmScratch* s; ~Release() { scratch_release(i, s); } } release_{idx, sc};
     hipStream_t stream = sc->stream;
     /* the sorted kernel's own buffers: [query | work list] up, [unit headers | unit candidates (k = 1)] */
     const size_t o_q = 0, b_q = (sizeof dq + 15) & ~(size_t)15;
@@ -1578,11 +1584,12 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     const size_t total = o_cd + b_cd;
     if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
     if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total + 16))) return rc;
-    /* the list: [counter 16 B | keys | weights | hits | the ordering's bitmap and prefix counts] */
+    /* the list: [counter 16 B | keys | weights | hits | the ordering's bitmap and prefix counts | the caller's extra bytes] */
     const size_t tmp_bytes = xgm_all_order_bytes(idx->hdr.lastdocid);
     const size_t a_cnt = 0, a_k0 = 16, a_v0 = a_k0 + cap_dev * 8, a_hit = a_v0 + cap_dev * 8;
-    const size_t a_tmp = (a_hit + cap_dev * sizeof(xgm_hit) + 255) & ~(size_t)255, a_total = a_tmp + tmp_bytes;
+    const size_t a_tmp = (a_hit + cap_dev * sizeof(xgm_hit) + 255) & ~(size_t)255, a_ext = (a_tmp + tmp_bytes + 255) & ~(size_t)255, a_total = a_ext + extra_bytes;
     if ((rc = grow(&sc->d_all, &sc->cap_all, a_total))) return rc;
+    if (d_extra) *d_extra = sc->d_all + a_ext;
     unsigned char* hb = (unsigned char*)sc->h_sorted;
     memcpy(hb + o_q, &dq, sizeof dq);
     memcpy(hb + o_wk, bp.work.data(), (size_t)n_work * sizeof(xgm_work));
@@ -1591,7 +1598,7 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = (xgm_dev_query*)(sc->d_sorted + o_q);
-    L.nq = 1; L.n_work = n_work; L.work = (xgm_work*)(sc->d_sorted + o_wk); L.stripes_per_group = bp.stripes_per_group;
+    L.nq = 1; L.n_work = n_work; L.work = (xgm_work*)(sc->d_sorted + o_wk); L.stripes_per_group = bp.stripes_per_group; L.sub_bits = bp.sub_bits;
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = 1;
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
@@ -1614,22 +1621,95 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
         matches += g.matches;
         if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
     }
-    if (matches != n) return xgm_set_error(XGM_E_DEVICE, "xgm_search_all: %llu documents listed, %llu counted", (unsigned long long)n, (unsigned long long)matches);
+    if ((dq.flags & XGM_QF_LIST_CONJ) ? matches > n : matches != n)
+        return xgm_set_error(XGM_E_DEVICE, "xgm_search_all: %llu documents listed, %llu counted", (unsigned long long)n, (unsigned long long)matches);
     memset(hdr, 0, sizeof *hdr);
-    hdr->matches_exact = n;
+    hdr->matches_exact = matches;
     hdr->max_possible = q->max_possible;
     if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
+    *n_list = n; *n_matches = matches;
+    if (n > cap_dev || n == 0) return XGM_OK;                       /* does not fit (the caller decides what that means) / nothing to order */
+    xgm_hit* d_out = (xgm_hit*)(sc->d_all + a_hit);
+    if ((rc = xgm_all_order_pack(sc->d_all + a_tmp, idx->hdr.lastdocid, k0, v0, (size_t)n, d_out, stream))) return rc;
+    *d_list = d_out;
+    return XGM_OK;
+}
+
+/* a scratch goes back to the pool only when nothing enqueued on its stream still uses it (the early returns) */
+struct ScratchRelease { xgm_index* i; XgmScratch* s; ~ScratchRelease() { hipStreamSynchronize(s->stream); scratch_release(i, s); } };
+
+extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr) {
+    if (!idx || !q || !n_matches || !hdr || (cap && !hits)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    *n_matches = 0;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    /* no more documents can match than the tree's own upper bound (the reference's get_termfreq_max, which the planner restates) —
+     * nor than the shard holds, nor than the caller has room for */
+    uint64_t cap_dev = std::min<uint64_t>(cap, idx->hdr.doccount);
+    if (q->est_max) cap_dev = std::min<uint64_t>(cap_dev, q->est_max);
+    XgmScratch* sc;
+    if ((rc = scratch_acquire(idx, &sc))) return rc;
+    ScratchRelease release_{idx, sc};
+    xgm_hit* d_out = nullptr;
+    uint64_t n = 0, m = 0;
+    if ((rc = search_all_device(idx, q, sc, false, cap_dev, &d_out, &n, &m, hdr, 0, nullptr))) return rc;
     *n_matches = n;
     if (n > cap_dev) {
         if (n > cap) return XGM_OK;                                /* the caller's buffer is too small: nothing written, *n_matches says how many there are */
         return xgm_set_error(XGM_E_DEVICE, "xgm_search_all: %llu matches exceed the plan's upper bound %u", (unsigned long long)n, q->est_max);
     }
     if (n == 0) return XGM_OK;
-    xgm_hit* d_out = (xgm_hit*)(sc->d_all + a_hit);
-    if ((rc = xgm_all_order_pack(sc->d_all + a_tmp, idx->hdr.lastdocid, k0, v0, (size_t)n, d_out, stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(hits, d_out, (size_t)n * sizeof(xgm_hit), hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpyAsync(hits, d_out, (size_t)n * sizeof(xgm_hit), hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
     hdr->n_hits = (uint32_t)n;
+    return XGM_OK;
+}
+
+/* ---- the reference's collation of a search by relevance, replayed on the device (include/xgm.h: xgm_search_replay) ----------
+ * search_all_device leaves the match in docid order in HBM; xgm_replay_kernel (xgm_replay.hip) walks it as ProtoMSet would.  Only the
+ * page (first + maxitems hits) and 48 bytes of figures cross PCIe. */
+extern "C" int xgm_search_replay(xgm_index* idx, const xgm_query* q, uint32_t mode, xgm_hit* hits, xgm_result_hdr* hdr, uint64_t* known_matching_docs) {
+    if (!idx || !q || !hdr || !known_matching_docs || mode > XGM_REPLAY_FROZEN_WEIGHT) return xgm_set_error(XGM_E_INVALID, "bad argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    const uint64_t k64 = (uint64_t)q->first + q->maxitems;
+    if (k64 > XGM_MAX_K) return XGM_UNSUPPORTED;
+    const uint32_t k = (uint32_t)k64;
+    if (k && !hits) return xgm_set_error(XGM_E_INVALID, "null hits");
+    const bool positional = (q->op == XGM_OP_PHRASE || q->op == XGM_OP_NEAR) && q->phrase_active;
+    if (mode == XGM_REPLAY_FROZEN_WEIGHT && !positional) return xgm_set_error(XGM_E_INVALID, "the frozen weight is a positional query's");
+    *known_matching_docs = 0;
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    /* room: the tree's own upper bound (for the frozen weight: the underlying conjunction's, which is what a positional tree reports) */
+    uint64_t cap_dev = idx->hdr.doccount;
+    if (q->est_max) cap_dev = std::min<uint64_t>(cap_dev, q->est_max);
+    cap_dev = std::max<uint64_t>(cap_dev, 1);
+    XgmScratch* sc;
+    if ((rc = scratch_acquire(idx, &sc))) return rc;
+    ScratchRelease release_{idx, sc};
+    xgm_hit* d_list = nullptr;
+    uint64_t n = 0, m = 0;
+    unsigned char* d_ext = nullptr;
+    const size_t b_hits = ((size_t)std::max(k, 1u) * sizeof(xgm_hit) + 255) & ~(size_t)255, ext = b_hits + 256;
+    if ((rc = search_all_device(idx, q, sc, mode == XGM_REPLAY_FROZEN_WEIGHT, cap_dev, &d_list, &n, &m, hdr, ext, &d_ext))) return rc;
+    if (n > cap_dev) return xgm_set_error(XGM_E_DEVICE, "xgm_search_replay: %llu documents exceed the plan's upper bound %u", (unsigned long long)n, q->est_max);
+    hdr->n_hits = 0;
+    if (n == 0) return XGM_OK;
+    xgm_hit* d_page = (xgm_hit*)d_ext;
+    xgm_replay_out* d_out = (xgm_replay_out*)(d_ext + b_hits);
+    if ((rc = xgm_launch_replay(d_list, n, k, q->check_at_least, mode == XGM_REPLAY_FROZEN_WEIGHT, d_page, d_out, sc->stream))) return rc;
+    if ((rc = grow_pinned(&sc->h_down, &sc->cap_down, ext))) return rc;
+    HIP_TRY(hipMemcpyAsync(sc->h_down, d_ext, ext, hipMemcpyDeviceToHost, sc->stream));
+    HIP_TRY(hipStreamSynchronize(sc->stream));
+    const xgm_replay_out* o = (const xgm_replay_out*)((unsigned char*)sc->h_down + b_hits);
+    if (o->n_hits > k) return xgm_set_error(XGM_E_DEVICE, "xgm_search_replay: %u documents kept for a page of %u", o->n_hits, k);
+    memcpy(hits, sc->h_down, (size_t)o->n_hits * sizeof(xgm_hit));
+    *known_matching_docs = o->known_matching_docs;
+    hdr->n_hits = o->n_hits;
+    /* ProtoMSet's own max_weight (update_max_weight sees what add() is shown: the frozen weight where it was served) */
+    hdr->max_attained = o->max_weight;
+    hdr->max_weight_subqs_matched = o->max_weight_subqs;
     return XGM_OK;
 }
 

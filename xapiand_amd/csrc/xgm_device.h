@@ -27,6 +27,9 @@
 #define XGM_QF_FLAT 128u            /* a plain conjunction / FILTER of 2..4 terms, k <= 64, led by a term WITHOUT containers that has a flat posting array
                                        (every other term: containers or a flat array): its units run xgm_flat_unit (xgm_flat_body.inc) inside xgm_andw_kernel */
 #define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
+#define XGM_QF_LIST_CONJ 512u       /* xgm_search_replay, frozen-weight mode: the match list of a positional query also carries the documents of the
+                                       underlying conjunction that FAIL the positional test, flagged XGM_ALL_NOT_A_MATCH in their subqs word */
+#define XGM_ALL_NOT_A_MATCH 0x80000000u
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */
 typedef struct {

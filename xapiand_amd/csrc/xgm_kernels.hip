@@ -2322,7 +2322,8 @@ size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phras
 
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
     dim3 grid(L.n_work), block(XGM_WG);
-    const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
+    if (L.sub_bits > L.seg.stripe_bits || L.seg.stripe_bits - L.sub_bits < 8u) return xgm_launch_error("match kernel", 0, "bad sub-stripe width");
+    const size_t smem = xgm_match_smem_bytes(L.seg.stripe_bits - L.sub_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
 #define XGM_LAUNCH(TT, PH)                                                                                   \
     do {                                                                                                     \
@@ -2330,7 +2331,7 @@ int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream) {
         static std::atomic<size_t> seen{0};                                                                  \
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
-                           L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);                                  \
+                           L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.sub_bits);                      \
     } while (0)
     if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
     else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }
@@ -2347,7 +2348,8 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
                             const uint32_t* cord, uint32_t cmax, xgm_cand_sorted* cand, hipStream_t stream,
                             unsigned long long* all_keys, unsigned long long* all_vals, unsigned long long* all_count, unsigned long long all_cap) {
     dim3 grid(L.n_work), block(XGM_WG);
-    const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
+    if (L.sub_bits > L.seg.stripe_bits || L.seg.stripe_bits - L.sub_bits < 8u) return xgm_launch_error("sorted match kernel", 0, "bad sub-stripe width");
+    const size_t smem = xgm_match_sorted_smem_bytes(L.seg.stripe_bits - L.sub_bits, L.tab_terms, L.phrase, L.cap, L.wide, L.stripes_per_group);
     if (smem > 160u * 1024u) return xgm_launch_error("sorted match kernel LDS budget", 0, "LDS request exceeds 160 KiB");
     if (mode < 1u || mode > 4u || (!ord && mode != 4u) || (spy_counts && !spy_ord) || (cord && cmax == 0u) || L.cap > 8u * XGM_WG ||
         (all_keys && (!all_vals || !all_count)))
@@ -2359,7 +2361,7 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
                            L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cord, cmax, cand, L.ghdr, \
-                           all_keys, all_vals, all_count, all_cap);                                            \
+                           all_keys, all_vals, all_count, all_cap, L.sub_bits);                                \
     } while (0)
     if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
     else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }

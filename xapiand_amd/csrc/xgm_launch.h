@@ -12,6 +12,9 @@ struct xgm_match_launch {
     uint32_t nq, n_work;              /* queries in the batch, work units (= workgroups)          */
     const xgm_work* work;             /* device, [n_work], heaviest first                         */
     uint32_t stripes_per_group;       /* max stripes of a unit (sizes the LDS run table)          */
+    uint32_t sub_bits = 0;            /* workgroup kernels: a stripe is taken in 2^sub_bits passes over tables of W >> sub_bits slots
+                                         (positional queries of more than XGM_PHRASE_MAX_TERMS_WG terms; the *_smem_bytes functions then
+                                         take stripe_bits - sub_bits) */
     uint32_t tab_terms;               /* max n_terms in the batch (LDS table rows)               */
     uint32_t cap;                     /* top-k buffer capacity, power of two >= k_max + XGM_WG    */
     uint32_t k_stride;                /* candidates reserved per (query, group)                   */
@@ -40,6 +43,17 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
 size_t xgm_all_order_bytes(uint32_t lastdocid);
 int xgm_all_order_pack(void* tmp, uint32_t lastdocid, const unsigned long long* keys, const unsigned long long* vals, size_t n, xgm_hit* out,
                        hipStream_t stream);
+/* xgm_search_replay's second half (xgm_replay.hip): ProtoMSet's collation of a search by relevance replayed over the match list in docid
+ * order — one workgroup; out_hits [max_size] gets the page in rank order, *out the figures.  frozen_mode: the list carries the underlying
+ * conjunction of a positional query (entries flagged XGM_ALL_NOT_A_MATCH are not matches) and the weight freezes as SelectPostList's does. */
+typedef struct {
+    uint64_t known_matching_docs;
+    double max_weight;                /* ProtoMSet::max_weight: the heaviest weight it was shown, 0 if none */
+    double frozen_weight;
+    uint32_t max_weight_subqs, n_hits, frozen, reserved;
+} xgm_replay_out;
+int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, xgm_hit* out_hits,
+                      xgm_replay_out* out, hipStream_t stream);
 /* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
  *  column's ordinals or NULL, cmax = collapse_max) */
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */

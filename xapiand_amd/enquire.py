@@ -455,6 +455,21 @@ def search_all(db, planned, cap=None):
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(n.value)], hdr
 
 
+REPLAY_COUNT, REPLAY_FROZEN_WEIGHT = 0, 1
+
+
+def search_replay(db, planned, mode=REPLAY_COUNT):
+    """xgm_search_replay: ProtoMSet's collation of one planned query replayed on the device over its whole match in docid order
+    (protomset.h:340-400; for PHRASE / NEAR with REPLAY_FROZEN_WEIGHT also SelectPostList's frozen weight, selectpostlist.cc:28-55).
+    Returns ([(docid, weight, subqs)] = the page as the reference keeps it, hdr, known_matching_docs)."""
+    k = max(1, planned.first + planned.maxitems)
+    hits = (_lib.Hit * k)()
+    hdr = _lib.ResultHdr()
+    known = C.c_uint64()
+    _lib.check(_lib.lib().xgm_search_replay(db._h, C.byref(planned), mode, hits, C.byref(hdr), C.byref(known)))
+    return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(hdr.n_hits)], hdr, known.value
+
+
 def search_batch(db, plans):
     """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
     nq = len(plans)
