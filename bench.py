@@ -188,7 +188,7 @@ def run_steps(db, searcher, leg, steps, bps, depth, world, keep_last=False):
                 sl["ev"].synchronize()
                 delivered += int(sl["hdrs"][0, 0].item() != -1.0)
             h0 = time.perf_counter()
-            oh, od = searcher.run_descs(d, g, BATCH, k)
+            oh, od = searcher.run_descs(d, g, BATCH, k, slot=i & 1)        # (two sets of device buffers: batch i + 1 is enqueued while batch i's copy is in flight)
             sl["hits"].copy_(oh, non_blocking=True)
             sl["hdrs"].copy_(od, non_blocking=True)
             sl["ev"].record()
@@ -771,6 +771,20 @@ def time_reference(H, qfile, threads, repeat, seconds, dbdir):
     return json.loads(H.xapian_ref("time", qfile, threads, repeat, "--seconds", seconds, dbdir))
 
 
+def reference_all_cores(H, qfile, cores, seconds, dbdir):
+    """The reference on every core — and on half and a quarter of them: one Database handle per thread, and every get_mset reads its B-tree
+    blocks with pread(); on a 256-thread host the kernel side of those reads can serialise the threads (measured at 1 M documents: 256
+    threads answer 10x one thread's rate, each query's own latency only 1.7x longer).  The BEST thread count is reported as the all-core
+    figure (generous to the CPU side), every measurement beside it with the share of the threads' time spent inside get_mset."""
+    runs = []
+    for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+        r = time_reference(H, qfile, t, 64, seconds, dbdir)
+        runs.append({"threads": t, "value": r["qps"], "p50_ms": r["p50_us"] / 1e3, "p99_ms": r["p99_us"] / 1e3, "queries": r["queries"], "seconds": r["wall_s"],
+                     "share_of_thread_time_inside_get_mset": r["sum_latency_s"] / (t * r["wall_s"])})
+    best = max(runs, key=lambda x: x["value"])
+    return best, runs, r
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -811,7 +825,7 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
         # all cores: the whole timed pool (>= 8 queries per thread wherever the pool allows), handed out by one atomic counter, time-boxed
         pool_file = os.path.join(tmp, "q_pool.txt")
         H.write_queries(pool_file, [dict(q, first=0, maxitems=k) for q in (pool_all or sample)])
-        many = time_reference(H, pool_file, cores, 64, args.ref_seconds, dbdir)
+        best, sweep, many = reference_all_cores(H, pool_file, cores, max(3.0, args.ref_seconds / 2), dbdir)
         others = {}
         if hook_pools is not None:
             # the reference itself on C3 and C5: 1 thread on the first 48 queries, all cores on the pool, same index
@@ -823,10 +837,10 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
                     H.write_queries(qf1, [dict(q, first=0, maxitems=kk) for q in hook_pools[name][:48]])
                     H.write_queries(qfp, [dict(q, first=0, maxitems=kk) for q in hook_pools[name]])
                     o1 = time_reference(H, qf1, 1, 1, 30, dbdir)
-                    om = time_reference(H, qfp, cores, 64, max(4.0, args.ref_seconds / 2), dbdir)
+                    ob, osweep, om = reference_all_cores(H, qfp, cores, max(3.0, args.ref_seconds / 3), dbdir)
                     others[name] = {"kind": "reference", "value": o1["qps"], "unit": "queries/s", "cores": 1, "p50_ms": o1["p50_us"] / 1e3, "queries": o1["queries"],
-                                    "all_cores": {"value": om["qps"], "unit": "queries/s", "cores": cores, "p50_ms": om["p50_us"] / 1e3, "queries": om["queries"],
-                                                  "pool": om["pool"], "seconds": om["wall_s"]},
+                                    "all_cores": {"value": ob["value"], "unit": "queries/s", "cores": cores, "threads": ob["threads"], "p50_ms": ob["p50_ms"], "queries": ob["queries"],
+                                                  "pool": om["pool"], "seconds": ob["seconds"], "thread_counts_tried": osweep},
                                     "docs": ref_docs,
                                     "sample": "Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time) on the glass index of the headline leg (%d documents%s): "
                                               "1 thread over the first 48 queries of the timed pool, all cores over %d queries of it for %.0f s" % (
@@ -856,9 +870,9 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
             ora.close()
             small.close()
         out = {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
-               "all_cores": {"value": many["qps"], "unit": "queries/s", "cores": cores, "p50_ms": many["p50_us"] / 1e3, "queries": many["queries"], "pool": many["pool"],
-                             "seconds": many["wall_s"], "efficiency_vs_cores_x_one_thread": many["qps"] / (cores * one["qps"]),
-                             "scheduling": many.get("scheduling")},
+               "all_cores": {"value": best["value"], "unit": "queries/s", "cores": cores, "threads": best["threads"], "p50_ms": best["p50_ms"], "queries": best["queries"],
+                             "pool": many["pool"], "seconds": best["seconds"], "efficiency_vs_cores_x_one_thread": best["value"] / (cores * one["qps"]),
+                             "thread_counts_tried": sweep, "scheduling": many.get("scheduling")},
                "cpu_model": cpu_model(), "_others": others,
                "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
                "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}

@@ -530,6 +530,14 @@ int xgm_merge_shards_device(xgm_index*, const void* d_all_hits, const void* d_al
                             uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* k,
                             void* d_out_hits, void* d_out_hdrs);
 
+/* The same after ONE all-gather per batch: every rank packs its results as one record — [nq][k_stride] xgm_hit immediately followed by
+ * [nq] xgm_result_hdr, xgm_shard_record_bytes(nq, k_stride) bytes: hand xgm_*_batch_device d_hits = record, d_hdrs = record +
+ * nq * k_stride * sizeof(xgm_hit) — and d_all_records is the n_shards records one after the other, as ncclAllGather / torch's
+ * all_gather_into_tensor leave them.  (Two collectives per batch — hits and headers — cost a second launch + ring latency on xGMI.) */
+size_t xgm_shard_record_bytes(uint32_t nq, uint32_t k_stride);
+int xgm_merge_shards_packed_device(xgm_index*, const void* d_all_records, uint32_t n_shards, uint32_t nq, uint32_t k_stride,
+                                   const uint32_t* k, void* d_out_hits, void* d_out_hdrs);
+
 /* The whole per-shard protocol of the reference for a node whose shards all live in THIS process
  * (one xgm_index per shard, on any mix of devices): what DocMatcher does around Enquire in
  * reference src/database/handler.cc:1485-1549 — prepare_mset on every shard and add_prepared_mset

@@ -168,7 +168,7 @@ int main(int argc, char** argv) {
             xgm_hook::set_exact_bounds(exact_bounds_on);
             xgm_hook::set_positional_mode(positional_reference_on ? xgm_hook::POSITIONAL_REFERENCE : xgm_hook::POSITIONAL_INTENDED);
         }
-        const xgm_hook::Counters c0 = xgm_hook::counters();
+        const xgm_hook::Counters c0 = leg.file.empty() ? xgm_hook::Counters{} : xgm_hook::counters();     /* (the classic single run reports the process's totals: --stale counts declines before the loop) */
         unsigned bad = 0, bounds_bad = 0, http_total_equal = 0;
         double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;

@@ -1,7 +1,9 @@
-"""CPU-only, world_size 2, gloo: the N > 1 path of xapiand_amd.distributed — statistics all-reduce,
-fixed-size top-k all-gather, unshard + merge — with the per-shard search supplied by the CPU oracle
-(the HIP search cannot run without a GPU).  The merged answer must equal Xapiand's protocol run on the
-oracle directly (which tests/test_oracle_vs_reference.py pins to the real reference)."""
+"""CPU-only, world_size 2 and 8 (the node's shape), gloo: the N > 1 path of xapiand_amd.distributed — statistics all-reduce,
+ONE packed all-gather of fixed-size top-k records per batch, unshard + merge — with the per-shard search supplied by the CPU
+oracle (the HIP search cannot run without a GPU).  The merged answer must equal Xapiand's protocol run on the oracle directly
+(which tests/test_oracle_vs_reference.py pins to the real reference) and, on the queries of the 8-shard golden fixture, the
+MSets the compiled reference itself produced over 8 shards (tests/golden/sharded8_and3_top10.json)."""
+import json
 import os
 import socket
 import struct
@@ -14,7 +16,7 @@ import torch.multiprocessing as mp
 
 import helpers as H
 
-N_DOCS, VOCAB, WORLD, K = 3000, 8000, 2, 10
+N_DOCS, VOCAB, K = 3000, 8000, 10
 
 
 class OracleShard:
@@ -44,15 +46,15 @@ def pack_hits(rows, hdr, k):
     return hits, h
 
 
-def worker(rank, port, queries, ret):
+def worker(rank, port, batches, ret, WORLD, n_docs, vocab):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     try:
         from xapiand_amd.distributed import ShardedSearcher, decode_results
         from xapiand_amd.enquire import Query
-        corpus = H.Corpus(N_DOCS, VOCAB, n_shards=WORLD, shard=rank)
+        corpus = H.Corpus(n_docs, vocab, n_shards=WORLD, shard=rank)
         shard = OracleShard(corpus)
-        qobjs = [Query(q["op"], q["terms"]) for q in queries]
         state = {}
 
         def search_fn(batch, nq, k, hits, hdrs):
@@ -92,10 +94,15 @@ def worker(rank, port, queries, ret):
             out_hdrs.copy_(torch.from_numpy(db.view(np.float64).reshape(nq, 4)))
 
         ss = ShardedSearcher(shard, rank, WORLD, torch.device("cpu"), search_fn=search_fn, merge_fn=merge_fn)
-        state["stats"] = ss.merged_stats(qobjs)
-        hits, hdrs = ss.run_batch(queries, len(queries), K)
-        got = decode_results(hits, hdrs)
-        ret[rank] = [[(d, w) for d, w, _ in rows] for rows, _ in got]
+        out = []
+        for queries, k in batches:
+            qobjs = [Query(q["op"], q["terms"]) for q in queries]
+            state["stats"] = ss.merged_stats(qobjs)
+            hits, hdrs = ss.run_batch(queries, len(queries), k)
+            got = decode_results(hits, hdrs)
+            out.append([([(d, w) for d, w, _ in rows], h["max_possible"]) for rows, h in got])
+        ret[rank] = out
+        ret["collectives%d" % rank] = ss.n_collectives            # ONE all-gather per batch (hits and headers packed in one record)
         # every rank must also agree on the merged statistics
         ret["stats%d" % rank] = [(g.total_length, g.collection_size, [g.termfreq[j] for j in range(3)]) for g in state["stats"][:5]]
     finally:
@@ -110,21 +117,46 @@ def free_port():
     return p
 
 
-def test_two_rank_sharded_search_matches_protocol(built):
-    queries = H.gen_term_queries("AND", 12, 3, 1, 64, maxitems=K, seed=91) + H.gen_term_queries("OR", 8, 4, 1, 400, maxitems=K, seed=92)
+def run_ranks(world, batches, n_docs, vocab):
     mgr = mp.Manager()
     ret = mgr.dict()
     port = free_port()
-    procs = [mp.get_context("spawn").Process(target=worker, args=(r, port, queries, ret)) for r in range(WORLD)]
+    procs = [mp.get_context("spawn").Process(target=worker, args=(r, port, batches, ret, world, n_docs, vocab)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(600)
         assert p.exitcode == 0
-    shards = [H.Corpus(N_DOCS, VOCAB, n_shards=WORLD, shard=s) for s in range(WORLD)]
+    return ret
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_search_matches_protocol(built, world):
+    queries = H.gen_term_queries("AND", 12, 3, 1, 64, maxitems=K, seed=91) + H.gen_term_queries("OR", 8, 4, 1, 400, maxitems=K, seed=92)
+    ret = run_ranks(world, [(queries, K)], N_DOCS, VOCAB)
+    shards = [H.Corpus(N_DOCS, VOCAB, n_shards=world, shard=s) for s in range(world)]
     want = [[(d, w) for d, w, _ in H.oracle_search_sharded(shards, q["op"], q["terms"], 0, K)] for q in queries]
-    assert ret[0] == want
-    assert ret[1] == want
-    assert ret["stats0"] == ret["stats1"]
+    for r in range(world):
+        assert [rows for rows, _ in ret[r][0]] == want, r
+        assert ret["stats%d" % r] == ret["stats0"]
+        assert ret["collectives%d" % r] == 1
     full = H.Corpus(N_DOCS, VOCAB)
     assert ret["stats0"][0][0] == full.v.total_length and ret["stats0"][0][1] == full.v.doccount
+
+
+def test_eight_ranks_reproduce_the_reference_over_eight_shards(built):
+    """The queries of the golden fixture the COMPILED REFERENCE answered through Xapiand's protocol over 8 shards, here over 8 gloo ranks:
+    docid at every rank of the MSet, weight bits, max_possible (multi.h:38-73 unshard with n = 8, handler.cc:1532-1549)."""
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sharded8_and3_top10.json")))
+    c = fx["corpus"]
+    groups = {}
+    for r in fx["results"]:
+        groups.setdefault(r["query"]["first"] + r["query"]["maxitems"], []).append(r)
+    batches = [([dict(op=r["query"]["op"], terms=r["query"]["terms"]) for r in rs], k) for k, rs in sorted(groups.items())]
+    ret = run_ranks(8, batches, c["n_docs"], c["vocab"])
+    for rank in range(8):
+        assert ret["collectives%d" % rank] == len(batches)
+        for (k, rs), got in zip(sorted(groups.items()), ret[rank]):
+            for r, (rows, max_possible) in zip(rs, got):
+                assert rows == [(d, float.fromhex(w)) for d, w, _ in r["hits"]], (rank, r["query"])
+                assert max_possible == float.fromhex(r["max_possible"]), (rank, r["query"])

@@ -142,6 +142,8 @@ _API = [
     ("xgm_search_sharded", C.c_int, [_P(C.c_void_p), C.c_uint32, _P(QueryDesc), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_debug_sharded_info", C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     ("xgm_merge_shards_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
+    ("xgm_merge_shards_packed_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, _P(C.c_uint32), C.c_void_p, C.c_void_p]),
+    ("xgm_shard_record_bytes", C.c_size_t, [C.c_uint32, C.c_uint32]),
     ("xgm_index_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_index_set_near_colocated", C.c_int, [C.c_void_p, C.c_int]),
     ("xgm_last_kernel_ms", C.c_double, [C.c_void_p]),

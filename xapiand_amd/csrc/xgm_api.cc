@@ -2007,7 +2007,7 @@ extern "C" int xgm_get_mset_batch(xgm_index* idx, const xgm_query_desc* descs, c
 }
 
 static int merge_shards_device_on(xgm_index* idx, hipStream_t on, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
-                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs);
+                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs, size_t shard_record_bytes = 0);
 
 extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
                                        uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
@@ -2015,8 +2015,19 @@ extern "C" int xgm_merge_shards_device(xgm_index* idx, const void* d_all_hits, c
     return merge_shards_device_on(idx, nullptr, d_all_hits, d_all_hdrs, n_shards, nq, k_stride, k, d_out_hits, d_out_hdrs);
 }
 
+/* the same after ONE all-gather of packed per-shard records (include/xgm.h) */
+extern "C" int xgm_merge_shards_packed_device(xgm_index* idx, const void* d_all_records, uint32_t n_shards, uint32_t nq, uint32_t k_stride,
+                                              const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
+    if (!idx || !d_all_records || !k || !d_out_hits || !d_out_hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    const size_t rec = xgm_shard_record_bytes(nq, k_stride);
+    return merge_shards_device_on(idx, nullptr, d_all_records, (const unsigned char*)d_all_records + (size_t)nq * k_stride * sizeof(xgm_hit), n_shards, nq, k_stride, k,
+                                  d_out_hits, d_out_hdrs, rec);
+}
+
+extern "C" size_t xgm_shard_record_bytes(uint32_t nq, uint32_t k_stride) { return (size_t)nq * ((size_t)k_stride * sizeof(xgm_hit) + sizeof(xgm_result_hdr)); }
+
 static int merge_shards_device_on(xgm_index* idx, hipStream_t on, const void* d_all_hits, const void* d_all_hdrs, uint32_t n_shards,
-                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs) {
+                                  uint32_t nq, uint32_t k_stride, const uint32_t* k, void* d_out_hits, void* d_out_hdrs, size_t shard_record_bytes) {
     if (nq == 0) return XGM_OK;
     int rc = use_device(idx->device);
     if (rc) return rc;
@@ -2035,7 +2046,7 @@ static int merge_shards_device_on(xgm_index* idx, hipStream_t on, const void* d_
         hipError_t e = hipMemcpyAsync(s->d_mkq, s->h_up, (size_t)nq * 4, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { rc = xgm_launch_error("hipMemcpyAsync", (int)e, hipGetErrorString(e)); break; }
         rc = xgm_launch_merge_shards((const xgm_hit*)d_all_hits, (const xgm_result_hdr*)d_all_hdrs, n_shards, nq, k_stride, s->d_mkq,
-                                     cap, (xgm_hit*)d_out_hits, (xgm_result_hdr*)d_out_hdrs, stream);
+                                     cap, (xgm_hit*)d_out_hits, (xgm_result_hdr*)d_out_hdrs, stream, shard_record_bytes);
     } while (0);
     if (hipEventRecord(s->ev_done, stream) == hipSuccess) s->pending = true; else hipStreamSynchronize(stream);
     if (!on && !idx->stream) hipStreamSynchronize(stream);

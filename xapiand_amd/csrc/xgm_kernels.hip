@@ -2125,8 +2125,11 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_kernel(const xgm_cand* __res
 __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit* __restrict__ all_hits, const xgm_result_hdr* __restrict__ all_hdrs,
                                                                    uint32_t n_shards, uint32_t nq, uint32_t k_stride, const uint32_t* __restrict__ kq,
                                                                    uint32_t cap, xgm_hit* __restrict__ hits, xgm_result_hdr* __restrict__ hdrs,
-                                                                   uint32_t unshard, const uint32_t* __restrict__ row_of) {
-    /* unshard == 0: the sources are the PARTS of one shard's query (same docid space; xgm_launch_merge_parts) */
+                                                                   uint32_t unshard, const uint32_t* __restrict__ row_of,
+                                                                   unsigned long long hit_shard_bytes, unsigned long long hdr_shard_bytes) {
+    /* unshard == 0: the sources are the PARTS of one shard's query (same docid space; xgm_launch_merge_parts).
+     * hit_shard_bytes / hdr_shard_bytes: distance between two shards' arrays — nq * k_stride hits / nq headers when the shards' arrays are
+     * gathered one after the other; one packed record ([nq][k_stride] hits then [nq] headers) when ONE all-gather brought both */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t tid = threadIdx.x, qi = blockIdx.x;
     const uint32_t orow = row_of ? row_of[qi] : qi;
@@ -2145,8 +2148,8 @@ __global__ __launch_bounds__(XGM_WG) void xgm_merge_shards_kernel(const xgm_hit*
     for (uint32_t i = tid; i < cap; i += XGM_WG) { tk.w[i] = 0; tk.d[i] = 0xFFFFFFFFu; tk.m[i] = 0xFFFFFFFFu; }
     __syncthreads();
     for (uint32_t sh = 0; sh < n_shards; ++sh) {
-        const xgm_result_hdr h = all_hdrs[(size_t)sh * nq + qi];
-        const xgm_hit* src = all_hits + ((size_t)sh * nq + qi) * k_stride;
+        const xgm_result_hdr h = reinterpret_cast<const xgm_result_hdr*>(reinterpret_cast<const unsigned char*>(all_hdrs) + (size_t)sh * hdr_shard_bytes)[qi];
+        const xgm_hit* src = reinterpret_cast<const xgm_hit*>(reinterpret_cast<const unsigned char*>(all_hits) + (size_t)sh * hit_shard_bytes) + (size_t)qi * k_stride;
         if (tid == 0) {
             base = fill; fill += h.n_hits;
             matches = ((matches & ~XGM_MATCHES_LOWER_BOUND) + (h.matches_exact & ~XGM_MATCHES_LOWER_BOUND)) | ((matches | h.matches_exact) & XGM_MATCHES_LOWER_BOUND);
@@ -2480,18 +2483,20 @@ int xgm_launch_merge_parts(const xgm_hit* all_hits, const xgm_result_hdr* all_hd
     const size_t smem = (size_t)cap * 16 + 64;
     { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_shards_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_parts, nq,
-                       k_stride, kq, cap, hits, hdrs, 0u, row_of);
+                       k_stride, kq, cap, hits, hdrs, 0u, row_of, (unsigned long long)nq * k_stride * sizeof(xgm_hit), (unsigned long long)nq * sizeof(xgm_result_hdr));
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }
 
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
-                            hipStream_t stream) {
+                            hipStream_t stream, size_t shard_record_bytes) {
     const size_t smem = (size_t)cap * 16 + 64;
     { static std::atomic<size_t> seen{0}; if (int rc_ = ensure_dyn_smem(xgm_merge_shards_kernel, smem, seen)) return rc_; }
     hipLaunchKernelGGL(xgm_merge_shards_kernel, dim3(nq), dim3(XGM_WG), smem, stream, all_hits, all_hdrs, n_shards, nq,
-                       k_stride, kq, cap, hits, hdrs, 1u, (const uint32_t*)nullptr);
+                       k_stride, kq, cap, hits, hdrs, 1u, (const uint32_t*)nullptr,
+                       shard_record_bytes ? (unsigned long long)shard_record_bytes : (unsigned long long)nq * k_stride * sizeof(xgm_hit),
+                       shard_record_bytes ? (unsigned long long)shard_record_bytes : (unsigned long long)nq * sizeof(xgm_result_hdr));
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

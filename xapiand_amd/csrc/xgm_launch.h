@@ -83,7 +83,9 @@ int xgm_launch_merge_parts(const xgm_hit* all_hits, const xgm_result_hdr* all_hd
                            const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs, const uint32_t* row_of, hipStream_t stream);
 int xgm_launch_merge_shards(const xgm_hit* all_hits, const xgm_result_hdr* all_hdrs, uint32_t n_shards, uint32_t nq,
                             uint32_t k_stride, const uint32_t* kq, uint32_t cap, xgm_hit* hits, xgm_result_hdr* hdrs,
-                            hipStream_t stream);
+                            hipStream_t stream, size_t shard_record_bytes = 0);
+/* (shard_record_bytes != 0: shard s's hits start at all_hits + s * shard_record_bytes, its headers at all_hdrs + s * shard_record_bytes —
+ *  the packed records of ONE all-gather, xgm_merge_shards_packed_device) */
 int xgm_launch_decode(const xgm_seg_dev& seg, uint32_t term_id, uint32_t b0, uint32_t nblk, const uint64_t* ord_base,
                       uint32_t* out_did, uint32_t* out_wdf, hipStream_t stream);
 

@@ -518,12 +518,18 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     /* quantised bounds for a threshold th (> 0): which terms are essential (MaxScore over all terms: only the A/B variant without the
      * bound sum uses it) and, per lane t, the quantised bound of term t at its largest wdf (q2) and at wdf = 1 (q1).
      * Quantised UP: q >= ub * kQ / th, so sum(q) >= kQ whenever sum(ub) >= th */
+    /* (a threshold moves rarely — the histogram is looked at every fourth stripe and mostly says the same: the last answer is kept and the
+     *  two fp64 divisions are paid only when the threshold's bits changed, round 5) */
+    uint64_t qz_bits = 0, qz_ess = 0;
+    uint32_t qz_q2 = 0, qz_q1 = 0;
     auto quantise = [&](uint64_t th_bits, uint64_t& ess, uint32_t& q2, uint32_t& q1) {
+        if (th_bits == qz_bits) { ess = qz_ess; q2 = qz_q2; q1 = qz_q1; return; }
         const double th = __longlong_as_double((long long)th_bits);
         ess = __ballot(present_reg && !(prefix_reg < th));
         const double r2 = ub_reg * (double)kQ / th, r1 = ub1_reg * (double)kQ / th;
         q2 = r2 >= (double)kQ ? kQ : (uint32_t)r2 + 1u;
         q1 = r1 >= (double)kQ ? kQ : (uint32_t)r1 + 1u;
+        qz_bits = th_bits; qz_ess = ess; qz_q2 = q2; qz_q1 = q1;
     };
     /* the histogram's bound of the final k-th weight: highest bucket with >= k documents at or above it */
     auto hist_bound = [&](const uint32_t* hc) {

@@ -3,8 +3,10 @@
 Reference protocol (src/database/handler.cc:1485-1549): prepare_mset on every shard → Σ statistics
 (Enquire::add_prepared_mset, src/xapian/api/enquire.cc:385-394) → get_mset(0, first+maxitems) on every
 shard with the merged statistics → unshard_docids + merge_mset.  Here: one all-reduce(SUM) of the
-statistics per query pool, then per batch one all-gather of fixed-size top-k records (RCCL over xGMI on
-GPUs, gloo in the CPU tests) and a merge on every rank.  No other collective is on the data path.
+statistics per query pool, then per batch ONE all-gather of fixed-size top-k records — every rank's hits and headers packed
+in one buffer ([nq][k] xgm_hit then [nq] xgm_result_hdr: a second collective per batch would cost a second launch and a second
+trip round the xGMI ring for 8 KB; round 5) — RCCL over xGMI on GPUs, gloo in the CPU tests, and a merge on every rank
+(xgm_merge_shards_packed_device).  No other collective is on the data path.
 
 The search and merge steps are injectable so the collective logic can be exercised on CPU (gloo) where
 the HIP path cannot run: the defaults call the C ABI (xgm_search_batch_device /
@@ -36,6 +38,7 @@ class ShardedSearcher:
         self.merge_fn = merge_fn or self._device_merge
         self.force_collective = force_collective
         self._bufs = {}
+        self._ks = {}
         self._host_collectives = False
         if world > 1 or force_collective:
             # gloo has no device all-gather: stage the (tiny) records through pinned host memory — the path of the
@@ -84,12 +87,17 @@ class ShardedSearcher:
         return descs, gs
 
     # -- one batch ----------------------------------------------------------------------------------
-    def _buffers(self, nq, k):
-        key = (nq, k)
+    def _buffers(self, nq, k, slot=0):
+        """Per (batch shape, slot): this rank's packed record (hits and hdrs are VIEWS into it), the gathered records of all ranks
+        (all_hits / all_hdrs: strided views for host-side merges), the merged output.  `slot` lets a caller keep two batches in flight."""
+        key = (nq, k, slot)
         if key not in self._bufs:
             mk = lambda *shape: torch.zeros(shape, dtype=torch.float64, device=self.device)  # noqa: E731
-            self._bufs[key] = dict(hits=mk(nq, k, HIT_F64), hdrs=mk(nq, HDR_F64), all_hits=mk(self.world, nq, k, HIT_F64),
-                                   all_hdrs=mk(self.world, nq, HDR_F64), out_hits=mk(nq, k, HIT_F64), out_hdrs=mk(nq, HDR_F64))
+            nh, nd = nq * k * HIT_F64, nq * HDR_F64
+            rec, all_rec = mk(nh + nd), mk(self.world, nh + nd)
+            self._bufs[key] = dict(rec=rec, hits=rec[:nh].view(nq, k, HIT_F64), hdrs=rec[nh:].view(nq, HDR_F64), all_rec=all_rec,
+                                   all_hits=all_rec[:, :nh].view(self.world, nq, k, HIT_F64), all_hdrs=all_rec[:, nh:].view(self.world, nq, HDR_F64),
+                                   out_hits=mk(nq, k, HIT_F64), out_hdrs=mk(nq, HDR_F64))
         return self._bufs[key]
 
     def run_batch(self, batch, nq, k):
@@ -99,11 +107,12 @@ class ShardedSearcher:
         self.search_fn(batch, nq, k, b["hits"], b["hdrs"])
         return self._gather_merge(b, nq, k)
 
-    def run_descs(self, descs, gstats, nq, k):
+    def run_descs(self, descs, gstats, nq, k, slot=0):
         """Like run_batch, from query DESCRIPTIONS: planning (dictionary lookups, BM25Weight::init, leaf order) happens
         inside the call (xgm_get_mset_batch_device) — what the matcher hook does per get_mset.  descs: (xgm_query_desc * nq),
-        gstats: (xgm_global_stats * nq) merged statistics or None."""
-        b = self._buffers(nq, k)
+        gstats: (xgm_global_stats * nq) merged statistics or None.  Everything is enqueued on torch's current stream and nothing is
+        waited for: with slot alternating between 0 and 1 the host plans batch i + 1 while the GPU runs batch i."""
+        b = self._buffers(nq, k, slot)
         self._bind_stream()
         _lib.check(_lib.lib().xgm_get_mset_batch_device(self.shard._h, descs, gstats, nq, k, b["hits"].data_ptr(), b["hdrs"].data_ptr()))
         return self._gather_merge(b, nq, k)
@@ -111,18 +120,16 @@ class ShardedSearcher:
     def _gather_merge(self, b, nq, k):
         if self.world == 1 and not self.force_collective:
             return b["hits"], b["hdrs"]
-        # output = concatenation of the ranks' inputs along dim 0 (the layout both RCCL and gloo accept)
+        # ONE collective: output = the ranks' packed records one after the other (the layout both RCCL and gloo accept)
         if self._host_collectives:
-            hh, hd = b["hits"].cpu(), b["hdrs"].cpu()
-            ah = torch.empty((self.world * nq, k, HIT_F64), dtype=torch.float64)
-            ad = torch.empty((self.world * nq, HDR_F64), dtype=torch.float64)
-            dist.all_gather_into_tensor(ah, hh, group=self.group)
-            dist.all_gather_into_tensor(ad, hd, group=self.group)
-            b["all_hits"].view(self.world * nq, k, HIT_F64).copy_(ah)
-            b["all_hdrs"].view(self.world * nq, HDR_F64).copy_(ad)
+            mine = b["rec"].cpu()
+            gathered = torch.empty((self.world * mine.numel(),), dtype=torch.float64)
+            dist.all_gather_into_tensor(gathered, mine, group=self.group)
+            b["all_rec"].view(-1).copy_(gathered)
         else:
-            dist.all_gather_into_tensor(b["all_hits"].view(self.world * nq, k, HIT_F64), b["hits"], group=self.group)
-            dist.all_gather_into_tensor(b["all_hdrs"].view(self.world * nq, HDR_F64), b["hdrs"], group=self.group)
+            dist.all_gather_into_tensor(b["all_rec"].view(-1), b["rec"], group=self.group)
+        self.n_collectives = getattr(self, "n_collectives", 0) + 1
+        self._all_rec = b["all_rec"]
         self.merge_fn(b["all_hits"], b["all_hdrs"], self.world, nq, k, b["out_hits"], b["out_hdrs"])
         return b["out_hits"], b["out_hdrs"]
 
@@ -142,9 +149,12 @@ class ShardedSearcher:
     def _device_merge(self, all_hits, all_hdrs, n_shards, nq, k, out_hits, out_hdrs):
         if self._bind_stream() == 0:
             torch.cuda.current_stream(self.device).synchronize()
-        ks = (C.c_uint32 * nq)(*([k] * nq))
-        _lib.check(_lib.lib().xgm_merge_shards_device(self.shard._h, all_hits.data_ptr(), all_hdrs.data_ptr(), n_shards, nq, k, ks,
-                                                      out_hits.data_ptr(), out_hdrs.data_ptr()))
+        ks = self._ks.get((nq, k))
+        if ks is None:
+            ks = self._ks[(nq, k)] = (C.c_uint32 * nq)(*([k] * nq))
+        # (all_hits / all_hdrs are views into the gathered packed records: the device merge takes the records themselves)
+        _lib.check(_lib.lib().xgm_merge_shards_packed_device(self.shard._h, self._all_rec.data_ptr(), n_shards, nq, k, ks,
+                                                             out_hits.data_ptr(), out_hdrs.data_ptr()))
 
 
 def decode_results(hits, hdrs):
