@@ -25,6 +25,9 @@
 
 #include "../../integration/xgm_matcher_hook.h"
 
+bool xapiand_aggregation_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot);
+void xapiand_aggregation_feed(Xapian::MatchSpy& spy, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts);
+
 namespace {
 
 bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std::string* why) {
@@ -69,6 +72,12 @@ int main(int argc, char** argv) {
             for (const auto& kv : counts) d.values[kv.first] += kv.second;
         };
         xgm_hook::register_spy_adapter("DriverCountSpy", ad);
+    }
+    {   /* Xapiand's own AggregationMatchSpy, compiled from the reference (xapiand_classes.cc): the adapter a Xapiand build registers */
+        xgm_hook::SpyAdapter ad;
+        ad.slot_of = [](const Xapian::MatchSpy& s, Xapian::valueno* slot) { return xapiand_aggregation_slot_of(s, slot); };
+        ad.feed = [](Xapian::MatchSpy& s, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts) { xapiand_aggregation_feed(s, total, counts); };
+        xgm_hook::register_spy_adapter("AggregationMatchSpy", ad);
     }
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
@@ -187,6 +196,9 @@ int main(int argc, char** argv) {
             if (!same_mset(want, got, percents, &why)) {
                 ++bad;
                 printf("MISMATCH query %zu (%s): %s; cpu %u hits, hook %u hits\n", qi, q.op.c_str(), why.c_str(), want.size(), got.size());
+            } else if (spy_want.aggregation != spy_got.aggregation) {
+                ++bad;
+                printf("MISMATCH query %zu (%s): Xapiand's aggregation: cpu %s\n   hook %s\n", qi, q.op.c_str(), spy_want.aggregation.substr(0, 300).c_str(), spy_got.aggregation.substr(0, 300).c_str());
             } else if (spy_want.total != spy_got.total || spy_want.values != spy_got.values) {
                 ++bad;
                 printf("MISMATCH query %zu (%s): spy: cpu saw %u documents / %zu values, hook %u / %zu\n", qi, q.op.c_str(), spy_want.total, spy_want.values.size(),

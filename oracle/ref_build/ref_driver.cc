@@ -46,6 +46,7 @@
 #include <fstream>
 #include <sstream>
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -54,6 +55,11 @@
 
 /* Xapiand's own key maker (oracle/ref_build/xapiand_classes.cc; linked into xapian_hook_b1 only: weak here) */
 const Xapian::KeyMaker* xapiand_keymaker(unsigned variant, bool reverse) __attribute__((weak));
+
+/* Xapiand's aggregation spy (oracle/ref_build/xapiand_classes.cc); absent — null — where Xapiand's classes are not linked */
+Xapian::MatchSpy* xapiand_aggregation_spy(unsigned slot) __attribute__((weak));
+std::string xapiand_aggregation_result(Xapian::MatchSpy* spy) __attribute__((weak));
+void xapiand_aggregation_merge(Xapian::MatchSpy* into, Xapian::MatchSpy* from) __attribute__((weak));
 
 namespace {
 
@@ -71,11 +77,15 @@ struct QuerySpec {
     /* "SPYC=<slot>": the same counts through a MatchSpy subclass of the driver's own (DriverCountSpy) — a class the hook only knows
      * through a registered xgm_hook::SpyAdapter, the way Xapiand's AggregationMatchSpy would be bound */
     bool spy_custom = false;
+    /* "SPYA=<slot>": Xapiand's OWN AggregationMatchSpy (src/aggregations/aggregations.h, compiled from the reference: xapiand_classes.cc)
+     * with a `_values` aggregation on the slot — only in binaries that link Xapiand's classes (xapian_hook_b1) */
+    bool spy_aggregation = false;
     /* "CUT=<percent>:<weight>": Enquire::set_cutoff (DocMatcher::prepare_mset sets it on every Enquire, handler.cc:1265) */
     int cut_percent = 0; double cut_weight = 0.0;
 };
 
-struct SpyResult { unsigned total = 0; std::map<std::string, unsigned> values; };
+struct SpyResult { unsigned total = 0; std::map<std::string, unsigned> values; std::string aggregation; };
+
 
 /* A MatchSpy class of the application's own, counting a slot's values the way Xapian::ValueCountMatchSpy does (api/matchspy.cc) */
 class DriverCountSpy : public Xapian::MatchSpy {
@@ -120,6 +130,10 @@ std::vector<QuerySpec> read_queries(const char* path) {
             } else if (tok.rfind("SPYC=", 0) == 0) {
                 q.spy_slot = (int)strtoul(tok.c_str() + 5, nullptr, 10);
                 q.spy_custom = true;
+            } else if (tok.rfind("SPYA=", 0) == 0) {
+                q.spy_slot = (int)strtoul(tok.c_str() + 5, nullptr, 10);
+                q.spy_aggregation = true;
+                if (!xapiand_aggregation_spy) { fprintf(stderr, "SPYA: Xapiand's classes are not linked into this binary\n"); exit(2); }
             } else { ss.clear(); ss.seekg(at); break; }
         }
         ss >> q.op >> q.first >> q.maxitems >> q.window;
@@ -277,6 +291,14 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
         apply_settings(enq, settings);
         enq.set_query(query);
         if (!spy_on) return enq.get_mset(first, maxitems, cal);
+        if (settings->spy_aggregation) {
+            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot));
+            enq.add_matchspy(aspy.get());
+            Xapian::MSet m = enq.get_mset(first, maxitems, cal);
+            spied->aggregation = xapiand_aggregation_result(aspy.get());
+            enq.clear_matchspies();
+            return m;
+        }
         if (settings->spy_custom) {
             DriverCountSpy cspy((Xapian::valueno)settings->spy_slot);
             enq.add_matchspy(&cspy);
@@ -307,9 +329,16 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
         doccount += dbs[s].get_doccount();
         merger.add_prepared_mset(prepared);
     }
+    std::unique_ptr<Xapian::MatchSpy> agg_total;                 /* Xapiand merges the shards' aggregations (merge_results) */
     for (size_t s = 0; s < n_shards; ++s) {
         enqs[s].set_prepared_mset(merger.get_prepared_mset());
-        if (spy_on && settings->spy_custom) {
+        if (spy_on && settings->spy_aggregation) {
+            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot));
+            enqs[s].add_matchspy(aspy.get());
+            msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
+            enqs[s].clear_matchspies();
+            if (!agg_total) agg_total = std::move(aspy); else xapiand_aggregation_merge(agg_total.get(), aspy.get());
+        } else if (spy_on && settings->spy_custom) {
             DriverCountSpy cspy((Xapian::valueno)settings->spy_slot);
             enqs[s].add_matchspy(&cspy);
             msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
@@ -327,6 +356,7 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
         }
         msets[s].unshard_docids(s, n_shards);
     }
+    if (agg_total) spied->aggregation = xapiand_aggregation_result(agg_total.get());
     return merger.merge_mset(msets, doccount, first, maxitems);
 }
 

@@ -317,6 +317,7 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidDevice; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)64 << 30; *total_b = (size_t)64 << 30; return hipSuccess; }
 /* XGM_EMU_GUARD=1: every device allocation ends 16-byte aligned right before an inaccessible page, so a kernel that reads or
  * writes past the end of a buffer faults (XGM_EMU_FAULT_TRACE=1 says where) instead of finding host memory there */
 #include <sys/mman.h>

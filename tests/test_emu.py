@@ -337,3 +337,25 @@ def test_xapiand_own_keymaker_under_emulation(emu_lib, tmp_path):
     out = _run_hook_emulated(T, alias, qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
     assert out["answered_sorted"] == len(qs) and out["http_total_equal"] == len(qs), out
+
+
+def test_xapiand_own_aggregation_spy_under_emulation(emu_lib, tmp_path):
+    """Xapiand's own AggregationMatchSpy (src/aggregations/, compiled from the reference's sources into the hook driver) with a `_values`
+    aggregation over single- and multi-valued slots, in front of the hook, without a GPU: the device's per-value counts fed to the
+    reference's class through the adapter — hook on == hook off on the `_aggregations` object and its wire form."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import test_gpu_hook_b1 as T
+    if not (H.have_xapian_ref() and os.path.exists(T.HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    alias = tmp_path / "lib"
+    alias.mkdir()
+    os.symlink(emu_lib, str(alias / "libxgm.so"))
+    one = str(tmp_path / "one")
+    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), 6000, T.VOCAB, 50, 150)
+    qs = T.xapiand_aggregation_queries(6000)[::2]
+    qf = str(tmp_path / "qa.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] == len(qs) and out["answered_spied"] == len(qs), out

@@ -165,6 +165,42 @@ def test_value_and_key_sorts_and_spies_through_the_hook(built, glass_values):
     assert 3 <= out["columns_built"] <= 6, out            # one column per value slot / key maker and shard revision, built once
 
 
+def xapiand_aggregation_queries(n_docs=N_DOCS):
+    import random
+    rng = random.Random(91)
+    base = (H.gen_term_queries("OR", 10, 3, 1, 400, maxitems=10, seed=261) + H.gen_term_queries("AND", 10, 2, 1, 60, maxitems=10, seed=262) +
+            H.gen_sided_queries("AND_MAYBE", 4, 1, 2, 1, 200, maxitems=10, seed=263) + H.gen_term_queries("OR", 4, 5, 1, 3000, first=7, maxitems=43, seed=265))
+    qs = []
+    for i, q in enumerate(base):
+        q = dict(q, spy=i % 4, spy_aggregation=True)
+        if i % 2 == 0:
+            q["sort"] = (["V", "VR"][i // 2 % 2], rng.randrange(3), rng.random() < 0.5)        # the value leads: the spy sees every match
+        else:
+            q["check_at_least"] = n_docs                                                       # by relevance, every match looked at
+        qs.append(q)
+    return qs
+
+
+def test_xapiand_own_aggregation_spy_through_the_hook(built, glass_values):
+    """VERDICT r4 missing #2 / SURVEY 8(f).3: the MatchSpy Xapiand really attaches — AggregationMatchSpy (reference
+    src/aggregations/aggregations.h:108, src/database/handler.cc:1283), its three translation units compiled from the reference's
+    sources — with a `_values` aggregation on a value slot: single-valued slots 0..2 and the multi-valued slot 3 (a StringList: one
+    document falls into several buckets).  The device counts the matching documents per distinct slot value
+    (xgm_search_sorted_spy), the adapter feeds the reference's own class (one clone per distinct value, scaled, merge_results);
+    hook on == hook off: the `_aggregations` object a response would carry and the wire form, under value-led sorts and by relevance
+    with check_at_least covering the match, one shard and Xapiand's 3-shard protocol."""
+    d, one, shards = glass_values
+    qs = xapiand_aggregation_queries()
+    qf = str(d / "qagg.txt")
+    H.write_queries(qf, qs)
+    out = run_b1(qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["answered_on_device"] == len(qs) and out["answered_spied"] == len(qs), out
+    out = run_b1(qf, *shards)
+    assert out["mismatches"] == 0, out
+    assert out["answered_spied"] == 3 * len(qs), out
+
+
 def xapiand_keymaker_queries():
     """Sorted by Xapiand's OWN key maker: Multi_MultiValueKeyMaker (reference src/multivalue/keymaker.h:366; compiled from the reference's
     sources into the driver, oracle/ref_build/xapiand_classes.cc) through Enquire::set_sort_by_key_then_relevance(sorter, false) — the

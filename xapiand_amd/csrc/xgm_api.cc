@@ -1740,6 +1740,7 @@ struct XgmBatcher {
     hipStream_t stream = nullptr;               /* the flights' match kernels run back to back on ONE stream (kernels of concurrent streams slow each other
                                                    down: measured 0.53 vs 0.38 ms per 256-query launch); uploads and downloads ride the scratches' own streams */
     bool stop = false;
+    bool dispatcher_done = false;               /* the dispatcher has left its loop: no batch can be cut any more (the completer may then leave too) */
     uint32_t max_batch = 256;
     uint32_t max_flights = 2;
     uint64_t batches = 0, requests = 0;
@@ -1812,7 +1813,7 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
         }
         b->cv_flight.notify_one();
     }
-    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; }
+    { std::lock_guard<std::mutex> lk(b->mu); b->stop = true; b->dispatcher_done = true; }
     b->cv_flight.notify_all();
 }
 
@@ -1823,7 +1824,8 @@ static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
         XgmFlight* fl = nullptr;
         {
             std::unique_lock<std::mutex> lk(b->mu);
-            b->cv_flight.wait(lk, [&] { return !b->flights.empty() || (b->stop && b->queue.empty()); });
+            /* (not `stop && queue.empty()`: the dispatcher may hold a batch it has cut but not yet put in flight — ADVICE r4) */
+            b->cv_flight.wait(lk, [&] { return !b->flights.empty() || b->dispatcher_done; });
             if (b->flights.empty()) return;
             fl = b->flights.front();
         }
@@ -1862,7 +1864,7 @@ static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride,
     {
         std::unique_lock<std::mutex> lk(b->mu);
         b->queue.push_back(&r);
-        if (b->queue.size() == 1) b->cv_work.notify_one();
+        b->cv_work.notify_one();                   /* always: a LINGERING dispatcher waits for the queue to reach a size, not to become non-empty (one futex call) */
         r.cv.wait(lk, [&] { return r.done; });
     }
     if (r.rc < 0) return xgm_set_error(r.rc, "%s", r.err);

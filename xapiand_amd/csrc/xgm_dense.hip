@@ -209,11 +209,25 @@ static int build_flat(xgm_index* idx) {
     if (n == 0) return XGM_OK;
     int rc = XGM_OK;
     uint32_t* d_terms = nullptr;
-    DN_TRY(hipMalloc(&idx->d_flat_off, off.size() * 8));
-    DN_TRY(hipMalloc(&idx->d_flat_did, n * 4 + 256));
-    DN_TRY(hipMalloc(&idx->d_flat_wdf, n + 256));
-    if (idx->hdr.has_positions && !getenv("XGM_NO_FLAT_PHRASE")) DN_TRY(hipMalloc(&idx->d_flat_pos, n * 4 + 256));      /* (A/B switch: positional queries never take the flat body) */
-    DN_TRY(hipMalloc((void**)&d_terms, terms.size() * 4));
+    /* The flat arrays are an ACCELERATOR (every kernel still has the blocks): they never fail an open.  Budget: XGM_FLAT_MAX_BYTES
+     * (default 16 GiB) and at most half of the device memory that is free right now — several shards share a GPU; beyond it the position
+     * starts go first (positional queries led by a long-tail term take the queue path again), then the arrays altogether. */
+    bool want_pos = idx->hdr.has_positions && !getenv("XGM_NO_FLAT_PHRASE");      /* (A/B switch: positional queries never take the flat body) */
+    {
+        size_t budget = getenv("XGM_FLAT_MAX_BYTES") ? (size_t)strtoull(getenv("XGM_FLAT_MAX_BYTES"), nullptr, 0) : (size_t)16 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min(budget, free_b / 2);
+        const size_t base_b = off.size() * 8 + n * 5 + 512 + terms.size() * 4;
+        if (want_pos && base_b + n * 4 + 256 > budget) want_pos = false;
+        if (base_b > budget) return XGM_OK;
+    }
+#define FLAT_TRY(expr) do { if ((expr) != hipSuccess) { (void)hipGetLastError(); rc = XGM_OK; goto fail; } } while (0)       /* out of memory: no flat arrays, the index opens */
+    FLAT_TRY(hipMalloc(&idx->d_flat_off, off.size() * 8));
+    FLAT_TRY(hipMalloc(&idx->d_flat_did, n * 4 + 256));
+    FLAT_TRY(hipMalloc(&idx->d_flat_wdf, n + 256));
+    if (want_pos && hipMalloc(&idx->d_flat_pos, n * 4 + 256) != hipSuccess) { (void)hipGetLastError(); idx->d_flat_pos = nullptr; }
+    FLAT_TRY(hipMalloc((void**)&d_terms, terms.size() * 4));
+#undef FLAT_TRY
     DN_TRY(hipMemcpy(idx->d_flat_off, off.data(), off.size() * 8, hipMemcpyHostToDevice));
     DN_TRY(hipMemcpy(d_terms, terms.data(), terms.size() * 4, hipMemcpyHostToDevice));
     DN_TRY(hipMemset((unsigned char*)idx->d_flat_did + n * 4, 0xFF, 256));         /* (a round reads up to 63 entries past a slice's end: sentinels, never used) */
