@@ -24,6 +24,7 @@
 #include <chrono>
 
 #include "../../integration/xgm_matcher_hook.h"
+#include "../../integration/xgm_xapiand_glue.h"
 
 bool xapiand_aggregation_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot);
 void xapiand_aggregation_feed(Xapian::MatchSpy& spy, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts);
@@ -50,11 +51,35 @@ bool same_mset(const Xapian::MSet& a, const Xapian::MSet& b, bool percents, std:
     return true;
 }
 
+/* The body of Xapiand's search response as HttpClient::search_view forms it from the MSet (reference src/server/http_client.cc:2544-2599,
+ * field names src/response.h:25-43): "aggregations" (the spy's result, when the request had _aggs), "count" = mset.size(), "total" =
+ * mset.get_matches_estimated(), and per hit — with ?comments — "#docid", "#shard" = (docid - 1) % shards + 1, "#rank", "#weight",
+ * "#percent".  The stored document (its _id and data) is read from the document store after the match and is not part of this path.
+ * A restatement of those 50 lines over the REAL MSet: the server itself (cmake, 376 k lines, its own event loop) is not built here. */
+std::string http_body(const Xapian::MSet& m, size_t n_shards, const std::string& aggregation) {
+    std::string body = "{";
+    if (!aggregation.empty()) body += "\"aggregations\":" + aggregation.substr(0, aggregation.find('|')) + ",";
+    body += "\"hits\":[";
+    char buf[256];
+    bool firsth = true;
+    for (auto it = m.begin(); it != m.end(); ++it) {
+        const Xapian::docid did = *it;
+        snprintf(buf, sizeof buf, "%s{\"#docid\":%u,\"#shard\":%zu,\"#rank\":%u,\"#weight\":%.17g,\"#percent\":%d}", firsth ? "" : ",", did,
+                 (size_t)((did - 1) % n_shards) + 1, it.get_rank(), it.get_weight(), it.get_percent());
+        body += buf;
+        firsth = false;
+    }
+    snprintf(buf, sizeof buf, "],\"count\":%u,\"total\":%u}", m.size(), m.get_matches_estimated());
+    body += buf;
+    return body;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
     int a = 1;
-    bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false;
+    bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false, commit_glue = false;
+    const char* bodies_dir = nullptr;
     struct Leg { std::string name, mode, file; };
     std::vector<Leg> legs;
     xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_INTENDED);        /* the deployment's choice; the tests pick per run */
@@ -87,6 +112,8 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
         else if (!strcmp(argv[a], "--replay")) { xgm_hook::set_replay(true); replay_on = true; }
         else if (!strcmp(argv[a], "--stale")) stale = true;
+        else if (!strcmp(argv[a], "--commit-glue")) commit_glue = true;       /* shards reach the device through integration/xgm_xapiand_glue.cc (what xapiand_shard_hook.patch calls) */
+        else if (!strcmp(argv[a], "--http-bodies") && a + 1 < argc) bodies_dir = argv[++a];      /* write every response body (hook off / on) there */
         else if (!strcmp(argv[a], "--leg") && a + 1 < argc) {
             const std::string spec = argv[++a];
             const size_t c1 = spec.find(':'), c2 = c1 == std::string::npos ? c1 : spec.find(':', c1 + 1);
@@ -108,6 +135,15 @@ int main(int argc, char** argv) {
         auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         for (int i = a + 1; i < argc; ++i) {
             dbs.emplace_back(argv[i]);
+            if (commit_glue) {
+                /* Xapiand's way in: Shard::commit → xgm_xapiand::on_commit (export, load, register); the first time in full */
+                const double t_e0 = now_s();
+                if (!xgm_xapiand::on_commit(argv[i], dbs.back(), 0)) { fprintf(stderr, "on_commit(%s) failed\n", argv[i]); return 1; }
+                export_s += now_s() - t_e0;
+                idx.push_back(nullptr);
+                seg_files.push_back("");
+                continue;
+            }
             char seg[64];
             snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%d.seg", (int)getpid(), i);
             const double t_e0 = now_s();
@@ -127,6 +163,7 @@ int main(int argc, char** argv) {
         /* the shard moved on: refresh its segment INCREMENTALLY — documents below first_changed come from the old segment, only
          * the rest is read from glass (xgm_segment_refresh_from_glass; byte-identical to a full export, tests/test_glass.py) */
         auto export_and_register = [&](size_t i, const char* dir, uint32_t first_changed) -> int {
+            if (commit_glue) return xgm_xapiand::on_commit(dir, dbs[i], first_changed) ? 0 : 1;       /* (an incremental refresh from the registered segment) */
             char seg[64];
             snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%zu_r.seg", (int)getpid(), i);
             if (xgm_segment_refresh_from_glass(seg_files[i].c_str(), dir, first_changed, 0, seg) != XGM_OK) { fprintf(stderr, "refresh %s: %s\n", dir, xgm_last_error()); return 1; }
@@ -178,7 +215,7 @@ int main(int argc, char** argv) {
             xgm_hook::set_positional_mode(positional_reference_on ? xgm_hook::POSITIONAL_REFERENCE : xgm_hook::POSITIONAL_INTENDED);
         }
         const xgm_hook::Counters c0 = leg.file.empty() ? xgm_hook::Counters{} : xgm_hook::counters();     /* (the classic single run reports the process's totals: --stale counts declines before the loop) */
-        unsigned bad = 0, bounds_bad = 0, http_total_equal = 0;
+        unsigned bad = 0, bounds_bad = 0, http_total_equal = 0, http_bodies_equal = 0;
         double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;
         for (size_t qi = 0; qi < queries.size(); ++qi) {
@@ -207,6 +244,17 @@ int main(int argc, char** argv) {
             /* Xapiand's HTTP response: "total" = mset.get_matches_estimated(), "_percent" = get_percent() of every hit (reference
              * src/server/http_client.cc:2553-2554, 2598) — the percentages are part of same_mset above */
             if (want.get_matches_estimated() == got.get_matches_estimated()) ++http_total_equal;
+            {
+                const std::string bw = http_body(want, dbs.size(), spy_want.aggregation), bg = http_body(got, dbs.size(), spy_got.aggregation);
+                if (bw == bg) ++http_bodies_equal;
+                if (bodies_dir) {
+                    char fn[512];
+                    snprintf(fn, sizeof fn, "%s/q%04zu.cpu.json", bodies_dir, qi);
+                    if (FILE* f = fopen(fn, "w")) { fputs(bw.c_str(), f); fputc('\n', f); fclose(f); }
+                    snprintf(fn, sizeof fn, "%s/q%04zu.hook.json", bodies_dir, qi);
+                    if (FILE* f = fopen(fn, "w")) { fputs(bg.c_str(), f); fputc('\n', f); fclose(f); }
+                }
+            }
             /* the upper bound is a static property of the postlist tree: identical; the lower bound may be looser than the CPU
              * matcher's (which counts the documents it happened to weigh) but never above it or the estimate.  Where the value leads
              * the sort the matcher shows ProtoMSet every document: all three figures must be the reference's. */
@@ -249,17 +297,20 @@ int main(int argc, char** argv) {
         printf(" \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
                "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu, "
-               "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f}\n",
+               "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f, "
+               "\"http_bodies_equal\": %u, \"glue_full_exports\": %llu, \"glue_refreshes\": %llu, \"glue_failures\": %llu}\n",
                bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
                (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed,
-               (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s);
+               (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s, http_bodies_equal,
+               (unsigned long long)xgm_xapiand::stats().full_exports, (unsigned long long)xgm_xapiand::stats().refreshes, (unsigned long long)xgm_xapiand::stats().failures);
         fflush(stdout);
         bad_total += bad + bounds_bad;
         }   /* legs */
-        for (auto& d : dbs) xgm_hook::unregister_shard(d);
-        for (auto* h : idx) xgm_index_close(h);
-        for (const std::string& f : seg_files) unlink(f.c_str());
+        if (commit_glue) { for (auto& d : dbs) xgm_xapiand::on_close(d); }
+        else for (auto& d : dbs) xgm_hook::unregister_shard(d);
+        for (auto* h : idx) if (h) xgm_index_close(h);
+        for (const std::string& f : seg_files) if (!f.empty()) unlink(f.c_str());
         return bad_total ? 1 : 0;
     } catch (const Xapian::Error& e) {
         fprintf(stderr, "Xapian error: %s\n", e.get_description().c_str());

@@ -352,10 +352,46 @@ def test_xapiand_own_aggregation_spy_under_emulation(emu_lib, tmp_path):
     alias.mkdir()
     os.symlink(emu_lib, str(alias / "libxgm.so"))
     one = str(tmp_path / "one")
-    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), 6000, T.VOCAB, 50, 150)
-    qs = T.xapiand_aggregation_queries(6000)[::2]
+    H.xapian_ref("build_values", one, hex(H.CORPUS_SEED), 3000, T.VOCAB, 50, 150)
+    qs = T.xapiand_aggregation_queries(3000)[::3]
     qf = str(tmp_path / "qa.txt")
     H.write_queries(qf, qs)
     out = _run_hook_emulated(T, alias, qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
     assert out["answered_on_device"] == len(qs) and out["answered_spied"] == len(qs), out
+
+
+def test_commit_glue_and_http_bodies_under_emulation(emu_lib, tmp_path):
+    """The Xapiand side of the seam (integration/xgm_xapiand_glue.cc: what integration/xapiand_shard_hook.patch calls from Shard::commit /
+    do_close) without a GPU: full export on the first commit, incremental refresh on the next, searches on a revision the device does not
+    hold yet declined; and the search response's body as http_client.cc:2544-2599 forms it, byte-identical hook off vs hook on."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    import test_gpu_hook_b1 as T
+    if not (H.have_xapian_ref() and os.path.exists(T.HOOK_B1)):
+        pytest.skip("oracle/_ref is not built (needs /root/reference at build time)")
+    alias = tmp_path / "lib"
+    alias.mkdir()
+    os.symlink(emu_lib, str(alias / "libxgm.so"))
+    one = str(tmp_path / "one")
+    H.xapian_ref("build", one, hex(H.CORPUS_SEED), 3000, T.VOCAB, 50, 150)
+    qs = H.gen_term_queries("AND", 8, 2, 1, 100, maxitems=10, seed=223) + H.gen_term_queries("OR", 4, 3, 1, 400, maxitems=10, seed=224)
+    qf = str(tmp_path / "qg.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, "--commit-glue", "--stale", "--exact-bounds", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["declined_revision"] >= 8, out
+    assert out["glue_full_exports"] == 1 and out["glue_refreshes"] == 1 and out["glue_failures"] == 0, out
+    assert out["http_bodies_equal"] == len(qs) and out["answered_on_device"] >= len(qs), out
+
+
+def test_integration_patches_apply_to_the_reference():
+    """integration/matcher_hook.patch (src/xapian/matcher/matcher.cc) and integration/xapiand_shard_hook.patch (src/database/shard.cc)
+    apply to the reference's files as they are."""
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("the reference is not present")
+    for patch, target in (("matcher_hook.patch", "xapian/matcher/matcher.cc"), ("xapiand_shard_hook.patch", "database/shard.cc")):
+        r = subprocess.run(["patch", "--dry-run", "-s", "-o", "/dev/null", os.path.join(ref, target), os.path.join(ROOT, "integration", patch)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, (patch, r.stdout, r.stderr)

@@ -201,6 +201,45 @@ def test_xapiand_own_aggregation_spy_through_the_hook(built, glass_values):
     assert out["answered_spied"] == 3 * len(qs), out
 
 
+def test_commit_glue_and_http_response_bodies(built, glass, glass_values, tmp_path):
+    """SURVEY 8(f).4 second half, as far as this image goes (the server itself — cmake, 376 k lines — is not built): (1) the Xapiand side
+    of the seam, integration/xgm_xapiand_glue.cc — what integration/xapiand_shard_hook.patch calls from Shard::commit and do_close
+    (src/database/shard.cc:641-766) — keeps the device's segment in step with the committed revision: the first commit exports in full,
+    a later one refreshes incrementally, searches on a revision the device does not hold yet are declined; (2) the BODY of the search
+    response as HttpClient::search_view forms it from the MSet (src/server/http_client.cc:2544-2599: aggregations, hits with #docid /
+    #shard / #rank / #weight / #percent, count, total) is byte-identical hook off vs hook on — incl. Xapiand's own aggregations."""
+    d, one, _ = glass
+    copy = str(tmp_path / "one_copy")
+    shutil.copytree(one, copy)
+    bodies = tmp_path / "bodies"
+    bodies.mkdir()
+    qs = (H.gen_term_queries("AND", 16, 2, 1, 100, maxitems=10, seed=223) + H.gen_term_queries("OR", 8, 3, 1, 400, maxitems=10, seed=224) +
+          H.gen_phrase_queries(6, N_DOCS, VOCAB, seed=225))
+    qf = str(tmp_path / "qglue.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--commit-glue", "--stale", "--exact-bounds", "--http-bodies", bodies, qf, copy)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["declined_revision"] >= 8 and out["refreshed_shards"] == 1, out                  # the moved-on revision: CPU until on_commit ran
+    assert out["glue_full_exports"] == 1 and out["glue_refreshes"] == 1 and out["glue_failures"] == 0, out
+    assert out["http_bodies_equal"] == len(qs) and out["http_total_equal"] == len(qs), out
+    assert out["answered_on_device"] >= len(qs), out
+    files = sorted(os.listdir(str(bodies)))
+    assert len(files) == 2 * len(qs)
+    for i in range(len(qs)):
+        cpu, hook = (open(str(bodies / ("q%04d.%s.json" % (i, w)))).read() for w in ("cpu", "hook"))
+        assert cpu == hook and json.loads(cpu)["count"] == len(json.loads(cpu)["hits"]), i
+    # ... and with Xapiand's own aggregations in the body, one shard and three
+    dv, onev, shardsv = glass_values
+    qa = xapiand_aggregation_queries()[::2]
+    qfa = str(tmp_path / "qglue_agg.txt")
+    H.write_queries(qfa, qa)
+    out = run_b1("--commit-glue", "--http-bodies", bodies, qfa, onev)
+    assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["answered_spied"] == len(qa), out
+    assert "aggregations" in json.loads(open(str(bodies / "q0000.hook.json")).read())
+    out = run_b1("--commit-glue", qfa, *shardsv)
+    assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["glue_full_exports"] == 3, out
+
+
 def xapiand_keymaker_queries():
     """Sorted by Xapiand's OWN key maker: Multi_MultiValueKeyMaker (reference src/multivalue/keymaker.h:366; compiled from the reference's
     sources into the driver, oracle/ref_build/xapiand_classes.cc) through Enquire::set_sort_by_key_then_relevance(sorter, false) — the
