@@ -284,7 +284,7 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
         matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in leg.timed_plans[b * BATCH:(b + 1) * BATCH])
         tl = (C.c_uint64 * 10)()
-        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_dense_kernel")
+        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel")
         bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
         alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
         if have_tally:

@@ -29,11 +29,15 @@ PHRASE_SELECT = "phrase or other_stripe_widths or edge_cases"
                                            ("XGM_NO_FLAT", SELECT + " or phrase"), ("XGM_NO_DENSE_PHRASE_BODY", PHRASE_SELECT), ("XGM_NO_FLAT_PHRASE", PHRASE_SELECT),
                                            # the disjunction's guess of the k-th weight far too high: every unit must go round again
                                            # below it (second pass) and still skip what the first pass weighed; and a little too high
-                                           ("XGM_OR_SEED_SCALE=8", SELECT), ("XGM_OR_SEED_SCALE=1.3", SELECT)])
+                                           ("XGM_OR_SEED_SCALE=8", SELECT), ("XGM_OR_SEED_SCALE=1.3", SELECT),
+                                           # round 5: the disjunction's terms without containers through the block decode again (no flat arrays); the
+                                           # opt-in word-major kernel xgm_orw2_kernel, also with a guess that forces its repair pass
+                                           ("XGM_NO_OR_FLAT", SELECT), ("XGM_ORW2=1", SELECT), ("XGM_ORW2=1,XGM_OR_SEED_SCALE=8", SELECT)])
 def test_parity_with_fast_path_disabled(built, switch, select):
     env = dict(os.environ)
-    name, _, val = switch.partition("=")
-    env[name] = val or "1"
+    for one in switch.split(","):
+        name, _, val = one.partition("=")
+        env[name] = val or "1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
                         "-k", select, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "%s=1:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-2000:])

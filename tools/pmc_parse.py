@@ -17,8 +17,8 @@ def is_tally(name):
     if not m:
         return False
     args = [a.strip() for a in m.group(1).split(",")]
-    return name.startswith(("void (anonymous namespace)::xgm_andw_kernel", "void (anonymous namespace)::xgm_orw_kernel", "void (anonymous namespace)::xgm_dense_kernel",
-                            "xgm_andw_kernel", "xgm_orw_kernel", "xgm_dense_kernel")) and args[-1] in ("true", "1", "(bool)1")
+    return name.startswith(("void (anonymous namespace)::xgm_andw_kernel", "void (anonymous namespace)::xgm_orw_kernel", "void (anonymous namespace)::xgm_orw2_kernel", "void (anonymous namespace)::xgm_dense_kernel",
+                            "xgm_andw_kernel", "xgm_orw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel")) and args[-1] in ("true", "1", "(bool)1")
 
 
 def short(name):

@@ -651,10 +651,13 @@ struct BatchPlan {
     bool fused = false; /* the conjunction kernel finishes its queries itself (xgm_unit_finish.h): no merge launch, no parts */
     uint32_t parts = 1; /* > 1: a query's units are merged in `parts` groups (pseudo-query p * nq + q of goff) and the groups' lists once more */
     uint32_t sub_bits = 0; /* workgroup kernels: every stripe in 2^sub_bits passes over narrower tables (positional queries of > 3 terms) */
+    int orw2 = 0;          /* orw batch whose every query xgm_orw2_kernel takes: 1 = containers only, 2 = with flat-array terms */
+    bool or_flat = false;  /* orw batch: every term without a container has a flat posting array (xgm_orw_kernel's FLAT instantiation) */
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
 static bool flat_kind(const xgm_index* idx, const xgm_query& q);
+static int or2_kind(const xgm_index* idx, const xgm_query& q);
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
                       BatchPlan* bp, bool force_general = false) {
@@ -711,6 +714,22 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     while ((uint64_t)((n_stripes + orw_spg - 1u) / orw_spg) * k_pad > XGM_MERGE_CAP && orw_spg < 4096u) orw_spg *= 2u;
     bp->orw = or_only && (uint64_t)((n_stripes + orw_spg - 1u) / orw_spg) * k_pad <= XGM_MERGE_CAP &&
               xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), bp->wide, orw_spg) <= 160u * 1024u;
+    static const bool no_or_flat = getenv("XGM_NO_OR_FLAT") != nullptr;                 /* A/B switch (the variant tests): block decode for every term without a container */
+    if (bp->orw && !bp->wide && !no_or_flat && idx->view.flat_off && idx->view.n_dense && idx->flat_postings < 0xFFFFFFFFull) {
+        bool all = true;
+        for (uint32_t i = 0; i < nq && all; ++i)
+            for (uint32_t t = 0; t < qs[i].n_terms && all; ++t) {
+                const uint32_t id = qs[i].terms[t].term_id;
+                if (id == UINT32_MAX || (uint64_t)idx->term_df[id] >= idx->dense_min_df) continue;       /* absent, or it has a container */
+                all = idx->term_wdfub[id] <= 254u && idx->term_df[id] != 0;                             /* (what build_flat gives an array) */
+            }
+        bp->or_flat = all;
+    }
+    if (bp->orw && !bp->wide && bp->tab_terms <= 8u) {
+        int kind = 1;
+        for (uint32_t i = 0; i < nq && kind; ++i) { const int kq_ = or2_kind(idx, qs[i]); kind = kq_ == 0 ? 0 : std::max(kind, kq_); }
+        if (kind && xgm_orw2_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, std::max(128u, next_pow2(bp->k_max + 64u)), orw_spg, kind == 2) <= 160u * 1024u) bp->orw2 = kind;
+    }
     const bool wave_units = bp->andw || bp->orw;
     /* plain conjunctions over containers only: their units take xgm_dense_unit inside xgm_andw_kernel<uint8_t, false, 0> */
     /* ... and positional queries over containers only that prune by weight: xgm_dense_unit<PHRASE> inside the positional instantiation
@@ -853,7 +872,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     static const double units_per_query = getenv("XGM_UNITS_PER_QUERY") ? atof(getenv("XGM_UNITS_PER_QUERY")) : 48.0;
     static const double units_floor = getenv("XGM_UNITS_FLOOR") ? atof(getenv("XGM_UNITS_FLOOR")) : 3072.0;                     /* A/B switch */
     const double scaled_units = (units_per_query > 0.0 && nq > 4u) ? std::min(and_units, std::max(units_floor, units_per_query * (double)nq)) : and_units;
-    const double target_units = bp->orw ? orw_units : scaled_units;
+    /* ... and a disjunction launch of a FEW queries (the class split leaves xgm_orw_kernel the odd query xgm_orw2_kernel does not take) is not cut
+     * into 8 192 units of one stripe each: 32 units per query, at least 1 024 */
+    const double orw_scaled = nq >= 192u ? orw_units : std::min(orw_units, std::max(1024.0, 32.0 * (double)nq));
+    const double target_units = bp->orw ? orw_scaled : scaled_units;
     double unit_cost = std::max(1.0, total_cost / (wave_units ? target_units : 3072.0));
     if (wave_units) {
         /* the floor of g_min units per query (the LDS table bounds a unit's stripes) eats part of the budget: raise the
@@ -915,6 +937,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     uint32_t g_most = 0;
     for (size_t i = 0; i + 1 < bp->goff.size(); ++i) g_most = std::max(g_most, bp->goff[i + 1] - bp->goff[i]);
     const size_t smem = bp->andw ? xgm_andw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group, bp->phrase, bp->sided == 2)
+                        : bp->orw2 ? xgm_orw2_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->stripes_per_group, bp->orw2 == 2)
                         : bp->orw ? xgm_orw_smem_bytes(idx->hdr.stripe_bits, bp->tab_terms, bp->cap, bp->wide, bp->stripes_per_group)
                                  : xgm_match_smem_bytes(idx->hdr.stripe_bits - bp->sub_bits, bp->tab_terms, bp->phrase, bp->cap, bp->wide, bp->stripes_per_group);
     if (smem > 160u * 1024u) return XGM_UNSUPPORTED;
@@ -1021,7 +1044,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
-    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0; L.orw2 = bp.orw2; L.or_flat = bp.or_flat;
     L.tally = idx->tally;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;
@@ -1037,7 +1060,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
-    idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw || (bp.andw && bp.phrase)) {
         if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
@@ -1089,6 +1112,9 @@ extern "C" int xgm_debug_host_ns(uint64_t* out4) {      /* (u64[8]) */
  * (Xapiand's HTTP threads issue whatever the clients send): run_batch cuts it into one launch per class present instead
  * of sending the whole batch to the slowest common denominator. */
 enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_OR, XGM_CLS_OTHER, XGM_CLS_BIGK, XGM_CLS_DENSE_AND, XGM_CLS_DENSE_PHRASE,
+       XGM_CLS_OR2,                              /* disjunctions for xgm_orw2_kernel (or2_kind): ONE launch — its flat-array instantiation takes the queries whose
+                                                    every term has a container too (measured, round 5: a launch per kind cost 3.7 ms per 256-query batch against
+                                                    2.0 for the old kernel alone: three tails, three sets of unit prologues) */
        XGM_CLS_COUNT };
 
 /* xgm_dense_kernel's queries (xgm_dense_and.hip): a conjunction / FILTER — or a positional query that prunes by weight — of 2 to 4
@@ -1141,6 +1167,23 @@ static bool flat_kind(const xgm_index* idx, const xgm_query& q) {
     return true;
 }
 
+/* A disjunction xgm_orw2_kernel takes (xgm_or.hip): <= 8 terms, first + maxitems <= 192, every term of the shard with a one-byte wdf and either a
+ * probe container (→ 1 when all have one) or a flat posting array (→ 2; at most two such terms per query).  0: xgm_orw_kernel. */
+static int or2_kind(const xgm_index* idx, const xgm_query& q) {
+    if (q.op != XGM_OP_OR || q.n_terms == 0 || q.n_terms > 8u || (uint64_t)q.first + q.maxitems > 192u || !xgm_orw2_enabled()) return 0;
+    if (!idx->view.n_dense || !idx->dense_min_df) return 0;
+    uint32_t flat = 0;
+    for (uint32_t t = 0; t < q.n_terms; ++t) {
+        const uint32_t id = q.terms[t].term_id;
+        if (id == UINT32_MAX) continue;
+        if (idx->term_wdfub[id] > 254u) return 0;
+        if ((uint64_t)idx->term_df[id] >= idx->dense_min_df) continue;
+        if (!idx->view.flat_off || idx->flat_postings >= 0xFFFFFFFFull) return 0;
+        if (++flat > 2u) return 0;
+    }
+    return flat ? 2 : 1;
+}
+
 static int classify_query(const xgm_index* idx, const xgm_query& q) {
     const uint32_t T = q.n_terms;
     if (const int dk = dense_kind(idx, q)) return dk == 2 ? XGM_CLS_DENSE_PHRASE : XGM_CLS_DENSE_AND;
@@ -1149,7 +1192,7 @@ static int classify_query(const xgm_index* idx, const xgm_query& q) {
     if (q.op != XGM_OP_OR && q.first + q.maxitems > 192u) return XGM_CLS_BIGK;
     const uint32_t prefix = q.req_mask && !(q.req_mask & (q.req_mask + 1u));            /* required terms = plan positions [0, n_req) */
     switch (q.op) {
-    case XGM_OP_OR: return XGM_CLS_OR;
+    case XGM_OP_OR: return or2_kind(idx, q) ? XGM_CLS_OR2 : XGM_CLS_OR;
     case XGM_OP_PHRASE:
     case XGM_OP_NEAR: return (q.phrase_active && T >= 2u) ? XGM_CLS_PHRASE : XGM_CLS_OTHER;
     case XGM_OP_AND:
@@ -1698,7 +1741,7 @@ extern "C" int xgm_search_replay(xgm_index* idx, const xgm_query* q, uint32_t mo
     if (n == 0) return XGM_OK;
     xgm_hit* d_page = (xgm_hit*)d_ext;
     xgm_replay_out* d_out = (xgm_replay_out*)(d_ext + b_hits);
-    if ((rc = xgm_launch_replay(d_list, n, k, q->check_at_least, mode == XGM_REPLAY_FROZEN_WEIGHT, d_page, d_out, sc->stream))) return rc;
+    if ((rc = xgm_launch_replay(d_list, n, k, q->check_at_least, mode == XGM_REPLAY_FROZEN_WEIGHT, m, d_page, d_out, sc->stream))) return rc;
     if ((rc = grow_pinned(&sc->h_down, &sc->cap_down, ext))) return rc;
     HIP_TRY(hipMemcpyAsync(sc->h_down, d_ext, ext, hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
@@ -2470,7 +2513,7 @@ extern "C" int64_t xgm_debug_plan_batch(const xgm_index* idx, const xgm_query* q
     BatchPlan bp;
     int rc = plan_batch(idx, qs, nq, dq.data(), kq.data(), mp.data(), &bp);
     if (rc) return rc;
-    snprintf(kernel, 32, "%s%s", bp.andw ? "xgm_andw_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel",
+    snprintf(kernel, 32, "%s%s", bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel",
              bp.andw && bp.phrase ? ":phrase" : bp.andw && bp.sided == 2 ? ":sided2" : bp.andw && bp.sided == 1 ? ":sided1" : "");
     for (uint64_t i = 0; i < bp.work.size() && i < cap; ++i) {
         units[4 * i] = bp.work[i].qi; units[4 * i + 1] = bp.work[i].s_begin; units[4 * i + 2] = bp.work[i].s_end; units[4 * i + 3] = bp.work[i].slot;

@@ -21,6 +21,8 @@ struct xgm_match_launch {
     bool phrase, wide;                /* kernel variant: positional tables / 16-bit wdf tables    */
     bool tally = false;               /* wave kernels: also fill the traffic tallies of xgm_group_hdr (measurement)  */
     int sided = 0;                    /* conjunction batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
+    bool or_flat = false;             /* disjunction batch whose every term without a container has a flat posting array: xgm_orw_kernel<…, FLAT> */
+    int orw2 = 0;                     /* disjunction batch for xgm_orw2_kernel: 1 = every term has a container, 2 = up to two terms per query come from flat arrays */
     uint32_t* hist = nullptr;         /* device, [nq][XGM_OR_HIST] zeroed: the query-wide weight histogram of xgm_orw_kernel and of the
                                          positional instantiation of xgm_andw_kernel (units of one query share their k-th weight bound) */
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
@@ -52,8 +54,9 @@ typedef struct {
     double frozen_weight;
     uint32_t max_weight_subqs, n_hits, frozen, reserved;
 } xgm_replay_out;
-int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, xgm_hit* out_hits,
-                      xgm_replay_out* out, hipStream_t stream);
+int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, uint64_t total_matches,
+                      xgm_hit* out_hits, xgm_replay_out* out, hipStream_t stream);
+/* (total_matches: the matching documents among the n entries — frozen mode stops walking once the rest of the loop can only count) */
 /* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
  *  column's ordinals or NULL, cmax = collapse_max) */
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
@@ -73,6 +76,9 @@ uint32_t xgm_dense_max_stripes();
 int xgm_launch_dense(const xgm_match_launch& L, hipStream_t stream);
 /* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
+/* ... xgm_orw2_kernel (round 5: <= 8 terms with containers or flat arrays, one-byte wdf; three / four waves per SIMD) */
+size_t xgm_orw2_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, uint32_t spg, bool sparse);
+bool xgm_orw2_enabled();
 int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream);
 int xgm_launch_merge(const xgm_cand* cand, const xgm_group_hdr* ghdr, const uint32_t* goff, uint32_t k_stride_in,
                      const uint32_t* kq, uint32_t nq, uint32_t cap, uint32_t k_stride_out, xgm_hit* hits,

@@ -149,7 +149,11 @@ __device__ __forceinline__ uint32_t orw_bfi(uint32_t mask, uint32_t a, uint32_t 
     return (mask & a) | (~mask & b);
 }
 
-template <typename TabT, bool TALLY>
+/* FLAT (round 5): every term without a container is read from its flat posting array (docids + one wdf byte, decoded once when the index was
+ * opened: xgm_dense.hip) — a cursor per term, 64 postings per coalesced load — instead of decoding its blocks twice per stripe (once for the
+ * bitmaps, once more for the candidates' wdf): no run table, no block headers, no payload staging, no unpack.  plan_batch selects the
+ * instantiation when every such term of the batch has an array (XGM_NO_OR_FLAT=1: A/B switch, the variant tests). */
+template <typename TabT, bool TALLY, bool FLAT>
 __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -213,12 +217,14 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     uint64_t tbase_reg = 0;
     uint32_t dense_reg = kNoDense;
     bool present_reg = false;
+    uint32_t fl_cur = 0, fl_end = 0, fl_c0 = 0, fl_n = 0;           /* FLAT, lane t: term t's cursor into flat_did / end of its slice; this stripe's first posting and count */
     if (!empty && lane < T) {
         const uint32_t id = q.term_id[lane];
         if (id != 0xFFFFFFFFu) {
             present_reg = true;
             tbase_reg = seg.term_word[id];
             if (sizeof(TabT) == 1 && seg.dense_id) dense_reg = seg.dense_id[id];
+            if (FLAT && dense_reg == kNoDense) { fl_cur = (uint32_t)seg.flat_off[id]; fl_end = (uint32_t)seg.flat_off[id + 1]; }
         }
     }
     const uint64_t present_mask = __ballot(present_reg);
@@ -267,8 +273,19 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         if (sbk >= 1) seed_bits = (uint64_t)(sbk > (int)XGM_OR_HIST - 1 ? (uint32_t)hbase + XGM_OR_HIST - 1u : sb_lo) << kHistShift;
     }
 
+    if (FLAT) {
+        /* the first posting at or after the unit's first docid: a 64-ary search of the term's slice, once per unit */
+        for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+            const uint32_t lo = rl32(fl_cur, t), hi = rl32(fl_end, t);
+            const uint32_t c = wave_lower_bound(seg.flat_did + lo, 0u, hi - lo, s_begin << SB, lane);
+            if (lane == t) fl_cur = lo + c;
+            if (TALLY) { cn_aux += 64u; }
+        }
+    }
+    const uint32_t fl_start = fl_cur;                              /* (the repair pass walks the slices again) */
     /* block ranges of every block-decoded term inside the unit's docid range -> run table */
-    for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
+    for (uint64_t sm = FLAT ? 0ull : sparse_mask; sm; sm &= sm - 1u) {
         const uint32_t t = (uint32_t)__builtin_ctzll(sm);
         const uint32_t id = q.term_id[t];
         const uint32_t b0 = (uint32_t)seg.term_blk[id], b1 = (uint32_t)seg.term_blk[id + 1];
@@ -291,14 +308,14 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     uint32_t sp_t[kOrwRegSparse];
     uint32_t n_sp = 0;
     {
-        uint64_t sm = sparse_mask;
+        uint64_t sm = FLAT ? 0ull : sparse_mask;
 #pragma unroll
         for (uint32_t u = 0; u < kOrwRegSparse; ++u) {
             sp_t[u] = 0;
             if (sm) { sp_t[u] = (uint32_t)__builtin_ctzll(sm); sm &= sm - 1u; n_sp = u + 1u; }
         }
     }
-    uint64_t slow_sparse_mask = sparse_mask;                       /* block-decoded terms beyond the pipelined ones */
+    uint64_t slow_sparse_mask = FLAT ? 0ull : sparse_mask;         /* block-decoded terms beyond the pipelined ones */
     for (uint32_t u = 0; u < n_sp; ++u) slow_sparse_mask &= slow_sparse_mask - 1u;
 
     uint32_t tkn = 0;                                              /* wave-uniform top-k state */
@@ -574,10 +591,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             if (th_now >= seed_bits) break;
             fix = true;
             quantise(seed_bits, essA_mask, qA2_reg, qA1_reg);
+            if (FLAT) fl_cur = fl_start;
         }
 
         auto next_active = [&](uint32_t from) {
-            if (dense_mask) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere */
+            if (dense_mask || FLAT) return from < n_local ? from : n_local;    /* a dense term is (almost) everywhere (FLAT without one: every stripe is looked at — a few instructions where no term has a posting) */
             uint32_t x = from;
             for (; x < n_local; ++x) {
                 bool any = false;
@@ -772,7 +790,29 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         if (w < NW) { bm_ess[w] = 0; bm_ne[w] = 0; }
                     }
                     wave_lds_fence();
-                    const uint32_t rb0 = rs[t * SPG + sl], nb = re[t * SPG + sl] - rb0;
+                    if (FLAT) {
+                        /* this stripe's postings of the term, 64 per coalesced load, straight into the bitmap pair */
+                        uint32_t c = rl32(fl_cur, t);
+                        const uint32_t e_ = rl32(fl_end, t), stripe_end = stripe_base + W, c0 = c;
+                        while (true) {
+                            const uint32_t g = c + lane;
+                            const bool in_arr = g < e_;
+                            const uint32_t d = in_arr ? seg.flat_did[g] : 0xFFFFFFFFu;
+                            const uint32_t wf = in_arr ? (uint32_t)seg.flat_wdf[g] : 0u;
+                            if (TALLY) { cn_blkw += 80u; }                            /* (64 docids + 64 wdf bytes, in 4-byte words) */
+                            const bool in = in_arr && d < stripe_end;                 /* (the cursor sits at the stripe's first posting) */
+                            if (in) {
+                                const uint32_t s_ = d - stripe_base;
+                                atomicOr(&bm_ess[s_ >> 5], 1u << (s_ & 31u));
+                                if (wf >= 2u) atomicOr(&bm_ne[s_ >> 5], 1u << (s_ & 31u));
+                            }
+                            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                            c += n_in;
+                            if (n_in < 64u) break;
+                        }
+                        if (lane == t) { fl_cur = c; fl_c0 = c0; fl_n = c - c0; }
+                    }
+                    const uint32_t rb0 = FLAT ? 0u : rs[t * SPG + sl], nb = FLAT ? 0u : re[t * SPG + sl] - rb0;
                     /* the pipelined terms' headers are already in registers (lane j = block j of the run) */
                     int pu = -1;
 #pragma unroll
@@ -934,7 +974,27 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     const unsigned long long mm = (hi >= 63u ? ~0ull : ((1ull << (hi + 1u)) - 1ull)) & ~((1ull << lo) - 1ull);
                     return (coarse & mm) != 0ull;
                 };
-                if (sparse_mask) {
+                if (FLAT) {
+                    /* wdf of the flat terms for this chunk's candidates: the stripe's slice of the array once more (an L2 hit), scattered to
+                     * the candidates' ordinals through the candidate bitmap and rankw — no decode */
+                    for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
+                        const uint32_t t = (uint32_t)__builtin_ctzll(sm);
+                        const uint32_t c0 = rl32(fl_c0, t), nn = rl32(fl_n, t);
+                        TabT* row = c_w + (size_t)t * kOrwCand;
+                        for (uint32_t done = 0; done < nn; done += 64u) {
+                            const bool v = done + lane < nn;
+                            const uint32_t d = v ? seg.flat_did[c0 + done + lane] : 0u;
+                            const uint32_t wf = v ? (uint32_t)seg.flat_wdf[c0 + done + lane] : 0u;
+                            if (v) {
+                                const uint32_t s_ = d - stripe_base, wd = s_ >> 5, bit = s_ & 31u;
+                                if (wd >= wlo && wd < whi) {
+                                    const uint32_t bm = bm_ess[wd];
+                                    if ((bm >> bit) & 1u) row[(uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (TabT)(wf + 1u);
+                                }
+                            }
+                        }
+                    }
+                } else if (sparse_mask) {
                     uint64_t bmask[kOrwRegSparse];
 #pragma unroll
                     for (uint32_t u = 0; u < kOrwRegSparse; ++u) bmask[u] = __ballot(lane < cnb[u] && bucket_need(cf[u], cn[u]));
@@ -1045,6 +1105,581 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 #undef XGM_SU
 }
 
+
+/* ================================================================================================================================
+ * xgm_orw2_kernel (round 5): the disjunction kernel written again for the shape that is nearly all of C3 — <= 8 terms, every one
+ * with a probe container or (<= 2 of them) a flat posting array, one-byte wdf, k <= 192 — and for OCCUPANCY.  xgm_orw_kernel holds
+ * ~250 VGPRs and 15 KB of LDS per wave: two waves per SIMD, and its stripe loop is a chain of dependent round trips (rounds 2-4:
+ * 0.22 of HBM peak, issue slots half empty; forcing three waves onto it spills ~90 registers and loses).  What held the registers:
+ * a lane owned FOUR words of every bitmap (5 terms x 2 planes x 4 words in flight, a 6-plane bit-sliced sum x 4 words kept across the
+ * block decode of the terms without containers), the block headers of two such terms software-pipelined in registers, the decode's
+ * own temporaries.  Here:
+ *   - a stripe is taken in word-major PASSES: pass i = words i * 64 + lane.  A lane holds ONE word per term and plane, the bound sum's
+ *     six planes are transient per pass (S0..S5: six registers, not twenty-four), candidates come out in docid order pass by pass;
+ *   - terms without containers are read from their FLAT arrays (round 4: docids + one wdf byte, decoded once when the index was
+ *     opened): a cursor per term, 64 postings per coalesced load, bits set in a per-term LDS bitmap pair that then joins the passes
+ *     like a container's pair; the candidates' wdf of such a term is scattered from the same registers — no block headers, no payload,
+ *     no unpack, no second decode;
+ *   - LDS per wave: 6 KB (all terms with containers) or 12 KB: four resp. three waves per SIMD.
+ * Semantics — exact match count, safe pruning by quantised bound sums against the planner's guess and the query-wide histogram, the
+ * repair pass when the guess was too high, BM25 in the reference's operation order, top-k — are xgm_orw_kernel's, line for line where
+ * the structure allows; both kernels are checked against the oracle by the same tests (XGM_NO_ORW2=1 selects the old one). */
+#ifndef XGM_ORW2_WAVES_DENSE
+#define XGM_ORW2_WAVES_DENSE 3      /* waves per SIMD the all-container instantiation is compiled for (A/B: tools/ab_build.sh) */
+#endif
+#ifndef XGM_ORW2_WAVES_SPARSE
+#define XGM_ORW2_WAVES_SPARSE 3
+#endif
+constexpr uint32_t kO2Cand = 256u;          /* candidates the queue holds */
+constexpr uint32_t kO2MaxT = 8u;
+constexpr uint32_t kO2Sparse = 2u;          /* terms read from flat arrays (LDS bitmap pairs) */
+
+__host__ __device__ inline size_t orw2_wave_bytes(uint32_t W, uint32_t T, uint32_t cap, uint32_t spg, bool sparse) {
+    size_t off = 0;
+    off += (size_t)cap * 8;                                    /* tk_w */
+    off += (size_t)cap * 4;                                    /* tk_d */
+    off += (size_t)XGM_OR_HIST * 4;                            /* lh */
+    off += (size_t)T * spg * 4;                                /* dir_tab */
+    off += (size_t)kO2Cand * 4;                                /* c_did */
+    if (sparse) {
+        off += (size_t)kO2Sparse * (W / 32u) * 4 * 2;          /* bmS: per flat term its documents / those with wdf >= 2 */
+        off += (size_t)(W / 32u) * 4;                          /* bm_e: the stripe's candidates (the scatter looks them up) */
+        off += (size_t)(W / 32u) * 2;                          /* rankw (u16) */
+        off += (size_t)kO2Sparse * kO2Cand;                    /* c_w (u8): wdf + 1 of the queued candidates per flat term */
+    }
+    off += (size_t)cap;                                        /* tk_m (u8) */
+    return (off + 15) & ~(size_t)15;
+}
+
+template <bool SPARSE, bool TALLY>
+__global__ __launch_bounds__(XGM_WG, SPARSE ? XGM_ORW2_WAVES_SPARSE : XGM_ORW2_WAVES_DENSE) void xgm_orw2_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                          const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
+                                                          uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                          uint32_t* __restrict__ hist_all,
+                                                          xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
+    if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
+    const xgm_work wk = work[unit];
+    const xgm_dev_query& q = queries[wk.qi];
+    const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
+    const uint32_t T = q.n_terms, k = q.k;
+    const unsigned long long t_unit_start = __builtin_readcyclecounter();
+    uint32_t cn_bmpw = 0, cn_probe_raw = 0, cn_dl_raw = 0, cn_aux = 0, cn_flat = 0;      /* traffic tallies (wave-uniform) */
+    const uint32_t* ipa32 = reinterpret_cast<const uint32_t*>(q.ip_a);
+    const uint32_t* ipb32 = reinterpret_cast<const uint32_t*>(q.ip_b);
+    const uint64_t prog_a = ((uint64_t)rfl32(ipa32[1]) << 32) | rfl32(ipa32[0]);
+    const uint64_t prog_b = ((uint64_t)rfl32(ipb32[1]) << 32) | rfl32(ipb32[0]);
+    const uint32_t prog_root = __builtin_amdgcn_readfirstlane(q.ip_root);
+
+    unsigned char* base = smem + (size_t)wave * orw2_wave_bytes(W, tab_terms, cap, SPG, SPARSE);
+    size_t off = 0;
+    uint64_t* tk_w = reinterpret_cast<uint64_t*>(base + off); off += (size_t)cap * 8;
+    uint32_t* tk_d = reinterpret_cast<uint32_t*>(base + off); off += (size_t)cap * 4;
+    uint32_t* lh = reinterpret_cast<uint32_t*>(base + off); off += (size_t)XGM_OR_HIST * 4;
+    uint32_t* dir_tab = reinterpret_cast<uint32_t*>(base + off); off += (size_t)tab_terms * SPG * 4;
+    uint32_t* c_did = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kO2Cand * 4;
+    uint32_t* bmS = nullptr; uint32_t* bm_e = nullptr; uint16_t* rankw = nullptr; uint8_t* c_w = nullptr;
+    if (SPARSE) {
+        bmS = reinterpret_cast<uint32_t*>(base + off); off += (size_t)kO2Sparse * NW * 4 * 2;
+        bm_e = reinterpret_cast<uint32_t*>(base + off); off += (size_t)NW * 4;
+        rankw = reinterpret_cast<uint16_t*>(base + off); off += (size_t)NW * 2;
+        c_w = reinterpret_cast<uint8_t*>(base + off); off += (size_t)kO2Sparse * kO2Cand;
+    }
+    uint8_t* tk_m = reinterpret_cast<uint8_t*>(base + off);
+
+    const uint32_t s_begin = wk.s_begin, s_end = wk.s_end;
+    const bool empty = (q.flags & XGM_QF_EMPTY) || s_begin >= s_end || k == 0;
+    for (uint32_t i = lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
+    for (uint32_t i = lane; i < XGM_OR_HIST; i += 64u) lh[i] = 0;
+    if (SPARSE) for (uint32_t i = lane; i < kO2Sparse * kO2Cand; i += 64u) c_w[i] = 0;
+    wave_lds_fence();
+
+    /* lane t: term t's container index, or the slice of its flat array that lies in the unit's docid range */
+    uint32_t dense_reg = kNoDense;
+    bool present_reg = false;
+    uint32_t fl_cur = 0, fl_end = 0;                                /* (indices into flat_did: plan_batch sends queries here only while the arrays hold < 2^32 postings) */
+    if (!empty && lane < T) {
+        const uint32_t id = q.term_id[lane];
+        if (id != 0xFFFFFFFFu) {
+            present_reg = true;
+            if (seg.dense_id) dense_reg = seg.dense_id[id];
+            if (dense_reg == kNoDense && seg.flat_off) { fl_cur = (uint32_t)seg.flat_off[id]; fl_end = (uint32_t)seg.flat_off[id + 1]; }
+        }
+    }
+    const uint64_t present_mask = __ballot(present_reg);
+    const uint64_t dense_mask = __ballot(present_reg && dense_reg != kNoDense);
+    const uint64_t sparse_mask = present_mask & ~dense_mask;
+    /* the flat terms (plan_batch sent the query here only if there are <= kO2Sparse of them): slot u = term sp_t[u] */
+    uint32_t sp_t[kO2Sparse], n_sp = 0;
+    {
+        uint64_t sm = sparse_mask;
+#pragma unroll
+        for (uint32_t u = 0; u < kO2Sparse; ++u) { sp_t[u] = 0; if (sm) { sp_t[u] = (uint32_t)__builtin_ctzll(sm); sm &= sm - 1u; n_sp = u + 1u; } }
+    }
+    if (SPARSE) {
+        /* the first posting at or after the unit's first docid: a 64-ary search of the term's slice, once per unit */
+        for (uint32_t u = 0; u < n_sp; ++u) {
+            const uint32_t lo = rl32(fl_cur, sp_t[u]), hi = rl32(fl_end, sp_t[u]);
+            const uint32_t len = hi - lo;
+            const uint32_t c = wave_lower_bound(seg.flat_did + lo, 0u, len, s_begin << SB, lane);
+            if (lane == sp_t[u]) fl_cur = lo + c;
+            if (TALLY) { cn_aux += 64u; }
+        }
+    }
+
+    /* MaxScore order (ascending weight bound), prefix sums, quantisation: as xgm_orw_kernel */
+    double prefix_reg = 0.0, ub_reg = 0.0, ub1_reg = 0.0;
+    uint32_t rank_reg = 0;
+    if (lane < T) {
+        const double my = q.ub[lane];
+        ub_reg = my;
+        ub1_reg = (dense_reg != kNoDense && !seg.dense_plane) ? my : q.ub1[lane];
+        for (uint32_t j = 0; j < T; ++j) {
+            const double uj = q.ub[j];
+            if (uj < my || (uj == my && j <= lane)) { prefix_reg += uj; ++rank_reg; }
+        }
+        prefix_reg *= 1.000000001;
+    }
+    /* every present term in ascending order of its bound, 4 bits each: the order the bound sum adds them in */
+    uint64_t term_ord = 0;
+    uint32_t n_ord = 0;
+    for (uint32_t p = 1; p <= T; ++p) {
+        const uint64_t m = __ballot(lane < T && rank_reg == p);
+        if (m) {
+            const uint32_t t = (uint32_t)__builtin_ctzll(m);
+            if ((present_mask >> t) & 1ull) { term_ord |= (uint64_t)t << (4u * n_ord); ++n_ord; }
+        }
+    }
+    const uint64_t top_mask = __ballot(present_reg && rank_reg == T);
+    const uint32_t r_term = top_mask ? (uint32_t)__builtin_ctzll(top_mask) : 0u;
+    const uint64_t mp_bits = top_mask ? rl64((uint64_t)__double_as_longlong(prefix_reg), r_term) : 0ull;
+    const int hbase = (int)(mp_bits >> kHistShift) - (int)(XGM_OR_HIST - 1u);
+    const bool prune = top_mask != 0ull && hbase > 0 && !empty;
+    uint32_t* hist_g = hist_all + (size_t)wk.qi * XGM_OR_HIST;
+    uint64_t seed_bits = 0;
+    if (prune) {
+        const uint64_t sb = (uint64_t)__double_as_longlong(q.theta_seed) >> kHistShift;
+        const uint32_t sb_lo = __builtin_amdgcn_readfirstlane((uint32_t)sb);
+        const int sbk = (int)sb_lo - hbase;
+        if (sbk >= 1) seed_bits = (uint64_t)(sbk > (int)XGM_OR_HIST - 1 ? (uint32_t)hbase + XGM_OR_HIST - 1u : sb_lo) << kHistShift;
+    }
+
+    uint32_t tkn = 0;
+    bool theta_valid = false;
+    uint64_t theta_w = 0;
+    uint32_t theta_d = 0;
+    uint64_t theta_glob = 0;
+    uint32_t matches32 = 0;                                         /* per lane: a unit's stripes x 1 word x 4 passes x 32 documents < 2^32 */
+    uint32_t n_scored = 0;
+    bool lh_dirty = false;
+    const uint32_t n_local = empty ? 0u : s_end - s_begin;
+
+    for (uint64_t dm = dense_mask; dm; dm &= dm - 1u) {
+        const uint32_t t = (uint32_t)__builtin_ctzll(dm);
+        const uint32_t dr = rl32(dense_reg, t);
+        if (TALLY) { cn_aux += n_local; }
+        for (uint32_t i = lane; i < n_local; i += 64u) dir_tab[t * SPG + i] = seg.dense_dir[(size_t)dr * seg.n_stripes + (s_begin + i)];
+    }
+    wave_lds_fence();
+
+    bool fix = false;
+    uint32_t qA2_reg = 0, qA1_reg = 0;
+
+    /* one round of gathers a round ahead of its use: the document length and the container terms' wdf bytes */
+    uint32_t pf_dl = 1u, pf_pb[kO2MaxT] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto prefetch_round = [&](uint32_t i0, uint32_t n_c) {
+        const uint32_t o = i0 + lane;
+        const bool valid = o < n_c;
+        const uint32_t cd = valid ? c_did[o] : 0u;
+        const uint32_t slot = cd & (W - 1u), csl = valid ? (cd >> SB) - s_begin : 0u;
+        pf_dl = valid ? seg.doclen[cd] : 1u;
+        if (TALLY) { const uint32_t nv = n_c - i0 < 64u ? n_c - i0 : 64u; cn_dl_raw += nv; cn_probe_raw += nv * (uint32_t)__popcll(dense_mask); }
+#pragma unroll
+        for (uint32_t t = 0; t < kO2MaxT; ++t) {
+            pf_pb[t] = 0;
+            if ((dense_mask >> t) & 1ull) {
+                const uint32_t oo = valid ? dir_tab[t * SPG + csl] : 0u;
+                if (oo) pf_pb[t] = seg.dense_data[(size_t)oo * 16 + (size_t)NW * 4 + slot];
+            }
+        }
+    };
+
+    auto score_candidates = [&](uint32_t n_c) {
+        n_scored += n_c;
+        for (uint32_t i0 = 0; i0 < n_c; i0 += 64u) {
+            if (tkn + 64u > cap) {
+                orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
+                tkn = tkn < k ? tkn : k;
+                if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
+                for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
+                wave_lds_fence();
+            }
+            const uint32_t o = i0 + lane;
+            const bool valid = o < n_c;
+            const uint32_t did = valid ? c_did[o] : 0u;
+            const uint32_t dlen = pf_dl;
+            uint32_t pb[kO2MaxT];
+#pragma unroll
+            for (uint32_t t = 0; t < kO2MaxT; ++t) pb[t] = pf_pb[t];
+#ifndef XGM_ORW2_NO_PREFETCH
+            if (i0 + 64u < n_c) prefetch_round(i0 + 64u, n_c);
+#endif
+            /* BM25Weight::get_sumpart, bm25weight.cc:170-181 — same operations, same order */
+            const double len = (double)dlen;
+            double normlen = len * q.len_factor;
+            normlen = normlen > q.min_normlen ? normlen : q.min_normlen;
+            const double denom_len = q.k1 * (normlen * q.b + (1.0 - q.b));
+            uint32_t subqs = 0, sumA = 0;
+            orw_d8 v;
+#pragma unroll
+            for (uint32_t g = 0; g < 2u; ++g) {
+                uint32_t ev[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t t = g * 4u + u;
+                    ev[u] = pb[t];
+                    if (SPARSE) {
+#pragma unroll
+                        for (uint32_t x = 0; x < kO2Sparse; ++x)
+                            if (x < n_sp && sp_t[x] == t && valid) ev[u] = (uint32_t)c_w[x * kO2Cand + o];
+                    }
+                }
+                double wt[4] = {-0.0, -0.0, -0.0, -0.0};
+                if (g * 4u < T && __ballot((ev[0] | ev[1] | ev[2] | ev[3]) != 0u)) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) {
+                        const double wdf = (double)(ev[u] - 1u);
+                        const double denom = denom_len + wdf;
+                        const double x = q.termweight[g * 4u + u] * (wdf / denom);
+                        wt[u] = ev[u] ? x : -0.0;
+                        subqs += ev[u] ? 1u : 0u;
+                        if (fix && g * 4u + u < T) {
+                            const uint32_t t = g * 4u + u;
+                            const uint32_t a2_ = rl32(qA2_reg, t), a1_ = rl32(qA1_reg, t);
+                            sumA += ev[u] ? (ev[u] >= 3u ? a2_ : a1_) : 0u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) v[g * 4u + u] = wt[u];
+            }
+            if (SPARSE) {
+#pragma unroll
+                for (uint32_t x = 0; x < kO2Sparse; ++x) if (x < n_sp && valid) c_w[x * kO2Cand + o] = 0;       /* the queue slot is free again */
+            }
+            for (uint32_t j = 0; j + 1u < T; ++j) {
+                const uint32_t a = (uint32_t)(prog_a >> (8u * j)) & 7u, b = (uint32_t)(prog_b >> (8u * j)) & 7u;
+                const double x = v[a] + v[b];
+                v[a] = x;
+            }
+            const double weight = v[prog_root & 7u];
+            const uint64_t wb = (uint64_t)__double_as_longlong(weight);
+            const bool in_first = fix && sumA >= kQ;
+            const bool live = valid && subqs != 0u && wb >= theta_glob && !in_first;
+            if (prune && live) {
+                int b = (int)(wb >> kHistShift) - hbase;
+                b = b < 0 ? 0 : (b > (int)XGM_OR_HIST - 1 ? (int)XGM_OR_HIST - 1 : b);
+                atomicAdd(&lh[b], 1u);
+            }
+            if (prune && __ballot(live)) lh_dirty = true;
+            const bool take = live && (!theta_valid || cand_before(wb, did, theta_w, theta_d));
+            const uint64_t tm = __ballot(take);
+            if (take) { const uint32_t p = tkn + mbcnt(tm); tk_w[p] = wb; tk_d[p] = did; tk_m[p] = (uint8_t)subqs; }
+            tkn += (uint32_t)__popcll(tm);
+#ifdef XGM_ORW2_NO_PREFETCH
+            if (i0 + 64u < n_c) prefetch_round(i0 + 64u, n_c);
+#endif
+        }
+    };
+    uint32_t qn = 0;
+    auto flush_queue = [&]() {
+        if (qn == 0u) return;
+        wave_lds_fence();
+        prefetch_round(0u, qn);
+        score_candidates(qn);
+        wave_lds_fence();
+        qn = 0;
+    };
+
+    uint64_t qz_bits = 0, qz_ess = 0;
+    uint32_t qz_q2 = 0, qz_q1 = 0;
+    auto quantise = [&](uint64_t th_bits, uint64_t& ess, uint32_t& q2, uint32_t& q1) {
+        if (th_bits == qz_bits) { ess = qz_ess; q2 = qz_q2; q1 = qz_q1; return; }
+        const double th = __longlong_as_double((long long)th_bits);
+        ess = __ballot(present_reg && !(prefix_reg < th));
+        const double r2 = ub_reg * (double)kQ / th, r1 = ub1_reg * (double)kQ / th;
+        q2 = r2 >= (double)kQ ? kQ : (uint32_t)r2 + 1u;
+        q1 = r1 >= (double)kQ ? kQ : (uint32_t)r1 + 1u;
+        qz_bits = th_bits; qz_ess = ess; qz_q2 = q2; qz_q1 = q1;
+    };
+    auto hist_bound = [&](const uint32_t* hc) {
+        const uint32_t s4 = hc[0] + hc[1] + hc[2] + hc[3];
+        const uint32_t P = wave_incl_scan(s4);
+        const uint32_t suf = __builtin_amdgcn_readlane(P, 63) - P + s4;
+        const uint64_t okm = __ballot(suf >= k);
+        if (okm) {
+            const uint32_t Lh = 63u - (uint32_t)__builtin_clzll(okm);
+            const uint32_t cum = __builtin_amdgcn_readlane(suf, Lh) - __builtin_amdgcn_readlane(s4, Lh);
+            uint32_t bsel = 4u * Lh;
+            const uint32_t c3 = __builtin_amdgcn_readlane(hc[3], Lh), c2 = __builtin_amdgcn_readlane(hc[2], Lh), c1 = __builtin_amdgcn_readlane(hc[1], Lh);
+            if (cum + c3 >= k) bsel = 4u * Lh + 3u;
+            else if (cum + c3 + c2 >= k) bsel = 4u * Lh + 2u;
+            else if (cum + c3 + c2 + c1 >= k) bsel = 4u * Lh + 1u;
+            if (bsel > 0u) {
+                const uint64_t tb = (uint64_t)((uint32_t)hbase + bsel) << kHistShift;
+                theta_glob = tb > theta_glob ? tb : theta_glob;
+            }
+        }
+    };
+    auto publish_hist = [&]() {
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const uint32_t vv = lh[lane * 4u + i];
+            if (vv) { atomicAdd(&hist_g[lane * 4u + i], vv); lh[lane * 4u + i] = 0; }
+        }
+        lh_dirty = false;
+        wave_lds_fence();
+    };
+
+    const uint32_t fl_start = fl_cur;                               /* (the repair pass walks the flat slices again) */
+    for (uint32_t pass = 0; pass < 2u; ++pass) {
+        if (pass == 1u) {
+            if (!seed_bits || empty) break;
+            if (lh_dirty) publish_hist();
+            uint32_t hc[4];
+            if (TALLY) { cn_aux += XGM_OR_HIST; }
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            hist_bound(hc);
+            const uint64_t th_now = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
+            if (th_now >= seed_bits) break;
+            fix = true;
+            uint64_t essA;
+            quantise(seed_bits, essA, qA2_reg, qA1_reg);
+            fl_cur = fl_start;
+        }
+        for (uint32_t sl = 0; sl < n_local; ++sl) {
+            const uint32_t stripe_base = (s_begin + sl) << SB;
+            /* ---- threshold ---- */
+            const bool have_th = seed_bits || theta_valid || theta_glob;
+            const bool look = prune && (fix || !have_th || (sl & 3u) == 0u);
+            /* ---- flat terms: this stripe's postings -> the term's LDS bitmap pair (kept in registers for the scatter) ---- */
+            uint32_t sp_did[kO2Sparse], sp_wdf[kO2Sparse], sp_n[kO2Sparse];
+            uint32_t sp_c0[kO2Sparse];
+#pragma unroll
+            for (uint32_t u = 0; u < kO2Sparse; ++u) { sp_did[u] = 0; sp_wdf[u] = 0; sp_n[u] = 0; sp_c0[u] = 0; }
+            if (SPARSE) {
+#pragma unroll
+                for (uint32_t u = 0; u < kO2Sparse; ++u) {
+                    if (u < n_sp) {
+                        uint32_t* bA = bmS + (size_t)u * NW * 2u;
+                        uint32_t* bB = bA + NW;
+                        for (uint32_t w = lane; w < NW; w += 64u) { bA[w] = 0; bB[w] = 0; }
+                        wave_lds_fence();
+                        uint32_t c = rl32(fl_cur, sp_t[u]);
+                        const uint32_t e = rl32(fl_end, sp_t[u]);
+                        sp_c0[u] = c;
+                        const uint32_t stripe_end = stripe_base + W;
+                        while (true) {
+                            const uint32_t g = c + lane;
+                            const bool in_arr = g < e;
+                            const uint32_t d = in_arr ? seg.flat_did[g] : 0xFFFFFFFFu;
+                            const uint32_t wf = in_arr ? (uint32_t)seg.flat_wdf[g] : 0u;
+                            if (TALLY) { cn_flat += 64u; }
+                            const bool in = in_arr && d < stripe_end;             /* (the cursor sits at the stripe's first posting: d >= stripe_base) */
+                            const uint32_t n_in = (uint32_t)__popcll(__ballot(in));
+                            if (in) {
+                                const uint32_t s = d - stripe_base;
+                                atomicOr(&bA[s >> 5], 1u << (s & 31u));
+                                if (wf >= 2u) atomicOr(&bB[s >> 5], 1u << (s & 31u));
+                            }
+                            if (sp_n[u] == 0u) { sp_did[u] = d; sp_wdf[u] = wf; }      /* (the stripe's first 64: what the scatter uses unless there are more) */
+                            sp_n[u] += n_in;
+                            c += n_in;
+                            if (n_in < 64u) break;
+                        }
+                        if (lane == sp_t[u]) fl_cur = c;
+                        wave_lds_fence();
+                    }
+                }
+            }
+            /* ---- this stripe's threshold, quantised bounds ---- */
+            uint64_t ess_mask = present_mask;
+            bool use_sum = false;
+            uint32_t q2_reg = kQ, q1_reg = kQ;
+            if (prune) {
+                if (look) {
+                    uint32_t hc[4];
+                    if (TALLY) { cn_aux += XGM_OR_HIST; }
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; ++i) hc[i] = __hip_atomic_load(&hist_g[lane * 4u + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hist_bound(hc);
+                }
+                uint64_t th_bits = theta_valid && theta_w > theta_glob ? theta_w : theta_glob;
+                if (fix && th_bits >= seed_bits) break;                      /* whatever is left was weighed by the first pass or cannot reach the top k */
+                if (!fix && seed_bits > th_bits) th_bits = seed_bits;
+                if (th_bits) { quantise(th_bits, ess_mask, q2_reg, q1_reg); use_sum = true; }
+            }
+            const bool want_planes = use_sum && seg.dense_plane != 0u;
+            const uint32_t hc_cur = (present_reg && dense_reg != kNoDense) ? dir_tab[lane * SPG + sl] : 0u;      /* lane t: container of term t in this stripe */
+
+            /* ---- the passes: word w = i * 64 + lane of every term's bitmap pair ---- */
+            for (uint32_t i = 0; i * 64u < NW; ++i) {
+                const uint32_t w = i * 64u + lane;
+                const bool wv = w < NW;
+                uint32_t xb[kO2MaxT], xp[kO2MaxT];
+#pragma unroll
+                for (uint32_t u = 0; u < kO2MaxT; ++u) {
+                    xb[u] = 0; xp[u] = 0;
+                    if (u < n_ord) {
+                        const uint32_t t = (uint32_t)(term_ord >> (4u * u)) & 15u;
+                        const uint32_t oo = rl32(hc_cur, t);
+                        if ((dense_mask >> t) & 1ull) {
+                            if (TALLY) { if (oo) cn_bmpw += (want_planes ? 2u : 1u) * (NW < 64u ? NW : 64u); }
+                            if (oo && wv) {
+                                xb[u] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo * 16)[w];
+                                if (want_planes) xp[u] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo * 16 + seg.dense_plane)[w];
+                            }
+                        } else if (SPARSE) {
+#pragma unroll
+                            for (uint32_t x = 0; x < kO2Sparse; ++x)
+                                if (x < n_sp && sp_t[x] == t && wv) { xb[u] = bmS[(size_t)x * NW * 2u + w]; xp[u] = bmS[(size_t)x * NW * 2u + NW + w]; }
+                        }
+                    }
+                }
+                /* union (exact match count) and the bit-sliced sum of the quantised bounds: six planes, transient per pass */
+                uint32_t a = 0, ovf = 0;
+                uint32_t S0 = 0, S1 = 0, S2 = 0, S3 = 0, S4 = 0, S5 = 0;
+                uint32_t max_sum = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < kO2MaxT; ++u) {
+                    if (u < n_ord) {
+                        a |= xb[u];
+                        if (use_sum) {
+                            const uint32_t t = (uint32_t)(term_ord >> (4u * u)) & 15u;
+                            uint32_t q1v = rl32(q1_reg, t), q2v = rl32(q2_reg, t);
+                            const bool sparse_t = SPARSE && !((dense_mask >> t) & 1ull);
+                            if (!want_planes && !sparse_t) q1v = q2v;                 /* no wdf >= 2 plane at hand: every document at the term's maximum */
+                            const uint32_t B = xb[u], P = xp[u] & xb[u], lo = B & ~P;
+                            /* documents of lo get q1v, those of P get q2v >= q1v */
+                            if (q1v >= kQ) { ovf |= B; continue; }
+                            uint32_t addlo = lo, addP = P, qlo = q1v, qP = q2v;
+                            if (q2v >= kQ) { ovf |= P; addP = 0; qP = 0; }
+                            if (q1v == q2v) { addlo = B; addP = 0; qP = 0; }
+                            const uint32_t qmax = qP > qlo ? qP : qlo;
+                            const uint32_t nm = max_sum + qmax;
+                            max_sum = nm < kQ ? nm : kQ;
+                            const uint32_t np = nm >= kQ ? 6u : 32u - (uint32_t)__builtin_clz(nm | 1u);
+                            uint32_t carry = 0;
+#define O2_PLANE(J, SJ)                                                                                                           \
+                            if (J < np) {                                                                                         \
+                                const uint32_t b1 = (qlo >> J) & 1u, b2 = (qP >> J) & 1u;                                         \
+                                const uint32_t ad = (b1 ? addlo : 0u) | (b2 ? addP : 0u);                                         \
+                                const uint32_t sj = SJ, xo = sj ^ ad;                                                             \
+                                SJ = xo ^ carry;                                                                                  \
+                                carry = orw_bfi(xo, carry, sj);                                                                   \
+                            }
+                            O2_PLANE(0u, S0) O2_PLANE(1u, S1) O2_PLANE(2u, S2) O2_PLANE(3u, S3) O2_PLANE(4u, S4) O2_PLANE(5u, S5)
+#undef O2_PLANE
+                            if (np == 6u) ovf |= carry;
+                        }
+                    }
+                }
+                (void)S5;
+                const uint32_t e = use_sum ? ovf : a;
+                if (!fix) matches32 += (uint32_t)__popc(a);
+                /* ---- candidates of this pass, in docid order, to the queue (chunks of lanes holding <= kO2Cand of them) ---- */
+                const uint32_t cnt = (uint32_t)__popc(e);
+                const uint32_t incl = wave_incl_scan(cnt);
+                const uint32_t n_total = __builtin_amdgcn_readlane(incl, 63);
+                if (SPARSE && wv) bm_e[w] = e;
+                for (uint32_t lane_lo = 0; lane_lo < 64u && n_total != 0u;) {
+                    const uint32_t ord_base = lane_lo ? __builtin_amdgcn_readlane(incl, lane_lo - 1u) : 0u;
+                    if (ord_base == n_total) break;
+                    const uint64_t fit = __ballot(incl - ord_base <= kO2Cand);
+                    const uint32_t lane_hi = 64u - (uint32_t)__builtin_clzll(fit);
+                    const uint32_t hi_incl = __builtin_amdgcn_readlane(incl, lane_hi - 1u);
+                    const uint32_t n_c = hi_incl - ord_base;
+                    const bool in_chunk = lane >= lane_lo && lane < lane_hi;
+                    const uint32_t wlo = i * 64u + lane_lo, whi = i * 64u + lane_hi;
+                    lane_lo = lane_hi;
+                    if (n_c == 0u) continue;
+                    if (qn + n_c > kO2Cand) flush_queue();
+                    const uint32_t qb = qn;
+                    if (in_chunk) {
+                        uint32_t o = qb + incl - cnt - ord_base;
+                        if (SPARSE && wv) rankw[w] = (uint16_t)o;
+                        uint32_t m = e;
+                        while (m) {
+                            const uint32_t bit = (uint32_t)__ffs(m) - 1u;
+                            c_did[o] = stripe_base + w * 32u + bit;
+                            m &= m - 1u;
+                            ++o;
+                        }
+                    }
+                    wave_lds_fence();
+                    if (SPARSE) {
+                        /* wdf of the flat terms for this chunk's candidates: from the registers the bitmaps were made of (a stripe with more
+                         * than 64 postings of the term: its flat slice once more) */
+#pragma unroll
+                        for (uint32_t u = 0; u < kO2Sparse; ++u) {
+                            if (u < n_sp && sp_n[u]) {
+                                uint32_t done = 0;
+                                const bool reload = sp_n[u] > 64u;
+                                while (done < sp_n[u]) {
+                                    uint32_t d = sp_did[u], wf = sp_wdf[u];
+                                    const uint32_t nb = sp_n[u] - done < 64u ? sp_n[u] - done : 64u;
+                                    if (reload) {
+                                        const uint32_t g = sp_c0[u] + done + lane;
+                                        d = lane < nb ? seg.flat_did[g] : 0xFFFFFFFFu;
+                                        wf = lane < nb ? (uint32_t)seg.flat_wdf[g] : 0u;
+                                    }
+                                    if (lane < nb) {
+                                        const uint32_t s = d - stripe_base, wd = s >> 5, bit = s & 31u;
+                                        if (wd >= wlo && wd < whi) {
+                                            const uint32_t bm = bm_e[wd];
+                                            if ((bm >> bit) & 1u) c_w[u * kO2Cand + (uint32_t)rankw[wd] + (uint32_t)__popc(bm & ((1u << bit) - 1u))] = (uint8_t)(wf + 1u);
+                                        }
+                                    }
+                                    done += nb;
+                                }
+                            }
+                        }
+                        wave_lds_fence();
+                    }
+                    qn = qb + n_c;
+                    if (qn >= 128u || !use_sum) flush_queue();
+                }
+            }
+            if (lh_dirty && (fix || !have_th || (sl & 3u) == 2u || sl + 1u >= n_local)) publish_hist();
+        }
+        flush_queue();
+        if (lh_dirty) publish_hist();
+    }
+
+    /* ---- unit epilogue ---- */
+    orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
+    unsigned long long matches = matches32;
+    for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
+    const uint32_t n_out = tkn < k ? tkn : k;
+    xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
+    for (uint32_t i = lane; i < n_out; i += 64u) {
+        xgm_cand c;
+        c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = tk_m[i];
+        out[i] = c;
+    }
+    if (lane == 0) {
+        xgm_group_hdr h;
+        h.matches = matches; h.n_cand = n_out; h.pad = n_scored;
+        h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
+        h.c_pos = 0; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe_raw; h.c_blk_words = cn_flat * 5u / 4u; h.c_hdrs = 0;
+        h.c_doclen = cn_dl_raw; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = fix ? 0x80000000u : 0u; h.c_pad[1] = 0;
+        ghdr_out[wk.slot] = h;
+    }
+}
+
 template <class K>
 int orw_ensure_dyn_smem(K kern, size_t smem, std::atomic<size_t>& seen) {
     if (smem <= seen.load(std::memory_order_relaxed)) return XGM_OK;
@@ -1074,7 +1709,43 @@ size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap
     return XGM_WAVES * orw_wave_bytes(1u << stripe_bits, tab_terms, cap, wide ? 2 : 1, spg);
 }
 
+size_t xgm_orw2_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, uint32_t spg, bool sparse) {
+    return XGM_WAVES * orw2_wave_bytes(1u << stripe_bits, tab_terms, cap, spg, sparse);
+}
+
+/* OPT-IN (XGM_ORW2=1): measured on the MI355X in round 5 the kernel is SLOWER than xgm_orw_kernel on C3 — 2.30 ms per launch of 250 queries
+ * against 1.98 ms for 256 — although it runs three waves per SIMD without a spill in its loops where the old one runs two: taking a stripe
+ * in four single-word passes repeats the wave-uniform control of the bound sum (plane / addend selection, lane reads of the quantised
+ * bounds) four times, and that, not occupancy, is what the launch is made of (static count: 835 VALU + 536 SALU in one pass's sum).
+ * Kept as an A/B kernel with its parity tests (tests/test_gpu_variants.py); it implements the default pruning configuration only. */
+bool xgm_orw2_enabled() {
+    static const bool on = getenv("XGM_ORW2") && atoi(getenv("XGM_ORW2")) && !getenv("XGM_NO_PRUNE") && !getenv("XGM_NO_PHASE_A") && !getenv("XGM_NO_BOUND_SUM") && !getenv("XGM_PHASE_TIMING");
+    return on;
+}
+
+static int launch_orw2(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream) {
+    const bool sparse = L.orw2 == 2;
+    const size_t smem = xgm_orw2_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.stripes_per_group, sparse);
+    const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);
+    int rc = XGM_OK;
+#define ORW2_LAUNCH(SP, TL)                                                                                                          \
+    do {                                                                                                                             \
+        auto kern = xgm_orw2_kernel<SP, TL>;                                                                                         \
+        static std::atomic<size_t> seen{0};                                                                                          \
+        if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
+                           L.cap, L.k_stride, hist, L.cand, L.ghdr);                                                                 \
+    } while (0)
+    if (sparse) { if (L.tally) ORW2_LAUNCH(true, true); else ORW2_LAUNCH(true, false); }
+    else { if (L.tally) ORW2_LAUNCH(false, true); else ORW2_LAUNCH(false, false); }
+#undef ORW2_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return xgm_launch_error("xgm_orw2_kernel launch", (int)e, hipGetErrorString(e));
+    return XGM_OK;
+}
+
 int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream) {
+    if (L.orw2) return launch_orw2(L, hist, stream);
     static const bool no_prune = getenv("XGM_NO_PRUNE") != nullptr;          /* A/B switches for measurements */
     static const bool no_phase_a = getenv("XGM_NO_PHASE_A") != nullptr;
     static const bool no_sum = getenv("XGM_NO_BOUND_SUM") != nullptr;
@@ -1088,16 +1759,26 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
     int rc = XGM_OK;
 #define ORW_LAUNCH(TABT, TL)                                                                                                         \
     do {                                                                                                                             \
-        auto kern = xgm_orw_kernel<TABT, TL>;                                                                                        \
+        auto kern = xgm_orw_kernel<TABT, TL, false>;                                                                                 \
+        static std::atomic<size_t> seen{0};                                                                                          \
+        if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
+        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
+                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
+    } while (0)
+#define ORW_LAUNCH_FLAT(TL)                                                                                                          \
+    do {                                                                                                                             \
+        auto kern = xgm_orw_kernel<uint8_t, TL, true>;                                                                               \
         static std::atomic<size_t> seen{0};                                                                                          \
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
                            L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
     } while (0)
     /* L.tally: the instantiation that also fills the traffic tallies of xgm_group_hdr (measurement only) */
-    if (L.wide) { if (L.tally) ORW_LAUNCH(uint16_t, true); else ORW_LAUNCH(uint16_t, false); }
+    if (L.or_flat && !L.wide) { if (L.tally) ORW_LAUNCH_FLAT(true); else ORW_LAUNCH_FLAT(false); }
+    else if (L.wide) { if (L.tally) ORW_LAUNCH(uint16_t, true); else ORW_LAUNCH(uint16_t, false); }
     else { if (L.tally) ORW_LAUNCH(uint8_t, true); else ORW_LAUNCH(uint8_t, false); }
 #undef ORW_LAUNCH
+#undef ORW_LAUNCH_FLAT
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("xgm_orw_kernel launch", (int)e, hipGetErrorString(e));
     return XGM_OK;

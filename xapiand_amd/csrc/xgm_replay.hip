@@ -37,7 +37,7 @@ struct ReplayLds {
 __device__ __forceinline__ bool rp_before(double aw, uint32_t ad, double bw, uint32_t bd) { return aw > bw || (aw == bw && ad < bd); }
 
 __global__ __launch_bounds__(kThreads) void xgm_replay_kernel(const xgm_hit* __restrict__ list, unsigned long long n, uint32_t max_size,
-                                                              unsigned long long check_at_least, uint32_t frozen_mode,
+                                                              unsigned long long check_at_least, uint32_t frozen_mode, unsigned long long total_matches,
                                                               xgm_hit* __restrict__ out_hits, xgm_replay_out* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     ReplayLds& L = *reinterpret_cast<ReplayLds*>(smem);
@@ -189,6 +189,10 @@ __global__ __launch_bounds__(kThreads) void xgm_replay_kernel(const xgm_hit* __r
                 if (gn < n) { w_star = list[gn].weight; have_star = true; } else stop = true;       /* no document left: the loop ends */
             }
             if (frozen && have_star && w_star < min_w) stop = true;          /* vet() rejects every later document untested */
+            /* ... or none can replace a kept one any more (the frozen weight does not beat the worst kept; a later docid never wins a tie) while
+             * every one still reaches ProtoMSet::add: the rest of the loop only counts, and the count is known — every match so far was shown
+             * (min_weight was <= 0 until the freeze, the frozen weight >= min_weight since), so known_matching_docs ends at the match count */
+            if (frozen && have_star && !stop && !rp_before(w_star, 0xFFFFFFFFu, worst_w, worst_d)) { known = total_matches; stop = true; }
         }
     }
     __syncthreads();
@@ -228,12 +232,12 @@ __global__ __launch_bounds__(kThreads) void xgm_replay_kernel(const xgm_hit* __r
 
 }  // namespace
 
-int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, xgm_hit* out_hits,
-                      xgm_replay_out* out, hipStream_t stream) {
+int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, uint64_t total_matches,
+                      xgm_hit* out_hits, xgm_replay_out* out, hipStream_t stream) {
     if (max_size > XGM_MAX_K) return xgm_launch_error("xgm_replay_kernel", 0, "first + maxitems beyond XGM_MAX_K");
     const size_t smem = ((sizeof(ReplayLds) + 15) & ~(size_t)15) + (size_t)max_size * 16 + 16;
     hipLaunchKernelGGL(xgm_replay_kernel, dim3(1), dim3(kThreads), smem, stream, list, (unsigned long long)n, max_size, (unsigned long long)check_at_least,
-                       frozen_mode ? 1u : 0u, out_hits, out);
+                       frozen_mode ? 1u : 0u, (unsigned long long)total_matches, out_hits, out);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("xgm_replay_kernel", (int)e, hipGetErrorString(e));
     return 0;
