@@ -427,6 +427,12 @@ typedef struct {
 int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                       xgm_result_hdr* hdr);
 
+/* nq searches under ONE sort in one launch: hits [nq][k_stride] (k_stride >= every first + maxitems), hit_ord [nq][k_stride] or NULL, hdrs [nq]
+ * — what xgm_search_sorted answers for each, without a launch, a copy each way and a synchronisation per query: Xapiand's HTTP threads all sort by
+ * the same few fields (DocMatcher::get_mset, reference src/database/handler.cc:1338, once per request).  XGM_UNSUPPORTED if any query is. */
+int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                            uint32_t* hit_ord, xgm_result_hdr* hdrs);
+
 /* ... with a Xapian::ValueCountMatchSpy (what Xapiand's AggregationMatchSpy derives from, src/aggregations/) on value slot
  * spy_slot in the same pass: counts[o] = matching documents whose value has ordinal o in that slot's column, counts[0] those
  * without a value; n_counts = the column's distinct values + 1; hdr->matches_exact is the spy's total.  The counts are those of

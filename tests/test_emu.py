@@ -84,7 +84,7 @@ def test_value_sorts_under_emulation(device_runs):
     both directions, AND / OR / AND_NOT / AND_MAYBE, deep pages, two stripe widths; the ValueCountMatchSpy of the same pass; set_collapse_key by relevance and under the sorts; and, through the Enquire mirror,
     the MSets the compiled reference itself recorded (golden fixtures: docid, weight bits, percentage, sort key at every rank)."""
     out = device_runs("value_sorts")
-    assert "8 passed" in out, out
+    assert "9 passed" in out, out
 
 
 def test_match_kernels_under_emulation(device_runs):

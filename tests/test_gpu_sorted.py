@@ -10,7 +10,7 @@ import pytest
 
 import helpers as H
 from xapiand_amd import Database, Enquire, Query, ValueCountMatchSpy, _lib
-from xapiand_amd.enquire import merged_stats, plan, read_column_values, search_collapsed, search_sorted, search_sorted_spy
+from xapiand_amd.enquire import merged_stats, plan, read_column_values, search_collapsed, search_sorted, search_sorted_batch, search_sorted_spy
 
 pytestmark = [pytest.mark.gpu]
 
@@ -54,6 +54,41 @@ def test_value_sorts_vs_oracle(built, tmp_path, stripe_bits):
             assert hdr.matches_exact == whdr.matches and hdr.max_attained == whdr.max_attained, (q, mode, slot, rev)
             n_items += len(got)
     assert n_items > (60 if QUICK else 500)
+    db.close()
+    c.close()
+
+
+def test_sorted_batch_equals_single_searches_and_the_oracle(built, tmp_path):
+    """xgm_search_sorted_batch (round 5): >= 64 searches of mixed shapes and page sizes under ONE sort in one launch give what
+    xgm_search_sorted gives for each (hits, ordinals, match count, best weight) — and a sample of them what the pinned oracle gives."""
+    c = H.Corpus(*((3000, 8000) if QUICK else (30000, 60000)))
+    db = Database(c.build_segment(str(tmp_path / "b.seg")))
+    values = {}
+    for slot in range(3):
+        p = write_column(c, slot, str(tmp_path / ("col%d" % slot)))
+        db.attach_column(p)
+        values[slot] = read_column_values(p)
+    n = (lambda full, quick: quick if QUICK else full)
+    base = (H.gen_term_queries("OR", n(28, 6), 3, 1, 400, maxitems=10, seed=151) + H.gen_term_queries("AND", n(24, 5), 2, 1, 60, maxitems=10, seed=152) +
+            H.gen_sided_queries("AND_MAYBE", n(8, 2), 1, 2, 1, 200, maxitems=10, seed=153) + H.gen_sided_queries("AND_NOT", n(8, 2), 1, 2, 1, 200, maxitems=10, seed=154) +
+            H.gen_term_queries("OR", n(6, 1), 5, 1, 3000, first=7, maxitems=33, seed=155) + H.gen_term_queries("AND", n(4, 1), 1, 1, 30, maxitems=20, seed=156))
+    assert len(base) >= (16 if QUICK else 64)
+    plans = [plan(db, Query(q["op"], q["terms"], n_required=q.get("n_required", 0)), q["first"], q["maxitems"]) for q in base]
+    checked = 0
+    for mode, slot, rev in (("V", 0, False), ("VR", 2, True), ("RV", 1, False)):
+        res = search_sorted_batch(db, plans, MODES[mode], slot, rev)
+        assert len(res) == len(base)
+        for qi, (q, p, (got, hdr)) in enumerate(zip(base, plans, res)):
+            one, ohdr = search_sorted(db, p, MODES[mode], slot, rev)
+            assert got == one, (q, mode)
+            assert (hdr.n_hits, hdr.matches_exact, hdr.max_attained, hdr.max_weight_subqs_matched) == (ohdr.n_hits, ohdr.matches_exact, ohdr.max_attained, ohdr.max_weight_subqs_matched), q
+            if qi % 5 == 0:
+                want, whdr = H.oracle_search_sorted(c, q["op"], q["terms"], q["first"], q["maxitems"], mode, slot, rev, n_required=q.get("n_required", 0))
+                assert [(d, w, m) for d, w, m, _ in got] == [(d, w, m) for d, w, m, _ in want], (q, mode, slot, rev)
+                assert [values[slot][o - 1] if o else b"" for _, _, _, o in got] == [k for _, _, _, k in want], (q, mode, slot, rev)
+                assert hdr.matches_exact == whdr.matches
+                checked += 1
+    assert checked >= (9 if QUICK else 36)
     db.close()
     c.close()
 

@@ -1421,6 +1421,9 @@ extern "C" int xgm_index_attach_column_ordinals(xgm_index* idx, uint32_t slot, c
     return attach_ordinals(idx, slot, ord, n_ord, n_distinct);
 }
 
+/* a scratch goes back to the pool only when nothing enqueued on its stream still uses it (ADVICE r4: the early returns) */
+struct ScratchRelease { xgm_index* i; XgmScratch* s; ~ScratchRelease() { hipStreamSynchronize(s->stream); scratch_release(i, s); } };
+
 namespace {
 struct DeviceBuffers {                       /* freed on every way out */
     std::vector<void*> p;
@@ -1582,6 +1585,103 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, -1, nullptr, 0);
 }
 
+/* nq searches under ONE sort in ONE launch (include/xgm.h: xgm_search_sorted_batch): the workgroup kernel's units of every query go up in one
+ * work list (plan_batch), every unit leaves its best k under the sort, the host merges each query's units — what xgm_search_sorted does
+ * for one query, without a launch, an upload, a download and a synchronisation per query. */
+extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                                       uint32_t* hit_ord, xgm_result_hdr* hdrs) {
+    if (!idx || !qs || !sort || !hits || !hdrs || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
+    if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
+    const uint32_t mode = sort->sort_by;
+    const bool reverse = sort->reverse != 0;
+    const uint32_t* d_ord = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(idx->columns_mu);
+        auto it = idx->columns.find(sort->slot);
+        if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+        d_ord = (const uint32_t*)it->second.first;
+    }
+    int rc = use_device(idx->device);
+    if (rc) return rc;
+    std::vector<xgm_dev_query> dq(nq);
+    std::vector<uint32_t> kq(nq);
+    std::vector<double> mp(nq);
+    BatchPlan bp;
+    if ((rc = plan_batch(idx, qs, nq, dq.data(), kq.data(), mp.data(), &bp, true))) return rc;
+    if (bp.andw || bp.orw || bp.and_only || bp.cap > 8u * XGM_WG || bp.parts != 1u) return XGM_UNSUPPORTED;
+    for (uint32_t i = 0; i < nq; ++i) if (dq[i].k == 0 || dq[i].k > k_stride) return dq[i].k ? xgm_set_error(XGM_E_INVALID, "k_stride %u < first + maxitems %u", k_stride, dq[i].k) : XGM_UNSUPPORTED;
+    if (xgm_match_sorted_smem_bytes(idx->hdr.stripe_bits - bp.sub_bits, bp.tab_terms, bp.phrase, bp.cap, bp.wide, bp.stripes_per_group) > 160u * 1024u) return XGM_UNSUPPORTED;
+    const uint32_t n_work = bp.n_work, kc = bp.k_stride_c;
+    XgmScratch* sc;
+    if ((rc = scratch_acquire(idx, &sc))) return rc;
+    ScratchRelease release_{idx, sc};
+    hipStream_t stream = sc->stream;
+    const size_t o_q = 0, b_q = ((size_t)nq * sizeof(xgm_dev_query) + 15) & ~(size_t)15;
+    const size_t o_wk = o_q + b_q, b_wk = ((size_t)n_work * sizeof(xgm_work) + 15) & ~(size_t)15;
+    const size_t up_bytes = o_wk + b_wk;
+    const size_t o_gh = up_bytes, b_gh = (size_t)n_work * sizeof(xgm_group_hdr);
+    const size_t o_cd = o_gh + b_gh, b_cd = (size_t)n_work * kc * sizeof(xgm_cand_sorted);
+    const size_t total = o_cd + b_cd;
+    if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
+    if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total))) return rc;
+    unsigned char* hb = (unsigned char*)sc->h_sorted;
+    memcpy(hb + o_q, dq.data(), (size_t)nq * sizeof(xgm_dev_query));
+    memcpy(hb + o_wk, bp.work.data(), (size_t)n_work * sizeof(xgm_work));
+    HIP_TRY(hipMemcpyAsync(sc->d_sorted, hb, up_bytes, hipMemcpyHostToDevice, stream));
+    xgm_match_launch L;
+    L.seg = idx->view;
+    L.queries = (xgm_dev_query*)(sc->d_sorted + o_q);
+    L.nq = nq; L.n_work = n_work; L.work = (xgm_work*)(sc->d_sorted + o_wk); L.stripes_per_group = bp.stripes_per_group; L.sub_bits = bp.sub_bits;
+    L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = kc;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
+    L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
+    idx->last_kernel = "xgm_match_sorted_kernel";
+    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, nullptr, nullptr, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(hb + o_gh, sc->d_sorted + o_gh, total - o_gh, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const xgm_group_hdr* gh = (const xgm_group_hdr*)(hb + o_gh);
+    const xgm_cand_sorted* cand = (const xgm_cand_sorted*)(hb + o_cd);
+    const bool use_x = mode == XGM_SORT_VALUE_RELEVANCE || mode == XGM_SORT_RELEVANCE_VALUE;
+    const bool weight_first = mode >= XGM_SORT_RELEVANCE_VALUE;
+    std::vector<xgm_cand_sorted> all;
+    for (uint32_t qi = 0; qi < nq; ++qi) {
+        const uint32_t k = dq[qi].k;
+        all.clear();
+        uint64_t matches = 0, max_w = 0;
+        uint32_t max_d = UINT32_MAX, max_m = 0;
+        for (uint32_t u = bp.goff[qi]; u < bp.goff[qi + 1]; ++u) {
+            const xgm_group_hdr& g = gh[u];
+            if (g.n_cand > k) return xgm_set_error(XGM_E_DEVICE, "sorted batch: unit %u reports %u candidates for k = %u", u, g.n_cand, k);
+            matches += g.matches;
+            all.insert(all.end(), cand + (size_t)u * kc, cand + (size_t)u * kc + g.n_cand);
+            if (g.c_pad[0] != UINT32_MAX && (max_d == UINT32_MAX || g.c_pos > max_w || (g.c_pos == max_w && g.c_pad[0] < max_d))) { max_w = g.c_pos; max_d = g.c_pad[0]; max_m = g.c_pad[1]; }
+        }
+        std::sort(all.begin(), all.end(), [&](const xgm_cand_sorted& a, const xgm_cand_sorted& b) {
+            if (a.kw != b.kw) return a.kw > b.kw;
+            if (use_x && a.kx != b.kx) return a.kx > b.kx;
+            return a.did < b.did;
+        });
+        const uint32_t n = (uint32_t)std::min<size_t>(k, all.size());
+        xgm_hit* out = hits + (size_t)qi * k_stride;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t wbits = weight_first ? all[i].kw : all[i].kx;
+            const uint32_t okey = (uint32_t)(weight_first ? all[i].kx : all[i].kw);
+            out[i].docid = all[i].did;
+            out[i].subqs_matched = all[i].subqs;
+            memcpy(&out[i].weight, &wbits, 8);
+            if (hit_ord) hit_ord[(size_t)qi * k_stride + i] = reverse ? okey : ~okey;
+        }
+        xgm_result_hdr* hdr = &hdrs[qi];
+        memset(hdr, 0, sizeof *hdr);
+        hdr->n_hits = n;
+        hdr->matches_exact = matches;
+        hdr->max_possible = qs[qi].max_possible;
+        if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
+    }
+    return XGM_OK;
+}
+
 extern "C" int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                                      xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts) {
     return sorted_core(idx, q, sort, hits, hit_ord, hdr, (int)spy_slot, counts, n_counts);
@@ -1678,8 +1778,6 @@ static int search_all_device(xgm_index* idx, const xgm_query* q, XgmScratch* sc,
     return XGM_OK;
 }
 
-/* a scratch goes back to the pool only when nothing enqueued on its stream still uses it (ADVICE r4: the early returns) */
-struct ScratchRelease { xgm_index* i; XgmScratch* s; ~ScratchRelease() { hipStreamSynchronize(s->stream); scratch_release(i, s); } };
 
 extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits, uint64_t cap, uint64_t* n_matches, xgm_result_hdr* hdr) {
     if (!idx || !q || !n_matches || !hdr || (cap && !hits)) return xgm_set_error(XGM_E_INVALID, "null argument");
