@@ -626,6 +626,8 @@ int xgm_debug_batch_launches(const xgm_index*, const xgm_query* qs, uint32_t nq,
  * of launches. */
 int xgm_debug_host_ns(uint64_t* out8);
 
+/* Diagnostics: out2 = {xgm_search_replay calls walked by one workgroup, calls walked by segments in parallel} of this process. */
+int xgm_debug_replay_info(uint64_t* out2);
 /* Diagnostics: out3 = {batches the dispatcher launched, requests it served, max_batch}. */
 int xgm_debug_batching_info(const xgm_index*, uint64_t* out3);
 /* Diagnostics / bench.py's server leg: n_threads host threads, each answering per_thread queries one at a time through

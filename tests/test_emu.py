@@ -42,7 +42,7 @@ DEVICE_RUNS = {
     # conjunctions through xgm_and_kernel (its guarded payload loads carry XGM_EMU hooks)
     "and_workgroup_kernel": ([PARITY, "-k", "edge_cases or (golden_single_shard and and_paging)"], {k: v for k, v in WORKGROUP.items() if k != "XGM_NO_AND_KERNEL"}),
     "wave_kernels": ([PARITY, "-k", EMU_SELECT], {}),
-    "search_all": ([os.path.join("tests", "test_gpu_all.py")], WORKGROUP),
+    "search_all": ([os.path.join("tests", "test_gpu_all.py")], dict(WORKGROUP, XGM_REPLAY_SEG_MIN="128")),      # (the replay also in parallel segments)
     "flat": ([os.path.join("tests", "test_gpu_flat.py")], {}),
     "positional": ([os.path.join("tests", "test_gpu_positional.py"), "-k", "slow_path or colocated"], {}),
 }

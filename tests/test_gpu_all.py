@@ -168,6 +168,15 @@ def test_replay_counts_what_protomset_counts(built, tmp_path):
             events += known < len(every)
             big += len(every) > 2048                               # (more than one block of the replay kernel)
     assert events >= (3 if QUICK else 40) and big >= (1 if QUICK else 10), (events, big)
+    # which formulation walked the lists: one workgroup, or segments in parallel (lists of >= 4 x 4 096 entries — or whatever
+    # XGM_REPLAY_SEG_MIN says: tests/test_gpu_variants.py and tests/test_emu.py run this test with small segments)
+    import ctypes as C
+    from xapiand_amd import _lib
+    info = (C.c_uint64 * 2)()
+    _lib.lib().xgm_debug_replay_info.argtypes = [C.POINTER(C.c_uint64)]
+    _lib.lib().xgm_debug_replay_info(info)
+    if os.environ.get("XGM_REPLAY_SEG_MIN"):
+        assert info[1] >= (5 if QUICK else 10), list(info)
     db.close()
     c.close()
 

@@ -41,3 +41,13 @@ def test_parity_with_fast_path_disabled(built, switch, select):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu",
                         "-k", select, "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, "%s=1:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_replay_in_parallel_segments(built):
+    """xgm_search_replay's parallel formulation (segments replayed from the prefix's top k, xgm_replay.hip) on lists far smaller than the
+    4 x 4 096 entries it starts at by default: XGM_REPLAY_SEG_MIN=128 sends the counting test's lists through it (the test asserts so)."""
+    env = dict(os.environ, XGM_REPLAY_SEG_MIN="128")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_all.py"), "-x", "-q", "-m", "gpu", "-k", "replay_counts",
+                        "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -131,6 +131,7 @@ _API = [
     ("xgm_search", C.c_int, [C.c_void_p, _P(Query), _P(Hit), _P(ResultHdr)]),
     ("xgm_search_all", C.c_int, [C.c_void_p, _P(Query), _P(Hit), C.c_uint64, _P(C.c_uint64), _P(ResultHdr)]),
     ("xgm_search_replay", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, _P(Hit), _P(ResultHdr), _P(C.c_uint64)]),
+    ("xgm_debug_replay_info", C.c_int, [_P(C.c_uint64)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch_begin", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     ("xgm_get_mset_batch_begin", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),

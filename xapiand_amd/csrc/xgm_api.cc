@@ -1810,6 +1810,10 @@ extern "C" int xgm_search_all(xgm_index* idx, const xgm_query* q, xgm_hit* hits,
 /* ---- the reference's collation of a search by relevance, replayed on the device (include/xgm.h: xgm_search_replay) ----------
  * search_all_device leaves the match in docid order in HBM; xgm_replay_kernel (xgm_replay.hip) walks it as ProtoMSet would.  Only the
  * page (first + maxitems hits) and 48 bytes of figures cross PCIe. */
+constexpr uint32_t kReplaySegments = 512u;           /* at most: one wave each; the states' exclusive scan is sequential over them */
+static std::atomic<uint64_t> g_replays[2];          /* diagnostics: replays walked by one workgroup / by segments in parallel */
+extern "C" int xgm_debug_replay_info(uint64_t* out2) { if (!out2) return -1; out2[0] = g_replays[0].load(); out2[1] = g_replays[1].load(); return 0; }
+
 extern "C" int xgm_search_replay(xgm_index* idx, const xgm_query* q, uint32_t mode, xgm_hit* hits, xgm_result_hdr* hdr, uint64_t* known_matching_docs) {
     if (!idx || !q || !hdr || !known_matching_docs || mode > XGM_REPLAY_FROZEN_WEIGHT) return xgm_set_error(XGM_E_INVALID, "bad argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
@@ -1832,22 +1836,42 @@ extern "C" int xgm_search_replay(xgm_index* idx, const xgm_query* q, uint32_t mo
     xgm_hit* d_list = nullptr;
     uint64_t n = 0, m = 0;
     unsigned char* d_ext = nullptr;
-    const size_t b_hits = ((size_t)std::max(k, 1u) * sizeof(xgm_hit) + 255) & ~(size_t)255, ext = b_hits + 256;
+    /* the parallel formulation (xgm_replay.hip: segments replayed from the prefix's top k) takes the counting mode whenever ProtoMSet's state is a
+     * function of the prefix: check_at_least within the page; scratch for up to 256 segment states rides behind the page (XGM_REPLAY_SERIAL=1: A/B) */
+    static const bool serial_only = getenv("XGM_REPLAY_SERIAL") != nullptr;
+    const bool may_parallel = mode == XGM_REPLAY_COUNT && k >= 1u && q->check_at_least <= k && !serial_only;
+    const size_t b_hits = ((size_t)std::max(k, 1u) * sizeof(xgm_hit) + 255) & ~(size_t)255, b_down = b_hits + 256;
+    const size_t ext = b_down + (may_parallel ? xgm_replay_parallel_bytes(kReplaySegments, k) : 0);
     if ((rc = search_all_device(idx, q, sc, mode == XGM_REPLAY_FROZEN_WEIGHT, cap_dev, &d_list, &n, &m, hdr, ext, &d_ext))) return rc;
     if (n > cap_dev) return xgm_set_error(XGM_E_DEVICE, "xgm_search_replay: %llu documents exceed the plan's upper bound %u", (unsigned long long)n, q->est_max);
     hdr->n_hits = 0;
     if (n == 0) return XGM_OK;
     xgm_hit* d_page = (xgm_hit*)d_ext;
     xgm_replay_out* d_out = (xgm_replay_out*)(d_ext + b_hits);
-    if ((rc = xgm_launch_replay(d_list, n, k, q->check_at_least, mode == XGM_REPLAY_FROZEN_WEIGHT, m, d_page, d_out, sc->stream))) return rc;
-    if ((rc = grow_pinned(&sc->h_down, &sc->cap_down, ext))) return rc;
-    HIP_TRY(hipMemcpyAsync(sc->h_down, d_ext, ext, hipMemcpyDeviceToHost, sc->stream));
+    unsigned long long* d_known = (unsigned long long*)(d_ext + b_hits + 128);
+    /* segments of >= 4 096 entries (XGM_REPLAY_SEG_MIN: the tests run small lists through the parallel path), longer than the page, at least four */
+    static const uint64_t seg_min_env = getenv("XGM_REPLAY_SEG_MIN") ? (uint64_t)std::max(64, atoi(getenv("XGM_REPLAY_SEG_MIN"))) : 4096u;
+    const uint64_t seg_min = std::max<uint64_t>(seg_min_env, (uint64_t)k + 64u);
+    const bool parallel = may_parallel && n >= 4u * seg_min;
+    ++g_replays[parallel ? 1 : 0];
+    if (parallel) {
+        const uint32_t S = (uint32_t)std::min<uint64_t>(kReplaySegments, n / seg_min);
+        const uint64_t seg_len = (((n + S - 1u) / S) + 63u) & ~(uint64_t)63;
+        if ((rc = xgm_launch_replay_parallel(d_list, n, k, q->check_at_least, S, seg_len, d_ext + b_down, d_page, d_out, d_known, sc->stream))) return rc;
+    } else if ((rc = xgm_launch_replay(d_list, n, k, q->check_at_least, mode == XGM_REPLAY_FROZEN_WEIGHT, m, d_page, d_out, sc->stream))) return rc;
+    if ((rc = grow_pinned(&sc->h_down, &sc->cap_down, b_down))) return rc;
+    HIP_TRY(hipMemcpyAsync(sc->h_down, d_ext, b_down, hipMemcpyDeviceToHost, sc->stream));
     HIP_TRY(hipStreamSynchronize(sc->stream));
     const xgm_replay_out* o = (const xgm_replay_out*)((unsigned char*)sc->h_down + b_hits);
     if (o->n_hits > k) return xgm_set_error(XGM_E_DEVICE, "xgm_search_replay: %u documents kept for a page of %u", o->n_hits, k);
     memcpy(hits, sc->h_down, (size_t)o->n_hits * sizeof(xgm_hit));
-    *known_matching_docs = o->known_matching_docs;
     hdr->n_hits = o->n_hits;
+    if (parallel) {
+        /* (the counting mode shows ProtoMSet the true weights: its max_weight is the match's, already in hdr from the unit headers) */
+        *known_matching_docs = *(const unsigned long long*)((unsigned char*)sc->h_down + b_hits + 128);
+        return XGM_OK;
+    }
+    *known_matching_docs = o->known_matching_docs;
     /* ProtoMSet's own max_weight (update_max_weight sees what add() is shown: the frozen weight where it was served) */
     hdr->max_attained = o->max_weight;
     hdr->max_weight_subqs_matched = o->max_weight_subqs;

@@ -57,6 +57,11 @@ typedef struct {
 int xgm_launch_replay(const xgm_hit* list, uint64_t n, uint32_t max_size, uint64_t check_at_least, bool frozen_mode, uint64_t total_matches,
                       xgm_hit* out_hits, xgm_replay_out* out, hipStream_t stream);
 /* (total_matches: the matching documents among the n entries — frozen mode stops walking once the rest of the loop can only count) */
+/* the same in parallel (check_at_least <= K, no frozen weight): S segments of seg_len entries (> K), one wave each — per-segment top K, an
+ * exclusive scan of the states, per-segment replay; *known_sum (device, zeroed here) receives known_matching_docs, out->n_hits / out_hits the page */
+size_t xgm_replay_parallel_bytes(uint32_t S, uint32_t K);
+int xgm_launch_replay_parallel(const xgm_hit* list, uint64_t n, uint32_t K, uint64_t check_at_least, uint32_t S, uint64_t seg_len, void* scratch,
+                               xgm_hit* out_hits, xgm_replay_out* out, unsigned long long* known_sum, hipStream_t stream);
 /* (mode 4 = relevance alone, ord may be NULL; spy_counts — device, zeroed, one u32 per ordinal of spy_ord — may be NULL; cord = the collapse
  *  column's ordinals or NULL, cmax = collapse_max) */
 /* conjunction-only batches (every query: AND of >= 2 terms, no positional filter) */
