@@ -260,22 +260,60 @@ namespace {
 constexpr uint32_t kSegMaxK = 1024u;
 
 struct WaveState {
-    double* w; uint32_t* d; uint32_t* m;      /* LDS: the kept documents */
-    uint32_t size; bool heap_built;
-    double min_w, worst_w; uint32_t worst_d, worst_i;
+    double* w; uint32_t* d; uint32_t* m;      /* LDS: the kept documents — in RANK order (best first) once the heap is made */
+    uint32_t size, cap; bool heap_built;        /* cap: the page size K; slot [cap] is a spare one */
+    double min_w, worst_w; uint32_t worst_d;
 };
 
-__device__ __forceinline__ void wave_find_worst(WaveState& st, uint32_t lane) {
+__device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double w = 0.0; uint32_t d = 0, i = 0xFFFFFFFFu;
-    for (uint32_t j = lane; j < st.size; j += 64u)
-        if (i == 0xFFFFFFFFu || rp_before(w, d, st.w[j], st.d[j])) { w = st.w[j]; d = st.d[j]; i = j; }
-    for (int sh = 32; sh > 0; sh >>= 1) {
-        const double ow = __shfl_xor(w, sh); const uint32_t od = (uint32_t)__shfl_xor((int)d, sh), oi = (uint32_t)__shfl_xor((int)i, sh);
-        if (oi != 0xFFFFFFFFu && (i == 0xFFFFFFFFu || rp_before(w, d, ow, od))) { w = ow; d = od; i = oi; }
+}
+
+/* the kept documents put in rank order in place (ranks by counting: each lane ranks its own entries, all reads before any write) */
+__device__ __forceinline__ void wave_sort_kept(WaveState& st, uint32_t lane) {
+    wave_lds_sync();
+    double rw[16]; uint32_t rd[16], rm[16], rr[16];
+#pragma unroll
+    for (uint32_t t = 0; t < 16u; ++t) {
+        const uint32_t i = lane + t * 64u;
+        rr[t] = 0xFFFFFFFFu; rw[t] = 0.0; rd[t] = 0; rm[t] = 0;
+        if (i < st.size) {
+            rw[t] = st.w[i]; rd[t] = st.d[i]; rm[t] = st.m[i];
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < st.size; ++j) r += rp_before(st.w[j], st.d[j], rw[t], rd[t]) ? 1u : 0u;
+            rr[t] = r;
+        }
     }
-    st.worst_w = w; st.worst_d = d; st.worst_i = i;
+    wave_lds_sync();
+#pragma unroll
+    for (uint32_t t = 0; t < 16u; ++t) if (rr[t] != 0xFFFFFFFFu) { st.w[rr[t]] = rw[t]; st.d[rr[t]] = rd[t]; st.m[rr[t]] = rm[t]; }
+    wave_lds_sync();
+}
+
+/* (ew, ed, em) ranks before the worst kept: it takes its place in the rank order, the worst drops out.  The place = the kept documents that rank
+ * before it (a ballot count per 64); the entries from there on move down one slot, highest indices first. */
+__device__ __forceinline__ void wave_insert_sorted(WaveState& st, double ew, uint32_t ed, uint32_t em, uint32_t lane) {
+    uint32_t r = 0;
+    for (uint32_t i0 = 0; i0 < st.size; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        r += (uint32_t)__popcll(__ballot(i < st.size && rp_before(st.w[i], st.d[i], ew, ed)));
+    }
+    const uint32_t last = st.size - 1u;                      /* the worst: overwritten by the shift */
+    /* (no branch between the wave barriers: a lane with nothing to move moves the spare slot st.cap onto itself) */
+    for (uint32_t hi = last; hi > r;) {                      /* move [r, last) to [r + 1, last], in chunks from the top */
+        const uint32_t lo = hi - r > 64u ? hi - 64u : r;     /* this chunk: source indices [lo, hi) */
+        const uint32_t from = lo + lane < hi ? lo + lane : st.cap, to = lo + lane < hi ? lo + lane + 1u : st.cap;
+        const double w = st.w[from]; const uint32_t d = st.d[from], m = st.m[from];
+        wave_lds_sync();
+        st.w[to] = w; st.d[to] = d; st.m[to] = m;
+        wave_lds_sync();
+        hi = lo;
+    }
+    const uint32_t at = lane == 0u ? r : st.cap;
+    st.w[at] = ew; st.d[at] = ed; st.m[at] = em;
+    wave_lds_sync();
+    st.worst_w = st.w[last]; st.worst_d = st.d[last];
 }
 
 /* entries [begin, end) of the list through ProtoMSet::add, one wave; returns how many reached it.  known_base: what the documents before
@@ -285,7 +323,7 @@ __device__ __forceinline__ unsigned long long wave_replay_segment(const xgm_hit*
                                                                   uint32_t lane) {
     unsigned long long known = 0;
     if (begin >= end) return 0;
-    /* four chunks in flight: a wave alone on its SIMD has nothing else to hide a load's latency behind (measured with one: 3.6 us per chunk) */
+    /* four chunks in flight: a wave alone on its SIMD has nothing else to hide a load's latency behind */
     xgm_hit ring[4];
 #pragma unroll
     for (uint32_t r = 0; r < 4u; ++r) {
@@ -333,12 +371,12 @@ __device__ __forceinline__ unsigned long long wave_replay_segment(const xgm_hit*
             const uint32_t ed = (uint32_t)__shfl((int)h.docid, (int)ev), em = (uint32_t)__shfl((int)h.subqs_matched, (int)ev);
             if (!st.heap_built) {
                 st.heap_built = true;
-                wave_find_worst(st, lane);
+                wave_sort_kept(st, lane);                                     /* (Heap::make's counterpart: from here on the kept set stays in rank order) */
+                st.worst_w = st.w[st.size - 1u]; st.worst_d = st.d[st.size - 1u];
                 if (known + known_base >= check_at_least) st.min_w = st.worst_w;
             }
             if (rp_before(ew, ed, st.worst_w, st.worst_d)) {
-                if (lane == 0u) { st.w[st.worst_i] = ew; st.d[st.worst_i] = ed; st.m[st.worst_i] = em; }
-                wave_find_worst(st, lane);
+                wave_insert_sorted(st, ew, ed, em, lane);
                 if (known + known_base >= check_at_least) st.min_w = st.worst_w;
             }
         }
@@ -346,25 +384,22 @@ __device__ __forceinline__ unsigned long long wave_replay_segment(const xgm_hit*
     return known;
 }
 
-/* the kept documents in rank order → out[0 .. size) (ranks by counting: the set is small) */
-__device__ __forceinline__ void wave_write_sorted(const WaveState& st, xgm_hit* __restrict__ out, uint32_t lane) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+/* the kept documents in rank order → out[0 .. size) */
+__device__ __forceinline__ void wave_write_sorted(WaveState& st, xgm_hit* __restrict__ out, uint32_t lane) {
+    if (!st.heap_built) wave_sort_kept(st, lane);                            /* (a list that never filled the page) */
+    wave_lds_sync();
     for (uint32_t i = lane; i < st.size; i += 64u) {
-        const double w = st.w[i]; const uint32_t d = st.d[i];
-        uint32_t r = 0;
-        for (uint32_t j = 0; j < st.size; ++j) r += rp_before(st.w[j], st.d[j], w, d) ? 1u : 0u;
-        xgm_hit h; h.docid = d; h.subqs_matched = st.m[i]; h.weight = w;
-        out[r] = h;
+        xgm_hit h; h.docid = st.d[i]; h.subqs_matched = st.m[i]; h.weight = st.w[i];
+        out[i] = h;
     }
 }
 
 __device__ __forceinline__ WaveState wave_state_carve(unsigned char* smem, uint32_t K) {
     WaveState st;
     st.w = reinterpret_cast<double*>(smem);
-    st.d = reinterpret_cast<uint32_t*>(st.w + K);
-    st.m = st.d + K;
-    st.size = 0; st.heap_built = false; st.min_w = 0.0; st.worst_w = 0.0; st.worst_d = 0; st.worst_i = 0;
+    st.d = reinterpret_cast<uint32_t*>(st.w + K + 1u);
+    st.m = st.d + K + 1u;
+    st.cap = K; st.size = 0; st.heap_built = false; st.min_w = 0.0; st.worst_w = 0.0; st.worst_d = 0;
     return st;
 }
 
@@ -379,43 +414,49 @@ __global__ __launch_bounds__(64) void xgm_replay_segtop_kernel(const xgm_hit* __
     if (lane == 0u) seg_n[s] = st.size;
 }
 
-/* start[s] = top K of segments 0 .. s - 1: one wave, S merges of two sorted lists (an entry's place = its index + the entries of the other
- * list that rank before it: a binary search) */
-__global__ __launch_bounds__(64) void xgm_replay_prefix_kernel(const xgm_hit* __restrict__ seg_top, const uint32_t* __restrict__ seg_n, uint32_t S, uint32_t K,
-                                                               xgm_hit* __restrict__ start, uint32_t* __restrict__ start_n) {
+/* entries of the sorted arr that rank before (w, d) */
+__device__ __forceinline__ uint32_t count_before(const xgm_hit* arr, uint32_t n, double w, uint32_t d) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (rp_before(arr[mid].weight, arr[mid].docid, w, d)) lo = mid + 1u; else hi = mid;
+    }
+    return lo;
+}
+
+/* Exclusive scan of top-K lists under "merge and keep the best K", one wave per GROUP of `gs` lists: start[s] = top K of the lists of s's group
+ * before s; total[g] = top K of the whole group (when asked for).  An entry's place in a merge = its index + the entries of the other list that
+ * rank before it (a binary search).  Two levels (groups of segments, then the groups' totals with one group of all of them) keep the sequential
+ * depth at gs + S / gs merges instead of S. */
+__global__ __launch_bounds__(64) void xgm_replay_prefix_kernel(const xgm_hit* __restrict__ seg_top, const uint32_t* __restrict__ seg_n, uint32_t S, uint32_t gs,
+                                                               uint32_t K, xgm_hit* __restrict__ start, uint32_t* __restrict__ start_n,
+                                                               xgm_hit* __restrict__ total, uint32_t* __restrict__ total_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     xgm_hit* cur = reinterpret_cast<xgm_hit*>(smem);
     xgm_hit* oth = cur + K;
     xgm_hit* out = oth + K;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t lane = threadIdx.x, g = blockIdx.x;
+    const uint32_t s0 = g * gs, s1 = s0 + gs < S ? s0 + gs : S;
     uint32_t n_cur = 0;
-    auto count_before = [&](const xgm_hit* arr, uint32_t n, double w, uint32_t d) {       /* entries of the sorted arr that rank before (w, d) */
-        uint32_t lo = 0, hi = n;
-        while (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            if (rp_before(arr[mid].weight, arr[mid].docid, w, d)) lo = mid + 1u; else hi = mid;
-        }
-        return lo;
-    };
-    /* the next segment's list is requested while this one is merged (two entries per lane: K <= 128 in one go; a longer tail is read when needed) */
+    /* the next list is requested while this one is merged (two entries per lane: K <= 128 in one go; a longer tail is read when needed) */
     xgm_hit pre0, pre1; pre0.docid = 0; pre0.subqs_matched = 0; pre0.weight = 0.0; pre1 = pre0;
-    uint32_t pre_n = S ? seg_n[0] : 0u;
-    if (lane < pre_n) pre0 = seg_top[lane];
-    if (lane + 64u < pre_n) pre1 = seg_top[lane + 64u];
-    for (uint32_t s = 0; s < S; ++s) {
+    uint32_t pre_n = s0 < s1 ? seg_n[s0] : 0u;
+    if (lane < pre_n) pre0 = seg_top[(size_t)s0 * K + lane];
+    if (lane + 64u < pre_n) pre1 = seg_top[(size_t)s0 * K + lane + 64u];
+    for (uint32_t s = s0; s < s1; ++s) {
         for (uint32_t i = lane; i < n_cur; i += 64u) start[(size_t)s * K + i] = cur[i];
         if (lane == 0u) start_n[s] = n_cur;
+        if (s + 1u == s1 && total == nullptr) break;
         const uint32_t n_b = pre_n;
         if (lane < n_b) oth[lane] = pre0;
         if (lane + 64u < n_b) oth[lane + 64u] = pre1;
         for (uint32_t i = lane + 128u; i < n_b; i += 64u) oth[i] = seg_top[(size_t)s * K + i];
-        if (s + 1u < S) {
+        if (s + 1u < s1) {
             pre_n = seg_n[s + 1u];
             if (lane < pre_n) pre0 = seg_top[(size_t)(s + 1u) * K + lane];
             if (lane + 64u < pre_n) pre1 = seg_top[(size_t)(s + 1u) * K + lane + 64u];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         for (uint32_t i = lane; i < n_cur; i += 64u) {
             const uint32_t r = i + count_before(oth, n_b, cur[i].weight, cur[i].docid);
             if (r < K) out[r] = cur[i];
@@ -424,28 +465,49 @@ __global__ __launch_bounds__(64) void xgm_replay_prefix_kernel(const xgm_hit* __
             const uint32_t r = i + count_before(cur, n_cur, oth[i].weight, oth[i].docid);
             if (r < K) out[r] = oth[i];
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
         n_cur = n_cur + n_b < K ? n_cur + n_b : K;
         xgm_hit* t = cur; cur = out; out = t;
+    }
+    if (total != nullptr) {
+        for (uint32_t i = lane; i < n_cur; i += 64u) total[(size_t)g * K + i] = cur[i];
+        if (lane == 0u) total_n[g] = n_cur;
     }
 }
 
 __global__ __launch_bounds__(64) void xgm_replay_segcount_kernel(const xgm_hit* __restrict__ list, unsigned long long n, unsigned long long seg_len, uint32_t K,
                                                                  unsigned long long check_at_least, const xgm_hit* __restrict__ start,
-                                                                 const uint32_t* __restrict__ start_n, uint32_t S, xgm_hit* __restrict__ out_hits,
+                                                                 const uint32_t* __restrict__ start_n, const xgm_hit* __restrict__ gpre,
+                                                                 const uint32_t* __restrict__ gpre_n, uint32_t gs, uint32_t S, xgm_hit* __restrict__ out_hits,
                                                                  xgm_replay_out* __restrict__ out, unsigned long long* __restrict__ known_sum) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x, s = blockIdx.x;
     WaveState st = wave_state_carve(smem, K);
     unsigned long long base = 0;
     if (s != 0u) {
-        /* the state a sequential walk has when it reaches this segment: the prefix's top K kept, the heap made (the prefix holds more than K
-         * documents: seg_len > K), min_weight = the worst kept (check_at_least <= K was passed when the heap was made) */
-        st.size = start_n[s];
-        for (uint32_t i = lane; i < st.size; i += 64u) { const xgm_hit h = start[(size_t)s * K + i]; st.w[i] = h.weight; st.d[i] = h.docid; st.m[i] = h.subqs_matched; }
-        st.heap_built = true;
-        wave_find_worst(st, lane);
+        /* the state a sequential walk has when it reaches this segment: the prefix's top K kept — the merge of its group's lists before it (start[s])
+         * and the groups before (gpre[g]) —, the heap made (the prefix holds more than K documents: seg_len > K), min_weight = the worst kept
+         * (check_at_least <= K was passed when the heap was made) */
+        xgm_hit* la = reinterpret_cast<xgm_hit*>(smem + (((size_t)K + 1u) * 16u));
+        xgm_hit* lb = la + K;
+        const uint32_t g = s / gs, n_a = gpre_n[g], n_b = start_n[s];
+        for (uint32_t i = lane; i < n_a; i += 64u) la[i] = gpre[(size_t)g * K + i];
+        for (uint32_t i = lane; i < n_b; i += 64u) lb[i] = start[(size_t)s * K + i];
+        wave_lds_sync();
+        for (uint32_t i = lane; i < n_a; i += 64u) {
+            const xgm_hit h = la[i];
+            const uint32_t r = i + count_before(lb, n_b, h.weight, h.docid);
+            if (r < K) { st.w[r] = h.weight; st.d[r] = h.docid; st.m[r] = h.subqs_matched; }
+        }
+        for (uint32_t i = lane; i < n_b; i += 64u) {
+            const xgm_hit h = lb[i];
+            const uint32_t r = i + count_before(la, n_a, h.weight, h.docid);
+            if (r < K) { st.w[r] = h.weight; st.d[r] = h.docid; st.m[r] = h.subqs_matched; }
+        }
+        st.size = n_a + n_b < K ? n_a + n_b : K;
+        st.heap_built = true;                                                  /* (in rank order: the worst is the last) */
+        wave_lds_sync();
+        if (st.size) { st.worst_w = st.w[st.size - 1u]; st.worst_d = st.d[st.size - 1u]; }
         st.min_w = K != 0u ? st.worst_w : 0.0;
         base = check_at_least;
     }
@@ -465,23 +527,34 @@ __global__ __launch_bounds__(64) void xgm_replay_segcount_kernel(const xgm_hit* 
 
 }  // namespace
 
+constexpr uint32_t kReplayGroup = 16u;      /* segments per group of the two-level scan */
+
 /* bytes of device scratch the parallel replay needs for S segments of a page of K */
-size_t xgm_replay_parallel_bytes(uint32_t S, uint32_t K) { return (size_t)2 * S * (K ? K : 1u) * sizeof(xgm_hit) + (size_t)2 * S * 4 + 64; }
+size_t xgm_replay_parallel_bytes(uint32_t S, uint32_t K) {
+    const size_t k = K ? K : 1u, G = (S + kReplayGroup - 1u) / kReplayGroup;
+    return (2 * (size_t)S + 2 * G) * k * sizeof(xgm_hit) + (2 * (size_t)S + 2 * G) * 4 + 64;
+}
 
 int xgm_launch_replay_parallel(const xgm_hit* list, uint64_t n, uint32_t K, uint64_t check_at_least, uint32_t S, uint64_t seg_len, void* scratch,
                                xgm_hit* out_hits, xgm_replay_out* out, unsigned long long* known_sum, hipStream_t stream) {
     if (K == 0u || K > kSegMaxK || check_at_least > K || S == 0u || seg_len <= K) return xgm_launch_error("parallel replay", 0, "bad arguments");
+    const uint32_t G = (S + kReplayGroup - 1u) / kReplayGroup;
     xgm_hit* seg_top = (xgm_hit*)scratch;
     xgm_hit* start = seg_top + (size_t)S * K;
-    uint32_t* seg_n = (uint32_t*)(start + (size_t)S * K);
+    xgm_hit* gtop = start + (size_t)S * K;
+    xgm_hit* gpre = gtop + (size_t)G * K;
+    uint32_t* seg_n = (uint32_t*)(gpre + (size_t)G * K);
     uint32_t* start_n = seg_n + S;
+    uint32_t* gtop_n = start_n + S;
+    uint32_t* gpre_n = gtop_n + G;
     hipError_t e = hipMemsetAsync(known_sum, 0, 8, stream);
     if (e != hipSuccess) return xgm_launch_error("hipMemsetAsync", (int)e, hipGetErrorString(e));
-    const size_t lds_state = (size_t)K * 16 + 16, lds_prefix = (size_t)3 * K * sizeof(xgm_hit) + 16;
+    const size_t lds_state = ((size_t)K + 1u) * 16 + (size_t)2 * K * sizeof(xgm_hit), lds_prefix = (size_t)3 * K * sizeof(xgm_hit) + 16;
     hipLaunchKernelGGL(xgm_replay_segtop_kernel, dim3(S), dim3(64), lds_state, stream, list, (unsigned long long)n, (unsigned long long)seg_len, K, seg_top, seg_n);
-    hipLaunchKernelGGL(xgm_replay_prefix_kernel, dim3(1), dim3(64), lds_prefix, stream, seg_top, seg_n, S, K, start, start_n);
+    hipLaunchKernelGGL(xgm_replay_prefix_kernel, dim3(G), dim3(64), lds_prefix, stream, seg_top, seg_n, S, kReplayGroup, K, start, start_n, gtop, gtop_n);
+    hipLaunchKernelGGL(xgm_replay_prefix_kernel, dim3(1), dim3(64), lds_prefix, stream, gtop, gtop_n, G, G, K, gpre, gpre_n, (xgm_hit*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(xgm_replay_segcount_kernel, dim3(S), dim3(64), lds_state, stream, list, (unsigned long long)n, (unsigned long long)seg_len, K,
-                       (unsigned long long)check_at_least, start, start_n, S, out_hits, out, known_sum);
+                       (unsigned long long)check_at_least, start, start_n, gpre, gpre_n, kReplayGroup, S, out_hits, out, known_sum);
     e = hipGetLastError();
     if (e != hipSuccess) return xgm_launch_error("parallel replay kernels", (int)e, hipGetErrorString(e));
     return 0;
