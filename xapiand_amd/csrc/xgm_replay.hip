@@ -330,10 +330,14 @@ __device__ __forceinline__ unsigned long long wave_replay_segment(const xgm_hit*
         ring[r].docid = 0; ring[r].subqs_matched = 0; ring[r].weight = 0.0;
         if (begin + r * 64u + lane < end) ring[r] = list[begin + r * 64u + lane];
     }
-    for (unsigned long long c0 = begin; c0 < end; c0 += 64u) {
-        const xgm_hit h = ring[0];
-        ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = ring[3];
-        if (c0 + 256u + lane < end) ring[3] = list[c0 + 256u + lane];
+    /* (the ring is indexed by unrolled constants: rotating it through register copies would wait for the newest load every chunk) */
+    for (unsigned long long c4 = begin; c4 < end; c4 += 256u)
+#pragma unroll
+    for (uint32_t rj = 0; rj < 4u; ++rj) {
+        const unsigned long long c0 = c4 + rj * 64u;
+        if (c0 >= end) break;
+        const xgm_hit h = ring[rj];
+        if (c0 + 256u + lane < end) ring[rj] = list[c0 + 256u + lane];
         const bool valid = c0 + lane < end;
         uint32_t start = 0;
         while (start < 64u) {
