@@ -451,6 +451,42 @@ def byte_compatible_leg(db, leg, ora, n=256, n_check=128):
            "replayed_on_device": replayed,
            "what": ("xgm_search + xgm_search_replay(XGM_REPLAY_FROZEN_WEIGHT) per query: the reference's own top-%d incl. its frozen weight" % k) if positional else
                    ("xgm_search + xgm_search_replay(XGM_REPLAY_COUNT) per query: the page + the reference's known_matching_docs (exact HTTP total)")}
+    # the same per-query sequence from 8 host threads at once (Xapiand calls get_mset from every HTTP worker thread; every call takes its
+    # own scratch and stream from the index's pool): rows compared with the one-in-flight answers above
+    import threading
+    n_thr = 8
+    errors = []
+
+    def worker(t):
+        try:
+            h_, p_ = (_lib.Hit * k)(), (_lib.Hit * k)()
+            r_, r2_, kn_ = _lib.ResultHdr(), _lib.ResultHdr(), C.c_uint64()
+            for i in range(t, n, n_thr):
+                pl = leg.timed_plans[i]
+                _lib.check(L.xgm_search(db._h, C.byref(pl), h_, C.byref(r_)))
+                rows_, k_ = None, None
+                if r_.n_hits == k and (r_.matches_exact & ((1 << 63) - 1)) > k or (positional and r_.n_hits == k):
+                    _lib.check(L.xgm_search_replay(db._h, C.byref(pl), mode, p_, C.byref(r2_), C.byref(kn_)))
+                    k_ = kn_.value
+                    if positional:
+                        rows_ = [(p_[j].docid, p_[j].weight) for j in range(r2_.n_hits)]
+                if rows_ is None:
+                    rows_ = [(h_[j].docid, h_[j].weight) for j in range(r_.n_hits)]
+                if (rows_, k_) != answers[i]:
+                    errors.append(i)
+        except Exception as e:            # noqa: BLE001  (reported below: a thread must not die silently)
+            errors.append(repr(e))
+
+    thr = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
+    t0 = time.perf_counter()
+    for t in thr:
+        t.start()
+    for t in thr:
+        t.join()
+    wall_c = time.perf_counter() - t0
+    assert not errors, "concurrent byte-compatible searches differ from the sequential ones: %r" % errors[:4]
+    out["concurrent"] = {"value": n / wall_c, "unit": "queries/s", "host_threads": n_thr, "queries": n,
+                         "rows_equal_to_one_in_flight": True}
     if positional:
         sample = leg.timed_pool[:min(n_check, n)]
         want = H.oracle_search_batch(ora, sample, 0, k, reference_select_bug=True)
