@@ -17,8 +17,15 @@ def is_tally(name):
     if not m:
         return False
     args = [a.strip() for a in m.group(1).split(",")]
-    return name.startswith(("void (anonymous namespace)::xgm_andw_kernel", "void (anonymous namespace)::xgm_orw_kernel", "void (anonymous namespace)::xgm_orw2_kernel", "void (anonymous namespace)::xgm_dense_kernel",
-                            "xgm_andw_kernel", "xgm_orw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel")) and args[-1] in ("true", "1", "(bool)1")
+    base = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    # which template argument is TALLY: xgm_orw_kernel<TabT, TALLY, FLAT> (round 5: FLAT came after it); the others carry it last
+    if base.startswith("xgm_orw_kernel"):
+        flag = args[1] if len(args) > 1 else "false"
+    elif base.startswith(("xgm_andw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel")):
+        flag = args[-1]
+    else:
+        return False
+    return flag in ("true", "1", "(bool)1")
 
 
 def short(name):
