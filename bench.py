@@ -63,6 +63,7 @@ def parse_args():
     ap.add_argument("--no-hook-parity", action="store_true", help="skip the hook-on == hook-off leg on the reference's own glass index")
     ap.add_argument("--ref-no-positions", action="store_true", help="build the reference index of the headline run WITHOUT positions (faster; C5's reference baseline and hook-parity leg are then skipped)")
     ap.add_argument("--ref-seconds", type=float, default=12.0, help="time box of the reference's all-core leg")
+    ap.add_argument("--ref-build-budget", type=float, default=1000.0, help="seconds the reference's index build may take (normally ~520 on 128 cores) before the leg is given up and the port reported (0 = no limit)")
     ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--vocab", type=int, default=1_000_000)
     ap.add_argument("--op", default="AND")
@@ -853,7 +854,7 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
     tmp = tempfile.mkdtemp(prefix="xgm_ref_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
     try:
         dbdir = os.path.join(tmp, "glass")
-        binfo = ref_index.build(dbdir, ref_docs, nopos=not with_positions, vocab=args.vocab)
+        binfo = ref_index.build(dbdir, ref_docs, nopos=not with_positions, vocab=args.vocab, budget_s=args.ref_build_budget or None)
         qfile = os.path.join(tmp, "q.txt")
         H.write_queries(qfile, [dict(q, first=0, maxitems=k) for q in sample])
         cores = max(1, os.cpu_count() or 1)

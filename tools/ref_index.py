@@ -20,8 +20,9 @@ XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
 CORPUS_SEED = 0x5EED0001
 
 
-def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, len_hi=150, seed=CORPUS_SEED, keep_parts=False):
-    """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced."""
+def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, len_hi=150, seed=CORPUS_SEED, keep_parts=False, budget_s=None):
+    """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced.  budget_s: give up (TimeoutError, the writers this call
+    started are killed) when indexing + compaction take longer — a caller with a time limit of its own (bench.py) falls back."""
     if not os.path.exists(XAPIAN_REF):
         raise RuntimeError("oracle/_ref/xapian_ref is not built")
     # more writers than ~1/2 of the cores fight each other (measured on the 256-core MI355X host: 254 processes index
@@ -42,15 +43,29 @@ def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, l
         parts.append(d)
         cmd = [XAPIAN_REF, "build_range", d, hex(seed), str(g0), str(g1), str(vocab), str(len_lo), str(len_hi)] + (["nopos"] if nopos else [])
         running.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL))
+    deadline = None if budget_s is None else t0 + budget_s
     for p in running:
-        if p.wait() != 0:
+        try:
+            rc = p.wait(timeout=None if deadline is None else max(0.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            for q in running:
+                if q.poll() is None:
+                    q.kill()
+            shutil.rmtree(parts_dir, ignore_errors=True)
+            raise TimeoutError("indexing %d documents exceeded %.0f s" % (n_docs, budget_s))
+        if rc != 0:
             raise RuntimeError("xapian_ref build_range failed")
     t1 = time.time()
     if len(parts) == 1:
         os.rename(parts[0], outdir)
         info = dict(doccount=n_docs)
     else:
-        out = subprocess.run([XAPIAN_REF, "compact", outdir] + parts, check=True, capture_output=True, text=True).stdout
+        try:
+            out = subprocess.run([XAPIAN_REF, "compact", outdir] + parts, check=True, capture_output=True, text=True,
+                                 timeout=None if deadline is None else max(1.0, deadline - time.time())).stdout
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(parts_dir, ignore_errors=True)
+            raise TimeoutError("indexing + compacting %d documents exceeded %.0f s" % (n_docs, budget_s))
         info = json.loads(out)
     t2 = time.time()
     if not keep_parts:
