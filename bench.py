@@ -12,7 +12,7 @@ Workload (N = 1, BASELINE.json configs[1], "C2"): 10 M-doc / 1 M-term Zipf synth
 256 queries each (4 096 queries; 20 steps ≈ 130 ms of GPU work) AS THE MATCHER HOOK RECEIVES THEM (terms, operator,
 first/maxitems, BM25 parameters, merged statistics): xgm_get_mset_batch_begin = dictionary lookups + BM25Weight::init +
 leaf ordering (xgm_plan_query) → decode → intersect → BM25 → top-k → merge → the hits and headers of EVERY batch copied
-to pinned HOST memory (xgm_batch_end hands them out); up to three batches are in flight, so planning, match and
+to pinned HOST memory (xgm_batch_end hands them out); two batches are in flight (--in-flight), so planning, match and
 download overlap (round 4: rounds 1-3 left the results in HBM).  The default run also times C3 (5-term OR, top-100) and
 C5 (2-3-term PHRASE, top-10) the same way (`other_configs`), each checked against the oracle on 128 queries.  N > 1 is configs[3] scaled ("C4"): the corpus has 10 M × N documents sharded
 N ways exactly like the reference (global doc g → shard (g-1) % N, src/xapian/backends/multi.h:38-73), every rank
@@ -58,7 +58,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batches-per-step", type=int, default=16, help="batches of 256 queries one step submits")
-    ap.add_argument("--in-flight", type=int, default=3, help="batches in flight (xgm_get_mset_batch_begin ... xgm_batch_end)")
+    ap.add_argument("--in-flight", type=int, default=2, help="batches in flight (xgm_get_mset_batch_begin ... xgm_batch_end); measured on the MI355X, round 5: 2 beats 3 by 4-7 %% on C2 (the host needs 0.15 ms per batch, the kernel 0.35: one batch queued behind the running one is enough, a third only adds queue traffic)")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the C3 / C5 sub-legs of the default (C2) line")
     ap.add_argument("--no-hook-parity", action="store_true", help="skip the hook-on == hook-off leg on the reference's own glass index")
     ap.add_argument("--ref-no-positions", action="store_true", help="build the reference index of the headline run WITHOUT positions (faster; C5's reference baseline and hook-parity leg are then skipped)")

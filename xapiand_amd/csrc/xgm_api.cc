@@ -83,6 +83,7 @@ struct XgmScratch {
     void* h_down = nullptr; size_t cap_down = 0;
     void* h_work = nullptr; size_t cap_hwork = 0;     /* pinned copy of the work list + group offsets */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t last_stop = nullptr; /* the completion event the LAST launch of the current batch carries itself (run_class_batch: fused wave kernel), or null */
     hipEvent_t ev_done = nullptr;   /* recorded after an asynchronous call that still uses this scratch */
     bool pending = false;
 };
@@ -1068,6 +1069,17 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         L.hist = s->d_hist;
     }
     if (fused) L.fuse = (const xgm_fuse*)(din + o_fu);
+    /* the wave kernels' dispatch packets carry their events themselves (xgm_launch.h): the profiling pair, and — when the kernel is the
+     * batch's last launch (the fused merge) — the event the download waits for.  XGM_NO_EXT_LAUNCH=1: A/B switch (events recorded around) */
+    static const bool ext_launch = getenv("XGM_NO_EXT_LAUNCH") == nullptr;
+    const bool ext = ext_launch && !dense && (bp.andw || (bp.orw && !bp.orw2));
+    s->last_stop = nullptr;
+    if (ext) {
+        L.ev_start = pe0;
+        L.ev_stop = pe1 ? pe1 : (fused ? s->ev1 : nullptr);
+        if (fused) s->last_stop = L.ev_stop;
+        pe0 = pe1 = nullptr;
+    }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
     if ((rc = dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
               : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
@@ -1211,6 +1223,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     static thread_local std::vector<uint8_t> cls;
     cls.resize(nq);
     uint32_t present = 0;
+    s->last_stop = nullptr;
     for (uint32_t i = 0; i < nq; ++i) { cls[i] = (uint8_t)classify_query(idx, qs[i]); if (count[cls[i]]++ == 0) ++present; }
     if (present <= 1u || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
     /* one launch per class present, all on `stream`; the first uses the caller's scratch, the others take their own
@@ -1232,6 +1245,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         }
         first = false;
     }
+    s->last_stop = nullptr;              /* several launches: the download waits behind the last one (an event recorded in stream order) */
     return rc;
 }
 
@@ -1287,8 +1301,9 @@ static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_
         static const bool copy_in_order = getenv("XGM_COPY_ON_BATCH_STREAM") != nullptr;
         hipError_t e = hipSuccess;
         if (stream != s->stream && !copy_in_order && !s->inorder) {
-            e = hipEventRecord(s->ev1, stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, s->ev1, 0);
+            hipEvent_t after = s->last_stop;                       /* the batch's one launch carries its completion event itself */
+            if (!after) { after = s->ev1; e = hipEventRecord(after, stream); }
+            if (e == hipSuccess) e = hipStreamWaitEvent(s->stream, after, 0);
             if (e == hipSuccess) e = hipMemcpyAsync(s->h_down, s->d_hits, down, hipMemcpyDeviceToHost, s->stream);
             if (e == hipSuccess) e = hipEventRecord(s->ev_done, s->stream);
         } else {

@@ -2431,7 +2431,7 @@ static int launch_andw_inst(const xgm_match_launch& L, size_t smem, hipStream_t 
     auto kern = xgm_andw_kernel<TabT, PHRASE, SIDED, TALLY>;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-    hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
+    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }

@@ -3,6 +3,7 @@
 #define XGM_LAUNCH_H
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "xgm_device.h"
 
@@ -28,7 +29,18 @@ struct xgm_match_launch {
     xgm_cand* cand;                   /* device, [n_work][k_stride]                               */
     xgm_group_hdr* ghdr;              /* device, [n_work]                                         */
     const xgm_fuse* fuse = nullptr;   /* xgm_andw_kernel only: device copy of the parameters with which the kernel writes the final hits itself (no merge launch) */
+    /* wave kernels: events carried by the kernel's OWN dispatch packet (hipExtLaunchKernel) — its start / its completion — instead of
+     * hipEventRecord()s around it: every recorded event is one more barrier packet the command processor works through between two match
+     * kernels of consecutive batches (measured: DESIGN.md 11) */
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
 };
+
+/* launch with the events of L (if any) attached to the dispatch */
+#define XGM_LAUNCH_TIMED(L_, kern, grid, block, smem, stream, ...)                                                                          \
+    do {                                                                                                                                \
+        if ((L_).ev_start || (L_).ev_stop) hipExtLaunchKernelGGL(kern, grid, block, (uint32_t)(smem), stream, (L_).ev_start, (L_).ev_stop, 0u, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__);                                                         \
+    } while (0)
 
 size_t xgm_match_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, bool phrase, uint32_t cap, bool wide, uint32_t stripes_per_group);
 int xgm_launch_match(const xgm_match_launch& L, hipStream_t stream);

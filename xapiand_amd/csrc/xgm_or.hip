@@ -1762,7 +1762,7 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
         auto kern = xgm_orw_kernel<TABT, TL, false>;                                                                                 \
         static std::atomic<size_t> seen{0};                                                                                          \
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
+        XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
                            L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
     } while (0)
 #define ORW_LAUNCH_FLAT(TL)                                                                                                          \
@@ -1770,7 +1770,7 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
         auto kern = xgm_orw_kernel<uint8_t, TL, true>;                                                                               \
         static std::atomic<size_t> seen{0};                                                                                          \
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
-        hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
+        XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
                            L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
     } while (0)
     /* L.tally: the instantiation that also fills the traffic tallies of xgm_group_hdr (measurement only) */
