@@ -444,6 +444,12 @@ int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, co
 int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,
                           xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
 
+/* xgm_search_sorted_batch with that spy on every search: counts [nq][n_counts], one row per query (Xapiand's `_aggregations` over a field
+ * ride on every search of a dashboard: many HTTP threads, the same sort, the same spy slot — one launch).  The same caveat on what a
+ * spy sees applies per query. */
+int xgm_search_sorted_spy_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                                uint32_t* hit_ord, xgm_result_hdr* hdrs, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
+
 /* ... with Enquire::set_collapse_key(collapse_slot, collapse_max) in force (sort == NULL: ranked by relevance): of the documents
  * sharing a value in the collapse slot only the best collapse_max under the ranking stay; documents without a value are never
  * collapsed.  hit_collapse_ord[i] = ordinal of hit i's collapse key in that slot's column (MSetIterator::get_collapse_key),

@@ -89,6 +89,20 @@ def test_sorted_batch_equals_single_searches_and_the_oracle(built, tmp_path):
                 assert hdr.matches_exact == whdr.matches
                 checked += 1
     assert checked >= (9 if QUICK else 36)
+    # ... and with a ValueCountMatchSpy riding on every search of the batch: the page of the plain batch, the counts of the single spied search
+    from xapiand_amd.enquire import search_sorted_spy, search_sorted_spy_batch
+    nd = len(values[1])
+    plain = search_sorted_batch(db, plans, MODES["V"], 0, False)
+    spied = search_sorted_spy_batch(db, plans, MODES["V"], 0, False, 1, nd)
+    totals = 0
+    for qi, (p, (got, hdr), (sgot, shdr, counts)) in enumerate(zip(plans, plain, spied)):
+        assert sgot == got and shdr.matches_exact == hdr.matches_exact, base[qi]
+        assert sum(counts) == hdr.matches_exact, base[qi]
+        if qi % 3 == 0:
+            _, _, one_counts = search_sorted_spy(db, p, MODES["V"], 0, False, 1, nd)
+            assert counts == one_counts, base[qi]
+        totals += sum(counts)
+    assert totals > 0
     db.close()
     c.close()
 

@@ -111,6 +111,8 @@ _API = [
     ("xgm_index_attach_column", C.c_int, [C.c_void_p, C.c_char_p]),
     ("xgm_search_sorted", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), _P(Hit), _P(C.c_uint32), _P(ResultHdr)]),
     ("xgm_search_sorted_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, _P(SortSpec), C.c_uint32, _P(Hit), _P(C.c_uint32), _P(ResultHdr)]),
+    ("xgm_search_sorted_spy_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, _P(SortSpec), C.c_uint32, _P(Hit), _P(C.c_uint32), _P(ResultHdr),
+                                     C.c_uint32, _P(C.c_uint32), C.c_uint32]),
     ("xgm_search_collapsed", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), C.c_uint32, C.c_uint32, _P(Hit), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32),
                                        _P(ResultHdr), _P(C.c_uint64)]),
     ("xgm_search_sorted_spy", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), _P(Hit), _P(C.c_uint32), _P(ResultHdr), C.c_uint32, _P(C.c_uint32), C.c_uint32]),

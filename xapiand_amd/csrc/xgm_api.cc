@@ -1603,19 +1603,26 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
 /* nq searches under ONE sort in ONE launch (include/xgm.h: xgm_search_sorted_batch): the workgroup kernel's units of every query go up in one
  * work list (plan_batch), every unit leaves its best k under the sort, the host merges each query's units — what xgm_search_sorted does
  * for one query, without a launch, an upload, a download and a synchronisation per query. */
-extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
-                                       uint32_t* hit_ord, xgm_result_hdr* hdrs) {
+static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                             uint32_t* hit_ord, xgm_result_hdr* hdrs, int spy_slot, uint32_t* counts, uint32_t n_counts) {
     if (!idx || !qs || !sort || !hits || !hdrs || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
     if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
     const uint32_t mode = sort->sort_by;
     const bool reverse = sort->reverse != 0;
     const uint32_t* d_ord = nullptr;
+    const uint32_t* d_spy_ord = nullptr;
     {
         std::lock_guard<std::mutex> lk(idx->columns_mu);
         auto it = idx->columns.find(sort->slot);
         if (it == idx->columns.end()) return XGM_UNSUPPORTED;
         d_ord = (const uint32_t*)it->second.first;
+        if (spy_slot >= 0) {
+            auto sp = idx->columns.find((uint32_t)spy_slot);
+            if (sp == idx->columns.end()) return XGM_UNSUPPORTED;
+            if (!counts || n_counts != sp->second.second + 1u) return xgm_set_error(XGM_E_INVALID, "n_counts %u, the spy column has %u distinct values", n_counts, sp->second.second);
+            d_spy_ord = (const uint32_t*)sp->second.first;
+        }
     }
     int rc = use_device(idx->device);
     if (rc) return rc;
@@ -1636,14 +1643,17 @@ extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint
     const size_t o_wk = o_q + b_q, b_wk = ((size_t)n_work * sizeof(xgm_work) + 15) & ~(size_t)15;
     const size_t up_bytes = o_wk + b_wk;
     const size_t o_gh = up_bytes, b_gh = (size_t)n_work * sizeof(xgm_group_hdr);
-    const size_t o_cd = o_gh + b_gh, b_cd = (size_t)n_work * kc * sizeof(xgm_cand_sorted);
-    const size_t total = o_cd + b_cd;
+    const size_t o_cd = o_gh + b_gh, b_cd = ((size_t)n_work * kc * sizeof(xgm_cand_sorted) + 15) & ~(size_t)15;
+    const size_t o_ct = o_cd + b_cd, b_ct = d_spy_ord ? (size_t)nq * n_counts * 4 : 0;          /* the spy: one row of counts per query */
+    const size_t total = o_ct + b_ct;
     if ((rc = grow(&sc->d_sorted, &sc->cap_sorted, total))) return rc;
     if ((rc = grow_pinned(&sc->h_sorted, &sc->cap_hsorted, total))) return rc;
     unsigned char* hb = (unsigned char*)sc->h_sorted;
     memcpy(hb + o_q, dq.data(), (size_t)nq * sizeof(xgm_dev_query));
     memcpy(hb + o_wk, bp.work.data(), (size_t)n_work * sizeof(xgm_work));
     HIP_TRY(hipMemcpyAsync(sc->d_sorted, hb, up_bytes, hipMemcpyHostToDevice, stream));
+    uint32_t* d_counts = d_spy_ord ? (uint32_t*)(sc->d_sorted + o_ct) : nullptr;
+    if (d_counts) HIP_TRY(hipMemsetAsync(d_counts, 0, b_ct, stream));
     xgm_match_launch L;
     L.seg = idx->view;
     L.queries = (xgm_dev_query*)(sc->d_sorted + o_q);
@@ -1652,9 +1662,11 @@ extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint
     L.phrase = bp.phrase; L.wide = bp.wide; L.sided = 0;
     L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
     idx->last_kernel = "xgm_match_sorted_kernel";
-    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, nullptr, nullptr, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream))) return rc;
+    L.spy_stride = d_counts ? n_counts : 0u;
+    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream))) return rc;
     HIP_TRY(hipMemcpyAsync(hb + o_gh, sc->d_sorted + o_gh, total - o_gh, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (d_counts) memcpy(counts, hb + o_ct, b_ct);
     const xgm_group_hdr* gh = (const xgm_group_hdr*)(hb + o_gh);
     const xgm_cand_sorted* cand = (const xgm_cand_sorted*)(hb + o_cd);
     const bool use_x = mode == XGM_SORT_VALUE_RELEVANCE || mode == XGM_SORT_RELEVANCE_VALUE;
@@ -1695,6 +1707,18 @@ extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint
         if (max_d != UINT32_MAX) { memcpy(&hdr->max_attained, &max_w, 8); hdr->max_weight_subqs_matched = max_m; }
     }
     return XGM_OK;
+}
+
+extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                                       uint32_t* hit_ord, xgm_result_hdr* hdrs) {
+    return sorted_batch_core(idx, qs, nq, sort, k_stride, hits, hit_ord, hdrs, -1, nullptr, 0);
+}
+
+/* ... every search with a ValueCountMatchSpy on spy_slot (include/xgm.h: xgm_search_sorted_spy_batch): counts [nq][n_counts] */
+extern "C" int xgm_search_sorted_spy_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
+                                           uint32_t* hit_ord, xgm_result_hdr* hdrs, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts) {
+    if (!counts) return xgm_set_error(XGM_E_INVALID, "null argument");
+    return sorted_batch_core(idx, qs, nq, sort, k_stride, hits, hit_ord, hdrs, (int)spy_slot, counts, n_counts);
 }
 
 extern "C" int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* sort, xgm_hit* hits, uint32_t* hit_ord,

@@ -2364,7 +2364,7 @@ int xgm_launch_match_sorted(const xgm_match_launch& L, const uint32_t* ord, uint
         if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;                                         \
         hipLaunchKernelGGL(kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.stripes_per_group,     \
                            L.tab_terms, L.cap, L.k_stride, ord, mode, reverse, spy_ord, spy_counts, cord, cmax, cand, L.ghdr, \
-                           all_keys, all_vals, all_count, all_cap, L.sub_bits);                                \
+                           all_keys, all_vals, all_count, all_cap, L.sub_bits, L.spy_stride);                  \
     } while (0)
     if (L.wide) { if (L.phrase) XGM_LAUNCH(uint16_t, true); else XGM_LAUNCH(uint16_t, false); }
     else { if (L.phrase) XGM_LAUNCH(uint8_t, true); else XGM_LAUNCH(uint8_t, false); }

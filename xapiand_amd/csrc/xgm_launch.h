@@ -33,6 +33,7 @@ struct xgm_match_launch {
      * hipEventRecord()s around it: every recorded event is one more barrier packet the command processor works through between two match
      * kernels of consecutive batches (measured: DESIGN.md 11) */
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    uint32_t spy_stride = 0;          /* xgm_match_sorted_kernel with a spy in a BATCH: counts of query qi at spy_counts + qi * spy_stride (0: one query, one row) */
 };
 
 /* launch with the events of L (if any) attached to the dispatch */

@@ -427,6 +427,22 @@ def search_sorted_batch(db, plans, sort_by, slot, reverse=False):
     return [([(hits[q * ks + i].docid, hits[q * ks + i].weight, hits[q * ks + i].subqs_matched, ords[q * ks + i]) for i in range(hdrs[q].n_hits)], hdrs[q]) for q in range(nq)]
 
 
+def search_sorted_spy_batch(db, plans, sort_by, slot, reverse, spy_slot, n_distinct):
+    """xgm_search_sorted_spy_batch: search_sorted_batch with a ValueCountMatchSpy on spy_slot for every query → [(hits, hdr, counts)]."""
+    nq = len(plans)
+    ks = max(1, max(p.first + p.maxitems for p in plans))
+    qs = (_lib.Query * nq)(*plans)
+    hits = (_lib.Hit * (nq * ks))()
+    ords = (C.c_uint32 * (nq * ks))()
+    hdrs = (_lib.ResultHdr * nq)()
+    nc = n_distinct + 1
+    counts = (C.c_uint32 * (nq * nc))()
+    spec = _lib.SortSpec(sort_by, slot, 1 if reverse else 0, 0)
+    _lib.check(_lib.lib().xgm_search_sorted_spy_batch(db._h, qs, nq, C.byref(spec), ks, hits, ords, hdrs, spy_slot, counts, nc))
+    return [([(hits[q * ks + i].docid, hits[q * ks + i].weight, hits[q * ks + i].subqs_matched, ords[q * ks + i]) for i in range(hdrs[q].n_hits)], hdrs[q],
+             list(counts[q * nc:(q + 1) * nc])) for q in range(nq)]
+
+
 def search_sorted_spy(db, planned, sort_by, slot, reverse, spy_slot, n_distinct):
     """xgm_search_sorted_spy: search_sorted plus a ValueCountMatchSpy on spy_slot (a column with n_distinct values attached).
     Returns (hits, hdr, counts) with counts[o] = matching documents whose value has ordinal o (0 = no value)."""
