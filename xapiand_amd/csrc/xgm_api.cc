@@ -1020,9 +1020,17 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     }
     const uint64_t t_cp = now_ns();
     g_host_ns[4] += t_cp - t_st;
+    bool hist_zeroed = false;
     if (stream != s->stream && !s->inorder) {
         /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
          * kernels of the previous batch still running on the caller's stream */
+        if (bp.orw || (bp.andw && bp.phrase)) {
+            /* the query-wide histogram is zeroed here, ahead of the upload on the scratch's stream, not between two match kernels on the
+             * caller's (the scratch is this batch's alone: whatever used it before has completed — scratch_acquire) */
+            if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
+            HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, s->stream));
+            hist_zeroed = true;
+        }
         HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipEventRecord(s->ev0, s->stream));
         HIP_TRY(hipStreamWaitEvent(stream, s->ev0, 0));
@@ -1064,8 +1072,10 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw || (bp.andw && bp.phrase)) {
-        if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
-        HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
+        if (!hist_zeroed) {
+            if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
+            HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
+        }
         L.hist = s->d_hist;
     }
     if (fused) L.fuse = (const xgm_fuse*)(din + o_fu);
