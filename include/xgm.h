@@ -462,6 +462,13 @@ int xgm_search_collapsed(xgm_index* idx, const xgm_query* q, const xgm_sort_spec
                          xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord, uint32_t* hit_collapse_count, xgm_result_hdr* hdr,
                          uint64_t* collapsed_lower_bound);
 
+/* nq searches under ONE collapse key (and one sort, or NULL = by relevance) in one launch: the per-hit arrays are [nq][k_stride],
+ * hdrs and collapsed_lower_bound [nq]; same answers as xgm_search_collapsed for each.  XGM_UNSUPPORTED if any query is, or if a row of
+ * per-key counters for every query would not fit (a collapse column of very many distinct keys under a large batch). */
+int xgm_search_collapsed_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t collapse_slot,
+                               uint32_t collapse_max, uint32_t k_stride, xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord,
+                               uint32_t* hit_collapse_count, xgm_result_hdr* hdrs, uint64_t* collapsed_lower_bound);
+
 /* EVERY matching document of a planned query — no page, no pruning — in ASCENDING DOCID order, each with its weight and the number
  * of weighted leaves matching it: the sequence the reference's matcher loop is shown by its posting-list tree (Matcher::get_local_mset,
  * matcher/matcher.cc:482-536) before ProtoMSet, the collapser, the spies or a cut-off look at it.  The plan's first / maxitems /

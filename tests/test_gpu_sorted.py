@@ -103,6 +103,18 @@ def test_sorted_batch_equals_single_searches_and_the_oracle(built, tmp_path):
             assert counts == one_counts, base[qi]
         totals += sum(counts)
     assert totals > 0
+    # ... and under a collapse key (by relevance, and under a value sort): what xgm_search_collapsed gives for each
+    from xapiand_amd.enquire import search_collapsed, search_collapsed_batch
+    collapsed_somewhere = 0
+    for sort_by, slot, cmax in ((None, 0, 1), (MODES["V"], 0, 2)):
+        res = search_collapsed_batch(db, plans, 2, cmax, sort_by, slot, False)
+        assert len(res) == len(plans)
+        for qi, (p, (got, hdr, lb)) in enumerate(zip(plans, res)):
+            one, ohdr, olb = search_collapsed(db, p, 2, cmax, sort_by, slot, False)
+            assert got == one and lb == olb, (base[qi], sort_by, cmax)
+            assert (hdr.n_hits, hdr.matches_exact, hdr.max_attained) == (ohdr.n_hits, ohdr.matches_exact, ohdr.max_attained), base[qi]
+            collapsed_somewhere += sum(1 for r in got if r[5])
+    assert collapsed_somewhere > 0
     db.close()
     c.close()
 

@@ -116,6 +116,8 @@ _API = [
     ("xgm_search_collapsed", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), C.c_uint32, C.c_uint32, _P(Hit), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint32),
                                        _P(ResultHdr), _P(C.c_uint64)]),
     ("xgm_search_sorted_spy", C.c_int, [C.c_void_p, _P(Query), _P(SortSpec), _P(Hit), _P(C.c_uint32), _P(ResultHdr), C.c_uint32, _P(C.c_uint32), C.c_uint32]),
+    ("xgm_search_collapsed_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, _P(SortSpec), C.c_uint32, C.c_uint32, C.c_uint32, _P(Hit), _P(C.c_uint32),
+                                    _P(C.c_uint32), _P(C.c_uint32), _P(ResultHdr), _P(C.c_uint64)]),
     ("xgm_segment_refresh_from_glass", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_char_p]),
     ("xgm_glass_export_raw", C.c_int, [C.c_char_p, C.c_char_p]),
     ("xgm_glass_info", C.c_int, [C.c_char_p, _P(C.c_uint64), _P(C.c_uint32), _P(C.c_uint32), _P(C.c_uint64)]),

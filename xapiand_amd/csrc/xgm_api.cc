@@ -1613,20 +1613,39 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
 /* nq searches under ONE sort in ONE launch (include/xgm.h: xgm_search_sorted_batch): the workgroup kernel's units of every query go up in one
  * work list (plan_batch), every unit leaves its best k under the sort, the host merges each query's units — what xgm_search_sorted does
  * for one query, without a launch, an upload, a download and a synchronisation per query. */
+/* collapse_slot >= 0 (sorted_core's counterpart for a batch): the kernel collapses inside every unit, the merge below once more per query; the
+ * matches per collapse key — the spy mechanism on the collapse column, one row per query — give the collapse counts and lower bounds */
 static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
-                             uint32_t* hit_ord, xgm_result_hdr* hdrs, int spy_slot, uint32_t* counts, uint32_t n_counts) {
-    if (!idx || !qs || !sort || !hits || !hdrs || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+                             uint32_t* hit_ord, xgm_result_hdr* hdrs, int spy_slot, uint32_t* counts, uint32_t n_counts,
+                             int collapse_slot = -1, uint32_t cmax = 0, uint32_t* hit_cord = nullptr, uint32_t* hit_ccount = nullptr, uint64_t* collapsed_lb = nullptr) {
+    if (!idx || !qs || !hits || !hdrs || nq == 0 || (!sort && collapse_slot < 0)) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
-    if (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
-    const uint32_t mode = sort->sort_by;
-    const bool reverse = sort->reverse != 0;
+    if (sort && (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE)) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
+    if (collapse_slot >= 0 && (cmax == 0 || spy_slot >= 0)) return xgm_set_error(XGM_E_INVALID, "collapse_max 0, or a spy together with a collapse key");
+    const uint32_t mode = sort ? sort->sort_by : 4u;
+    const bool reverse = sort && sort->reverse != 0;
     const uint32_t* d_ord = nullptr;
     const uint32_t* d_spy_ord = nullptr;
+    const uint32_t* d_cord = nullptr;
+    std::vector<uint32_t> key_counts;                         /* collapse: [nq][n_counts] matches per key */
     {
         std::lock_guard<std::mutex> lk(idx->columns_mu);
-        auto it = idx->columns.find(sort->slot);
-        if (it == idx->columns.end()) return XGM_UNSUPPORTED;
-        d_ord = (const uint32_t*)it->second.first;
+        if (sort) {
+            auto it = idx->columns.find(sort->slot);
+            if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+            d_ord = (const uint32_t*)it->second.first;
+        }
+        if (collapse_slot >= 0) {
+            auto it = idx->columns.find((uint32_t)collapse_slot);
+            if (it == idx->columns.end()) return XGM_UNSUPPORTED;
+            /* a row of counters per query: a column of many distinct keys under a large batch is left to single searches */
+            if (((size_t)it->second.second + 1u) * nq > ((size_t)64 << 20)) return XGM_UNSUPPORTED;
+            d_cord = (const uint32_t*)it->second.first;
+            d_spy_ord = d_cord;
+            n_counts = it->second.second + 1u;
+            key_counts.assign((size_t)n_counts * nq, 0u);
+            counts = key_counts.data();
+        }
         if (spy_slot >= 0) {
             auto sp = idx->columns.find((uint32_t)spy_slot);
             if (sp == idx->columns.end()) return XGM_UNSUPPORTED;
@@ -1673,7 +1692,7 @@ static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, c
     L.cand = nullptr; L.ghdr = (xgm_group_hdr*)(sc->d_sorted + o_gh);
     idx->last_kernel = "xgm_match_sorted_kernel";
     L.spy_stride = d_counts ? n_counts : 0u;
-    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, nullptr, 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream))) return rc;
+    if ((rc = xgm_launch_match_sorted(L, d_ord, mode, reverse ? 1u : 0u, d_spy_ord, d_counts, d_cord, d_cord ? cmax : 0u, (xgm_cand_sorted*)(sc->d_sorted + o_cd), stream))) return rc;
     HIP_TRY(hipMemcpyAsync(hb + o_gh, sc->d_sorted + o_gh, total - o_gh, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (d_counts) memcpy(counts, hb + o_ct, b_ct);
@@ -1699,6 +1718,22 @@ static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, c
             if (use_x && a.kx != b.kx) return a.kx > b.kx;
             return a.did < b.did;
         });
+        const uint32_t* kc_q = d_cord ? counts + (size_t)qi * n_counts : nullptr;        /* this query's matches per collapse key */
+        if (d_cord) {
+            /* the merged ranking collapsed once more: of every key the first cmax stay */
+            std::vector<uint32_t> kept_of(n_counts, 0u);
+            size_t keep = 0;
+            for (const xgm_cand_sorted& c : all) {
+                if (c.cord >= n_counts) return xgm_set_error(XGM_E_DEVICE, "sorted batch: collapse ordinal %u beyond the column", c.cord);
+                if (c.cord == 0u || kept_of[c.cord]++ < cmax) all[keep++] = c;
+            }
+            all.resize(keep);
+            if (collapsed_lb) {
+                uint64_t lb = kc_q[0];                                       /* Collapser::get_matches_lower_bound */
+                for (uint32_t o = 1; o < n_counts; ++o) lb += std::min<uint32_t>(kc_q[o], cmax);
+                collapsed_lb[qi] = lb;
+            }
+        }
         const uint32_t n = (uint32_t)std::min<size_t>(k, all.size());
         xgm_hit* out = hits + (size_t)qi * k_stride;
         for (uint32_t i = 0; i < n; ++i) {
@@ -1707,7 +1742,9 @@ static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, c
             out[i].docid = all[i].did;
             out[i].subqs_matched = all[i].subqs;
             memcpy(&out[i].weight, &wbits, 8);
-            if (hit_ord) hit_ord[(size_t)qi * k_stride + i] = reverse ? okey : ~okey;
+            if (hit_ord) hit_ord[(size_t)qi * k_stride + i] = sort ? (reverse ? okey : ~okey) : 0u;
+            if (hit_cord) hit_cord[(size_t)qi * k_stride + i] = all[i].cord;
+            if (hit_ccount) hit_ccount[(size_t)qi * k_stride + i] = (d_cord && all[i].cord && kc_q[all[i].cord] > cmax) ? kc_q[all[i].cord] - cmax : 0u;
         }
         xgm_result_hdr* hdr = &hdrs[qi];
         memset(hdr, 0, sizeof *hdr);
@@ -1722,6 +1759,14 @@ static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, c
 extern "C" int xgm_search_sorted_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
                                        uint32_t* hit_ord, xgm_result_hdr* hdrs) {
     return sorted_batch_core(idx, qs, nq, sort, k_stride, hits, hit_ord, hdrs, -1, nullptr, 0);
+}
+
+/* ... every search under Enquire::set_collapse_key(collapse_slot, collapse_max) (include/xgm.h: xgm_search_collapsed_batch) */
+extern "C" int xgm_search_collapsed_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t collapse_slot,
+                                          uint32_t collapse_max, uint32_t k_stride, xgm_hit* hits, uint32_t* hit_ord, uint32_t* hit_collapse_ord,
+                                          uint32_t* hit_collapse_count, xgm_result_hdr* hdrs, uint64_t* collapsed_lower_bound) {
+    return sorted_batch_core(idx, qs, nq, sort, k_stride, hits, hit_ord, hdrs, -1, nullptr, 0, (int)collapse_slot, collapse_max, hit_collapse_ord,
+                             hit_collapse_count, collapsed_lower_bound);
 }
 
 /* ... every search with a ValueCountMatchSpy on spy_slot (include/xgm.h: xgm_search_sorted_spy_batch): counts [nq][n_counts] */

@@ -470,6 +470,23 @@ def search_collapsed(db, planned, collapse_slot, collapse_max, sort_by=None, slo
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched, ords[i], cords[i], ccounts[i]) for i in range(hdr.n_hits)], hdr, clb.value
 
 
+def search_collapsed_batch(db, plans, collapse_slot, collapse_max, sort_by=None, slot=0, reverse=False):
+    """xgm_search_collapsed_batch: every planned query under one collapse key (and one sort or relevance) in one launch →
+    [([(docid, weight, subqs, sort ordinal, collapse ordinal, collapse count)], hdr, collapsed lower bound)]."""
+    nq = len(plans)
+    ks = max(1, max(p.first + p.maxitems for p in plans))
+    qs = (_lib.Query * nq)(*plans)
+    hits = (_lib.Hit * (nq * ks))()
+    ords, cords, ccounts = (C.c_uint32 * (nq * ks))(), (C.c_uint32 * (nq * ks))(), (C.c_uint32 * (nq * ks))()
+    hdrs = (_lib.ResultHdr * nq)()
+    clb = (C.c_uint64 * nq)()
+    spec = _lib.SortSpec(sort_by, slot, 1 if reverse else 0, 0) if sort_by else None
+    _lib.check(_lib.lib().xgm_search_collapsed_batch(db._h, qs, nq, C.byref(spec) if spec else None, collapse_slot, collapse_max, ks, hits, ords, cords,
+                                                     ccounts, hdrs, clb))
+    return [([(hits[q * ks + i].docid, hits[q * ks + i].weight, hits[q * ks + i].subqs_matched, ords[q * ks + i], cords[q * ks + i], ccounts[q * ks + i])
+              for i in range(hdrs[q].n_hits)], hdrs[q], clb[q]) for q in range(nq)]
+
+
 def search_all(db, planned, cap=None):
     """xgm_search_all: EVERY matching document of one planned query in ascending docid order — the sequence the reference's matcher
     loop is shown (matcher.cc:482-536).  Returns ([(docid, weight, subqs)], hdr); cap defaults to the plan's own upper bound."""
