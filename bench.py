@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--required", type=int, default=1, help="AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND")
     ap.add_argument("--topk", type=int, default=10)
+    ap.add_argument("--replay", choices=("none", "frozen"), default="none",
+                    help="PHRASE: frozen = every query carries XGM_REPLAY_BATCH_FROZEN — the REFERENCE's own page (SelectPostList's frozen weight) at batch throughput")
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -109,15 +111,19 @@ def workload_name(args, world, n_docs_global, k):
 class Leg:
     """One workload on the resident index: its query pool as the hook would receive it, cut into batches."""
 
-    def __init__(self, searcher, op, terms, required, k, n_docs_global, vocab, n_batches):
+    def __init__(self, searcher, op, terms, required, k, n_docs_global, vocab, n_batches, replay=0):
         import helpers as H
         from xapiand_amd import Query, _lib
-        self.op, self.terms, self.required, self.k = op, terms, required, k
+        self.op, self.terms, self.required, self.k, self.replay = op, terms, required, k, replay
         self.sided = op in ("AND_NOT", "AND_MAYBE", "FILTER")
         self.pool = H.bench_pool(op, terms, required, n_docs_global, vocab, n=100 + n_batches * BATCH, seed=QUERY_SEED, maxitems=k)
         qobjs = [Query(q["op"], q["terms"], n_required=required if self.sided else 0) for q in self.pool]
         self.descs, self.gstats = searcher.describe(qobjs, 0, k)       # what the hook is handed per get_mset
         self.plans = searcher.prepare(qobjs, 0, k)                     # bookkeeping only (algorithmic bytes, parity leg)
+        if replay:                                                     # XGM_REPLAY_BATCH_* bits: the reference's own collation inside the batch
+            for i in range(len(self.pool)):
+                self.descs[i].replay = replay
+                self.plans[i].replay = replay
         self._keep = searcher._keep                                   # (the descriptions' term bytes)
         n = len(self.pool)
 
@@ -388,7 +394,7 @@ def parity_vs_port(db, leg, n=128, snapshot=None):
     sample = leg.timed_pool[:n]
     ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]], positions=leg.op == "PHRASE")
     ora.warm()
-    want = H.oracle_search_batch(ora, sample, 0, leg.k)
+    want = H.oracle_search_batch(ora, sample, 0, leg.k, reference_select_bug=bool(leg.replay))      # (replay bits: the oracle in reference mode — SelectPostList's frozen weight restated)
     db.set_stream(0)
     k = leg.k
     qs = (_lib.Query * n)(*leg.timed_plans[:n])
@@ -582,7 +588,8 @@ def main():
     searcher = ShardedSearcher(db, rank, world, dev)
     L = _lib.lib()
     n_pool_batches = max(4, args.batches_per_step)
-    leg = Leg(searcher, args.op, args.terms, args.required, k, n_docs_global, args.vocab, n_pool_batches)
+    leg = Leg(searcher, args.op, args.terms, args.required, k, n_docs_global, args.vocab, n_pool_batches,
+              replay=_lib.XGM_REPLAY_BATCH_FROZEN if (args.replay == "frozen" and args.op == "PHRASE") else 0)
     m = measure(db, searcher, leg, args, world, rank, dev, args.steps, args.warmup)
     n_timed = len(leg.timed_pool)
 

@@ -275,6 +275,8 @@ typedef struct {
     uint32_t wqf[XGM_MAX_TERMS];          /* within-query frequency of terms[i] (QueryTerm::get_wqf); 0 = 1         */
     xgm_tree_op tree[XGM_MAX_TREE];
     double tree_scale[XGM_MAX_TREE];      /* XGM_T_SCALE ops: the factor                                            */
+    uint32_t replay;                      /* XGM_REPLAY_BATCH_* bits: answer this query as the reference's own collation does (copied into the plan) */
+    uint32_t reserved;
 } xgm_query_desc;
 
 /* Collection statistics merged over all shards of the index, i.e. what Enquire::add_prepared_mset
@@ -326,8 +328,20 @@ typedef struct {
     /* PostList::get_termfreq_min / _est / _max of the tree the reference builds for this query on this shard — the
      * static inputs of MSet::get_matches_lower_bound / _estimated / _upper_bound (protomset.h:484-619; xgm_mset_bounds) */
     uint32_t est_min, est_est, est_max;
-    uint32_t reserved2;
+    /* XGM_REPLAY_BATCH_* bits (0 = none): the batch entry points answer this query as the reference's own collation would — see below */
+    uint32_t replay;
 } xgm_query;
+
+/* The reference-identical answer INSIDE a batch (xgm_search_batch*, xgm_get_mset_batch*, the dispatcher of xgm_index_set_batching): what
+ * xgm_search_replay gives one query at a time, at batch throughput.
+ *   XGM_REPLAY_BATCH_FROZEN   OP_PHRASE / OP_NEAR: the page, weights and max_attained of the REFERENCE — SelectPostList's frozen weight
+ *                             included (matcher/selectpostlist.cc:28-55): the query's units list their first matches in docid order with
+ *                             their successors in the conjunction, one wave per query replays ProtoMSet over them (xgm_frozen.hip).
+ *                             hdr->matches_exact may be a lower bound (units stop listing early).  Ignored on other operators.  Queries
+ *                             the listing kernel does not take (terms without probe containers / flat arrays, > 4 terms, a page > 64,
+ *                             check_at_least beyond the page) are answered by xgm_search_replay when the batch is collected: same rows.
+ * xgm_batch_known (below) hands out ProtoMSet's known_matching_docs per query where a mode computed it. */
+#define XGM_REPLAY_BATCH_FROZEN 1u
 
 
 #define XGM_N_AND 1
@@ -537,6 +551,11 @@ int xgm_search_batch_begin(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_
 int xgm_get_mset_batch_begin(xgm_index*, const xgm_query_desc* descs, const xgm_global_stats* gs, uint32_t nq, uint32_t k_stride,
                              xgm_inflight** out);
 int xgm_batch_end(xgm_inflight*, const xgm_hit** hits, const xgm_result_hdr** hdrs);
+/* After xgm_batch_end: *known = [nq] ProtoMSet's known_matching_docs of the queries that carried XGM_REPLAY_BATCH_* bits (0 for the others), valid until
+ * xgm_batch_release; XGM_KNOWN_LOWER_BOUND set where the figure is a lower bound (a frozen-weight page whose units stopped listing early).
+ * *known = NULL when no query of the batch asked for a replay. */
+#define XGM_KNOWN_LOWER_BOUND (1ull << 63)
+int xgm_batch_known(xgm_inflight*, const uint64_t** known);
 int xgm_batch_poll(xgm_inflight*);
 void xgm_batch_release(xgm_inflight*);
 
@@ -641,6 +660,9 @@ int xgm_debug_host_ns(uint64_t* out8);
 
 /* Diagnostics: out2 = {xgm_search_replay calls walked by one workgroup, calls walked by segments in parallel} of this process. */
 int xgm_debug_replay_info(uint64_t* out2);
+/* Diagnostics: out3 = {rows with XGM_REPLAY_BATCH_* bits the listing kernel took, rows it declined on the device, rows answered by xgm_search_replay when their
+ * batch was collected} of this process. */
+int xgm_debug_batch_replay_info(uint64_t* out3);
 /* Diagnostics: out3 = {batches the dispatcher launched, requests it served, max_batch}. */
 int xgm_debug_batching_info(const xgm_index*, uint64_t* out3);
 /* Diagnostics / bench.py's server leg: n_threads host threads, each answering per_thread queries one at a time through

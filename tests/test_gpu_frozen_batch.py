@@ -1,0 +1,86 @@
+"""The reference-identical answer of positional queries INSIDE a batch (include/xgm.h, XGM_REPLAY_BATCH_FROZEN): xgm_andw_list_kernel's units
+list their first matches in docid order with their successors in the conjunction, xgm_frozen_finish_kernel replays ProtoMSet +
+SelectPostList's frozen weight over them (protomset.h:340-400, selectpostlist.cc:28-55).  Checked against (a) xgm_search_replay, the
+one-query-per-call form that walks the WHOLE match (itself pinned to the compiled reference through the hook tests), (b) the oracle's
+reference mode (pinned to the compiled reference, tests/test_oracle_vs_reference.py).  Also runs under the CPU emulation (tests/test_emu.py)."""
+import ctypes as C
+import os
+
+import pytest
+
+import helpers as H
+from xapiand_amd import Database, Query, _lib
+from xapiand_amd.enquire import plan, search_batch, search_batch_replay, search_replay, REPLAY_FROZEN_WEIGHT
+
+pytestmark = [pytest.mark.gpu]
+
+QUICK = bool(os.environ.get("XGM_EMU_QUICK"))
+LB = _lib.XGM_KNOWN_LOWER_BOUND
+
+
+def replay_info():
+    info = (C.c_uint64 * 3)()
+    _lib.lib().xgm_debug_batch_replay_info(info)
+    return list(info)
+
+
+@pytest.mark.parametrize("stripe_bits", [0, 10])
+def test_batch_frozen_equals_the_per_query_replay_and_the_reference(built, tmp_path, stripe_bits):
+    n_docs, vocab = (3000, 300) if QUICK else (40000, 3000)             # (a small vocabulary: phrases with hundreds of matches)
+    c = H.Corpus(n_docs, vocab)
+    db = Database(c.build_segment(str(tmp_path / "f.seg"), stripe_bits=stripe_bits))
+    n = (lambda full, quick: quick if QUICK else full)
+    qs = (H.gen_phrase_queries(n(40, 6), n_docs, vocab, seed=281) + H.gen_phrase_queries(n(12, 2), n_docs, vocab, seed=282, window_extra=3) +
+          H.gen_phrase_queries(n(12, 2), n_docs, vocab, seed=283, window_extra=4, op="NEAR") +
+          H.gen_phrase_queries(n(10, 2), n_docs, vocab, seed=284, lengths=(4,)) +
+          H.gen_phrase_queries(n(6, 1), n_docs, vocab, seed=285, lengths=(5, 6)))          # (> 4 terms: no LIST body — answered when the batch is collected)
+    shapes = [(0, 10, 0), (0, 3, 0), (2, 5, 0), (0, 1, 0), (0, 64, 0), (0, 100, 0), (0, 10, 25), (0, 10, 10 ** 6)]
+    plans, meta = [], []
+    for qi, q in enumerate(qs):
+        query = Query(q["op"], q["terms"], window=q.get("window", 0))
+        for first, maxitems, cal in (shapes if not QUICK else shapes[qi % 3::3]):
+            plans.append(plan(db, query, first, maxitems, check_at_least=max(cal, first + maxitems)))
+            meta.append((q, first, maxitems, cal))
+    # plain operators ride in the same batch: their replay bits mean nothing
+    others = H.gen_term_queries("AND", n(6, 2), 3, 1, 60, seed=286) + H.gen_term_queries("OR", n(6, 2), 4, 1, 300, seed=287)
+    other_plans = [plan(db, Query(q["op"], q["terms"]), 0, 10) for q in others]
+    before = replay_info()
+    got = search_batch_replay(db, plans + other_plans)
+    after = replay_info()
+    listed, declined, collected = (after[i] - before[i] for i in range(3))
+    froze = differs = exact_known = 0
+    for (q, first, maxitems, cal), p, (page, hdr, known) in zip(meta, plans, got):
+        k = first + maxitems
+        want_page, want_hdr, want_known = search_replay(db, p, REPLAY_FROZEN_WEIGHT)
+        what = (q, first, maxitems, cal)
+        assert page == want_page, (what, page[:3], want_page[:3])
+        assert hdr.n_hits == want_hdr.n_hits and hdr.max_possible == want_hdr.max_possible, what
+        if want_page:
+            assert hdr.max_attained == want_hdr.max_attained and hdr.max_weight_subqs_matched == want_hdr.max_weight_subqs_matched, what
+        m, m_lb = hdr.matches_exact & ~_lib.XGM_MATCHES_LOWER_BOUND, bool(hdr.matches_exact & _lib.XGM_MATCHES_LOWER_BOUND)
+        assert (m <= want_hdr.matches_exact and m >= len(page)) if m_lb else m == want_hdr.matches_exact, (what, m, m_lb, want_hdr.matches_exact)
+        assert ((known & ~LB) <= want_known) if known & LB else known == want_known, (what, known, want_known)
+        exact_known += not (known & LB)
+        if cal == 0:
+            ref, _ = H.oracle_search(c, q["op"], q["terms"], first, maxitems, q.get("window", 0), reference_select_bug=True)
+            assert page[first:] == ref[first:] or page == ref, what
+        intended, _ = search_batch(db, [p])[0]
+        froze += want_hdr.matches_exact > k
+        differs += [(d, w) for d, w, _ in page] != [(h.docid, h.weight) for h in intended]
+    for q, p, (page, hdr, known) in zip(others, other_plans, got[len(plans):]):
+        want, _ = search_batch(db, [p])[0]
+        assert [(d, w) for d, w, _ in page] == [(h.docid, h.weight) for h in want], q
+        assert known == 0, q
+    assert listed >= (4 if QUICK else 200) and collected >= (1 if QUICK else 30), (listed, declined, collected)
+    assert froze >= (3 if QUICK else 80) and differs >= (1 if QUICK else 20), (froze, differs)
+    # the same rows from the synchronous entry point, one query per call (what the matcher hook issues)
+    for p, (page, hdr, _) in list(zip(plans, got))[:: (7 if not QUICK else 3)]:
+        qs1 = (_lib.Query * 1)()
+        C.memmove(C.byref(qs1[0]), C.byref(p), C.sizeof(_lib.Query))
+        qs1[0].replay = _lib.XGM_REPLAY_BATCH_FROZEN
+        k = max(1, p.first + p.maxitems)
+        hits, h1 = (_lib.Hit * k)(), (_lib.ResultHdr * 1)()
+        _lib.check(_lib.lib().xgm_search_batch(db._h, qs1, 1, k, hits, h1))
+        assert [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(h1[0].n_hits)] == page
+    db.close()
+    c.close()

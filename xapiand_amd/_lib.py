@@ -15,6 +15,8 @@ XGM_OK, XGM_UNSUPPORTED = 0, 1
 XGM_E_INVALID, XGM_E_IO, XGM_E_NO_DEVICE, XGM_E_DEVICE, XGM_E_REVISION, XGM_E_NOMEM = -1, -2, -3, -4, -5, -6
 XGM_OP_AND, XGM_OP_OR, XGM_OP_PHRASE = 1, 2, 3
 XGM_OP_AND_NOT, XGM_OP_AND_MAYBE, XGM_OP_FILTER, XGM_OP_NEAR = 4, 5, 6, 7
+XGM_REPLAY_BATCH_FROZEN = 1         # xgm_query.replay / xgm_query_desc.replay (include/xgm.h)
+XGM_KNOWN_LOWER_BOUND = 1 << 63
 XGM_MATCHES_LOWER_BOUND = 1 << 63    # xgm_result_hdr.matches_exact: the count is a lower bound (include/xgm.h)
 XGM_DEVICE_NONE = -1          # xgm_index_open: dictionary and statistics only (host memory), no searches
 UINT64_MAX = (1 << 64) - 1
@@ -59,7 +61,8 @@ class QueryDesc(C.Structure):
                 ("maxitems", C.c_uint32), ("check_at_least", C.c_uint32),
                 ("k1", C.c_double), ("k2", C.c_double), ("k3", C.c_double), ("b", C.c_double),
                 ("min_normlen", C.c_double), ("n_required", C.c_uint32), ("n_tree", C.c_uint32),
-                ("wqf", C.c_uint32 * XGM_MAX_TERMS), ("tree", TreeOp * XGM_MAX_TREE), ("tree_scale", C.c_double * XGM_MAX_TREE)]
+                ("wqf", C.c_uint32 * XGM_MAX_TERMS), ("tree", TreeOp * XGM_MAX_TREE), ("tree_scale", C.c_double * XGM_MAX_TREE),
+                ("replay", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class GlobalStats(C.Structure):
@@ -80,7 +83,7 @@ class Query(C.Structure):
                 ("tree_len", C.c_uint32), ("n_groups", C.c_uint32), ("tree_root", C.c_uint32), ("total_subqs", C.c_uint32),
                 ("group_scored", C.c_uint32), ("group_of", C.c_uint8 * XGM_MAX_TERMS), ("group_weight", C.c_double * XGM_MAX_TERMS),
                 ("tree_op", C.c_uint8 * XGM_MAX_TREE), ("tree_a", C.c_uint8 * XGM_MAX_TREE), ("tree_b", C.c_uint8 * XGM_MAX_TREE),
-                ("est_min", C.c_uint32), ("est_est", C.c_uint32), ("est_max", C.c_uint32), ("reserved2", C.c_uint32)]
+                ("est_min", C.c_uint32), ("est_est", C.c_uint32), ("est_max", C.c_uint32), ("replay", C.c_uint32)]
 
 
 class SortSpec(C.Structure):
@@ -136,10 +139,12 @@ _API = [
     ("xgm_search_all", C.c_int, [C.c_void_p, _P(Query), _P(Hit), C.c_uint64, _P(C.c_uint64), _P(ResultHdr)]),
     ("xgm_search_replay", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, _P(Hit), _P(ResultHdr), _P(C.c_uint64)]),
     ("xgm_debug_replay_info", C.c_int, [_P(C.c_uint64)]),
+    ("xgm_debug_batch_replay_info", C.c_int, [_P(C.c_uint64)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
     ("xgm_search_batch_begin", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     ("xgm_get_mset_batch_begin", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     ("xgm_batch_end", C.c_int, [C.c_void_p, _P(_P(Hit)), _P(_P(ResultHdr))]),
+    ("xgm_batch_known", C.c_int, [C.c_void_p, _P(_P(C.c_uint64))]),
     ("xgm_batch_poll", C.c_int, [C.c_void_p]),
     ("xgm_batch_release", None, [C.c_void_p]),
     ("xgm_search_batch_device", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),

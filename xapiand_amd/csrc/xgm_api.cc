@@ -661,7 +661,7 @@ static bool flat_kind(const xgm_index* idx, const xgm_query& q);
 static int or2_kind(const xgm_index* idx, const xgm_query& q);
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
-                      BatchPlan* bp, bool force_general = false) {
+                      BatchPlan* bp, bool force_general = false, bool list = false) {
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
@@ -912,8 +912,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
     /* xgm_andw_kernel merges a query's lists in its last unit, whatever their number (XGM_NO_FUSED_MERGE: A/B switch, the variant tests) */
     static const bool no_fused = getenv("XGM_NO_FUSED_MERGE") != nullptr;
-    bp->fused = bp->andw && !no_fused;                                                             /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
-    const uint32_t P = bp->fused ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
+    bp->fused = bp->andw && !no_fused && !list;                                                    /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
+    /* (list: xgm_andw_list_kernel's units are walked in stripe order by xgm_frozen_finish_kernel, whatever their number: one part) */
+    const uint32_t P = (bp->fused || list) ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
     bp->parts = std::max(1u, P);
     const uint32_t upp = bp->parts > 1 ? units_per_part : g_most_q + 1u;
     bp->goff.assign((size_t)nq * bp->parts + 1, 0);
@@ -950,8 +951,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
 
 /* Runs one batch of ONE kernel class (or a batch whose mix plan_batch resolves by itself); results land in rows
  * rows[i] (i when rows == NULL) of d_hits / d_hdrs (device).  Asynchronous on `stream`. */
+constexpr int XGM_LIST_DECLINED = 2;       /* run_class_batch(list): the batch is not one xgm_andw_list_kernel takes — nothing was enqueued */
 static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
-                           xgm_hit* d_hits, xgm_result_hdr* d_hdrs, const uint32_t* rows) {
+                           xgm_hit* d_hits, xgm_result_hdr* d_hdrs, const uint32_t* rows, bool list = false, unsigned long long* d_extra = nullptr) {
     int rc;
     /* planned in ordinary (cached) memory and copied to the pinned staging buffer in one go below: the CPU reads pinned
      * host memory at a few GB/s (measured: 250 us per batch for reading 180 KB of device queries back out of it) */
@@ -963,10 +965,15 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     uint32_t* h_kq = (uint32_t*)(h_mp + nq);
     BatchPlan bp;
     const uint64_t t_pb = now_ns();
-    if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp))) return rc;
+    if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp, false, list))) return rc;
     const uint64_t t_st = now_ns();
     g_host_ns[1] += t_st - t_pb;
     if (k_stride < bp.k_max) return xgm_set_error(XGM_E_INVALID, "k_stride %u < first+maxitems %u", k_stride, bp.k_max);
+    if (list) {
+        /* the reference-identical mode of positional queries: the units list their first matches (xgm_prefix_entry, 24 bytes) where their candidates would be */
+        if (!bp.andw || !bp.phrase || bp.wide || bp.sided || !d_extra) return XGM_LIST_DECLINED;
+        bp.k_stride_c = XGM_PREFIX_CAND_STRIDE(bp.k_max);
+    }
     if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)bp.n_work * bp.k_stride_c))) return rc;
     if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)bp.n_work))) return rc;
     /* every per-call input goes up in ONE copy: [dev queries | max_possible | work list | k | group offsets] */
@@ -988,7 +995,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     memcpy(hin + o_go, bp.goff.data(), b_go);
     if (rows) memcpy(hin + o_ro, rows, b_ro);
     /* every query of the batch a conjunction over probe containers only (dense_kind, all of one kind): the kernel written for that */
-    bool dense = bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
+    bool dense = !list && bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
     for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
     static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
     if (dense_class_old_kernel) dense = false;
@@ -1024,7 +1031,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     if (stream != s->stream && !s->inorder) {
         /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
          * kernels of the previous batch still running on the caller's stream */
-        if (bp.orw || (bp.andw && bp.phrase)) {
+        if (bp.orw || (bp.andw && bp.phrase && !list)) {
             /* the query-wide histogram is zeroed here, ahead of the upload on the scratch's stream, not between two match kernels on the
              * caller's (the scratch is this batch's alone: whatever used it before has completed — scratch_acquire) */
             if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
@@ -1069,9 +1076,9 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
-    idx->last_kernel = dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    idx->last_kernel = list ? "xgm_andw_list_kernel" : dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
-    if (bp.orw || (bp.andw && bp.phrase)) {
+    if (bp.orw || (bp.andw && bp.phrase && !list)) {
         if (!hist_zeroed) {
             if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
             HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
@@ -1091,7 +1098,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe0 = pe1 = nullptr;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
+    if ((rc = list ? xgm_launch_andw_list(L, stream) : dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
               : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
               : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream)))
         return rc;
@@ -1099,7 +1106,11 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     const uint64_t t_mk = now_ns();
     g_host_ns[6] += t_mk - t_up;
     const uint32_t* d_rows = rows ? (const uint32_t*)(din + o_ro) : nullptr;
-    if (fused) {
+    if (list) {
+        /* one wave per query walks its units' lists as ProtoMSet + SelectPostList would and writes the row (xgm_frozen.hip) */
+        if ((rc = xgm_launch_frozen_finish(s->d_queries, nq, s->d_goff, s->d_cand, s->d_ghdr, bp.k_stride_c, s->d_maxposs, d_rows, d_hits, d_hdrs, d_extra, k_stride, stream)))
+            return rc;
+    } else if (fused) {
         /* (the kernel wrote d_hits / d_hdrs) */
     } else if (P == 1u) {
         if ((rc = xgm_launch_merge(s->d_cand, s->d_ghdr, s->d_goff, bp.k_stride_c, s->d_kq, nq, bp.merge_cap, k_stride, d_hits,
@@ -1137,6 +1148,7 @@ enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_
        XGM_CLS_OR2,                              /* disjunctions for xgm_orw2_kernel (or2_kind): ONE launch — its flat-array instantiation takes the queries whose
                                                     every term has a container too (measured, round 5: a launch per kind cost 3.7 ms per 256-query batch against
                                                     2.0 for the old kernel alone: three tails, three sets of unit prologues) */
+       XGM_CLS_FROZEN,                           /* positional queries answered as the reference answers them (XGM_REPLAY_BATCH_FROZEN) that xgm_andw_list_kernel takes */
        XGM_CLS_COUNT };
 
 /* xgm_dense_kernel's queries (xgm_dense_and.hip): a conjunction / FILTER — or a positional query that prunes by weight — of 2 to 4
@@ -1225,17 +1237,37 @@ static int classify_query(const xgm_index* idx, const xgm_query& q) {
     }
 }
 
-/* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`. */
+static std::atomic<uint64_t> g_batch_replays[3];    /* diagnostics: rows listed on the device / declined there / answered by xgm_search_replay when collected */
+extern "C" int xgm_debug_batch_replay_info(uint64_t* out3) { if (!out3) return -1; for (int i = 0; i < 3; ++i) out3[i] = g_batch_replays[i].load(); return 0; }
+
+/* xgm_andw_list_kernel's queries: positional, a page of at most 64 with check_at_least inside it, 2..4 terms that all have probe containers — or are
+ * led by a long-tail term with a flat posting array (the criteria of the two bodies that have a LIST form) */
+static bool list_kind(const xgm_index* idx, const xgm_query& q) {
+    const bool positional = (q.op == XGM_OP_PHRASE || q.op == XGM_OP_NEAR) && q.phrase_active;
+    return positional && (dense_kind(idx, q, true) == 2 || flat_kind(idx, q));
+}
+
+/* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`.
+ * d_extra != NULL (device, [nq] zeroed): the queries' XGM_REPLAY_BATCH_* bits are honoured — rows the device answers get their extra word
+ * (known_matching_docs | XGM_EXTRA_*), rows it does not take are appended to *host_replay (answered by xgm_batch_end). */
 static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
-                     xgm_hit* d_hits, xgm_result_hdr* d_hdrs) {
+                     xgm_hit* d_hits, xgm_result_hdr* d_hdrs, unsigned long long* d_extra = nullptr, std::vector<uint32_t>* host_replay = nullptr) {
     static const bool no_split = getenv("XGM_NO_CLASS_SPLIT") != nullptr;          /* A/B switch for measurements */
+    static const bool no_list = getenv("XGM_NO_LIST_KERNEL") != nullptr;           /* A/B switch (the variant tests): every replay on the host side of the batch */
     uint32_t count[XGM_CLS_COUNT] = {};
     static thread_local std::vector<uint8_t> cls;
     cls.resize(nq);
     uint32_t present = 0;
     s->last_stop = nullptr;
-    for (uint32_t i = 0; i < nq; ++i) { cls[i] = (uint8_t)classify_query(idx, qs[i]); if (count[cls[i]]++ == 0) ++present; }
-    if (present <= 1u || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
+    for (uint32_t i = 0; i < nq; ++i) {
+        cls[i] = (uint8_t)classify_query(idx, qs[i]);
+        if (d_extra && host_replay && (qs[i].replay & XGM_REPLAY_BATCH_FROZEN) && (qs[i].op == XGM_OP_PHRASE || qs[i].op == XGM_OP_NEAR) && qs[i].phrase_active) {
+            if (!no_list && !no_split && list_kind(idx, qs[i])) { cls[i] = XGM_CLS_FROZEN; ++g_batch_replays[0]; }
+            else host_replay->push_back(i);
+        }
+        if (count[cls[i]]++ == 0) ++present;
+    }
+    if ((present <= 1u && !count[XGM_CLS_FROZEN]) || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
     /* one launch per class present, all on `stream`; the first uses the caller's scratch, the others take their own
      * from the pool (each is marked pending behind its launch) */
     static thread_local std::vector<xgm_query> sub;
@@ -1248,7 +1280,14 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         for (uint32_t i = 0; i < nq; ++i) if (cls[i] == c) { sub.push_back(qs[i]); rows.push_back(i); }
         XgmScratch* sc = s;
         if (!first && (rc = scratch_acquire(idx, &sc))) break;
-        rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows.data());
+        const uint32_t* rows_arg = (present == 1u) ? nullptr : rows.data();
+        rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows_arg, c == XGM_CLS_FROZEN, d_extra);
+        if (rc == XGM_LIST_DECLINED) {
+            /* (the batch as a whole is not the listing kernel's: the intended-semantics launch now, the replays when the batch is collected) */
+            for (uint32_t r : rows) host_replay->push_back(r);
+            g_batch_replays[0] -= rows.size();
+            rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows_arg);
+        }
         if (sc != s) {
             if (hipEventRecord(sc->ev_done, stream) == hipSuccess) sc->pending = true; else hipStreamSynchronize(stream);
             scratch_release(idx, sc);
@@ -1287,6 +1326,11 @@ struct xgm_inflight {
     uint32_t nq = 0, k_stride = 0;
     bool ended = false;
     int rc_end = XGM_OK;
+    /* queries with XGM_REPLAY_BATCH_* bits: the downloaded rows end with [nq] extra words (known_matching_docs | XGM_EXTRA_*); the plans are
+     * kept so that xgm_batch_end can answer the rows the device declined (host_replay: known at launch; XGM_EXTRA_FALLBACK: found on the device) */
+    bool has_extra = false;
+    std::vector<xgm_query> plans;
+    std::vector<uint32_t> host_replay;
 };
 
 static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_inflight** out, hipStream_t on = nullptr, bool inorder = false) {
@@ -1297,14 +1341,22 @@ static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_
     if ((rc = scratch_acquire(idx, &s))) return rc;
     hipStream_t stream = on ? on : pick_stream(idx, s);
     s->inorder = inorder;
+    bool has_extra = false;
+    for (uint32_t i = 0; i < nq && !has_extra; ++i) has_extra = qs[i].replay != 0u;
+    std::vector<uint32_t> host_replay;
     do {
-        /* hits and headers share one device buffer → one download */
+        /* hits and headers share one device buffer → one download (+ one extra word per query when any carries replay bits) */
         const size_t n_hit = (size_t)nq * k_stride;
-        if ((rc = grow(&s->d_hits, &s->cap_hits, n_hit + (size_t)nq * 2))) break;
+        if ((rc = grow(&s->d_hits, &s->cap_hits, n_hit + (size_t)nq * 2 + (has_extra ? (nq + 1u) / 2u : 0u)))) break;
         xgm_result_hdr* d_hdrs = reinterpret_cast<xgm_result_hdr*>(s->d_hits + n_hit);
-        const size_t down = n_hit * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr);
+        unsigned long long* d_extra = has_extra ? reinterpret_cast<unsigned long long*>(s->d_hits + n_hit + (size_t)nq * 2) : nullptr;
+        const size_t down = n_hit * sizeof(xgm_hit) + (size_t)nq * sizeof(xgm_result_hdr) + (has_extra ? (size_t)nq * 8 : 0);
         if ((rc = grow_pinned(&s->h_down, &s->cap_down, down))) break;
-        if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, d_hdrs))) break;
+        if (has_extra) {
+            const hipError_t ez = hipMemsetAsync(d_extra, 0, (size_t)nq * 8, stream);
+            if (ez != hipSuccess) { rc = xgm_launch_error("hipMemsetAsync", (int)ez, hipGetErrorString(ez)); break; }
+        }
+        if ((rc = run_batch(idx, s, stream, qs, nq, k_stride, s->d_hits, d_hdrs, d_extra, has_extra ? &host_replay : nullptr))) break;
         /* an index bound to ONE stream (xgm_index_set_stream) runs its batches' kernels back to back there; the download of batch i then
          * goes on the scratch's own stream behind an event, so that it does not sit between the match kernels of batches i and i + 1
          * (XGM_COPY_ON_BATCH_STREAM=1: A/B switch, the copy in stream order) */
@@ -1330,6 +1382,7 @@ static int batch_begin(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_
     }
     xgm_inflight* f = new xgm_inflight();
     f->idx = idx; f->s = s; f->nq = nq; f->k_stride = k_stride;
+    if (has_extra) { f->has_extra = true; f->plans.assign(qs, qs + nq); f->host_replay.swap(host_replay); }
     *out = f;
     return XGM_OK;
 }
@@ -1355,15 +1408,53 @@ extern "C" int xgm_get_mset_batch_begin(xgm_index* idx, const xgm_query_desc* de
     return batch_begin(idx, plans.data(), nq, k_stride, out);
 }
 
+/* The rows of a collected batch that carry replay bits and were not answered on the device: each by xgm_search_replay, into the batch's own
+ * pinned rows.  A row needs it only when its page is full (fewer matches than the page: the reference's answer IS the intended one). */
+static int batch_host_replays(xgm_inflight* f) {
+    xgm_hit* h_hits = (xgm_hit*)f->s->h_down;
+    xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + (size_t)f->nq * f->k_stride);
+    unsigned long long* h_extra = (unsigned long long*)(h_hdrs + f->nq);
+    for (uint32_t i = 0; i < f->nq; ++i) if (h_extra[i] & XGM_EXTRA_FALLBACK) { f->host_replay.push_back(i); ++g_batch_replays[1]; }
+    if (f->host_replay.empty()) return XGM_OK;
+    std::vector<xgm_hit> page(XGM_MAX_K);
+    for (uint32_t i : f->host_replay) {
+        const xgm_query& q = f->plans[i];
+        const uint32_t k = q.first + q.maxitems;
+        const bool device_declined = (h_extra[i] & XGM_EXTRA_FALLBACK) != 0ull;
+        h_extra[i] = 0;
+        if (!(q.replay & XGM_REPLAY_BATCH_FROZEN)) continue;
+        if (!device_declined && h_hdrs[i].n_hits < k) { h_extra[i] = h_hdrs[i].n_hits; continue; }      /* (the intended-semantics row of a page that did not fill: every match was shown to ProtoMSet) */
+        xgm_result_hdr hdr;
+        uint64_t known = 0;
+        const int rc = xgm_search_replay(f->idx, &q, XGM_REPLAY_FROZEN_WEIGHT, page.data(), &hdr, &known);
+        if (rc) return rc;
+        ++g_batch_replays[2];
+        hdr.max_possible = q.max_possible;
+        memcpy(h_hits + (size_t)i * f->k_stride, page.data(), (size_t)hdr.n_hits * sizeof(xgm_hit));
+        h_hdrs[i] = hdr;
+        h_extra[i] = known;
+    }
+    return XGM_OK;
+}
+
 extern "C" int xgm_batch_end(xgm_inflight* f, const xgm_hit** hits, const xgm_result_hdr** hdrs) {
     if (!f) return xgm_set_error(XGM_E_INVALID, "null argument");
     if (!f->ended) {
         f->ended = true;
         hipError_t e = hipEventSynchronize(f->s->ev_done);
         if (e != hipSuccess) f->rc_end = xgm_launch_error("batch completion", (int)e, hipGetErrorString(e));
+        else if (f->has_extra) f->rc_end = batch_host_replays(f);
     }
     if (hits) *hits = (const xgm_hit*)f->s->h_down;
     if (hdrs) *hdrs = (const xgm_result_hdr*)((const xgm_hit*)f->s->h_down + (size_t)f->nq * f->k_stride);
+    return f->rc_end;
+}
+
+extern "C" int xgm_batch_known(xgm_inflight* f, const uint64_t** known) {
+    if (!f || !known) return xgm_set_error(XGM_E_INVALID, "null argument");
+    *known = nullptr;
+    if (!f->ended) return xgm_set_error(XGM_E_INVALID, "xgm_batch_known before xgm_batch_end");
+    if (f->has_extra) *known = (const uint64_t*)((const xgm_result_hdr*)((const xgm_hit*)f->s->h_down + (size_t)f->nq * f->k_stride) + f->nq);
     return f->rc_end;
 }
 

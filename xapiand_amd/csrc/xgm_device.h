@@ -115,6 +115,29 @@ typedef struct {
     uint32_t c_pad[2];
 } xgm_group_hdr;
 
+/* xgm_andw_kernel's LIST instantiation (the reference-identical batch mode of positional queries, include/xgm.h XGM_REPLAY_BATCH_FROZEN):
+ * what a work unit reports instead of a top-k list — the unit's FIRST matches in docid order, each with the weight of the document of
+ * the underlying conjunction that follows it inside the unit (SelectPostList::vet weighs that document when min_weight turns positive and
+ * serves its weight from then on, selectpostlist.cc:28-55).  A unit stops after 2 (k + 1) matches: ProtoMSet's page is decided by the first
+ * k + 1 matches of the QUERY, the frozen weight and at most k later matches (xgm_frozen.hip).  The entries live where the unit's candidates
+ * would (cand_out + slot * k_stride, k_stride = XGM_PREFIX_CAND_STRIDE(k_max) candidates); the unit's xgm_group_hdr carries: matches = the
+ * matches it found (| XGM_MATCHES_LOWER_BOUND when it stopped early), n_cand = entries written, pad = XGM_PFX_* flags, c_pos = weight bits
+ * of the unit's first conjunction document. */
+typedef struct {
+    uint64_t wbits;        /* the match's own weight */
+    uint64_t next_wbits;   /* weight of the conjunction's next document in the unit (a match or not); valid when has_next */
+    uint32_t did;
+    uint32_t has_next;     /* 0: the match is the unit's last conjunction document — the successor is the first one of a later unit */
+} xgm_prefix_entry;        /* 24 bytes */
+#define XGM_PFX_HAS_FIRST 1u    /* the unit holds a document of the conjunction (c_pos valid) */
+#define XGM_PFX_COMPLETE 2u     /* the unit walked its whole docid range: its entries are ALL its matches */
+#define XGM_PFX_DECLINED 4u     /* the unit's query has no LIST body (neither xgm_dense_unit nor xgm_flat_unit): answered by the per-query replay */
+/* per-row extra word of a batch with replay bits: known_matching_docs | ... */
+#define XGM_EXTRA_LOWER_BOUND (1ull << 63)   /* = XGM_KNOWN_LOWER_BOUND */
+#define XGM_EXTRA_FALLBACK (1ull << 62)      /* the device declined: xgm_batch_end answers the row with xgm_search_replay */
+#define XGM_PREFIX_ENTRIES(k) (2u * ((k) + 1u))
+#define XGM_PREFIX_CAND_STRIDE(k_max) (3u * ((k_max) + 1u))      /* 2 (k + 1) entries of 24 bytes in candidates of 16 */
+
 /* xgm_andw_kernel finishing its queries itself (xgm_unit_finish.h): the LAST unit of a query to arrive merges the units' lists into
  * the final hits — no merge launch.  arrive == NULL: the units only write their lists (xgm_merge_kernel follows). */
 typedef struct {

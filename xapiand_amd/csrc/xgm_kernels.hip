@@ -686,6 +686,33 @@ static_assert(dense_wave_bytes(true, 4) <= 6144 + 4 * 2048 && flat_wave_bytes(tr
               dense_wave_bytes(true, 2) <= 6144 + 2 * 2048 && flat_wave_bytes(true, 2) <= 6144 + 2 * 2048,
               "andw_wave_bytes reserves 6 KiB + T x 2 KiB for the positional bodies");
 
+/* The reference-identical batch mode of positional queries (include/xgm.h, XGM_REPLAY_BATCH_FROZEN): the same work units, the same two bodies,
+ * compiled in their LIST form — a unit reports its FIRST 2 (k + 1) matches in docid order with their successors in the conjunction
+ * (xgm_prefix_entry) instead of its best k, tests every document of the conjunction (no threshold) and stops as soon as the list is full.
+ * xgm_frozen_finish_kernel (xgm_frozen.hip) then walks each query's lists as ProtoMSet + SelectPostList would (protomset.h:340-400,
+ * selectpostlist.cc:28-55).  Queries with neither body (terms without containers and flat arrays, more than 4 terms, k > 64) are declined
+ * per unit: the host answers them with the per-query replay. */
+__global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                                                const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
+                                                                                uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                                                xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
+    if (unit >= n_work) return;                                    /* no barriers below */
+    const xgm_work wk = work[unit];
+    const uint32_t flags = rfl32(queries[wk.qi].flags);
+    const uint32_t W = 1u << seg.stripe_bits;
+    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, 1u, spg_max, true, false);
+    if (flags & XGM_QF_DENSE) { xgm_dense_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr); return; }
+    if (flags & XGM_QF_FLAT) { xgm_flat_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr); return; }
+    if (lane == 0u) {
+        xgm_group_hdr h = {};
+        h.pad = XGM_PFX_DECLINED;
+        ghdr_out[wk.slot] = h;
+    }
+}
+
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
  * instantiations, so that the plain conjunction pays nothing for them. */
@@ -2450,6 +2477,19 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
     if (L.sided == 2) return L.wide ? launch_andw_variant<uint16_t, false, 2>(L, smem, stream) : launch_andw_variant<uint8_t, false, 2>(L, smem, stream);
     if (L.sided == 1) return L.wide ? launch_andw_variant<uint16_t, false, 1>(L, smem, stream) : launch_andw_variant<uint8_t, false, 1>(L, smem, stream);
     return L.wide ? launch_andw_variant<uint16_t, false, 0>(L, smem, stream) : launch_andw_variant<uint8_t, false, 0>(L, smem, stream);
+}
+
+int xgm_launch_andw_list(const xgm_match_launch& L, hipStream_t stream) {
+    if (!L.phrase || L.wide || L.sided) return xgm_launch_error("andw list kernel", 0, "positional batches with one-byte wdf only");
+    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, false, L.stripes_per_group, true, false);
+    if (smem > 160u * 1024u) return xgm_launch_error("andw list kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+    const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
+    auto kern = xgm_andw_list_kernel;
+    static std::atomic<size_t> seen{0};
+    if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
+    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int xgm_merge_cycles_fetch(unsigned long long* out8) {

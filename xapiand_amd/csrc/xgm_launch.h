@@ -84,6 +84,13 @@ int xgm_launch_and(const xgm_match_launch& L, hipStream_t stream);
  * L.phrase selects the instantiation with the positional filter (every term block-decoded) */
 size_t xgm_andw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg, bool phrase, bool sided);
 int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream);
+/* positional batches in the reference-identical mode: the units' first matches in docid order (xgm_prefix_entry lists where the candidates would
+ * be: L.k_stride = XGM_PREFIX_CAND_STRIDE(k_max)), then — xgm_frozen.hip — one wave per query walks its units' lists as ProtoMSet and
+ * SelectPostList would and writes the page: hits [rows][k_stride_out], hdrs [rows], extra [rows] = known_matching_docs | status bits */
+int xgm_launch_andw_list(const xgm_match_launch& L, hipStream_t stream);
+int xgm_launch_frozen_finish(const xgm_dev_query* queries, uint32_t nq, const uint32_t* goff, const xgm_cand* cand, const xgm_group_hdr* ghdr, uint32_t k_stride_c,
+                             const double* max_possible, const uint32_t* row_of, xgm_hit* hits, xgm_result_hdr* hdrs, unsigned long long* extra, uint32_t k_stride_out,
+                             hipStream_t stream);
 size_t xgm_body_wave_bytes(bool flat, bool phrase, uint32_t terms);      /* LDS a unit of xgm_flat_unit (flat) / xgm_dense_unit uses of the wave's slice */
 /* conjunctions (or positional queries that prune by weight) whose every term has probe containers, <= xgm_dense_max_terms() terms,
  * k <= xgm_dense_max_k(), units of <= xgm_dense_max_stripes() stripes: xgm_dense_and.hip; L.phrase selects the positional instantiation */

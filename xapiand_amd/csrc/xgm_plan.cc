@@ -464,6 +464,7 @@ int plan_tree(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_st
 extern "C" int xgm_plan_query(const xgm_index* idx, const xgm_query_desc* d, const xgm_global_stats* gs, xgm_query* out) {
     if (!idx || !d || !out) return xgm_set_error(XGM_E_INVALID, "null argument");
     memset(out, 0, sizeof *out);
+    out->replay = d->replay;
     const uint32_t n = d->n_terms;
     if (d->op < XGM_OP_AND || d->op > XGM_OP_TREE) return XGM_UNSUPPORTED;
     if (n == 0 || n > XGM_MAX_TERMS) return XGM_UNSUPPORTED;

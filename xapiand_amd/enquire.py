@@ -516,6 +516,35 @@ def search_replay(db, planned, mode=REPLAY_COUNT):
     return [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(hdr.n_hits)], hdr, known.value
 
 
+def search_batch_replay(db, plans, replay=_lib.XGM_REPLAY_BATCH_FROZEN):
+    """A batch in flight whose queries carry XGM_REPLAY_BATCH_* bits (xgm_search_batch_begin / xgm_batch_end / xgm_batch_known): the reference's own
+    answers at batch throughput → list of ([(docid, weight, subqs)], hdr, known_matching_docs incl. XGM_KNOWN_LOWER_BOUND)."""
+    nq = len(plans)
+    if nq == 0:
+        return []
+    k_stride = max(1, max(p.first + p.maxitems for p in plans))
+    qs = (_lib.Query * nq)()
+    for i, p in enumerate(plans):
+        C.memmove(C.byref(qs[i]), C.byref(p), C.sizeof(_lib.Query))
+        qs[i].replay = replay
+    L = _lib.lib()
+    f = C.c_void_p()
+    _lib.check(L.xgm_search_batch_begin(db._h, qs, nq, k_stride, C.byref(f)))
+    try:
+        hp, dp, kp = C.POINTER(_lib.Hit)(), C.POINTER(_lib.ResultHdr)(), C.POINTER(C.c_uint64)()
+        _lib.check(L.xgm_batch_end(f, C.byref(hp), C.byref(dp)))
+        _lib.check(L.xgm_batch_known(f, C.byref(kp)))
+        out = []
+        for i in range(nq):
+            hdr = _lib.ResultHdr()
+            C.memmove(C.byref(hdr), C.byref(dp[i]), C.sizeof(_lib.ResultHdr))
+            out.append(([(hp[i * k_stride + j].docid, hp[i * k_stride + j].weight, hp[i * k_stride + j].subqs_matched) for j in range(hdr.n_hits)], hdr,
+                        kp[i] if kp else 0))
+        return out
+    finally:
+        L.xgm_batch_release(f)
+
+
 def search_batch(db, plans):
     """xgm_search_batch over already planned queries → list of (hits[], hdr)."""
     nq = len(plans)
