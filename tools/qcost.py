@@ -30,6 +30,13 @@ def arg(name, default):
 
 
 def close(self):
+    if os.environ.get("XGM_QCOST_LIST"):
+        # the reference-identical batch mode (xgm_andw_list_kernel): the same 256 queries once more with XGM_REPLAY_BATCH_FROZEN, then its units
+        pool_ = H.bench_pool("PHRASE", 3, 1, 10_000_000, 1_000_000, n=100 + 16 * bench.BATCH, seed=bench.QUERY_SEED, maxitems=int(arg("--topk", 10)))
+        qs_ = pool_[100 + 3 * bench.BATCH: 100 + 4 * bench.BATCH]
+        plans_ = [enquire.plan(self, enquire.Query(q["op"], q["terms"]), 0, int(arg("--topk", 10))) for q in qs_]
+        self.set_stream(0)
+        enquire.search_batch_replay(self, plans_)
     cap = 40000
     buf = (C.c_ulonglong * (8 * cap))()
     pos = (C.c_ulonglong * cap)()

@@ -794,7 +794,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* Cost model of a query (unit: ~1k cycles of one wave, measured on MI355X): every
      * active stripe pays a fixed latency chain; each posting block that still has to be decoded (terms
      * without probe containers) adds ~1; each candidate costs a probe + a share of the scoring. */
-    std::vector<double> cost(nq);
+    std::vector<double> cost(nq), conj_per_stripe(nq, 0.0);
     double total_cost = 0;
     const double n_docs = std::max<double>(1.0, idx->hdr.doccount);
     const double Wd = (double)(1u << idx->hdr.stripe_bits);
@@ -819,6 +819,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         /* AND visits only stripes where the rarest term has postings */
         const double stripes = qs[i].op == XGM_OP_OR ? n_stripes : std::min<double>(n_stripes, min_df);
         const double cand_per_stripe = all_dense ? Wd * dens : (stripes > 0 ? min_df / stripes : 0.0);
+        conj_per_stripe[i] = cand_per_stripe;
         /* a candidate of a positional query costs a 64-byte sector per term, its positions and the predicate on top of the probe */
         static const double phrase_cand = getenv("XGM_PHRASE_CAND_COST") ? atof(getenv("XGM_PHRASE_CAND_COST")) : 0.25;
         /* ... and with three or more terms the matches are rarer, the query-wide threshold comes later and more of the candidates are tested
@@ -903,6 +904,15 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
         if (bp->phrase && bp->andw && phrase_unit_stripes && (dq[i].flags & XGM_QF_DENSE) && nq > 4u)
             gq = std::max(gq, std::min(g_max, (n_stripes + phrase_unit_stripes - 1u) / phrase_unit_stripes));
+        if (list && (dq[i].flags & XGM_QF_DENSE)) {
+            /* a LIST unit tests the positions of EVERY document of the conjunction in its range, in docid order, until the query's first matches are
+             * found: the launch ends with the longest such walk (measured, round 6: a 3-stripe unit of `t3 t8 t9` — 7 000 documents of the conjunction,
+             * 104 matches in the shard — ran 2.5 M cycles, the whole launch 1.27 ms).  Units of about XGM_LIST_UNIT_DOCS documents: the later ones
+             * cost nothing once the earlier ones hold the matches that decide the page (PrefixList::look_back) */
+            static const double list_unit_docs = getenv("XGM_LIST_UNIT_DOCS") ? atof(getenv("XGM_LIST_UNIT_DOCS")) : 1024.0;      /* A/B switch */
+            const uint32_t spg_l = (uint32_t)std::max(1.0, std::min(32.0, std::floor(list_unit_docs / std::max(1.0, conj_per_stripe[i]))));
+            gq = std::max(gq, std::min(n_stripes, (n_stripes + spg_l - 1u) / spg_l));
+        }
         uint32_t spg = (n_stripes + gq - 1) / gq;
         gq = (n_stripes + spg - 1) / spg;
         spg_used = std::max(spg_used, spg);
@@ -934,6 +944,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             bp->work.push_back(w);
         }
     }
+    /* a LIST launch: stripe order — the units of lower stripes are done (and have published their match counts) when those of higher stripes
+     * start, which then have nothing to do for every query whose page is decided (PrefixList::look_back) */
+    static const bool list_lpt = getenv("XGM_LIST_LPT_ORDER") != nullptr;            /* A/B switch: heaviest first, as the other launches */
+    if (list && !list_lpt) std::stable_sort(bp->work.begin(), bp->work.end(), [](const xgm_work& a, const xgm_work& b) { return a.s_begin < b.s_begin; });
     bp->n_work = (uint32_t)bp->work.size();
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
@@ -1023,6 +1037,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
             fu.row_of = rows ? (const uint32_t*)(din_ + o_ro) : nullptr;
             fu.hits = d_hits; fu.hdrs = d_hdrs; fu.k_stride_out = k_stride;
         }
+        if (list) fu.goff = (const uint32_t*)(din_ + o_go);      /* (xgm_andw_list_kernel: the first unit slot of every query) */
         memcpy(hin + o_fu, &fu, sizeof fu);
     }
     const uint64_t t_cp = now_ns();
@@ -1031,11 +1046,13 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     if (stream != s->stream && !s->inorder) {
         /* asynchronous caller: the inputs go up on the scratch's own stream, so the copy overlaps the
          * kernels of the previous batch still running on the caller's stream */
-        if (bp.orw || (bp.andw && bp.phrase && !list)) {
+        if (bp.orw || (bp.andw && bp.phrase)) {
             /* the query-wide histogram is zeroed here, ahead of the upload on the scratch's stream, not between two match kernels on the
              * caller's (the scratch is this batch's alone: whatever used it before has completed — scratch_acquire) */
-            if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
-            HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, s->stream));
+            /* (list: the same buffer holds the units' match counters, one per unit) */
+            const size_t n_hist = list ? (size_t)bp.n_work : (size_t)nq * XGM_OR_HIST;
+            if ((rc = grow(&s->d_hist, &s->cap_hist, n_hist))) return rc;
+            HIP_TRY(hipMemsetAsync(s->d_hist, 0, n_hist * 4, s->stream));
             hist_zeroed = true;
         }
         HIP_TRY(hipMemcpyAsync(s->d_in, hin, in_bytes, hipMemcpyHostToDevice, s->stream));
@@ -1078,14 +1095,15 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     }
     idx->last_kernel = list ? "xgm_andw_list_kernel" : dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
-    if (bp.orw || (bp.andw && bp.phrase && !list)) {
+    if (bp.orw || (bp.andw && bp.phrase)) {
         if (!hist_zeroed) {
-            if ((rc = grow(&s->d_hist, &s->cap_hist, (size_t)nq * XGM_OR_HIST))) return rc;
-            HIP_TRY(hipMemsetAsync(s->d_hist, 0, (size_t)nq * XGM_OR_HIST * 4, stream));
+            const size_t n_hist = list ? (size_t)bp.n_work : (size_t)nq * XGM_OR_HIST;
+            if ((rc = grow(&s->d_hist, &s->cap_hist, n_hist))) return rc;
+            HIP_TRY(hipMemsetAsync(s->d_hist, 0, n_hist * 4, stream));
         }
         L.hist = s->d_hist;
     }
-    if (fused) L.fuse = (const xgm_fuse*)(din + o_fu);
+    if (fused || list) L.fuse = (const xgm_fuse*)(din + o_fu);
     /* the wave kernels' dispatch packets carry their events themselves (xgm_launch.h): the profiling pair, and — when the kernel is the
      * batch's last launch (the fused merge) — the event the download waits for.  XGM_NO_EXT_LAUNCH=1: A/B switch (events recorded around) */
     static const bool ext_launch = getenv("XGM_NO_EXT_LAUNCH") == nullptr;

@@ -110,16 +110,17 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
                     if (rl32(my.has_next, j)) { w_star = __longlong_as_double((long long)rl64(my.next_wbits, j)); have_star = true; }
                     else {
                         /* the match is its unit's last document of the conjunction: the successor opens a later unit — or there is none and the loop ends */
-                        for (uint32_t v0 = u + 1u; v0 < U && !have_star; v0 += 64u) {
+                        for (uint32_t v0 = u + 1u; v0 < U && !have_star && !fallback; v0 += 64u) {
                             const uint32_t v = v0 + lane;
-                            const bool has = v < U && (ghdr[g0 + v].pad & XGM_PFX_HAS_FIRST) != 0u;
-                            const uint64_t hm = __ballot(has);
-                            if (hm) {
-                                const uint32_t L = (uint32_t)__builtin_ctzll(hm);
-                                w_star = __longlong_as_double((long long)ghdr[g0 + v0 + L].c_pos);
-                                have_star = true;
-                            }
+                            const uint32_t vp = v < U ? ghdr[g0 + v].pad : XGM_PFX_COMPLETE;
+                            const uint64_t hm = __ballot((vp & XGM_PFX_HAS_FIRST) != 0u);
+                            /* (a unit that stopped before it met a document of the conjunction says nothing about its range: the answer is not in the lists) */
+                            const uint64_t um = __ballot(!(vp & XGM_PFX_HAS_FIRST) && !(vp & XGM_PFX_COMPLETE));
+                            const uint32_t Lh = hm ? (uint32_t)__builtin_ctzll(hm) : 64u, Lu = um ? (uint32_t)__builtin_ctzll(um) : 64u;
+                            if (Lu < Lh) fallback = true;
+                            else if (hm) { w_star = __longlong_as_double((long long)ghdr[g0 + v0 + Lh].c_pos); have_star = true; }
                         }
+                        if (fallback) stop = true;
                         if (!have_star) stop = true;
                     }
                 }

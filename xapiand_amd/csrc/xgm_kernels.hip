@@ -695,7 +695,10 @@ static_assert(dense_wave_bytes(true, 4) <= 6144 + 4 * 2048 && flat_wave_bytes(tr
 __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                                                 const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                                                 uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
-                                                                                xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out) {
+                                                                                xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out,
+                                                                                uint32_t* __restrict__ unit_matches, const xgm_fuse* __restrict__ fuse) {
+    /* unit_matches [n_work] zeroed: matches found so far per unit slot — a unit stops once the units of lower stripes hold 2 (k + 1) (PrefixList::look_back);
+     * fuse: only goff (the first unit slot of every query) */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
@@ -704,8 +707,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel
     const uint32_t flags = rfl32(queries[wk.qi].flags);
     const uint32_t W = 1u << seg.stripe_bits;
     unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, 1u, spg_max, true, false);
-    if (flags & XGM_QF_DENSE) { xgm_dense_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr); return; }
-    if (flags & XGM_QF_FLAT) { xgm_flat_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr); return; }
+    if (flags & XGM_QF_DENSE) { xgm_dense_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
+    if (flags & XGM_QF_FLAT) { xgm_flat_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
     if (lane == 0u) {
         xgm_group_hdr h = {};
         h.pad = XGM_PFX_DECLINED;
@@ -2487,7 +2490,7 @@ int xgm_launch_andw_list(const xgm_match_launch& L, hipStream_t stream) {
     auto kern = xgm_andw_list_kernel;
     static std::atomic<size_t> seen{0};
     if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr);
+    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }
