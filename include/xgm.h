@@ -342,6 +342,12 @@ typedef struct {
  *                             check_at_least beyond the page) are answered by xgm_search_replay when the batch is collected: same rows.
  * xgm_batch_known (below) hands out ProtoMSet's known_matching_docs per query where a mode computed it. */
 #define XGM_REPLAY_BATCH_FROZEN 1u
+/*   XGM_REPLAY_BATCH_COUNT    ProtoMSet's known_matching_docs, EXACT (what MSet::get_matches_lower_bound / _estimated are derived from, protomset.h:484-619:
+ *                             Xapiand's HTTP "total").  With XGM_REPLAY_BATCH_FROZEN on a positional query: the listing units walk their whole docid
+ *                             range (every document of the conjunction is tested: the match count is exact) — slower than the page alone, still one
+ *                             launch per batch.  On other operators: the page is the batch's, the count comes from xgm_search_replay(XGM_REPLAY_COUNT)
+ *                             when the batch is collected. */
+#define XGM_REPLAY_BATCH_COUNT 2u
 
 
 #define XGM_N_AND 1
@@ -521,6 +527,11 @@ int xgm_search_replay(xgm_index*, const xgm_query* q, uint32_t mode, xgm_hit* hi
 /* nq queries in one launch; hits is [nq][k_stride] with k_stride >= max(first+maxitems). */
 int xgm_search_batch(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
                      xgm_hit* hits, xgm_result_hdr* hdrs);
+
+/* xgm_search_batch honouring the queries' XGM_REPLAY_BATCH_* bits with their figures handed back: known [nq] = ProtoMSet's known_matching_docs
+ * (xgm_batch_known's array; may be NULL).  Like xgm_search_batch, a single-query call rides in the dispatcher's shared launches when
+ * xgm_index_set_batching is on: the matcher hook's byte-compatible modes at the throughput of the others. */
+int xgm_search_batch_known(xgm_index*, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs, uint64_t* known);
 
 /* Same, but results stay in HBM: d_hits ([nq][k_stride] xgm_hit) and d_hdrs ([nq] xgm_result_hdr)
  * are DEVICE pointers owned by the caller (e.g. torch tensors feeding an RCCL all-gather).

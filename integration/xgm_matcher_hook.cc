@@ -34,7 +34,9 @@ struct ShardColumns {
     std::map<std::string, std::shared_ptr<Column>> by_key;       /* "v<slot>" | "k<KeyMaker name>\0<serialised>" */
     uint32_t next_slot = 0x40000000u;                            /* synthetic slot numbers of the index's column map */
 };
-struct Shard { xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; };
+/* own: shared ownership of the device index — a search copies the Shard under g_mu and so keeps the index alive for its whole call, whatever
+ * the registry does meanwhile (a commit replacing the revision, the shard closing: ADVICE r5); idx = own.get() */
+struct Shard { std::shared_ptr<xgm_index> own; xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; };
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
 std::map<std::string, std::shared_ptr<const SpyAdapter>> g_spy_adapters;      /* (shared: a search keeps its adapter although the name is registered again meanwhile) */
@@ -427,16 +429,40 @@ int fetch_all(xgm_index* idx, const xgm_query& plan, Xapian::doccount doccount, 
 
 }  // namespace
 
-void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch) {
+static void register_ptr(const std::string& uuid, Xapian::rev revision, std::shared_ptr<xgm_index> own, uint32_t batch) {
+    xgm_index* idx = own.get();
     if (batch) xgm_index_set_batching(idx, batch);
     if (g_near_colocated.load(std::memory_order_relaxed)) xgm_index_set_near_colocated(idx, 1);
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_shards[db.get_uuid()] = Shard{idx, db.get_revision(), std::make_shared<ShardColumns>()};
+    Shard replaced;                                                /* (its index — if the registry's was the last reference — is closed outside the lock) */
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(uuid);
+        if (it != g_shards.end()) replaced = std::move(it->second);
+        g_shards[uuid] = Shard{std::move(own), idx, revision, std::make_shared<ShardColumns>()};
+    }
+}
+
+void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch) {
+    register_ptr(db.get_uuid(), db.get_revision(), std::shared_ptr<xgm_index>(idx, [](xgm_index*) {}), batch);      /* not owned: the caller closes it */
+}
+
+void register_shard_owned(const std::string& uuid, uint64_t revision, xgm_index* idx, uint32_t batch, std::function<void()> released) {
+    register_ptr(uuid, (Xapian::rev)revision, std::shared_ptr<xgm_index>(idx, [released](xgm_index* p) { xgm_index_close(p); if (released) released(); }), batch);
+}
+
+void register_shard_owned(const Xapian::Database& db, xgm_index* idx, uint32_t batch, std::function<void()> released) {
+    register_shard_owned(db.get_uuid(), db.get_revision(), idx, batch, std::move(released));
 }
 
 void unregister_shard(const Xapian::Database& db) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_shards.erase(db.get_uuid());
+    Shard gone;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_shards.find(db.get_uuid());
+        if (it == g_shards.end()) return;
+        gone = std::move(it->second);
+        g_shards.erase(it);
+    }
 }
 
 void set_enabled(bool on) { g_enabled.store(on); }
@@ -556,8 +582,18 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     const bool plain = by_rel && spies.empty() && collapse_max == 0;
     std::shared_ptr<Column> sort_col, collapse_col;
     uint64_t collapsed_lb = 0;
+    /* The byte-compatible modes ride in the SAME call as every other search (round 6; round 5: a second, one-query-at-a-time call behind it):
+     * the plan carries XGM_REPLAY_BATCH_* bits, the library answers with the reference's own collation — and, with xgm_index_set_batching on, in
+     * the dispatcher's shared launches.  POSITIONAL_REFERENCE: the page ProtoMSet + SelectPostList's frozen weight leave (selectpostlist.cc:28-55)
+     * and its known_matching_docs; exact bounds: known_matching_docs of any other shape (protomset.h:340-400). */
+    const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
+    const bool pos_ref = plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0;
+    const bool want_count = plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0;
+    uint64_t known_raw = 0;
     if (plain) {
-        rc = xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
+        plan.replay = pos_ref ? (XGM_REPLAY_BATCH_FROZEN | XGM_REPLAY_BATCH_COUNT) : want_count ? XGM_REPLAY_BATCH_COUNT : 0u;
+        rc = plan.replay ? xgm_search_batch_known(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr, &known_raw)
+                         : xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
     } else {
         if (k == 0 || plan.max_possible == 0.0) { ++g_shape; return false; }      /* (max_possible == 0: the matcher renormalises the sort, matcher.cc:421-434) */
         /* the columns this search ranks, counts and collapses by */
@@ -625,24 +661,10 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     if (rc > 0) { ++g_dev; return false; }                                   /* declined by the device path: CPU matcher */
     if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
 
-    /* POSITIONAL_REFERENCE: a full page of a positional query — the reference's own answer, replayed ON THE DEVICE (round 5; rounds
-     * 3-4 downloaded the whole match and looped on the host): xgm_search_replay tests every candidate's positions, walks the match in
-     * docid order as ProtoMSet would and freezes the weight as SelectPostList does (selectpostlist.cc:28-55) — phrases of up to 8 terms */
-    const bool positional = L.d.op == XGM_OP_PHRASE || L.d.op == XGM_OP_NEAR;
-    bool replayed = false;
-    uint64_t replay_known = 0;
-    if (plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0 && hdr.n_hits == k) {
-        xgm_result_hdr hdr2;
-        memset(&hdr2, 0, sizeof hdr2);
-        const int rc2 = xgm_search_replay(sh.idx, &plan, XGM_REPLAY_FROZEN_WEIGHT, hits.data(), &hdr2, &replay_known);
-        if (rc2 != XGM_OK) { ++g_dev; return false; }                          /* declined or failed: the CPU matcher answers (nothing was lost) */
-        hdr.n_hits = hdr2.n_hits;
-        hdr.max_attained = hdr2.max_attained;
-        hdr.max_weight_subqs_matched = hdr2.max_weight_subqs_matched;
-        hdr.matches_exact = hdr2.matches_exact;
-        replayed = true;
-        ++g_replayed;
-    }
+    /* (the figures of a row that carried replay bits: ProtoMSet's own count, exact unless flagged) */
+    const bool replayed = plain && plan.replay != 0u && !(known_raw & XGM_KNOWN_LOWER_BOUND);
+    const uint64_t replay_known = known_raw & ~XGM_KNOWN_LOWER_BOUND;
+    if (replayed && hdr.n_hits == k) ++g_replayed;
 
     /* the MSet, as ProtoMSet::finalise builds it (protomset.h:466-471, 484-682) */
     std::vector<Result> items;
@@ -665,27 +687,12 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     uint32_t lb = 0, est = 0, ub = 0;
     const uint64_t m_all = XGM_MATCHES_COUNT(hdr.matches_exact);
     if (replayed) {
-        xgm_mset_bounds_known(&plan, &hdr, replay_known, &lb, &est, &ub);        /* ProtoMSet's own count of the replay */
+        /* known_matching_docs is a function of the match in docid order with its weights — for the operators that visit every match (a term,
+         * AND, FILTER, AND_NOT, PHRASE, NEAR) and for those whose tree prunes by weight (OR, AND_MAYBE, nested trees: it only ever skips documents
+         * the matcher's loop would drop anyway, matcher.cc:500-505) alike: the device counted as ProtoMSet would */
+        xgm_mset_bounds_known(&plan, &hdr, replay_known, &lb, &est, &ub);
     } else if (sort_by == int(EI::VAL) || sort_by == int(EI::VAL_REL)) {
         xgm_mset_bounds_known(&plan, &hdr, m_all, &lb, &est, &ub);
-    } else if (plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0 && hdr.n_hits == k &&
-               !(hdr.matches_exact & XGM_MATCHES_LOWER_BOUND) && m_all > k && m_all >= plan.check_at_least) {
-        /* known_matching_docs is a function of the match in docid order with its weights — for the operators that visit every match (a
-         * term, AND, FILTER, AND_NOT) and for those whose tree prunes by weight (OR, AND_MAYBE, nested trees: it only ever skips documents
-         * the matcher's loop would drop anyway, matcher.cc:500-505) alike.  The device counts as ProtoMSet would, over the whole match, which
-         * never leaves HBM (xgm_search_replay; rounds 3-4: a download of 16 B per match + the reference's own loop over a ReplayPostList —
-         * slower than the CPU matcher on frequent-term disjunctions).  The page stays the search's own: ProtoMSet keeps the same documents. */
-        std::vector<xgm_hit> page(k);
-        xgm_result_hdr hdr2;
-        memset(&hdr2, 0, sizeof hdr2);
-        uint64_t known = 0;
-        const int rc2 = xgm_search_replay(sh.idx, &plan, XGM_REPLAY_COUNT, page.data(), &hdr2, &known);
-        if (rc2 == XGM_OK && hdr2.matches_exact == m_all) {
-            xgm_mset_bounds_known(&plan, &hdr, known, &lb, &est, &ub);
-            ++g_replayed;
-        } else {
-            xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
-        }
     } else {
         xgm_mset_bounds(&plan, &hdr, &lb, &est, &ub);
     }

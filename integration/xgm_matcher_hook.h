@@ -55,8 +55,15 @@ namespace Xapian { namespace Internal { class PostList; } }
 
 namespace xgm_hook {
 
-/* registry (thread-safe).  batch: the index's micro-batching queue (0 = leave it as it is). */
+/* registry (thread-safe).  batch: the index's micro-batching queue (0 = leave it as it is).
+ * register_shard: the caller keeps ownership — it closes the index after unregister_shard, and only when no search can still be inside the
+ * library (tests, single-threaded drivers).  register_shard_owned: the HOOK owns the index — every search that picks the shard up shares the
+ * ownership for its call, so replacing the registration (a newer revision) or unregistering never frees an index under a reader; when the last
+ * holder lets go the index is closed (xgm_index_close) and released() runs (remove the segment file, count).  This is what a server does
+ * (xgm_xapiand_glue.cc): Xapiand's readers are Shard objects of the DatabasePool that search while the writer commits. */
 void register_shard(const Xapian::Database& db, xgm_index* idx, uint32_t batch = 256);
+void register_shard_owned(const Xapian::Database& db, xgm_index* idx, uint32_t batch, std::function<void()> released);
+void register_shard_owned(const std::string& uuid, uint64_t revision, xgm_index* idx, uint32_t batch, std::function<void()> released);
 void unregister_shard(const Xapian::Database& db);
 
 /* switches (process-wide) */

@@ -21,7 +21,9 @@
 #include <unistd.h>
 #include <sys/stat.h>
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 
 #include "../../integration/xgm_matcher_hook.h"
 #include "../../integration/xgm_xapiand_glue.h"
@@ -78,7 +80,8 @@ std::string http_body(const Xapian::MSet& m, size_t n_shards, const std::string&
 
 int main(int argc, char** argv) {
     int a = 1;
-    bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false, commit_glue = false;
+    bool stale = false, exact_bounds_on = false, replay_on = false, positional_reference_on = false, commit_glue = false, commit_during = false;
+    unsigned n_threads = 0, thread_repeat = 1;
     const char* bodies_dir = nullptr;
     struct Leg { std::string name, mode, file; };
     std::vector<Leg> legs;
@@ -112,6 +115,9 @@ int main(int argc, char** argv) {
         else if (!strcmp(argv[a], "--collapse-reference")) { xgm_hook::set_collapse_mode(xgm_hook::COLLAPSE_REFERENCE); replay_on = true; }
         else if (!strcmp(argv[a], "--replay")) { xgm_hook::set_replay(true); replay_on = true; }
         else if (!strcmp(argv[a], "--stale")) stale = true;
+        else if (!strcmp(argv[a], "--threads") && a + 1 < argc) n_threads = (unsigned)atoi(argv[++a]);      /* Xapiand's load shape: T threads, each its own Database handles, one get_mset at a time through the patched matcher (src/manager.cc:161, src/database/handler.cc:1338) */
+        else if (!strcmp(argv[a], "--thread-repeat") && a + 1 < argc) thread_repeat = (unsigned)std::max(1, atoi(argv[++a]));
+        else if (!strcmp(argv[a], "--commit-during")) commit_during = true;   /* ... while the writer commits and the glue replaces the registered revision under them (needs --commit-glue) */
         else if (!strcmp(argv[a], "--commit-glue")) commit_glue = true;       /* shards reach the device through integration/xgm_xapiand_glue.cc (what xapiand_shard_hook.patch calls) */
         else if (!strcmp(argv[a], "--http-bodies") && a + 1 < argc) bodies_dir = argv[++a];      /* write every response body (hook off / on) there */
         else if (!strcmp(argv[a], "--leg") && a + 1 < argc) {
@@ -138,7 +144,10 @@ int main(int argc, char** argv) {
             if (commit_glue) {
                 /* Xapiand's way in: Shard::commit → xgm_xapiand::on_commit (export, load, register); the first time in full */
                 const double t_e0 = now_s();
+                /* (queued: the writer does not wait for the export — this driver does, before it searches) */
                 if (!xgm_xapiand::on_commit(argv[i], dbs.back(), 0)) { fprintf(stderr, "on_commit(%s) failed\n", argv[i]); return 1; }
+                xgm_xapiand::wait_idle();
+                if (xgm_xapiand::stats().failures) { fprintf(stderr, "the export of %s failed\n", argv[i]); return 1; }
                 export_s += now_s() - t_e0;
                 idx.push_back(nullptr);
                 seg_files.push_back("");
@@ -163,7 +172,12 @@ int main(int argc, char** argv) {
         /* the shard moved on: refresh its segment INCREMENTALLY — documents below first_changed come from the old segment, only
          * the rest is read from glass (xgm_segment_refresh_from_glass; byte-identical to a full export, tests/test_glass.py) */
         auto export_and_register = [&](size_t i, const char* dir, uint32_t first_changed) -> int {
-            if (commit_glue) return xgm_xapiand::on_commit(dir, dbs[i], first_changed) ? 0 : 1;       /* (an incremental refresh from the registered segment) */
+            if (commit_glue) {                       /* (an incremental refresh from the registered segment: the floor as Shard's mutators report it, xgm_xapiand::on_touch) */
+                xgm_xapiand::on_touch(dbs[i], first_changed);
+                const bool ok = xgm_xapiand::on_commit(dir, dbs[i]);
+                xgm_xapiand::wait_idle();
+                return ok && !xgm_xapiand::stats().failures ? 0 : 1;
+            }
             char seg[64];
             snprintf(seg, sizeof seg, "/tmp/xgm_b1_%d_%zu_r.seg", (int)getpid(), i);
             if (xgm_segment_refresh_from_glass(seg_files[i].c_str(), dir, first_changed, 0, seg) != XGM_OK) { fprintf(stderr, "refresh %s: %s\n", dir, xgm_last_error()); return 1; }
@@ -218,6 +232,7 @@ int main(int argc, char** argv) {
         unsigned bad = 0, bounds_bad = 0, http_total_equal = 0, http_bodies_equal = 0;
         double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;
+        std::vector<Xapian::MSet> wants;                             /* the CPU matcher's answers, for the threaded leg */
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const QuerySpec& q = queries[qi];
             const Xapian::Query query = make_query(q);
@@ -230,6 +245,7 @@ int main(int argc, char** argv) {
             Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems, &q, &spy_got);
             cpu_s += t_q1 - t_q0; hook_s += now_s() - t_q1;
             std::string why;
+            if (n_threads) wants.push_back(want);
             if (!same_mset(want, got, percents, &why)) {
                 ++bad;
                 printf("MISMATCH query %zu (%s): %s; cpu %u hits, hook %u hits\n", qi, q.op.c_str(), why.c_str(), want.size(), got.size());
@@ -288,6 +304,63 @@ int main(int argc, char** argv) {
                        got.get_matches_upper_bound(), want.get_matches_lower_bound(), want.get_matches_estimated(), want.get_matches_upper_bound());
             }
         }
+        /* ---- the hook under Xapiand's load shape: T threads, each with its OWN Database handles (a Xapian::Database is not thread-safe: the pool
+         * hands every HTTP worker its own Shard), one Enquire::get_mset at a time through the patched matcher; the hook's single-query calls meet in
+         * the index's dispatcher (xgm_index_set_batching).  Every answer is compared with the CPU matcher's.  --commit-during: meanwhile the writer
+         * commits and the glue registers the new revision — the readers' revision is replaced UNDER them (they hold the old index through their
+         * calls, then are declined: their handles still name the old revision) ---- */
+        unsigned thr_bad = 0;
+        unsigned long long thr_done = 0, thr_device = 0;
+        double thr_s = 0.0;
+        if (n_threads && !queries.empty()) {
+            std::vector<std::string> paths;
+            for (int i = a + 1; i < argc; ++i) paths.push_back(argv[i]);
+            std::atomic<size_t> next{0};
+            std::atomic<unsigned> bad_t{0};
+            const size_t total = queries.size() * thread_repeat;
+            const xgm_hook::Counters t0c = xgm_hook::counters();
+            xgm_hook::set_enabled(true);
+            /* (handles opened before the clock starts; every thread checks its own revision against the registry through the hook) */
+            std::vector<std::vector<Xapian::Database>> handles(n_threads);
+            for (unsigned t = 0; t < n_threads; ++t) for (const std::string& p : paths) handles[t].emplace_back(p);
+            const double t_b = now_s();
+            std::vector<std::thread> pool;
+            for (unsigned t = 0; t < n_threads; ++t)
+                pool.emplace_back([&, t]() {
+                    try {
+                        for (size_t i = next.fetch_add(1); i < total; i = next.fetch_add(1)) {
+                            const size_t qi = i % queries.size();
+                            const QuerySpec& q = queries[qi];
+                            SpyResult spy;
+                            Xapian::MSet got = run_query(handles[t], make_query(q), q.first, q.maxitems, &q, &spy);
+                            std::string why;
+                            if (!same_mset(wants[qi], got, percents, &why)) { if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: %s\n", t, qi, why.c_str()); }
+                        }
+                    } catch (const Xapian::Error& e) {
+                        bad_t.fetch_add(1);
+                        printf("MISMATCH (thread %u): %s\n", t, e.get_description().c_str());
+                    }
+                });
+            if (commit_during && commit_glue) {
+                /* the writer: one more document and a commit per shard while the readers search; Shard::commit's patch line follows */
+                for (size_t i = 0; i < paths.size(); ++i) {
+                    Xapian::WritableDatabase w(paths[i], Xapian::DB_OPEN);
+                    Xapian::Document doc;
+                    doc.add_posting("t1", 1); doc.add_posting("t2", 2);
+                    const Xapian::docid did = w.add_document(doc).did;
+                    w.commit();
+                    xgm_xapiand::on_touch(w, did);
+                    xgm_xapiand::on_commit(paths[i], w);
+                }
+                xgm_xapiand::wait_idle();
+            }
+            for (auto& th : pool) th.join();
+            thr_s = now_s() - t_b;
+            thr_bad = bad_t.load();
+            thr_done = total;
+            thr_device = xgm_hook::counters().answered - t0c.answered;
+            bad += thr_bad;
+        }
         xgm_hook::Counters c = xgm_hook::counters();
         c.answered -= c0.answered; c.declined_shape -= c0.declined_shape; c.declined_unregistered -= c0.declined_unregistered; c.declined_revision -= c0.declined_revision;
         c.declined_device -= c0.declined_device; c.answered_sorted -= c0.answered_sorted; c.answered_spied -= c0.answered_spied; c.answered_collapsed -= c0.answered_collapsed;
@@ -298,16 +371,19 @@ int main(int argc, char** argv) {
                "\"declined_unregistered\": %llu, \"declined_revision\": %llu, \"declined_by_planner\": %llu, \"refreshed_shards\": %u, "
                "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu, "
                "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f, "
-               "\"http_bodies_equal\": %u, \"glue_full_exports\": %llu, \"glue_refreshes\": %llu, \"glue_failures\": %llu}\n",
+               "\"http_bodies_equal\": %u, \"glue_full_exports\": %llu, \"glue_refreshes\": %llu, \"glue_failures\": %llu, \"glue_released\": %llu, \"glue_overtaken\": %llu, "
+               "\"threads\": %u, \"threaded_queries\": %llu, \"threaded_seconds\": %.4f, \"threaded_mismatches\": %u, \"threaded_answered_on_device\": %llu, \"commit_during\": %s}\n",
                bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
                (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed,
                (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s, http_bodies_equal,
-               (unsigned long long)xgm_xapiand::stats().full_exports, (unsigned long long)xgm_xapiand::stats().refreshes, (unsigned long long)xgm_xapiand::stats().failures);
+               (unsigned long long)xgm_xapiand::stats().full_exports, (unsigned long long)xgm_xapiand::stats().refreshes, (unsigned long long)xgm_xapiand::stats().failures,
+               (unsigned long long)xgm_xapiand::stats().released, (unsigned long long)xgm_xapiand::stats().overtaken,
+               n_threads, thr_done, thr_s, thr_bad, thr_device, (commit_during && commit_glue) ? "true" : "false");
         fflush(stdout);
         bad_total += bad + bounds_bad;
         }   /* legs */
-        if (commit_glue) { for (auto& d : dbs) xgm_xapiand::on_close(d); }
+        if (commit_glue) { xgm_xapiand::wait_idle(); for (auto& d : dbs) xgm_xapiand::on_close(d); }
         else for (auto& d : dbs) xgm_hook::unregister_shard(d);
         for (auto* h : idx) if (h) xgm_index_close(h);
         for (const std::string& f : seg_files) if (!f.empty()) unlink(f.c_str());

@@ -383,6 +383,15 @@ def test_commit_glue_and_http_bodies_under_emulation(emu_lib, tmp_path):
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["declined_revision"] >= 8, out
     assert out["glue_full_exports"] == 1 and out["glue_refreshes"] == 1 and out["glue_failures"] == 0, out
     assert out["http_bodies_equal"] == len(qs) and out["answered_on_device"] >= len(qs), out
+    # the hook under Xapiand's load shape: 8 threads search (each its own Database handles) WHILE the writer commits and the glue registers the
+    # new revision — the index of the readers' revision is replaced under them: shared ownership keeps it alive through their calls,
+    # afterwards it is released; every answer equals the CPU matcher's
+    two = str(tmp_path / "two")
+    shutil.copytree(one, two)
+    out = _run_hook_emulated(T, alias, "--commit-glue", "--threads", "8", "--thread-repeat", "2", "--commit-during", "--exact-bounds", qf, two)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["threaded_queries"] == 2 * len(qs), out
+    assert out["commit_during"] and out["glue_refreshes"] == 1 and out["glue_failures"] == 0 and out["glue_released"] >= 1, out
+    assert out["threaded_answered_on_device"] + out["declined_revision"] >= 2 * len(qs), out
 
 
 def test_integration_patches_apply_to_the_reference():

@@ -82,5 +82,16 @@ def test_batch_frozen_equals_the_per_query_replay_and_the_reference(built, tmp_p
         hits, h1 = (_lib.Hit * k)(), (_lib.ResultHdr * 1)()
         _lib.check(_lib.lib().xgm_search_batch(db._h, qs1, 1, k, hits, h1))
         assert [(hits[i].docid, hits[i].weight, hits[i].subqs_matched) for i in range(h1[0].n_hits)] == page
+    # XGM_REPLAY_BATCH_COUNT on top: the same pages, every figure exact (the listing units walk their whole range; plain operators are
+    # counted by xgm_search_replay when the batch is collected)
+    sel = list(range(0, len(plans), 5 if not QUICK else 2))
+    both = _lib.XGM_REPLAY_BATCH_FROZEN | _lib.XGM_REPLAY_BATCH_COUNT
+    got2 = search_batch_replay(db, [plans[i] for i in sel] + other_plans, replay=both)
+    for i, (page, hdr, known) in zip(sel, got2):
+        want_page, want_hdr, want_known = search_replay(db, plans[i], REPLAY_FROZEN_WEIGHT)
+        assert page == want_page and known == want_known and hdr.matches_exact == want_hdr.matches_exact, (meta[i], known, want_known, hdr.matches_exact, want_hdr.matches_exact)
+    for q, p, (page, hdr, known) in zip(others, other_plans, got2[len(sel):]):
+        want_page, want_hdr, want_known = search_replay(db, p)
+        assert page == want_page and known == want_known and hdr.matches_exact == want_hdr.matches_exact, (q, known, want_known)
     db.close()
     c.close()

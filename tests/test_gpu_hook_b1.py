@@ -240,6 +240,30 @@ def test_commit_glue_and_http_response_bodies(built, glass, glass_values, tmp_pa
     assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["glue_full_exports"] == 3, out
 
 
+def test_searches_from_many_threads_while_the_writer_commits(built, glass, tmp_path):
+    """The hook under Xapiand's load shape: DocMatcher::get_mset is called from every thread of the HTTP pool
+    (src/manager.cc:161, src/database/handler.cc:1338), each with its own Shard / Database handle, while the shard's writer commits
+    (src/database/shard.cc:706-810).  16 threads run the query pool several times over through the patched matcher — single-query calls that
+    meet in the index's dispatcher, byte-compatible modes included (exact bounds, POSITIONAL_REFERENCE) — while the driver's writer adds a
+    document, commits and the glue exports and registers the new revision: the index of the readers' revision is REPLACED under them.
+    Shared ownership keeps it alive through every call that picked it up and releases it afterwards; every answer equals the CPU matcher's."""
+    d, one, _ = glass
+    copy = str(tmp_path / "one_mt")
+    shutil.copytree(one, copy)
+    qs = (H.gen_term_queries("AND", 24, 2, 1, 100, maxitems=10, seed=323) + H.gen_term_queries("OR", 12, 3, 1, 400, maxitems=10, seed=324) +
+          H.gen_phrase_queries(12, N_DOCS, VOCAB, seed=325))
+    qf = str(tmp_path / "qmt.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--commit-glue", "--threads", "16", "--thread-repeat", "12", "--commit-during", "--exact-bounds", "--positional-reference", qf, copy)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["threaded_queries"] == 12 * len(qs) and out["commit_during"], out
+    assert out["glue_refreshes"] == 1 and out["glue_failures"] == 0 and out["glue_released"] >= 1, out
+    assert out["threaded_answered_on_device"] >= len(qs), out                    # (before the revision moved on; afterwards the readers' handles are declined)
+    # ... and without a commit: everything on the device, from 16 threads
+    out = run_b1("--commit-glue", "--threads", "16", "--thread-repeat", "6", "--exact-bounds", "--positional-reference", qf, copy)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["threaded_answered_on_device"] == 6 * len(qs), out
+
+
 def xapiand_keymaker_queries():
     """Sorted by Xapiand's OWN key maker: Multi_MultiValueKeyMaker (reference src/multivalue/keymaker.h:366; compiled from the reference's
     sources into the driver, oracle/ref_build/xapiand_classes.cc) through Enquire::set_sort_by_key_then_relevance(sorter, false) — the

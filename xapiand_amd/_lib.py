@@ -15,6 +15,7 @@ XGM_OK, XGM_UNSUPPORTED = 0, 1
 XGM_E_INVALID, XGM_E_IO, XGM_E_NO_DEVICE, XGM_E_DEVICE, XGM_E_REVISION, XGM_E_NOMEM = -1, -2, -3, -4, -5, -6
 XGM_OP_AND, XGM_OP_OR, XGM_OP_PHRASE = 1, 2, 3
 XGM_OP_AND_NOT, XGM_OP_AND_MAYBE, XGM_OP_FILTER, XGM_OP_NEAR = 4, 5, 6, 7
+XGM_REPLAY_BATCH_COUNT = 2
 XGM_REPLAY_BATCH_FROZEN = 1         # xgm_query.replay / xgm_query_desc.replay (include/xgm.h)
 XGM_KNOWN_LOWER_BOUND = 1 << 63
 XGM_MATCHES_LOWER_BOUND = 1 << 63    # xgm_result_hdr.matches_exact: the count is a lower bound (include/xgm.h)
@@ -141,6 +142,7 @@ _API = [
     ("xgm_debug_replay_info", C.c_int, [_P(C.c_uint64)]),
     ("xgm_debug_batch_replay_info", C.c_int, [_P(C.c_uint64)]),
     ("xgm_search_batch", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr)]),
+    ("xgm_search_batch_known", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(Hit), _P(ResultHdr), _P(C.c_uint64)]),
     ("xgm_search_batch_begin", C.c_int, [C.c_void_p, _P(Query), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     ("xgm_get_mset_batch_begin", C.c_int, [C.c_void_p, _P(QueryDesc), _P(GlobalStats), C.c_uint32, C.c_uint32, _P(C.c_void_p)]),
     ("xgm_batch_end", C.c_int, [C.c_void_p, _P(_P(Hit)), _P(_P(ResultHdr))]),

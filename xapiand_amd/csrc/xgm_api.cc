@@ -575,6 +575,7 @@ static int to_dev_query(const xgm_index* idx, const xgm_query* q, xgm_dev_query*
          * the match count is accurate; within it (Xapiand passes 0) the matcher may stop caring about documents that cannot rank */
         static const bool no_pos_prune = getenv("XGM_NO_POS_PRUNE") != nullptr;         /* A/B switch for measurements */
         if (!no_pos_prune && q->check_at_least <= q->first + q->maxitems) d->flags |= XGM_QF_POSPRUNE;
+        if (q->replay & XGM_REPLAY_BATCH_COUNT) d->flags |= XGM_QF_COUNT_ALL;       /* (read by xgm_andw_list_kernel's units only) */
         if (q->op == XGM_OP_NEAR) d->flags |= XGM_QF_NEAR | (idx->near_colocated.load(std::memory_order_relaxed) ? XGM_QF_NEAR_COLOC : 0u);
         else if (q->window == q->n_terms) d->flags |= XGM_QF_EXACT;
     }
@@ -1279,10 +1280,11 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
     s->last_stop = nullptr;
     for (uint32_t i = 0; i < nq; ++i) {
         cls[i] = (uint8_t)classify_query(idx, qs[i]);
-        if (d_extra && host_replay && (qs[i].replay & XGM_REPLAY_BATCH_FROZEN) && (qs[i].op == XGM_OP_PHRASE || qs[i].op == XGM_OP_NEAR) && qs[i].phrase_active) {
+        const uint32_t rp = (d_extra && host_replay) ? qs[i].replay : 0u;
+        if ((rp & XGM_REPLAY_BATCH_FROZEN) && (qs[i].op == XGM_OP_PHRASE || qs[i].op == XGM_OP_NEAR) && qs[i].phrase_active) {
             if (!no_list && !no_split && list_kind(idx, qs[i])) { cls[i] = XGM_CLS_FROZEN; ++g_batch_replays[0]; }
             else host_replay->push_back(i);
-        }
+        } else if (rp & XGM_REPLAY_BATCH_COUNT) host_replay->push_back(i);       /* (the count of a plain operator: by xgm_search_replay when the batch is collected) */
         if (count[cls[i]]++ == 0) ++present;
     }
     if ((present <= 1u && !count[XGM_CLS_FROZEN]) || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
@@ -1318,9 +1320,9 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
 
 static hipStream_t pick_stream(xgm_index* idx, XgmScratch* s) { return idx->stream ? (hipStream_t)idx->stream : s->stream; }
 
-static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr);
+static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr, uint64_t* known = nullptr);
 
-static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs);
+static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs, uint64_t* known = nullptr);
 
 extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits,
                                 xgm_result_hdr* hdrs) {
@@ -1329,6 +1331,14 @@ extern "C" int xgm_search_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq
     /* server mode: single-query calls of many host threads ride in shared launches (xgm_index_set_batching) */
     if (nq == 1 && idx->batcher) return batcher_submit(idx, qs, k_stride, hits, hdrs);
     return search_batch_now(idx, qs, nq, k_stride, hits, hdrs);
+}
+
+extern "C" int xgm_search_batch_known(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs, uint64_t* known) {
+    if (!idx || !qs || !hits || !hdrs) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (nq == 0) return XGM_OK;
+    if (known) memset(known, 0, (size_t)nq * 8);
+    if (nq == 1 && idx->batcher) return batcher_submit(idx, qs, k_stride, hits, hdrs, known);
+    return search_batch_now(idx, qs, nq, k_stride, hits, hdrs, known);
 }
 
 /* ---- a batch in flight ---------------------------------------------------------------------------------------------------
@@ -1439,18 +1449,22 @@ static int batch_host_replays(xgm_inflight* f) {
         const xgm_query& q = f->plans[i];
         const uint32_t k = q.first + q.maxitems;
         const bool device_declined = (h_extra[i] & XGM_EXTRA_FALLBACK) != 0ull;
+        const bool positional = (q.op == XGM_OP_PHRASE || q.op == XGM_OP_NEAR) && q.phrase_active;
+        const bool frozen = (q.replay & XGM_REPLAY_BATCH_FROZEN) && positional;
         h_extra[i] = 0;
-        if (!(q.replay & XGM_REPLAY_BATCH_FROZEN)) continue;
-        if (!device_declined && h_hdrs[i].n_hits < k) { h_extra[i] = h_hdrs[i].n_hits; continue; }      /* (the intended-semantics row of a page that did not fill: every match was shown to ProtoMSet) */
+        if (!frozen && !(q.replay & XGM_REPLAY_BATCH_COUNT)) continue;
+        /* a page that did not fill: every match was shown to ProtoMSet — the intended row is the reference's, the count its length */
+        if (!device_declined && h_hdrs[i].n_hits < k && !(h_hdrs[i].matches_exact & XGM_MATCHES_LOWER_BOUND)) { h_extra[i] = h_hdrs[i].n_hits; continue; }
         xgm_result_hdr hdr;
         uint64_t known = 0;
-        const int rc = xgm_search_replay(f->idx, &q, XGM_REPLAY_FROZEN_WEIGHT, page.data(), &hdr, &known);
+        const int rc = xgm_search_replay(f->idx, &q, frozen ? XGM_REPLAY_FROZEN_WEIGHT : XGM_REPLAY_COUNT, page.data(), &hdr, &known);
         if (rc) return rc;
         ++g_batch_replays[2];
+        h_extra[i] = known;
+        if (!frozen) { h_hdrs[i].matches_exact = hdr.matches_exact; continue; }      /* (the counting mode keeps the batch's own page: ProtoMSet keeps the same documents) */
         hdr.max_possible = q.max_possible;
         memcpy(h_hits + (size_t)i * f->k_stride, page.data(), (size_t)hdr.n_hits * sizeof(xgm_hit));
         h_hdrs[i] = hdr;
-        h_extra[i] = known;
     }
     return XGM_OK;
 }
@@ -1489,7 +1503,7 @@ extern "C" void xgm_batch_release(xgm_inflight* f) {
     delete f;
 }
 
-static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs) {
+static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdrs, uint64_t* known) {
     xgm_inflight* f = nullptr;
     int rc = batch_begin(idx, qs, nq, k_stride, &f);
     if (rc) return rc;
@@ -1501,6 +1515,8 @@ static int search_batch_now(xgm_index* idx, const xgm_query* qs, uint32_t nq, ui
         /* only the valid prefix of each row is defined on the device */
         for (uint32_t i = 0; i < nq; ++i)
             memcpy(hits + (size_t)i * k_stride, h_hits + (size_t)i * k_stride, (size_t)h_hdrs[i].n_hits * sizeof(xgm_hit));
+        const uint64_t* kn = nullptr;
+        if (known && xgm_batch_known(f, &kn) == XGM_OK && kn) memcpy(known, kn, (size_t)nq * 8);
     }
     xgm_batch_release(f);
     return rc;
@@ -2088,7 +2104,7 @@ extern "C" int xgm_search_replay(xgm_index* idx, const xgm_query* q, uint32_t mo
  * heterogeneous batch, then hands every caller its rows.  "Natural" batching: nothing waits on a timer; while one batch
  * runs the next one fills, so batches grow with the offered load and an idle server adds no latency. */
 struct XgmBatchReq {
-    const xgm_query* q; uint32_t k_stride; xgm_hit* hits; xgm_result_hdr* hdr;
+    const xgm_query* q; uint32_t k_stride; xgm_hit* hits; xgm_result_hdr* hdr; uint64_t* known = nullptr;
     int rc = 0; bool done = false; char err[192];
     std::condition_variable cv;                 /* this request's own: a finished batch wakes exactly its callers */
 };
@@ -2166,7 +2182,7 @@ static void batcher_loop(xgm_index* idx, XgmBatcher* b) {
             /* one query of the batch was declined or failed: answer each on its own so that only that caller sees it */
             delete fl;
             for (uint32_t i = 0; i < n; ++i) {
-                const int r1 = n > 1 ? search_batch_now(idx, take[i]->q, 1, take[i]->k_stride, take[i]->hits, take[i]->hdr) : rc;
+                const int r1 = n > 1 ? search_batch_now(idx, take[i]->q, 1, take[i]->k_stride, take[i]->hits, take[i]->hdr, take[i]->known) : rc;
                 batcher_finish(b, take[i], r1, xgm_last_error());
             }
             std::lock_guard<std::mutex> lk(b->mu);
@@ -2202,11 +2218,15 @@ static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
         const int rc = xgm_batch_end(fl->f, &hh, &hd);
         const std::string err = rc < 0 ? xgm_last_error() : "";
         const uint32_t n = (uint32_t)fl->reqs.size();
-        if (rc == XGM_OK)
+        if (rc == XGM_OK) {
+            const uint64_t* kn = nullptr;
+            xgm_batch_known(fl->f, &kn);
             for (uint32_t i = 0; i < n; ++i) {
                 *fl->reqs[i]->hdr = hd[i];
                 memcpy(fl->reqs[i]->hits, hh + (size_t)i * fl->ks, (size_t)hd[i].n_hits * sizeof(xgm_hit));
+                if (fl->reqs[i]->known) *fl->reqs[i]->known = kn ? kn[i] : 0;
             }
+        }
         xgm_batch_release(fl->f);
         {
             std::lock_guard<std::mutex> lk(b->mu);
@@ -2225,10 +2245,10 @@ static void batcher_done_loop(xgm_index* idx, XgmBatcher* b) {
     }
 }
 
-static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr) {
+static int batcher_submit(xgm_index* idx, const xgm_query* q, uint32_t k_stride, xgm_hit* hits, xgm_result_hdr* hdr, uint64_t* known) {
     XgmBatcher* b = idx->batcher;
     XgmBatchReq r;
-    r.q = q; r.k_stride = k_stride; r.hits = hits; r.hdr = hdr; r.err[0] = 0;
+    r.q = q; r.k_stride = k_stride; r.hits = hits; r.hdr = hdr; r.known = known; r.err[0] = 0;
     {
         std::unique_lock<std::mutex> lk(b->mu);
         b->queue.push_back(&r);

@@ -29,6 +29,7 @@
 #define XGM_QF_TREE 16u             /* a nested query: match and weigh by the node program over term GROUPS */
 #define XGM_QF_LIST_CONJ 512u       /* xgm_search_replay, frozen-weight mode: the match list of a positional query also carries the documents of the
                                        underlying conjunction that FAIL the positional test, flagged XGM_ALL_NOT_A_MATCH in their subqs word */
+#define XGM_QF_COUNT_ALL 1024u      /* xgm_andw_list_kernel (XGM_REPLAY_BATCH_COUNT): the unit lists its first matches AND walks its whole range: the match count is exact */
 #define XGM_ALL_NOT_A_MATCH 0x80000000u
 
 /* Executable form of xgm_query, one per query of a batch, read with scalar loads. */
@@ -130,7 +131,7 @@ typedef struct {
     uint32_t has_next;     /* 0: the match is the unit's last conjunction document — the successor is the first one of a later unit */
 } xgm_prefix_entry;        /* 24 bytes */
 #define XGM_PFX_HAS_FIRST 1u    /* the unit holds a document of the conjunction (c_pos valid) */
-#define XGM_PFX_COMPLETE 2u     /* the unit walked its whole docid range: its entries are ALL its matches */
+#define XGM_PFX_COMPLETE 2u     /* the unit walked its whole docid range: `matches` is exact — and the entries are all its matches when matches == n_cand */
 #define XGM_PFX_DECLINED 4u     /* the unit's query has no LIST body (neither xgm_dense_unit nor xgm_flat_unit): answered by the per-query replay */
 /* per-row extra word of a batch with replay bits: known_matching_docs | ... */
 #define XGM_EXTRA_LOWER_BOUND (1ull << 63)   /* = XGM_KNOWN_LOWER_BOUND */

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
     for (uint32_t u = 0; u < U && !stop; ++u) {
         const xgm_group_hdr& h = ghdr[g0 + u];
         const uint32_t n = rfl32(h.n_cand), pad = rfl32(h.pad);
+        const bool truncated = !(pad & XGM_PFX_COMPLETE) || (h.matches & ~XGM_MATCHES_LOWER_BOUND) > (unsigned long long)n;      /* the unit has (or may have) matches it did not list */
         const xgm_prefix_entry* ent = reinterpret_cast<const xgm_prefix_entry*>(cand + (size_t)(g0 + u) * k_stride_c);
         for (uint32_t e0 = 0; e0 < n && !stop; e0 += 64u) {
             xgm_prefix_entry my; my.wbits = 0; my.next_wbits = 0; my.did = 0; my.has_next = 0;
@@ -129,8 +130,8 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
                 if (frozen && have_star && !stop && !fz_before(w_star, 0xFFFFFFFFu, worst_w, worst_d)) { known_is_total = true; stop = true; }
             }
         }
-        /* a unit that stopped listing early, walked to its end with the collation still open: more of the match is needed than was listed */
-        if (!stop && !(pad & XGM_PFX_COMPLETE)) { fallback = true; stop = true; }
+        /* a unit that stopped listing early, its list walked to the end with the collation still open: more of the match is needed than was listed */
+        if (!stop && truncated) { fallback = true; stop = true; }
     }
 
     if (fallback) {
