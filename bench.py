@@ -285,13 +285,19 @@ def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
         db.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     alg_bytes, model_sector, model_useful, tallies = [], [], [], []
     for b in range(min(len(leg.batches), 4)):
-        searcher.run_descs(leg.batches[b][0], leg.batches[b][1], BATCH, k)
-        torch.cuda.synchronize()
-        h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
-        matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
+        if leg.replay and world == 1:
+            # (the replay bits are honoured by the host-delivering entry points: the tallied launch must be the one that was timed)
+            th_, td_ = (_lib.Hit * (BATCH * k))(), (_lib.ResultHdr * BATCH)()
+            _lib.check(L.xgm_get_mset_batch(db._h, leg.batches[b][0], leg.batches[b][1], BATCH, k, th_, td_))
+            matches = np.array([td_[q].matches_exact & ((1 << 63) - 1) for q in range(BATCH)], dtype=np.uint64)
+        else:
+            searcher.run_descs(leg.batches[b][0], leg.batches[b][1], BATCH, k)
+            torch.cuda.synchronize()
+            h = searcher._buffers(BATCH, k)["hdrs"].cpu().numpy().view(np.uint8).reshape(BATCH, 32)   # this shard's own header
+            matches = h[:, 8:16].copy().view(np.uint64).reshape(BATCH) & np.uint64((1 << 63) - 1)      # (bit 63: lower bound only, include/xgm.h)
         post = sum(L.xgm_query_postings_bytes(db._h, C.byref(p)) for p in leg.timed_plans[b * BATCH:(b + 1) * BATCH])
         tl = (C.c_uint64 * 10)()
-        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel")
+        have_tally = L.xgm_last_batch_traffic(db._h, tl, 10) == 0 and kernel_name in ("xgm_andw_kernel", "xgm_orw_kernel", "xgm_orw2_kernel", "xgm_dense_kernel", "xgm_andw_list_kernel")
         bmpw, probes, blkw, hdrs_, dls, aux, cands, npos, probes_raw, dls_raw = [int(x) for x in tl]
         alg_bytes.append(post + int(matches.sum()) * 4 + npos * 4 + BATCH * k * 16)
         if have_tally:
@@ -383,7 +389,7 @@ def snapshot_rows(snap, k, n):
     return out
 
 
-def parity_vs_port(db, leg, n=128, snapshot=None):
+def parity_vs_port(db, leg, n=128, snapshot=None, ora=None):
     """The GPU's answers to the first n queries of the timed pool against the oracle port run on the very postings the device holds
     (copied back from HBM): docids, weight bit patterns, match counts — through xgm_search_batch AND, when `snapshot` is given, the very
     rows the TIMED entry point (xgm_get_mset_batch_begin ... xgm_batch_end) delivered to the host for batch 0 of the last timed step.
@@ -392,8 +398,9 @@ def parity_vs_port(db, leg, n=128, snapshot=None):
     from xapiand_amd import _lib
     L = _lib.lib()
     sample = leg.timed_pool[:n]
-    ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]], positions=leg.op == "PHRASE")
-    ora.warm()
+    if ora is None:
+        ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]], positions=leg.op == "PHRASE")
+        ora.warm()
     want = H.oracle_search_batch(ora, sample, 0, leg.k, reference_select_bug=bool(leg.replay))      # (replay bits: the oracle in reference mode — SelectPostList's frozen weight restated)
     db.set_stream(0)
     k = leg.k
@@ -404,86 +411,72 @@ def parity_vs_port(db, leg, n=128, snapshot=None):
     for qi, (rows, oh) in enumerate(want):
         got = [(hits[qi * k + j].docid, hits[qi * k + j].weight) for j in range(hdrs[qi].n_hits)]
         assert got == [(d, w) for d, w, _ in rows], "GPU/CPU parity failure on %s bench query %d" % (leg.op, qi)
-        H.check_matches(hdrs[qi].matches_exact, oh["matches"], len(got), (leg.op, qi))
+        if not leg.replay:           # (the oracle's reference mode reports what ITS walk counted before SelectPostList shut the loop, not the match count)
+            H.check_matches(hdrs[qi].matches_exact, oh["matches"], len(got), (leg.op, qi))
     timed_rows = 0
     if snapshot is not None:
         for qi, ((rows, oh), (got, hd)) in enumerate(zip(want, snapshot_rows(snapshot, k, min(n, BATCH)))):
             assert got == [(d, w) for d, w, _ in rows], "timed batch / oracle parity failure on %s bench query %d" % (leg.op, qi)
-            H.check_matches(hd[2], oh["matches"], len(got), (leg.op, qi, "timed batch"))
+            if not leg.replay:
+                H.check_matches(hd[2], oh["matches"], len(got), (leg.op, qi, "timed batch"))
             timed_rows += 1
     return len(want), ora, timed_rows
 
 
 def byte_compatible_leg(db, leg, ora, n=256, n_check=128):
-    """The REFERENCE-IDENTICAL modes of C5 / C3 through the C ABI, one query in flight (what the matcher hook does per get_mset in its
-    byte-compatible modes): the ordinary search for the page; then, when the page is full, xgm_search_replay — ProtoMSet's collation
-    replayed on the device over the whole match in docid order (the match never leaves HBM):
-      PHRASE  XGM_REPLAY_FROZEN_WEIGHT: the page, weights and known_matching_docs of the reference incl. SelectPostList's frozen weight
-              (selectpostlist.cc:28-55) — checked here against the oracle's reference mode (pinned to the compiled reference);
-      OR      XGM_REPLAY_COUNT: known_matching_docs behind the HTTP total (protomset.h:340-400) — checked against the host restatement
-              (xgm_known_matching_docs, pinned to the compiled reference) over xgm_search_all's list on a few queries.
-    Returns a dict with queries/s in that mode."""
+    """The byte-compatible modes as the MATCHER HOOK issues them — one query per call, one call per query: xgm_search_batch_known(nq = 1) with
+    the plan's XGM_REPLAY_BATCH_* bits (round 6; round 5: xgm_search, then xgm_search_replay behind it):
+      PHRASE  FROZEN | COUNT: the page, weights and known_matching_docs of the reference incl. SelectPostList's frozen weight
+              (selectpostlist.cc:28-55), listed and replayed on the device — checked against the oracle's reference mode (pinned to the compiled reference);
+      OR      COUNT: known_matching_docs behind the HTTP total (protomset.h:340-400), counted by xgm_search_replay when the call is collected —
+              checked against the host restatement (xgm_known_matching_docs, pinned to the compiled reference) over xgm_search_all's list on a few queries.
+    One query in flight, then 8 host threads.  Returns a dict with queries/s."""
     import helpers as H
     from xapiand_amd import _lib
     L = _lib.lib()
     k = leg.k
     positional = leg.op == "PHRASE"
-    mode = 1 if positional else 0
-    hits = (_lib.Hit * k)()
-    page = (_lib.Hit * k)()
-    hdr, hdr2 = _lib.ResultHdr(), _lib.ResultHdr()
-    known = C.c_uint64()
+    bits = (_lib.XGM_REPLAY_BATCH_FROZEN | _lib.XGM_REPLAY_BATCH_COUNT) if positional else _lib.XGM_REPLAY_BATCH_COUNT
     db.set_stream(0)
     n = min(n, len(leg.timed_plans))
-    lat, answers, replayed = [], [], 0
+    plans = (_lib.Query * n)()
+    for i in range(n):
+        C.memmove(C.byref(plans[i]), C.byref(leg.timed_plans[i]), C.sizeof(_lib.Query))
+        plans[i].replay = bits
+    hits = (_lib.Hit * k)()
+    hdr = _lib.ResultHdr()
+    known = C.c_uint64()
+    lat, answers, full_pages = [], [], 0
     t0 = time.perf_counter()
     for i in range(n):
         a = time.perf_counter()
-        p = leg.timed_plans[i]
-        _lib.check(L.xgm_search(db._h, C.byref(p), hits, C.byref(hdr)))
-        rows, kn = None, None
-        if hdr.n_hits == k and (hdr.matches_exact & ((1 << 63) - 1)) > k or (positional and hdr.n_hits == k):
-            _lib.check(L.xgm_search_replay(db._h, C.byref(p), mode, page, C.byref(hdr2), C.byref(known)))
-            replayed += 1
-            kn = known.value
-            if positional:
-                rows = [(page[j].docid, page[j].weight) for j in range(hdr2.n_hits)]
-        if rows is None:
-            rows = [(hits[j].docid, hits[j].weight) for j in range(hdr.n_hits)]
+        _lib.check(L.xgm_search_batch_known(db._h, C.byref(plans[i]), 1, k, hits, C.byref(hdr), C.byref(known)))
         lat.append(time.perf_counter() - a)
-        answers.append((rows, kn))
+        full_pages += hdr.n_hits == k
+        answers.append(([(hits[j].docid, hits[j].weight) for j in range(hdr.n_hits)], known.value))
     wall = time.perf_counter() - t0
     lat.sort()
     out = {"value": n / wall, "unit": "queries/s", "queries": n, "in_flight": 1, "p50_us": lat[len(lat) // 2] * 1e6, "p99_us": lat[int(len(lat) * 0.99)] * 1e6,
-           "replayed_on_device": replayed,
-           "what": ("xgm_search + xgm_search_replay(XGM_REPLAY_FROZEN_WEIGHT) per query: the reference's own top-%d incl. its frozen weight" % k) if positional else
-                   ("xgm_search + xgm_search_replay(XGM_REPLAY_COUNT) per query: the page + the reference's known_matching_docs (exact HTTP total)")}
-    # the same per-query sequence from 8 host threads at once (Xapiand calls get_mset from every HTTP worker thread; every call takes its
-    # own scratch and stream from the index's pool): rows compared with the one-in-flight answers above
+           "full_pages": full_pages,
+           "what": ("xgm_search_batch_known(nq = 1, FROZEN | COUNT) per query: the reference's own top-%d incl. its frozen weight + its known_matching_docs" % k) if positional else
+                   ("xgm_search_batch_known(nq = 1, COUNT) per query: the page + the reference's known_matching_docs (exact HTTP total)")}
+    # the same calls from 8 host threads at once (Xapiand calls get_mset from every HTTP worker thread), with the index's dispatcher on: the
+    # single-query calls meet in shared launches; rows compared with the one-in-flight answers above
     import threading
     n_thr = 8
     errors = []
 
     def worker(t):
         try:
-            h_, p_ = (_lib.Hit * k)(), (_lib.Hit * k)()
-            r_, r2_, kn_ = _lib.ResultHdr(), _lib.ResultHdr(), C.c_uint64()
+            h_, r_, kn_ = (_lib.Hit * k)(), _lib.ResultHdr(), C.c_uint64()
             for i in range(t, n, n_thr):
-                pl = leg.timed_plans[i]
-                _lib.check(L.xgm_search(db._h, C.byref(pl), h_, C.byref(r_)))
-                rows_, k_ = None, None
-                if r_.n_hits == k and (r_.matches_exact & ((1 << 63) - 1)) > k or (positional and r_.n_hits == k):
-                    _lib.check(L.xgm_search_replay(db._h, C.byref(pl), mode, p_, C.byref(r2_), C.byref(kn_)))
-                    k_ = kn_.value
-                    if positional:
-                        rows_ = [(p_[j].docid, p_[j].weight) for j in range(r2_.n_hits)]
-                if rows_ is None:
-                    rows_ = [(h_[j].docid, h_[j].weight) for j in range(r_.n_hits)]
-                if (rows_, k_) != answers[i]:
+                _lib.check(L.xgm_search_batch_known(db._h, C.byref(plans[i]), 1, k, h_, C.byref(r_), C.byref(kn_)))
+                if ([(h_[j].docid, h_[j].weight) for j in range(r_.n_hits)], kn_.value) != answers[i]:
                     errors.append(i)
         except Exception as e:            # noqa: BLE001  (reported below: a thread must not die silently)
             errors.append(repr(e))
 
+    _lib.check(L.xgm_index_set_batching(db._h, 64))
     thr = [threading.Thread(target=worker, args=(t,)) for t in range(n_thr)]
     t0 = time.perf_counter()
     for t in thr:
@@ -491,34 +484,30 @@ def byte_compatible_leg(db, leg, ora, n=256, n_check=128):
     for t in thr:
         t.join()
     wall_c = time.perf_counter() - t0
+    _lib.check(L.xgm_index_set_batching(db._h, 0))
     assert not errors, "concurrent byte-compatible searches differ from the sequential ones: %r" % errors[:4]
-    out["concurrent"] = {"value": n / wall_c, "unit": "queries/s", "host_threads": n_thr, "queries": n,
-                         "rows_equal_to_one_in_flight": True}
+    out["concurrent"] = {"value": n / wall_c, "unit": "queries/s", "host_threads": n_thr, "queries": n, "dispatcher": "xgm_index_set_batching(64)",
+                         "rows_equal_to_one_in_flight": True, "note": "Python threads: the GIL bounds this figure; hook_parity's threaded legs run native threads"}
     if positional:
         sample = leg.timed_pool[:min(n_check, n)]
         want = H.oracle_search_batch(ora, sample, 0, k, reference_select_bug=True)
-        differs_from_intended = 0
-        intended = H.oracle_search_batch(ora, sample, 0, k)
-        for qi, ((rows, _), (irows, _)) in enumerate(zip(want, intended)):
+        for qi, (rows, _) in enumerate(want):
             assert answers[qi][0] == [(d, w) for d, w, _ in rows], "reference-mode parity failure on C5 bench query %d" % qi
-            differs_from_intended += [(d, w) for d, w, _ in rows] != [(d, w) for d, w, _ in irows]
         out["parity_checked_queries"] = len(want)
         out["parity_against"] = "oracle/xgm_oracle.cc in reference mode (SelectPostList's stale cached weight restated; pinned to the compiled reference)"
-        out["answers_that_differ_from_the_intended_top_k"] = differs_from_intended
     else:
         L.xgm_known_matching_docs.restype = C.c_uint64
         L.xgm_known_matching_docs.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.c_uint32]
         checked = 0
+        hdr2 = _lib.ResultHdr()
         for qi in range(min(6, n)):
-            if answers[qi][1] is None:
-                continue
             p = leg.timed_plans[qi]
             cap = max(1, p.est_max)
             allh = (_lib.Hit * cap)()
             nm = C.c_uint64()
             _lib.check(L.xgm_search_all(db._h, C.byref(p), allh, cap, C.byref(nm), C.byref(hdr2)))
             w = (C.c_double * nm.value)(*[allh[j].weight for j in range(nm.value)])
-            assert L.xgm_known_matching_docs(w, nm.value, k, p.check_at_least) == answers[qi][1], "known_matching_docs differs on C3 bench query %d" % qi
+            assert L.xgm_known_matching_docs(w, nm.value, k, p.check_at_least) == answers[qi][1], "known_matching_docs differs on %s bench query %d" % (leg.op, qi)
             checked += 1
         out["known_matching_docs_checked_queries"] = checked
     return out
@@ -645,15 +634,33 @@ def main():
     # ---- the other single-GPU configurations of BASELINE.json in the same run: C3 (5-term OR, top-100), C5 (2-3-term PHRASE, top-10) ----
     if rank == 0 and headline and not args.no_other_configs:
         others = {}
-        for name, op, terms, kk, st in (("C3", "OR", 5, 100, max(2, args.steps // 4)), ("C5", "PHRASE", 3, 10, max(2, args.steps // 4))):
+        FROZEN, COUNT = _lib.XGM_REPLAY_BATCH_FROZEN, _lib.XGM_REPLAY_BATCH_COUNT
+        for name, op, terms, kk, st in (("C3", "OR", 5, 100, max(10, args.steps // 2)), ("C5", "PHRASE", 3, 10, max(10, args.steps // 2))):
             try:
-                lg = Leg(searcher, op, terms, 1, kk, n_docs_global, args.vocab, n_pool_batches)
+                # C5's credited figure is the REFERENCE's answer: every query carries XGM_REPLAY_BATCH_FROZEN — the page
+                # SelectPostList's frozen weight leaves (selectpostlist.cc:28-55), listed and replayed on the device inside the batch
+                lg = Leg(searcher, op, terms, 1, kk, n_docs_global, args.vocab, n_pool_batches, replay=FROZEN if op == "PHRASE" else 0)
                 mm = measure(db, searcher, lg, args, world, rank, dev, st, 1)
                 ll = latency_leg(db, lg, min(220, len(lg.timed_pool))) if not args.no_latency else []
                 checked, ora, timed_rows = parity_vs_port(db, lg, 128, mm.pop("_snapshot", None))
                 port = None
                 if not args.no_cpu_baseline:
                     port = time_port(ora, lg.timed_pool[:32], op, kk, min(4.0, args.cpu_seconds), 0)
+                extra_modes = {}
+                if op == "PHRASE":
+                    # beside it: the intended semantics (the top-k of the reference's own full ranking, positional pruning) and the reference's
+                    # page WITH its exact known_matching_docs (FROZEN | COUNT: the listing units walk their whole range)
+                    for mname, bits in (("intended_semantics_mode", 0), ("reference_identical_with_exact_count_mode", FROZEN | COUNT)):
+                        lg2 = Leg(searcher, op, terms, 1, kk, n_docs_global, args.vocab, n_pool_batches, replay=bits)
+                        m2 = measure(db, searcher, lg2, args, world, rank, dev, st, 1)
+                        c2, _, t2 = parity_vs_port(db, lg2, 128, m2.pop("_snapshot", None), ora=ora)
+                        extra_modes[mname] = {"value": m2["value"], "unit": "queries/s", "ms_per_batch": m2["ms_per_batch"], "kernel": m2["roofline"]["kernel"],
+                                              "kernel_ms": m2["roofline"]["kernel_ms"], "parity_checked_queries": c2, "timed_batch_rows_checked_against_oracle": t2,
+                                              "roofline_frac": m2["roofline"]["frac"], "roofline_basis": m2["roofline"]["basis"]}
+                    intended = H.oracle_search_batch(ora, lg.timed_pool[:128], 0, kk)
+                    refmode = H.oracle_search_batch(ora, lg.timed_pool[:128], 0, kk, reference_select_bug=True)
+                    extra_modes["answers_that_differ_between_the_two_semantics"] = sum(
+                        [(d, w) for d, w, _ in a[0]] != [(d, w) for d, w, _ in b[0]] for a, b in zip(intended, refmode))
                 try:
                     compat = byte_compatible_leg(db, lg, ora)
                 except Exception as e:
@@ -666,14 +673,25 @@ def main():
                                 "last_batch_on_host_equals_synchronous_search": mm["last_batch_on_host_equals_synchronous_search"],
                                 "p50_latency_us": ll[len(ll) // 2] * 1e6 if ll else None, "p99_latency_us": ll[int(len(ll) * 0.99)] * 1e6 if ll else None,
                                 "roofline": mm["roofline"], "parity_checked_queries": checked, "timed_batch_rows_checked_against_oracle": timed_rows,
-                                ("reference_identical_mode" if op == "PHRASE" else "exact_bounds_mode"): compat,
-                                "headline_mode": ("intended semantics (the top-k of the reference's own full ranking, positional pruning); the reference itself answers part of these "
-                                                  "queries differently (SelectPostList's frozen weight, DESIGN.md 7.1): `reference_identical_mode` is its answer, measured beside it") if op == "PHRASE" else
-                                                 "the reference's own top-k (bit-identical); `exact_bounds_mode` adds its known_matching_docs (the exact HTTP total)",
+                                "parity_against": ("oracle/xgm_oracle.cc in REFERENCE mode (SelectPostList's stale cached weight restated; pinned to the compiled reference)"
+                                                   if op == "PHRASE" else "oracle/xgm_oracle.cc (pinned to the compiled reference)"),
+                                "one_query_per_call_mode": compat,
+                                "headline_mode": ("REFERENCE-IDENTICAL: every query carries XGM_REPLAY_BATCH_FROZEN — the reference's own page incl. SelectPostList's frozen weight "
+                                                  "(xgm_andw_list_kernel + xgm_frozen_finish_kernel inside the batch); `intended_semantics_mode` and the mode with the exact "
+                                                  "known_matching_docs are measured beside it") if op == "PHRASE" else
+                                                 "the reference's own top-k (bit-identical); `one_query_per_call_mode` adds its known_matching_docs (the exact HTTP total)",
                                 "cpu_baseline": dict(port, kind="port", sample="first 32 queries of the timed pool, oracle port on the postings copied back from HBM") if port else None}
+                others[name].update(extra_modes)
             except Exception as e:                # a sub-leg must not take the headline line down with it: say what happened
                 others[name] = {"error": repr(e)}
         result["other_configs"] = others
+        # (top-level copies: the driver's record keeps top-level keys)
+        for name in ("C3", "C5"):
+            oc = others.get(name, {})
+            if "value" in oc:
+                result["%s_value" % name.lower()] = oc["value"]
+                result["%s_roofline_frac" % name.lower()] = oc["roofline"]["frac"]
+                result["%s_kernel_ms" % name.lower()] = oc["roofline"]["kernel_ms"]
 
     # ---- CPU baseline: the real reference + the oracle port, on this box's host cores -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -780,29 +798,42 @@ def hook_parity_leg(args, tmp, dbdir, ref_docs, pools, has_positions):
     if not os.path.exists(HOOK_B1):
         return {"skipped": "oracle/_ref/xapian_hook_b1 is not built"}
     out = {"docs": ref_docs, "shapes": {}}
-    total = dict(queries=0, mismatches=0, bounds_violations=0, http_total_equal=0, answered_on_device=0)
-    flags = []
-    for name, mode in (("C2", "exact-bounds"), ("C3", "exact-bounds"), ("C5", "positional-reference")):
+    total = dict(queries=0, mismatches=0, bounds_violations=0, http_total_equal=0, answered_on_device=0, threaded_queries=0, threaded_mismatches=0)
+    # every configuration twice over ONE export + load: in its byte-compatible mode (exact match-count figures; C5: the reference's page AND figures) and in
+    # the hook's default mode (C5: POSITIONAL_REFERENCE's page alone) — each followed by the SAME queries from 64 native threads (Xapiand's load shape:
+    # every HTTP worker its own Database handle, one get_mset at a time; the calls meet in the index's dispatcher), every answer compared
+    flags = ["--threads", "64", "--thread-repeat", "4"]
+    labels = {}
+    for name, mode, label in (("C2", "exact-bounds", "C2"), ("C3", "exact-bounds", "C3"), ("C5", "positional-reference", "C5 (POSITIONAL_REFERENCE)"),
+                              ("C2", "plain", "C2 (default mode)"), ("C3", "plain", "C3 (default mode)"), ("C5", "positional-reference-page", "C5 (POSITIONAL_REFERENCE, page only)")):
         if name == "C5" and not has_positions:
             continue
         qf = os.path.join(tmp, "hook_%s.txt" % name)
-        H.write_queries(qf, [dict(q, first=0) for q in pools[name][:128]])
-        flags += ["--leg", "%s:%s:%s" % (name, mode, qf)]
+        if not os.path.exists(qf):
+            H.write_queries(qf, [dict(q, first=0) for q in pools[name][:128]])
+        leg_name = "%s_%s" % (name, mode)
+        labels[leg_name] = label
+        flags += ["--leg", "%s:%s:%s" % (leg_name, mode, qf)]
     for r in run_hook_b1(flags + ["-"], None, dbdir):
         name = r.pop("leg", "error")
-        out["shapes"]["C5 (POSITIONAL_REFERENCE)" if name == "C5" else name] = r
+        out["shapes"][labels.get(name, name)] = r
         if r.get("queries") and r.get("hook_seconds"):
             r["hook_queries_per_second"] = r["queries"] / r["hook_seconds"]
             r["cpu_matcher_queries_per_second"] = r["queries"] / r["cpu_matcher_seconds"]
+        if r.get("threaded_queries") and r.get("threaded_seconds"):
+            r["threaded_hook_queries_per_second"] = r["threaded_queries"] / r["threaded_seconds"]
         if "export_seconds" in r and "exporter" not in out:
             out["exporter"] = {"docs": r["docs"], "seconds": r["export_seconds"], "segment_bytes": r["segment_bytes"], "open_seconds": r["open_seconds"], "positions": has_positions,
                                "what": "xgm_segment_build_from_glass: the glass B-trees read natively (postlist.glass, position.glass), block-encoded, written; once for all legs"}
     if has_positions:
         out["docs_with_positions"] = ref_docs
-    for r in out["shapes"].values():
+    for label, r in out["shapes"].items():
+        fast = "default mode" in label or "page only" in label          # (the fast modes' match-count figures are bounds, not the reference's: not part of the byte-compatible totals)
         for key in total:
-            if key in r:
+            if key in r and (not fast or key.startswith("threaded")):
                 total[key] += r[key]
+        if fast and r.get("mismatches"):
+            total["mismatches"] += r["mismatches"]
         if "error" in r:
             total["errors"] = total.get("errors", 0) + 1
     out.update(total)

@@ -591,7 +591,9 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     const bool want_count = plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0;
     uint64_t known_raw = 0;
     if (plain) {
-        plan.replay = pos_ref ? (XGM_REPLAY_BATCH_FROZEN | XGM_REPLAY_BATCH_COUNT) : want_count ? XGM_REPLAY_BATCH_COUNT : 0u;
+        /* (POSITIONAL_REFERENCE alone: the reference's page — ranks, docids, weights; with set_exact_bounds its match-count figures too, for which every
+         * document of the conjunction has to be tested: ~9 x the time on frequent-term phrases) */
+        plan.replay = pos_ref ? (XGM_REPLAY_BATCH_FROZEN | (g_exact_bounds.load(std::memory_order_relaxed) ? XGM_REPLAY_BATCH_COUNT : 0u)) : want_count ? XGM_REPLAY_BATCH_COUNT : 0u;
         rc = plan.replay ? xgm_search_batch_known(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr, &known_raw)
                          : xgm_search_batch(sh.idx, &plan, 1, k ? k : 1, hits.data(), &hdr);
     } else {

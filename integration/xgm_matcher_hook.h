@@ -74,11 +74,13 @@ void set_enabled(bool on);                 /* default: on */
  * the intended top-k.  The choice is the deployment's and has to be made:
  *   POSITIONAL_DECLINE   — positional queries stay on the CPU matcher (byte-compatible by construction);
  *   POSITIONAL_INTENDED  — answered on the device with the intended semantics;
- *   POSITIONAL_REFERENCE — byte-compatible AND on the device: when the match exceeds the page, the reference's loop is replayed ON THE
- *     DEVICE over the whole match in docid order (xgm_search_replay, XGM_REPLAY_FROZEN_WEIGHT: a match of any size, phrases of up to 8
- *     terms; rounds 3-4 downloaded the match and looped on the host, <= 3 terms) — true weights until ProtoMSet's min_weight turns
- *     positive, then the FROZEN weight: that of the first document of the underlying conjunction after that point (vet() weighs before
- *     test_doc()), served for every later match and compared against min_weight to skip the rest.  Only the page crosses PCIe.
+ *   POSITIONAL_REFERENCE — the reference's own page AND on the device (round 6: inside the batch every other search rides in): the plan carries
+ *     XGM_REPLAY_BATCH_FROZEN — the query's units list their first matches in docid order, one wave replays ProtoMSet over them: true weights until
+ *     min_weight turns positive, then the FROZEN weight: that of the first document of the underlying conjunction after that point (vet() weighs
+ *     before test_doc()), served for every later match (xgm_andw_list_kernel + xgm_frozen_finish_kernel; shapes the listing kernel does not take —
+ *     more than 4 terms, pages beyond 64 — are replayed one query at a time over the whole match, xgm_search_replay).  Ranks, docids, weights,
+ *     max_attained are the reference's; its match-count figures too when set_exact_bounds(true) (XGM_REPLAY_BATCH_COUNT: every document of the
+ *     conjunction is then tested — slower), else the looser bounds of every other shape.
  * Until set_positional_mode has been called positional queries are declined. */
 enum PositionalMode { POSITIONAL_DECLINE = 0, POSITIONAL_INTENDED = 1, POSITIONAL_REFERENCE = 2 };
 void set_positional_mode(PositionalMode m);

@@ -10,7 +10,7 @@
  *   xapian_hook_b1 [--decline-positional] [--stale] <queries.txt> <dbdir> [<dbdir> ...]
  *   xapian_hook_b1 --leg <name>:<mode>:<queries.txt> [--leg ...] - <dbdir> [...]      several query files against ONE export + load of the
  *       shards (bench.py's hook_parity at 10 M documents: the export is the expensive part); mode = plain | exact-bounds |
- *       positional-reference | positional-intended; one JSON line per leg ("leg": name), the exit code covers all of them
+ *       positional-reference (page + exact figures) | positional-reference-page | positional-intended; one JSON line per leg ("leg": name), the exit code covers all of them
  * Each shard's segment is exported from its glass directory by the native reader (xgm_segment_build_from_glass) and
  * loaded onto device 0.  --stale registers every shard under a wrong revision: every search must then be declined
  * (CPU path) and still answer identically.  Test infrastructure (tests/test_gpu_hook_b1.py); query file format as
@@ -223,8 +223,9 @@ int main(int argc, char** argv) {
         for (const Leg& leg : legs) {
         if (!leg.file.empty()) {
             queries = read_queries(leg.file.c_str());
-            exact_bounds_on = leg.mode == "exact-bounds";
-            positional_reference_on = leg.mode == "positional-reference";
+            /* (positional-reference: the reference's page AND its match-count figures; positional-reference-page: the page alone — the faster mode) */
+            exact_bounds_on = leg.mode == "exact-bounds" || leg.mode == "positional-reference";
+            positional_reference_on = leg.mode == "positional-reference" || leg.mode == "positional-reference-page";
             xgm_hook::set_exact_bounds(exact_bounds_on);
             xgm_hook::set_positional_mode(positional_reference_on ? xgm_hook::POSITIONAL_REFERENCE : xgm_hook::POSITIONAL_INTENDED);
         }
@@ -282,7 +283,7 @@ int main(int argc, char** argv) {
             const bool positional = q.op == "PHRASE" || q.op == "NEAR";
             const bool exact_bounds = !q.collapse_max && (q.sort_mode == "V" || q.sort_mode == "VR" || q.sort_mode == "K" || q.sort_mode == "KR" ||
                                                           (exact_bounds_on && !positional && q.sort_mode.empty()) ||
-                                                          (positional_reference_on && positional && q.sort_mode.empty()) ||
+                                                          (positional_reference_on && exact_bounds_on && positional && q.sort_mode.empty()) ||
                                                           (want.get_matches_lower_bound() == want.get_matches_upper_bound()));
             if (dbs.size() == 1 && replay_on && (q.collapse_max || q.cut_percent || q.cut_weight != 0.0 || q.spy_slot >= 0)) {
                 /* replayed through the reference's own collation: every figure is the CPU matcher's */

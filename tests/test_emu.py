@@ -223,7 +223,7 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
     assert len(qs) >= 8, len(qs)
     qf = str(tmp_path / "qp.txt")
     H.write_queries(qf, qs)
-    out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
+    out = _run_hook_emulated(T, alias, "--positional-reference", "--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
     assert out["answered_on_device"] == len(qs), out
 
@@ -261,7 +261,7 @@ def test_byte_compatible_modes_beyond_one_device_page_under_emulation(emu_lib, t
     assert out["http_total_equal"] == len(plain) and out["replayed"] >= 3, out
     qf = str(tmp_path / "qbigpos.txt")
     H.write_queries(qf, positional)
-    out = _run_hook_emulated(T, alias, "--positional-reference", qf, one)
+    out = _run_hook_emulated(T, alias, "--positional-reference", "--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(positional), out
     assert out["answered_on_device"] == len(positional), out
 
@@ -314,7 +314,7 @@ def test_near_colocated_switch_through_the_hook_under_emulation(emu_lib, tmp_pat
     H.write_queries(qc, qs)
     intended = _run_hook_emulated(T, alias, "--near-colocated", qc, dbc, mismatches_expected=True)
     assert intended["answered_on_device"] == len(qs) and 0 < intended["mismatches"] <= len(qs), intended
-    compat = _run_hook_emulated(T, alias, "--near-colocated", "--positional-reference", qc, dbc)
+    compat = _run_hook_emulated(T, alias, "--near-colocated", "--positional-reference", "--exact-bounds", qc, dbc)
     assert compat["answered_on_device"] == 0 and compat["mismatches"] == 0 and compat["bounds_violations"] == 0, compat
 
 

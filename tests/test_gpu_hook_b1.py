@@ -433,9 +433,13 @@ def test_positional_reference_mode_is_byte_compatible(built, glass):
     assert len(qs) >= 24, len(qs)
     qf = str(d / "qpr.txt")
     H.write_queries(qf, qs)
-    out = run_b1("--positional-reference", qf, one)
+    out = run_b1("--positional-reference", "--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
     assert out["answered_on_device"] == len(qs), out
+    # the page alone (POSITIONAL_REFERENCE without exact bounds — the fast mode: the listing units stop as soon as the page is decided):
+    # ranks, docids, weight bits, percentages are the CPU matcher's; the match-count figures are bounds that hold
+    out = run_b1("--positional-reference", qf, one)
+    assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
     # the same queries with the intended semantics: the device's answer is NOT the CPU matcher's on some of them (that is the quirk)
     r = subprocess.run([HOOK_B1, qf, one], capture_output=True, text=True, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -463,7 +467,7 @@ def test_positional_reference_mode_takes_long_phrases(built, tmp_path):
     assert len(qs) >= 20 and sum(len(q["terms"]) >= 5 for q in qs) >= 4, (len(qs), [len(q["terms"]) for q in qs])
     qf = str(tmp_path / "qlong.txt")
     H.write_queries(qf, qs)
-    out = run_b1("--positional-reference", qf, one)
+    out = run_b1("--positional-reference", "--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(qs), out
     assert out["answered_on_device"] == len(qs) and out["replayed"] == len(qs), out
 
@@ -547,6 +551,6 @@ def test_byte_compatible_modes_beyond_one_device_page(built, glass):
     assert out["http_total_equal"] == len(plain) and out["replayed"] >= 10, out
     qf = str(d / "qbigpos.txt")
     H.write_queries(qf, positional)
-    out = run_b1("--positional-reference", qf, one)
+    out = run_b1("--positional-reference", "--exact-bounds", qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["http_total_equal"] == len(positional), out
     assert out["answered_on_device"] == len(positional), out

@@ -2815,9 +2815,11 @@ extern "C" int xgm_last_batch_traffic(xgm_index* idx, uint64_t* out, uint32_t n)
     HIP_TRY(hipDeviceSynchronize());
     std::vector<xgm_group_hdr> h(idx->last_n_work);
     HIP_TRY(hipMemcpy(h.data(), idx->last_ghdr, h.size() * sizeof(xgm_group_hdr), hipMemcpyDeviceToHost));
+    /* (a LIST launch: c_pos carries the unit's first weight, the positions tested ride in c_pad[1]; its entries are 24 bytes, 1.5 candidates) */
+    const bool list = idx->last_kernel && !strcmp(idx->last_kernel, "xgm_andw_list_kernel");
     for (const xgm_group_hdr& g : h) {
         t[0] += g.c_bmp_words; t[1] += g.c_probes; t[2] += g.c_blk_words; t[3] += g.c_hdrs;
-        t[4] += g.c_doclen; t[5] += g.c_aux_words; t[6] += g.n_cand; t[7] += g.c_pos;
+        t[4] += g.c_doclen; t[5] += g.c_aux_words; t[6] += list ? (g.n_cand * 3u + 1u) / 2u : g.n_cand; t[7] += list ? g.c_pad[1] : g.c_pos;
         t[8] += g.c_probes_raw; t[9] += g.c_doclen_raw;
     }
     for (uint32_t i = 0; i < n && i < XGM_TRAFFIC_FIELDS; ++i) out[i] = t[i];

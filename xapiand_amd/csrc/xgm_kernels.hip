@@ -692,6 +692,7 @@ static_assert(dense_wave_bytes(true, 4) <= 6144 + 4 * 2048 && flat_wave_bytes(tr
  * xgm_frozen_finish_kernel (xgm_frozen.hip) then walks each query's lists as ProtoMSet + SelectPostList would (protomset.h:340-400,
  * selectpostlist.cc:28-55).  Queries with neither body (terms without containers and flat arrays, more than 4 terms, k > 64) are declined
  * per unit: the host answers them with the per-query replay. */
+template <bool TALLY>
 __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                                                 const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
                                                                                 uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -707,8 +708,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel
     const uint32_t flags = rfl32(queries[wk.qi].flags);
     const uint32_t W = 1u << seg.stripe_bits;
     unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, 1u, spg_max, true, false);
-    if (flags & XGM_QF_DENSE) { xgm_dense_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
-    if (flags & XGM_QF_FLAT) { xgm_flat_unit<true, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
+    if (flags & XGM_QF_DENSE) { xgm_dense_unit<true, TALLY, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
+    if (flags & XGM_QF_FLAT) { xgm_flat_unit<true, TALLY, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, unit_matches, fuse); return; }
     if (lane == 0u) {
         xgm_group_hdr h = {};
         h.pad = XGM_PFX_DECLINED;
@@ -2487,10 +2488,17 @@ int xgm_launch_andw_list(const xgm_match_launch& L, hipStream_t stream) {
     const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, false, L.stripes_per_group, true, false);
     if (smem > 160u * 1024u) return xgm_launch_error("andw list kernel LDS budget", 0, "LDS request exceeds 160 KiB");
     const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
-    auto kern = xgm_andw_list_kernel;
-    static std::atomic<size_t> seen{0};
-    if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
-    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
+    if (L.tally) {
+        auto kern = xgm_andw_list_kernel<true>;
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
+        XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
+    } else {
+        auto kern = xgm_andw_list_kernel<false>;
+        static std::atomic<size_t> seen{0};
+        if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
+        XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, L.hist, L.fuse);
+    }
     XGM_HIP_CHECK(hipGetLastError());
     return 0;
 }
