@@ -70,8 +70,9 @@ def parse_args():
     ap.add_argument("--terms", type=int, default=3)
     ap.add_argument("--required", type=int, default=1, help="AND_NOT / AND_MAYBE / FILTER: terms of the left-hand AND")
     ap.add_argument("--topk", type=int, default=10)
-    ap.add_argument("--replay", choices=("none", "frozen"), default="none",
-                    help="PHRASE: frozen = every query carries XGM_REPLAY_BATCH_FROZEN — the REFERENCE's own page (SelectPostList's frozen weight) at batch throughput")
+    ap.add_argument("--replay", choices=("none", "frozen", "count", "frozen+count"), default="none",
+                    help="frozen (PHRASE): every query carries XGM_REPLAY_BATCH_FROZEN — the REFERENCE's own page (SelectPostList's frozen weight) at batch throughput; "
+                         "count: XGM_REPLAY_BATCH_COUNT — ProtoMSet's known_matching_docs (the exact HTTP total) with every page")
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -578,7 +579,8 @@ def main():
     L = _lib.lib()
     n_pool_batches = max(4, args.batches_per_step)
     leg = Leg(searcher, args.op, args.terms, args.required, k, n_docs_global, args.vocab, n_pool_batches,
-              replay=_lib.XGM_REPLAY_BATCH_FROZEN if (args.replay == "frozen" and args.op == "PHRASE") else 0)
+              replay=((_lib.XGM_REPLAY_BATCH_FROZEN if ("frozen" in args.replay and args.op == "PHRASE") else 0) |
+                      (_lib.XGM_REPLAY_BATCH_COUNT if "count" in args.replay else 0)))
     m = measure(db, searcher, leg, args, world, rank, dev, args.steps, args.warmup)
     n_timed = len(leg.timed_pool)
 

@@ -95,3 +95,40 @@ def test_batch_frozen_equals_the_per_query_replay_and_the_reference(built, tmp_p
         assert page == want_page and known == want_known and hdr.matches_exact == want_hdr.matches_exact, (q, known, want_known)
     db.close()
     c.close()
+
+
+@pytest.mark.parametrize("stripe_bits", [0, 10])
+def test_batch_count_of_conjunctions_equals_the_per_query_replay(built, tmp_path, stripe_bits):
+    """XGM_REPLAY_BATCH_COUNT on plain conjunctions: xgm_andw_all_kernel's units list every match, xgm_count.hip scans the units' top-k lists and replays
+    ProtoMSet per unit — page, header and known_matching_docs against xgm_search_replay(XGM_REPLAY_COUNT), which walks one query's whole match (itself
+    checked against the host restatement pinned to the compiled reference, tests/test_gpu_all.py).  Frequent and rare terms (the dense and the flat body),
+    pages of several sizes, a first > 0, FILTER, a check_at_least beyond the page (counted when the batch is collected) and a tiny arena (overflow)."""
+    n_docs, vocab = (3000, 300) if QUICK else (60000, 6000)
+    c = H.Corpus(n_docs, vocab)
+    db = Database(c.build_segment(str(tmp_path / "c.seg"), stripe_bits=stripe_bits))
+    n = (lambda full, quick: quick if QUICK else full)
+    qs = (H.gen_term_queries("AND", n(30, 5), 2, 1, 30, seed=381) + H.gen_term_queries("AND", n(30, 5), 3, 1, 200, seed=382) +
+          H.gen_term_queries("AND", n(20, 3), 2, 20, 3000, seed=383) + H.gen_term_queries("AND", n(10, 2), 4, 1, 40, seed=384) +
+          H.gen_sided_queries("FILTER", n(10, 2), 2, 1, 1, 100, seed=385))
+    shapes = [(0, 10, 0), (0, 1, 0), (3, 7, 0), (0, 64, 0), (0, 10, 500), (0, 100, 0)]
+    plans, meta = [], []
+    for qi, q in enumerate(qs):
+        query = Query(q["op"], q["terms"], n_required=q.get("n_required", 0))
+        for first, maxitems, cal in (shapes if not QUICK else shapes[qi % 2::2]):
+            plans.append(plan(db, query, first, maxitems, check_at_least=max(cal, first + maxitems)))
+            meta.append((q, first, maxitems, cal))
+    before = replay_info()
+    got = search_batch_replay(db, plans, replay=_lib.XGM_REPLAY_BATCH_COUNT)
+    after = replay_info()
+    on_device, declined, collected = (after[i] - before[i] for i in range(3))
+    events = 0
+    for what, p, (page, hdr, known) in zip(meta, plans, got):
+        want_page, want_hdr, want_known = search_replay(db, p)
+        assert page == want_page, (what, page[:3], want_page[:3])
+        assert known == want_known and hdr.matches_exact == want_hdr.matches_exact and hdr.n_hits == want_hdr.n_hits, (what, known, want_known, hdr.matches_exact, want_hdr.matches_exact)
+        if want_page:
+            assert hdr.max_attained == want_hdr.max_attained and hdr.max_weight_subqs_matched == want_hdr.max_weight_subqs_matched, what
+        events += known < want_hdr.matches_exact
+    assert on_device >= (6 if QUICK else 300) and collected >= (1 if QUICK else 30) and events >= (2 if QUICK else 50), (on_device, declined, collected, events)
+    db.close()
+    c.close()

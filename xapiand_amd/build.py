@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libxgm.so")
-SOURCES = ["xgm_api.cc", "xgm_plan.cc", "xgm_segment_build.cc", "xgm_glass.cc", "xgm_kernels.hip", "xgm_dense_and.hip", "xgm_or.hip", "xgm_synth.hip", "xgm_dense.hip", "xgm_all.hip", "xgm_replay.hip", "xgm_frozen.hip"]
+SOURCES = ["xgm_api.cc", "xgm_plan.cc", "xgm_segment_build.cc", "xgm_glass.cc", "xgm_kernels.hip", "xgm_dense_and.hip", "xgm_or.hip", "xgm_synth.hip", "xgm_dense.hip", "xgm_all.hip", "xgm_replay.hip", "xgm_frozen.hip", "xgm_count.hip"]
 # -ffp-contract=off: BM25 must round exactly like the reference's separate mul/add/div (no FMA).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result",
          "-x", "hip"]

@@ -74,6 +74,8 @@ struct XgmScratch {
     void* h_sorted = nullptr; size_t cap_hsorted = 0;
     xgm_hit* d_part_hits = nullptr; size_t cap_part_hits = 0;   /* results of a heavy batch's parts (run_class_batch, bp.parts > 1) */
     xgm_result_hdr* d_part_hdrs = nullptr; size_t cap_part_hdrs = 0;
+    xgm_hit* d_arena = nullptr; size_t cap_arena = 0;           /* XGM_REPLAY_BATCH_COUNT on conjunctions: every match of the batch (xgm_all_out) */
+    unsigned char* d_count = nullptr; size_t cap_count = 0;     /* ... the arena's cursor, the units' chunk tables, arrival states and document counts */
     unsigned char* d_all = nullptr; size_t cap_all = 0;         /* xgm_search_all: counter, unordered + ordered match lists, the sort's temporary storage */
     bool inorder = false;                                       /* this batch's upload and download go on the batch's stream (the dispatcher's small batches: fewer HIP calls) */
     bool arrive_dirty = false;                                  /* a fused launch on this scratch was not enqueued completely: zero the counters before the next */
@@ -172,6 +174,7 @@ static void scratch_release(xgm_index* idx, XgmScratch* s) {
 static void scratch_destroy(XgmScratch* s) {
     if (!s) return;
     hipFree(s->d_cand); hipFree(s->d_ghdr); hipFree(s->d_in); hipFree(s->d_mkq); hipFree(s->d_hist);
+    hipFree(s->d_arena); hipFree(s->d_count);
     hipFree(s->d_hits); hipFree(s->d_hdrs); hipFree(s->d_part_hits); hipFree(s->d_part_hdrs); hipFree(s->d_arrive); hipFree(s->d_sorted); hipFree(s->d_all);
     if (s->h_sorted) hipHostFree(s->h_sorted);
     if (s->h_up) hipHostFree(s->h_up);
@@ -662,7 +665,8 @@ static bool flat_kind(const xgm_index* idx, const xgm_query& q);
 static int or2_kind(const xgm_index* idx, const xgm_query& q);
 
 static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xgm_dev_query* dq, uint32_t* kq, double* maxposs,
-                      BatchPlan* bp, bool force_general = false, bool list = false) {
+                      BatchPlan* bp, bool force_general = false, int mode = 0) {
+    const bool list = mode == 1;                     /* xgm_andw_list_kernel's launch; mode 2: xgm_andw_all_kernel's (both: one part, no last-unit merge) */
     bp->nq = nq; bp->k_max = 1; bp->tab_terms = 1; bp->phrase = false; bp->wide = false; bp->and_only = true;
     bool or_only = getenv("XGM_NO_ORW") == nullptr;                                  /* A/B switch for measurements */
     bool conj_only = true;       /* every query: AND / PHRASE of >= 2 terms (positional filter or not) */
@@ -905,7 +909,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
         uint32_t gq = (uint32_t)std::min<double>(g_max, std::max<double>(g_min, std::ceil(cost[i] / unit_cost)));
         if (bp->phrase && bp->andw && phrase_unit_stripes && (dq[i].flags & XGM_QF_DENSE) && nq > 4u)
             gq = std::max(gq, std::min(g_max, (n_stripes + phrase_unit_stripes - 1u) / phrase_unit_stripes));
-        if (list && (dq[i].flags & XGM_QF_DENSE)) {
+        if (list && bp->phrase && (dq[i].flags & XGM_QF_DENSE)) {
             /* a LIST unit tests the positions of EVERY document of the conjunction in its range, in docid order, until the query's first matches are
              * found: the launch ends with the longest such walk (measured, round 6: a 3-stripe unit of `t3 t8 t9` — 7 000 documents of the conjunction,
              * 104 matches in the shard — ran 2.5 M cycles, the whole launch 1.27 ms).  Units of about XGM_LIST_UNIT_DOCS documents: the later ones
@@ -923,9 +927,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
     /* xgm_andw_kernel merges a query's lists in its last unit, whatever their number (XGM_NO_FUSED_MERGE: A/B switch, the variant tests) */
     static const bool no_fused = getenv("XGM_NO_FUSED_MERGE") != nullptr;
-    bp->fused = bp->andw && !no_fused && !list;                                                    /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
+    bp->fused = bp->andw && !no_fused && mode == 0;                                                    /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
     /* (list: xgm_andw_list_kernel's units are walked in stripe order by xgm_frozen_finish_kernel, whatever their number: one part) */
-    const uint32_t P = (bp->fused || list) ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
+    const uint32_t P = (bp->fused || mode != 0) ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
     bp->parts = std::max(1u, P);
     const uint32_t upp = bp->parts > 1 ? units_per_part : g_most_q + 1u;
     bp->goff.assign((size_t)nq * bp->parts + 1, 0);
@@ -968,8 +972,9 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
  * rows[i] (i when rows == NULL) of d_hits / d_hdrs (device).  Asynchronous on `stream`. */
 constexpr int XGM_LIST_DECLINED = 2;       /* run_class_batch(list): the batch is not one xgm_andw_list_kernel takes — nothing was enqueued */
 static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xgm_query* qs, uint32_t nq, uint32_t k_stride,
-                           xgm_hit* d_hits, xgm_result_hdr* d_hdrs, const uint32_t* rows, bool list = false, unsigned long long* d_extra = nullptr) {
+                           xgm_hit* d_hits, xgm_result_hdr* d_hdrs, const uint32_t* rows, int mode = 0, unsigned long long* d_extra = nullptr) {
     int rc;
+    const bool list = mode == 1, all = mode == 2;      /* the reference-identical modes: positional queries listed (xgm_andw_list_kernel), conjunctions counted (xgm_andw_all_kernel) */
     /* planned in ordinary (cached) memory and copied to the pinned staging buffer in one go below: the CPU reads pinned
      * host memory at a few GB/s (measured: 250 us per batch for reading 180 KB of device queries back out of it) */
     size_t up_bytes = (size_t)nq * (sizeof(xgm_dev_query) + sizeof(uint32_t) + sizeof(double));
@@ -980,7 +985,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     uint32_t* h_kq = (uint32_t*)(h_mp + nq);
     BatchPlan bp;
     const uint64_t t_pb = now_ns();
-    if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp, false, list))) return rc;
+    if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp, false, mode))) return rc;
     const uint64_t t_st = now_ns();
     g_host_ns[1] += t_st - t_pb;
     if (k_stride < bp.k_max) return xgm_set_error(XGM_E_INVALID, "k_stride %u < first+maxitems %u", k_stride, bp.k_max);
@@ -988,6 +993,23 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         /* the reference-identical mode of positional queries: the units list their first matches (xgm_prefix_entry, 24 bytes) where their candidates would be */
         if (!bp.andw || !bp.phrase || bp.wide || bp.sided || !d_extra) return XGM_LIST_DECLINED;
         bp.k_stride_c = XGM_PREFIX_CAND_STRIDE(bp.k_max);
+    }
+    size_t o_cur = 0, o_tab = 0, o_state = 0, o_before = 0;
+    xgm_all_out all_out;
+    memset(&all_out, 0, sizeof all_out);
+    if (all) {
+        /* every match of the batch goes to one arena (XGM_COUNT_ARENA_ENTRIES, default 16 M entries = 256 MB per batch in flight; a unit whose chunk
+         * does not fit flags its query, which xgm_batch_end then counts by itself) */
+        if (!bp.andw || bp.phrase || bp.wide || bp.sided || !d_extra || bp.k_max > 64u) return XGM_LIST_DECLINED;
+        static const size_t arena_entries = getenv("XGM_COUNT_ARENA_ENTRIES") ? (size_t)std::max(4096ll, atoll(getenv("XGM_COUNT_ARENA_ENTRIES"))) : ((size_t)16 << 20);
+        if ((rc = grow(&s->d_arena, &s->cap_arena, arena_entries))) return rc;
+        o_cur = 0; o_tab = 64;
+        o_state = o_tab + (((size_t)bp.n_work * XGM_ALL_CHUNKS * 4 + 63) & ~(size_t)63);
+        o_before = o_state + (size_t)bp.n_work * bp.k_stride_c * sizeof(xgm_cand);
+        if ((rc = grow(&s->d_count, &s->cap_count, o_before + (size_t)bp.n_work * 8))) return rc;
+        all_out.arena = s->d_arena; all_out.cursor = (unsigned long long*)(s->d_count + o_cur); all_out.cap = std::min<unsigned long long>(arena_entries, 0xFFFFFFFFull);
+        all_out.chunk_tab = (uint32_t*)(s->d_count + o_tab);
+        HIP_TRY(hipMemsetAsync(s->d_count, 0, 64, stream));
     }
     if ((rc = grow(&s->d_cand, &s->cap_cand, (size_t)bp.n_work * bp.k_stride_c))) return rc;
     if ((rc = grow(&s->d_ghdr, &s->cap_ghdr, (size_t)bp.n_work))) return rc;
@@ -1010,7 +1032,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     memcpy(hin + o_go, bp.goff.data(), b_go);
     if (rows) memcpy(hin + o_ro, rows, b_ro);
     /* every query of the batch a conjunction over probe containers only (dense_kind, all of one kind): the kernel written for that */
-    bool dense = !list && bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
+    bool dense = mode == 0 && bp.andw && !bp.wide && bp.sided == 0 && bp.stripes_per_group <= xgm_dense_max_stripes();
     for (uint32_t i = 0; i < nq && dense; ++i) dense = dense_kind(idx, qs[i]) == (bp.phrase ? 2 : 1);
     static const bool dense_class_old_kernel = getenv("XGM_DENSE_CLASS_OLD_KERNEL") != nullptr;      /* A/B: the same class split, xgm_andw_kernel for both */
     if (dense_class_old_kernel) dense = false;
@@ -1094,7 +1116,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe1 = (hipEvent_t)idx->prof_events[idx->prof_used].second;
         ++idx->prof_used;
     }
-    idx->last_kernel = list ? "xgm_andw_list_kernel" : dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
+    idx->last_kernel = all ? "xgm_andw_all_kernel" : list ? "xgm_andw_list_kernel" : dense ? "xgm_dense_kernel" : bp.andw ? "xgm_andw_kernel" : bp.orw2 ? "xgm_orw2_kernel" : bp.orw ? "xgm_orw_kernel" : bp.and_only ? "xgm_and_kernel" : "xgm_match_kernel";
     idx->last_ghdr = s->d_ghdr; idx->last_n_work = bp.n_work;        /* xgm_last_batch_traffic */
     if (bp.orw || (bp.andw && bp.phrase)) {
         if (!hist_zeroed) {
@@ -1117,7 +1139,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         pe0 = pe1 = nullptr;
     }
     if (pe0) HIP_TRY(hipEventRecord(pe0, stream));
-    if ((rc = list ? xgm_launch_andw_list(L, stream) : dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
+    if ((rc = all ? xgm_launch_andw_all(L, all_out, stream) : list ? xgm_launch_andw_list(L, stream) : dense ? xgm_launch_dense(L, stream) : bp.andw ? xgm_launch_andw(L, stream)
               : bp.orw ? xgm_launch_orw(L, s->d_hist, stream)
               : bp.and_only ? xgm_launch_and(L, stream) : xgm_launch_match(L, stream)))
         return rc;
@@ -1128,6 +1150,11 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     if (list) {
         /* one wave per query walks its units' lists as ProtoMSet + SelectPostList would and writes the row (xgm_frozen.hip) */
         if ((rc = xgm_launch_frozen_finish(s->d_queries, nq, s->d_goff, s->d_cand, s->d_ghdr, bp.k_stride_c, s->d_maxposs, d_rows, d_hits, d_hdrs, d_extra, k_stride, stream)))
+            return rc;
+    } else if (all) {
+        /* the scan of the units' top-k lists (= the merge: pages and headers) and ProtoMSet's count per unit, added onto the rows' extra words (xgm_count.hip) */
+        if ((rc = xgm_launch_count_finish(s->d_queries, nq, s->d_work, bp.n_work, s->d_goff, s->d_cand, s->d_ghdr, bp.k_stride_c, all_out, (xgm_cand*)(s->d_count + o_state),
+                                          (unsigned long long*)(s->d_count + o_before), s->d_maxposs, d_rows, d_hits, d_hdrs, d_extra, k_stride, stream)))
             return rc;
     } else if (fused) {
         /* (the kernel wrote d_hits / d_hdrs) */
@@ -1167,6 +1194,7 @@ enum { XGM_CLS_AND = 0, XGM_CLS_SIDED1, XGM_CLS_SIDED2, XGM_CLS_PHRASE, XGM_CLS_
        XGM_CLS_OR2,                              /* disjunctions for xgm_orw2_kernel (or2_kind): ONE launch — its flat-array instantiation takes the queries whose
                                                     every term has a container too (measured, round 5: a launch per kind cost 3.7 ms per 256-query batch against
                                                     2.0 for the old kernel alone: three tails, three sets of unit prologues) */
+       XGM_CLS_COUNTED,                          /* plain conjunctions with XGM_REPLAY_BATCH_COUNT that xgm_andw_all_kernel takes: ProtoMSet's count on the device */
        XGM_CLS_FROZEN,                           /* positional queries answered as the reference answers them (XGM_REPLAY_BATCH_FROZEN) that xgm_andw_list_kernel takes */
        XGM_CLS_COUNT };
 
@@ -1266,6 +1294,14 @@ static bool list_kind(const xgm_index* idx, const xgm_query& q) {
     return positional && (dense_kind(idx, q, true) == 2 || flat_kind(idx, q));
 }
 
+/* xgm_andw_all_kernel's queries: a plain conjunction / FILTER the dense or the flat body takes, a page of at most 64 with check_at_least inside it */
+static bool all_kind(const xgm_index* idx, const xgm_query& q) {
+    if (q.op != XGM_OP_AND && q.op != XGM_OP_FILTER) return false;
+    const uint32_t k = q.first + q.maxitems;
+    if (k == 0u || k > 64u || q.check_at_least > k) return false;
+    return dense_kind(idx, q, true) == 1 || flat_kind(idx, q);
+}
+
 /* Runs the batch; results land in d_hits / d_hdrs (device).  Asynchronous on `stream`.
  * d_extra != NULL (device, [nq] zeroed): the queries' XGM_REPLAY_BATCH_* bits are honoured — rows the device answers get their extra word
  * (known_matching_docs | XGM_EXTRA_*), rows it does not take are appended to *host_replay (answered by xgm_batch_end). */
@@ -1284,10 +1320,14 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         if ((rp & XGM_REPLAY_BATCH_FROZEN) && (qs[i].op == XGM_OP_PHRASE || qs[i].op == XGM_OP_NEAR) && qs[i].phrase_active) {
             if (!no_list && !no_split && list_kind(idx, qs[i])) { cls[i] = XGM_CLS_FROZEN; ++g_batch_replays[0]; }
             else host_replay->push_back(i);
-        } else if (rp & XGM_REPLAY_BATCH_COUNT) host_replay->push_back(i);       /* (the count of a plain operator: by xgm_search_replay when the batch is collected) */
+        } else if (rp & XGM_REPLAY_BATCH_COUNT) {
+            /* ProtoMSet's count: conjunctions on the device (xgm_andw_all_kernel + xgm_count.hip), any other operator by xgm_search_replay when the batch is collected */
+            if (!no_list && !no_split && all_kind(idx, qs[i])) { cls[i] = XGM_CLS_COUNTED; ++g_batch_replays[0]; }
+            else host_replay->push_back(i);
+        }
         if (count[cls[i]]++ == 0) ++present;
     }
-    if ((present <= 1u && !count[XGM_CLS_FROZEN]) || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
+    if ((present <= 1u && !count[XGM_CLS_FROZEN] && !count[XGM_CLS_COUNTED]) || no_split) return run_class_batch(idx, s, stream, qs, nq, k_stride, d_hits, d_hdrs, nullptr);
     /* one launch per class present, all on `stream`; the first uses the caller's scratch, the others take their own
      * from the pool (each is marked pending behind its launch) */
     static thread_local std::vector<xgm_query> sub;
@@ -1301,7 +1341,7 @@ static int run_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, const xg
         XgmScratch* sc = s;
         if (!first && (rc = scratch_acquire(idx, &sc))) break;
         const uint32_t* rows_arg = (present == 1u) ? nullptr : rows.data();
-        rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows_arg, c == XGM_CLS_FROZEN, d_extra);
+        rc = run_class_batch(idx, sc, stream, sub.data(), (uint32_t)sub.size(), k_stride, d_hits, d_hdrs, rows_arg, c == XGM_CLS_FROZEN ? 1 : c == XGM_CLS_COUNTED ? 2 : 0, d_extra);
         if (rc == XGM_LIST_DECLINED) {
             /* (the batch as a whole is not the listing kernel's: the intended-semantics launch now, the replays when the batch is collected) */
             for (uint32_t r : rows) host_replay->push_back(r);
@@ -1461,7 +1501,7 @@ static int batch_host_replays(xgm_inflight* f) {
         if (rc) return rc;
         ++g_batch_replays[2];
         h_extra[i] = known;
-        if (!frozen) { h_hdrs[i].matches_exact = hdr.matches_exact; continue; }      /* (the counting mode keeps the batch's own page: ProtoMSet keeps the same documents) */
+        if (!frozen && !device_declined) { h_hdrs[i].matches_exact = hdr.matches_exact; continue; }      /* (the counting mode keeps the batch's own page: ProtoMSet keeps the same documents) */
         hdr.max_possible = q.max_possible;
         memcpy(h_hits + (size_t)i * f->k_stride, page.data(), (size_t)hdr.n_hits * sizeof(xgm_hit));
         h_hdrs[i] = hdr;

@@ -139,6 +139,22 @@ typedef struct {
 #define XGM_PREFIX_ENTRIES(k) (2u * ((k) + 1u))
 #define XGM_PREFIX_CAND_STRIDE(k_max) (3u * ((k_max) + 1u))      /* 2 (k + 1) entries of 24 bytes in candidates of 16 */
 
+/* xgm_andw_all_kernel (XGM_REPLAY_BATCH_COUNT on plain conjunctions): the units leave their top-k lists as always AND every match — docid, weight — in
+ * docid order, for ProtoMSet's collation to be replayed over (xgm_count.hip).  A unit's list grows in chunks handed out of one arena by an atomic cursor:
+ * chunk c holds XGM_ALL_CHUNK0 << c entries (13 chunks: 524 224 entries, more than a unit's 32 stripes can hold), its first entry in chunk_tab.  The
+ * unit's header: matches = entries listed (exact), c_pad[0] = chunks, c_pad[1] = XGM_ALL_OVERFLOW when the arena ran out (the query is then counted
+ * by the per-query replay when the batch is collected). */
+#define XGM_ALL_CHUNKS 13u
+#define XGM_ALL_CHUNK0 64u
+#define XGM_ALL_OVERFLOW 1u
+#define XGM_ALL_DECLINED 2u     /* the unit's query has no ALL body */
+typedef struct {
+    xgm_hit* arena;
+    unsigned long long* cursor;        /* entries handed out (zeroed before the launch) */
+    unsigned long long cap;            /* entries of the arena (< 2^32) */
+    uint32_t* chunk_tab;               /* [n_work][XGM_ALL_CHUNKS] */
+} xgm_all_out;
+
 /* xgm_andw_kernel finishing its queries itself (xgm_unit_finish.h): the LAST unit of a query to arrive merges the units' lists into
  * the final hits — no merge launch.  arrive == NULL: the units only write their lists (xgm_merge_kernel follows). */
 typedef struct {

@@ -717,6 +717,30 @@ __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel
     }
 }
 
+/* XGM_REPLAY_BATCH_COUNT on plain conjunctions (include/xgm.h): the same units and bodies, which also list EVERY match — docid, weight — in docid order
+ * (xgm_device.h, xgm_all_out); xgm_count.hip then replays ProtoMSet's collation over the lists: an exclusive scan of the units' top-k lists gives every
+ * unit the state the reference's walk has on arrival, one wave per unit counts what ProtoMSet::add would be shown (protomset.h:340-400). */
+__global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_all_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
+                                                                             const xgm_work* __restrict__ work, uint32_t n_work, uint32_t spg_max,
+                                                                             uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
+                                                                             xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out, xgm_all_out all_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
+    if (unit >= n_work) return;                                    /* no barriers below */
+    const xgm_work wk = work[unit];
+    const uint32_t flags = rfl32(queries[wk.qi].flags);
+    const uint32_t W = 1u << seg.stripe_bits;
+    unsigned char* base = smem + (size_t)wave * andw_wave_bytes(W, tab_terms, cap, 1u, spg_max, false, false);
+    if (flags & XGM_QF_DENSE) { xgm_dense_unit<false, false, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr, &all_out); return; }
+    if (flags & XGM_QF_FLAT) { xgm_flat_unit<false, false, false, true>(seg, queries, wk, base, lane, k_stride, cand_out, ghdr_out, nullptr, nullptr, &all_out); return; }
+    if (lane == 0u) {
+        xgm_group_hdr h = {};
+        h.c_pad[1] = XGM_ALL_DECLINED;
+        ghdr_out[wk.slot] = h;
+    }
+}
+
 /* SIDED: 1 = the batch holds AND_NOT queries (excluded terms after the required ones), 2 = also AND_MAYBE
  * (optional terms: weight by the query's summation program, per-document subquery counts).  Separate
  * instantiations, so that the plain conjunction pays nothing for them. */
@@ -2481,6 +2505,19 @@ int xgm_launch_andw(const xgm_match_launch& L, hipStream_t stream) {
     if (L.sided == 2) return L.wide ? launch_andw_variant<uint16_t, false, 2>(L, smem, stream) : launch_andw_variant<uint8_t, false, 2>(L, smem, stream);
     if (L.sided == 1) return L.wide ? launch_andw_variant<uint16_t, false, 1>(L, smem, stream) : launch_andw_variant<uint8_t, false, 1>(L, smem, stream);
     return L.wide ? launch_andw_variant<uint16_t, false, 0>(L, smem, stream) : launch_andw_variant<uint8_t, false, 0>(L, smem, stream);
+}
+
+int xgm_launch_andw_all(const xgm_match_launch& L, const xgm_all_out& out, hipStream_t stream) {
+    if (L.phrase || L.wide || L.sided) return xgm_launch_error("andw all kernel", 0, "plain conjunctions with one-byte wdf only");
+    const size_t smem = xgm_andw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, false, L.stripes_per_group, false, false);
+    if (smem > 160u * 1024u) return xgm_launch_error("andw all kernel LDS budget", 0, "LDS request exceeds 160 KiB");
+    const dim3 grid((L.n_work + XGM_WAVES - 1) / XGM_WAVES), block(XGM_WG);
+    auto kern = xgm_andw_all_kernel;
+    static std::atomic<size_t> seen{0};
+    if (int rc_ = ensure_dyn_smem(kern, smem, seen)) return rc_;
+    XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms, L.cap, L.k_stride, L.cand, L.ghdr, out);
+    XGM_HIP_CHECK(hipGetLastError());
+    return 0;
 }
 
 int xgm_launch_andw_list(const xgm_match_launch& L, hipStream_t stream) {
