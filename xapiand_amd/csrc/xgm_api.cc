@@ -994,7 +994,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         if (!bp.andw || !bp.phrase || bp.wide || bp.sided || !d_extra) return XGM_LIST_DECLINED;
         bp.k_stride_c = XGM_PREFIX_CAND_STRIDE(bp.k_max);
     }
-    size_t o_cur = 0, o_tab = 0, o_state = 0, o_before = 0;
+    size_t o_cur = 0, o_tab = 0, o_state = 0, o_before = 0, o_ver = 0;
     xgm_all_out all_out;
     memset(&all_out, 0, sizeof all_out);
     if (all) {
@@ -1005,8 +1005,9 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
         if ((rc = grow(&s->d_arena, &s->cap_arena, arena_entries))) return rc;
         o_cur = 0; o_tab = 64;
         o_state = o_tab + (((size_t)bp.n_work * XGM_ALL_CHUNKS * 4 + 63) & ~(size_t)63);
-        o_before = o_state + (size_t)bp.n_work * bp.k_stride_c * sizeof(xgm_cand);
-        if ((rc = grow(&s->d_count, &s->cap_count, o_before + (size_t)bp.n_work * 8))) return rc;
+        o_before = o_state + ((size_t)bp.n_work + nq) * bp.k_stride_c * sizeof(xgm_cand);
+        o_ver = o_before + (size_t)bp.n_work * 8;
+        if ((rc = grow(&s->d_count, &s->cap_count, o_ver + (size_t)bp.n_work * 4))) return rc;
         all_out.arena = s->d_arena; all_out.cursor = (unsigned long long*)(s->d_count + o_cur); all_out.cap = std::min<unsigned long long>(arena_entries, 0xFFFFFFFFull);
         all_out.chunk_tab = (uint32_t*)(s->d_count + o_tab);
         HIP_TRY(hipMemsetAsync(s->d_count, 0, 64, stream));
@@ -1154,7 +1155,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     } else if (all) {
         /* the scan of the units' top-k lists (= the merge: pages and headers) and ProtoMSet's count per unit, added onto the rows' extra words (xgm_count.hip) */
         if ((rc = xgm_launch_count_finish(s->d_queries, nq, s->d_work, bp.n_work, s->d_goff, s->d_cand, s->d_ghdr, bp.k_stride_c, all_out, (xgm_cand*)(s->d_count + o_state),
-                                          (unsigned long long*)(s->d_count + o_before), s->d_maxposs, d_rows, d_hits, d_hdrs, d_extra, k_stride, stream)))
+                                          (uint32_t*)(s->d_count + o_ver), (unsigned long long*)(s->d_count + o_before), s->d_maxposs, d_rows, d_hits, d_hdrs, d_extra, k_stride, stream)))
             return rc;
     } else if (fused) {
         /* (the kernel wrote d_hits / d_hdrs) */

@@ -92,11 +92,11 @@ int xgm_launch_frozen_finish(const xgm_dev_query* queries, uint32_t nq, const ui
                              const double* max_possible, const uint32_t* row_of, xgm_hit* hits, xgm_result_hdr* hdrs, unsigned long long* extra, uint32_t k_stride_out,
                              hipStream_t stream);
 /* plain conjunctions with XGM_REPLAY_BATCH_COUNT: the units' top-k lists (L.cand / L.ghdr, no merge) + every match in docid order (out: arena, cursor, chunk
- * table); then — xgm_count.hip — per query an exclusive scan of the units' top-k lists (the page = its total; unit_state [n_work][k_stride_c] = what ProtoMSet
- * keeps when the walk reaches the unit) and per unit the count of what ProtoMSet::add is shown, added onto extra[row] */
+ * table); then — xgm_count.hip — per query an exclusive scan of the units' top-k lists (the page = its total; states [n_work + nq][k_stride_c] = the versions of what ProtoMSet keeps, unit_ver [n_work]
+ * = the version the walk reaches a unit with, unit_before [n_work] = the documents it has seen by then) and per unit the count of what ProtoMSet::add is shown, added onto extra[row] */
 int xgm_launch_andw_all(const xgm_match_launch& L, const xgm_all_out& out, hipStream_t stream);
 int xgm_launch_count_finish(const xgm_dev_query* queries, uint32_t nq, const xgm_work* work, uint32_t n_work, const uint32_t* goff, const xgm_cand* cand,
-                            const xgm_group_hdr* ghdr, uint32_t k_stride_c, const xgm_all_out& lists, xgm_cand* unit_state, unsigned long long* unit_before,
+                            const xgm_group_hdr* ghdr, uint32_t k_stride_c, const xgm_all_out& lists, xgm_cand* states, uint32_t* unit_ver, unsigned long long* unit_before,
                             const double* max_possible, const uint32_t* row_of, xgm_hit* hits, xgm_result_hdr* hdrs, unsigned long long* extra, uint32_t k_stride_out,
                             hipStream_t stream);
 size_t xgm_body_wave_bytes(bool flat, bool phrase, uint32_t terms);      /* LDS a unit of xgm_flat_unit (flat) / xgm_dense_unit uses of the wave's slice */
