@@ -76,6 +76,7 @@ def parse_args():
     ap.add_argument("--stripe-bits", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--ref-docs-per-shard", type=int, default=1_000_000, help="N > 1: documents per shard of the reference's shard indexes (the CPU baseline of C4: a bounded sample)")
     ap.add_argument("--ref-docs", type=int, default=-1, help="documents of the reference glass index built on this box (0: skip the reference leg; "
                     "default: the configuration's own size for the headline workload — indexing 10 M documents through the reference's "
                     "WritableDatabase takes ~3.5 min on the 256-core host —, 1/5 of it for the other operators)")
@@ -206,7 +207,12 @@ def run_steps(db, searcher, leg, steps, bps, depth, world, keep_last=False):
     for b in range(2):
         if pending[b]:
             slots[b]["ev"].synchronize()
-    return host_s, delivered, None
+    last = None
+    if keep_last and i:
+        # the LAST timed batch as it reached the host: (pool batch index, merged hits [BATCH][k][2] f64 views of xgm_hit, headers)
+        sl = slots[(i - 1) & 1]
+        last = ((steps * bps - 1) % nb, sl["hits"].clone(), sl["hdrs"].clone())
+    return host_s, delivered, last
 
 
 def measure(db, searcher, leg, args, world, rank, dev, steps, warmup):
@@ -534,6 +540,87 @@ def latency_leg(db, leg, n_timed):
     return lat
 
 
+def sharded_parity(db, leg, world, rank, k, last, n=32):
+    """N > 1: the first n queries of the LAST TIMED batch — the merged hits as they reached the host inside the timed region — against Xapiand's
+    per-shard protocol run on the ORACLE: every rank answers its own shard (the postings copied back from its GPU) with the MERGED statistics
+    (Enquire::add_prepared_mset, api/enquire.cc:385-394), the per-shard top k are gathered, docids unsharded ((local - 1) * n + shard + 1,
+    mset.cc:367-373) and merged by (weight desc, docid asc) (Matcher::merge_mset, matcher.cc:653-781).  Returns the queries checked (rank 0)."""
+    import struct
+    import torch.distributed as dist
+    import helpers as H
+    b_last, hits_t, hdrs_t = last
+    idx0 = 100 + b_last * BATCH
+    sample = [leg.pool[(idx0 + i) % len(leg.pool)] for i in range(n)]
+    ora = H.DeviceOracle(db, [t for q in sample for t in q["terms"]])
+    mine = []
+    for i, q in enumerate(sample):
+        g = leg.gstats[(idx0 + i) % len(leg.pool)]
+        gs = dict(total_length=g.total_length, collection_size=g.collection_size, has_positions=bool(g.full_db_has_positions),
+                  termfreq=[g.termfreq[t] for t in range(len(q["terms"]))])
+        rows, _ = H.oracle_search(ora, q["op"], q["terms"], 0, k, global_stats=gs)
+        mine.append([(d, w) for d, w, _ in rows])
+    ora.close()
+    allr = [None] * world
+    dist.all_gather_object(allr, mine)
+    if rank != 0:
+        return 0
+    raw = hits_t.numpy().tobytes()
+    hraw = hdrs_t.numpy().tobytes()
+    for qi in range(n):
+        want = sorted(((d - 1) * world + s + 1, w) for s in range(world) for d, w in allr[s][qi])
+        want = sorted(want, key=lambda r: (-r[1], r[0]))[:k]
+        nh = struct.unpack_from("<I", hraw, qi * 32)[0]
+        got = [struct.unpack_from("<IId", raw, (qi * k + j) * 16) for j in range(nh)]
+        assert [(d, w) for d, _, w in got] == want, "sharded parity failure on query %d of the last timed batch: %r vs %r" % (qi, got[:3], want[:3])
+    return n
+
+
+def sharded_cpu_baseline(args, leg, world, k):
+    """N > 1 (C4): the REAL reference running Xapiand's per-shard protocol (prepare_mset on every shard, add_prepared_mset, get_mset per shard,
+    unshard_docids, merge_mset — src/database/handler.cc:1532-1549; oracle/ref_build/ref_driver.cc run_query over several Database handles) on
+    `world` shard indexes built on this box's host cores.  A BOUNDED sample: --ref-docs-per-shard documents per shard (default 1 M; the GPUs hold
+    --docs-per-gpu each), the same round-robin sharding, the same queries; 1 thread and all cores."""
+    import shutil
+    import tempfile
+    import helpers as H
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import ref_index
+    if not H.have_xapian_ref():
+        return {"error": "oracle/_ref/xapian_ref is not built"}
+    per_shard = args.ref_docs_per_shard
+    tmp = tempfile.mkdtemp(prefix="xgm_ref_sh_", dir="/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None)
+    try:
+        t0 = time.time()
+        dirs = []
+        for sh in range(world):
+            d = os.path.join(tmp, "shard%d" % sh)
+            ref_index.build(d, per_shard * world, nopos=True, vocab=args.vocab, n_shards=world, shard=sh, budget_s=args.ref_build_budget or None)
+            dirs.append(d)
+        build_s = time.time() - t0
+        qf1, qfp = os.path.join(tmp, "q1.txt"), os.path.join(tmp, "qp.txt")
+        H.write_queries(qf1, [dict(q, first=0, maxitems=k) for q in leg.timed_pool[:64]])
+        H.write_queries(qfp, [dict(q, first=0, maxitems=k) for q in leg.timed_pool])
+        cores = max(1, os.cpu_count() or 1)
+        one = json.loads(H.xapian_ref("time", qf1, 1, 2, "--seconds", 20, *dirs))
+        runs = []
+        for t in sorted({cores, max(1, cores // 2), max(1, cores // 4)}, reverse=True):
+            runs.append(json.loads(H.xapian_ref("time", qfp, t, 64, "--seconds", max(3.0, args.ref_seconds / 3), *dirs)))
+        best = max(runs, key=lambda r: r["qps"])
+        return {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3, "queries": one["queries"],
+                "all_cores": {"value": best["qps"], "unit": "queries/s", "hardware_threads": cores, "threads": best["threads"], "p50_ms": best["p50_us"] / 1e3,
+                              "thread_counts_tried": [{"threads": r["threads"], "value": r["qps"]} for r in runs]},
+                "cpu_model": cpu_model(), "shards": world, "docs_per_shard": per_shard, "docs_total": per_shard * world, "index_build_seconds": build_s,
+                "index_storage": tmp,
+                "sample": ("Enquire::get_mset of the vendored Xapian through Xapiand's per-shard protocol (prepare_mset / add_prepared_mset / get_mset / unshard_docids / "
+                           "merge_mset, handler.cc:1532-1549; oracle/_ref/xapian_ref time over %d Database handles) on %d round-robin shard indexes of %d documents each "
+                           "(a bounded sample: the GPUs hold %d each), without positions, same queries: 1 thread over the first 64 queries of the timed pool, all cores over the pool"
+                           % (world, world, per_shard, args.docs_per_gpu))}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -584,6 +671,11 @@ def main():
     m = measure(db, searcher, leg, args, world, rank, dev, args.steps, args.warmup)
     n_timed = len(leg.timed_pool)
 
+    # ---- N > 1: one timed batch against Xapiand's protocol on the oracle (every rank takes part) --------------------
+    sharded_checked = None
+    if world > 1 and m.get("_snapshot") is not None:
+        sharded_checked = sharded_parity(db, leg, world, rank, k, m["_snapshot"])
+
     # ---- planning cost (inside every timed step): host microseconds per query ------------------------------------
     plan_us = L.xgm_debug_plan_us(db._h, leg.batches[0][0], leg.batches[0][1], BATCH, 20)
 
@@ -632,6 +724,41 @@ def main():
         }
         if server:
             result["server_mode"] = server
+        if world == 1:
+            result["n_ranks_seen"] = 1
+            result["code_path"] = ("one GPU: xgm_get_mset_batch_begin ... xgm_batch_end, %d batches in flight (no collective; the N > 1 lines add one all-gather of "
+                                   "packed top-k records + a device merge per batch: their N = 1 point is THIS path, not the sharded one)" % args.in_flight)
+
+    # ---- C2 with the reference's known_matching_docs (the exact HTTP total) for every query: XGM_REPLAY_BATCH_COUNT inside the batch ----
+    if rank == 0 and headline and not args.no_other_configs:
+        try:
+            lgc = Leg(searcher, args.op, args.terms, args.required, k, n_docs_global, args.vocab, n_pool_batches, replay=_lib.XGM_REPLAY_BATCH_COUNT)
+            mc = measure(db, searcher, lgc, args, world, rank, dev, max(10, args.steps // 2), 1)
+            # known_matching_docs of a few queries against the host restatement (pinned to the compiled reference) over xgm_search_all's list
+            L.xgm_known_matching_docs.restype = C.c_uint64
+            L.xgm_known_matching_docs.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_uint32, C.c_uint32]
+            nchk = 24
+            qs_ = (_lib.Query * nchk)(*lgc.timed_plans[:nchk])
+            hh, hd, kn = (_lib.Hit * (nchk * k))(), (_lib.ResultHdr * nchk)(), (C.c_uint64 * nchk)()
+            db.set_stream(0)
+            _lib.check(L.xgm_search_batch_known(db._h, qs_, nchk, k, hh, hd, kn))
+            hdr2 = _lib.ResultHdr()
+            for qi in range(nchk):
+                p = lgc.timed_plans[qi]
+                cap = max(1, p.est_max)
+                allh = (_lib.Hit * cap)()
+                nm = C.c_uint64()
+                _lib.check(L.xgm_search_all(db._h, C.byref(p), allh, cap, C.byref(nm), C.byref(hdr2)))
+                w = (C.c_double * max(1, nm.value))(*[allh[j].weight for j in range(nm.value)])
+                assert L.xgm_known_matching_docs(w, nm.value, k, p.check_at_least) == kn[qi], "known_matching_docs differs on C2 bench query %d" % qi
+                assert hd[qi].matches_exact == nm.value, "match count differs on C2 bench query %d" % qi
+            result["exact_bounds_mode"] = {"value": mc["value"], "unit": "queries/s", "ms_per_batch": mc["ms_per_batch"], "kernel": mc["roofline"]["kernel"],
+                                           "kernel_ms": mc["roofline"]["kernel_ms"], "known_matching_docs_checked_queries": nchk,
+                                           "last_batch_on_host_equals_synchronous_search": mc["last_batch_on_host_equals_synchronous_search"],
+                                           "what": "every query carries XGM_REPLAY_BATCH_COUNT: the page + ProtoMSet's known_matching_docs (the exact HTTP total), counted on the "
+                                                   "device inside the batch (xgm_andw_all_kernel lists every match, xgm_count.hip replays ProtoMSet per unit)"}
+        except Exception as e:
+            result["exact_bounds_mode"] = {"error": repr(e)}
 
     # ---- the other single-GPU configurations of BASELINE.json in the same run: C3 (5-term OR, top-100), C5 (2-3-term PHRASE, top-10) ----
     if rank == 0 and headline and not args.no_other_configs:
@@ -698,6 +825,13 @@ def main():
     # ---- CPU baseline: the real reference + the oracle port, on this box's host cores -------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(db, leg.timed_pool, args, k, leg.timed_plans, result, m.get("_snapshot"))
+    if rank == 0 and world > 1:
+        result["parity_checked_queries"] = sharded_checked
+        result["parity_against"] = "Xapiand's per-shard protocol on oracle/xgm_oracle.cc (every rank its own shard with the merged statistics; unshard + merge), the LAST TIMED batch's rows as delivered to the host"
+        result["n_ranks_seen"] = dist.get_world_size()
+        result["code_path"] = "sharded (xgm_get_mset_batch_device + one all-gather of packed records + xgm_merge_shards_packed_device per batch, double-buffered)"
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = sharded_cpu_baseline(args, leg, world, k)
     if rank == 0:
         print(json.dumps(result), flush=True)
     db.close()

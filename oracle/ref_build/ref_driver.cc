@@ -414,12 +414,13 @@ int cmd_build(int argc, char** argv) {
     return 0;
 }
 
-/* build_range <dbdir> <seed> <g_first> <g_last> <vocab> <len_lo> <len_hi> [nopos]
+/* build_range <dbdir> <seed> <g_first> <g_last> <vocab> <len_lo> <len_hi> [nopos|pos [<n_shards> <shard>]]
  * One contiguous slice [g_first, g_last] of the global corpus as its own glass DB (local docids 1..n in global
  * order).  Slices built by parallel processes and merged with `compact` give exactly the database a sequential
  * `build` produces (same documents under the same docids), in a fraction of the wall time — how bench.py gets a
  * reference index onto the GPU box's host cores.  "nopos": wdf only (add_term), for baselines that need no
- * positions. */
+ * positions.  With <n_shards> <shard>: only the documents of that round-robin shard ((g - 1) % n_shards == shard, backends/multi.h:38-73) — the
+ * slices of ONE shard of a sharded corpus (bench.py's N > 1 CPU baseline: Xapiand's per-shard protocol over n_shards such indexes). */
 int cmd_build_range(int argc, char** argv) {
     if (argc < 9) return 2;
     const char* dir = argv[2];
@@ -430,12 +431,15 @@ int cmd_build_range(int argc, char** argv) {
     cp.len_lo = (uint32_t)strtoul(argv[7], nullptr, 0);
     cp.len_hi = (uint32_t)strtoul(argv[8], nullptr, 0);
     const bool nopos = argc > 9 && std::string(argv[9]) == "nopos";
+    const uint64_t n_shards = argc > 11 ? strtoull(argv[10], nullptr, 0) : 1, shard = argc > 11 ? strtoull(argv[11], nullptr, 0) : 0;
+    if (n_shards == 0 || shard >= n_shards) return 2;
     std::vector<uint64_t> thr(cp.vocab);
     xgm_zipf_thresholds(cp.vocab, thr.data());
     Xapian::WritableDatabase db(dir, Xapian::DB_CREATE_OR_OVERWRITE | Xapian::DB_BACKEND_GLASS | Xapian::DB_NO_SYNC);
     char name[16];
     uint64_t added = 0;
     for (uint64_t g = g0; g <= g1; ++g) {
+        if ((g - 1) % n_shards != shard) continue;
         Xapian::Document doc;
         uint32_t len = xgm_doc_len(&cp, g);
         for (uint32_t pos = 1; pos <= len; ++pos) {

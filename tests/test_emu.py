@@ -45,6 +45,9 @@ DEVICE_RUNS = {
     "search_all": ([os.path.join("tests", "test_gpu_all.py")], dict(WORKGROUP, XGM_REPLAY_SEG_MIN="128")),      # (the replay also in parallel segments)
     "flat": ([os.path.join("tests", "test_gpu_flat.py")], {}),
     "positional": ([os.path.join("tests", "test_gpu_positional.py"), "-k", "slow_path or colocated"], {}),
+    # round 6: the reference's collation INSIDE a batch — positional queries listed and replayed (xgm_andw_list_kernel, xgm_frozen.hip), conjunctions counted
+    # (xgm_andw_all_kernel, xgm_count.hip)
+    "batch_replay": ([os.path.join("tests", "test_gpu_frozen_batch.py")], {}),
 }
 
 
@@ -270,6 +273,13 @@ def test_flat_led_conjunctions_under_emulation(device_runs):
     """xgm_flat_unit and the flat posting arrays (round 4) against the oracle, every path through the tallies, without a GPU."""
     out = device_runs("flat")
     assert "3 passed" in out, out
+
+
+def test_batch_replay_modes_under_emulation(device_runs):
+    """XGM_REPLAY_BATCH_FROZEN / _COUNT without a GPU: the listing units, the look-back between them, the frozen-weight walk per query, the lists of every
+    match with their chunks, the scan of the units' top-k lists and the per-unit count — against the one-query replay and the oracle's reference mode."""
+    text = device_runs("batch_replay")
+    assert " passed" in text and "failed" not in text, text[-2000:]
 
 
 def test_positional_slow_paths_under_emulation(device_runs):

@@ -20,8 +20,9 @@ XAPIAN_REF = os.path.join(ROOT, "oracle", "_ref", "xapian_ref")
 CORPUS_SEED = 0x5EED0001
 
 
-def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, len_hi=150, seed=CORPUS_SEED, keep_parts=False, budget_s=None):
-    """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced.  budget_s: give up (TimeoutError, the writers this call
+def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, len_hi=150, seed=CORPUS_SEED, keep_parts=False, budget_s=None, n_shards=1, shard=0):
+    """Returns dict(doccount, build_s, compact_s, procs).  outdir is replaced.  n_shards > 1: the index of round-robin shard `shard` of the n_docs-document
+    corpus (global document g lives in shard (g - 1) % n_shards under local docid (g - 1) // n_shards + 1: backends/multi.h:38-73).  budget_s: give up (TimeoutError, the writers this call
     started are killed) when indexing + compaction take longer — a caller with a time limit of its own (bench.py) falls back."""
     if not os.path.exists(XAPIAN_REF):
         raise RuntimeError("oracle/_ref/xapian_ref is not built")
@@ -41,7 +42,9 @@ def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, l
             break
         d = os.path.join(parts_dir, "p%04d" % i)
         parts.append(d)
-        cmd = [XAPIAN_REF, "build_range", d, hex(seed), str(g0), str(g1), str(vocab), str(len_lo), str(len_hi)] + (["nopos"] if nopos else [])
+        cmd = [XAPIAN_REF, "build_range", d, hex(seed), str(g0), str(g1), str(vocab), str(len_lo), str(len_hi)] + (["nopos"] if nopos else ["pos"] if n_shards > 1 else [])
+        if n_shards > 1:
+            cmd += [str(n_shards), str(shard)]
         running.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL))
     deadline = None if budget_s is None else t0 + budget_s
     for p in running:
@@ -58,7 +61,7 @@ def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, l
     t1 = time.time()
     if len(parts) == 1:
         os.rename(parts[0], outdir)
-        info = dict(doccount=n_docs)
+        info = dict(doccount=n_docs if n_shards == 1 else (n_docs - shard + n_shards - 1) // n_shards)
     else:
         try:
             out = subprocess.run([XAPIAN_REF, "compact", outdir] + parts, check=True, capture_output=True, text=True,
@@ -70,8 +73,9 @@ def build(outdir, n_docs, procs=None, nopos=False, vocab=1_000_000, len_lo=50, l
     t2 = time.time()
     if not keep_parts:
         shutil.rmtree(parts_dir, ignore_errors=True)
-    assert info["doccount"] == n_docs, info
-    return dict(doccount=n_docs, build_s=t1 - t0, compact_s=t2 - t1, procs=len(parts), positions=not nopos)
+    want_docs = n_docs if n_shards == 1 else (n_docs - shard + n_shards - 1) // n_shards
+    assert info["doccount"] == want_docs, (info, want_docs)
+    return dict(doccount=want_docs, build_s=t1 - t0, compact_s=t2 - t1, procs=len(parts), positions=not nopos)
 
 
 if __name__ == "__main__":
