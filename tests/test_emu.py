@@ -48,6 +48,8 @@ DEVICE_RUNS = {
     # round 6: the reference's collation INSIDE a batch — positional queries listed and replayed (xgm_andw_list_kernel, xgm_frozen.hip), conjunctions counted
     # (xgm_andw_all_kernel, xgm_count.hip)
     "batch_replay": ([os.path.join("tests", "test_gpu_frozen_batch.py")], {}),
+    # ... with listing units of a few documents: every stripe of a frequent-term phrase in quarters, the look-back between units at work everywhere
+    "batch_replay_parts": ([os.path.join("tests", "test_gpu_frozen_batch.py"), "-k", "per_query_replay_and_the_reference"], dict(XGM_LIST_UNIT_DOCS="8")),
 }
 
 
@@ -279,6 +281,8 @@ def test_batch_replay_modes_under_emulation(device_runs):
     """XGM_REPLAY_BATCH_FROZEN / _COUNT without a GPU: the listing units, the look-back between them, the frozen-weight walk per query, the lists of every
     match with their chunks, the scan of the units' top-k lists and the per-unit count — against the one-query replay and the oracle's reference mode."""
     text = device_runs("batch_replay")
+    assert " passed" in text and "failed" not in text, text[-2000:]
+    text = device_runs("batch_replay_parts")
     assert " passed" in text and "failed" not in text, text[-2000:]
 
 

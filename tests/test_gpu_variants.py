@@ -53,3 +53,20 @@ def test_replay_in_parallel_segments(built):
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_all.py"), "-x", "-q", "-m", "gpu", "-k", "replay_counts",
                         "-p", "no:cacheprovider"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("switch", ["XGM_LIST_UNIT_DOCS=8", "XGM_LIST_UNIT_DOCS=8,XGM_LIST_NO_STRIPE_PARTS=1", "XGM_LIST_LPT_ORDER=1", "XGM_NO_LIST_KERNEL=1",
+                                    "XGM_COUNT_ARENA_ENTRIES=4096"])
+def test_batch_replay_variants(built, switch):
+    """The reference's collation inside a batch (tests/test_gpu_frozen_batch.py) under its own switches: listing units of a few documents — every stripe of a
+    frequent-term phrase cut into quarters (bits 24.. of a unit's s_end), the look-back between them at work everywhere —, whole stripes only, the work
+    list heaviest-first instead of in stripe order, no listing / counting kernels at all (every row answered by the one-query replay when the batch is
+    collected), and an arena far too small (the counting units overflow: the queries are counted when the batch is collected)."""
+    env = dict(os.environ)
+    for one in switch.split(","):
+        name, _, val = one.partition("=")
+        env[name] = val or "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_frozen_batch.py"), "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "%s:\n%s\n%s" % (switch, r.stdout[-3000:], r.stderr[-2000:])

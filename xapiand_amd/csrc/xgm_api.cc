@@ -898,7 +898,7 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     uint32_t spg_used = 1;
     /* units in descending cost order (longest first); the units of a query share one cost, so ordering the QUERIES
      * (stable) orders the units exactly as a stable sort of all of them would */
-    std::vector<uint32_t> gqv(nq), spgv(nq), order(nq);
+    std::vector<uint32_t> gqv(nq), spgv(nq), order(nq), subv(nq, 1u);       /* subv: LIST — units per stripe (1, 2 or 4: parts of a stripe, see xgm_dense_unit) */
     uint32_t g_most_q = 0;
     /* positional queries: what a unit costs depends on how soon it holds k matches (until then every candidate's positions are tested),
      * which the cost model cannot know — a 3-term phrase of frequent terms with few matches ran 2 ms in ONE 30-stripe unit while the
@@ -917,9 +917,14 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             static const double list_unit_docs = getenv("XGM_LIST_UNIT_DOCS") ? atof(getenv("XGM_LIST_UNIT_DOCS")) : 1024.0;      /* A/B switch */
             const uint32_t spg_l = (uint32_t)std::max(1.0, std::min(32.0, std::floor(list_unit_docs / std::max(1.0, conj_per_stripe[i]))));
             gq = std::max(gq, std::min(n_stripes, (n_stripes + spg_l - 1u) / spg_l));
+            /* ... and below one stripe: halves or quarters of it (word-major bitmaps: a component of the lanes' words is a quarter of the stripe) */
+            static const bool no_parts = getenv("XGM_LIST_NO_STRIPE_PARTS") != nullptr;      /* A/B switch */
+            if (!no_parts && xgm_dense_word_major() && idx->hdr.stripe_bits >= 9u && conj_per_stripe[i] > 1.5 * list_unit_docs && (uint64_t)n_stripes * 4u < (1u << 24))
+                subv[i] = conj_per_stripe[i] > 3.0 * list_unit_docs ? 4u : 2u;
         }
         uint32_t spg = (n_stripes + gq - 1) / gq;
         gq = (n_stripes + spg - 1) / spg;
+        if (subv[i] > 1u && spg == 1u) gq = n_stripes * subv[i]; else subv[i] = 1u;
         spg_used = std::max(spg_used, spg);
         gqv[i] = gq; spgv[i] = spg; order[i] = i;
         g_most_q = std::max(g_most_q, gq);
@@ -946,6 +951,10 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
             xgm_work w;
             const uint32_t p = bp->parts > 1 ? g / upp : 0u;
             w.qi = i; w.s_begin = g * spg; w.s_end = std::min(n_stripes, (g + 1) * spg); w.slot = bp->goff[(size_t)p * nq + i] + (g - p * (bp->parts > 1 ? upp : 0u));
+            if (subv[i] > 1u) {                                    /* part g % sub of stripe g / sub: its component mask rides in s_end's top byte */
+                const uint32_t sub = subv[i], st = g / sub, part = g % sub;
+                w.s_begin = st; w.s_end = (st + 1u) | ((sub == 4u ? (1u << part) : (3u << (2u * part))) << 24);
+            }
             bp->work.push_back(w);
         }
     }
@@ -2535,8 +2544,8 @@ struct ShardDev {
     int device = -1;
     hipStream_t stream = nullptr;
     hipEvent_t ev = nullptr;
-    xgm_hit* all_hits = nullptr;          /* [n_shards][nq_cap * k_cap] gathered array on this device */
-    xgm_result_hdr* all_hdrs = nullptr;   /* [n_shards][nq_cap] */
+    unsigned char* all_rec = nullptr;     /* the gathered array on this device: n_shards packed records — [nq][k_stride] hits then [nq] headers each (xgm_shard_record_bytes) —
+                                             dense for the CALL's nq and k_stride: ONE all-gather / peer copy per shard and call (round 6; two before) */
     xgm_nccl_comm comm = nullptr;
 };
 
@@ -2557,9 +2566,8 @@ struct XgmShardCtx {
 static void shard_ctx_free_buffers(XgmShardCtx* c) {
     for (ShardDev& d : c->devs) {
         if (hipSetDevice(d.device) != hipSuccess) continue;
-        if (d.all_hits) hipFree(d.all_hits);
-        if (d.all_hdrs) hipFree(d.all_hdrs);
-        d.all_hits = nullptr; d.all_hdrs = nullptr;
+        if (d.all_rec) hipFree(d.all_rec);
+        d.all_rec = nullptr;
     }
     if (!c->devs.empty() && hipSetDevice(c->devs[0].device) == hipSuccess) {
         if (c->d_out_hits) hipFree(c->d_out_hits);
@@ -2694,8 +2702,7 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
         const size_t ch = std::max(n_hit, c->cap_hit), cn = std::max<size_t>(nq, c->cap_nq);
         for (ShardDev& d : c->devs) {
             if ((rc = use_device(d.device))) return rc;
-            if ((e = hipMalloc((void**)&d.all_hits, (size_t)n_shards * ch * sizeof(xgm_hit))) != hipSuccess) break;
-            if ((e = hipMalloc((void**)&d.all_hdrs, (size_t)n_shards * cn * sizeof(xgm_result_hdr))) != hipSuccess) break;
+            if ((e = hipMalloc((void**)&d.all_rec, (size_t)n_shards * (ch * sizeof(xgm_hit) + cn * sizeof(xgm_result_hdr)))) != hipSuccess) break;
         }
         if (e == hipSuccess && !(rc = use_device(c->devs[0].device))) {
             if ((e = hipMalloc((void**)&c->d_out_hits, ch * sizeof(xgm_hit))) == hipSuccess)
@@ -2710,12 +2717,12 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
     shard_ctx_try_rccl(c);
     ++c->calls;
 
-    /* the gathered arrays of THIS call are dense [n_shards][nq][k_stride] / [n_shards][nq] at the head of the buffers */
+    /* the gathered records of THIS call are dense at the head of the buffers: shard s's at s * rec — its hits, then its headers */
+    const size_t rec = xgm_shard_record_bytes(nq, k_stride), o_hdr = n_hit * sizeof(xgm_hit);
     /* 1. every shard's search, enqueued on its device's stream — nothing waits yet */
     for (uint32_t s = 0; s < n_shards; ++s) {
         ShardDev& d = c->devs[c->dev_of[s]];
-        if ((rc = search_batch_device_on(shards[s], d.stream, plans[s].data(), nq, k_stride, d.all_hits + (size_t)s * n_hit,
-                                         d.all_hdrs + (size_t)s * nq)))
+        if ((rc = search_batch_device_on(shards[s], d.stream, plans[s].data(), nq, k_stride, d.all_rec + (size_t)s * rec, d.all_rec + (size_t)s * rec + o_hdr)))
             break;
     }
     /* 2. the exchange */
@@ -2725,8 +2732,7 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
         int nrc = api.GroupStart();
         for (size_t r = 0; r < c->devs.size() && nrc == 0; ++r) {
             ShardDev& d = c->devs[r];
-            nrc = api.AllGather(d.all_hits + r * n_hit, d.all_hits, n_hit * sizeof(xgm_hit), /*ncclUint8*/ 1, d.comm, d.stream);
-            if (nrc == 0) nrc = api.AllGather(d.all_hdrs + r * nq, d.all_hdrs, (size_t)nq * sizeof(xgm_result_hdr), 1, d.comm, d.stream);
+            nrc = api.AllGather(d.all_rec + r * rec, d.all_rec, rec, /*ncclUint8*/ 1, d.comm, d.stream);      /* (one shard per device: rank r holds shard r) */
         }
         const int nrc2 = api.GroupEnd();
         if (nrc || nrc2) rc = xgm_set_error(XGM_E_DEVICE, "ncclAllGather failed (%d)", nrc ? nrc : nrc2);
@@ -2735,10 +2741,7 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
         for (uint32_t s = 0; s < n_shards && e == hipSuccess; ++s) {
             ShardDev& d = c->devs[c->dev_of[s]];
             if (c->dev_of[s] == 0) continue;
-            if ((e = hipMemcpyPeerAsync(d0.all_hits + (size_t)s * n_hit, d0.device, d.all_hits + (size_t)s * n_hit, d.device,
-                                        n_hit * sizeof(xgm_hit), d.stream)) != hipSuccess) break;
-            e = hipMemcpyPeerAsync(d0.all_hdrs + (size_t)s * nq, d0.device, d.all_hdrs + (size_t)s * nq, d.device,
-                                   (size_t)nq * sizeof(xgm_result_hdr), d.stream);
+            e = hipMemcpyPeerAsync(d0.all_rec + (size_t)s * rec, d0.device, d.all_rec + (size_t)s * rec, d.device, rec, d.stream);
         }
         for (size_t r = 1; r < c->devs.size() && e == hipSuccess; ++r) {
             if (hipSetDevice(c->devs[r].device) != hipSuccess) { e = hipErrorInvalidDevice; break; }
@@ -2749,7 +2752,7 @@ extern "C" int xgm_search_sharded(xgm_index* const* shards, uint32_t n_shards, c
     }
     /* 3. merge on shards[0]'s device, one download, ONE wait */
     if (rc == XGM_OK && e == hipSuccess && !(rc = use_device(d0.device))) {
-        rc = merge_shards_device_on(shards[0], d0.stream, d0.all_hits, d0.all_hdrs, n_shards, nq, k_stride, kq.data(), c->d_out_hits, c->d_out_hdrs);
+        rc = merge_shards_device_on(shards[0], d0.stream, d0.all_rec, d0.all_rec + o_hdr, n_shards, nq, k_stride, kq.data(), c->d_out_hits, c->d_out_hdrs, rec);
         xgm_hit* h_hits = (xgm_hit*)c->h_out;
         xgm_result_hdr* h_hdrs = (xgm_result_hdr*)(h_hits + n_hit);
         if (rc == XGM_OK) e = hipMemcpyAsync(h_hits, c->d_out_hits, n_hit * sizeof(xgm_hit), hipMemcpyDeviceToHost, d0.stream);

@@ -52,6 +52,7 @@ size_t xgm_dense_smem_bytes(bool phrase) { return XGM_WAVES * dense_wave_bytes(p
 uint32_t xgm_dense_max_terms() { return kDenseT; }
 uint32_t xgm_dense_max_k() { return kDenseCap - 64u; }
 uint32_t xgm_dense_max_stripes() { return kDenseSpg; }
+bool xgm_dense_word_major() { return XGM_DENSE_WORD_MAJOR != 0; }     /* (the positional body's bitmaps: a component of a lane's words = a quarter of the stripe) */
 
 template <bool PHRASE, bool TALLY>
 static int launch_dense_inst(const xgm_match_launch& L, hipStream_t stream) {

@@ -106,6 +106,7 @@ size_t xgm_dense_smem_bytes(bool phrase);
 uint32_t xgm_dense_max_terms();
 uint32_t xgm_dense_max_k();
 uint32_t xgm_dense_max_stripes();
+bool xgm_dense_word_major();
 int xgm_launch_dense(const xgm_match_launch& L, hipStream_t stream);
 /* disjunction-only batches: one wave per work unit, MaxScore pruning; hist = [nq][XGM_OR_HIST] zeroed u32 */
 size_t xgm_orw_smem_bytes(uint32_t stripe_bits, uint32_t tab_terms, uint32_t cap, bool wide, uint32_t spg);
