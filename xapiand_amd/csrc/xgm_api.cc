@@ -658,6 +658,9 @@ struct BatchPlan {
     uint32_t sub_bits = 0; /* workgroup kernels: every stripe in 2^sub_bits passes over narrower tables (positional queries of > 3 terms) */
     int orw2 = 0;          /* orw batch whose every query xgm_orw2_kernel takes: 1 = containers only, 2 = with flat-array terms */
     bool or_flat = false;  /* orw batch: every term without a container has a flat posting array (xgm_orw_kernel's FLAT instantiation) */
+    /* (a plan that is kept between calls — run_class_batch's, per thread: a work list of tens of thousands of units is a megabyte that would otherwise be
+     *  allocated, faulted in and released per batch) */
+    void reset() { work.clear(); goff.clear(); fused = false; parts = 1; sub_bits = 0; orw2 = 0; or_flat = false; }
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
@@ -961,7 +964,17 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* a LIST launch: stripe order — the units of lower stripes are done (and have published their match counts) when those of higher stripes
      * start, which then have nothing to do for every query whose page is decided (PrefixList::look_back) */
     static const bool list_lpt = getenv("XGM_LIST_LPT_ORDER") != nullptr;            /* A/B switch: heaviest first, as the other launches */
-    if (list && !list_lpt) std::stable_sort(bp->work.begin(), bp->work.end(), [](const xgm_work& a, const xgm_work& b) { return a.s_begin < b.s_begin; });
+    if (list && !list_lpt) {
+        /* (a counting sort on the first stripe, stable: tens of thousands of units per batch — a comparison sort of them was the host's largest item) */
+        static thread_local std::vector<uint32_t> at;
+        static thread_local std::vector<xgm_work> sorted;
+        at.assign((size_t)n_stripes + 1u, 0u);
+        for (const xgm_work& w : bp->work) ++at[w.s_begin + 1u];
+        for (uint32_t st = 0; st < n_stripes; ++st) at[st + 1u] += at[st];
+        sorted.resize(bp->work.size());
+        for (const xgm_work& w : bp->work) sorted[at[w.s_begin]++] = w;
+        bp->work.swap(sorted);
+    }
     bp->n_work = (uint32_t)bp->work.size();
     bp->stripes_per_group = spg_used;
     uint32_t g_most = 0;
@@ -992,7 +1005,9 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     xgm_dev_query* h_dq = (xgm_dev_query*)plan_buf.data();
     double* h_mp = (double*)(h_dq + nq);
     uint32_t* h_kq = (uint32_t*)(h_mp + nq);
-    BatchPlan bp;
+    static thread_local BatchPlan bp_tls;
+    BatchPlan& bp = bp_tls;
+    bp.reset();
     const uint64_t t_pb = now_ns();
     if ((rc = plan_batch(idx, qs, nq, h_dq, h_kq, h_mp, &bp, false, mode))) return rc;
     const uint64_t t_st = now_ns();
