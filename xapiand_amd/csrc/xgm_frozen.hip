@@ -77,10 +77,19 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
         worst_w = rl_f64(w, 0u); worst_d = rl32(d, 0u); worst_l = rl32(l, 0u);
     };
 
-    for (uint32_t u = 0; u < U && !stop; ++u) {
-        const xgm_group_hdr& h = ghdr[g0 + u];
-        const uint32_t n = rfl32(h.n_cand), pad = rfl32(h.pad);
-        const bool truncated = !(pad & XGM_PFX_COMPLETE) || (h.matches & ~XGM_MATCHES_LOWER_BOUND) > (unsigned long long)n;      /* the unit has (or may have) matches it did not list */
+    /* the units' headers 64 at a time (a query of frequent terms has thousands of units, nearly all of them empty: skipped by the look-back or without a
+     * match): only the units that list something — or whose list is cut short — are walked, in stripe order */
+    for (uint32_t u0 = 0; u0 < U && !stop; u0 += 64u) {
+        uint32_t hn_ = 0, hp_ = XGM_PFX_COMPLETE; unsigned long long hm_ = 0;
+        if (u0 + lane < U) { const xgm_group_hdr& hh = ghdr[g0 + u0 + lane]; hn_ = hh.n_cand; hp_ = hh.pad; hm_ = hh.matches & ~XGM_MATCHES_LOWER_BOUND; }
+        const bool cut_ = !(hp_ & XGM_PFX_COMPLETE) || hm_ > (unsigned long long)hn_;
+        uint64_t todo = __ballot(hn_ > 0u || cut_);
+    while (todo && !stop) {
+        const uint32_t L_ = (uint32_t)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t u = u0 + L_;
+        const uint32_t n = rl32(hn_, L_), pad = rl32(hp_, L_);
+        const bool truncated = ((__ballot(cut_) >> L_) & 1ull) != 0ull;      /* the unit has (or may have) matches it did not list */
         const xgm_prefix_entry* ent = reinterpret_cast<const xgm_prefix_entry*>(cand + (size_t)(g0 + u) * k_stride_c);
         for (uint32_t e0 = 0; e0 < n && !stop; e0 += 64u) {
             xgm_prefix_entry my; my.wbits = 0; my.next_wbits = 0; my.did = 0; my.has_next = 0;
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
         }
         /* a unit that stopped listing early, its list walked to the end with the collation still open: more of the match is needed than was listed */
         if (!stop && truncated) { fallback = true; stop = true; }
+    }
     }
 
     if (fallback) {
