@@ -35,13 +35,19 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
     /* ---- the units' counts and flags ---- */
     unsigned long long total = 0;
     bool incomplete = false, declined = K > 64u || K == 0u;
-    for (uint32_t u0 = 0; u0 < U; u0 += 64u) {
-        const uint32_t u = u0 + lane;
-        if (u < U) {
-            const xgm_group_hdr& h = ghdr[g0 + u];
-            total += h.matches & ~XGM_MATCHES_LOWER_BOUND;
-            incomplete = incomplete || !(h.pad & XGM_PFX_COMPLETE);
-            declined = declined || (h.pad & XGM_PFX_DECLINED) != 0u;
+    for (uint32_t u0 = 0; u0 < U; u0 += 256u) {                   /* (four headers per lane in flight: a query of frequent terms has thousands of units) */
+        unsigned long long hm4[4]; uint32_t hp4[4];
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+            const uint32_t u = u0 + b * 64u + lane;
+            hm4[b] = 0; hp4[b] = XGM_PFX_COMPLETE;
+            if (u < U) { const xgm_group_hdr& h = ghdr[g0 + u]; hm4[b] = h.matches; hp4[b] = h.pad; }
+        }
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {
+            total += hm4[b] & ~XGM_MATCHES_LOWER_BOUND;
+            incomplete = incomplete || !(hp4[b] & XGM_PFX_COMPLETE);
+            declined = declined || (hp4[b] & XGM_PFX_DECLINED) != 0u;
         }
     }
     for (int sh = 32; sh > 0; sh >>= 1) total += (unsigned long long)__shfl_xor((long long)total, sh);
@@ -79,9 +85,18 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
 
     /* the units' headers 64 at a time (a query of frequent terms has thousands of units, nearly all of them empty: skipped by the look-back or without a
      * match): only the units that list something — or whose list is cut short — are walked, in stripe order */
-    for (uint32_t u0 = 0; u0 < U && !stop; u0 += 64u) {
-        uint32_t hn_ = 0, hp_ = XGM_PFX_COMPLETE; unsigned long long hm_ = 0;
-        if (u0 + lane < U) { const xgm_group_hdr& hh = ghdr[g0 + u0 + lane]; hn_ = hh.n_cand; hp_ = hh.pad; hm_ = hh.matches & ~XGM_MATCHES_LOWER_BOUND; }
+    for (uint32_t u256 = 0; u256 < U && !stop; u256 += 256u) {
+        uint32_t hn4[4], hp4[4]; unsigned long long hm4[4];
+#pragma unroll
+        for (uint32_t b = 0; b < 4u; ++b) {                            /* four batches of headers in flight */
+            hn4[b] = 0; hp4[b] = XGM_PFX_COMPLETE; hm4[b] = 0;
+            if (u256 + b * 64u + lane < U) { const xgm_group_hdr& hh = ghdr[g0 + u256 + b * 64u + lane]; hn4[b] = hh.n_cand; hp4[b] = hh.pad; hm4[b] = hh.matches & ~XGM_MATCHES_LOWER_BOUND; }
+        }
+#pragma unroll
+    for (uint32_t b4 = 0; b4 < 4u; ++b4) {
+        const uint32_t u0 = u256 + b4 * 64u;
+        if (u0 >= U || stop) break;
+        const uint32_t hn_ = hn4[b4], hp_ = hp4[b4]; const unsigned long long hm_ = hm4[b4];
         const bool cut_ = !(hp_ & XGM_PFX_COMPLETE) || hm_ > (unsigned long long)hn_;
         uint64_t todo = __ballot(hn_ > 0u || cut_);
     while (todo && !stop) {
@@ -141,6 +156,7 @@ __global__ __launch_bounds__(64) void xgm_frozen_finish_kernel(const xgm_dev_que
         }
         /* a unit that stopped listing early, its list walked to the end with the collation still open: more of the match is needed than was listed */
         if (!stop && truncated) { fallback = true; stop = true; }
+    }
     }
     }
 
