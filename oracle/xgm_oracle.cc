@@ -134,6 +134,99 @@ Corpus* corpus_build(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint
     return c;
 }
 
+/* The same corpus inverted on the HOST for a handful of terms only — what lets a test at a configuration's full size (10 M documents) feed the oracle
+ * from tools/xgm_corpus.h directly instead of from postings read back from the device.  Every document is generated (doclen and
+ * statistics are the whole shard's), only the tokens of `ranks` are kept: two passes over the documents on n_threads threads — count per (thread, term),
+ * then place — so that no global sort of a billion tokens is needed: a thread's documents ascend, the threads' slices follow each other. */
+Corpus* corpus_build_terms(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint32_t len_lo, uint32_t len_hi, uint32_t n_shards, uint32_t shard,
+                           bool with_positions, const uint32_t* ranks, uint32_t n_ranks, uint32_t n_threads) {
+    xgm_corpus_params cp{seed, vocab, len_lo, len_hi};
+    std::vector<uint64_t> thr(vocab);
+    xgm_zipf_thresholds(vocab, thr.data());
+    /* term order = bytewise order of "t<rank>" */
+    std::vector<uint32_t> rk(ranks, ranks + n_ranks);
+    std::sort(rk.begin(), rk.end());
+    rk.erase(std::unique(rk.begin(), rk.end()), rk.end());
+    std::vector<std::string> names(rk.size());
+    for (size_t i = 0; i < rk.size(); ++i) names[i] = "t" + std::to_string(rk[i]);
+    std::vector<uint32_t> perm(rk.size());
+    for (size_t i = 0; i < perm.size(); ++i) perm[i] = (uint32_t)i;
+    std::sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return names[a] < names[b]; });
+    std::vector<uint32_t> rank2id(vocab + 1, UINT32_MAX);
+    Corpus* c = new Corpus();
+    c->has_positions = with_positions;
+    for (size_t i = 0; i < perm.size(); ++i) { c->terms.push_back(names[perm[i]]); rank2id[rk[perm[i]]] = (uint32_t)i; }
+    const size_t NT = c->terms.size();
+    const uint64_t n_local = n_docs_global > shard ? (n_docs_global - shard + n_shards - 1) / n_shards : 0;
+    c->lastdocid = c->doccount = (uint32_t)n_local;
+    c->doclen.assign(n_local + 1, 0);
+    n_threads = std::max(1u, std::min<uint32_t>(n_threads, (uint32_t)std::max<uint64_t>(1, n_local / 1024)));
+    /* thread t owns local documents (lo_t, hi_t]: global g = (local - 1) * n_shards + shard + 1 */
+    auto lo_of = [&](uint32_t t) { return n_local * t / n_threads; };
+    /* pass 1: per (thread, term) postings and positions; document lengths */
+    std::vector<std::vector<uint64_t>> n_post(n_threads, std::vector<uint64_t>(NT, 0)), n_pos(n_threads, std::vector<uint64_t>(NT, 0));
+    std::vector<uint64_t> len_sum(n_threads, 0);
+    auto walk = [&](uint32_t t, auto&& on_doc_term) {
+        std::vector<uint32_t> cnt(NT, 0), touched;
+        std::vector<std::vector<uint32_t>> ppos(NT);
+        for (uint64_t local = lo_of(t) + 1; local <= lo_of(t + 1); ++local) {
+            const uint64_t g = (local - 1) * n_shards + shard + 1;
+            const uint32_t len = xgm_doc_len(&cp, g);
+            c->doclen[local] = len;
+            touched.clear();
+            for (uint32_t p = 1; p <= len; ++p) {
+                const uint32_t id = rank2id[xgm_token(&cp, thr.data(), g, p)];
+                if (id == UINT32_MAX) continue;
+                if (cnt[id]++ == 0) touched.push_back(id);
+                if (with_positions) ppos[id].push_back(p);
+            }
+            for (uint32_t id : touched) { on_doc_term(id, (uint32_t)local, cnt[id], ppos[id]); cnt[id] = 0; ppos[id].clear(); }
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t]() {
+                uint64_t ls = 0;
+                walk(t, [&](uint32_t id, uint32_t, uint32_t wdf, const std::vector<uint32_t>&) { ++n_post[t][id]; n_pos[t][id] += wdf; });
+                for (uint64_t local = lo_of(t) + 1; local <= lo_of(t + 1); ++local) ls += c->doclen[local];
+                len_sum[t] = ls;
+            });
+        for (auto& x : th) x.join();
+    }
+    for (uint32_t t = 0; t < n_threads; ++t) c->total_length += len_sum[t];
+    /* offsets: term-major, then thread */
+    c->df.assign(NT, 0);
+    c->term_start.assign(NT + 1, 0);
+    std::vector<std::vector<uint64_t>> o_post(n_threads, std::vector<uint64_t>(NT, 0)), o_pos(n_threads, std::vector<uint64_t>(NT, 0));
+    uint64_t np = 0, npos = 0;
+    for (size_t id = 0; id < NT; ++id) {
+        c->term_start[id] = np;
+        for (uint32_t t = 0; t < n_threads; ++t) { o_post[t][id] = np; o_pos[t][id] = npos; np += n_post[t][id]; npos += n_pos[t][id]; c->df[id] += (uint32_t)n_post[t][id]; }
+    }
+    c->term_start[NT] = np;
+    c->did.assign(np, 0); c->wdf.assign(np, 0);
+    if (with_positions) { c->pos_off.assign(np + 1, 0); c->pos.assign(npos, 0); }
+    /* pass 2: place */
+    {
+        std::vector<std::thread> th;
+        for (uint32_t t = 0; t < n_threads; ++t)
+            th.emplace_back([&, t]() {
+                std::vector<uint64_t> at = o_post[t], pat = o_pos[t];
+                walk(t, [&](uint32_t id, uint32_t local, uint32_t wdf, const std::vector<uint32_t>& pp) {
+                    const uint64_t i = at[id]++;
+                    c->did[i] = local; c->wdf[i] = wdf;
+                    if (with_positions) { c->pos_off[i] = pat[id]; for (uint32_t x : pp) c->pos[pat[id]++] = x; }
+                });
+            });
+        for (auto& x : th) x.join();
+    }
+    if (with_positions) c->pos_off[np] = npos;
+    for (auto& s : c->terms) { c->term_len.push_back((uint32_t)s.size()); }
+    for (auto& s : c->terms) c->term_ptr.push_back(s.data());
+    return c;
+}
+
 /* ----------------------------------------------------------------------------- glass lists ----- */
 
 void put_varint(std::vector<uint8_t>& out, uint64_t v) {         /* pack_uint, common/pack.h:296-310 */
@@ -1149,6 +1242,10 @@ extern "C" {
 void* xgo_corpus_build(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint32_t len_lo, uint32_t len_hi,
                        uint32_t n_shards, uint32_t shard, int with_positions) {
     return corpus_build(seed, n_docs_global, vocab, len_lo, len_hi, n_shards, shard, with_positions != 0);
+}
+void* xgo_corpus_build_terms(uint64_t seed, uint64_t n_docs_global, uint32_t vocab, uint32_t len_lo, uint32_t len_hi, uint32_t n_shards, uint32_t shard,
+                             int with_positions, const uint32_t* ranks, uint32_t n_ranks, uint32_t n_threads) {
+    return corpus_build_terms(seed, n_docs_global, vocab, len_lo, len_hi, n_shards, shard, with_positions != 0, ranks, n_ranks, n_threads);
 }
 void xgo_corpus_free(void* c) { delete (Corpus*)c; }
 

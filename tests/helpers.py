@@ -62,6 +62,9 @@ def olib():
         l = C.CDLL(ORACLE_LIB)
         l.xgo_corpus_build.restype = C.c_void_p
         l.xgo_corpus_build.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        l.xgo_corpus_build_terms.restype = C.c_void_p
+        l.xgo_corpus_build_terms.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint32),
+                                             C.c_uint32, C.c_uint32]
         l.xgo_corpus_free.argtypes = [C.c_void_p]
         l.xgo_corpus_get.argtypes = [C.c_void_p, C.POINTER(CorpusView)]
         l.xgo_index_from_raw.restype = C.c_void_p
@@ -444,6 +447,26 @@ def bench_pool(op, n_terms=3, n_required=1, n_docs_global=10_000_000, vocab=1_00
         out.append(dict(op=op, terms=["t%d" % r for r in ranks], first=0, maxitems=maxitems, window=0,
                         n_required=n_required if op in SIDED else 0))
     return out
+
+
+class TermsCorpus(Corpus):
+    """The synthetic corpus inverted on the HOST (oracle/xgm_oracle.cc::corpus_build_terms, tools/xgm_corpus.h) for a handful of terms only: every document is
+    generated — lengths and statistics are the whole shard's —, only the postings of `terms` ("t<rank>") are kept.  What feeds the oracle at a
+    configuration's full size WITHOUT reading anything back from the device (DeviceOracle does); same interface as Corpus for the oracle functions."""
+
+    def __init__(self, n_docs_global, vocab, terms, seed=CORPUS_SEED, len_lo=50, len_hi=150, n_shards=1, shard=0, positions=False, n_threads=None):
+        ranks = sorted({int((t.decode() if isinstance(t, bytes) else t)[1:]) for t in terms})
+        arr = (C.c_uint32 * len(ranks))(*ranks)
+        self.params = dict(seed=seed, n_docs_global=n_docs_global, vocab=vocab, len_lo=len_lo, len_hi=len_hi, n_shards=n_shards, shard=shard)
+        self._h = olib().xgo_corpus_build_terms(seed, n_docs_global, vocab, len_lo, len_hi, n_shards, shard, 1 if positions else 0, arr, len(ranks),
+                                                n_threads or max(1, os.cpu_count() or 1))
+        self.v = CorpusView()
+        olib().xgo_corpus_get(self._h, C.byref(self.v))
+        self._oidx = None
+
+    def warm(self):
+        for i in range(self.v.n_terms):
+            olib().xgo_index_warm(self.oracle_index(), self.v.terms[i], self.v.term_len[i])
 
 
 class ManualCorpus(Corpus):

@@ -64,7 +64,7 @@ def test_batch_frozen_equals_the_per_query_replay_and_the_reference(built, tmp_p
         exact_known += not (known & LB)
         if cal == 0:
             ref, _ = H.oracle_search(c, q["op"], q["terms"], first, maxitems, q.get("window", 0), reference_select_bug=True)
-            assert page[first:] == ref[first:] or page == ref, what
+            assert page == ref, what          # (the oracle, like the device, hands out the first + maxitems best: the caller drops `first`)
         intended, _ = search_batch(db, [p])[0]
         froze += want_hdr.matches_exact > k
         differs += [(d, w) for d, w, _ in page] != [(h.docid, h.weight) for h in intended]
