@@ -607,10 +607,10 @@ def sharded_cpu_baseline(args, leg, world, k):
             runs.append(json.loads(H.xapian_ref("time", qfp, t, 64, "--seconds", max(3.0, args.ref_seconds / 3), *dirs)))
         best = max(runs, key=lambda r: r["qps"])
         return {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3, "queries": one["queries"],
-                "all_cores": {"value": best["qps"], "unit": "queries/s", "hardware_threads": cores, "threads": best["threads"], "p50_ms": best["p50_us"] / 1e3,
+                "all_cores": {"value": best["qps"], "unit": "queries/s", "cores": physical_cores(), "hardware_threads": cores, "threads": best["threads"], "p50_ms": best["p50_us"] / 1e3,
                               "thread_counts_tried": [{"threads": r["threads"], "value": r["qps"]} for r in runs]},
                 "cpu_model": cpu_model(), "shards": world, "docs_per_shard": per_shard, "docs_total": per_shard * world, "index_build_seconds": build_s,
-                "index_storage": tmp,
+                "index_storage": storage_of(tmp),
                 "sample": ("Enquire::get_mset of the vendored Xapian through Xapiand's per-shard protocol (prepare_mset / add_prepared_mset / get_mset / unshard_docids / "
                            "merge_mset, handler.cc:1532-1549; oracle/_ref/xapian_ref time over %d Database handles) on %d round-robin shard indexes of %d documents each "
                            "(a bounded sample: the GPUs hold %d each), without positions, same queries: 1 thread over the first 64 queries of the timed pool, all cores over the pool"
@@ -1006,6 +1006,38 @@ def cpu_model():
     return None
 
 
+def physical_cores():
+    """(sockets x cores per socket) from /proc/cpuinfo — os.cpu_count() counts hardware THREADS (2 per core with SMT)."""
+    try:
+        pairs = set()
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        return len(pairs) or None
+    except OSError:
+        return None
+
+
+def storage_of(path):
+    """The file system a path lives on (the reference's glass index: tmpfs = page-cache resident by construction)."""
+    try:
+        best = ("", "?", "?")
+        for line in open("/proc/mounts"):
+            dev, mnt, fstype = line.split()[:3]
+            if (path == mnt or path.startswith(mnt.rstrip("/") + "/")) and len(mnt) > len(best[0]):
+                best = (mnt, fstype, dev)
+        return {"mount": best[0], "fstype": best[1]}
+    except OSError:
+        return None
+
+
 def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, pool_all=None):
     """The real reference on this box: build a glass index of the first --ref-docs documents of the corpus with
     the reference's own WritableDatabase (parallel slices + Database::compact, tools/ref_index.py), time
@@ -1050,7 +1082,7 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
                     o1 = time_reference(H, qf1, 1, 1, 30, dbdir)
                     ob, osweep, om = reference_all_cores(H, qfp, cores, max(3.0, args.ref_seconds / 3), dbdir)
                     others[name] = {"kind": "reference", "value": o1["qps"], "unit": "queries/s", "cores": 1, "p50_ms": o1["p50_us"] / 1e3, "queries": o1["queries"],
-                                    "all_cores": {"value": ob["value"], "unit": "queries/s", "cores": cores, "threads": ob["threads"], "p50_ms": ob["p50_ms"], "queries": ob["queries"],
+                                    "all_cores": {"value": ob["value"], "unit": "queries/s", "cores": physical_cores(), "hardware_threads": cores, "threads": ob["threads"], "p50_ms": ob["p50_ms"], "queries": ob["queries"],
                                                   "pool": om["pool"], "seconds": ob["seconds"], "thread_counts_tried": osweep},
                                     "docs": ref_docs,
                                     "sample": "Enquire::get_mset of the vendored Xapian (oracle/_ref/xapian_ref time) on the glass index of the headline leg (%d documents%s): "
@@ -1081,10 +1113,10 @@ def reference_leg(args, sample, k, n_required, full, ora_full, hook_pools=None, 
             ora.close()
             small.close()
         out = {"kind": "reference", "value": one["qps"], "unit": "queries/s", "cores": 1, "p50_ms": one["p50_us"] / 1e3,
-               "all_cores": {"value": best["value"], "unit": "queries/s", "cores": cores, "threads": best["threads"], "p50_ms": best["p50_ms"], "queries": best["queries"],
+               "all_cores": {"value": best["value"], "unit": "queries/s", "cores": physical_cores(), "hardware_threads": cores, "threads": best["threads"], "p50_ms": best["p50_ms"], "queries": best["queries"],
                              "pool": many["pool"], "seconds": best["seconds"], "efficiency_vs_cores_x_one_thread": best["value"] / (cores * one["qps"]),
                              "thread_counts_tried": sweep, "scheduling": many.get("scheduling")},
-               "cpu_model": cpu_model(), "_others": others,
+               "cpu_model": cpu_model(), "physical_cores": physical_cores(), "hardware_threads": cores, "index_storage": storage_of(tmp), "_others": others,
                "docs": ref_docs, "index_build": binfo, "port_same_index": {kk: vv for kk, vv in port.items() if kk != "all_cores"},
                "port_over_reference": port["value"] / one["qps"], "port_vs_reference_parity_checked": checked}
         if hook_pools is not None:

@@ -28,8 +28,8 @@
 #include "../../integration/xgm_matcher_hook.h"
 #include "../../integration/xgm_xapiand_glue.h"
 
-bool xapiand_aggregation_slot_of(const Xapian::MatchSpy& spy, Xapian::valueno* slot);
-void xapiand_aggregation_feed(Xapian::MatchSpy& spy, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts);
+#include "../../integration/xgm_aggregation_adapter.h"
+bool xapiand_stand_in_lookup(std::string_view field, Xapian::valueno* slot, bool* integral);      /* xapiand_classes.cc: the stand-in for Schema::get_slot_field */
 
 namespace {
 
@@ -101,12 +101,9 @@ int main(int argc, char** argv) {
         };
         xgm_hook::register_spy_adapter("DriverCountSpy", ad);
     }
-    {   /* Xapiand's own AggregationMatchSpy, compiled from the reference (xapiand_classes.cc): the adapter a Xapiand build registers */
-        xgm_hook::SpyAdapter ad;
-        ad.slot_of = [](const Xapian::MatchSpy& s, Xapian::valueno* slot) { return xapiand_aggregation_slot_of(s, slot); };
-        ad.feed = [](Xapian::MatchSpy& s, Xapian::doccount total, const std::vector<std::pair<std::string, Xapian::doccount>>& counts) { xapiand_aggregation_feed(s, total, counts); };
-        xgm_hook::register_spy_adapter("AggregationMatchSpy", ad);
-    }
+    /* Xapiand's own AggregationMatchSpy, compiled from the reference: the PRODUCT adapter (integration/xgm_aggregation_adapter.cc), registered as a Xapiand
+     * build would — with this harness's stand-in for the Schema lookup */
+    xgm_xapiand::register_aggregation_adapter(xapiand_stand_in_lookup);
     for (; a < argc && argv[a][0] == '-'; ++a) {
         if (!strcmp(argv[a], "--decline-positional")) xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_DECLINE);
         else if (!strcmp(argv[a], "--positional-reference")) { xgm_hook::set_positional_mode(xgm_hook::POSITIONAL_REFERENCE); positional_reference_on = true; }

@@ -53,11 +53,13 @@
 
 #include "xgm_corpus.h"
 
+std::string sortable_serialise(long double value);      /* XAPIAND's own (reference src/sortable_serialise.cc, compiled where it lies): how its numeric fields are stored */
+
 /* Xapiand's own key maker (oracle/ref_build/xapiand_classes.cc; linked into xapian_hook_b1 only: weak here) */
 const Xapian::KeyMaker* xapiand_keymaker(unsigned variant, bool reverse) __attribute__((weak));
 
 /* Xapiand's aggregation spy (oracle/ref_build/xapiand_classes.cc); absent — null — where Xapiand's classes are not linked */
-Xapian::MatchSpy* xapiand_aggregation_spy(unsigned slot) __attribute__((weak));
+Xapian::MatchSpy* xapiand_aggregation_spy(unsigned slot, unsigned kind) __attribute__((weak));
 std::string xapiand_aggregation_result(Xapian::MatchSpy* spy) __attribute__((weak));
 void xapiand_aggregation_merge(Xapian::MatchSpy* into, Xapian::MatchSpy* from) __attribute__((weak));
 
@@ -80,6 +82,7 @@ struct QuerySpec {
     /* "SPYA=<slot>": Xapiand's OWN AggregationMatchSpy (src/aggregations/aggregations.h, compiled from the reference: xapiand_classes.cc)
      * with a `_values` aggregation on the slot — only in binaries that link Xapiand's classes (xapian_hook_b1) */
     bool spy_aggregation = false;
+    unsigned agg_kind = 0;        /* "SPYA=<slot>:<kind>": which `_aggs` description (xapiand_classes.cc aggs_conf: 0 `_values`, 1 `_stats`, 2 metrics, 3 `_histogram` + sub, 4 `_range`, ...) */
     /* "CUT=<percent>:<weight>": Enquire::set_cutoff (DocMatcher::prepare_mset sets it on every Enquire, handler.cc:1265) */
     int cut_percent = 0; double cut_weight = 0.0;
 };
@@ -133,6 +136,7 @@ std::vector<QuerySpec> read_queries(const char* path) {
             } else if (tok.rfind("SPYA=", 0) == 0) {
                 q.spy_slot = (int)strtoul(tok.c_str() + 5, nullptr, 10);
                 q.spy_aggregation = true;
+                { const size_t c = tok.find(':'); if (c != std::string::npos) q.agg_kind = (unsigned)strtoul(tok.c_str() + c + 1, nullptr, 10); }
                 if (!xapiand_aggregation_spy) { fprintf(stderr, "SPYA: Xapiand's classes are not linked into this binary\n"); exit(2); }
             } else { ss.clear(); ss.seekg(at); break; }
         }
@@ -292,7 +296,7 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
         enq.set_query(query);
         if (!spy_on) return enq.get_mset(first, maxitems, cal);
         if (settings->spy_aggregation) {
-            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot));
+            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot, settings->agg_kind));
             enq.add_matchspy(aspy.get());
             Xapian::MSet m = enq.get_mset(first, maxitems, cal);
             spied->aggregation = xapiand_aggregation_result(aspy.get());
@@ -333,7 +337,7 @@ Xapian::MSet run_query(std::vector<Xapian::Database>& dbs, const Xapian::Query& 
     for (size_t s = 0; s < n_shards; ++s) {
         enqs[s].set_prepared_mset(merger.get_prepared_mset());
         if (spy_on && settings->spy_aggregation) {
-            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot));
+            std::unique_ptr<Xapian::MatchSpy> aspy(xapiand_aggregation_spy((unsigned)settings->spy_slot, settings->agg_kind));
             enqs[s].add_matchspy(aspy.get());
             msets[s] = enqs[s].get_mset(0, first + maxitems, cal);
             enqs[s].clear_matchspies();
@@ -403,6 +407,13 @@ int cmd_build(int argc, char** argv) {
                 std::string sl(1, '\0');
                 for (const std::string& v : have) { sl += (char)(unsigned char)v.size(); sl += v; }
                 doc.add_value(3, sl);
+            }
+            /* slot 4: slot 1's six-digit number the way XAPIAND stores a positive integer field — sortable_serialise (reference src/serialise.h:184-186) —:
+             * what its metric / histogram / range aggregations read (about one document in 23 has none) */
+            {
+                char nb[16];
+                const uint32_t n = xgm_doc_value(&cp, g, 1, nb);
+                if (n && g % 23u != 0u) doc.add_value(4, sortable_serialise((long double)strtoul(nb, nullptr, 10)));
             }
         }
         db.add_document(doc);

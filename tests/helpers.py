@@ -298,7 +298,10 @@ def write_queries(path, queries):
             if q.get("check_at_least"):
                 pre += "CAL=%d " % q["check_at_least"]
             if q.get("spy") is not None:
-                pre += ("SPYA=%d " if q.get("spy_aggregation") else "SPYC=%d " if q.get("spy_custom") else "SPY=%d ") % q["spy"]
+                if q.get("spy_aggregation"):
+                    pre += "SPYA=%d:%d " % (q["spy"], q.get("agg_kind", 0))          # Xapiand's own AggregationMatchSpy; kind: oracle/ref_build/xapiand_classes.cc aggs_conf
+                else:
+                    pre += ("SPYC=%d " if q.get("spy_custom") else "SPY=%d ") % q["spy"]
             if q.get("cutoff"):
                 pre += "CUT=%d:%r " % (q["cutoff"][0], float(q["cutoff"][1]))
             f.write("%s%s %d %d %d %s\n" % (pre, op, q["first"], q["maxitems"], q.get("window", 0), " ".join(q["terms"])))

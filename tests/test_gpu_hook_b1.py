@@ -172,7 +172,10 @@ def xapiand_aggregation_queries(n_docs=N_DOCS):
             H.gen_sided_queries("AND_MAYBE", 4, 1, 2, 1, 200, maxitems=10, seed=263) + H.gen_term_queries("OR", 4, 5, 1, 3000, first=7, maxitems=43, seed=265))
     qs = []
     for i, q in enumerate(base):
-        q = dict(q, spy=i % 4, spy_aggregation=True)
+        # agg_kind (oracle/ref_build/xapiand_classes.cc aggs_conf): 0 `_values` on keyword slot i % 4 (slot 3: multi-valued); on the numeric slot 4: 1 `_stats`,
+        # 2 eight metrics side by side, 3 `_histogram` with `_max` / `_sum` sub-aggregations, 4 `_range`; 5 (two fields) and 6 (`_median`) are NOT the adapter's
+        kind = (0, 0, 1, 2, 3, 4, 0, 5, 6, 3, 1, 4)[i % 12]
+        q = dict(q, spy=i % 4, spy_aggregation=True, agg_kind=kind)
         if i % 2 == 0:
             q["sort"] = (["V", "VR"][i // 2 % 2], rng.randrange(3), rng.random() < 0.5)        # the value leads: the spy sees every match
         else:
@@ -184,21 +187,25 @@ def xapiand_aggregation_queries(n_docs=N_DOCS):
 def test_xapiand_own_aggregation_spy_through_the_hook(built, glass_values):
     """VERDICT r4 missing #2 / SURVEY 8(f).3: the MatchSpy Xapiand really attaches — AggregationMatchSpy (reference
     src/aggregations/aggregations.h:108, src/database/handler.cc:1283), its three translation units compiled from the reference's
-    sources — with a `_values` aggregation on a value slot: single-valued slots 0..2 and the multi-valued slot 3 (a StringList: one
-    document falls into several buckets).  The device counts the matching documents per distinct slot value
-    (xgm_search_sorted_spy), the adapter feeds the reference's own class (one clone per distinct value, scaled, merge_results);
-    hook on == hook off: the `_aggregations` object a response would carry and the wire form, under value-led sorts and by relevance
-    with check_at_least covering the match, one shard and Xapiand's 3-shard protocol."""
+    sources — through the PRODUCT adapter (integration/xgm_aggregation_adapter.cc, round 6): `_values` on the single-valued keyword slots 0..2 and the
+    multi-valued slot 3 (a StringList: one document falls into several buckets); on the numeric slot 4 (a positive integer, stored as Xapiand stores it)
+    `_stats`, eight metrics side by side (`_count` / `_sum` / `_avg` / `_min` / `_max` / `_extended_stats` / `_variance` / `_std_deviation`), a `_histogram`
+    whose buckets carry `_max` and `_sum` sub-aggregations, `_range`; and two shapes the adapter must DECLINE (a sub-aggregation on another field, `_median`).
+    The device counts the matching documents per distinct slot value (xgm_search_sorted_spy); per distinct value the reference's own class is shown one
+    document and that result is merged count times by doubling with its own merge_results.  Hook on == hook off: the `_aggregations` object a response
+    would carry and the wire form, under value-led sorts and by relevance with check_at_least covering the match, one shard and Xapiand's 3-shard protocol."""
     d, one, shards = glass_values
     qs = xapiand_aggregation_queries()
     qf = str(d / "qagg.txt")
     H.write_queries(qf, qs)
+    on_device = sum(q["agg_kind"] <= 4 for q in qs)
+    assert on_device >= len(qs) * 2 // 3 and on_device < len(qs)
     out = run_b1(qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0, out
-    assert out["answered_on_device"] == len(qs) and out["answered_spied"] == len(qs), out
+    assert out["answered_on_device"] == on_device and out["answered_spied"] == on_device, out
     out = run_b1(qf, *shards)
     assert out["mismatches"] == 0, out
-    assert out["answered_spied"] == 3 * len(qs), out
+    assert out["answered_spied"] == 3 * on_device, out
 
 
 def test_commit_glue_and_http_response_bodies(built, glass, glass_values, tmp_path):
@@ -234,7 +241,8 @@ def test_commit_glue_and_http_response_bodies(built, glass, glass_values, tmp_pa
     qfa = str(tmp_path / "qglue_agg.txt")
     H.write_queries(qfa, qa)
     out = run_b1("--commit-glue", "--http-bodies", bodies, qfa, onev)
-    assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["answered_spied"] == len(qa), out
+    on_device = sum(q["agg_kind"] <= 4 for q in qa)                 # (two-field and `_median` aggregations are not the adapter's: the CPU matcher answers them)
+    assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["answered_spied"] == on_device, out
     assert "aggregations" in json.loads(open(str(bodies / "q0000.hook.json")).read())
     out = run_b1("--commit-glue", qfa, *shardsv)
     assert out["mismatches"] == 0 and out["http_bodies_equal"] == len(qa) and out["glue_full_exports"] == 3, out
