@@ -46,6 +46,7 @@
 #include "xgm_device.h"
 #include "xgm_launch.h"
 #include "xgm_wave.h"
+#include "xgm_unit_finish.h"
 
 namespace {
 
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                           uint32_t* __restrict__ hist_all, int prune_flags,
                                                           xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out,
-                                                          unsigned long long* __restrict__ phase_cycles) {
+                                                          unsigned long long* __restrict__ phase_cycles, const xgm_fuse* __restrict__ fuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
@@ -1089,10 +1090,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     for (int sh = 32; sh > 0; sh >>= 1) matches += (unsigned long long)__shfl_xor((long long)matches, sh);
     const uint32_t n_out = tkn < k ? tkn : k;
     xgm_cand* out = cand_out + (size_t)wk.slot * k_stride;
+    const bool through = fuse != nullptr;                          /* the launch finishes its queries itself (xgm_unit_finish.h; round 6 — the conjunction kernel since round 3) */
     for (uint32_t i = lane; i < n_out; i += 64u) {
         xgm_cand c;
         c.wbits = tk_w[i]; c.did = tk_d[i]; c.subqs = tk_m[i];
-        out[i] = c;
+        xgm_store_cand(through, &out[i], c);
     }
     if (lane == 0) {
         xgm_group_hdr h;
@@ -1100,8 +1102,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         h.t_start = t_unit_start; h.t_end = __builtin_readcyclecounter();
         h.c_pos = 0; h.c_bmp_words = cn_bmpw; h.c_probes = cn_probe; h.c_blk_words = cn_blkw; h.c_hdrs = cn_hdr;
         h.c_doclen = cn_dl; h.c_aux_words = cn_aux; h.c_probes_raw = cn_probe_raw; h.c_doclen_raw = cn_dl_raw; h.c_pad[0] = (cn_fixw & 0x7FFFFFFFu) | (fix ? 0x80000000u : 0u); h.c_pad[1] = cn_first;
-        ghdr_out[wk.slot] = h;
+        xgm_store_hdr(through, &ghdr_out[wk.slot], h);
     }
+    /* the query's last unit to arrive merges the units' lists into the final hits (the merge launch and the gaps around it cost 137 us per batch of C3) */
+    if (through) xgm_unit_arrive<true>(*fuse, wk.qi, k, 0u, tk_w, tk_d, tk_m, cap, cand_out, ghdr_out, k_stride, lane, [&]() { orw_topk_sort(tk_w, tk_d, tk_m, cap, lane); });
 #undef XGM_SU
 }
 
@@ -1763,7 +1767,7 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
         static std::atomic<size_t> seen{0};                                                                                          \
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
         XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
-                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
+                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles, L.fuse);                                    \
     } while (0)
 #define ORW_LAUNCH_FLAT(TL)                                                                                                          \
     do {                                                                                                                             \
@@ -1771,7 +1775,7 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
         static std::atomic<size_t> seen{0};                                                                                          \
         if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
         XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
-                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles);                                            \
+                           L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles, L.fuse);                                    \
     } while (0)
     /* L.tally: the instantiation that also fills the traffic tallies of xgm_group_hdr (measurement only) */
     if (L.or_flat && !L.wide) { if (L.tally) ORW_LAUNCH_FLAT(true); else ORW_LAUNCH_FLAT(false); }
