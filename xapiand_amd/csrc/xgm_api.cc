@@ -935,9 +935,11 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
     /* parts: units [p * upp, (p + 1) * upp) of query q are pseudo-query p * nq + q of goff */
     /* xgm_andw_kernel merges a query's lists in its last unit, whatever their number (XGM_NO_FUSED_MERGE: A/B switch, the variant tests) */
     static const bool no_fused = getenv("XGM_NO_FUSED_MERGE") != nullptr;
-    /* ... and so does xgm_orw_kernel (round 6; XGM_NO_OR_FUSED_MERGE: A/B switch, the variant tests) */
-    static const bool no_or_fused = getenv("XGM_NO_OR_FUSED_MERGE") != nullptr;
-    bp->fused = ((bp->andw && !no_fused) || (bp->orw && !bp->orw2 && !no_fused && !no_or_fused)) && mode == 0;                                                    /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
+    /* ... xgm_orw_kernel can as well (round 6) — OPT-IN, XGM_OR_FUSED_MERGE=1: measured on the MI355X it LOSES (C3: 135.1 k queries/s, kernel 1.848 ms, against
+     * 139.1 k / 1.774 ms with the merge launch): one wave merging 32 lists of 100 candidates lengthens the launch's tail by more than the merge launch and the
+     * gap before it cost; the conjunction's k = 10 lists are another matter */
+    static const bool or_fused = getenv("XGM_OR_FUSED_MERGE") != nullptr;
+    bp->fused = ((bp->andw && !no_fused) || (bp->orw && !bp->orw2 && !no_fused && or_fused)) && mode == 0;                                                    /* (the stand-alone dense kernel, XGM_DENSE_KERNEL=1, finishes its queries the same way) */
     /* (list: xgm_andw_list_kernel's units are walked in stripe order by xgm_frozen_finish_kernel, whatever their number: one part) */
     const uint32_t P = (bp->fused || mode != 0) ? 1u : (g_most_q + units_per_part - 1) / units_per_part;
     bp->parts = std::max(1u, P);
