@@ -6,16 +6,17 @@ tag=$1
 # (GPU tests and the headline line: tools/final_a.sh)
 # (counter calibration: tools/calib.sh, kept from the first pass of this round — profiles/r02_fetch_calib.txt)
 : > gpurun_out/${tag}_traffic_entries.jsonl
-for w in "and3 andw" "or5 orw --op OR --terms 5 --topk 100" "phrase andw --op PHRASE --topk 10"; do
+# (round 6: + C5 in its credited, reference-identical batch mode — xgm_andw_list_kernel — and C2 with ProtoMSet's count — xgm_andw_all_kernel)
+for w in "and3 andw_kernel" "or5 orw --op OR --terms 5 --topk 100" "phrase andw_kernel --op PHRASE --topk 10" "phrasef andw_list --op PHRASE --topk 10 --replay frozen" "and3count andw_all --replay count"; do
   set -- $w; n=$1; rx=$2; shift 2
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_$c.log 2>&1
+    timeout -k 5 200 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-hook-parity --ref-docs 0 --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_$c.log 2>&1
   done
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_SQ -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_SQ.log 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT --kernel-include-regex "xgm_$rx" --output-format csv -d gpurun_out/${tag}_pmc_${n}_SQ -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-hook-parity --ref-docs 0 --no-latency --threads 0 $* > gpurun_out/${tag}_pmc_${n}_SQ.log 2>&1
   python tools/pmc_parse.py gpurun_out/${tag}_pmc_${n}_FETCH_SIZE gpurun_out/${tag}_pmc_${n}_WRITE_SIZE gpurun_out/${tag}_pmc_${n}_SQ > gpurun_out/${tag}_pmc_${n}.txt
-  timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --threads 0 $* > gpurun_out/${tag}_model_${n}.json 2>/dev/null
+  timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-hook-parity --ref-docs 0 --no-latency --threads 0 $* > gpurun_out/${tag}_model_${n}.json 2>/dev/null
   python tools/traffic.py gpurun_out/${tag}_pmc_${n}.txt gpurun_out/${tag}_model_${n}.json xgm_$rx >> gpurun_out/${tag}_traffic_entries.jsonl
-  timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_${n} -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-latency --threads 0 $* > gpurun_out/${tag}_prof_${n}.log 2>&1
+  timeout -k 5 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${tag}_prof_${n} -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-other-configs --no-hook-parity --ref-docs 0 --no-latency --threads 0 $* > gpurun_out/${tag}_prof_${n}.log 2>&1
 done
 python - <<PY
 import json

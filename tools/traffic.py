@@ -23,7 +23,7 @@ for l in open(pmc):
 assert len(names) == 1, "the kernel substring %r matches %d kernels in %s: %s" % (kern, len(names), pmc, sorted(names))
 d = json.load(open(bench))
 r = d["roofline"]
-c = r["model_counts"]
+c = r["model_counts"] or dict(bitmap_words=0, payload_words=0, block_headers=0, aux_words=0)      # (a kernel without a tallying instantiation: counters alone)
 streamed = 4 * c["bitmap_words"] + 4 * c["payload_words"] + 12 * c["block_headers"] + 4 * c["aux_words"]
 fetch = vals["FETCH_SIZE"] * 1024.0
 write = vals["WRITE_SIZE"] * 1024.0
@@ -35,7 +35,7 @@ lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None   
 print(json.dumps({
     "lib_sha": lib_sha,
     "kernel": r["kernel"], "kernel_instantiation": sorted(names)[0], "op": cfg["op"], "docs_per_gpu": cfg["docs_per_gpu"], "top_k": cfg["top_k"],
-    "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"],
+    "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"], "streamed_bytes_tallied": r["model_counts"] is not None,
     "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"], "streamed_bytes_model": streamed,
     "hbm_bytes_per_launch": total,
     "counters": {k: v for k, v in vals.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")},
