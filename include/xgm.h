@@ -465,8 +465,8 @@ int xgm_search_sorted_spy(xgm_index* idx, const xgm_query* q, const xgm_sort_spe
                           xgm_result_hdr* hdr, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
 
 /* xgm_search_sorted_batch with that spy on every search: counts [nq][n_counts], one row per query (Xapiand's `_aggregations` over a field
- * ride on every search of a dashboard: many HTTP threads, the same sort, the same spy slot — one launch).  The same caveat on what a
- * spy sees applies per query. */
+ * ride on every search of a dashboard: many HTTP threads, the same sort, the same spy slot — one launch).  sort may be NULL (by relevance), as
+ * for the single search.  The same caveat on what a spy sees applies per query. */
 int xgm_search_sorted_spy_batch(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
                                 uint32_t* hit_ord, xgm_result_hdr* hdrs, uint32_t spy_slot, uint32_t* counts, uint32_t n_counts);
 

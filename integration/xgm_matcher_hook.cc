@@ -6,12 +6,15 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <string>
+#include <tuple>
 
 #include "xapian/error.h"
 #include "xapian/api/enquireinternal.h"
@@ -36,7 +39,7 @@ struct ShardColumns {
 };
 /* own: shared ownership of the device index — a search copies the Shard under g_mu and so keeps the index alive for its whole call, whatever
  * the registry does meanwhile (a commit replacing the revision, the shard closing: ADVICE r5); idx = own.get() */
-struct Shard { std::shared_ptr<xgm_index> own; xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; };
+struct Shard { std::shared_ptr<xgm_index> own; xgm_index* idx; Xapian::rev revision; std::shared_ptr<ShardColumns> cols; uint32_t batch = 0; };
 std::mutex g_mu;
 std::map<std::string, Shard> g_shards;
 std::map<std::string, std::shared_ptr<const SpyAdapter>> g_spy_adapters;      /* (shared: a search keeps its adapter although the name is registered again meanwhile) */
@@ -44,7 +47,7 @@ std::atomic<bool> g_enabled{true}, g_exact_bounds{false}, g_near_colocated{false
 std::atomic<int> g_positional{POSITIONAL_DECLINE}, g_collapse{COLLAPSE_DECLINE};
 std::atomic<uint64_t> g_replay_limit{4u * 1000u * 1000u};       /* matches up to which a replay downloads the match (set_replay_limit) */
 std::atomic<uint32_t> g_column_limit{50u * 1000u * 1000u};     /* documents per shard up to which a column is built on the search thread */
-std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0};
+std::atomic<uint64_t> g_answered{0}, g_shape{0}, g_unreg{0}, g_rev{0}, g_dev{0}, g_sorted{0}, g_spied{0}, g_collapsed{0}, g_columns{0}, g_replayed{0}, g_combined{0}, g_combined_launches{0};
 
 struct Lowered {
     xgm_query_desc d;
@@ -408,6 +411,117 @@ class ReplayPostList : public Xapian::Internal::PostList {
     std::string get_description() const override { return "XgmReplay(" + std::to_string(n_hits) + ")"; }
 };
 
+/* ---- searches under a sort, with a spy or collapsed, from many threads: ONE launch for those that wait together (round 6) -----------------------
+ * The plain searches of concurrent threads meet in the library's dispatcher (xgm_index_set_batching).  These have their own entry points —
+ * xgm_search_sorted_batch / _sorted_spy_batch / _collapsed_batch: nq searches under ONE sort spec, spy slot or collapse key — so the hook
+ * combines them itself: searches of the same index and the same spec form a lane; the first to arrive launches at once, those that arrive
+ * while a launch of the lane is in flight wait together and go out as ONE launch when it returns (no linger, no timer: the batch is what
+ * accumulated behind the launch before it).  Every search gets exactly what its single call would have given it
+ * (tests/test_gpu_sorted.py::test_sorted_batch_equals_single_searches_and_the_oracle); a batch the library declines as a whole is run one by one. */
+struct ComboKey {
+    xgm_index* idx; uint32_t kind;                     /* 0 sorted, 1 sorted + spy, 2 collapsed */
+    uint32_t has_sort, sort_by, sort_slot, reverse, aux_slot, aux_max;
+    bool operator<(const ComboKey& o) const {
+        return std::tie(idx, kind, has_sort, sort_by, sort_slot, reverse, aux_slot, aux_max) <
+               std::tie(o.idx, o.kind, o.has_sort, o.sort_by, o.sort_slot, o.reverse, o.aux_slot, o.aux_max);
+    }
+};
+struct ComboReq {
+    const xgm_query* plan; uint32_t k;
+    xgm_hit* hits; uint32_t* ord; uint32_t* cord; uint32_t* ccount; xgm_result_hdr* hdr; uint64_t* clb; uint32_t* counts; uint32_t n_counts;
+    int rc; std::string error;
+};
+struct ComboGroup { std::vector<ComboReq*> reqs; std::condition_variable cv; bool done = false; };
+struct ComboLane { bool running = false; std::deque<std::shared_ptr<ComboGroup>> waiting; };
+constexpr size_t kComboMax = 256;
+/* (never destroyed: threads of the host may still be searching when the process exits) */
+std::mutex& g_combo_mu = *new std::mutex;
+std::map<ComboKey, ComboLane>& g_combo = *new std::map<ComboKey, ComboLane>;
+
+int combo_single(const ComboKey& K, const xgm_sort_spec* sort, ComboReq& r) {
+    int rc;
+    if (K.kind == 2u) rc = xgm_search_collapsed(K.idx, r.plan, sort, K.aux_slot, K.aux_max, r.hits, r.ord, r.cord, r.ccount, r.hdr, r.clb);
+    else if (K.kind == 1u) rc = xgm_search_sorted_spy(K.idx, r.plan, sort, r.hits, r.ord, r.hdr, K.aux_slot, r.counts, r.n_counts);
+    else rc = xgm_search_sorted(K.idx, r.plan, sort, r.hits, r.ord, r.hdr);
+    if (rc < 0) r.error = xgm_last_error();            /* (the library's message is per thread: the leader's, handed to the request's own thread) */
+    return rc;
+}
+
+void combo_run(const ComboKey& K, ComboGroup& g) {
+    xgm_sort_spec spec;
+    memset(&spec, 0, sizeof spec);
+    spec.sort_by = K.sort_by; spec.slot = K.sort_slot; spec.reverse = K.reverse;
+    const xgm_sort_spec* sort = K.has_sort ? &spec : nullptr;
+    const size_t n = g.reqs.size();
+    if (n > 1) {
+        uint32_t ks = 1;
+        for (const ComboReq* r : g.reqs) ks = std::max(ks, r->k);
+        const uint32_t nc = g.reqs[0]->n_counts;
+        std::vector<xgm_query> plans(n);
+        for (size_t i = 0; i < n; ++i) plans[i] = *g.reqs[i]->plan;
+        std::vector<xgm_hit> hits(n * ks);
+        std::vector<uint32_t> ord(sort ? n * ks : 0), cord(K.kind == 2u ? n * ks : 0), ccount(K.kind == 2u ? n * ks : 0), counts(K.kind == 1u ? n * (size_t)nc : 0);
+        std::vector<xgm_result_hdr> hdrs(n);
+        std::vector<uint64_t> clb(n, 0);
+        int rc;
+        if (K.kind == 2u) rc = xgm_search_collapsed_batch(K.idx, plans.data(), (uint32_t)n, sort, K.aux_slot, K.aux_max, ks, hits.data(), sort ? ord.data() : nullptr,
+                                                          cord.data(), ccount.data(), hdrs.data(), clb.data());
+        else if (K.kind == 1u) rc = xgm_search_sorted_spy_batch(K.idx, plans.data(), (uint32_t)n, sort, ks, hits.data(), sort ? ord.data() : nullptr, hdrs.data(),
+                                                                K.aux_slot, counts.data(), nc);
+        else rc = xgm_search_sorted_batch(K.idx, plans.data(), (uint32_t)n, sort, ks, hits.data(), ord.data(), hdrs.data());
+        if (rc == XGM_OK) {
+            for (size_t i = 0; i < n; ++i) {
+                ComboReq& r = *g.reqs[i];
+                const uint32_t m = std::min(hdrs[i].n_hits, r.k);
+                std::copy(hits.begin() + i * ks, hits.begin() + i * ks + m, r.hits);
+                if (r.ord && sort) std::copy(ord.begin() + i * ks, ord.begin() + i * ks + m, r.ord);
+                if (r.cord) std::copy(cord.begin() + i * ks, cord.begin() + i * ks + m, r.cord);
+                if (r.ccount) std::copy(ccount.begin() + i * ks, ccount.begin() + i * ks + m, r.ccount);
+                if (r.counts) std::copy(counts.begin() + i * (size_t)nc, counts.begin() + (i + 1) * (size_t)nc, r.counts);
+                if (r.clb) *r.clb = clb[i];
+                *r.hdr = hdrs[i];
+                r.rc = XGM_OK;
+            }
+            g_combined += n;
+            ++g_combined_launches;
+            return;
+        }
+        /* declined (one query of the batch is of a shape the batch entry does not take) or failed as a whole: each on its own */
+    }
+    for (ComboReq* r : g.reqs) r->rc = combo_single(K, sort, *r);
+}
+
+/* the calling thread's search `r`, alone or in a launch with those of other threads */
+int combo_search(const ComboKey& K, ComboReq& r) {
+    std::unique_lock<std::mutex> lk(g_combo_mu);
+    ComboLane& lane = g_combo[K];
+    if (lane.waiting.empty() || lane.waiting.back()->reqs.size() >= kComboMax) lane.waiting.push_back(std::make_shared<ComboGroup>());
+    std::shared_ptr<ComboGroup> grp = lane.waiting.back();
+    grp->reqs.push_back(&r);
+    const bool first = grp->reqs.size() == 1;
+    while (!grp->done) {
+        if (first && !lane.running && lane.waiting.front() == grp) {
+            lane.running = true;
+            lane.waiting.pop_front();                   /* closed: later arrivals start the next group */
+            lk.unlock();
+            try {
+                combo_run(K, *grp);
+            } catch (const std::exception& e) {         /* (out of memory for the group's buffers: every member is told, the lane goes on) */
+                for (ComboReq* q : grp->reqs) { q->rc = XGM_E_INVALID; q->error = e.what(); }
+            }
+            lk.lock();
+            lane.running = false;
+            grp->done = true;
+            grp->cv.notify_all();
+            if (!lane.waiting.empty()) lane.waiting.front()->cv.notify_all();      /* its first member launches it */
+            else g_combo.erase(K);
+            break;
+        }
+        grp->cv.wait(lk);
+    }
+    return r.rc;
+}
+
 /* EVERY matching document of a planned query in ascending docid order with its weight (xgm_search_all): what the byte-compatible
  * modes replay — of any size since round 4 (rounds 1-3: at most XGM_MAX_K documents, fetched as one page and sorted here).  The
  * buffer is sized by the tree's own upper bound (plan.est_max = PostList::get_termfreq_max of the tree the reference builds), left
@@ -438,7 +552,7 @@ static void register_ptr(const std::string& uuid, Xapian::rev revision, std::sha
         std::lock_guard<std::mutex> lk(g_mu);
         auto it = g_shards.find(uuid);
         if (it != g_shards.end()) replaced = std::move(it->second);
-        g_shards[uuid] = Shard{std::move(own), idx, revision, std::make_shared<ShardColumns>()};
+        g_shards[uuid] = Shard{std::move(own), idx, revision, std::make_shared<ShardColumns>(), batch};
     }
 }
 
@@ -485,7 +599,7 @@ void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter)
 }
 Counters counters() {
     return Counters{g_answered.load(), g_shape.load(), g_unreg.load(), g_rev.load(), g_dev.load(), g_sorted.load(), g_spied.load(),
-                    g_collapsed.load(), g_columns.load(), g_replayed.load()};
+                    g_collapsed.load(), g_columns.load(), g_replayed.load(), g_combined.load(), g_combined_launches.load()};
 }
 
 bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const Xapian::Weight::Internal& stats,
@@ -590,6 +704,7 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
     const bool pos_ref = plain && positional && plan.phrase_active && g_positional.load(std::memory_order_relaxed) == POSITIONAL_REFERENCE && k > 0;
     const bool want_count = plain && !positional && g_exact_bounds.load(std::memory_order_relaxed) && k > 0;
     uint64_t known_raw = 0;
+    std::string combo_error;                        /* the library's message when the search failed on another thread (the leader of a combined launch) */
     if (plain) {
         /* (POSITIONAL_REFERENCE alone: the reference's page — ranks, docids, weights; with set_exact_bounds its match-count figures too, for which every
          * document of the conjunction has to be tested: ~9 x the time on frequent-term phrases) */
@@ -614,14 +729,24 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
             if (!sp.col) { ++g_shape; return false; }
         }
         const xgm_sort_spec* sp_sort = by_value ? &spec : nullptr;
+        /* one search of this thread — in a launch with those other threads issue under the same sort / spy slot / collapse key meanwhile when the
+         * shard was registered with batching on (combo_search above), else on its own */
+        auto search = [&](uint32_t kind, uint32_t aux_slot, uint32_t aux_max, xgm_hit* h, uint32_t* o, uint32_t* co, uint32_t* cc, xgm_result_hdr* hd,
+                          uint64_t* clb, uint32_t* cnt, uint32_t n_cnt) {
+            const ComboKey K{sh.idx, kind, sp_sort ? 1u : 0u, spec.sort_by, spec.slot, spec.reverse, aux_slot, aux_max};
+            ComboReq r{&plan, k, h, o, co, cc, hd, clb, cnt, n_cnt, 0, std::string()};
+            const int rc_ = sh.batch > 1u ? combo_search(K, r) : (r.rc = combo_single(K, sp_sort, r));
+            if (rc_ < 0) combo_error = r.error;
+            return rc_;
+        };
         if (collapse_max != 0) {
             collapse_col = value_column(sh, db, collapse_key);
             if (!collapse_col) { ++g_shape; return false; }
             hit_cord.resize(k); hit_ccount.resize(k);
-            rc = xgm_search_collapsed(sh.idx, &plan, sp_sort, collapse_col->slot_id, collapse_max, hits.data(), by_value ? hit_ord.data() : nullptr,
-                                      hit_cord.data(), hit_ccount.data(), &hdr, &collapsed_lb);
+            rc = search(2u, collapse_col->slot_id, collapse_max, hits.data(), by_value ? hit_ord.data() : nullptr, hit_cord.data(), hit_ccount.data(), &hdr,
+                        &collapsed_lb, nullptr, 0);
         } else if (spies.empty()) {
-            rc = xgm_search_sorted(sh.idx, &plan, sp_sort, hits.data(), hit_ord.data(), &hdr);
+            rc = search(0u, 0u, 0u, hits.data(), hit_ord.data(), nullptr, nullptr, &hdr, nullptr, nullptr, 0);
         } else {
             /* one pass per spy (each counts one column); the first pass's page is the answer */
             std::vector<std::vector<uint32_t>> counts(spies.size());
@@ -629,8 +754,8 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
                 counts[i].assign(spies[i].col->values.size() + 1, 0u);
                 std::vector<xgm_hit> h2(i ? k : 0);
                 xgm_result_hdr hd2;
-                rc = xgm_search_sorted_spy(sh.idx, &plan, sp_sort, i ? h2.data() : hits.data(), i ? nullptr : (by_value ? hit_ord.data() : nullptr),
-                                           i ? &hd2 : &hdr, spies[i].col->slot_id, counts[i].data(), (uint32_t)counts[i].size());
+                rc = search(1u, spies[i].col->slot_id, 0u, i ? h2.data() : hits.data(), i ? nullptr : (by_value ? hit_ord.data() : nullptr), nullptr, nullptr,
+                            i ? &hd2 : &hdr, nullptr, counts[i].data(), (uint32_t)counts[i].size());
             }
             /* A spy is shown every matching document when the value leads the sort (ProtoMSet::early_reject, protomset.h:249-283:
              * min_weight stays 0) or when the match does not exceed check_at_least (min_weight is raised only once checked_enough());
@@ -661,7 +786,7 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
         }
     }
     if (rc > 0) { ++g_dev; return false; }                                   /* declined by the device path: CPU matcher */
-    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + xgm_last_error());
+    if (rc < 0) throw Xapian::DatabaseError(std::string("xgm: ") + (combo_error.empty() ? std::string(xgm_last_error()) : combo_error));
 
     /* (the figures of a row that carried replay bits: ProtoMSet's own count, exact unless flagged) */
     const bool replayed = plain && plan.replay != 0u && !(known_raw & XGM_KNOWN_LOWER_BOUND);

@@ -150,7 +150,9 @@ struct SpyAdapter {
 void register_spy_adapter(const std::string& spy_class_name, SpyAdapter adapter);
 
 struct Counters { uint64_t answered, declined_shape, declined_unregistered, declined_revision, declined_device, answered_sorted, answered_spied,
-                  answered_collapsed, columns_built, replayed; };
+                  answered_collapsed, columns_built, replayed,
+                  combined,            /* sorted / spied / collapsed searches that went out in a launch shared with other threads' */
+                  combined_launches; };
 Counters counters();
 
 /* The call the patch adds.  sort_by: Enquire::Internal::sort_setting as an int.  Returns true and fills `out` when the

@@ -231,6 +231,7 @@ int main(int argc, char** argv) {
         double cpu_s = 0.0, hook_s = 0.0;
         const bool percents = dbs.size() == 1;
         std::vector<Xapian::MSet> wants;                             /* the CPU matcher's answers, for the threaded leg */
+        std::vector<SpyResult> spy_wants;
         for (size_t qi = 0; qi < queries.size(); ++qi) {
             const QuerySpec& q = queries[qi];
             const Xapian::Query query = make_query(q);
@@ -243,7 +244,7 @@ int main(int argc, char** argv) {
             Xapian::MSet got = run_query(dbs, query, q.first, q.maxitems, &q, &spy_got);
             cpu_s += t_q1 - t_q0; hook_s += now_s() - t_q1;
             std::string why;
-            if (n_threads) wants.push_back(want);
+            if (n_threads) { wants.push_back(want); spy_wants.push_back(spy_want); }
             if (!same_mset(want, got, percents, &why)) {
                 ++bad;
                 printf("MISMATCH query %zu (%s): %s; cpu %u hits, hook %u hits\n", qi, q.op.c_str(), why.c_str(), want.size(), got.size());
@@ -333,6 +334,10 @@ int main(int argc, char** argv) {
                             Xapian::MSet got = run_query(handles[t], make_query(q), q.first, q.maxitems, &q, &spy);
                             std::string why;
                             if (!same_mset(wants[qi], got, percents, &why)) { if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: %s\n", t, qi, why.c_str()); }
+                            else if (spy.total != spy_wants[qi].total || spy.values != spy_wants[qi].values || spy.aggregation != spy_wants[qi].aggregation) {
+                                if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: spy: cpu saw %u documents / %zu values, hook %u / %zu\n", t, qi,
+                                                                   spy_wants[qi].total, spy_wants[qi].values.size(), spy.total, spy.values.size());
+                            }
                         }
                     } catch (const Xapian::Error& e) {
                         bad_t.fetch_add(1);
@@ -362,7 +367,7 @@ int main(int argc, char** argv) {
         xgm_hook::Counters c = xgm_hook::counters();
         c.answered -= c0.answered; c.declined_shape -= c0.declined_shape; c.declined_unregistered -= c0.declined_unregistered; c.declined_revision -= c0.declined_revision;
         c.declined_device -= c0.declined_device; c.answered_sorted -= c0.answered_sorted; c.answered_spied -= c0.answered_spied; c.answered_collapsed -= c0.answered_collapsed;
-        c.replayed -= c0.replayed;
+        c.replayed -= c0.replayed; c.combined -= c0.combined; c.combined_launches -= c0.combined_launches;
         if (!leg.name.empty()) printf("{\"leg\": \"%s\", \"mode\": \"%s\", ", leg.name.c_str(), leg.mode.c_str());
         printf("%s\"queries\": %zu, \"shards\": %zu,", leg.name.empty() ? "{" : "", queries.size(), dbs.size());
         printf(" \"mismatches\": %u, \"bounds_violations\": %u, \"answered_on_device\": %llu, \"declined_shape\": %llu, "
@@ -370,14 +375,16 @@ int main(int argc, char** argv) {
                "\"answered_sorted\": %llu, \"answered_spied\": %llu, \"answered_collapsed\": %llu, \"columns_built\": %llu, \"http_total_equal\": %u, \"replayed\": %llu, "
                "\"docs\": %u, \"export_seconds\": %.3f, \"segment_bytes\": %llu, \"open_seconds\": %.3f, \"cpu_matcher_seconds\": %.3f, \"hook_seconds\": %.3f, "
                "\"http_bodies_equal\": %u, \"glue_full_exports\": %llu, \"glue_refreshes\": %llu, \"glue_failures\": %llu, \"glue_released\": %llu, \"glue_overtaken\": %llu, "
-               "\"threads\": %u, \"threaded_queries\": %llu, \"threaded_seconds\": %.4f, \"threaded_mismatches\": %u, \"threaded_answered_on_device\": %llu, \"commit_during\": %s}\n",
+               "\"threads\": %u, \"threaded_queries\": %llu, \"threaded_seconds\": %.4f, \"threaded_mismatches\": %u, \"threaded_answered_on_device\": %llu, \"commit_during\": %s, "
+               "\"combined_searches\": %llu, \"combined_launches\": %llu}\n",
                bad, bounds_bad, (unsigned long long)c.answered, (unsigned long long)c.declined_shape,
                (unsigned long long)c.declined_unregistered, (unsigned long long)c.declined_revision, (unsigned long long)c.declined_device, refreshed,
                (unsigned long long)c.answered_sorted, (unsigned long long)c.answered_spied, (unsigned long long)c.answered_collapsed, (unsigned long long)c.columns_built, http_total_equal, (unsigned long long)c.replayed,
                (unsigned)dbs[0].get_doccount(), export_s, segment_bytes, open_s, cpu_s, hook_s, http_bodies_equal,
                (unsigned long long)xgm_xapiand::stats().full_exports, (unsigned long long)xgm_xapiand::stats().refreshes, (unsigned long long)xgm_xapiand::stats().failures,
                (unsigned long long)xgm_xapiand::stats().released, (unsigned long long)xgm_xapiand::stats().overtaken,
-               n_threads, thr_done, thr_s, thr_bad, thr_device, (commit_during && commit_glue) ? "true" : "false");
+               n_threads, thr_done, thr_s, thr_bad, thr_device, (commit_during && commit_glue) ? "true" : "false",
+               (unsigned long long)c.combined, (unsigned long long)c.combined_launches);
         fflush(stdout);
         bad_total += bad + bounds_bad;
         }   /* legs */

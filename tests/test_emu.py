@@ -195,6 +195,13 @@ def test_matcher_hook_modes_under_emulation(emu_lib, tmp_path):
     out = _run_hook_emulated(T, alias, qf, one)
     assert out["mismatches"] == 0 and out["bounds_violations"] == 0 and out["answered_on_device"] == len(qs), out
     assert out["answered_sorted"] >= n_sorted // 2 and out["answered_spied"] >= 6 and out["columns_built"] >= 3, out
+    # the same kinds of search from 8 threads under shared sort specs and spy slots: they go out in shared launches (the hook's lanes)
+    qs = T.combined_queries()
+    qf = str(tmp_path / "qc.txt")
+    H.write_queries(qf, qs)
+    out = _run_hook_emulated(T, alias, "--threads", "8", "--thread-repeat", "2", qf, one)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["threaded_answered_on_device"] == 2 * len(qs), out
+    assert out["combined_searches"] > 0 and out["combined_launches"] < out["combined_searches"], out
     # replay: collapse / cut-offs / spies by relevance with pages inside the match
     c = H.Corpus(n_docs, T.VOCAB)
     qs = []

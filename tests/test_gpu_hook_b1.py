@@ -272,6 +272,45 @@ def test_searches_from_many_threads_while_the_writer_commits(built, glass, tmp_p
     assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["threaded_answered_on_device"] == 6 * len(qs), out
 
 
+def combined_queries(collapse=False):
+    """Searches many threads issue under the SAME sort / spy slot / collapse key (a dashboard: Xapiand's HTTP threads sort by the same few fields):
+    pages of different sizes and offsets, conjunctions and disjunctions."""
+    base = H.gen_term_queries("AND", 16, 2, 1, 400, maxitems=10, seed=411) + H.gen_term_queries("OR", 16, 3, 1, 400, maxitems=10, seed=412)
+    qs = []
+    for i, q in enumerate(base):
+        if collapse:
+            qs.append(dict(q, first=0, maxitems=400, collapse=(1, 1)))
+        else:
+            qs.append(dict(q, first=i % 3, maxitems=5 + i % 7, sort=("V", 1, False)))
+            qs.append(dict(q, first=0, maxitems=10, sort=("VR", 2, True), spy=0))
+    return qs
+
+
+def test_sorted_spied_and_collapsed_searches_of_many_threads_share_launches(built, glass_values, tmp_path):
+    """value-sorted searches, searches with a spy and collapsed searches issued by many threads under the same sort / spy slot /
+    collapse key go out in shared launches (the hook's lanes over xgm_search_sorted_batch / _sorted_spy_batch / _collapsed_batch): whatever
+    arrives while a launch of the lane is in flight is the next launch.  Every answer — page, sort keys, spy counts, collapse keys and counts,
+    bounds — equals the CPU matcher's; the driver reports how many searches shared a launch."""
+    d, one, _ = glass_values
+    qs = combined_queries()
+    qf = str(tmp_path / "qcomb.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--threads", "32", "--thread-repeat", "8", qf, one)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0 and out["bounds_violations"] == 0, out
+    assert out["threaded_answered_on_device"] == 8 * len(qs), out
+    assert out["combined_searches"] >= len(qs) and out["combined_launches"] < out["combined_searches"], out
+    # collapse with the page covering the match (where the reference's collapser and the intended semantics agree)
+    c = H.Corpus(N_DOCS, VOCAB)
+    qs = [q for q in combined_queries(collapse=True) if 0 < H.oracle_search(c, q["op"], q["terms"], 0, 1)[1].matches <= 400]
+    c.close()
+    assert len(qs) >= 8, len(qs)
+    qf = str(tmp_path / "qcombc.txt")
+    H.write_queries(qf, qs)
+    out = run_b1("--collapse-intended", "--threads", "32", "--thread-repeat", "8", qf, one)
+    assert out["mismatches"] == 0 and out["threaded_mismatches"] == 0, out
+    assert out["threaded_answered_on_device"] == 8 * len(qs) and out["combined_searches"] > 0, out
+
+
 def xapiand_keymaker_queries():
     """Sorted by Xapiand's OWN key maker: Multi_MultiValueKeyMaker (reference src/multivalue/keymaker.h:366; compiled from the reference's
     sources into the driver, oracle/ref_build/xapiand_classes.cc) through Enquire::set_sort_by_key_then_relevance(sorter, false) — the

@@ -1641,7 +1641,25 @@ extern "C" int xgm_index_attach_column_ordinals(xgm_index* idx, uint32_t slot, c
 }
 
 /* a scratch goes back to the pool only when nothing enqueued on its stream still uses it (the early returns) */
-struct ScratchRelease { xgm_index* i; XgmScratch* s; ~ScratchRelease() { hipStreamSynchronize(s->stream); scratch_release(i, s); } };
+/* The whole-match list of a replay / xgm_search_all (d_all) is sized by the match's upper bound — hundreds of MB for a frequent-term query on a
+ * 10 M-document shard — and the pool keeps a scratch per concurrent caller: ONE scratch of the pool keeps such a list (a caller that replays one
+ * query after another gets it back: no allocation per call), any further one is trimmed when it returns. */
+constexpr size_t kAllKeepBytes = (size_t)64 << 20;
+struct ScratchRelease {
+    xgm_index* i; XgmScratch* s;
+    ~ScratchRelease() {
+        hipStreamSynchronize(s->stream);
+        if (s->cap_all > kAllKeepBytes) {
+            bool another = false;
+            {
+                std::lock_guard<std::mutex> lk(i->scratch_mu);
+                for (const XgmScratch* o : i->scratch_pool) another = another || o->cap_all > kAllKeepBytes;
+            }
+            if (another) { hipFree(s->d_all); s->d_all = nullptr; s->cap_all = 0; }
+        }
+        scratch_release(i, s);
+    }
+};
 
 namespace {
 struct DeviceBuffers {                       /* freed on every way out */
@@ -1711,7 +1729,7 @@ static int sorted_core(xgm_index* idx, const xgm_query* q, const xgm_sort_spec* 
      * searches of concurrent threads do not serialise): [query | work list] go up in one copy, [headers | counters | candidates] come down in one */
     XgmScratch* sc;
     if ((rc = scratch_acquire(idx, &sc))) return rc;
-    struct Release { xgm_index* i; XgmScratch* s; ~Release() { scratch_release(i, s); } } release_{idx, sc};
+    ScratchRelease release_{idx, sc};            /* (synchronises the stream before the scratch goes back to the pool: an error return leaves nothing in flight on it) */
     hipStream_t stream = sc->stream;
     const size_t o_q = 0, b_q = (sizeof dq + 15) & ~(size_t)15;
     const size_t o_wk = o_q + b_q, b_wk = ((size_t)n_work * sizeof(xgm_work) + 15) & ~(size_t)15;
@@ -1812,7 +1830,8 @@ extern "C" int xgm_search_sorted(xgm_index* idx, const xgm_query* q, const xgm_s
 static int sorted_batch_core(xgm_index* idx, const xgm_query* qs, uint32_t nq, const xgm_sort_spec* sort, uint32_t k_stride, xgm_hit* hits,
                              uint32_t* hit_ord, xgm_result_hdr* hdrs, int spy_slot, uint32_t* counts, uint32_t n_counts,
                              int collapse_slot = -1, uint32_t cmax = 0, uint32_t* hit_cord = nullptr, uint32_t* hit_ccount = nullptr, uint64_t* collapsed_lb = nullptr) {
-    if (!idx || !qs || !hits || !hdrs || nq == 0 || (!sort && collapse_slot < 0)) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (!idx || !qs || !hits || !hdrs || nq == 0) return xgm_set_error(XGM_E_INVALID, "null argument");
+    if (!sort && collapse_slot < 0 && spy_slot < 0) return xgm_set_error(XGM_E_INVALID, "neither a sort nor a collapse key nor a spy");
     if (idx->device == XGM_DEVICE_NONE) return xgm_set_error(XGM_E_NO_DEVICE, "index opened without a device");
     if (sort && (sort->sort_by < XGM_SORT_VALUE || sort->sort_by > XGM_SORT_RELEVANCE_VALUE)) return xgm_set_error(XGM_E_INVALID, "sort_by %u", sort->sort_by);
     if (collapse_slot >= 0 && (cmax == 0 || spy_slot >= 0)) return xgm_set_error(XGM_E_INVALID, "collapse_max 0, or a spy together with a collapse key");
