@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -735,7 +736,8 @@ bool try_get_mset(const Xapian::Database& db, const Xapian::Query& query, const 
                           uint64_t* clb, uint32_t* cnt, uint32_t n_cnt) {
             const ComboKey K{sh.idx, kind, sp_sort ? 1u : 0u, spec.sort_by, spec.slot, spec.reverse, aux_slot, aux_max};
             ComboReq r{&plan, k, h, o, co, cc, hd, clb, cnt, n_cnt, 0, std::string()};
-            const int rc_ = sh.batch > 1u ? combo_search(K, r) : (r.rc = combo_single(K, sp_sort, r));
+            static const bool no_combine = getenv("XGM_HOOK_NO_COMBINE") != nullptr;        /* A/B switch: every search its own launch */
+            const int rc_ = (sh.batch > 1u && !no_combine) ? combo_search(K, r) : (r.rc = combo_single(K, sp_sort, r));
             if (rc_ < 0) combo_error = r.error;
             return rc_;
         };

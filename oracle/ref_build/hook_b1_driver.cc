@@ -23,6 +23,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <mutex>
 #include <thread>
 
 #include "../../integration/xgm_matcher_hook.h"
@@ -316,6 +317,7 @@ int main(int argc, char** argv) {
             for (int i = a + 1; i < argc; ++i) paths.push_back(argv[i]);
             std::atomic<size_t> next{0};
             std::atomic<unsigned> bad_t{0};
+            std::vector<std::mutex> want_mu(queries.size());
             const size_t total = queries.size() * thread_repeat;
             const xgm_hook::Counters t0c = xgm_hook::counters();
             xgm_hook::set_enabled(true);
@@ -333,7 +335,14 @@ int main(int argc, char** argv) {
                             SpyResult spy;
                             Xapian::MSet got = run_query(handles[t], make_query(q), q.first, q.maxitems, &q, &spy);
                             std::string why;
-                            if (!same_mset(wants[qi], got, percents, &why)) { if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: %s\n", t, qi, why.c_str()); }
+                            bool same;
+                            {   /* (a Xapian::MSet is a handle on a reference-counted body whose count is NOT atomic, and iterating one copies the handle:
+                                 *  two threads comparing against the same expected MSet at once — searches that shared a launch return together — would
+                                 *  corrupt the count and free the body under each other) */
+                                std::lock_guard<std::mutex> lk(want_mu[qi]);
+                                same = same_mset(wants[qi], got, percents, &why);
+                            }
+                            if (!same) { if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: %s\n", t, qi, why.c_str()); }
                             else if (spy.total != spy_wants[qi].total || spy.values != spy_wants[qi].values || spy.aggregation != spy_wants[qi].aggregation) {
                                 if (bad_t.fetch_add(1) < 5) printf("MISMATCH (thread %u) query %zu: spy: cpu saw %u documents / %zu values, hook %u / %zu\n", t, qi,
                                                                    spy_wants[qi].total, spy_wants[qi].values.size(), spy.total, spy.values.size());

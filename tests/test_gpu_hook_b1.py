@@ -277,10 +277,16 @@ def combined_queries(collapse=False):
     pages of different sizes and offsets, conjunctions and disjunctions."""
     base = H.gen_term_queries("AND", 16, 2, 1, 400, maxitems=10, seed=411) + H.gen_term_queries("OR", 16, 3, 1, 400, maxitems=10, seed=412)
     qs = []
+    if collapse:
+        # (the page covers the match — there the reference's collapser and the intended semantics agree —: small matches, one collapse key)
+        c = H.Corpus(N_DOCS, VOCAB)
+        for q in (H.gen_term_queries("AND", 60, 2, 1, 400, maxitems=10, seed=70) + H.gen_term_queries("OR", 40, 2, 300, 6000, maxitems=10, seed=71)):
+            if 0 < H.oracle_search(c, q["op"], q["terms"], 0, 1)[1].matches <= 400:
+                qs.append(dict(q, first=0, maxitems=400, collapse=(1, 1)))
+        c.close()
+        return qs
     for i, q in enumerate(base):
-        if collapse:
-            qs.append(dict(q, first=0, maxitems=400, collapse=(1, 1)))
-        else:
+        if True:
             qs.append(dict(q, first=i % 3, maxitems=5 + i % 7, sort=("V", 1, False)))
             qs.append(dict(q, first=0, maxitems=10, sort=("VR", 2, True), spy=0))
     return qs
@@ -300,9 +306,7 @@ def test_sorted_spied_and_collapsed_searches_of_many_threads_share_launches(buil
     assert out["threaded_answered_on_device"] == 8 * len(qs), out
     assert out["combined_searches"] >= len(qs) and out["combined_launches"] < out["combined_searches"], out
     # collapse with the page covering the match (where the reference's collapser and the intended semantics agree)
-    c = H.Corpus(N_DOCS, VOCAB)
-    qs = [q for q in combined_queries(collapse=True) if 0 < H.oracle_search(c, q["op"], q["terms"], 0, 1)[1].matches <= 400]
-    c.close()
+    qs = combined_queries(collapse=True)
     assert len(qs) >= 8, len(qs)
     qf = str(tmp_path / "qcombc.txt")
     H.write_queries(qf, qs)

@@ -23,7 +23,7 @@ def close(self):
     if L.xgm_debug_orw_phase_cycles(out) == 0 and sum(out):
         v = list(out)
         tot = sum(v) or 1
-        names = ["theta+bitmaps+sum", "decode+candset", "enumerate", "dense probes", "block scatter", "score-loop", "hist flush", "setup", "sort", "dlen+leaves", "tree", "hist+insert", "s0:prologue+hist issue", "s0:group loads+hist bound+quantise", "s0:prefetched bitmaps+sum", "-"]
+        names = ["theta+bitmaps+sum", "decode+candset", "enumerate", "dense probes", "block scatter", "score-loop", "hist flush", "setup", "sort", "dlen+leaves", "tree", "hist+insert", "loads issued+hist bound+quantise", "bound sum (after the wait)", "wait for the bitmaps", "flat: zero+loads+atomics"]
         print("ORW PHASES:", {n: round(100.0 * x / tot, 1) for n, x in zip(names, v)}, "total Gcycles", round(tot / 1e9, 2))
     out = (C.c_ulonglong * 8)()
     L.xgm_debug_merge_cycles.argtypes = [C.POINTER(C.c_ulonglong)]

@@ -51,23 +51,29 @@
 namespace {
 
 #ifndef XGM_ORW_CAND
-#define XGM_ORW_CAND 512
+#define XGM_ORW_CAND 384            /* (512 until round 6: with 384 three workgroups' LDS slices fit a CU at C3's shape — see XGM_ORW_MINWG) */
 #endif
 constexpr uint32_t kOrwCand = XGM_ORW_CAND;   /* candidates per scoring chunk */
 #ifndef XGM_ORW_REGSPARSE
 #define XGM_ORW_REGSPARSE 2
 #endif
 #ifndef XGM_ORW_MINWG
-#define XGM_ORW_MINWG 2
+#define XGM_ORW_MINWG 3             /* round 6: once the unit, the query and the threshold live in scalar registers the kernel needs 189 VGPRs; capped at 168 it
+                                       spills 14 and runs three waves per SIMD: 1.50 -> 1.30 ms per launch of C3 (round 5's attempts spilled 87-136 and lost) */
 #endif
 #ifndef XGM_ORW_GROUP
-#define XGM_ORW_GROUP 5             /* dense terms whose bitmaps (+ wdf >= 2 bitmaps) are in flight together */
+#define XGM_ORW_GROUP 4             /* dense terms whose bitmaps (+ wdf >= 2 bitmaps) are in flight together (5 until round 6: 40 registers of bitmaps; at three
+                                       waves per SIMD 4 and 3 measure 1.18 ms per launch of C3, 5 1.30, 2 1.22) */
 #endif
 #ifndef XGM_ORW_TIMERS
 #define XGM_ORW_TIMERS 0            /* section timers cost ~30 VGPRs: A/B builds only (tools/ab_build.sh) */
 #endif
 constexpr uint32_t kOrwRegSparse = XGM_ORW_REGSPARSE;   /* block-decoded terms whose headers are software-pipelined */
 static_assert(kOrwRegSparse >= 1u && kOrwRegSparse <= 2u, "the per-term decode of xgm_orw_kernel picks between two header register sets");
+#ifndef XGM_ORW_FLPRE
+#define XGM_ORW_FLPRE 2             /* flat terms whose next postings are prefetched a stripe ahead */
+#endif
+constexpr uint32_t kFlPre = XGM_ORW_FLPRE;
 constexpr uint32_t kNoDense = 0xFFFFFFFFu;
 constexpr uint32_t kQ = 64;              /* quantisation of a weight bound relative to the threshold  */
 constexpr uint32_t kHistShift = 47;      /* weight bits >> 47: sign, exponent, 5 mantissa bits         */
@@ -144,6 +150,7 @@ __device__ __forceinline__ void orw_block(const Words4& pv, uint32_t meta, uint3
 }
 
 typedef double orw_d8 __attribute__((ext_vector_type(8)));
+typedef uint32_t orw_u4 __attribute__((ext_vector_type(4)));
 
 /* (mask & a) | (~mask & b): v_bfi_b32.  With mask = x ^ y: the majority of (x, y, a) when b = x — the carry of a full adder. */
 __device__ __forceinline__ uint32_t orw_bfi(uint32_t mask, uint32_t a, uint32_t b) {
@@ -162,7 +169,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                                                           xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out,
                                                           unsigned long long* __restrict__ phase_cycles, const xgm_fuse* __restrict__ fuse) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    /* (the wave's index through readfirstlane: the compiler cannot prove threadIdx.x >> 6 uniform, and with it the unit, the query and every loop
+     *  bound read from them would live in vector registers — loops over the query's terms under exec masks, the query's fields fetched with vector
+     *  loads, copies at every join: round 6, as xgm_dense_unit since round 3) */
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl32(threadIdx.x >> 6);
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
     const xgm_work wk = work[unit];
@@ -285,6 +295,30 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         }
     }
     const uint32_t fl_start = fl_cur;                              /* (the repair pass walks the slices again) */
+    /* FLAT, round 6: the next 64 postings from the cursor of the first kFlPre flat terms are requested as soon as the cursor has moved — a stripe
+     * ahead of their use — instead of when the stripe's term loop gets to them (one exposed memory round trip per flat term and stripe: the
+     * section took 20 % of the kernel's cycles on C3) */
+    uint32_t pre_t[kFlPre], pre_d[kFlPre], pre_w[kFlPre];
+    uint32_t n_pre = 0;
+    {
+        uint64_t sm = FLAT ? sparse_mask : 0ull;
+#pragma unroll
+        for (uint32_t u = 0; u < kFlPre; ++u) {
+            pre_t[u] = 0xFFu; pre_d[u] = 0xFFFFFFFFu; pre_w[u] = 0u;
+            if (sm) { pre_t[u] = (uint32_t)__builtin_ctzll(sm); sm &= sm - 1u; n_pre = u + 1u; }
+        }
+    }
+    auto flat_prefetch = [&](uint32_t u) {                        /* (u: compile-time after unrolling) */
+        const uint32_t t = pre_t[u] & 63u;
+        const uint32_t g = rl32(fl_cur, t) + lane, e_ = rl32(fl_end, t);
+        const bool in_arr = u < n_pre && g < e_;
+        pre_d[u] = in_arr ? seg.flat_did[g] : 0xFFFFFFFFu;
+        pre_w[u] = in_arr ? (uint32_t)seg.flat_wdf[g] : 0u;
+    };
+    if (FLAT) {
+#pragma unroll
+        for (uint32_t u = 0; u < kFlPre; ++u) flat_prefetch(u);
+    }
     /* block ranges of every block-decoded term inside the unit's docid range -> run table */
     for (uint64_t sm = FLAT ? 0ull : sparse_mask; sm; sm &= sm - 1u) {
         const uint32_t t = (uint32_t)__builtin_ctzll(sm);
@@ -404,7 +438,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             if (tkn + 64u > cap) {
                 orw_topk_sort(tk_w, tk_d, tk_m, cap, lane);
                 tkn = tkn < k ? tkn : k;
-                if (tkn == k) { theta_valid = true; theta_w = tk_w[k - 1]; theta_d = tk_d[k - 1]; }
+                /* (the same LDS word read by every lane is still a VECTOR value to the compiler: everything decided by the threshold — the stripe
+                 *  loop's exits, the planes the bound sum touches — then runs under exec masks with copies at every join; through readfirstlane
+                 *  it is the scalar it is: round 6) */
+                if (tkn == k) { theta_valid = true; theta_w = rl64(tk_w[k - 1], 0u); theta_d = rl32(tk_d[k - 1], 0u); }
                 for (uint32_t i = tkn + lane; i < cap; i += 64u) { tk_w[i] = 0; tk_d[i] = 0xFFFFFFFFu; tk_m[i] = 0; }
                 wave_lds_fence();
             }
@@ -592,7 +629,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             if (th_now >= seed_bits) break;
             fix = true;
             quantise(seed_bits, essA_mask, qA2_reg, qA1_reg);
-            if (FLAT) fl_cur = fl_start;
+            if (FLAT) {
+                fl_cur = fl_start;
+#pragma unroll
+                for (uint32_t u = 0; u < kFlPre; ++u) flat_prefetch(u);
+            }
         }
 
         auto next_active = [&](uint32_t from) {
@@ -647,7 +688,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
              * document's sum can have so far — terms are added in ascending order of their bounds, so the early ones stay low) */
             uint32_t max_sum = 0;
             auto planes_for = [&](uint32_t add) {
-                const uint32_t nm = max_sum + add;
+                const uint32_t nm = rfl32(max_sum + add);
                 max_sum = nm < kQ ? nm : kQ;
                 return nm >= kQ ? 6u : 32u - (uint32_t)__builtin_clz(nm | 1u);
             };
@@ -742,15 +783,24 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     tt[u] = 0; oo[u] = 0;
                     if (dp < n_dense_ord) { tt[u] = (uint32_t)(dense_ord >> (4u * dp)) & 15u; ++dp; oo[u] = rl32(hc_cur, tt[u]); }
                     if (TALLY) { if (oo[u]) cn_bmpw += want_planes ? 2u * NW : NW; }
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        x[u][i] = 0; pl[u][i] = 0;
-                        const uint32_t w = lane * 4u + i;
-                        if (oo[u] && w < NW) {
-                            x[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16)[w];
-                            if (want_planes) pl[u][i] = reinterpret_cast<const uint32_t*>(seg.dense_data + (size_t)oo[u] * 16 + seg.dense_plane)[w];
-                        }
-                    }
+                    /* ONE 16-byte load per lane and bitmap, issued without a branch around it (NW is a multiple of 4: XGM_MIN_STRIPE_BITS; containers
+                     * start on 16-byte boundaries and so do their planes) — written word by word under `w < NW` the compiler cannot merge the four
+                     * loads and wraps each in an exec-mask region: 40 load instructions per stripe where 10 do (round 6) */
+                    const bool lane_in = lane * 4u < NW;
+                    /* (no container in this stripe — or no containers at all: dense_data is null then —: the load still goes out, to 16 bytes that
+                     *  are always there (the query array), and its result is dropped.  A branch around each load measured 1.75 ms per launch of C3
+                     *  against 1.50 with the ten loads back to back) */
+                    const bool has = oo[u] != 0u;
+                    const unsigned char* safe = reinterpret_cast<const unsigned char*>(queries);
+                    const unsigned char* cp = has ? seg.dense_data + (size_t)oo[u] * 16 : safe;
+                    const unsigned char* pp = has ? cp + seg.dense_plane : safe;
+                    const uint32_t li = (has && lane_in) ? lane : 0u;
+                    orw_u4 xv = reinterpret_cast<const orw_u4*>(cp)[li];
+                    orw_u4 pv_ = orw_u4{0u, 0u, 0u, 0u};
+                    if (want_planes) pv_ = reinterpret_cast<const orw_u4*>(pp)[li];
+                    if (!(has && lane_in)) { xv = orw_u4{0u, 0u, 0u, 0u}; pv_ = orw_u4{0u, 0u, 0u, 0u}; }
+                    x[u][0] = xv.x; x[u][1] = xv.y; x[u][2] = xv.z; x[u][3] = xv.w;
+                    pl[u][0] = pv_.x; pl[u][1] = pv_.y; pl[u][2] = pv_.z; pl[u][3] = pv_.w;
                 }
                 if (first_group) {
                     first_group = false;
@@ -766,6 +816,8 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         }
                     }
                 }
+                ORW_PH(12);
+                if (XGM_ORW_TIMERS && phase_cycles) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ORW_PH(14); }      /* (diagnostics: the wait for the bitmaps apart from the sum) */
 #pragma unroll
                 for (uint32_t u = 0; u < XGM_ORW_GROUP; ++u) {
 #pragma unroll
@@ -778,28 +830,38 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 }
             }
             if (stop) break;
-            ORW_PH(0);
+            ORW_PH(13);
             uint32_t es[4] = {0, 0, 0, 0};                         /* bound sum switched off (A/B): union of the essential block-decoded terms */
             if (sparse_mask) {
                 /* ---- 1b. block-decoded terms, one at a time: every block of the stripe is decoded into two LDS bitmaps — the term's
                  * documents, and those whose wdf is >= 2 — which then join the bound sum exactly like a container's pair ---- */
                 for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
                     const uint32_t t = (uint32_t)__builtin_ctzll(sm);
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        const uint32_t w = lane * 4u + i;
-                        if (w < NW) { bm_ess[w] = 0; bm_ne[w] = 0; }
+                    /* (the LDS bitmaps 16 bytes per lane at a time: their slices start on 16-byte boundaries, NW is a multiple of 4) */
+                    if (lane * 4u < NW) {
+                        reinterpret_cast<orw_u4*>(bm_ess)[lane] = orw_u4{0u, 0u, 0u, 0u};
+                        reinterpret_cast<orw_u4*>(bm_ne)[lane] = orw_u4{0u, 0u, 0u, 0u};
                     }
                     wave_lds_fence();
                     if (FLAT) {
                         /* this stripe's postings of the term, 64 per coalesced load, straight into the bitmap pair */
                         uint32_t c = rl32(fl_cur, t);
                         const uint32_t e_ = rl32(fl_end, t), stripe_end = stripe_base + W, c0 = c;
+                        /* the 64 postings at the cursor were requested when the cursor last moved */
+                        int pf = -1;
+                        uint32_t d0 = 0xFFFFFFFFu, w0 = 0u;
+#pragma unroll
+                        for (uint32_t u = 0; u < kFlPre; ++u) if (pre_t[u] == t) { pf = (int)u; d0 = pre_d[u]; w0 = pre_w[u]; }
+                        bool first_round = pf >= 0;
                         while (true) {
                             const uint32_t g = c + lane;
                             const bool in_arr = g < e_;
-                            const uint32_t d = in_arr ? seg.flat_did[g] : 0xFFFFFFFFu;
-                            const uint32_t wf = in_arr ? (uint32_t)seg.flat_wdf[g] : 0u;
+                            uint32_t d, wf;
+                            if (first_round) { d = d0; wf = w0; first_round = false; }
+                            else {
+                                d = in_arr ? seg.flat_did[g] : 0xFFFFFFFFu;
+                                wf = in_arr ? (uint32_t)seg.flat_wdf[g] : 0u;
+                            }
                             if (TALLY) { cn_blkw += 80u; }                            /* (64 docids + 64 wdf bytes, in 4-byte words) */
                             const bool in = in_arr && d < stripe_end;                 /* (the cursor sits at the stripe's first posting) */
                             if (in) {
@@ -812,6 +874,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                             if (n_in < 64u) break;
                         }
                         if (lane == t) { fl_cur = c; fl_c0 = c0; fl_n = c - c0; }
+#pragma unroll
+                        for (uint32_t u = 0; u < kFlPre; ++u) if (pf == (int)u) flat_prefetch(u);      /* the next stripe's */
+                        ORW_PH(15);
                     }
                     const uint32_t rb0 = FLAT ? 0u : rs[t * SPG + sl], nb = FLAT ? 0u : re[t * SPG + sl] - rb0;
                     /* the pipelined terms' headers are already in registers (lane j = block j of the run) */
@@ -845,10 +910,10 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                     }
                     wave_lds_fence();
                     uint32_t xb[4] = {0, 0, 0, 0}, xp[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        const uint32_t w = lane * 4u + i;
-                        if (w < NW) { xb[i] = bm_ess[w]; xp[i] = bm_ne[w]; }
+                    if (lane * 4u < NW) {
+                        const orw_u4 vb = reinterpret_cast<const orw_u4*>(bm_ess)[lane], vp = reinterpret_cast<const orw_u4*>(bm_ne)[lane];
+                        xb[0] = vb.x; xb[1] = vb.y; xb[2] = vb.z; xb[3] = vb.w;
+                        xp[0] = vp.x; xp[1] = vp.y; xp[2] = vp.z; xp[3] = vp.w;
                     }
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) a[i] |= xb[i];
@@ -882,13 +947,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 for (uint32_t i = 0; i < 4u; ++i) e[i] = a[i];
             }
             /* the scatter of the block-decoded terms looks candidates up in bm_ess */
-            if (sparse_mask) {
-#pragma unroll
-                for (uint32_t i = 0; i < 4u; ++i) {
-                    const uint32_t w = lane * 4u + i;
-                    if (w < NW) bm_ess[w] = e[i];
-                }
-            }
+            if (sparse_mask && lane * 4u < NW) reinterpret_cast<orw_u4*>(bm_ess)[lane] = orw_u4{e[0], e[1], e[2], e[3]};
             ORW_PH(1);
 
             /* ---- exact match count (first pass); candidates in docid order ---- */
@@ -978,14 +1037,32 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 if (FLAT) {
                     /* wdf of the flat terms for this chunk's candidates: the stripe's slice of the array once more (an L2 hit), scattered to
                      * the candidates' ordinals through the candidate bitmap and rankw — no decode */
+                    /* (the first kFlPre terms' slices are requested together, before any is scattered) */
+                    uint32_t sd[kFlPre], sw[kFlPre];
+#pragma unroll
+                    for (uint32_t u = 0; u < kFlPre; ++u) {
+                        const uint32_t t = pre_t[u] & 63u;
+                        const uint32_t c0 = rl32(fl_c0, t), nn = rl32(fl_n, t);
+                        const bool v = u < n_pre && lane < nn;
+                        sd[u] = v ? seg.flat_did[c0 + lane] : 0u;
+                        sw[u] = v ? (uint32_t)seg.flat_wdf[c0 + lane] : 0u;
+                    }
                     for (uint64_t sm = sparse_mask; sm; sm &= sm - 1u) {
                         const uint32_t t = (uint32_t)__builtin_ctzll(sm);
                         const uint32_t c0 = rl32(fl_c0, t), nn = rl32(fl_n, t);
                         TabT* row = c_w + (size_t)t * kOrwCand;
+                        bool pre = false;
+                        uint32_t d0 = 0u, w0 = 0u;
+#pragma unroll
+                        for (uint32_t u = 0; u < kFlPre; ++u) if (pre_t[u] == t) { pre = true; d0 = sd[u]; w0 = sw[u]; }
                         for (uint32_t done = 0; done < nn; done += 64u) {
                             const bool v = done + lane < nn;
-                            const uint32_t d = v ? seg.flat_did[c0 + done + lane] : 0u;
-                            const uint32_t wf = v ? (uint32_t)seg.flat_wdf[c0 + done + lane] : 0u;
+                            uint32_t d, wf;
+                            if (pre && done == 0u) { d = d0; wf = w0; }
+                            else {
+                                d = v ? seg.flat_did[c0 + done + lane] : 0u;
+                                wf = v ? (uint32_t)seg.flat_wdf[c0 + done + lane] : 0u;
+                            }
                             if (v) {
                                 const uint32_t s_ = d - stripe_base, wd = s_ >> 5, bit = s_ & 31u;
                                 if (wd >= wlo && wd < whi) {
