@@ -38,7 +38,7 @@ lib_sha = open(sha_path).read().strip() if os.path.exists(sha_path) else None   
 print(json.dumps({
     "lib_sha": lib_sha,
     "kernel": r["kernel"], "kernel_instantiation": sorted(names)[0], "op": cfg["op"], "docs_per_gpu": cfg["docs_per_gpu"], "top_k": cfg["top_k"],
-    "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"], "streamed_bytes_tallied": r["model_counts"] is not None,
+    "terms": cfg["terms_per_query"] if cfg["op"] != "PHRASE" else 0, "batch": cfg["batch"], "replay_bits": cfg.get("replay_bits", 0), "streamed_bytes_tallied": r["model_counts"] is not None,
     "fetch_size_kb_raw": vals["FETCH_SIZE"], "write_size_kb_raw": vals["WRITE_SIZE"], "streamed_bytes_model": streamed,
     "hbm_bytes_per_launch": total,
     "counters": {k: v for k, v in vals.items() if k not in ("FETCH_SIZE", "WRITE_SIZE")},

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_PHRASE_WAVES) void xgm_andw_list_kernel
     /* unit_matches [n_work] zeroed: matches found so far per unit slot — a unit stops once the units of lower stripes hold 2 (k + 1) (PrefixList::look_back);
      * fuse: only goff (the first unit slot of every query) */
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl32(threadIdx.x >> 6);
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below */
     const xgm_work wk = work[unit];
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ANDW_WAVES) void xgm_andw_all_kernel(xg
                                                                              uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
                                                                              xgm_cand* __restrict__ cand_out, xgm_group_hdr* __restrict__ ghdr_out, xgm_all_out all_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl32(threadIdx.x >> 6);
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below */
     const xgm_work wk = work[unit];
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(XGM_WG, PHRASE ? XGM_PHRASE_WAVES : XGM_ANDW_WAVES)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr uint32_t CAND = PHRASE ? kAndwCandPhrase : kAndwCandPlain;     /* candidates per chunk */
     constexpr uint32_t CHUNKB = CAND / XGM_BLOCK;                             /* = blocks of term 0 per chunk */
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u, wave = rfl32(threadIdx.x >> 6);  /* (a scalar: the unit, the query and the loops over its terms with it — xgm_or.hip, round 6) */
     const uint32_t unit = blockIdx.x * XGM_WAVES + wave;
     if (unit >= n_work) return;                                    /* no barriers below: early exit is safe */
     const xgm_work wk = work[unit];
