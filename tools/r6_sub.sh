@@ -1,4 +1,9 @@
-for a in "--steps 20 --warmup 3" "--op AND_NOT --terms 4 --required 2 --steps 6 --warmup 1" "--op AND_MAYBE --terms 4 --required 2 --steps 6 --warmup 1" "--op PHRASE --topk 10 --steps 10 --warmup 2" "--op PHRASE --topk 10 --replay frozen --steps 10 --warmup 2" "--replay count --steps 10 --warmup 2"; do
-  echo "== $a"
-  bash tools/ab_run.sh "$a --no-other-configs --no-hook-parity --ref-docs 0" newk oldk newk oldk
-done
+timeout 900 python bench.py --no-hook-parity --ref-docs 0 --no-cpu-baseline > gpurun_out/r6_sub_lat2.json 2>gpurun_out/r6_sub.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6_sub_lat2.json').read().strip().splitlines()[-1])
+print(round(d['value']), d['host_ms_per_batch'], 'count', round(d['exact_bounds_mode'].get('value',0)))
+for n in ('C3','C5'):
+    o=d['other_configs'][n]
+    print('  ',n, round(o['value']), o['ms_per_batch'], o.get('host_ms_per_batch'), o['roofline']['kernel_ms'])
+PY
