@@ -36,7 +36,10 @@ PHRASE_SELECT = "phrase or other_stripe_widths or edge_cases"
                                            # the wave kernels' events recorded around the launch again instead of riding in its dispatch packet
                                            ("XGM_NO_EXT_LAUNCH", SELECT + " or phrase"),
                                            # round 6: the disjunction kernel finishing its queries itself (opt-in: measured slower than the merge launch)
-                                           ("XGM_OR_FUSED_MERGE", SELECT)])
+                                           ("XGM_OR_FUSED_MERGE", SELECT),
+                                           # round 6: the bound sum's plane count (default: 4 where every query of the batch has 4-8 terms, else 6) forced either way —
+                                           # a coarser or finer rounding of the bounds changes which documents are weighed, never the answer
+                                           ("XGM_ORW_PLANES=4", SELECT), ("XGM_ORW_PLANES=6", SELECT), ("XGM_ORW_PLANES=4,XGM_OR_SEED_SCALE=8", SELECT)])
 def test_parity_with_fast_path_disabled(built, switch, select):
     env = dict(os.environ)
     for one in switch.split(","):

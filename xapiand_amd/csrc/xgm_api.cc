@@ -656,11 +656,12 @@ struct BatchPlan {
     bool fused = false; /* the conjunction kernel finishes its queries itself (xgm_unit_finish.h): no merge launch, no parts */
     uint32_t parts = 1; /* > 1: a query's units are merged in `parts` groups (pseudo-query p * nq + q of goff) and the groups' lists once more */
     uint32_t sub_bits = 0; /* workgroup kernels: every stripe in 2^sub_bits passes over narrower tables (positional queries of > 3 terms) */
+    int orw_planes = 6;    /* orw batch: planes of xgm_orw_kernel's bound sum (4 where every query has 4-8 terms) */
     int orw2 = 0;          /* orw batch whose every query xgm_orw2_kernel takes: 1 = containers only, 2 = with flat-array terms */
     bool or_flat = false;  /* orw batch: every term without a container has a flat posting array (xgm_orw_kernel's FLAT instantiation) */
     /* (a plan that is kept between calls — run_class_batch's, per thread: a work list of tens of thousands of units is a megabyte that would otherwise be
      *  allocated, faulted in and released per batch) */
-    void reset() { work.clear(); goff.clear(); fused = false; parts = 1; sub_bits = 0; orw2 = 0; or_flat = false; }
+    void reset() { work.clear(); goff.clear(); fused = false; parts = 1; sub_bits = 0; orw2 = 0; orw_planes = 6; or_flat = false; }
 };
 
 static int dense_kind(const xgm_index* idx, const xgm_query& q, bool fused = false);
@@ -733,6 +734,13 @@ static int plan_batch(const xgm_index* idx, const xgm_query* qs, uint32_t nq, xg
                 all = idx->term_wdfub[id] <= 254u && idx->term_df[id] != 0;                             /* (what build_flat gives an array) */
             }
         bp->or_flat = all;
+    }
+    if (bp->orw) {
+        /* planes of the bound sum (xgm_or.hip, PL): 4 where every query of the batch has 4-8 terms, else 6 (XGM_ORW_PLANES=4 | 6 forces one: A/B, the variant tests) */
+        static const int forced = getenv("XGM_ORW_PLANES") ? atoi(getenv("XGM_ORW_PLANES")) : 0;
+        bool four = true;
+        for (uint32_t i = 0; i < nq && four; ++i) four = qs[i].n_terms >= 4u && qs[i].n_terms <= 8u;
+        bp->orw_planes = forced == 4 || forced == 6 ? forced : (four ? 4 : 6);
     }
     if (bp->orw && !bp->wide && bp->tab_terms <= 8u) {
         int kind = 1;
@@ -1131,7 +1139,7 @@ static int run_class_batch(xgm_index* idx, XgmScratch* s, hipStream_t stream, co
     static const bool debug_units = getenv("XGM_DEBUG_UNITS") != nullptr;       /* tools/units.py; single-threaded use only */
     if (debug_units && nq > 1) { g_last_work = bp.work; g_last_ghdr = s->d_ghdr; }
     L.tab_terms = bp.tab_terms; L.cap = bp.cap; L.k_stride = bp.k_stride_c;
-    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0; L.orw2 = bp.orw2; L.or_flat = bp.or_flat;
+    L.phrase = bp.phrase; L.wide = bp.wide; L.sided = bp.andw ? bp.sided : 0; L.orw2 = bp.orw2; L.orw_planes = bp.orw_planes; L.or_flat = bp.or_flat;
     L.tally = idx->tally;
     L.cand = s->d_cand; L.ghdr = s->d_ghdr;
     hipEvent_t pe0 = nullptr, pe1 = nullptr;

@@ -23,6 +23,7 @@ struct xgm_match_launch {
     bool tally = false;               /* wave kernels: also fill the traffic tallies of xgm_group_hdr (measurement)  */
     int sided = 0;                    /* conjunction batch with right-hand terms: 1 = AND_NOT only, 2 = AND_MAYBE too */
     bool or_flat = false;             /* disjunction batch whose every term without a container has a flat posting array: xgm_orw_kernel<…, FLAT> */
+    int orw_planes = 6;               /* xgm_orw_kernel: planes of the bound sum, 4 where every query of the batch has 4-8 terms (plan_batch) */
     int orw2 = 0;                     /* disjunction batch for xgm_orw2_kernel: 1 = every term has a container, 2 = up to two terms per query come from flat arrays */
     uint32_t* hist = nullptr;         /* device, [nq][XGM_OR_HIST] zeroed: the query-wide weight histogram of xgm_orw_kernel and of the
                                          positional instantiation of xgm_andw_kernel (units of one query share their k-th weight bound) */

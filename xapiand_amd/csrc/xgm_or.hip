@@ -161,7 +161,14 @@ __device__ __forceinline__ uint32_t orw_bfi(uint32_t mask, uint32_t a, uint32_t 
  * opened: xgm_dense.hip) — a cursor per term, 64 postings per coalesced load — instead of decoding its blocks twice per stripe (once for the
  * bitmaps, once more for the candidates' wdf): no run table, no block headers, no payload staging, no unpack.  plan_batch selects the
  * instantiation when every such term of the batch has an array (XGM_NO_OR_FLAT=1: A/B switch, the variant tests). */
-template <typename TabT, bool TALLY, bool FLAT>
+/* PL (round 6): planes of the bit-sliced bound sum = how finely the weight bounds are quantised, kq = 2^PL steps of the threshold.  6 for every batch
+ * until round 6; 4 where every query of the batch has 4-8 terms (plan_batch) — measured per launch of 256 queries at 10 M documents, 6 / 5 / 4 planes:
+ * OR-2 top-10 0.748 / 0.781 / 1.174 ms, OR-3 top-10 0.794 / 0.766 / 0.782, OR-5 top-10 1.034 / 0.988 / 0.950, OR-5 top-100 (C3) 1.175 / 1.122 / 1.087,
+ * OR-8 top-100 2.116 / 2.023 / 1.934; 3 planes: worse everywhere.  A plane less is a sixth of the sum's instructions and four registers saved on every
+ * stripe, paid for with the documents the coarser rounding lets through — few where many terms share the threshold, many where two do.  A run-time
+ * plane count over the 6-plane code kept a third of the gain (1.163 ms): the planes' code and registers have to go.  Pruning is exact either way: the
+ * bounds are rounded UP. */
+template <typename TabT, bool TALLY, bool FLAT, uint32_t PL>
 __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_dev seg, const xgm_dev_query* __restrict__ queries,
                                                           const xgm_work* __restrict__ work, uint32_t n_work, uint32_t SPG,
                                                           uint32_t tab_terms, uint32_t cap, uint32_t k_stride,
@@ -179,6 +186,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
     const xgm_dev_query& q = queries[wk.qi];
     const uint32_t SB = seg.stripe_bits, W = 1u << SB, NW = W / 32u;
     const uint32_t T = q.n_terms, k = q.k;
+    constexpr uint32_t pl_q = PL, kq = 1u << PL;
     const unsigned long long t_unit_start = __builtin_readcyclecounter();
     /* traffic tallies (xgm_group_hdr): wave-uniform, kept in scalar registers */
     uint32_t cn_bmpw = 0, cn_probe = 0, cn_blkw = 0, cn_hdr = 0, cn_dl = 0, cn_aux = 0, cn_probe_raw = 0, cn_dl_raw = 0;
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             const uint64_t wb = (uint64_t)__double_as_longlong(weight);
             ORW_PH(10);
             /* weighed by the first pass: its bound sum reached the guess (the same quantised sum, document by document) */
-            const bool in_first = fix && sumA >= kQ;
+            const bool in_first = fix && sumA >= kq;
             const bool live = valid && subqs != 0u && wb >= theta_glob && !in_first;
             if (prune && live) {
                 int b = (int)(wb >> kHistShift) - hbase;
@@ -581,9 +589,9 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
         if (th_bits == qz_bits) { ess = qz_ess; q2 = qz_q2; q1 = qz_q1; return; }
         const double th = __longlong_as_double((long long)th_bits);
         ess = __ballot(present_reg && !(prefix_reg < th));
-        const double r2 = ub_reg * (double)kQ / th, r1 = ub1_reg * (double)kQ / th;
-        q2 = r2 >= (double)kQ ? kQ : (uint32_t)r2 + 1u;
-        q1 = r1 >= (double)kQ ? kQ : (uint32_t)r1 + 1u;
+        const double r2 = ub_reg * (double)kq / th, r1 = ub1_reg * (double)kq / th;
+        q2 = r2 >= (double)kq ? kq : (uint32_t)r2 + 1u;
+        q1 = r1 >= (double)kq ? kq : (uint32_t)r1 + 1u;
         qz_bits = th_bits; qz_ess = ess; qz_q2 = q2; qz_q1 = q1;
     };
     /* the histogram's bound of the final k-th weight: highest bucket with >= k documents at or above it */
@@ -678,22 +686,22 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
 
             /* ---- 1a. dense terms: union of the containers' bitmaps (4 words per lane) and, once a
              * threshold is known, the bit-sliced sum of the present terms' quantised weight bounds:
-             * plane j of S holds bit j of min(sum, 63) for 32 documents, ovf = the sum reached kQ. ---- */
+             * plane j of S holds bit j of min(sum, kq - 1) for 32 documents, ovf = the sum reached kq (pl_q planes in use). ---- */
             uint32_t a[4] = {0, 0, 0, 0}, e[4] = {0, 0, 0, 0};
-            uint32_t S[6][4], ovf[4] = {0, 0, 0, 0};
+            uint32_t S[PL][4], ovf[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (uint32_t j = 0; j < 6u; ++j) { S[j][0] = S[j][1] = S[j][2] = S[j][3] = 0; }
+            for (uint32_t j = 0; j < PL; ++j) { S[j][0] = S[j][1] = S[j][2] = S[j][3] = 0; }
             /* S += qv on the documents of B.  Planes outermost: the addend of plane j is chosen once (wave-uniform bit j of qv) for the
              * lane's four words; planes the running maximum of the sum cannot reach are not touched (max_sum: the largest value any
              * document's sum can have so far — terms are added in ascending order of their bounds, so the early ones stay low) */
             uint32_t max_sum = 0;
             auto planes_for = [&](uint32_t add) {
                 const uint32_t nm = rfl32(max_sum + add);
-                max_sum = nm < kQ ? nm : kQ;
-                return nm >= kQ ? 6u : 32u - (uint32_t)__builtin_clz(nm | 1u);
+                max_sum = nm < kq ? nm : kq;
+                return nm >= kq ? pl_q : 32u - (uint32_t)__builtin_clz(nm | 1u);
             };
             auto add_bound = [&](uint32_t qv, const uint32_t* B) {
-                if (qv >= kQ) {
+                if (qv >= kq) {
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= B[i];
                     return;
@@ -701,7 +709,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 const uint32_t np = planes_for(qv);
                 uint32_t carry[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t j = 0; j < 6u; ++j) {
+                for (uint32_t j = 0; j < PL; ++j) {
                     if (j < np) {
                         if ((qv >> j) & 1u) {
 #pragma unroll
@@ -720,7 +728,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         }
                     }
                 }
-                if (np == 6u) {
+                if (np == pl_q) {
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= carry[i];
                 }
@@ -728,11 +736,11 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
             /* documents of B get q1v, those also in P (wdf >= 2) get q2v >= q1v: one ripple pass, the addend of plane j chosen by the
              * (wave-uniform) bits j of the two values */
             auto add_bound2 = [&](uint32_t q1v, uint32_t q2v, const uint32_t* B, const uint32_t* P) {
-                if (q1v >= kQ || q1v == q2v) { add_bound(q1v, B); return; }
+                if (q1v >= kq || q1v == q2v) { add_bound(q1v, B); return; }
                 uint32_t lo[4];
 #pragma unroll
                 for (uint32_t i = 0; i < 4u; ++i) lo[i] = B[i] & ~P[i];
-                if (q2v >= kQ) {
+                if (q2v >= kq) {
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= P[i];
                     add_bound(q1v, lo);
@@ -741,7 +749,7 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                 const uint32_t np = planes_for(q2v);
                 uint32_t carry[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (uint32_t j = 0; j < 6u; ++j) {
+                for (uint32_t j = 0; j < PL; ++j) {
                     if (j < np) {
                         const uint32_t b1 = (q1v >> j) & 1u, b2 = (q2v >> j) & 1u;
                         if (b1 | b2) {
@@ -762,14 +770,14 @@ __global__ __launch_bounds__(XGM_WG, XGM_ORW_MINWG) void xgm_orw_kernel(xgm_seg_
                         }
                     }
                 }
-                if (np == 6u) {
+                if (np == pl_q) {
 #pragma unroll
                     for (uint32_t i = 0; i < 4u; ++i) ovf[i] |= carry[i];
                 }
             };
             uint64_t ess_mask = present_mask;                       /* block-decoded terms whose documents are all candidates */
             bool use_sum = false;                                   /* candidates of the dense terms come from the bound sum */
-            uint32_t q2_reg = kQ, q1_reg = kQ;                      /* lane t: quantised bounds of term t */
+            uint32_t q2_reg = kq, q1_reg = kq;                      /* lane t: quantised bounds of term t */
             bool first_group = true;
             bool stop = false;
             for (uint32_t dp = 0; dp < n_dense_ord || first_group;) {
@@ -1835,22 +1843,23 @@ int xgm_launch_orw(const xgm_match_launch& L, uint32_t* hist, hipStream_t stream
     /* bit 0: prune; bit 1: start from the planner's guess of the k-th weight (XGM_NO_PHASE_A keeps its old name: no seeded first pass);
      * bit 2: term-level MaxScore only, no bound sum (then no guess either) */
     const int flags = no_prune ? 0 : ((no_phase_a ? 1 : 3) | (no_sum ? 4 : 0));
+    const bool p4 = L.orw_planes == 4;                             /* (plan_batch: every query of the batch has 4-8 terms; XGM_ORW_PLANES forces 4 or 6) */
     const size_t smem = xgm_orw_smem_bytes(L.seg.stripe_bits, L.tab_terms, L.cap, L.wide, L.stripes_per_group);
     const dim3 grid((L.n_work + XGM_WAVES - 1u) / XGM_WAVES), block(XGM_WG);
     int rc = XGM_OK;
 #define ORW_LAUNCH(TABT, TL)                                                                                                         \
     do {                                                                                                                             \
-        auto kern = xgm_orw_kernel<TABT, TL, false>;                                                                                 \
-        static std::atomic<size_t> seen{0};                                                                                          \
-        if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
+        auto kern = p4 ? xgm_orw_kernel<TABT, TL, false, 4> : xgm_orw_kernel<TABT, TL, false, 6>;                                    \
+        static std::atomic<size_t> seen[2];                          /* (one per instantiation: [p4]) */                            \
+        if ((rc = orw_ensure_dyn_smem(kern, smem, seen[p4 ? 1 : 0]))) return rc;                                                     \
         XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
                            L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles, L.fuse);                                    \
     } while (0)
 #define ORW_LAUNCH_FLAT(TL)                                                                                                          \
     do {                                                                                                                             \
-        auto kern = xgm_orw_kernel<uint8_t, TL, true>;                                                                               \
-        static std::atomic<size_t> seen{0};                                                                                          \
-        if ((rc = orw_ensure_dyn_smem(kern, smem, seen))) return rc;                                                                 \
+        auto kern = p4 ? xgm_orw_kernel<uint8_t, TL, true, 4> : xgm_orw_kernel<uint8_t, TL, true, 6>;                                \
+        static std::atomic<size_t> seen[2];                          /* (one per instantiation: [p4]) */                            \
+        if ((rc = orw_ensure_dyn_smem(kern, smem, seen[p4 ? 1 : 0]))) return rc;                                                     \
         XGM_LAUNCH_TIMED(L, kern, grid, block, smem, stream, L.seg, L.queries, L.work, L.n_work, L.stripes_per_group, L.tab_terms,    \
                            L.cap, L.k_stride, hist, flags, L.cand, L.ghdr, g_orw_cycles, L.fuse);                                    \
     } while (0)
